@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: V-cycles/sec of the geometric multigrid hot path + achieved HBM GB/s of the
+fine-level smoother (BASELINE.json metric), on synthetic interior-liquid cubes.
+
+    python bench.py --gpus N --steps K --warmup W [--size 256|512|1024] [--levels L]
+                    [--smoother jacobi|gs] [--no-cpu]
+
+A "step" is one applyVCycle(useInitialGuess=true) on grids that are already
+resident in HBM.  Rank 0 prints ONE JSON line.  `roofline` is the fine-level full-domain smoother
+(the dominant kernel): algorithmic bytes (13 B per allocated fine cell) over
+its mean launch duration measured with HIP events inside the timed region, against the 8 TB/s
+HBM3E peak.  `cpu_baseline` is the fp64 CPU oracle (a port of the reference's CPU path, OpenMP)
+timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SMOOTHER_BYTES_PER_CELL = 13.0  # x r 4 + b r 4 + label 1 + x' w 4
+VCYCLE_BYTES_PER_FINE_CELL = 60.7
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=0, help="solver grid edge N (default: 256 = BASELINE config 2)")
+    ap.add_argument("--levels", type=int, default=0, help="multigrid levels (default: coarsest level 16^3)")
+    ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def default_levels(n):
+    lev = 1
+    while (n >> (lev - 1)) > 16:
+        lev += 1
+    return lev  # 256 -> 5 (BASELINE config 2), 512 -> 6, 1024 -> 7
+
+
+def cpu_baseline(n, levels, use_gs, budget_s):
+    """fp64 oracle V-cycle on the host cores.  Bounded: shrink the grid until one V-cycle fits the
+    budget; the unit stays V-cycles/sec of *that* grid and the sample string says which."""
+    import numpy as np
+
+    from geometricmultigridpressuresolver_amd import domains as D
+    from oracle.mg_oracle import Oracle
+
+    orc = Oracle()
+    cores = orc.get_threads()
+    sample_n, sample_levels = n, levels
+    # ~1.3e-8 s per cell per V-cycle per core-ish guess; stay safely inside the budget
+    while sample_n > 64 and (sample_n**3) * 6e-8 / max(cores, 1) * 8 > budget_s:
+        sample_n //= 2
+        sample_levels = max(2, sample_levels - 1)
+    lab, w, h = D.interior_cube(sample_n, sample_levels, dtype=np.float64)
+    s = orc.solver(lab.astype(np.int32), w, sample_levels, use_gs)
+    b = D.random_rhs(lab, h, dtype=np.float64)
+    x = np.zeros_like(b)
+    s.apply_vcycle(x, b, False)  # warm-up (page faults, first touch)
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < 5 and (time.time() < t_end or not times):
+        t0 = time.time()
+        s.apply_vcycle(x, b, True)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": 1.0 / med,
+        "unit": "V-cycles/sec",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{len(times)} V-cycles of the fp64 OpenMP oracle on a {sample_n}^3 interior cube, {sample_levels} levels, "
+        f"{'tiled GS' if use_gs else 'Jacobi'} smoother (median {med*1e3:.1f} ms)",
+        "grid": sample_n,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl")
+
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    n = args.size or 256
+    levels = args.levels or default_levels(n)
+    use_gs = args.smoother == "gs"
+    if world > 1:
+        raise SystemExit("multi-GPU slab path not built yet")
+
+    lab, w, h = D.interior_cube(n, levels)
+    solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank)
+    b = solver.to_device(D.random_rhs(lab, h))
+    x = solver.new_grid()
+    del w
+
+    solver.applyVCycle(x, b, False)
+    for _ in range(args.warmup):
+        solver.applyVCycle(x, b, True)
+    solver.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.applyVCycle(x, b, True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    smooth_ms, smooth_groups = solver.profile_read()
+    solver.profile_enable(False)
+
+    cells = float(n) ** 3
+    sweeps_per_group = 1  # Jacobi: one sweep; GS: two half sweeps touch every tile once = one sweep
+    t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group
+    achieved = SMOOTHER_BYTES_PER_CELL * cells / t_sweep / 1e9
+    vps = args.steps / elapsed
+    out = {
+        "metric": "V-cycles/sec",
+        "value": vps,
+        "unit": "V-cycles/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
+            f"(3 band Jacobi + {'2 tiled-GS half sweeps' if use_gs else '1 damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
+            "useInitialGuess=true, fp32 storage",
+            "grid": n,
+            "levels": levels,
+            "smoother": "tiled_gs" if use_gs else "jacobi",
+            "parallelism": f"zslab{world}",
+        },
+        "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
+        "roofline": {
+            "kernel": "fine-level tiled Gauss-Seidel sweep" if use_gs else "fine-level damped-Jacobi sweep (stencilQuadKernel)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "ms_per_launch": t_sweep * 1e3,
+            "launches": smooth_groups,
+        },
+    }
+    if not args.no_cpu and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,622 @@
+// Host side of the solver: domain expansion, structural checks and the multigrid hierarchy
+// (label coarsening, band lists, coarsest-level factorisation).  Pure C++17, no HIP calls, so the
+// whole file is exercised by the CPU test-suite.  Reference citations: "Ops.h" =
+// Source/HDK_GeometricMultigridOperators.h, "Ops.cpp" = Source/HDK_GeometricMultigridOperators.cpp,
+// "MG.cpp" = Source/HDK_GeometricMultigridPoissonSolver.cpp.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "mgps_internal.h"
+
+namespace mgps {
+
+static std::mutex gErrMutex;
+static std::string gLastError = "";
+
+void setLastGlobalError(const std::string &msg)
+{
+    std::lock_guard<std::mutex> lock(gErrMutex);
+    gLastError = msg;
+}
+const char *lastGlobalError()
+{
+    std::lock_guard<std::mutex> lock(gErrMutex);
+    static thread_local std::string copy;
+    copy = gLastError;
+    return copy.c_str();
+}
+
+static int fail(int code, const std::string &msg)
+{
+    setLastGlobalError(msg);
+    return code;
+}
+
+static inline int ilog2ceil(int v)
+{
+    int p = 0;
+    while ((1 << p) < v) ++p;
+    return p;
+}
+
+// run fn(begin, end) over [0, n) on a handful of host threads
+template <class F>
+static void parallelFor(int64_t n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = int(std::min<int64_t>(hw ? hw : 4, std::max<int64_t>(1, n / 4096)));
+    if (nt <= 1) {
+        fn(int64_t(0), n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        pool.emplace_back([=] { fn(b, e); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// Coarse labels from the 8 children, then BOUNDARY marking (Ops.cpp:23-163).
+static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
+{
+    const Dims fd = fine.d;
+    Dims cd;
+    cd.nx = fd.nx / 2;
+    cd.ny = fd.ny / 2;
+    cd.nz = fd.nz / 2;
+    coarse.d = cd;
+    coarse.labels.assign(cd.cells(), MGPS_EXTERIOR_CELL);
+    const uint8_t *fl = fine.labels.data();
+    uint8_t *cl = coarse.labels.data();
+    parallelFor(cd.nz, [&](int64_t k0, int64_t k1) {
+        for (int k = int(k0); k < int(k1); ++k)
+            for (int j = 0; j < cd.ny; ++j)
+                for (int i = 0; i < cd.nx; ++i) {
+                    bool dirichlet = false, active = false;
+                    for (int c = 0; c < 8; ++c) {
+                        const uint8_t l = fl[fd.idx(2 * i + (c & 1), 2 * j + ((c >> 1) & 1), 2 * k + (c >> 2))];
+                        dirichlet |= (l == MGPS_DIRICHLET_CELL);
+                        active |= isActive(l);
+                    }
+                    cl[cd.idx(i, j, k)] = dirichlet ? MGPS_DIRICHLET_CELL
+                                                    : (active ? MGPS_INTERIOR_CELL : MGPS_EXTERIOR_CELL);
+                }
+    });
+    // second pass on a snapshot of "is this neighbour EXTERIOR or DIRICHLET" -- marking only turns
+    // INTERIOR into BOUNDARY, neither of which the test looks for, so reading in place is safe
+    const ptrdiff_t stride[3] = {1, cd.nx, ptrdiff_t(cd.nx) * cd.ny};
+    parallelFor(cd.nz, [&](int64_t k0, int64_t k1) {
+        for (int k = int(k0); k < int(k1); ++k)
+            for (int j = 0; j < cd.ny; ++j)
+                for (int i = 0; i < cd.nx; ++i) {
+                    const size_t c = cd.idx(i, j, k);
+                    if (cl[c] != MGPS_INTERIOR_CELL) continue;
+                    bool bnd = false;
+                    for (int a = 0; a < 3 && !bnd; ++a)
+                        for (int s = -1; s <= 1; s += 2) {
+                            const uint8_t nl = cl[c + s * stride[a]];
+                            if (nl == MGPS_EXTERIOR_CELL || nl == MGPS_DIRICHLET_CELL) bnd = true;
+                        }
+                    if (bnd) cl[c] = MGPS_BOUNDARY_CELL;
+                }
+    });
+}
+
+// Band list (Ops.cpp:165-469): BOUNDARY cells plus `width`-1 rings of INTERIOR cells grown
+// through face neighbours, ordered by (tile id, k, j, i).
+static void buildBand(HostLevel &L, int width)
+{
+    const Dims d = L.d;
+    const uint8_t *lab = L.labels.data();
+    const size_t n = d.cells();
+    std::vector<uint8_t> mark(n, 0);  // 0 unvisited, 1 in band
+    std::vector<size_t> frontier, next;
+    for (size_t c = 0; c < n; ++c)
+        if (lab[c] == MGPS_BOUNDARY_CELL) {
+            frontier.push_back(c);
+            mark[c] = 1;
+        }
+    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
+    for (int ring = 1; ring < width; ++ring) {
+        next.clear();
+        for (size_t c : frontier)
+            for (int a = 0; a < 3; ++a)
+                for (int s = -1; s <= 1; s += 2) {
+                    const size_t nb = c + s * stride[a];
+                    if (lab[nb] == MGPS_INTERIOR_CELL && !mark[nb]) {
+                        mark[nb] = 1;
+                        next.push_back(nb);
+                    }
+                }
+        frontier.swap(next);
+    }
+    // emit in (tile, k, j, i) order: walk tiles in linear tile order, cells x-fastest inside
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    L.band.clear();
+    for (int t = 0; t < tx * ty * tz; ++t) {
+        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+        for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
+            for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
+                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i)
+                    if (mark[d.idx(i, j, k)]) L.band.push_back(int32_t(d.idx(i, j, k)));
+    }
+}
+
+static void buildTileLists(HostLevel &L)
+{
+    const Dims d = L.d;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    L.tilesOdd.clear();
+    L.tilesEven.clear();
+    L.activeCells = 0;
+    for (int t = 0; t < tx * ty * tz; ++t) {
+        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+        int64_t cnt = 0;
+        for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
+            for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
+                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) cnt += isActive(L.labels[d.idx(i, j, k)]);
+        if (!cnt) continue;
+        L.activeCells += cnt;
+        (((ti + tj + tk) & 1) ? L.tilesOdd : L.tilesEven).push_back(t);
+    }
+}
+
+}  // namespace mgps
+
+using namespace mgps;
+
+// Coarsest system (MG.cpp:288-411): one row per active cell, -1 per active neighbour, diagonal =
+// #active + #DIRICHLET neighbours; unknowns numbered tile by tile, x fastest inside a tile.
+// Factorised as a banded Cholesky (an exact SPD direct solve like Eigen::SimplicialCholesky).
+static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
+{
+    const HostLevel &L = H.lv[H.levels - 1];
+    const Dims d = L.d;
+    const size_t n = d.cells();
+    H.coarseIndex.assign(n, -1);
+    H.coarseCell.clear();
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    for (int t = 0; t < tx * ty * tz; ++t) {
+        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+        for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
+            for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
+                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i)
+                    if (isActive(L.labels[d.idx(i, j, k)])) {
+                        H.coarseIndex[d.idx(i, j, k)] = int32_t(H.coarseCell.size());
+                        H.coarseCell.push_back(int32_t(d.idx(i, j, k)));
+                    }
+    }
+    const int cn = int(H.coarseCell.size());
+    H.coarseN = cn;
+    if (cn > maxUnknowns)
+        return fail(MGPS_ERR_COARSE_TOO_LARGE,
+                    "coarsest level has " + std::to_string(cn) + " unknowns (cap " + std::to_string(maxUnknowns) +
+                        "): raise mg_levels or options.max_coarse_unknowns");
+    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
+    int bw = 0;
+    for (int r = 0; r < cn; ++r)
+        for (int a = 0; a < 3; ++a)
+            for (int s = -1; s <= 1; s += 2) {
+                const int q = H.coarseIndex[H.coarseCell[r] + s * stride[a]];
+                if (q >= 0) bw = std::max(bw, std::abs(q - r));
+            }
+    H.coarseBW = bw;
+    const int W = bw + 1;
+    std::vector<double> &A = H.coarseL;
+    A.assign(size_t(cn) * W, 0.0);
+    auto at = [&](int r, int c) -> double & { return A[size_t(r) * W + (bw - (r - c))]; };
+    for (int r = 0; r < cn; ++r) {
+        double diag = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int s = -1; s <= 1; s += 2) {
+                const size_t nb = H.coarseCell[r] + s * stride[a];
+                if (isActive(L.labels[nb])) {
+                    const int q = H.coarseIndex[nb];
+                    if (q < r) at(r, q) = -1.0;
+                    diag += 1.0;
+                } else if (L.labels[nb] == MGPS_DIRICHLET_CELL)
+                    diag += 1.0;
+            }
+        at(r, r) = diag;
+    }
+    for (int r = 0; r < cn; ++r) {
+        const int c0 = std::max(0, r - bw);
+        for (int c = c0; c <= r; ++c) {
+            double sum = at(r, c);
+            for (int m = std::max(c0, c - bw); m < c; ++m) sum -= at(r, m) * at(c, m);
+            if (c == r) {
+                if (!(sum > 0)) return fail(MGPS_ERR_COARSE_FACTOR, "coarsest-level matrix is not positive definite");
+                at(r, r) = std::sqrt(sum);
+            } else
+                at(r, c) = sum / at(c, c);
+        }
+    }
+    return MGPS_OK;
+}
+
+void mgps_hierarchy::bandedSolve(double *v) const
+{
+    const int n = coarseN, bw = coarseBW, W = bw + 1;
+    const double *Lm = coarseL.data();
+    for (int r = 0; r < n; ++r) {
+        double sum = v[r];
+        for (int c = std::max(0, r - bw); c < r; ++c) sum -= Lm[size_t(r) * W + (bw - (r - c))] * v[c];
+        v[r] = sum / Lm[size_t(r) * W + bw];
+    }
+    for (int r = n - 1; r >= 0; --r) {
+        double sum = v[r];
+        for (int c = r + 1; c <= std::min(n - 1, r + bw); ++c) sum -= Lm[size_t(c) * W + (bw - (c - r))] * v[c];
+        v[r] = sum / Lm[size_t(r) * W + bw];
+    }
+}
+
+// Dense inverse of the coarsest matrix, one banded solve per unit vector.  On the GPU the direct
+// solve is then a single dense mat-vec (n <= a few thousand), which beats two latency-bound banded
+// triangular sweeps by orders of magnitude.
+void mgps_hierarchy::buildDenseInverse()
+{
+    if (!coarseInverse.empty() || coarseN == 0) return;
+    const int n = coarseN;
+    coarseInverse.assign(size_t(n) * n, 0.f);
+    std::atomic<int> nextCol{0};
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nt = int(std::min<unsigned>(hw ? hw : 4, unsigned(std::max(1, n / 64))));
+    auto work = [&] {
+        std::vector<double> v(n);
+        for (;;) {
+            const int col = nextCol.fetch_add(1);
+            if (col >= n) break;
+            std::fill(v.begin(), v.end(), 0.0);
+            v[col] = 1.0;
+            bandedSolve(v.data());
+            for (int r = 0; r < n; ++r) coarseInverse[size_t(r) * n + col] = float(v[r]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
+extern "C" {
+
+void mgps_default_options(mgps_options *opt)
+{
+    if (!opt) return;
+    std::memset(opt, 0, sizeof(*opt));
+    opt->struct_size = int(sizeof(mgps_options));
+    opt->band_width = 3;               // MG.cpp:141
+    opt->band_iterations = 3;          // MG.cpp:142
+    opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
+    opt->device = -1;
+    opt->use_graph = 0;
+    opt->print_stats = 0;
+    opt->max_coarse_unknowns = 8192;
+    opt->interrupt = nullptr;
+    opt->interrupt_user = nullptr;
+}
+
+const char *mgps_status_string(int status)
+{
+    switch (status) {
+        case MGPS_OK: return "ok";
+        case MGPS_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case MGPS_ERR_NO_DEVICE: return "no HIP device";
+        case MGPS_ERR_HIP: return "HIP runtime error";
+        case MGPS_ERR_ALLOC: return "allocation failed";
+        case MGPS_ERR_HIERARCHY: return "multigrid hierarchy could not be built";
+        case MGPS_ERR_COARSE_TOO_LARGE: return "coarsest level too large for the direct solver";
+        case MGPS_ERR_COARSE_FACTOR: return "coarsest-level factorisation failed";
+        case MGPS_ERR_COMM: return "communication error";
+        case MGPS_ERR_INTERRUPTED: return "interrupted";
+        default: return "unknown status";
+    }
+}
+
+int mgps_expanded_layout(int bnx, int bny, int bnz, int levels_in, int power_of_two, int out_dims[3],
+                         int *out_offset, int *out_levels)
+{
+    if (bnx <= 0 || bny <= 0 || bnz <= 0 || !out_dims || !out_offset || !out_levels)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expanded_layout: bad arguments");
+    int levels = levels_in;
+    if (levels <= 0) levels = ilog2ceil(std::min(bnx, std::min(bny, bnz))) - 1;  // Ops.h:1341-1345
+    if (levels < 1) levels = 1;
+    const int pad = 1 << (levels - 1);  // Ops.h:1349
+    const int base[3] = {bnx, bny, bnz};
+    for (int a = 0; a < 3; ++a) {
+        const int need = base[a] + 2 * pad;
+        if (power_of_two)
+            out_dims[a] = 1 << ilog2ceil(need);  // Ops.h:1353-1360
+        else {
+            const int m = 1 << levels;  // every level needs even extents (Ops.h:751-752, Ops.cpp:27-30)
+            out_dims[a] = ((need + m - 1) / m) * m;
+        }
+    }
+    *out_offset = pad;
+    *out_levels = levels;
+    return MGPS_OK;
+}
+
+int mgps_expand_labels(uint8_t *expanded, const uint8_t *base, int bnx, int bny, int bnz, int enx, int eny,
+                       int enz, int offset)
+{
+    if (!expanded || !base || offset < 0 || enx < bnx + offset || eny < bny + offset || enz < bnz + offset)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expand_labels: bad arguments");
+    const Dims bd{bnx, bny, bnz}, ed{enx, eny, enz};
+    std::memset(expanded, MGPS_EXTERIOR_CELL, ed.cells());
+    for (int k = 0; k < bnz; ++k)
+        for (int j = 0; j < bny; ++j) {
+            const uint8_t *src = base + bd.idx(0, j, k);
+            uint8_t *dst = expanded + ed.idx(offset, j + offset, k + offset);
+            for (int i = 0; i < bnx; ++i)
+                if (src[i] != MGPS_EXTERIOR_CELL)
+                    dst[i] = (src[i] == MGPS_INTERIOR_CELL) ? MGPS_INTERIOR_CELL : MGPS_DIRICHLET_CELL;
+        }
+    return MGPS_OK;
+}
+
+int mgps_expand_weights(float *expanded, const float *base, int axis, int bnx, int bny, int bnz, int enx,
+                        int eny, int enz, int offset)
+{
+    if (!expanded || !base || axis < 0 || axis > 2)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expand_weights: bad arguments");
+    const Dims bf{bnx + (axis == 0), bny + (axis == 1), bnz + (axis == 2)};
+    const Dims ef{enx + (axis == 0), eny + (axis == 1), enz + (axis == 2)};
+    if (ef.nx < bf.nx + offset || ef.ny < bf.ny + offset || ef.nz < bf.nz + offset)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expand_weights: expanded grid too small");
+    std::memset(expanded, 0, ef.cells() * sizeof(float));
+    for (int k = 0; k < bf.nz; ++k)
+        for (int j = 0; j < bf.ny; ++j)
+            for (int i = 0; i < bf.nx; ++i) {
+                const float v = base[bf.idx(i, j, k)];
+                if (v > 0) expanded[ef.idx(i + offset, j + offset, k + offset)] = v;
+            }
+    return MGPS_OK;
+}
+
+static inline size_t faceIndex(const Dims &d, int axis, int i, int j, int k, int plus)
+{
+    const int fx = d.nx + (axis == 0), fy = d.ny + (axis == 1);
+    if (axis == 0) i += plus;
+    else if (axis == 1) j += plus;
+    else k += plus;
+    return (size_t(k) * fy + j) * fx + i;
+}
+
+int mgps_set_boundary_labels(uint8_t *labels, const float *wx, const float *wy, const float *wz, int nx, int ny,
+                             int nz)
+{
+    if (!labels || !wx || !wy || !wz || nx < 3 || ny < 3 || nz < 3)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_set_boundary_labels: bad arguments");
+    const Dims d{nx, ny, nz};
+    const float *w[3] = {wx, wy, wz};
+    const ptrdiff_t stride[3] = {1, nx, ptrdiff_t(nx) * ny};
+    parallelFor(nz - 2, [&](int64_t k0, int64_t k1) {
+        for (int k = int(k0) + 1; k < int(k1) + 1; ++k)
+            for (int j = 1; j < ny - 1; ++j)
+                for (int i = 1; i < nx - 1; ++i) {
+                    const size_t c = d.idx(i, j, k);
+                    if (labels[c] != MGPS_INTERIOR_CELL) continue;
+                    bool bnd = false;
+                    for (int a = 0; a < 3 && !bnd; ++a)
+                        for (int p = 0; p < 2 && !bnd; ++p) {
+                            const uint8_t nl = labels[c + (p ? stride[a] : -stride[a])];
+                            bnd = (nl == MGPS_DIRICHLET_CELL || nl == MGPS_EXTERIOR_CELL) ||
+                                  (w[a][faceIndex(d, a, i, j, k, p)] != 1.0f);
+                        }
+                    if (bnd) labels[c] = MGPS_BOUNDARY_CELL;
+                }
+    });
+    return MGPS_OK;
+}
+
+int mgps_check_exterior_cells(const uint8_t *labels, int nx, int ny, int nz, int *pass)
+{
+    if (!labels || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_exterior_cells: bad arguments");
+    const Dims d{nx, ny, nz};
+    *pass = 1;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const bool shell = i == 0 || j == 0 || k == 0 || i == nx - 1 || j == ny - 1 || k == nz - 1;
+                if (shell && labels[d.idx(i, j, k)] != MGPS_EXTERIOR_CELL) {
+                    *pass = 0;
+                    return MGPS_OK;
+                }
+            }
+    return MGPS_OK;
+}
+
+int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const float *wy, const float *wz, int nx,
+                              int ny, int nz, int *pass)
+{
+    if (!labels || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_boundary_cells: bad arguments");
+    const Dims d{nx, ny, nz};
+    const float *w[3] = {wx, wy, wz};
+    const bool weighted = wx && wy && wz;
+    const ptrdiff_t stride[3] = {1, nx, ptrdiff_t(nx) * ny};
+    *pass = 1;
+    for (int k = 1; k < nz - 1; ++k)
+        for (int j = 1; j < ny - 1; ++j)
+            for (int i = 1; i < nx - 1; ++i) {
+                const size_t c = d.idx(i, j, k);
+                if (labels[c] == MGPS_INTERIOR_CELL) {
+                    for (int a = 0; a < 3; ++a)
+                        for (int p = 0; p < 2; ++p)
+                            if (!isActive(labels[c + (p ? stride[a] : -stride[a])])) *pass = 0;
+                } else if (labels[c] == MGPS_BOUNDARY_CELL) {
+                    bool ok = false;
+                    for (int a = 0; a < 3; ++a)
+                        for (int p = 0; p < 2; ++p) {
+                            const uint8_t nl = labels[c + (p ? stride[a] : -stride[a])];
+                            if (!isActive(nl)) ok = true;
+                            else if (weighted && nl == MGPS_BOUNDARY_CELL && w[a][faceIndex(d, a, i, j, k, p)] != 1.0f)
+                                ok = true;
+                        }
+                    if (!ok) *pass = 0;
+                }
+                if (!*pass) return MGPS_OK;
+            }
+    return MGPS_OK;
+}
+
+int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, int fny, int fnz, int *pass)
+{
+    if (!coarse || !fine || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_coarsening: bad arguments");
+    const Dims fd{fnx, fny, fnz}, cd{fnx / 2, fny / 2, fnz / 2};
+    *pass = 0;
+    if ((fnx | fny | fnz | cd.nx | cd.ny | cd.nz) & 1) return MGPS_OK;
+    for (int k = 0; k < cd.nz; ++k)
+        for (int j = 0; j < cd.ny; ++j)
+            for (int i = 0; i < cd.nx; ++i) {
+                bool dch = false, ach = false, ech = false;
+                for (int c = 0; c < 8; ++c) {
+                    const uint8_t l = fine[fd.idx(2 * i + (c & 1), 2 * j + ((c >> 1) & 1), 2 * k + (c >> 2))];
+                    dch |= l == MGPS_DIRICHLET_CELL;
+                    ach |= isActive(l);
+                    ech |= l == MGPS_EXTERIOR_CELL;
+                }
+                const uint8_t cl = coarse[cd.idx(i, j, k)];
+                const bool good = (cl == MGPS_DIRICHLET_CELL) ? dch
+                                  : isActive(cl)              ? (!dch && ach)
+                                                              : (!dch && !ach && ech);
+                if (!good) return MGPS_OK;
+            }
+    *pass = 1;
+    return MGPS_OK;
+}
+
+int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
+                          const mgps_options *opt)
+{
+    if (!out) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: out is NULL");
+    *out = nullptr;
+    mgps_options o;
+    mgps_default_options(&o);
+    if (opt) {
+        if (opt->struct_size != int(sizeof(mgps_options)))
+            return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_options.struct_size mismatch: call mgps_default_options first");
+        o = *opt;
+    }
+    if (!labels || mg_levels < 1 || nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1))
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: extents must be even and >= 2, mg_levels >= 1");
+    if (size_t(nx) * ny * nz > size_t(0x7fffffff))
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: more than 2^31-1 cells per grid");
+    // MG.cpp:159-161: log2(res) + 1 >= mgLevels on every axis; every level must keep even extents
+    for (int l = 1; l < mg_levels; ++l)
+        if (((nx >> (l - 1)) & 1) || ((ny >> (l - 1)) & 1) || ((nz >> (l - 1)) & 1) || (nx >> l) < 1 || (ny >> l) < 1 ||
+            (nz >> l) < 1)
+            return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: extents are not divisible by 2^(levels-1)");
+    if (o.band_width < 1 || o.band_iterations < 0)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: band_width >= 1, band_iterations >= 0");
+
+    auto H = new mgps_hierarchy();
+    H->bandWidth = o.band_width;
+    H->lv.resize(mg_levels);
+    H->lv[0].d = Dims{nx, ny, nz};
+    H->lv[0].labels.assign(labels, labels + H->lv[0].d.cells());
+    {
+        int pass = 0;
+        mgps_check_exterior_cells(labels, nx, ny, nz, &pass);  // MG.cpp:235
+        if (!pass) {
+            delete H;
+            return fail(MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)");
+        }
+    }
+    auto solvable = [](const HostLevel &L) {
+        for (uint8_t l : L.labels)
+            if (isActive(l)) return true;
+        return false;
+    };
+    if (!solvable(H->lv[0])) {  // MG.cpp:233
+        delete H;
+        return fail(MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain");
+    }
+    int levels = mg_levels;
+    for (int l = 1; l < levels; ++l) {  // MG.cpp:238-253
+        coarsenLabels(H->lv[l - 1], H->lv[l]);
+        if (!solvable(H->lv[l])) {
+            levels = l - 1;  // the reference drops the last solvable level too (MG.cpp:245)
+            break;
+        }
+    }
+    if (levels < 1) {
+        delete H;
+        return fail(MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)");
+    }
+    H->levels = levels;
+    H->lv.resize(levels);
+    for (auto &L : H->lv) {
+        buildBand(L, H->bandWidth);  // MG.cpp:279-281
+        buildTileLists(L);
+    }
+    const int rc = buildCoarseSolver(*H, o.max_coarse_unknowns);
+    if (rc != MGPS_OK) {
+        delete H;
+        return rc;
+    }
+    *out = H;
+    return MGPS_OK;
+}
+
+void mgps_hierarchy_destroy(mgps_hierarchy *hier) { delete hier; }
+int mgps_hierarchy_levels(const mgps_hierarchy *hier) { return hier ? hier->levels : 0; }
+
+int mgps_hierarchy_level_dims(const mgps_hierarchy *hier, int level, int out_dims[3])
+{
+    if (!hier || level < 0 || level >= hier->levels || !out_dims)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_level_dims: bad arguments");
+    out_dims[0] = hier->lv[level].d.nx;
+    out_dims[1] = hier->lv[level].d.ny;
+    out_dims[2] = hier->lv[level].d.nz;
+    return MGPS_OK;
+}
+
+int mgps_hierarchy_level_labels(const mgps_hierarchy *hier, int level, uint8_t *out)
+{
+    if (!hier || level < 0 || level >= hier->levels || !out)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_level_labels: bad arguments");
+    std::memcpy(out, hier->lv[level].labels.data(), hier->lv[level].labels.size());
+    return MGPS_OK;
+}
+
+int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level)
+{
+    if (!hier || level < 0 || level >= hier->levels) return -1;
+    return int64_t(hier->lv[level].band.size());
+}
+
+int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *out_ijk)
+{
+    if (!hier || level < 0 || level >= hier->levels || !out_ijk)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_band_cells: bad arguments");
+    const Dims d = hier->lv[level].d;
+    size_t q = 0;
+    for (int32_t c : hier->lv[level].band) {
+        out_ijk[q++] = c % d.nx;
+        out_ijk[q++] = (c / d.nx) % d.ny;
+        out_ijk[q++] = c / (d.nx * d.ny);
+    }
+    return MGPS_OK;
+}
+
+int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier) { return hier ? hier->coarseN : 0; }
+
+int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b)
+{
+    if (!hier || !x || !b) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_coarse_solve: bad arguments");
+    std::vector<double> v(hier->coarseN);
+    for (int r = 0; r < hier->coarseN; ++r) v[r] = b[hier->coarseCell[r]];
+    hier->bandedSolve(v.data());
+    for (int r = 0; r < hier->coarseN; ++r) x[hier->coarseCell[r]] = float(v[r]);
+    return MGPS_OK;
+}
+
+}  // extern "C"

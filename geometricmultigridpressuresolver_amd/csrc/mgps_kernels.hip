@@ -1,0 +1,670 @@
+// HIP kernels of the multigrid hot path, written for gfx950 (MI355X, CDNA4): 64-wide wavefronts,
+// 16-byte vector loads along x (the contiguous axis), HBM-bound streaming structure, no MFMA (there
+// is no dense contraction in a 7-point stencil).  Reference semantics for every kernel are cited as
+// "Ops.h" = Source/HDK_GeometricMultigridOperators.h, "MG.cpp" =
+// Source/HDK_GeometricMultigridPoissonSolver.cpp.
+//
+// Shared conventions
+//  * grids are flat, x fastest; a cell is active iff its label is INTERIOR (0) or BOUNDARY (3);
+//  * INTERIOR cells have six active neighbours, unit face weights and diagonal 6
+//    (Ops.h:191-207) -- the fast path needs no label or weight look-ups for the neighbours;
+//  * BOUNDARY cells take the general path of computeLaplacian (Ops.h:208-256);
+//  * arithmetic is fp32; reductions accumulate in fp64.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "mgps_internal.h"
+
+namespace mgps {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
+
+__device__ __forceinline__ bool activeLabel(unsigned l) { return l == MGPS_INTERIOR_CELL || l == MGPS_BOUNDARY_CELL; }
+
+// General (BOUNDARY-centre) row of the operator, Ops.h:208-258.  X is any callable size_t -> float.
+template <class X>
+__device__ __forceinline__ void boundaryRow(const GridP &g, const X &xAt, int i, int j, int k, size_t c, float &lap,
+                                            float &diag)
+{
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const bool weighted = g.wx != nullptr;
+    lap = 0.f;
+    diag = 0.f;
+    const size_t nb[6] = {c - 1, c + 1, c - sy, c + sy, c - sz, c + sz};
+    float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (weighted) {
+        const size_t fx = (size_t(k) * g.ny + j) * (g.nx + 1) + i;
+        const size_t fy = (size_t(k) * (g.ny + 1) + j) * g.nx + i;
+        const size_t fz = c;  // (k*ny + j)*nx + i
+        w[0] = g.wx[fx];
+        w[1] = g.wx[fx + 1];
+        w[2] = g.wy[fy];
+        w[3] = g.wy[fy + g.nx];
+        w[4] = g.wz[fz];
+        w[5] = g.wz[fz + sz];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const unsigned nl = g.lab[nb[q]];
+        if (nl == MGPS_INTERIOR_CELL) {
+            lap -= xAt(nb[q]);
+            diag += 1.f;
+        } else if (nl == MGPS_BOUNDARY_CELL) {
+            lap -= w[q] * xAt(nb[q]);
+            diag += w[q];
+        } else if (nl == MGPS_DIRICHLET_CELL) {
+            diag += w[q];
+        }
+    }
+    lap += diag * xAt(c);
+}
+
+template <int OP>
+__device__ __forceinline__ float epilogue(float xc, float bc, float lap, float diag, float omega)
+{
+    if (OP == OP_JACOBI) return xc + omega * ((bc - lap) / diag);  // Ops.h:356-361
+    if (OP == OP_RESIDUAL) return bc - lap;                        // Ops.h:728-731
+    return lap;                                                    // Ops.h:708
+}
+template <int OP>
+__device__ __forceinline__ float inactiveValue(float xc)
+{
+    return OP == OP_JACOBI ? xc : 0.f;  // Jacobi leaves inactive cells alone; r and y are 0 there
+}
+
+// XCD-aware block remap: the hardware deals consecutive block ids round-robin over the 8 XCDs, each
+// with a private 4 MiB L2.  Giving every XCD one contiguous run of logical blocks keeps the y/z
+// neighbour rows a block re-reads inside the L2 that already holds them.  Pure speed: any mapping
+// is correct.
+__device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
+{
+    const unsigned per = nblocks / kXcds;
+    if (per == 0 || bid >= per * kXcds) return bid;  // ragged tail keeps its id
+    return (bid % kXcds) * per + bid / kXcds;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 7-point stencil sweep: Jacobi (out of place), residual, A.x.  One thread = 4 consecutive cells
+// along x (one 16-byte load / store per array), a wave = 256 contiguous cells of a row (or several
+// shorter rows).  x-1 / x+1 come from the neighbouring lanes (ds_bpermute), row ends from memory.
+// Requires nx % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
+                                                          const float *__restrict__ b, float omega, unsigned nblocks)
+{
+    const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
+    const size_t rows = size_t(g.ny) * g.nz;
+    const size_t totalQuads = size_t(nq) * rows;
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    const size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    const bool valid = t < totalQuads;
+    const size_t tt = valid ? t : totalQuads - 1;
+    const unsigned q = unsigned(tt % nq);
+    const size_t row = tt / nq;
+    const int j = int(row % g.ny), k = int(row / g.ny);
+    const int i = int(q) << 2;
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const size_t c = row * sy + i;
+
+    const float4 xc = *reinterpret_cast<const float4 *>(x + c);
+    // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
+    // results are discarded, the loads only have to stay in bounds
+    const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
+    const size_t czm = k > 0 ? c - sz : c, czp = k < g.nz - 1 ? c + sz : c;
+    const float4 ym = *reinterpret_cast<const float4 *>(x + cym);
+    const float4 yp = *reinterpret_cast<const float4 *>(x + cyp);
+    const float4 zm = *reinterpret_cast<const float4 *>(x + czm);
+    const float4 zp = *reinterpret_cast<const float4 *>(x + czp);
+    const uchar4 lab = *reinterpret_cast<const uchar4 *>(g.lab + c);
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (OP != OP_APPLY) bc = *reinterpret_cast<const float4 *>(b + c);
+
+    // x neighbours across the quad boundary
+    const int lane = threadIdx.x & (kWave - 1);
+    float left = __shfl_up(xc.w, 1);
+    float right = __shfl_down(xc.x, 1);
+    if (lane == 0 || q == 0) left = (i > 0) ? x[c - 1] : 0.f;
+    if (lane == kWave - 1 || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? x[c + 4] : 0.f;
+
+    const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
+    const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+    const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
+    const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+    const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
+    float res[4];
+    const bool allInterior = (lab.x | lab.y | lab.z | lab.w) == 0;
+    if (allInterior) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lap = 6.f * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+            res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, 6.f, omega);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ls[e] == MGPS_INTERIOR_CELL) {
+                const float lap = 6.f * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+                res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, 6.f, omega);
+            } else if (ls[e] == MGPS_BOUNDARY_CELL) {
+                float lap, diag;
+                boundaryRow(g, [&](size_t p) { return x[p]; }, i + e, j, k, c + e, lap, diag);
+                res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, diag, omega);
+            } else
+                res[e] = inactiveValue<OP>(xs[e + 1]);
+        }
+    }
+    if (valid) *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+// Scalar fallback for levels whose nx is not a multiple of 4 (only the tiniest coarse levels).
+template <int OP>
+__global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
+                                    const float *__restrict__ b, float omega)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const unsigned l = g.lab[c];
+    const float xc = x[c];
+    if (!activeLabel(l)) {
+        out[c] = inactiveValue<OP>(xc);
+        return;
+    }
+    const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / (size_t(g.nx) * g.ny));
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    float lap, diag;
+    if (l == MGPS_INTERIOR_CELL) {
+        lap = 6.f * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+        diag = 6.f;
+    } else
+        boundaryRow(g, [&](size_t p) { return x[p]; }, i, j, k, c, lap, diag);
+    out[c] = epilogue<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Band Jacobi (Ops.h:524-619): phase 1 computes the damped update of every band cell into a list,
+// phase 2 scatters it -- exactly the reference's two phases, so no band cell sees a neighbour
+// updated in the same pass.
+// ---------------------------------------------------------------------------------------------
+__global__ void bandComputeKernel(GridP g, const float *__restrict__ x, const float *__restrict__ b,
+                                  const int32_t *__restrict__ band, int nband, float *__restrict__ tmp, float omega)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nband) return;
+    const size_t c = size_t(band[t]);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const float xc = x[c];
+    float lap, diag;
+    if (g.lab[c] == MGPS_INTERIOR_CELL) {
+        lap = 6.f * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+        diag = 6.f;
+    } else {
+        const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / sz);
+        boundaryRow(g, [&](size_t p) { return x[p]; }, i, j, k, c, lap, diag);
+    }
+    tmp[t] = xc + omega * ((b[c] - lap) / diag);  // Ops.h:596-599
+}
+__global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restrict__ band, int nband,
+                                  const float *__restrict__ tmp)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nband) x[band[t]] = tmp[t];  // Ops.h:604-618
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile-coloured Gauss-Seidel (Ops.h:369-520).  One 256-thread workgroup owns one 16^3 tile of the
+// requested colour: the 18^3 halo cube of x, the labels (18^3) and the rhs (16^3) are staged in LDS,
+// then the tile is swept along anti-diagonal planes i+j+k = s.  For a 7-point stencil every cell
+// of plane s depends only on planes s-1 (already updated) and s+1 (still old), so marching s
+// upwards reproduces the reference's lexicographic forward sweep exactly, and marching downwards
+// its reversed sweep (Ops.h:497-516).  Face neighbours outside the tile belong to tiles of the
+// other colour and are constant during the pass (Ops.h:436-448).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalo = kTile + 2;
+__global__ __launch_bounds__(256) void tiledGSKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                     const int32_t *__restrict__ tiles, int forward)
+{
+    __shared__ float sx[kHalo * kHalo * kHalo];
+    __shared__ float sb[kTile * kTile * kTile];
+    __shared__ unsigned char sl[kHalo * kHalo * kHalo];
+
+    const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
+    const int tile = tiles[blockIdx.x];
+    const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+
+    for (int h = threadIdx.x; h < kHalo * kHalo * kHalo; h += blockDim.x) {
+        const int li = h % kHalo, lj = (h / kHalo) % kHalo, lk = h / (kHalo * kHalo);
+        const int gi = i0 + li - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
+        const bool in = gi >= 0 && gj >= 0 && gk >= 0 && gi < g.nx && gj < g.ny && gk < g.nz;
+        const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
+        sx[h] = in ? x[c] : 0.f;
+        sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
+    }
+    for (int h = threadIdx.x; h < kTile * kTile * kTile; h += blockDim.x) {
+        const int li = h % kTile, lj = (h / kTile) % kTile, lk = h / (kTile * kTile);
+        const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+        const bool in = gi < g.nx && gj < g.ny && gk < g.nz;
+        sb[h] = in ? b[(size_t(gk) * g.ny + gj) * g.nx + gi] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = threadIdx.x % kTile, lj = threadIdx.x / kTile;  // this thread's (i, j) column
+    constexpr int kPlanes = 3 * (kTile - 1) + 1;
+    const bool weighted = g.wx != nullptr;
+    for (int step = 0; step < kPlanes; ++step) {
+        const int s = forward ? step : kPlanes - 1 - step;
+        const int lk = s - li - lj;
+        if (lk >= 0 && lk < kTile) {
+            const int h = ((lk + 1) * kHalo + (lj + 1)) * kHalo + (li + 1);
+            const unsigned l = sl[h];
+            if (activeLabel(l)) {
+                const float xc = sx[h];
+                const float bc = sb[(lk * kTile + lj) * kTile + li];
+                float lap, diag;
+                if (l == MGPS_INTERIOR_CELL) {
+                    lap = 6.f * xc - (sx[h - 1] + sx[h + 1] + sx[h - kHalo] + sx[h + kHalo] + sx[h - kHalo * kHalo] +
+                                      sx[h + kHalo * kHalo]);
+                    diag = 6.f;
+                } else {
+                    const int hn[6] = {h - 1, h + 1, h - kHalo, h + kHalo, h - kHalo * kHalo, h + kHalo * kHalo};
+                    float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                    if (weighted) {
+                        const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+                        const size_t c = (size_t(gk) * g.ny + gj) * g.nx + gi;
+                        const size_t fx = (size_t(gk) * g.ny + gj) * (g.nx + 1) + gi;
+                        const size_t fy = (size_t(gk) * (g.ny + 1) + gj) * g.nx + gi;
+                        w[0] = g.wx[fx];
+                        w[1] = g.wx[fx + 1];
+                        w[2] = g.wy[fy];
+                        w[3] = g.wy[fy + g.nx];
+                        w[4] = g.wz[c];
+                        w[5] = g.wz[c + sz];
+                    }
+                    lap = 0.f;
+                    diag = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const unsigned nl = sl[hn[q]];
+                        if (nl == MGPS_INTERIOR_CELL) {
+                            lap -= sx[hn[q]];
+                            diag += 1.f;
+                        } else if (nl == MGPS_BOUNDARY_CELL) {
+                            lap -= w[q] * sx[hn[q]];
+                            diag += w[q];
+                        } else if (nl == MGPS_DIRICHLET_CELL)
+                            diag += w[q];
+                    }
+                    lap += diag * xc;
+                }
+                sx[h] = xc + (bc - lap) / diag;  // undamped, Ops.h:493
+            }
+        }
+        __syncthreads();
+    }
+    for (int h = threadIdx.x; h < kTile * kTile * kTile; h += blockDim.x) {
+        const int ci = h % kTile, cj = (h / kTile) % kTile, ck = h / (kTile * kTile);
+        const int gi = i0 + ci, gj = j0 + cj, gk = k0 + ck;
+        if (gi < g.nx && gj < g.ny && gk < g.nz) {
+            const int hh = ((ck + 1) * kHalo + (cj + 1)) * kHalo + (ci + 1);
+            if (activeLabel(sl[hh])) x[(size_t(gk) * g.ny + gj) * g.nx + gi] = sx[hh];
+        }
+    }
+    (void)sy;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full-weighting restriction (Ops.h:734-835): coarse C = sum over the 4x4x4 fine block starting at
+// 2C-1 with weights {1/8,3/8,3/8,1/8}^3; inactive coarse cells are 0 (destination cleared first,
+// Ops.h:756).  One thread per coarse cell.
+// ---------------------------------------------------------------------------------------------
+__global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine)
+{
+    const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (!activeLabel(cg.lab[c])) {
+        coarse[c] = 0.f;
+        return;
+    }
+    const int i = int(c % cg.nx), j = int((c / cg.nx) % cg.ny), k = int(c / (size_t(cg.nx) * cg.ny));
+    const int fnx = 2 * cg.nx, fny = 2 * cg.ny;
+    const float w[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    float acc = 0.f;
+#pragma unroll
+    for (int zo = 0; zo < 4; ++zo)
+#pragma unroll
+        for (int yo = 0; yo < 4; ++yo) {
+            const float *row = fine + (size_t(2 * k - 1 + zo) * fny + (2 * j - 1 + yo)) * fnx + (2 * i - 1);
+            const float wyz = w[yo] * w[zo];
+#pragma unroll
+            for (int xo = 0; xo < 4; ++xo) acc += (w[xo] * wyz) * row[xo];
+        }
+    coarse[c] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Prolongation + add (Ops.h:873-972): fine c += 4 * trilerp(coarse) at sample point c/2 - 1/4:
+// even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
+// (1-f) a + f b, x first, then y, then z (Ops.h:841-871).  One thread per fine cell.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
+
+__global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float *__restrict__ coarse)
+{
+    const size_t n = size_t(fg.nx) * fg.ny * fg.nz;
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (!activeLabel(fg.lab[c])) return;
+    const int i = int(c % fg.nx), j = int((c / fg.nx) % fg.ny), k = int(c / (size_t(fg.nx) * fg.ny));
+    const int cnx = fg.nx >> 1, cny = fg.ny >> 1;
+    const int bi = (i - 1) >> 1, bj = (j - 1) >> 1, bk = (k - 1) >> 1;  // active cells have i,j,k >= 1
+    const float fx = (i & 1) ? 0.25f : 0.75f, fy = (j & 1) ? 0.25f : 0.75f, fz = (k & 1) ? 0.25f : 0.75f;
+    const float *p = coarse + (size_t(bk) * cny + bj) * cnx + bi;
+    const size_t sy = size_t(cnx), sz = size_t(cnx) * cny;
+    const float v00 = lerpRef(p[0], p[1], fx), v10 = lerpRef(p[sy], p[sy + 1], fx);
+    const float v01 = lerpRef(p[sz], p[sz + 1], fx), v11 = lerpRef(p[sz + sy], p[sz + sy + 1], fx);
+    const float t = lerpRef(lerpRef(v00, v10, fy), lerpRef(v01, v11, fy), fz);
+    fine[c] += 4.f * t;  // Ops.h:964
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coarsest-level direct solve (MG.cpp:669-692) as x = A^-1 b with the dense inverse built at
+// set-up.  gather b -> v, one wave per row of the mat-vec, scatter into x.
+// ---------------------------------------------------------------------------------------------
+__global__ void coarseGatherKernel(int n, const int32_t *__restrict__ cells, const float *__restrict__ b,
+                                   float *__restrict__ v)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) v[t] = b[cells[t]];
+}
+__global__ __launch_bounds__(256) void coarseMatVecKernel(int n, const float *__restrict__ inv,
+                                                          const int32_t *__restrict__ cells,
+                                                          const float *__restrict__ v, float *__restrict__ x)
+{
+    const int row = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (row >= n) return;
+    const float *r = inv + size_t(row) * n;
+    double acc = 0.0;
+    for (int c = lane; c < n; c += kWave) acc += double(r[c]) * double(v[c]);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) x[cells[row]] = float(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vector updates on active cells (Ops.h:974-1195).  Quad version (16-byte accesses) + scalar tail.
+// ---------------------------------------------------------------------------------------------
+enum VecOp { V_AXPY = 0, V_XPAY = 1, V_SCALE = 2, V_MUL = 3 };
+
+template <int VOP>
+__device__ __forceinline__ float vecOp(float d, float a, float s, float scale)
+{
+    if (VOP == V_AXPY) return d + scale * a;   // addToVector: d += scale * a
+    if (VOP == V_XPAY) return a + scale * s;   // addVectors: d = a + scale * s
+    if (VOP == V_SCALE) return scale * d;      // scaleVector
+    return a * s;                              // d = a .* s (diagonal preconditioner)
+}
+
+template <int VOP>
+__global__ __launch_bounds__(256) void vecKernel(size_t n, const uint8_t *__restrict__ lab, float *dst, const float *a,
+                                                 const float *s, const float *scaleDev, float scaleHost, float sign)
+{
+    const float scale = sign * (scaleDev ? *scaleDev : scaleHost);
+    const size_t nq = n >> 2;
+    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x) {
+        const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
+        float4 d = reinterpret_cast<const float4 *>(dst)[q];
+        float4 av = d, sv = d;
+        if (VOP != V_SCALE) av = reinterpret_cast<const float4 *>(a)[q];
+        if (VOP == V_XPAY || VOP == V_MUL) sv = reinterpret_cast<const float4 *>(s)[q];
+        if (activeLabel(l.x)) d.x = vecOp<VOP>(d.x, av.x, sv.x, scale);
+        if (activeLabel(l.y)) d.y = vecOp<VOP>(d.y, av.y, sv.y, scale);
+        if (activeLabel(l.z)) d.z = vecOp<VOP>(d.z, av.z, sv.z, scale);
+        if (activeLabel(l.w)) d.w = vecOp<VOP>(d.w, av.w, sv.w, scale);
+        reinterpret_cast<float4 *>(dst)[q] = d;
+    }
+    // tail (n % 4 cells)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t c = (nq << 2) + threadIdx.x;
+        if (activeLabel(lab[c])) dst[c] = vecOp<VOP>(dst[c], VOP != V_SCALE ? a[c] : 0.f, (VOP == V_XPAY || VOP == V_MUL) ? s[c] : 0.f, scale);
+    }
+}
+
+// 1/diag of the fine operator for the diagonal preconditioner (Plug.cpp:500-553): 1/6 on INTERIOR
+// cells, 1/(sum of the six face weights) on BOUNDARY cells, 0 elsewhere.
+__global__ void diagInverseKernel(GridP g, float *__restrict__ dinv)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const unsigned l = g.lab[c];
+    float v = 0.f;
+    if (l == MGPS_INTERIOR_CELL) v = 1.f / 6.f;
+    else if (l == MGPS_BOUNDARY_CELL) {
+        const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / (size_t(g.nx) * g.ny));
+        float d = 6.f;
+        if (g.wx) {
+            const size_t fx = (size_t(k) * g.ny + j) * (g.nx + 1) + i;
+            const size_t fy = (size_t(k) * (g.ny + 1) + j) * g.nx + i;
+            d = g.wx[fx] + g.wx[fx + 1] + g.wy[fy] + g.wy[fy + g.nx] + g.wz[c] + g.wz[c + size_t(g.nx) * g.ny];
+        }
+        v = 1.f / d;
+    }
+    dinv[c] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reductions over active cells (Ops.h:1020-1085, 1205-1326): per-thread fp64 accumulation,
+// wavefront shuffle reduction, one partial per workgroup, then a single-workgroup second stage
+// that adds the partials in a fixed order (bitwise reproducible from run to run).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ double redTerm(float a, float b)
+{
+    if (KIND == 0) return double(a) * double(b);
+    if (KIND == 1) return double(a) * double(a);
+    if (KIND == 2) return double(a);
+    return double(fabsf(a));
+}
+template <int KIND>
+__device__ __forceinline__ double redCombine(double u, double v)
+{
+    return KIND <= 1 ? u + v : (u > v ? u : v);
+}
+template <int KIND>
+__device__ __forceinline__ double blockReduce(double acc)
+{
+    __shared__ double part[4];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc = redCombine<KIND>(acc, __shfl_down(acc, off));
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    double total = part[0];
+    for (int w = 1; w < int(blockDim.x / kWave); ++w) total = redCombine<KIND>(total, part[w]);
+    return total;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void reduceKernel(size_t n, const uint8_t *__restrict__ lab, const float *__restrict__ a,
+                                                    const float *__restrict__ b, double *__restrict__ partials)
+{
+    double acc = 0.0;  // identity for sums and for max(0, .) / max|.|
+    const size_t nq = n >> 2;
+    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x) {
+        const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
+        const float4 av = reinterpret_cast<const float4 *>(a)[q];
+        float4 bv = av;
+        if (KIND == 0) bv = reinterpret_cast<const float4 *>(b)[q];
+        if (activeLabel(l.x)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.x, bv.x));
+        if (activeLabel(l.y)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.y, bv.y));
+        if (activeLabel(l.z)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.z, bv.z));
+        if (activeLabel(l.w)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.w, bv.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t c = (nq << 2) + threadIdx.x;
+        if (activeLabel(lab[c])) acc = redCombine<KIND>(acc, redTerm<KIND>(a[c], KIND == 0 ? b[c] : 0.f));
+    }
+    const double total = blockReduce<KIND>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void reduceFinalKernel(int nparts, const double *__restrict__ partials,
+                                                         double *__restrict__ result)
+{
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x) acc = redCombine<KIND>(acc, partials[p]);
+    const double total = blockReduce<KIND>(acc);
+    if (threadIdx.x == 0) *result = total;
+}
+
+inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + per - 1) / per); }
+
+}  // namespace
+
+// ---- launchers -------------------------------------------------------------------------------
+
+int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    if ((g.nx & 3) == 0) {
+        const unsigned nb = blocksFor(n >> 2, 256);
+        switch (op) {
+            case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+            case OP_RESIDUAL: stencilQuadKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+            default: stencilQuadKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+        }
+    } else {
+        const unsigned nb = blocksFor(n, 256);
+        switch (op) {
+            case OP_JACOBI: stencilScalarKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega); break;
+            case OP_RESIDUAL: stencilScalarKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega); break;
+            default: stencilScalarKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega); break;
+        }
+    }
+    return int(hipGetLastError());
+}
+
+int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
+                     float *bandTmp, float omega)
+{
+    if (nband <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned nb = blocksFor(size_t(nband), 256);
+    bandComputeKernel<<<nb, 256, 0, s>>>(g, x, b, band, nband, bandTmp, omega);
+    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp);
+    return int(hipGetLastError());
+}
+
+int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *tiles, int ntiles,
+                  int forward)
+{
+    if (ntiles <= 0) return 0;
+    tiledGSKernel<<<unsigned(ntiles), 256, 0, static_cast<hipStream_t>(stream)>>>(g, x, b, tiles, forward);
+    return int(hipGetLastError());
+}
+
+int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine)
+{
+    const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
+    restrictKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
+    return int(hipGetLastError());
+}
+
+int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse)
+{
+    const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
+    prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
+    return int(hipGetLastError());
+}
+
+int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
+                      float *gathered)
+{
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    coarseGatherKernel<<<blocksFor(size_t(n), 256), 256, 0, s>>>(n, cells, b, gathered);
+    coarseMatVecKernel<<<blocksFor(size_t(n), 4), 256, 0, s>>>(n, inverse, cells, gathered, x);
+    return int(hipGetLastError());
+}
+
+static unsigned streamingBlocks(size_t quads)
+{
+    // memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8, no more
+    return unsigned(std::min<size_t>(std::max<size_t>(1, (quads + 255) / 256), 2048));
+}
+
+int launchAxpy(void *stream, const GridP &g, float *dst, const float *src, const float *scaleDev, float scaleHost,
+               float sign)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    vecKernel<V_AXPY><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, src, nullptr,
+                                                                                              scaleDev, scaleHost, sign);
+    return int(hipGetLastError());
+}
+int launchXpay(void *stream, const GridP &g, float *dst, const float *a, const float *sv, const float *scaleDev,
+               float scaleHost)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    vecKernel<V_XPAY><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, sv, scaleDev,
+                                                                                              scaleHost, 1.f);
+    return int(hipGetLastError());
+}
+int launchScale(void *stream, const GridP &g, float *v, float scale)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    vecKernel<V_SCALE><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, v, nullptr, nullptr,
+                                                                                               nullptr, scale, 1.f);
+    return int(hipGetLastError());
+}
+int launchMulMasked(void *stream, const GridP &g, float *dst, const float *a, const float *b)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    vecKernel<V_MUL><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, b, nullptr, 1.f,
+                                                                                             1.f);
+    return int(hipGetLastError());
+}
+int launchDiagInverse(void *stream, const GridP &g, float *dinv)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    diagInverseKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(g, dinv);
+    return int(hipGetLastError());
+}
+
+int launchReduce(void *stream, int kind, const GridP &g, const float *a, const float *b, double *partials,
+                 double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const unsigned nb = std::min<unsigned>(streamingBlocks(n >> 2), unsigned(kReducePartials));
+    switch (kind) {
+        case 0:
+            reduceKernel<0><<<nb, 256, 0, s>>>(n, g.lab, a, b, partials);
+            reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+            break;
+        case 1:
+            reduceKernel<1><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+            break;
+        case 2:
+            reduceKernel<2><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceFinalKernel<2><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+            break;
+        default:
+            reduceKernel<3><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+            break;
+    }
+    return int(hipGetLastError());
+}
+
+}  // namespace mgps

@@ -1,0 +1,213 @@
+/*
+ * mgps.h -- C ABI of the MI355X-native geometric multigrid pressure solver ("mgps").
+ *
+ * This is the drop-in boundary for the hot path of rgoldade/GeometricMultigridPressureSolver:
+ * everything the Houdini plugin HDK_GeometricFreeSurfacePressureSolver::solveGasSubclass calls
+ * between "build MG domain labels" and "apply solution to pressure"
+ * (Source/HDK_GeometricFreeSurfacePressureSolver.cpp:344-362 and 426-629) is reachable through
+ * the entry points below.  The reference has no C ABI of its own (it is C++ templates over HDK
+ * UT_VoxelArray); each entry point cites the reference interface it replaces.  INTEGRATION.md
+ * shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - Grids are dense flat arrays, x fastest: index = (k*ny + j)*nx + i -- the logical order
+ *    UT_VoxelArray exposes.  The face-weight grid of axis a has one more entry along a
+ *    (MG.cpp:167-177): wx is (nx+1)*ny*nz, wy nx*(ny+1)*nz, wz nx*ny*(nz+1).
+ *  - Labels are uint8 with the reference's values (HDK_GeometricMultigridOperators.h:11).
+ *  - Storage is fp32 (the reference stores double; fp32/mixed precision is its README TO-DO).
+ *    Scalars crossing the boundary (dot products, norms, tolerances) are double.
+ *  - Pointers named *_dev are HIP device pointers on the solver's device; *_host are host
+ *    pointers.  Every solution / rhs / residual grid must hold exactly 0 outside active
+ *    (INTERIOR or BOUNDARY) cells, the invariant the reference asserts at
+ *    HDK_GeometricMultigridOperators.h:821-823 and 950-953.
+ *  - Every function returns an mgps_status; no exception crosses the boundary; nothing aborts.
+ *    A handle is not thread-safe; distinct handles are independent (MG.h:35-52 has the same rule).
+ *  - All device work is enqueued on the handle's stream (mgps_set_stream); functions that return
+ *    a scalar to the host synchronise that stream, the others are asynchronous.
+ */
+#ifndef MGPS_H
+#define MGPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPS_VERSION 1
+
+/* HDK::GeometricMultigridOperators::CellLabels (HDK_GeometricMultigridOperators.h:11) */
+enum { MGPS_INTERIOR_CELL = 0, MGPS_EXTERIOR_CELL = 1, MGPS_DIRICHLET_CELL = 2, MGPS_BOUNDARY_CELL = 3 };
+
+typedef enum mgps_status {
+    MGPS_OK = 0,
+    MGPS_ERR_INVALID_ARGUMENT = 1,
+    MGPS_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime failure at start-up */
+    MGPS_ERR_HIP = 3,            /* a HIP call failed; see mgps_last_error */
+    MGPS_ERR_ALLOC = 4,
+    MGPS_ERR_HIERARCHY = 5,      /* no solvable cell / level cap left no level (MG.cpp:233-248) */
+    MGPS_ERR_COARSE_TOO_LARGE = 6, /* coarsest level has more unknowns than the direct solver takes */
+    MGPS_ERR_COARSE_FACTOR = 7,  /* coarsest matrix not positive definite (MG.cpp:411) */
+    MGPS_ERR_COMM = 8,           /* multi-GPU exchange failed */
+    MGPS_ERR_INTERRUPTED = 9     /* the interrupt callback asked to stop */
+} mgps_status;
+
+/* outcome of mgps_solve_pcg, mirrors the early-outs of HDK_GeometricCGPoissonSolver.h:36-40, 60-64 */
+enum { MGPS_PCG_CONVERGED = 0, MGPS_PCG_RHS_ZERO = 1, MGPS_PCG_ALREADY_CONVERGED = 2, MGPS_PCG_MAX_ITERATIONS = 3 };
+
+typedef struct mgps_solver mgps_solver;       /* device-resident solver: the MG object + level storage */
+typedef struct mgps_hierarchy mgps_hierarchy; /* host-only multigrid hierarchy (labels, bands, coarse factor) */
+
+/* Compile-time constants of the reference exposed as options with the reference's values as
+ * defaults: band width 3 / band iterations 3 (MG.cpp:141-142), omega = 2/3 (Ops.h:291, 554). */
+typedef struct mgps_options {
+    int struct_size;        /* sizeof(mgps_options), set by mgps_default_options */
+    int band_width;         /* 3 */
+    int band_iterations;    /* 3 */
+    float jacobi_weight;    /* 2/3 */
+    int device;             /* HIP device ordinal; -1 = current device */
+    int use_graph;          /* 1 = replay the V-cycle from a captured hipGraph when pointers repeat */
+    int print_stats;        /* doPrintStats of MG.h:24: per-stage timings on stdout */
+    int max_coarse_unknowns;/* direct-solve cap, default 8192 */
+    int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
+    void *interrupt_user;
+} mgps_options;
+
+typedef struct mgps_pcg_stats {
+    int outcome;                   /* MGPS_PCG_* */
+    int iterations;                /* value of `iteration` printed at CG.h:198 */
+    double rel_residual;           /* "Drifted relative L2 Error", CG.h:199-200 */
+    double rel_residual_recomputed;/* "Recomputed relative L2 Error", CG.h:203-206 */
+    double rhs_norm2;
+    double solve_ms;               /* device time of the solve, HIP events */
+} mgps_pcg_stats;
+
+void mgps_default_options(mgps_options *opt);
+const char *mgps_status_string(int status);
+/* Last error text of this handle (never NULL); mgps_last_error(NULL) returns the text of the last
+ * failed call that had no handle (mgps_create, mgps_hierarchy_create, domain helpers). */
+const char *mgps_last_error(const mgps_solver *h);
+int mgps_device_count(int *count);
+
+/* ---- domain expansion: host arrays --------------------------------------------------------
+ * buildExpandedCellLabels sizing rule (Ops.h:1340-1362).  levels_in = 0 applies the reference rule
+ * levels = ceil(log2(min res)) - 1; a positive levels_in keeps the caller's count.  power_of_two
+ * != 0 rounds every extent up to a power of two as the reference does (Ops.h:1353-1360); 0 gives
+ * the tight extents (multiples of 2^levels) that the operators actually need. */
+int mgps_expanded_layout(int bnx, int bny, int bnz, int levels_in, int power_of_two,
+                         int out_dims[3], int *out_offset, int *out_levels);
+/* buildExpandedCellLabels copy step (Ops.h:1364-1453): EXTERIOR everywhere, non-EXTERIOR base
+ * labels at +offset as INTERIOR or DIRICHLET. */
+int mgps_expand_labels(uint8_t *expanded, const uint8_t *base, int bnx, int bny, int bnz,
+                       int enx, int eny, int enz, int offset);
+/* buildExpandedBoundaryWeights (Ops.h:1458-1572): zero, positive base weights at +offset. */
+int mgps_expand_weights(float *expanded, const float *base, int axis, int bnx, int bny, int bnz,
+                        int enx, int eny, int enz, int offset);
+/* setBoundaryCellLabels (Ops.h:1574-1644), in place. */
+int mgps_set_boundary_labels(uint8_t *labels, const float *wx, const float *wy, const float *wz,
+                             int nx, int ny, int nz);
+/* unitTestBoundaryCells / unitTestExteriorCells / unitTestCoarsening (Ops.h:1771-1870,
+ * Ops.cpp:471-632): *pass = 1 when the invariant holds.  Weights may be NULL. */
+int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const float *wy,
+                              const float *wz, int nx, int ny, int nz, int *pass);
+int mgps_check_exterior_cells(const uint8_t *labels, int nx, int ny, int nz, int *pass);
+int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, int fny, int fnz, int *pass);
+
+/* ---- host-only hierarchy: the setup half of the GeometricMultigridPoissonSolver constructor
+ * (MG.cpp:135-418) without touching a GPU: label coarsening with the early level cap
+ * (Ops.cpp:23-163, MG.cpp:238-253), band lists (Ops.cpp:165-469), coarsest matrix + factor
+ * (MG.cpp:288-411).  mgps_create builds one of these and uploads it. */
+int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels,
+                          int mg_levels, const mgps_options *opt);
+void mgps_hierarchy_destroy(mgps_hierarchy *hier);
+int mgps_hierarchy_levels(const mgps_hierarchy *hier);
+int mgps_hierarchy_level_dims(const mgps_hierarchy *hier, int level, int out_dims[3]);
+int mgps_hierarchy_level_labels(const mgps_hierarchy *hier, int level, uint8_t *out);
+int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level);
+/* band cells as (i,j,k) int32 triples, in the reference's order (tile id, k, j, i) */
+int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *out_ijk);
+int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier);
+/* x = A_coarsest^{-1} b on the host, grids of the coarsest level's size (MG.cpp:669-692) */
+int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b);
+
+/* ---- the solver object -------------------------------------------------------------------
+ * GeometricMultigridPoissonSolver(labels, weights[3], mgLevels, useGaussSeidel, doPrintStats)
+ * (MG.h:20-24, MG.cpp:135-418).  labels / weights are HOST arrays and are copied (MG.cpp:164,
+ * 179-180).  use_gauss_seidel selects the tile-coloured Gauss-Seidel smoother (the plugin
+ * hard-wires it on, Plug.cpp:466); 0 selects damped Jacobi. */
+int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
+                const float *wx_host, const float *wy_host, const float *wz_host, int mg_levels,
+                int use_gauss_seidel, const mgps_options *opt);
+void mgps_destroy(mgps_solver *h);
+int mgps_levels(const mgps_solver *h);                       /* getMGLevels(), MG.h:31 */
+int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3]);
+const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *h);
+int mgps_set_stream(mgps_solver *h, void *hip_stream);       /* hipStream_t; NULL = default stream */
+int mgps_synchronize(mgps_solver *h);
+
+/* device grids of a level's size (level 0 = the solver grid) */
+int mgps_grid_alloc(mgps_solver *h, int level, float **out_dev);  /* zero-filled */
+int mgps_grid_free(mgps_solver *h, float *dev);
+int mgps_grid_upload(mgps_solver *h, int level, float *dst_dev, const float *src_host);
+int mgps_grid_download(mgps_solver *h, int level, float *dst_host, const float *src_dev);
+
+/* applyVCycle(solution, rhs, useInitialGuess) (MG.h:26-29, MG.cpp:420-881) */
+int mgps_apply_vcycle(mgps_solver *h, float *x_dev, const float *b_dev, int use_initial_guess);
+
+/* ---- HDK::GeometricMultigridOperators on level `level` of the hierarchy (level 0 carries the
+ * face weights, coarser levels use unit weights exactly as MG.cpp:447-451 vs 572-575) -------- */
+/* jacobiPoissonSmoother (Ops.h:262-367), in place */
+int mgps_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev);
+/* tiledGaussSeidelPoissonSmoother (Ops.h:369-520), in place */
+int mgps_tiled_gs_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev,
+                         int smooth_odd_tiles, int smooth_forward);
+/* boundaryJacobiPoissonSmoother over the level's band list (Ops.h:524-619), in place */
+int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev);
+/* applyPoissonMatrix (Ops.h:621-714).  Inactive cells of y are set to 0. */
+int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_dev);
+/* computePoissonResidual (Ops.h:716-732): r = b - A x, 0 on inactive cells */
+int mgps_residual(mgps_solver *h, int level, float *r_dev, const float *x_dev, const float *b_dev);
+/* downsample (Ops.h:734-835): coarse (level+1) = Restrict(fine (level)) */
+int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *fine_dev);
+/* upsampleAndAdd (Ops.h:873-972): fine (level) += 4 * Trilerp(coarse (level+1)) */
+int mgps_upsample_add(mgps_solver *h, int fine_level, float *fine_dev, const float *coarse_dev);
+/* coarsest-level direct solve (MG.cpp:669-692) on device grids of the coarsest level */
+int mgps_coarse_solve(mgps_solver *h, float *x_dev, const float *b_dev);
+/* dotProduct (Ops.h:1020-1085), squaredL2Norm / l2Norm (1197-1265); fp64 accumulation */
+int mgps_dot(mgps_solver *h, int level, const float *a_dev, const float *b_dev, double *out);
+int mgps_squared_l2_norm(mgps_solver *h, int level, const float *a_dev, double *out);
+int mgps_l2_norm(mgps_solver *h, int level, const float *a_dev, double *out);
+/* infNorm (Ops.h:1267-1326).  reference_signed_max != 0 reproduces the reference exactly:
+ * max(0, max_active v) with no absolute value; 0 gives the true max |v|. */
+int mgps_inf_norm(mgps_solver *h, int level, const float *a_dev, int reference_signed_max, double *out);
+/* addToVector: dst += scale*src (Ops.h:1087-1137); addVectors: dst = a + scale*s, dst may alias s
+ * (Ops.h:1139-1195); scaleVector (Ops.h:974-1018).  Active cells only. */
+int mgps_add_to_vector(mgps_solver *h, int level, float *dst_dev, const float *src_dev, double scale);
+int mgps_add_vectors(mgps_solver *h, int level, float *dst_dev, const float *a_dev,
+                     const float *scaled_dev, double scale);
+int mgps_scale_vector(mgps_solver *h, int level, float *v_dev, double scale);
+
+/* solveGeometricConjugateGradient (CG.h:18-207) with A = applyPoissonMatrix and
+ * M^-1 = applyVCycle (use_mg_preconditioner != 0; Plug.cpp:461-484) or the diagonal
+ * preconditioner (0; Plug.cpp:485-618).  x_dev holds the initial guess and receives the solution. */
+int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tolerance,
+                   int max_iterations, int use_mg_preconditioner, mgps_pcg_stats *stats);
+
+/* ---- measurement hooks (the reference's UT_StopWatch scopes, MG.cpp:461-492 "Smoother time") ----
+ * While enabled, HIP events bracket every fine-level full-domain smoother launch group inside
+ * mgps_apply_vcycle (the Jacobi sweep, or the two tile-coloured Gauss-Seidel half sweeps).
+ * mgps_profile_read synchronises, returns the accumulated device time and launch-group count
+ * since the last read, and resets both. */
+int mgps_profile_enable(mgps_solver *h, int enable);
+int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
+
+/* Host-buffer convenience forms: what the Houdini shim calls (upload, run, download). */
+int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, int use_initial_guess);
+int mgps_solve_pcg_host(mgps_solver *h, float *x_host, const float *b_host, double tolerance,
+                        int max_iterations, int use_mg_preconditioner, mgps_pcg_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGPS_H */

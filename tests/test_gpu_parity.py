@@ -1,0 +1,359 @@
+"""GPU parity tests: every HIP operator, the V-cycle and MG-PCG, called through the C ABI
+(libmgps.so), against the fp64 CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 storage + fp32 arithmetic on the GPU vs the reference's fp64):
+  * single operator pass:      max-abs error <= 5e-6 * max|oracle|
+  * one V-cycle:               relative L2 error <= 1e-5
+  * reductions (fp64 accum.):  relative error <= 1e-6
+  * PCG to 1e-5:               iteration count within +2 of the oracle's, recomputed residual <= 2e-5
+  * symmetry <Ma,b> = <Mb,a>:  relative difference <= 1e-4 (the reference's fp64 bound is 1e-10)
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 5e-6
+VCYCLE_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None):
+    import geometricmultigridpressuresolver_amd as G
+
+    lab, w, off, lev, dx = domain_factory(kind, g, levels, solver_shape)
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs)
+    lab32 = lab.astype(np.int32)
+    w64 = [a.astype(np.float64) for a in w]
+    orc = oracle.solver(lab32, w64, lev, use_gs)
+    return gpu, orc, lab, lab32, w64, off, lev, dx
+
+
+def _rand_active(lab, seed, scale=1.0):
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    v = rng.random(lab.shape) * scale
+    v[~D.active_mask(lab)] = 0
+    return v
+
+
+DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48)]
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_hierarchy_matches_oracle(kind, g, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    assert gpu.getMGLevels() == orc.levels
+    H = gpu.hierarchy()
+    for l in range(orc.levels):
+        assert (H.level_labels(l) == orc.level_labels(l)).all()
+        assert (H.band_cells(l) == orc.band(l)).all()
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_fine_level_operators(kind, g, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    x0 = _rand_active(lab, 1)
+    b0 = _rand_active(lab, 2, dx * dx)
+    band = orc.band(0)
+
+    # applyPoissonMatrix
+    y = np.zeros_like(x0)
+    oracle.apply_poisson(y, x0, lab32, w64)
+    xd, yd = gpu.to_device(x0), gpu.new_grid()
+    gpu.applyPoissonMatrix(yd, xd)
+    assert rel_err(yd.cpu().numpy(), y) < OP_TOL
+
+    # computePoissonResidual
+    r = np.zeros_like(x0)
+    oracle.residual(r, x0, b0, lab32, w64)
+    bd, rd = gpu.to_device(b0), gpu.new_grid()
+    gpu.computePoissonResidual(rd, xd, bd)
+    assert rel_err(rd.cpu().numpy(), r) < OP_TOL
+
+    # jacobiPoissonSmoother
+    xj = x0.copy()
+    oracle.jacobi(xj, b0, lab32, w64)
+    xjd = gpu.to_device(x0)
+    gpu.jacobiPoissonSmoother(xjd, bd)
+    assert rel_err(xjd.cpu().numpy(), xj) < OP_TOL
+
+    # boundaryJacobiPoissonSmoother, three passes
+    xb = x0.copy()
+    xbd = gpu.to_device(x0)
+    for _ in range(3):
+        oracle.boundary_jacobi(xb, b0, lab32, band, w64)
+        gpu.boundaryJacobiPoissonSmoother(xbd, bd)
+    assert rel_err(xbd.cpu().numpy(), xb) < OP_TOL
+
+    # tiledGaussSeidelPoissonSmoother, all four colour/direction combinations in V-cycle order
+    xg = x0.copy()
+    xgd = gpu.to_device(x0)
+    for odd, fwd in ((True, True), (False, True), (False, False), (True, False)):
+        oracle.tiled_gs(xg, b0, lab32, odd, fwd, w64)
+        gpu.tiledGaussSeidelPoissonSmoother(xgd, bd, odd, fwd)
+    assert rel_err(xgd.cpu().numpy(), xg) < 4 * OP_TOL
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_coarse_level_operators(kind, g, domain_factory, oracle, torch_cuda):
+    """Levels >= 1 use unit weights (MG.cpp:572-575) and smaller, differently aligned grids."""
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    for l in range(1, orc.levels):
+        ll = orc.level_labels(l)
+        x0 = _rand_active(ll, 10 + l)
+        b0 = _rand_active(ll, 20 + l)
+        bd = gpu.to_device(b0, l)
+        xj = x0.copy()
+        oracle.jacobi(xj, b0, ll)
+        xjd = gpu.to_device(x0, l)
+        gpu.jacobiPoissonSmoother(xjd, bd, level=l)
+        assert rel_err(xjd.cpu().numpy(), xj) < OP_TOL, l
+        r = np.zeros_like(x0)
+        oracle.residual(r, x0, b0, ll)
+        rd = gpu.new_grid(l)
+        gpu.computePoissonResidual(rd, gpu.to_device(x0, l), bd, level=l)
+        assert rel_err(rd.cpu().numpy(), r) < OP_TOL, l
+        xb = x0.copy()
+        oracle.boundary_jacobi(xb, b0, ll, orc.band(l))
+        xbd = gpu.to_device(x0, l)
+        gpu.boundaryJacobiPoissonSmoother(xbd, bd, level=l)
+        assert rel_err(xbd.cpu().numpy(), xb) < OP_TOL, l
+        xg = x0.copy()
+        xgd = gpu.to_device(x0, l)
+        for odd, fwd in ((True, True), (False, True), (False, False), (True, False)):
+            oracle.tiled_gs(xg, b0, ll, odd, fwd)
+            gpu.tiledGaussSeidelPoissonSmoother(xgd, bd, odd, fwd, level=l)
+        assert rel_err(xgd.cpu().numpy(), xg) < 4 * OP_TOL, l
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_transfer_operators(kind, g, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    for l in range(orc.levels - 1):
+        fl, cl = orc.level_labels(l), orc.level_labels(l + 1)
+        fine = _rand_active(fl, 30 + l)
+        coarse = np.zeros(cl.shape)
+        oracle.downsample(coarse, fine, cl)
+        cd = gpu.new_grid(l + 1)
+        gpu.downsample(cd, gpu.to_device(fine, l), fine_level=l)
+        assert rel_err(cd.cpu().numpy(), coarse) < OP_TOL, l
+        assert (cd.cpu().numpy()[~np.isin(cl, (0, 3))] == 0).all()
+
+        csrc = _rand_active(cl, 40 + l)
+        fdst = _rand_active(fl, 50 + l)
+        ref = fdst.copy()
+        oracle.upsample_add(ref, csrc, fl)
+        fd = gpu.to_device(fdst, l)
+        gpu.upsampleAndAdd(fd, gpu.to_device(csrc, l + 1), fine_level=l)
+        assert rel_err(fd.cpu().numpy(), ref) < OP_TOL, l
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_vector_ops_and_reductions(kind, g, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    a = _rand_active(lab, 3) - 0.4 * (lab == 0)
+    b = _rand_active(lab, 4)
+    ad, bd = gpu.to_device(a), gpu.to_device(b)
+    a32, b32 = ad.cpu().numpy().astype(np.float64), bd.cpu().numpy().astype(np.float64)
+    assert abs(gpu.dotProduct(ad, bd) - oracle.dot(a32, b32, lab32)) <= 1e-6 * abs(oracle.dot(a32, b32, lab32))
+    assert abs(gpu.squaredL2Norm(ad) - oracle.squared_l2(a32, lab32)) <= 1e-6 * oracle.squared_l2(a32, lab32)
+    assert abs(gpu.l2Norm(ad) - oracle.l2(a32, lab32)) <= 1e-6 * oracle.l2(a32, lab32)
+    assert gpu.infNorm(ad) == pytest.approx(oracle.inf_norm(a32, lab32), rel=1e-7)
+    neg = -np.abs(a32) - 1.0 * (np.isin(lab, (0, 3)))
+    negd = gpu.to_device(neg)
+    assert gpu.infNorm(negd) == 0.0  # the reference's signed max: max(0, max v), Ops.h:1303-1312
+    assert gpu.infNorm(negd, reference_signed_max=False) == pytest.approx(np.abs(negd.cpu().numpy()).max(), rel=1e-7)
+
+    ref = a32.copy()
+    oracle.add_to_vector(ref, b32, -0.37, lab32)
+    gpu.addToVector(ad, bd, -0.37)
+    assert rel_err(ad.cpu().numpy(), ref) < 1e-6
+    ref2 = np.zeros_like(a32)
+    oracle.add_vectors(ref2, a32, b32, 1.7, lab32)
+    dd = gpu.new_grid()
+    ad = gpu.to_device(a)
+    gpu.addVectors(dd, ad, bd, 1.7)
+    assert rel_err(dd.cpu().numpy(), ref2) < 1e-6
+    gpu.addVectors(bd, ad, bd, 1.7)  # destination aliases the scaled source (CG.h:191)
+    assert rel_err(bd.cpu().numpy(), ref2) < 1e-6
+    ref3 = a32.copy()
+    oracle.scale_vector(ref3, 0.25, lab32)
+    gpu.scaleVector(ad, 0.25)
+    assert rel_err(ad.cpu().numpy(), ref3) < 1e-6
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_coarse_direct_solve(kind, g, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    L = orc.levels - 1
+    cl = orc.level_labels(L)
+    b = _rand_active(cl, 60)
+    xd = gpu.new_grid(L)
+    gpu.coarseDirectSolve(xd, gpu.to_device(b, L))
+    x = xd.cpu().numpy().astype(np.float64)
+    y = np.zeros_like(x)
+    oracle.apply_poisson(y, x, cl)
+    assert rel_err(y, b) < 1e-5
+
+
+@pytest.mark.parametrize("use_gs", [False, True])
+@pytest.mark.parametrize("kind,g", DOMAINS)
+def test_vcycle_matches_oracle(kind, g, use_gs, domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, use_gs, domain_factory, oracle)
+    b = _rand_active(lab, 5, dx * dx)
+    x_ref = np.zeros_like(b)
+    xd, bd = gpu.new_grid(), gpu.to_device(b)
+    b_as_f32 = bd.cpu().numpy().astype(np.float64)
+    for it in range(3):
+        orc.apply_vcycle(x_ref, b_as_f32, it > 0)
+        gpu.applyVCycle(xd, bd, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    x = xd.cpu().numpy()
+    assert (x[~np.isin(lab, (0, 3))] == 0).all()  # zero outside active cells (Ops.h:821-823)
+
+
+@pytest.mark.parametrize("use_gs", [False, True])
+def test_vcycle_symmetry_fp32(use_gs, domain_factory, oracle, torch_cuda):
+    """<M a, b> = <M b, a> for M = 4 chained V-cycles (Test.cpp:1808-1875), fp32 bound 1e-4."""
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("solid", 48, use_gs, domain_factory, oracle)
+    a, b = gpu.to_device(_rand_active(lab, 6, dx * dx)), gpu.to_device(_rand_active(lab, 7, dx * dx))
+    xa, xb = gpu.new_grid(), gpu.new_grid()
+    for it in range(4):
+        gpu.applyVCycle(xa, a, it > 0)
+        gpu.applyVCycle(xb, b, it > 0)
+    da, db = gpu.dotProduct(xa, b), gpu.dotProduct(xb, a)
+    assert abs(da - db) / max(abs(da), abs(db)) < 1e-4
+
+
+def test_single_level_vcycle(domain_factory, oracle, torch_cuda):
+    """mgLevels == 1 returns after the fine smoothing stroke (MG.cpp:516-517)."""
+    import geometricmultigridpressuresolver_amd as G
+
+    lab, w, off, lev, dx = domain_factory("simple", 32)
+    for use_gs in (False, True):
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, 1, use_gs)
+        orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], 1, use_gs)
+        b = _rand_active(lab, 8, dx * dx)
+        bd = gpu.to_device(b)
+        x_ref = np.zeros_like(b)
+        orc.apply_vcycle(x_ref, bd.cpu().numpy().astype(np.float64), False)
+        xd = gpu.new_grid()
+        gpu.applyVCycle(xd, bd, False)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL
+
+
+@pytest.mark.parametrize("kind,g", [("simple", 64), ("solid", 64)])
+@pytest.mark.parametrize("use_gs", [True, False])
+def test_mg_pcg_matches_oracle(kind, g, use_gs, domain_factory, oracle, torch_cuda):
+    """testConjugateGradient (Test.cpp:675-1009): delta rhs, MG-preconditioned CG to 1e-5."""
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, use_gs, domain_factory, oracle)
+    b = D.delta_rhs(lab, g, off, dx, dtype=np.float32)
+    bd = gpu.to_device(b)
+    x_ref = np.zeros(lab.shape)
+    ref = orc.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 2500, True)
+    xd = gpu.new_grid()
+    st = gpu.solveGeometricConjugateGradient(xd, bd, 1e-5, 2500, True)
+    assert st["outcome"] == "converged"
+    assert abs(st["iterations"] - ref["iterations"]) <= 2
+    assert st["rel_residual_recomputed"] < 2e-5
+    # same pressure field: both solve A x = b to 1e-5; compare in the A-independent relative L2 sense
+    assert rel_l2(xd.cpu().numpy(), x_ref) < 2e-4
+
+
+def test_diagonal_pcg(domain_factory, oracle, torch_cuda):
+    """useMGPreconditioner off: Jacobi-preconditioned CG (Plug.cpp:485-618)."""
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("solid", 48, True, domain_factory, oracle)
+    b = D.delta_rhs(lab, 48, off, dx, dtype=np.float32)
+    x_ref = np.zeros(lab.shape)
+    ref = orc.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 2500, False)
+    xd = gpu.new_grid()
+    st = gpu.solveGeometricConjugateGradient(xd, gpu.to_device(b), 1e-5, 2500, False)
+    assert st["outcome"] == "converged"
+    assert abs(st["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 20)
+    assert st["rel_residual_recomputed"] < 2e-5
+
+
+def test_pcg_early_outs(domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("simple", 32, True, domain_factory, oracle)
+    xd, zd = gpu.new_grid(), gpu.new_grid()
+    st = gpu.solveGeometricConjugateGradient(xd, zd, 1e-5, 10, True)
+    assert st["outcome"] == "rhs_zero"  # CG.h:36-40
+    b = _rand_active(lab, 9, dx * dx)
+    bd = gpu.to_device(b)
+    st = gpu.solveGeometricConjugateGradient(xd, bd, 1e-5, 100, True)
+    assert st["outcome"] == "converged"
+    st2 = gpu.solveGeometricConjugateGradient(xd, bd, 1e-4, 100, True)
+    assert st2["outcome"] == "already_converged" and st2["iterations"] == 0  # CG.h:60-64
+
+
+def test_host_buffer_forms(domain_factory, oracle, torch_cuda):
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("complex", 32, True, domain_factory, oracle)
+    b = _rand_active(lab, 11, dx * dx).astype(np.float32)
+    x = gpu.applyVCycleHost(np.zeros_like(b), b, False)
+    x_ref = np.zeros(lab.shape)
+    orc.apply_vcycle(x_ref, b.astype(np.float64), False)
+    assert rel_l2(x, x_ref) < VCYCLE_TOL
+    xs, st = gpu.solvePcgHost(np.zeros_like(b), b, 1e-5, 100, True)
+    assert st["outcome"] == "converged"
+
+
+def test_convergence_trace(domain_factory, oracle, torch_cuda):
+    """testOneLevelVCycle (Test.cpp:1877-1960): b = 0, sine error, Jacobi V-cycles with
+    useInitialGuess; the error norm must contract monotonically and track the oracle's trace."""
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("simple", 64, False, domain_factory, oracle)
+    x0 = D.sine_initial_guess(lab, dx)
+    xd, zd = gpu.to_device(x0), gpu.new_grid()
+    x_ref, z = x0.astype(np.float64), np.zeros(lab.shape)
+    prev = gpu.l2Norm(xd)
+    for it in range(12):
+        gpu.applyVCycle(xd, zd, True)
+        orc.apply_vcycle(x_ref, z, True)
+        cur = gpu.l2Norm(xd)
+        assert cur < prev
+        assert cur == pytest.approx(oracle.l2(x_ref, lab32), rel=1e-3)
+        prev = cur
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE config 2 (256^3 interior cube, 5 levels) through size-independent properties: the
+    oracle is too slow for routine full-size comparison, so check linearity of the V-cycle,
+    zero-outside-active, symmetry and contraction at the benchmark size itself."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    lab, w, h = D.interior_cube(256, 5)
+    for use_gs in (False, True):
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, 5, use_gs)
+        a = gpu.to_device(D.random_rhs(lab, h, seed=1))
+        b = gpu.to_device(D.random_rhs(lab, h, seed=2))
+        xa, xb, xab = gpu.new_grid(), gpu.new_grid(), gpu.new_grid()
+        gpu.applyVCycle(xa, a)
+        gpu.applyVCycle(xb, b)
+        ab = a + 2.0 * b
+        gpu.applyVCycle(xab, ab)
+        lin = (xab - (xa + 2.0 * xb)).norm().item() / xab.norm().item()
+        assert lin < 5e-6  # M(a + 2b) = M a + 2 M b
+        da, db = gpu.dotProduct(xa, b), gpu.dotProduct(xb, a)
+        assert abs(da - db) / max(abs(da), abs(db)) < 1e-4
+        inactive = gpu.to_device((~D.active_mask(lab)).astype(np.float32))
+        assert (xa * inactive).abs().max().item() == 0.0
+        r = gpu.new_grid()
+        gpu.computePoissonResidual(r, xa, a)
+        assert gpu.l2Norm(r) < 0.7 * gpu.l2Norm(a)
