@@ -8,6 +8,12 @@ import ctypes as C
 import os
 import subprocess
 
+# torch first, always: its wheel bundles its own libamdhip64.so.7 and libmgps.so needs the same
+# SONAME.  Loaded in this order the dynamic linker binds libmgps.so to the runtime torch already
+# initialised (one HIP runtime per process); in the other order two runtimes coexist and the second
+# one sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmgps.so")

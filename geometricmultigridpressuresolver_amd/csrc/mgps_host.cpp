@@ -557,7 +557,9 @@ int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const ui
         buildBand(L, H->bandWidth);  // MG.cpp:279-281
         buildTileLists(L);
     }
-    const int rc = buildCoarseSolver(*H, o.max_coarse_unknowns);
+    // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
+    // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.
+    const int rc = levels > 1 ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
     if (rc != MGPS_OK) {
         delete H;
         return rc;
