@@ -149,23 +149,126 @@ static void buildBand(HostLevel &L, int width)
     }
 }
 
+static void buildTileBoundaryOffsets(HostLevel &L);
+
+// Operator rows of the BOUNDARY cells, evaluated once (Ops.h:208-256): an INTERIOR neighbour
+// contributes -x_n and +1 to the diagonal, a BOUNDARY neighbour -w x_n and +w, a DIRICHLET
+// neighbour only +w to the diagonal, an EXTERIOR neighbour nothing.  w = 1 on coarse levels.
+void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const float *wz)
+{
+    const Dims d = L.d;
+    const uint8_t *lab = L.labels.data();
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
+    L.codes = L.labels;
+    struct Row {
+        float w[6], diag;
+        bool simple;
+    };
+    auto rowOf = [&](size_t c) {
+        Row r{};
+        const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+        float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (wx) {
+            const size_t fx = (size_t(k) * d.ny + j) * (d.nx + 1) + i;
+            const size_t fy = (size_t(k) * (d.ny + 1) + j) * d.nx + i;
+            w[0] = wx[fx];
+            w[1] = wx[fx + 1];
+            w[2] = wy[fy];
+            w[3] = wy[fy + d.nx];
+            w[4] = wz[c];
+            w[5] = wz[c + sz];
+        }
+        r.simple = true;
+        for (int q = 0; q < 6; ++q) {
+            const uint8_t nl = lab[c + off[q]];
+            if (nl == MGPS_INTERIOR_CELL) {
+                r.w[q] = 1.f;
+                r.diag += 1.f;
+            } else if (nl == MGPS_BOUNDARY_CELL) {
+                r.w[q] = w[q];
+                r.diag += w[q];
+                r.simple &= (w[q] == 1.f);
+            } else if (nl == MGPS_DIRICHLET_CELL) {
+                r.diag += w[q];
+                r.simple &= (w[q] == 1.f);
+            }
+        }
+        return r;
+    };
+    // split the band: general BOUNDARY cells first, then everything else, each part in reference order
+    std::vector<int32_t> general, rest;
+    std::vector<uint8_t> restDiag;
+    std::vector<Row> generalRows;
+    for (int32_t c : L.band) {
+        if (lab[c] == MGPS_BOUNDARY_CELL) {
+            const Row r = rowOf(size_t(c));
+            if (r.simple) {
+                L.codes[c] = uint8_t(kCodeSimple + int(r.diag));
+                rest.push_back(c);
+                restDiag.push_back(uint8_t(int(r.diag)));
+            } else {
+                general.push_back(c);
+                generalRows.push_back(r);
+            }
+        } else {
+            rest.push_back(c);
+            restDiag.push_back(6);
+        }
+    }
+    L.numBoundary = int32_t(general.size());
+    L.bandDev = general;
+    L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());
+    L.bandDiag.assign(size_t(L.numBoundary), 0);
+    L.bandDiag.insert(L.bandDiag.end(), restDiag.begin(), restDiag.end());
+    buildTileBoundaryOffsets(L);
+    const size_t nb = size_t(L.numBoundary);
+    L.rows.assign(7 * nb, 0.f);
+    for (size_t t = 0; t < nb; ++t) {
+        for (int q = 0; q < 6; ++q) L.rows[q * nb + t] = generalRows[t].w[q];
+        L.rows[6 * nb + t] = generalRows[t].diag;
+    }
+}
+
 static void buildTileLists(HostLevel &L)
 {
     const Dims d = L.d;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    L.tilesOdd.clear();
-    L.tilesEven.clear();
+    for (auto *v : {&L.tilesOdd, &L.tilesEven, &L.pureOdd, &L.pureEven, &L.mixedOdd, &L.mixedEven}) v->clear();
     L.activeCells = 0;
     for (int t = 0; t < tx * ty * tz; ++t) {
         const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
-        int64_t cnt = 0;
+        int64_t active = 0, interior = 0;
         for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
             for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
-                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) cnt += isActive(L.labels[d.idx(i, j, k)]);
-        if (!cnt) continue;
-        L.activeCells += cnt;
-        (((ti + tj + tk) & 1) ? L.tilesOdd : L.tilesEven).push_back(t);
+                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) {
+                    const uint8_t l = L.labels[d.idx(i, j, k)];
+                    active += isActive(l);
+                    interior += (l == MGPS_INTERIOR_CELL);
+                }
+        if (!active) continue;
+        L.activeCells += active;
+        const bool odd = (ti + tj + tk) & 1;
+        (odd ? L.tilesOdd : L.tilesEven).push_back(t);
+        if (interior == int64_t(kTile) * kTile * kTile) (odd ? L.pureOdd : L.pureEven).push_back(t);
+        else (odd ? L.mixedOdd : L.mixedEven).push_back(t);
     }
+}
+
+// first BOUNDARY-list entry of every tile (bandDev holds the BOUNDARY cells in tile-major order)
+static void buildTileBoundaryOffsets(HostLevel &L)
+{
+    const Dims d = L.d;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    const int nt = tx * ty * tz;
+    L.tileBndStart.assign(size_t(nt) + 1, 0);
+    for (int32_t q = 0; q < L.numBoundary; ++q) {
+        const size_t c = size_t(L.bandDev[q]);
+        const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+        const int t = ((k / kTile) * ty + (j / kTile)) * tx + (i / kTile);
+        L.tileBndStart[size_t(t) + 1]++;
+    }
+    for (int t = 0; t < nt; ++t) L.tileBndStart[size_t(t) + 1] += L.tileBndStart[size_t(t)];
 }
 
 }  // namespace mgps
@@ -556,6 +659,8 @@ int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     for (auto &L : H->lv) {
         buildBand(L, H->bandWidth);  // MG.cpp:279-281
         buildTileLists(L);
+        buildBoundaryRows(L, nullptr, nullptr, nullptr);  // unit weights; level 0 is redone with the
+                                                          // face weights by mgps_create
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.

@@ -15,6 +15,19 @@ constexpr int kTile = 16;  // UT_VoxelArray tile edge: decides the Gauss-Seidel 
 
 inline bool isActive(uint8_t l) { return l == MGPS_INTERIOR_CELL || l == MGPS_BOUNDARY_CELL; }
 
+// Device-side cell codes.  The kernels read one byte per cell; INTERIOR / EXTERIOR / DIRICHLET keep
+// the reference's label values, BOUNDARY cells are split at set-up into
+//   kCodeGeneral      (= MGPS_BOUNDARY_CELL): some face weight is neither 0 nor 1 -- the operator row is
+//                     kept in the level's row list and applied by list kernels;
+//   kCodeSimple + d   (d = 1..6): every face weight towards an active or DIRICHLET neighbour is exactly
+//                     1, so the row is diag * x_c - sum of the six neighbours with diag = d = number of
+//                     non-EXTERIOR neighbours.  Inactive neighbours contribute 0 to that sum because
+//                     every grid holds exactly 0 outside active cells (the invariant asserted at
+//                     Ops.h:821-823, 950-953), so the full-domain sweeps handle these cells in line with
+//                     no extra loads.  All BOUNDARY cells of the unit-weight coarse levels are simple.
+constexpr uint8_t kCodeGeneral = MGPS_BOUNDARY_CELL;
+constexpr uint8_t kCodeSimple = 4;
+
 struct Dims {
     int nx = 0, ny = 0, nz = 0;
     size_t cells() const { return size_t(nx) * ny * nz; }
@@ -26,11 +39,25 @@ struct HostLevel {
     Dims d;
     std::vector<uint8_t> labels;
     std::vector<int32_t> band;       // linear indices of the band cells, reference order (tile,k,j,i)
-    std::vector<int32_t> tilesOdd;   // tiles (linear tile id) holding active cells, (tx+ty+tz) odd
-    std::vector<int32_t> tilesEven;
+    // device order of the same set: the BOUNDARY cells first (each in reference order), then the
+    // INTERIOR band cells.  Jacobi on the band is compute-then-scatter, so the order is free.
+    std::vector<int32_t> bandDev;
+    std::vector<uint8_t> bandDiag;   // diagonal (1..6) of every bandDev entry that is not a general cell
+    int32_t numBoundary = 0;         // bandDev[0 .. numBoundary) are the *general* BOUNDARY cells
+    // operator rows of the general BOUNDARY cells (Ops.h:208-256 evaluated once at set-up), SoA:
+    // rows[q*numBoundary + t], q = 0..5 the off-diagonal weight towards -x,+x,-y,+y,-z,+z (0 when that
+    // neighbour is not active), q = 6 the diagonal.
+    std::vector<float> rows;
+    std::vector<uint8_t> codes;      // device cell codes (see kCodeSimple)
+    // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
+    // kind: "pure" = all 4096 cells INTERIOR (no label or weight look-ups needed), "mixed" = the rest
+    std::vector<int32_t> tilesOdd, tilesEven;          // all active tiles of the colour (API / tests)
+    std::vector<int32_t> pureOdd, pureEven, mixedOdd, mixedEven;
+    std::vector<int32_t> tileBndStart;  // per tile (+1): first entry of its BOUNDARY cells in bandDev
     int64_t activeCells = 0;
 };
 
+void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const float *wz);
 void setLastGlobalError(const std::string &msg);
 const char *lastGlobalError();
 
@@ -40,16 +67,23 @@ struct GridP {
     int nx, ny, nz;
     const uint8_t *lab;
     const float *wx, *wy, *wz;  // fine level only; nullptr = unit weights (MG.cpp:572-575)
+    // general BOUNDARY cells: cell list + 7 x nbnd SoA coefficients (see HostLevel::rows)
+    const int32_t *bnd;
+    const float *rows;
+    int nbnd;
+    const uint8_t *bandDiag;  // per band-list entry: diagonal of the simple / INTERIOR cells
 };
 
 enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };
 
 // All launchers enqueue on `stream` (a hipStream_t passed as void*) and return a hipError_t as int.
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega);
+// band = device-ordered band list (BOUNDARY cells first, g.nbnd of them)
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                      float *bandTmp, float omega);
-int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *tiles, int ntiles,
-                  int forward);
+// pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
+int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse);
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,

@@ -8,7 +8,14 @@
 //  * grids are flat, x fastest; a cell is active iff its label is INTERIOR (0) or BOUNDARY (3);
 //  * INTERIOR cells have six active neighbours, unit face weights and diagonal 6
 //    (Ops.h:191-207) -- the fast path needs no label or weight look-ups for the neighbours;
-//  * BOUNDARY cells take the general path of computeLaplacian (Ops.h:208-256);
+//  * BOUNDARY cells take the general path of computeLaplacian (Ops.h:208-256), evaluated once at
+//    set-up.  "Simple" ones (all relevant face weights exactly 1: every BOUNDARY cell of a coarse
+//    level, and of a fine level away from cut cells / the free surface) carry their diagonal in the
+//    cell code and are swept in line; the rows of the "general" ones (six off-diagonal weights +
+//    diagonal) live in a compact SoA list per level and a short list kernel patches those cells
+//    after each full-domain sweep.  The sweeps themselves stay free of per-lane weight look-ups (on
+//    a box-shaped liquid every x-row holds two BOUNDARY cells: a look-up path would diverge in every
+//    single wavefront);
 //  * arithmetic is fp32; reductions accumulate in fp64.
 #include <hip/hip_runtime.h>
 
@@ -23,44 +30,29 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
 
-__device__ __forceinline__ bool activeLabel(unsigned l) { return l == MGPS_INTERIOR_CELL || l == MGPS_BOUNDARY_CELL; }
+// device cell codes (mgps_internal.h): 0 INTERIOR, 1 EXTERIOR, 2 DIRICHLET, 3 general BOUNDARY,
+// 4 + d simple BOUNDARY with diagonal d
+__device__ __forceinline__ bool activeLabel(unsigned l) { return l == MGPS_INTERIOR_CELL || l >= kCodeGeneral; }
+__device__ __forceinline__ bool simpleCell(unsigned l) { return l == MGPS_INTERIOR_CELL || l > kCodeSimple; }
+__device__ __forceinline__ float simpleDiag(unsigned l) { return l == MGPS_INTERIOR_CELL ? 6.f : float(int(l) - int(kCodeSimple)); }
 
-// General (BOUNDARY-centre) row of the operator, Ops.h:208-258.  X is any callable size_t -> float.
+// Row t of the BOUNDARY-cell list applied to x (any callable size_t -> float): lap = diag x_c -
+// sum_q w_q x_(c+off_q), the value computeLaplacian returns at Ops.h:258.
 template <class X>
-__device__ __forceinline__ void boundaryRow(const GridP &g, const X &xAt, int i, int j, int k, size_t c, float &lap,
-                                            float &diag)
+__device__ __forceinline__ void boundaryRow(const GridP &g, const X &xAt, int t, size_t c, float &lap, float &diag)
 {
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const bool weighted = g.wx != nullptr;
-    lap = 0.f;
-    diag = 0.f;
-    const size_t nb[6] = {c - 1, c + 1, c - sy, c + sy, c - sz, c + sz};
-    float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (weighted) {
-        const size_t fx = (size_t(k) * g.ny + j) * (g.nx + 1) + i;
-        const size_t fy = (size_t(k) * (g.ny + 1) + j) * g.nx + i;
-        const size_t fz = c;  // (k*ny + j)*nx + i
-        w[0] = g.wx[fx];
-        w[1] = g.wx[fx + 1];
-        w[2] = g.wy[fy];
-        w[3] = g.wy[fy + g.nx];
-        w[4] = g.wz[fz];
-        w[5] = g.wz[fz + sz];
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const unsigned nl = g.lab[nb[q]];
-        if (nl == MGPS_INTERIOR_CELL) {
-            lap -= xAt(nb[q]);
-            diag += 1.f;
-        } else if (nl == MGPS_BOUNDARY_CELL) {
-            lap -= w[q] * xAt(nb[q]);
-            diag += w[q];
-        } else if (nl == MGPS_DIRICHLET_CELL) {
-            diag += w[q];
-        }
-    }
-    lap += diag * xAt(c);
+    const size_t nb = size_t(g.nbnd);
+    const float *r = g.rows + t;
+    float acc = 0.f;
+    acc -= r[0] * xAt(c - 1);
+    acc -= r[nb] * xAt(c + 1);
+    acc -= r[2 * nb] * xAt(c - sy);
+    acc -= r[3 * nb] * xAt(c + sy);
+    acc -= r[4 * nb] * xAt(c - sz);
+    acc -= r[5 * nb] * xAt(c + sz);
+    diag = r[6 * nb];
+    lap = acc + diag * xAt(c);
 }
 
 template <int OP>
@@ -137,26 +129,13 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
     const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
     float res[4];
-    const bool allInterior = (lab.x | lab.y | lab.z | lab.w) == 0;
-    if (allInterior) {
+    // INTERIOR and simple BOUNDARY cells; general BOUNDARY cells are patched by boundaryOpKernel
+    // right after this launch
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float lap = 6.f * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-            res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, 6.f, omega);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (ls[e] == MGPS_INTERIOR_CELL) {
-                const float lap = 6.f * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-                res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, 6.f, omega);
-            } else if (ls[e] == MGPS_BOUNDARY_CELL) {
-                float lap, diag;
-                boundaryRow(g, [&](size_t p) { return x[p]; }, i + e, j, k, c + e, lap, diag);
-                res[e] = epilogue<OP>(xs[e + 1], bs[e], lap, diag, omega);
-            } else
-                res[e] = inactiveValue<OP>(xs[e + 1]);
-        }
+    for (int e = 0; e < 4; ++e) {
+        const float diag = simpleDiag(ls[e]);
+        const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+        res[e] = simpleCell(ls[e]) ? epilogue<OP>(xs[e + 1], bs[e], lap, diag, omega) : inactiveValue<OP>(xs[e + 1]);
     }
     if (valid) *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
 }
@@ -171,19 +150,28 @@ __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const floa
     if (c >= n) return;
     const unsigned l = g.lab[c];
     const float xc = x[c];
-    if (!activeLabel(l)) {
+    if (!simpleCell(l)) {
         out[c] = inactiveValue<OP>(xc);
         return;
     }
-    const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / (size_t(g.nx) * g.ny));
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    float lap, diag;
-    if (l == MGPS_INTERIOR_CELL) {
-        lap = 6.f * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-        diag = 6.f;
-    } else
-        boundaryRow(g, [&](size_t p) { return x[p]; }, i, j, k, c, lap, diag);
+    const float diag = simpleDiag(l);
+    const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
     out[c] = epilogue<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+}
+
+// BOUNDARY cells of a full-domain sweep: one thread per list entry, out of place like the sweep.
+template <int OP>
+__global__ void boundaryOpKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
+                                 const float *__restrict__ b, float omega, unsigned nblocks)
+{
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    const int t = int(block * blockDim.x + threadIdx.x);
+    if (t >= g.nbnd) return;
+    const size_t c = size_t(g.bnd[t]);
+    float lap, diag;
+    boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
+    out[c] = epilogue<OP>(x[c], OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,130 +180,236 @@ __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const floa
 // updated in the same pass.
 // ---------------------------------------------------------------------------------------------
 __global__ void bandComputeKernel(GridP g, const float *__restrict__ x, const float *__restrict__ b,
-                                  const int32_t *__restrict__ band, int nband, float *__restrict__ tmp, float omega)
+                                  const int32_t *__restrict__ band, int nband, float *__restrict__ tmp, float omega,
+                                  unsigned nblocks)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    const int t = int(block * blockDim.x + threadIdx.x);
     if (t >= nband) return;
     const size_t c = size_t(band[t]);
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
     const float xc = x[c];
     float lap, diag;
-    if (g.lab[c] == MGPS_INTERIOR_CELL) {
-        lap = 6.f * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-        diag = 6.f;
-    } else {
-        const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / sz);
-        boundaryRow(g, [&](size_t p) { return x[p]; }, i, j, k, c, lap, diag);
-    }
+    if (t >= g.nbnd) {  // INTERIOR or simple BOUNDARY cell (the list holds the general cells first)
+        diag = float(g.bandDiag[t]);
+        lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+    } else
+        boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
     tmp[t] = xc + omega * ((b[c] - lap) / diag);  // Ops.h:596-599
 }
 __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restrict__ band, int nband,
-                                  const float *__restrict__ tmp)
+                                  const float *__restrict__ tmp, unsigned nblocks)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = int(remapBlock(blockIdx.x, nblocks) * blockDim.x + threadIdx.x);
     if (t < nband) x[band[t]] = tmp[t];  // Ops.h:604-618
 }
 
 // ---------------------------------------------------------------------------------------------
 // Tile-coloured Gauss-Seidel (Ops.h:369-520).  One 256-thread workgroup owns one 16^3 tile of the
-// requested colour: the 18^3 halo cube of x, the labels (18^3) and the rhs (16^3) are staged in LDS,
-// then the tile is swept along anti-diagonal planes i+j+k = s.  For a 7-point stencil every cell
-// of plane s depends only on planes s-1 (already updated) and s+1 (still old), so marching s
-// upwards reproduces the reference's lexicographic forward sweep exactly, and marching downwards
-// its reversed sweep (Ops.h:497-516).  Face neighbours outside the tile belong to tiles of the
-// other colour and are constant during the pass (Ops.h:436-448).
+// requested colour: the 18^3 halo cube of x and the 16^3 rhs are staged in LDS, then the tile is
+// swept along anti-diagonal planes i+j+k = s.  For a 7-point stencil every cell of plane s depends
+// only on planes s-1 (already updated) and s+1 (still old), so marching s upwards reproduces the
+// reference's lexicographic forward sweep exactly and marching downwards its reversed sweep
+// (Ops.h:497-516).  Face neighbours outside the tile belong to tiles of the other colour and are
+// constant during the pass (Ops.h:436-448).
+//   * "pure" tiles (all 4096 cells INTERIOR) need no labels and no weights: 39 KB of LDS;
+//   * "mixed" tiles also stage the 18^3 labels and the operator rows of their BOUNDARY cells
+//     (tile-major slice of the level's row list) in LDS; a BOUNDARY cell finds its row through a
+//     per-x-row mask + prefix count built at load time.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHalo = kTile + 2;
-__global__ __launch_bounds__(256) void tiledGSKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
-                                                     const int32_t *__restrict__ tiles, int forward)
-{
-    __shared__ float sx[kHalo * kHalo * kHalo];
-    __shared__ float sb[kTile * kTile * kTile];
-    __shared__ unsigned char sl[kHalo * kHalo * kHalo];
+constexpr int kHalo3 = kHalo * kHalo * kHalo;
+constexpr int kTile3 = kTile * kTile * kTile;
+constexpr int kPlanes = 3 * (kTile - 1) + 1;
+constexpr int kRowPool = 1024;  // BOUNDARY rows of one tile kept in LDS; the rest is read from memory
 
+__device__ __forceinline__ int haloIdx(int li, int lj, int lk) { return ((lk + 1) * kHalo + (lj + 1)) * kHalo + (li + 1); }
+
+// stage the halo cube of x (and optionally the labels) and the rhs of tile (i0,j0,k0)
+template <bool LABELS>
+__device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restrict__ x, const float *__restrict__ b,
+                                           int i0, int j0, int k0, float *sx, float *sb, unsigned char *sl)
+{
+    const bool full = i0 + kTile <= g.nx && j0 + kTile <= g.ny && k0 + kTile <= g.nz;
+    if (full) {
+        // 18 x 18 rows of the cube; the 16 interior floats of a row as 4 aligned float4, the two x-halo
+        // cells as scalars
+        for (int r = threadIdx.x; r < kHalo * kHalo * 4; r += blockDim.x) {
+            const int q = r & 3, lj = (r >> 2) % kHalo, lk = (r >> 2) / kHalo;
+            const int gj = j0 + lj - 1, gk = k0 + lk - 1;
+            const bool in = gj >= 0 && gk >= 0 && gj < g.ny && gk < g.nz;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) v = *reinterpret_cast<const float4 *>(x + (size_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q);
+            float *dst = sx + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+            if (LABELS) {
+                uchar4 lv = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+                if (in) lv = *reinterpret_cast<const uchar4 *>(g.lab + (size_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q);
+                unsigned char *dl = sl + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
+                dl[0] = lv.x;
+                dl[1] = lv.y;
+                dl[2] = lv.z;
+                dl[3] = lv.w;
+            }
+        }
+        for (int r = threadIdx.x; r < kHalo * kHalo * 2; r += blockDim.x) {
+            const int side = r & 1, lj = (r >> 1) % kHalo, lk = (r >> 1) / kHalo;
+            const int gi = side ? i0 + kTile : i0 - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
+            const bool in = gi >= 0 && gi < g.nx && gj >= 0 && gk >= 0 && gj < g.ny && gk < g.nz;
+            const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
+            const int h = (lk * kHalo + lj) * kHalo + (side ? kHalo - 1 : 0);
+            sx[h] = in ? x[c] : 0.f;
+            if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
+        }
+        for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
+            const int q = r & 3, lj = (r >> 2) % kTile, lk = (r >> 2) / kTile;
+            const float4 v = *reinterpret_cast<const float4 *>(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q);
+            float *dst = sb + (lk * kTile + lj) * kTile + 4 * q;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+        }
+    } else {  // ragged tile at the end of a grid whose extent is not a multiple of 16
+        for (int h = threadIdx.x; h < kHalo3; h += blockDim.x) {
+            const int li = h % kHalo, lj = (h / kHalo) % kHalo, lk = h / (kHalo * kHalo);
+            const int gi = i0 + li - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
+            const bool in = gi >= 0 && gj >= 0 && gk >= 0 && gi < g.nx && gj < g.ny && gk < g.nz;
+            const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
+            sx[h] = in ? x[c] : 0.f;
+            if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
+        }
+        for (int h = threadIdx.x; h < kTile3; h += blockDim.x) {
+            const int li = h % kTile, lj = (h / kTile) % kTile, lk = h / (kTile * kTile);
+            const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+            const bool in = gi < g.nx && gj < g.ny && gk < g.nz;
+            sb[h] = in ? b[(size_t(gk) * g.ny + gj) * g.nx + gi] : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                         const int32_t *__restrict__ tiles, int forward)
+{
+    __shared__ float sx[kHalo3];
+    __shared__ float sb[kTile3];
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
     const int tile = tiles[blockIdx.x];
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-
-    for (int h = threadIdx.x; h < kHalo * kHalo * kHalo; h += blockDim.x) {
-        const int li = h % kHalo, lj = (h / kHalo) % kHalo, lk = h / (kHalo * kHalo);
-        const int gi = i0 + li - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
-        const bool in = gi >= 0 && gj >= 0 && gk >= 0 && gi < g.nx && gj < g.ny && gk < g.nz;
-        const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
-        sx[h] = in ? x[c] : 0.f;
-        sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
-    }
-    for (int h = threadIdx.x; h < kTile * kTile * kTile; h += blockDim.x) {
-        const int li = h % kTile, lj = (h / kTile) % kTile, lk = h / (kTile * kTile);
-        const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
-        const bool in = gi < g.nx && gj < g.ny && gk < g.nz;
-        sb[h] = in ? b[(size_t(gk) * g.ny + gj) * g.nx + gi] : 0.f;
-    }
+    gsLoadTile<false>(g, x, b, i0, j0, k0, sx, sb, nullptr);
     __syncthreads();
-
     const int li = threadIdx.x % kTile, lj = threadIdx.x / kTile;  // this thread's (i, j) column
-    constexpr int kPlanes = 3 * (kTile - 1) + 1;
-    const bool weighted = g.wx != nullptr;
     for (int step = 0; step < kPlanes; ++step) {
         const int s = forward ? step : kPlanes - 1 - step;
         const int lk = s - li - lj;
         if (lk >= 0 && lk < kTile) {
-            const int h = ((lk + 1) * kHalo + (lj + 1)) * kHalo + (li + 1);
+            const int h = haloIdx(li, lj, lk);
+            const float xc = sx[h];
+            const float lap = 6.f * xc - (sx[h - 1] + sx[h + 1] + sx[h - kHalo] + sx[h + kHalo] + sx[h - kHalo * kHalo] +
+                                          sx[h + kHalo * kHalo]);
+            sx[h] = xc + (sb[(lk * kTile + lj) * kTile + li] - lap) / 6.f;  // undamped, Ops.h:493
+        }
+        __syncthreads();
+    }
+    for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
+        const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
+        const float *src = sx + haloIdx(4 * q, cj, ck);
+        *reinterpret_cast<float4 *>(x + (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q) =
+            make_float4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                          const int32_t *__restrict__ tiles,
+                                                          const int32_t *__restrict__ tileBndStart, int forward)
+{
+    __shared__ float sx[kHalo3];
+    __shared__ float sb[kTile3];
+    __shared__ unsigned char sl[kHalo3];
+    __shared__ float srow[7 * kRowPool];
+    __shared__ unsigned short rowMask[kTile * kTile];   // bit i set: cell (i, j, k) of x-row (j,k) is BOUNDARY
+    __shared__ unsigned short rowStart[kTile * kTile];  // BOUNDARY cells of the tile before that x-row
+    __shared__ int scanTmp[4];
+
+    const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
+    const int tile = tiles[blockIdx.x];
+    const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
+    const int bndBase = tileBndStart[tile], bndCount = tileBndStart[tile + 1] - bndBase;
+    const size_t nb = size_t(g.nbnd);
+    gsLoadTile<true>(g, x, b, i0, j0, k0, sx, sb, sl);
+    for (int r = threadIdx.x; r < 7 * min(bndCount, kRowPool); r += blockDim.x) {
+        const int q = r / min(bndCount, kRowPool), t = r % min(bndCount, kRowPool);
+        srow[q * kRowPool + t] = g.rows[q * nb + bndBase + t];
+    }
+    __syncthreads();
+    {  // per x-row BOUNDARY mask and exclusive prefix over the 256 rows in (k, j) order = list order
+        const int rj = threadIdx.x % kTile, rk = threadIdx.x / kTile;
+        unsigned m = 0;
+        for (int i = 0; i < kTile; ++i) m |= (sl[haloIdx(i, rj, rk)] == kCodeGeneral) ? (1u << i) : 0u;
+        rowMask[threadIdx.x] = (unsigned short)m;
+        int cnt = __popc(m), incl = cnt;
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == kWave - 1) scanTmp[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += scanTmp[w];
+        rowStart[threadIdx.x] = (unsigned short)(base + incl - cnt);
+    }
+    __syncthreads();
+
+    const int li = threadIdx.x % kTile, lj = threadIdx.x / kTile;
+    for (int step = 0; step < kPlanes; ++step) {
+        const int s = forward ? step : kPlanes - 1 - step;
+        const int lk = s - li - lj;
+        if (lk >= 0 && lk < kTile) {
+            const int h = haloIdx(li, lj, lk);
             const unsigned l = sl[h];
             if (activeLabel(l)) {
                 const float xc = sx[h];
                 const float bc = sb[(lk * kTile + lj) * kTile + li];
+                const float xn[6] = {sx[h - 1], sx[h + 1], sx[h - kHalo], sx[h + kHalo], sx[h - kHalo * kHalo], sx[h + kHalo * kHalo]};
                 float lap, diag;
-                if (l == MGPS_INTERIOR_CELL) {
-                    lap = 6.f * xc - (sx[h - 1] + sx[h + 1] + sx[h - kHalo] + sx[h + kHalo] + sx[h - kHalo * kHalo] +
-                                      sx[h + kHalo * kHalo]);
-                    diag = 6.f;
+                if (simpleCell(l)) {
+                    diag = simpleDiag(l);
+                    lap = diag * xc - (xn[0] + xn[1] + xn[2] + xn[3] + xn[4] + xn[5]);
                 } else {
-                    const int hn[6] = {h - 1, h + 1, h - kHalo, h + kHalo, h - kHalo * kHalo, h + kHalo * kHalo};
-                    float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                    if (weighted) {
-                        const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
-                        const size_t c = (size_t(gk) * g.ny + gj) * g.nx + gi;
-                        const size_t fx = (size_t(gk) * g.ny + gj) * (g.nx + 1) + gi;
-                        const size_t fy = (size_t(gk) * (g.ny + 1) + gj) * g.nx + gi;
-                        w[0] = g.wx[fx];
-                        w[1] = g.wx[fx + 1];
-                        w[2] = g.wy[fy];
-                        w[3] = g.wy[fy + g.nx];
-                        w[4] = g.wz[c];
-                        w[5] = g.wz[c + sz];
-                    }
-                    lap = 0.f;
-                    diag = 0.f;
+                    const int row = lk * kTile + lj;
+                    const int t = int(rowStart[row]) + __popc(unsigned(rowMask[row]) & ((1u << li) - 1u));
+                    float w[7];
+                    if (t < kRowPool) {
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        const unsigned nl = sl[hn[q]];
-                        if (nl == MGPS_INTERIOR_CELL) {
-                            lap -= sx[hn[q]];
-                            diag += 1.f;
-                        } else if (nl == MGPS_BOUNDARY_CELL) {
-                            lap -= w[q] * sx[hn[q]];
-                            diag += w[q];
-                        } else if (nl == MGPS_DIRICHLET_CELL)
-                            diag += w[q];
+                        for (int q = 0; q < 7; ++q) w[q] = srow[q * kRowPool + t];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) w[q] = g.rows[q * nb + bndBase + t];
                     }
-                    lap += diag * xc;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc -= w[q] * xn[q];
+                    diag = w[6];
+                    lap = acc + diag * xc;
                 }
                 sx[h] = xc + (bc - lap) / diag;  // undamped, Ops.h:493
             }
         }
         __syncthreads();
     }
-    for (int h = threadIdx.x; h < kTile * kTile * kTile; h += blockDim.x) {
+    for (int h = threadIdx.x; h < kTile3; h += blockDim.x) {
         const int ci = h % kTile, cj = (h / kTile) % kTile, ck = h / (kTile * kTile);
         const int gi = i0 + ci, gj = j0 + cj, gk = k0 + ck;
         if (gi < g.nx && gj < g.ny && gk < g.nz) {
-            const int hh = ((ck + 1) * kHalo + (cj + 1)) * kHalo + (ci + 1);
+            const int hh = haloIdx(ci, cj, ck);
             if (activeLabel(sl[hh])) x[(size_t(gk) * g.ny + gj) * g.nx + gi] = sx[hh];
         }
     }
-    (void)sy;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,6 +465,56 @@ __global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float
     const float v01 = lerpRef(p[sz], p[sz + 1], fx), v11 = lerpRef(p[sz + sy], p[sz + sy + 1], fx);
     const float t = lerpRef(lerpRef(v00, v10, fy), lerpRef(v01, v11, fy), fz);
     fine[c] += 4.f * t;  // Ops.h:964
+}
+
+// Same operator, one thread per 4 consecutive fine cells (16-byte read-modify-write of the fine
+// grid).  Fine cells 4m..4m+3 interpolate from coarse x-indices 2m-1..2m+2:
+//   4m: (2m-1, 2m; f=3/4)   4m+1: (2m, 2m+1; 1/4)   4m+2: (2m, 2m+1; 3/4)   4m+3: (2m+1, 2m+2; 1/4)
+// Requires fine nx % 4 == 0.
+__global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__restrict__ fine,
+                                                            const float *__restrict__ coarse, unsigned nblocks)
+{
+    const unsigned nq = unsigned(fg.nx) >> 2;
+    const size_t total = size_t(nq) * fg.ny * fg.nz;
+    const size_t t = size_t(remapBlock(blockIdx.x, nblocks)) * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned m = unsigned(t % nq);
+    const size_t row = t / nq;
+    const int j = int(row % fg.ny), k = int(row / fg.ny);
+    const size_t c = row * size_t(fg.nx) + (size_t(m) << 2);
+    const uchar4 l = *reinterpret_cast<const uchar4 *>(fg.lab + c);
+    const bool a0 = activeLabel(l.x), a1 = activeLabel(l.y), a2 = activeLabel(l.z), a3 = activeLabel(l.w);
+    if (!(a0 | a1 | a2 | a3)) return;
+    const int cnx = fg.nx >> 1, cny = fg.ny >> 1, cnz = fg.nz >> 1;
+    // clamped coarse indices: the clamps only bite for cells on the EXTERIOR shell, whose values are dropped
+    const int x0 = max(2 * int(m) - 1, 0), x1 = 2 * int(m), x2 = 2 * int(m) + 1, x3 = min(2 * int(m) + 2, cnx - 1);
+    const int bj = max((j - 1) >> 1, 0), bk = max((k - 1) >> 1, 0);
+    const int bj1 = min(bj + 1, cny - 1), bk1 = min(bk + 1, cnz - 1);
+    const float fy = (j & 1) ? 0.25f : 0.75f, fz = (k & 1) ? 0.25f : 0.75f;
+    float v[2][2][4];  // [z][y][fine x]
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            const float *r = coarse + (size_t(zz ? bk1 : bk) * cny + (yy ? bj1 : bj)) * cnx;
+            const float c0 = r[x0], c3 = r[x3];
+            const float2 c12 = *reinterpret_cast<const float2 *>(r + x1);
+            (void)x2;
+            v[zz][yy][0] = lerpRef(c0, c12.x, 0.75f);
+            v[zz][yy][1] = lerpRef(c12.x, c12.y, 0.25f);
+            v[zz][yy][2] = lerpRef(c12.x, c12.y, 0.75f);
+            v[zz][yy][3] = lerpRef(c12.y, c3, 0.25f);
+        }
+    float4 f = *reinterpret_cast<const float4 *>(fine + c);
+    float add[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        add[e] = 4.f * lerpRef(lerpRef(v[0][0][e], v[0][1][e], fy), lerpRef(v[1][0][e], v[1][1][e], fy), fz);
+    if (a0) f.x += add[0];
+    if (a1) f.y += add[1];
+    if (a2) f.z += add[2];
+    if (a3) f.w += add[3];
+    *reinterpret_cast<float4 *>(fine + c) = f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,7 +591,7 @@ __global__ void diagInverseKernel(GridP g, float *__restrict__ dinv)
     const unsigned l = g.lab[c];
     float v = 0.f;
     if (l == MGPS_INTERIOR_CELL) v = 1.f / 6.f;
-    else if (l == MGPS_BOUNDARY_CELL) {
+    else if (l >= kCodeGeneral) {
         const int i = int(c % g.nx), j = int((c / g.nx) % g.ny), k = int(c / (size_t(g.nx) * g.ny));
         float d = 6.f;
         if (g.wx) {
@@ -551,6 +695,14 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
             default: stencilScalarKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega); break;
         }
     }
+    if (g.nbnd > 0) {
+        const unsigned nb = blocksFor(size_t(g.nbnd), 256);
+        switch (op) {
+            case OP_JACOBI: boundaryOpKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+            case OP_RESIDUAL: boundaryOpKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+            default: boundaryOpKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
+        }
+    }
     return int(hipGetLastError());
 }
 
@@ -560,16 +712,18 @@ int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, con
     if (nband <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned nb = blocksFor(size_t(nband), 256);
-    bandComputeKernel<<<nb, 256, 0, s>>>(g, x, b, band, nband, bandTmp, omega);
-    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp);
+    bandComputeKernel<<<nb, 256, 0, s>>>(g, x, b, band, nband, bandTmp, omega, nb);
+    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());
 }
 
-int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *tiles, int ntiles,
-                  int forward)
+int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward)
 {
-    if (ntiles <= 0) return 0;
-    tiledGSKernel<<<unsigned(ntiles), 256, 0, static_cast<hipStream_t>(stream)>>>(g, x, b, tiles, forward);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // same colour => no two tiles of either launch share a face: the two launches are independent
+    if (nmixed > 0) tiledGSMixedKernel<<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward);
+    if (npure > 0) tiledGSPureKernel<<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward);
     return int(hipGetLastError());
 }
 
@@ -583,7 +737,11 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse)
 {
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
-    prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
+    if ((fine.nx & 3) == 0 && fine.nx >= 8) {
+        const unsigned nb = blocksFor(n >> 2, 256);
+        prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
+    } else
+        prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
     return int(hipGetLastError());
 }
 

@@ -24,11 +24,15 @@ struct DevLevel {
     uint8_t *lab = nullptr;
     float *x = nullptr, *b = nullptr;  // coarse levels only; level 0 works on the caller's grids
     float *r = nullptr, *tmp = nullptr;
-    int32_t *band = nullptr;
+    int32_t *band = nullptr;  // device-ordered band list: BOUNDARY cells first
     int nband = 0;
     float *bandTmp = nullptr;
-    int32_t *tilesOdd = nullptr, *tilesEven = nullptr;
-    int nOdd = 0, nEven = 0;
+    float *rows = nullptr;    // 7 x numBoundary operator rows of the general BOUNDARY cells
+    uint8_t *bandDiag = nullptr;
+    // Gauss-Seidel tile lists per colour [0] = even, [1] = odd tiles
+    int32_t *pure[2] = {nullptr, nullptr}, *mixed[2] = {nullptr, nullptr};
+    int npure[2] = {0, 0}, nmixed[2] = {0, 0};
+    int32_t *tileBndStart = nullptr;
 };
 
 }  // namespace
@@ -117,8 +121,13 @@ void freeAll(mgps_solver *h)
         hipFree(L.tmp);
         hipFree(L.band);
         hipFree(L.bandTmp);
-        hipFree(L.tilesOdd);
-        hipFree(L.tilesEven);
+        hipFree(L.rows);
+        hipFree(L.bandDiag);
+        for (int c = 0; c < 2; ++c) {
+            hipFree(L.pure[c]);
+            hipFree(L.mixed[c]);
+        }
+        hipFree(L.tileBndStart);
     }
     for (int a = 0; a < 3; ++a) hipFree(h->w[a]);
     hipFree(h->cinv);
@@ -154,6 +163,14 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b)
     return MGPS_OK;
 }
 
+int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward)
+{
+    DevLevel &L = h->lv[l];
+    MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
+                                 L.tileBndStart, forward));
+    return MGPS_OK;
+}
+
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
 int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down)
@@ -173,11 +190,11 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     }
     if (h->useGS) {
         if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
-            MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, cur, b, L.tilesOdd, L.nOdd, 1));
-            MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, cur, b, L.tilesEven, L.nEven, 1));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1));
         } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
-            MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, cur, b, L.tilesEven, L.nEven, 0));
-            MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, cur, b, L.tilesOdd, L.nOdd, 0));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0));
         }
     } else {
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight));
@@ -409,18 +426,26 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
             return bail(failH(h, MGPS_ERR_HIP, "mgps_create: weight upload failed"));
     }
     h->lv.resize(hier->levels);
+    buildBoundaryRows(hier->lv[0], wx_host, wy_host, wz_host);  // fine level: the real face weights
     for (int l = 0; l < hier->levels; ++l) {
         const HostLevel &HL = hier->lv[l];
         DevLevel &L = h->lv[l];
         L.d = HL.d;
-        CREATE_TRY(devUpload(h, &L.lab, HL.labels));
-        CREATE_TRY(devUpload(h, &L.band, HL.band));
-        L.nband = int(HL.band.size());
+        CREATE_TRY(devUpload(h, &L.lab, HL.codes));
+        CREATE_TRY(devUpload(h, &L.bandDiag, HL.bandDiag));
+        CREATE_TRY(devUpload(h, &L.band, HL.bandDev));
+        CREATE_TRY(devUpload(h, &L.rows, HL.rows));
+        L.nband = int(HL.bandDev.size());
         CREATE_TRY(devAlloc(h, &L.bandTmp, HL.band.size(), false));
-        CREATE_TRY(devUpload(h, &L.tilesOdd, HL.tilesOdd));
-        CREATE_TRY(devUpload(h, &L.tilesEven, HL.tilesEven));
-        L.nOdd = int(HL.tilesOdd.size());
-        L.nEven = int(HL.tilesEven.size());
+        CREATE_TRY(devUpload(h, &L.pure[0], HL.pureEven));
+        CREATE_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
+        CREATE_TRY(devUpload(h, &L.mixed[0], HL.mixedEven));
+        CREATE_TRY(devUpload(h, &L.mixed[1], HL.mixedOdd));
+        L.npure[0] = int(HL.pureEven.size());
+        L.npure[1] = int(HL.pureOdd.size());
+        L.nmixed[0] = int(HL.mixedEven.size());
+        L.nmixed[1] = int(HL.mixedOdd.size());
+        CREATE_TRY(devUpload(h, &L.tileBndStart, HL.tileBndStart));
         if (l > 0) {
             CREATE_TRY(devAlloc(h, &L.x, L.d.cells(), true));
             CREATE_TRY(devAlloc(h, &L.b, L.d.cells(), true));
@@ -428,7 +453,7 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
         CREATE_TRY(devAlloc(h, &L.r, L.d.cells(), true));
         CREATE_TRY(devAlloc(h, &L.tmp, L.d.cells(), true));
         L.g = GridP{L.d.nx, L.d.ny, L.d.nz, L.lab, l == 0 ? h->w[0] : nullptr, l == 0 ? h->w[1] : nullptr,
-                    l == 0 ? h->w[2] : nullptr};
+                    l == 0 ? h->w[2] : nullptr, L.band, L.rows, int(HL.numBoundary), L.bandDiag};
     }
     (void)d0;
     hier->buildDenseInverse();
@@ -530,10 +555,7 @@ int mgps_tiled_gs_smooth(mgps_solver *h, int level, float *x_dev, const float *b
 {
     MGPS_TRY(checkLevel(h, level, "mgps_tiled_gs_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_tiled_gs_smooth: NULL grid");
-    DevLevel &L = h->lv[level];
-    MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x_dev, b_dev, smooth_odd_tiles ? L.tilesOdd : L.tilesEven,
-                                 smooth_odd_tiles ? L.nOdd : L.nEven, smooth_forward != 0));
-    return MGPS_OK;
+    return gsHalfSweep(h, level, x_dev, b_dev, smooth_odd_tiles ? 1 : 0, smooth_forward != 0);
 }
 
 int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev)

@@ -905,7 +905,10 @@ mgo_solver *mgo_solver_create(const int32_t *labels, const real *wx, const real 
         s->band_n[l] = mgo_build_boundary_cells(s->lab[l], d.nx, d.ny, d.nz, s->band_width, &s->band[l]);
     }
     s->scratch = (real *)malloc(n0 * sizeof(real));
-    if (build_coarse_direct(s) != 0) {
+    /* With one level applyVCycle returns before the direct solve (MG.cpp:516-517); the reference still
+     * factorises the fine matrix there (sparse Cholesky), which nothing ever uses -- skipped, a banded
+     * factor of a whole fine grid would take hours. */
+    if (s->levels > 1 && build_coarse_direct(s) != 0) {
         mgo_solver_destroy(s);
         return NULL;
     }

@@ -37,6 +37,26 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    shows every host core but grants a share; spinning one OpenMP thread per visible core there is
+    slower than running serially)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 class Oracle:
     def __init__(self, f32=False):
         build()
@@ -45,6 +65,8 @@ class Oracle:
         self.creal = C.c_float if f32 else C.c_double
         L = self.lib
         assert L.mgo_real_bytes() == np.dtype(self.real).itemsize
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.mgo_set_threads(effective_cpus())
         for name in ("mgo_dot", "mgo_squared_l2", "mgo_l2", "mgo_inf_norm", "mgo_ghost_fluid_weight"):
             getattr(L, name).restype = C.c_double
         L.mgo_build_boundary_cells.restype = C.c_int64
@@ -60,11 +82,6 @@ class Oracle:
     @staticmethod
     def lab(a):
         return np.ascontiguousarray(a, dtype=np.int32)
-
-    def _w(self, w):
-        if w is None:
-            return (None, None, None)
-        return tuple(_ptr(self.arr(a)) for a in w), w
 
     def set_threads(self, n):
         self.lib.mgo_set_threads(int(n))
