@@ -927,6 +927,20 @@ void mgo_solver_level_dims(const mgo_solver *s, int level, int *out)
 }
 int mgo_solver_coarse_unknowns(const mgo_solver *s) { return s->cn; }
 
+/* the direct solve of MG.cpp:669-692 alone, on grids of the coarsest level (test hook) */
+void mgo_solver_coarse_solve(const mgo_solver *s, real *x, const real *b)
+{
+    const dims_t d = s->dims[s->levels - 1];
+    const size_t n = (size_t)d.nx * d.ny * d.nz;
+    double *v = (double *)calloc((size_t)(s->cn > 0 ? s->cn : 1), sizeof(double));
+    for (size_t c = 0; c < n; ++c)
+        if (s->cindex[c] >= 0) v[s->cindex[c]] = (double)b[c];
+    coarse_solve(s, v);
+    for (size_t c = 0; c < n; ++c)
+        if (s->cindex[c] >= 0) x[c] = (real)v[s->cindex[c]];
+    free(v);
+}
+
 static void smooth_stroke(mgo_solver *s, int l, real *x, const real *b, int down)
 {
     const dims_t d = s->dims[l];

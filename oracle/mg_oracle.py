@@ -272,6 +272,13 @@ class OracleSolver:
     def coarse_unknowns(self):
         return self.o.lib.mgo_solver_coarse_unknowns(self.h)
 
+    def coarse_solve(self, b):
+        nx, ny, nz = self.level_dims(self.levels - 1)
+        b = self.o.arr(b)
+        x = np.zeros((nz, ny, nx), dtype=self.o.real)
+        self.o.lib.mgo_solver_coarse_solve(self.h, _ptr(x), _ptr(b))
+        return x
+
     def apply_vcycle(self, x, b, use_initial_guess=False):
         assert x.dtype == self.o.real and b.dtype == self.o.real and x.flags.c_contiguous
         self.o.lib.mgo_solver_apply_vcycle(self.h, _ptr(x), _ptr(b), int(bool(use_initial_guess)))

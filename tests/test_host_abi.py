@@ -1,0 +1,185 @@
+"""CPU tests of the C-ABI library (libmgps.so): it loads without a GPU, exports every symbol that
+include/mgps.h declares, and its host-side logic (domain expansion, structural checks, multigrid
+hierarchy, coarsest-level direct solve, error conventions) agrees with the oracle.  No device
+compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+import geometricmultigridpressuresolver_amd as G
+from conftest import ROOT, make_domain
+from geometricmultigridpressuresolver_amd import domains as D
+from geometricmultigridpressuresolver_amd._lib import Options, lib
+from test_oracle_properties import assemble
+
+KINDS = [("simple", 16), ("complex", 24), ("solid", 24)]
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mgps.h")).read()
+    names = sorted(set(re.findall(r"\b(mgps_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib(), n)]
+    assert not missing, missing
+
+
+def test_options_struct_matches_header():
+    o = G.default_options()
+    assert o.struct_size == C.sizeof(Options)
+    assert (o.band_width, o.band_iterations) == (3, 3)  # MG.cpp:141-142
+    assert o.jacobi_weight == pytest.approx(2.0 / 3.0)  # Ops.h:291
+    assert o.device == -1 and o.max_coarse_unknowns == 8192
+    assert lib().mgps_status_string(0) == b"ok" and lib().mgps_status_string(2) == b"no HIP device"
+
+
+def test_expanded_layout_rule(oracle):
+    for shape in [(128, 128, 128), (64, 64, 64), (400, 600, 600), (30, 100, 50), (17, 33, 65)]:
+        bz, by, bx = shape
+        (ez, ey, ex), off, lev = G.expanded_layout(shape)
+        dims, off2, lev2 = oracle.expanded_layout(bx, by, bz)
+        assert (ex, ey, ez) == dims and off == off2 and lev == lev2
+    # caller-chosen level count and tight (non power-of-two) extents
+    (ez, ey, ex), off, lev = G.expanded_layout((480, 480, 480), levels=5, power_of_two=False)
+    assert (ez, ey, ex, off, lev) == (512, 512, 512, 16, 5)
+    (ez, ey, ex), off, lev = G.expanded_layout((400, 600, 600), levels=0, power_of_two=False)
+    assert lev == 8 and off == 128 and (ez, ey, ex) == (768, 1024, 1024)
+
+
+@pytest.mark.parametrize("kind,g", KINDS)
+def test_expanded_domain_matches_oracle(kind, g, oracle):
+    if kind == "simple":
+        bl, bw, dx = D.build_simple_domain(g, 1, dtype=np.float32)
+    else:
+        bl, bw, dx = D.build_complex_domain(g, use_solid=(kind == "solid"), dtype=np.float32)
+    lab, w, off, lev = G.build_expanded_domain(bl, bw)
+    olab, ow, ooff, olev = oracle.build_expanded_domain(bl.astype(np.int32), [a.astype(np.float64) for a in bw])
+    assert (off, lev) == (ooff, olev)
+    assert (lab == olab).all()
+    for a in range(3):
+        assert (w[a] == ow[a].astype(np.float32)).all()
+    plab, pw, poff, plev = D.expand_domain(bl, bw)  # the numpy restatement used by the harness
+    assert (plab == lab).all() and poff == off and plev == lev
+    assert G.unit_test_boundary_cells(lab, w) and G.unit_test_exterior_cells(lab)
+
+
+@pytest.mark.parametrize("kind,g", KINDS)
+def test_structural_checks_reject_corruption(kind, g, oracle):
+    lab, w, off, lev, dx = make_domain(kind, g)
+    bad = lab.copy()
+    bad[0, 0, 0] = D.DIRICHLET
+    assert not G.unit_test_exterior_cells(bad) and not oracle.unit_test_exterior(bad.astype(np.int32))
+    k, j, i = [a[0] for a in np.nonzero(lab == D.BOUNDARY)]
+    bad = lab.copy()
+    bad[k, j, i] = D.INTERIOR  # an INTERIOR cell next to a non-active one
+    assert not G.unit_test_boundary_cells(bad, w)
+    assert not oracle.unit_test_boundary(bad.astype(np.int32), [a.astype(np.float64) for a in w])
+    H = G.Hierarchy(lab, lev)
+    c1 = H.level_labels(1)
+    assert G.unit_test_coarsening(c1, lab)
+    k, j, i = [a[0] for a in np.nonzero(c1 == D.DIRICHLET)]
+    c1[k, j, i] = D.EXTERIOR
+    assert not G.unit_test_coarsening(c1, lab)
+
+
+@pytest.mark.parametrize("kind,g", KINDS + [("solid", 40)])
+def test_hierarchy_matches_oracle(kind, g, oracle):
+    lab, w, off, lev, dx = make_domain(kind, g)
+    H = G.Hierarchy(lab, lev)
+    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, False)
+    assert H.levels == s.levels and H.coarse_unknowns == s.coarse_unknowns
+    for l in range(H.levels):
+        nx, ny, nz = s.level_dims(l)
+        assert H.level_shape(l) == (nz, ny, nx)
+        assert (H.level_labels(l) == s.level_labels(l)).all()
+        assert (H.band_cells(l) == s.band(l)).all()  # same cells in the reference's (tile,k,j,i) order
+
+
+def test_hierarchy_non_cubic(oracle):
+    bl = np.full((20, 12, 28), D.INTERIOR, dtype=np.uint8)
+    bl[-4:] = D.DIRICHLET
+    bw = [np.ones(D.face_shape(20, 12, 28, a), dtype=np.float32) for a in range(3)]
+    for a in range(3):
+        sl = [slice(None)] * 3
+        sl[2 - a] = 0
+        bw[a][tuple(sl)] = 0
+        sl[2 - a] = -1
+        bw[a][tuple(sl)] = 0
+    bw[2][-4:] = 0  # air/air faces closed (z axis faces inside the Dirichlet slab)
+    lab, w, off, lev = G.build_expanded_domain(bl, bw)
+    assert lab.shape == (32, 32, 64) and lev == 3
+    H = G.Hierarchy(lab, lev)
+    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, True)
+    for l in range(H.levels):
+        assert (H.level_labels(l) == s.level_labels(l)).all() and (H.band_cells(l) == s.band(l)).all()
+
+
+def test_level_cap_quirk(oracle):
+    lab, w, off, lev, dx = make_domain("simple", 16)
+    H = G.Hierarchy(lab, 5)
+    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], 5, False)
+    assert H.levels == s.levels < 5  # MG.cpp:243-248
+
+
+@pytest.mark.parametrize("kind,g", KINDS)
+def test_coarse_solve_matches_scipy_and_oracle(kind, g, oracle):
+    lab, w, off, lev, dx = make_domain(kind, g)
+    H = G.Hierarchy(lab, lev)
+    cl = H.level_labels(H.levels - 1)
+    A, idx, act = assemble(cl.astype(np.int32), None)
+    rng = np.random.default_rng(11)
+    b = np.zeros(cl.shape, dtype=np.float32)
+    b[act] = rng.random(A.shape[0])
+    x = H.coarse_solve(b)
+    ref = spla.spsolve(A.tocsc(), b[act].astype(np.float64))
+    assert np.abs(x[act] - ref).max() < 2e-6 * np.abs(ref).max()  # fp32 in / out
+    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, False)
+    assert np.abs(x - s.coarse_solve(b.astype(np.float64))).max() < 2e-6 * np.abs(ref).max()
+
+
+def test_error_conventions():
+    lab, w, off, lev, dx = make_domain("simple", 16)
+    L = lib()
+    h = C.c_void_p()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    nz, ny, nx = lab.shape
+    # odd extent
+    assert L.mgps_hierarchy_create(C.byref(h), nx - 1, ny, nz, p(lab), 2, None) == 1
+    assert b"even" in L.mgps_last_error(None)
+    # extents not divisible by 2^(levels-1)
+    assert L.mgps_hierarchy_create(C.byref(h), nx, ny, nz, p(lab), 7, None) == 1
+    # options struct of the wrong size
+    o = G.default_options()
+    o.struct_size = 4
+    assert L.mgps_hierarchy_create(C.byref(h), nx, ny, nz, p(lab), 2, C.byref(o)) == 1
+    # no EXTERIOR shell
+    bad = lab.copy()
+    bad[0] = D.DIRICHLET
+    assert L.mgps_hierarchy_create(C.byref(h), nx, ny, nz, p(bad), 2, None) == 5
+    # nothing to solve
+    empty = np.full_like(lab, D.EXTERIOR)
+    assert L.mgps_hierarchy_create(C.byref(h), nx, ny, nz, p(empty), 2, None) == 5
+    # coarsest level too large for the direct solver
+    o = G.default_options()
+    o.max_coarse_unknowns = 4
+    assert L.mgps_hierarchy_create(C.byref(h), nx, ny, nz, p(lab), 2, C.byref(o)) == 6
+    assert not h.value
+    # NULL handles never crash
+    assert L.mgps_apply_vcycle(None, None, None, 0) == 1
+    assert L.mgps_levels(None) == 0
+    L.mgps_destroy(None)
+
+
+def test_create_without_device_fails_loudly():
+    """The product has no CPU path: on a box without a HIP device the constructor reports it."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    lab, w, off, lev, dx = make_domain("simple", 16)
+    with pytest.raises(G.MgpsError) as e:
+        G.GeometricMultigridPoissonSolver(lab, w, lev, True)
+    assert e.value.status == 2 and "no CPU path" in str(e.value)
