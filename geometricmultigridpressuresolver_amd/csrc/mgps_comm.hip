@@ -1,0 +1,245 @@
+// RCCL transport of the Z-slab multi-GPU run (include/mgps.h, struct mgps_comm).  The reference is
+// single-process shared memory, so nothing here has a reference counterpart: the ghost-plane
+// exchange is one ncclSend/ncclRecv pair per Z-neighbour inside a single group call, enqueued on
+// the solver's stream, so it is ordered with the kernels around it without any host
+// synchronisation; over xGMI each GPU talks to at most two peers, each on its own direct link.
+//
+// librccl is opened with dlopen at communicator creation: a single-GPU user never loads it, and the
+// library links (and its CPU tests run) on machines without RCCL.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "mgps_internal.h"
+
+using namespace mgps;
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi gApi;
+std::once_flag gApiOnce;
+std::string gApiError;
+
+template <class F>
+bool sym(void *lib, const char *name, F &fn)
+{
+    fn = reinterpret_cast<F>(dlsym(lib, name));
+    if (!fn) gApiError = std::string("librccl: missing symbol ") + name;
+    return fn != nullptr;
+}
+
+bool loadRccl()
+{
+    std::call_once(gApiOnce, [] {
+        // a process that already holds an RCCL (torch bundles one with the same SONAME) gets that copy
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            gApi.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (gApi.lib) break;
+        }
+        if (!gApi.lib) {
+            gApiError = std::string("cannot open librccl: ") + dlerror();
+            return;
+        }
+        bool ok = sym(gApi.lib, "ncclGetUniqueId", gApi.GetUniqueId) && sym(gApi.lib, "ncclCommInitRank", gApi.CommInitRank) &&
+                  sym(gApi.lib, "ncclCommDestroy", gApi.CommDestroy) && sym(gApi.lib, "ncclGroupStart", gApi.GroupStart) &&
+                  sym(gApi.lib, "ncclGroupEnd", gApi.GroupEnd) && sym(gApi.lib, "ncclSend", gApi.Send) &&
+                  sym(gApi.lib, "ncclRecv", gApi.Recv) && sym(gApi.lib, "ncclAllReduce", gApi.AllReduce) &&
+                  sym(gApi.lib, "ncclGetErrorString", gApi.GetErrorString);
+        if (!ok) gApi.lib = nullptr;
+    });
+    return gApi.lib != nullptr;
+}
+
+struct RcclState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, size = 1, device = 0;
+    double *scratchDev = nullptr;  // all-reduce staging
+    double *scratchHost = nullptr;
+    hipStream_t own = nullptr;     // stream of the scalar all-reduces
+};
+
+#define NCCL_TRY(call)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess) {                                                                    \
+            setLastGlobalError(std::string(#call) + ": " + gApi.GetErrorString(r_));                \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+#define HIP_TRY(call)                                                                \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            setLastGlobalError(std::string(#call) + ": " + hipGetErrorString(e_));   \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+int rcclExchange(void *user, const void *sendLo, void *recvLo, const void *sendHi, void *recvHi, size_t bytes,
+                 void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NCCL_TRY(gApi.GroupStart());
+    if (sendLo) {
+        NCCL_TRY(gApi.Send(sendLo, bytes, ncclChar, s->rank - 1, s->comm, st));
+        NCCL_TRY(gApi.Recv(recvLo, bytes, ncclChar, s->rank - 1, s->comm, st));
+    }
+    if (sendHi) {
+        NCCL_TRY(gApi.Send(sendHi, bytes, ncclChar, s->rank + 1, s->comm, st));
+        NCCL_TRY(gApi.Recv(recvHi, bytes, ncclChar, s->rank + 1, s->comm, st));
+    }
+    NCCL_TRY(gApi.GroupEnd());
+    return 0;
+}
+
+int rcclAllreduce(void *user, double *values, int count, int op)
+{
+    auto *s = static_cast<RcclState *>(user);
+    if (count > 64) return 1;
+    std::memcpy(s->scratchHost, values, size_t(count) * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(s->scratchDev, s->scratchHost, size_t(count) * sizeof(double), hipMemcpyHostToDevice, s->own));
+    NCCL_TRY(gApi.AllReduce(s->scratchDev, s->scratchDev, size_t(count), ncclDouble, op == 0 ? ncclSum : ncclMax, s->comm, s->own));
+    HIP_TRY(hipMemcpyAsync(s->scratchHost, s->scratchDev, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, s->own));
+    HIP_TRY(hipStreamSynchronize(s->own));
+    std::memcpy(values, s->scratchHost, size_t(count) * sizeof(double));
+    return 0;
+}
+
+int rcclGather(void *user, const void *send, void *recv, size_t bytes, int root, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->rank == root) HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + size_t(root) * bytes, send, bytes, hipMemcpyDeviceToDevice, st));
+    NCCL_TRY(gApi.GroupStart());
+    if (s->rank == root) {
+        for (int r = 0; r < s->size; ++r)
+            if (r != root) NCCL_TRY(gApi.Recv(static_cast<char *>(recv) + size_t(r) * bytes, bytes, ncclChar, r, s->comm, st));
+    } else
+        NCCL_TRY(gApi.Send(send, bytes, ncclChar, root, s->comm, st));
+    NCCL_TRY(gApi.GroupEnd());
+    return 0;
+}
+
+int rcclScatter(void *user, const void *send, void *recv, size_t bytes, int root, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->rank == root) HIP_TRY(hipMemcpyAsync(recv, static_cast<const char *>(send) + size_t(root) * bytes, bytes, hipMemcpyDeviceToDevice, st));
+    NCCL_TRY(gApi.GroupStart());
+    if (s->rank == root) {
+        for (int r = 0; r < s->size; ++r)
+            if (r != root) NCCL_TRY(gApi.Send(static_cast<const char *>(send) + size_t(r) * bytes, bytes, ncclChar, r, s->comm, st));
+    } else
+        NCCL_TRY(gApi.Recv(recv, bytes, ncclChar, root, s->comm, st));
+    NCCL_TRY(gApi.GroupEnd());
+    return 0;
+}
+
+void rcclDestroy(void *user)
+{
+    auto *s = static_cast<RcclState *>(user);
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->comm) gApi.CommDestroy(s->comm);
+    (void)hipFree(s->scratchDev);
+    if (s->scratchHost) (void)hipHostFree(s->scratchHost);
+    if (s->own) (void)hipStreamDestroy(s->own);
+    delete s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgps_rccl_unique_id(unsigned char out_id[128])
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "mgps_rccl_unique_id ships 128 bytes");
+    if (!out_id) {
+        setLastGlobalError("mgps_rccl_unique_id: NULL");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    if (!loadRccl()) {
+        setLastGlobalError(gApiError);
+        return MGPS_ERR_COMM;
+    }
+    ncclUniqueId id;
+    if (gApi.GetUniqueId(&id) != ncclSuccess) {
+        setLastGlobalError("ncclGetUniqueId failed");
+        return MGPS_ERR_COMM;
+    }
+    std::memcpy(out_id, &id, 128);
+    return MGPS_OK;
+}
+
+int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned char id[128], int device)
+{
+    if (!out || !id || size < 1 || rank < 0 || rank >= size) {
+        setLastGlobalError("mgps_comm_create_rccl: bad arguments");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    std::memset(out, 0, sizeof(*out));
+    if (!loadRccl()) {
+        setLastGlobalError(gApiError);
+        return MGPS_ERR_COMM;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (hipSetDevice(device) != hipSuccess) {
+        setLastGlobalError("mgps_comm_create_rccl: hipSetDevice failed");
+        return MGPS_ERR_NO_DEVICE;
+    }
+    auto *s = new RcclState();
+    s->rank = rank;
+    s->size = size;
+    s->device = device;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, 128);
+    ncclResult_t r = gApi.CommInitRank(&s->comm, size, uid, rank);
+    if (r != ncclSuccess) {
+        setLastGlobalError(std::string("ncclCommInitRank: ") + gApi.GetErrorString(r));
+        delete s;
+        return MGPS_ERR_COMM;
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&s->scratchDev), 64 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&s->scratchHost), 64 * sizeof(double)) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking) != hipSuccess) {
+        setLastGlobalError("mgps_comm_create_rccl: scratch allocation failed");
+        rcclDestroy(s);
+        return MGPS_ERR_ALLOC;
+    }
+    out->struct_size = int(sizeof(mgps_comm));
+    out->rank = rank;
+    out->size = size;
+    out->user = s;
+    out->exchange = rcclExchange;
+    out->allreduce = rcclAllreduce;
+    out->gather = rcclGather;
+    out->scatter = rcclScatter;
+    out->destroy = rcclDestroy;
+    return MGPS_OK;
+}
+
+void mgps_comm_destroy(mgps_comm *comm)
+{
+    if (comm && comm->destroy) comm->destroy(comm->user);
+    if (comm) std::memset(comm, 0, sizeof(*comm));
+}
+
+}  // extern "C"

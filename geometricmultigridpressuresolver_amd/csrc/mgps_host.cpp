@@ -150,38 +150,59 @@ static void buildBand(HostLevel &L, int width)
 }
 
 static void buildTileBoundaryOffsets(HostLevel &L);
+static void buildTileLists(HostLevel &L, int tileZOffset);
 
-// Operator rows of the BOUNDARY cells, evaluated once (Ops.h:208-256): an INTERIOR neighbour
-// contributes -x_n and +1 to the diagonal, a BOUNDARY neighbour -w x_n and +w, a DIRICHLET
-// neighbour only +w to the diagonal, an EXTERIOR neighbour nothing.  w = 1 on coarse levels.
-void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const float *wz)
+// Everything the device needs for the planes [z0, z1) of level G (the whole level when z0 = 0,
+// z1 = nz): local labels, band list, cell codes (with one ghost plane of plain labels on each side),
+// the operator rows of the general BOUNDARY cells and the Gauss-Seidel tile lists.
+//
+// Operator rows (Ops.h:208-256, evaluated once): an INTERIOR neighbour contributes -x_n and +1 to the
+// diagonal, a BOUNDARY neighbour -w x_n and +w, a DIRICHLET neighbour only +w to the diagonal, an
+// EXTERIOR neighbour nothing.  w = 1 on coarse levels (wx == nullptr); otherwise wx / wy / wz are the
+// face weights of the slab (wz with the closing face plane).  z0 must be a multiple of 16 so that the
+// local 16^3 tiles coincide with the global ones.
+void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
+                    HostLevel &L)
 {
-    const Dims d = L.d;
-    const uint8_t *lab = L.labels.data();
-    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    const Dims gd = G.d;
+    Dims d = gd;
+    d.nz = z1 - z0;
+    L = HostLevel();
+    L.d = d;
+    const size_t plane = size_t(gd.nx) * gd.ny;
+    const uint8_t *glab = G.labels.data();
+    L.labels.assign(glab + size_t(z0) * plane, glab + size_t(z1) * plane);
+    const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    L.codes = L.labels;
+    // codes: ghost plane | owned planes | ghost plane
+    L.codes.assign((size_t(d.nz) + 2) * plane, MGPS_EXTERIOR_CELL);
+    std::memcpy(L.codes.data() + plane, L.labels.data(), L.labels.size());
+    if (z0 > 0) std::memcpy(L.codes.data(), glab + size_t(z0 - 1) * plane, plane);
+    if (z1 < gd.nz) std::memcpy(L.codes.data() + (size_t(d.nz) + 1) * plane, glab + size_t(z1) * plane, plane);
+    uint8_t *codes = L.codes.data() + plane;  // owned plane 0
+
     struct Row {
         float w[6], diag;
         bool simple;
     };
-    auto rowOf = [&](size_t c) {
+    auto rowOf = [&](size_t gc) {  // gc: global linear index
         Row r{};
-        const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+        const int i = int(gc % gd.nx), j = int((gc / gd.nx) % gd.ny), k = int(gc / plane) - z0;
         float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
         if (wx) {
             const size_t fx = (size_t(k) * d.ny + j) * (d.nx + 1) + i;
             const size_t fy = (size_t(k) * (d.ny + 1) + j) * d.nx + i;
+            const size_t fz = (size_t(k) * d.ny + j) * d.nx + i;
             w[0] = wx[fx];
             w[1] = wx[fx + 1];
             w[2] = wy[fy];
             w[3] = wy[fy + d.nx];
-            w[4] = wz[c];
-            w[5] = wz[c + sz];
+            w[4] = wz[fz];
+            w[5] = wz[fz + plane];
         }
         r.simple = true;
         for (int q = 0; q < 6; ++q) {
-            const uint8_t nl = lab[c + off[q]];
+            const uint8_t nl = glab[ptrdiff_t(gc) + off[q]];
             if (nl == MGPS_INTERIOR_CELL) {
                 r.w[q] = 1.f;
                 r.diag += 1.f;
@@ -196,15 +217,20 @@ void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const flo
         }
         return r;
     };
-    // split the band: general BOUNDARY cells first, then everything else, each part in reference order
+    // band of the slab in reference order, then split: general BOUNDARY cells first, the rest after
     std::vector<int32_t> general, rest;
     std::vector<uint8_t> restDiag;
     std::vector<Row> generalRows;
-    for (int32_t c : L.band) {
-        if (lab[c] == MGPS_BOUNDARY_CELL) {
-            const Row r = rowOf(size_t(c));
+    const size_t lo = size_t(z0) * plane, hi = size_t(z1) * plane;
+    for (int32_t gcI : G.band) {
+        const size_t gc = size_t(gcI);
+        if (gc < lo || gc >= hi) continue;
+        const int32_t c = int32_t(gc - lo);
+        L.band.push_back(c);
+        if (glab[gc] == MGPS_BOUNDARY_CELL) {
+            const Row r = rowOf(gc);
             if (r.simple) {
-                L.codes[c] = uint8_t(kCodeSimple + int(r.diag));
+                codes[c] = uint8_t(kCodeSimple + int(r.diag));
                 rest.push_back(c);
                 restDiag.push_back(uint8_t(int(r.diag)));
             } else {
@@ -221,6 +247,7 @@ void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const flo
     L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());
     L.bandDiag.assign(size_t(L.numBoundary), 0);
     L.bandDiag.insert(L.bandDiag.end(), restDiag.begin(), restDiag.end());
+    buildTileLists(L, z0 / kTile);
     buildTileBoundaryOffsets(L);
     const size_t nb = size_t(L.numBoundary);
     L.rows.assign(7 * nb, 0.f);
@@ -230,7 +257,8 @@ void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const flo
     }
 }
 
-static void buildTileLists(HostLevel &L)
+// tileZOffset: number of 16-plane tile layers below this slab (the colour uses the global tile index)
+static void buildTileLists(HostLevel &L, int tileZOffset)
 {
     const Dims d = L.d;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
@@ -248,7 +276,7 @@ static void buildTileLists(HostLevel &L)
                 }
         if (!active) continue;
         L.activeCells += active;
-        const bool odd = (ti + tj + tk) & 1;
+        const bool odd = (ti + tj + tk + tileZOffset) & 1;
         (odd ? L.tilesOdd : L.tilesEven).push_back(t);
         if (interior == int64_t(kTile) * kTile * kTile) (odd ? L.pureOdd : L.pureEven).push_back(t);
         else (odd ? L.mixedOdd : L.mixedEven).push_back(t);
@@ -599,6 +627,16 @@ int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, i
 int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
                           const mgps_options *opt)
 {
+    return mgps::hierarchyCreate(out, nx, ny, nz, labels, mg_levels, opt, false, true);
+}
+
+}  // extern "C"
+
+// forceCoarseSolver: factorise the last level even in a one-level hierarchy (the collapsed tail of a
+// slab solver can consist of the direct solve alone).  requireShell: insist on the EXTERIOR shell.
+int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
+                          const mgps_options *opt, bool forceCoarseSolver, bool requireShell)
+{
     if (!out) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: out is NULL");
     *out = nullptr;
     mgps_options o;
@@ -628,7 +666,7 @@ int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     {
         int pass = 0;
         mgps_check_exterior_cells(labels, nx, ny, nz, &pass);  // MG.cpp:235
-        if (!pass) {
+        if (!pass && requireShell) {
             delete H;
             return fail(MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)");
         }
@@ -658,13 +696,11 @@ int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     H->lv.resize(levels);
     for (auto &L : H->lv) {
         buildBand(L, H->bandWidth);  // MG.cpp:279-281
-        buildTileLists(L);
-        buildBoundaryRows(L, nullptr, nullptr, nullptr);  // unit weights; level 0 is redone with the
-                                                          // face weights by mgps_create
+        buildTileLists(L, 0);
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.
-    const int rc = levels > 1 ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
+    const int rc = (levels > 1 || forceCoarseSolver) ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
     if (rc != MGPS_OK) {
         delete H;
         return rc;
@@ -672,6 +708,8 @@ int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     *out = H;
     return MGPS_OK;
 }
+
+extern "C" {
 
 void mgps_hierarchy_destroy(mgps_hierarchy *hier) { delete hier; }
 int mgps_hierarchy_levels(const mgps_hierarchy *hier) { return hier ? hier->levels : 0; }

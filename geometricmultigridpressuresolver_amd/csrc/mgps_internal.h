@@ -48,7 +48,7 @@ struct HostLevel {
     // rows[q*numBoundary + t], q = 0..5 the off-diagonal weight towards -x,+x,-y,+y,-z,+z (0 when that
     // neighbour is not active), q = 6 the diagonal.
     std::vector<float> rows;
-    std::vector<uint8_t> codes;      // device cell codes (see kCodeSimple)
+    std::vector<uint8_t> codes;      // device cell codes (see kCodeSimple): ghost plane, owned planes, ghost plane
     // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
     // kind: "pure" = all 4096 cells INTERIOR (no label or weight look-ups needed), "mixed" = the rest
     std::vector<int32_t> tilesOdd, tilesEven;          // all active tiles of the colour (API / tests)
@@ -57,7 +57,10 @@ struct HostLevel {
     int64_t activeCells = 0;
 };
 
-void buildBoundaryRows(HostLevel &L, const float *wx, const float *wy, const float *wz);
+void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
+                    HostLevel &L);
+int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
+                    const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
 void setLastGlobalError(const std::string &msg);
 const char *lastGlobalError();
 
@@ -72,6 +75,10 @@ struct GridP {
     const float *rows;
     int nbnd;
     const uint8_t *bandDiag;  // per band-list entry: diagonal of the simple / INTERIOR cells
+    // Z-slab of a multi-GPU run: nz counts the planes this rank owns; when a flag is set the plane
+    // just below (k = -1) / above (k = nz) the owned range is a ghost plane held in the same
+    // allocation (every array pointer addresses owned plane 0), filled by the neighbour exchange.
+    int ghostLo, ghostHi;
 };
 
 enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
     // results are discarded, the loads only have to stay in bounds
     const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
-    const size_t czm = k > 0 ? c - sz : c, czp = k < g.nz - 1 ? c + sz : c;
+    const size_t czm = (k > 0 || g.ghostLo) ? c - sz : c, czp = (k < g.nz - 1 || g.ghostHi) ? c + sz : c;
     const float4 ym = *reinterpret_cast<const float4 *>(x + cym);
     const float4 yp = *reinterpret_cast<const float4 *>(x + cyp);
     const float4 zm = *reinterpret_cast<const float4 *>(x + czm);
@@ -237,9 +237,10 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
         for (int r = threadIdx.x; r < kHalo * kHalo * 4; r += blockDim.x) {
             const int q = r & 3, lj = (r >> 2) % kHalo, lk = (r >> 2) / kHalo;
             const int gj = j0 + lj - 1, gk = k0 + lk - 1;
-            const bool in = gj >= 0 && gk >= 0 && gj < g.ny && gk < g.nz;
+            const bool in = gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in) v = *reinterpret_cast<const float4 *>(x + (size_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q);
+            const ptrdiff_t rowOff = (ptrdiff_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q;
+            if (in) v = *reinterpret_cast<const float4 *>(x + rowOff);
             float *dst = sx + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
             dst[0] = v.x;
             dst[1] = v.y;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             dst[3] = v.w;
             if (LABELS) {
                 uchar4 lv = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-                if (in) lv = *reinterpret_cast<const uchar4 *>(g.lab + (size_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q);
+                if (in) lv = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
                 unsigned char *dl = sl + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
                 dl[0] = lv.x;
                 dl[1] = lv.y;
@@ -258,8 +259,8 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
         for (int r = threadIdx.x; r < kHalo * kHalo * 2; r += blockDim.x) {
             const int side = r & 1, lj = (r >> 1) % kHalo, lk = (r >> 1) / kHalo;
             const int gi = side ? i0 + kTile : i0 - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
-            const bool in = gi >= 0 && gi < g.nx && gj >= 0 && gk >= 0 && gj < g.ny && gk < g.nz;
-            const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
+            const bool in = gi >= 0 && gi < g.nx && gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
+            const ptrdiff_t c = in ? (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi : 0;
             const int h = (lk * kHalo + lj) * kHalo + (side ? kHalo - 1 : 0);
             sx[h] = in ? x[c] : 0.f;
             if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
@@ -277,8 +278,8 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
         for (int h = threadIdx.x; h < kHalo3; h += blockDim.x) {
             const int li = h % kHalo, lj = (h / kHalo) % kHalo, lk = h / (kHalo * kHalo);
             const int gi = i0 + li - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
-            const bool in = gi >= 0 && gj >= 0 && gk >= 0 && gi < g.nx && gj < g.ny && gk < g.nz;
-            const size_t c = in ? (size_t(gk) * g.ny + gj) * g.nx + gi : 0;
+            const bool in = gi >= 0 && gj >= 0 && gk >= -g.ghostLo && gi < g.nx && gj < g.ny && gk < g.nz + g.ghostHi;
+            const ptrdiff_t c = in ? (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi : 0;
             sx[h] = in ? x[c] : 0.f;
             if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
         }
@@ -434,7 +435,7 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float
     for (int zo = 0; zo < 4; ++zo)
 #pragma unroll
         for (int yo = 0; yo < 4; ++yo) {
-            const float *row = fine + (size_t(2 * k - 1 + zo) * fny + (2 * j - 1 + yo)) * fnx + (2 * i - 1);
+            const float *row = fine + (ptrdiff_t(2 * k - 1 + zo) * fny + (2 * j - 1 + yo)) * fnx + (2 * i - 1);
             const float wyz = w[yo] * w[zo];
 #pragma unroll
             for (int xo = 0; xo < 4; ++xo) acc += (w[xo] * wyz) * row[xo];
@@ -459,7 +460,7 @@ __global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float
     const int cnx = fg.nx >> 1, cny = fg.ny >> 1;
     const int bi = (i - 1) >> 1, bj = (j - 1) >> 1, bk = (k - 1) >> 1;  // active cells have i,j,k >= 1
     const float fx = (i & 1) ? 0.25f : 0.75f, fy = (j & 1) ? 0.25f : 0.75f, fz = (k & 1) ? 0.25f : 0.75f;
-    const float *p = coarse + (size_t(bk) * cny + bj) * cnx + bi;
+    const float *p = coarse + (ptrdiff_t(bk) * cny + bj) * cnx + bi;  // bk = -1 addresses the lower ghost plane
     const size_t sy = size_t(cnx), sz = size_t(cnx) * cny;
     const float v00 = lerpRef(p[0], p[1], fx), v10 = lerpRef(p[sy], p[sy + 1], fx);
     const float v01 = lerpRef(p[sz], p[sz + 1], fx), v11 = lerpRef(p[sz + sy], p[sz + sy + 1], fx);
@@ -488,15 +489,15 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
     const int cnx = fg.nx >> 1, cny = fg.ny >> 1, cnz = fg.nz >> 1;
     // clamped coarse indices: the clamps only bite for cells on the EXTERIOR shell, whose values are dropped
     const int x0 = max(2 * int(m) - 1, 0), x1 = 2 * int(m), x2 = 2 * int(m) + 1, x3 = min(2 * int(m) + 2, cnx - 1);
-    const int bj = max((j - 1) >> 1, 0), bk = max((k - 1) >> 1, 0);
-    const int bj1 = min(bj + 1, cny - 1), bk1 = min(bk + 1, cnz - 1);
+    const int bj = max((j - 1) >> 1, 0), bk = max((k - 1) >> 1, fg.ghostLo ? -1 : 0);
+    const int bj1 = min(bj + 1, cny - 1), bk1 = min(bk + 1, fg.ghostHi ? cnz : cnz - 1);
     const float fy = (j & 1) ? 0.25f : 0.75f, fz = (k & 1) ? 0.25f : 0.75f;
     float v[2][2][4];  // [z][y][fine x]
 #pragma unroll
     for (int zz = 0; zz < 2; ++zz)
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy) {
-            const float *r = coarse + (size_t(zz ? bk1 : bk) * cny + (yy ? bj1 : bj)) * cnx;
+            const float *r = coarse + (ptrdiff_t(zz ? bk1 : bk) * cny + (yy ? bj1 : bj)) * cnx;
             const float c0 = r[x0], c3 = r[x3];
             const float2 c12 = *reinterpret_cast<const float2 *>(r + x1);
             (void)x2;

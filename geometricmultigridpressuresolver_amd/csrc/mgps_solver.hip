@@ -1,8 +1,10 @@
 // The device-resident solver object and the C ABI (include/mgps.h): level storage in HBM, the
 // V-cycle schedule of GeometricMultigridPoissonSolver::applyVCycle (MG.cpp:420-881), the PCG driver
-// of solveGeometricConjugateGradient (CG.h:18-207).  Host orchestration only -- every arithmetic
-// step is a HIP kernel from mgps_kernels.hip; there is no CPU fallback: without a HIP device
-// mgps_create fails with MGPS_ERR_NO_DEVICE.
+// of solveGeometricConjugateGradient (CG.h:18-207), and the Z-slab multi-GPU orchestration (ghost
+// plane exchange before every operator that reads across a cut, collapse of the coarse tail to
+// rank 0).  Host orchestration only -- every arithmetic step is a HIP kernel from
+// mgps_kernels.hip; there is no CPU fallback: without a HIP device the constructors fail with
+// MGPS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,46 +20,58 @@ using namespace mgps;
 
 namespace {
 
+// One level on the device.  Every grid of a level is allocated with one spare plane below and one
+// above the owned planes (the ghost planes of a slab run; unused otherwise) and addressed through
+// the pointer to owned plane 0.
 struct DevLevel {
-    Dims d;
+    Dims d;  // owned planes
     GridP g{};
-    uint8_t *lab = nullptr;
-    float *x = nullptr, *b = nullptr;  // coarse levels only; level 0 works on the caller's grids
+    uint8_t *codes = nullptr;  // allocation base (ghost plane first); g.lab = codes + plane
+    float *x = nullptr, *b = nullptr;  // levels > 0 only; level 0 works on the caller's grids
     float *r = nullptr, *tmp = nullptr;
-    int32_t *band = nullptr;  // device-ordered band list: BOUNDARY cells first
+    int32_t *band = nullptr;  // device-ordered band list: general BOUNDARY cells first
     int nband = 0;
     float *bandTmp = nullptr;
-    float *rows = nullptr;    // 7 x numBoundary operator rows of the general BOUNDARY cells
+    float *rows = nullptr;  // 7 x numBoundary operator rows of the general BOUNDARY cells
     uint8_t *bandDiag = nullptr;
-    // Gauss-Seidel tile lists per colour [0] = even, [1] = odd tiles
+    // Gauss-Seidel tile lists per colour: [0] = even, [1] = odd tiles
     int32_t *pure[2] = {nullptr, nullptr}, *mixed[2] = {nullptr, nullptr};
     int npure[2] = {0, 0}, nmixed[2] = {0, 0};
     int32_t *tileBndStart = nullptr;
+    int z0 = 0, z1 = 0;  // owned global plane range
 };
 
 }  // namespace
 
 struct mgps_solver {
-    mgps_hierarchy *hier = nullptr;
+    mgps_hierarchy *hier = nullptr;  // global hierarchy (all levels, whole grid)
     mgps_options opt{};
     bool useGS = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<DevLevel> lv;
+    std::vector<DevLevel> lv;  // single GPU: all levels; slab run: the distributed levels + the collapse level
     float *w[3] = {nullptr, nullptr, nullptr};
     // coarsest-level dense inverse
     int cn = 0;
     float *cinv = nullptr, *cvec = nullptr;
     int32_t *ccells = nullptr;
+    bool tailOfSlabRun = false;  // this solver is the collapsed tail owned by rank 0 of a slab run
     // reductions
     double *partials = nullptr, *resultDev = nullptr, *resultHost = nullptr;
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
     float *pcg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *dinv = nullptr;
-    std::vector<void *> userGrids;
+    std::vector<void *> userGrids;  // allocation bases handed out by mgps_grid_alloc (ghost plane first)
+    // slab run
+    bool dist = false;
+    mgps_comm comm{};
+    int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
+    int totalLevels = 0;           // levels of the whole hierarchy
+    mgps_solver *tail = nullptr;   // rank 0: solver of levels distLevels .. totalLevels-1 on the whole grid
+    float *tailX = nullptr, *tailB = nullptr;
     // measurement hooks: event pairs around the fine-level full-domain smoother
     bool profiling = false;
-    std::vector<hipEvent_t> profEvents;  // start/stop pairs
+    std::vector<hipEvent_t> profEvents;
     size_t profUsed = 0;
     std::string lastError = "";
 };
@@ -71,22 +85,27 @@ int failH(mgps_solver *h, int code, const std::string &msg)
     return code;
 }
 
-#define MGPS_HIP(h, call)                                                                                  \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+#define MGPS_HIP(h, call)                                                                                 \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
     } while (0)
-#define MGPS_LAUNCH(h, call)                                                                               \
-    do {                                                                                                   \
-        int e_ = (call);                                                                                   \
-        if (e_ != 0)                                                                                       \
-            return failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(hipError_t(e_)));  \
+#define MGPS_LAUNCH(h, call)                                                                              \
+    do {                                                                                                  \
+        int e_ = (call);                                                                                  \
+        if (e_ != 0)                                                                                      \
+            return failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(hipError_t(e_))); \
     } while (0)
-#define MGPS_TRY(call)                 \
-    do {                               \
-        int s_ = (call);               \
-        if (s_ != MGPS_OK) return s_;  \
+#define MGPS_TRY(call)                \
+    do {                              \
+        int s_ = (call);              \
+        if (s_ != MGPS_OK) return s_; \
+    } while (0)
+#define MGPS_COMM(h, call)                                                           \
+    do {                                                                             \
+        int s_ = (call);                                                             \
+        if (s_ != 0) return failH(h, MGPS_ERR_COMM, std::string(#call) + " failed"); \
     } while (0)
 
 template <class T>
@@ -108,38 +127,55 @@ int devUpload(mgps_solver *h, T **p, const std::vector<T> &v)
     return MGPS_OK;
 }
 
+// a grid of d.nz owned planes with a zeroed ghost plane on each side; *p addresses owned plane 0
+int gridAlloc(mgps_solver *h, float **p, const Dims &d)
+{
+    const size_t plane = size_t(d.nx) * d.ny;
+    float *base = nullptr;
+    MGPS_TRY(devAlloc(h, &base, (size_t(d.nz) + 2) * plane, true));
+    *p = base + plane;
+    return MGPS_OK;
+}
+void gridFree(float *p, const Dims &d)
+{
+    if (p) (void)hipFree(p - size_t(d.nx) * d.ny);
+}
+
 void freeAll(mgps_solver *h)
 {
     if (!h) return;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->tail) freeAll(h->tail);
     for (auto &L : h->lv) {
-        hipFree(L.lab);
-        hipFree(L.x);
-        hipFree(L.b);
-        hipFree(L.r);
-        hipFree(L.tmp);
-        hipFree(L.band);
-        hipFree(L.bandTmp);
-        hipFree(L.rows);
-        hipFree(L.bandDiag);
+        (void)hipFree(L.codes);
+        gridFree(L.x, L.d);
+        gridFree(L.b, L.d);
+        gridFree(L.r, L.d);
+        gridFree(L.tmp, L.d);
+        (void)hipFree(L.band);
+        (void)hipFree(L.bandTmp);
+        (void)hipFree(L.rows);
+        (void)hipFree(L.bandDiag);
         for (int c = 0; c < 2; ++c) {
-            hipFree(L.pure[c]);
-            hipFree(L.mixed[c]);
+            (void)hipFree(L.pure[c]);
+            (void)hipFree(L.mixed[c]);
         }
-        hipFree(L.tileBndStart);
+        (void)hipFree(L.tileBndStart);
     }
-    for (int a = 0; a < 3; ++a) hipFree(h->w[a]);
-    hipFree(h->cinv);
-    hipFree(h->cvec);
-    hipFree(h->ccells);
-    hipFree(h->partials);
-    hipFree(h->resultDev);
-    if (h->resultHost) hipHostFree(h->resultHost);
-    for (int q = 0; q < 4; ++q) hipFree(h->pcg[q]);
-    hipFree(h->dinv);
-    for (void *p : h->userGrids) hipFree(p);
-    for (hipEvent_t e : h->profEvents) hipEventDestroy(e);
+    for (int a = 0; a < 3; ++a) (void)hipFree(h->w[a]);
+    (void)hipFree(h->cinv);
+    (void)hipFree(h->cvec);
+    (void)hipFree(h->ccells);
+    (void)hipFree(h->partials);
+    (void)hipFree(h->resultDev);
+    if (h->resultHost) (void)hipHostFree(h->resultHost);
+    if (!h->lv.empty()) {
+        for (int q = 0; q < 4; ++q) gridFree(h->pcg[q], h->lv[0].d);
+        gridFree(h->dinv, h->lv[0].d);
+    }
+    for (void *p : h->userGrids) (void)hipFree(p);
+    for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
     delete h;
 }
@@ -149,23 +185,41 @@ int checkLevel(mgps_solver *h, int level, const char *who)
     if (!h) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL handle");
     if (level < 0 || level >= int(h->lv.size()))
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, std::string(who) + ": level out of range");
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     return MGPS_OK;
 }
 
-// ---- level operators ---------------------------------------------------------------------------
+// ---- slab plumbing -------------------------------------------------------------------------------
 
-int bandPasses(mgps_solver *h, int l, float *x, const float *b)
+// refresh the two ghost planes of grid `a` of level l from the Z-neighbours
+int exchangeGhosts(mgps_solver *h, int l, float *a)
+{
+    if (!h->dist) return MGPS_OK;
+    const DevLevel &L = h->lv[l];
+    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
+    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, lo ? a - plane : nullptr,
+                                  hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, hi ? a + size_t(L.d.nz) * plane : nullptr,
+                                  plane * sizeof(float), h->stream));
+    return MGPS_OK;
+}
+
+// ---- level operators -----------------------------------------------------------------------------
+
+int bandPasses(mgps_solver *h, int l, float *x, const float *b, bool ghostsFresh)
 {
     DevLevel &L = h->lv[l];
-    for (int it = 0; it < h->opt.band_iterations; ++it)
+    for (int it = 0; it < h->opt.band_iterations; ++it) {
+        if (!(ghostsFresh && it == 0)) MGPS_TRY(exchangeGhosts(h, l, x));
         MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
+    }
     return MGPS_OK;
 }
 
 int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward)
 {
     DevLevel &L = h->lv[l];
+    MGPS_TRY(exchangeGhosts(h, l, x));  // the other colour's tiles across the cut changed in the previous pass
     MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
                                  L.tileBndStart, forward));
     return MGPS_OK;
@@ -173,10 +227,10 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
 
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
-int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down)
+int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh)
 {
     DevLevel &L = h->lv[l];
-    MGPS_TRY(bandPasses(h, l, cur, b));
+    MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh));
     const bool timed = h->profiling && l == 0;
     if (timed) {
         if (h->profUsed + 2 > h->profEvents.size()) {
@@ -197,6 +251,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0));
         }
     } else {
+        MGPS_TRY(exchangeGhosts(h, l, cur));
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight));
         std::swap(cur, other);
     }
@@ -204,39 +259,82 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + 1], h->stream));
         h->profUsed += 2;
     }
-    MGPS_TRY(bandPasses(h, l, cur, b));
+    MGPS_TRY(bandPasses(h, l, cur, b, false));
+    return MGPS_OK;
+}
+
+int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess);
+
+// levels distLevels .. totalLevels-1 of a slab run: gather the rhs of the collapse level to rank 0,
+// run the rest of the cycle there on the whole grid, scatter the correction back
+int collapsedTail(mgps_solver *h)
+{
+    DevLevel &C = h->lv[h->distLevels];
+    const size_t bytes = C.d.cells() * sizeof(float);
+    MGPS_COMM(h, h->comm.gather(h->comm.user, C.b, h->comm.rank == 0 ? h->tailB : nullptr, bytes, 0, h->stream));
+    if (h->comm.rank == 0) {
+        h->tail->stream = h->stream;
+        const int rc = vcycle(h->tail, h->tailX, h->tailB, false);
+        if (rc != MGPS_OK) return failH(h, rc, "collapsed tail: " + h->tail->lastError);
+    }
+    MGPS_COMM(h, h->comm.scatter(h->comm.user, h->comm.rank == 0 ? h->tailX : nullptr, C.x, bytes, 0, h->stream));
+    return MGPS_OK;
+}
+
+int zeroGrid(mgps_solver *h, float *a, const Dims &d, bool withGhosts)
+{
+    const size_t plane = size_t(d.nx) * d.ny;
+    if (withGhosts) MGPS_HIP(h, hipMemsetAsync(a - plane, 0, (d.cells() + 2 * plane) * sizeof(float), h->stream));
+    else MGPS_HIP(h, hipMemsetAsync(a, 0, d.cells() * sizeof(float), h->stream));
     return MGPS_OK;
 }
 
 int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
 {
-    const int L = int(h->lv.size());
-    std::vector<float *> cur(L), other(L);
+    const int nlv = int(h->lv.size());
+    if (h->tailOfSlabRun && nlv == 1) {  // the tail of a slab run can be the direct solve alone
+        MGPS_TRY(zeroGrid(h, x, h->lv[0].d, false));
+        MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, x, b, h->cvec));
+        return MGPS_OK;
+    }
+    // levels this object smooths on: all but its last one (direct solve, or the collapse level of a
+    // slab run), unless the whole hierarchy is a single level (MG.cpp:516-517)
+    const int nsmooth = nlv > 1 ? nlv - 1 : 1;
+    const bool hasBottom = nlv > 1;
+    std::vector<float *> cur(nlv, nullptr), other(nlv, nullptr);
     cur[0] = x;
     other[0] = h->lv[0].tmp;
-    if (!useInitialGuess) MGPS_HIP(h, hipMemsetAsync(x, 0, h->lv[0].d.cells() * sizeof(float), h->stream));  // MG.cpp:439
-    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true));
-    if (L > 1) {
+    bool fresh = false;
+    if (!useInitialGuess) {  // MG.cpp:439-440
+        MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
+        fresh = true;
+    }
+    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh));
+    if (hasBottom) {
         const float *rhs = b;
-        for (int l = 0; l < L - 1; ++l) {  // MG.cpp:519-553 (fine), 557-667 (coarser)
+        for (int l = 0; l < nsmooth; ++l) {  // MG.cpp:519-553 (fine), 557-667 (coarser)
             DevLevel &F = h->lv[l], &C = h->lv[l + 1];
             if (l > 0) {
                 cur[l] = F.x;
                 other[l] = F.tmp;
                 rhs = F.b;
-                MGPS_HIP(h, hipMemsetAsync(F.x, 0, F.d.cells() * sizeof(float), h->stream));  // MG.cpp:566
-                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true));
+                MGPS_TRY(zeroGrid(h, F.x, F.d, true));  // MG.cpp:566
+                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
+            MGPS_TRY(exchangeGhosts(h, l, cur[l]));
             MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f));
+            MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
         }
-        DevLevel &B = h->lv[L - 1];  // direct solve, MG.cpp:669-692
-        MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, B.x, B.b, h->cvec));
-        cur[L - 1] = B.x;
-        for (int l = L - 2; l >= 0; --l) {  // MG.cpp:695-784 (coarser), 787-880 (fine)
+        DevLevel &B = h->lv[nsmooth];
+        if (h->dist) MGPS_TRY(collapsedTail(h));
+        else MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, B.x, B.b, h->cvec));  // MG.cpp:669-692
+        cur[nsmooth] = B.x;
+        for (int l = nsmooth - 1; l >= 0; --l) {  // MG.cpp:695-784 (coarser), 787-880 (fine)
             DevLevel &F = h->lv[l];
+            MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
             MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
-            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false));
+            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false, false));
         }
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
@@ -251,18 +349,25 @@ int reduceToHost(mgps_solver *h, int kind, int level, const float *a, const floa
     MGPS_HIP(h, hipMemcpyAsync(h->resultHost, h->resultDev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     *out = *h->resultHost;
+    if (h->dist) MGPS_COMM(h, h->comm.allreduce(h->comm.user, out, 1, kind <= 1 ? 0 : 1));
     return MGPS_OK;
 }
 
 int ensurePcgGrids(mgps_solver *h, bool needDiag)
 {
-    const size_t n = h->lv[0].d.cells();
     for (int q = 0; q < 4; ++q)
-        if (!h->pcg[q]) MGPS_TRY(devAlloc(h, &h->pcg[q], n, true));
+        if (!h->pcg[q]) MGPS_TRY(gridAlloc(h, &h->pcg[q], h->lv[0].d));
     if (needDiag && !h->dinv) {
-        MGPS_TRY(devAlloc(h, &h->dinv, n, false));
+        MGPS_TRY(gridAlloc(h, &h->dinv, h->lv[0].d));
         MGPS_LAUNCH(h, launchDiagInverse(h->stream, h->lv[0].g, h->dinv));
     }
+    return MGPS_OK;
+}
+
+int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const float *b)
+{
+    MGPS_TRY(exchangeGhosts(h, level, x));
+    MGPS_LAUNCH(h, launchStencil(h->stream, op, h->lv[level].g, out, x, b, h->opt.jacobi_weight));
     return MGPS_OK;
 }
 
@@ -281,13 +386,13 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_HIP(h, hipEventRecord(e0, h->stream));
     auto finish = [&](int outcome) {
         st->outcome = outcome;
-        hipEventRecord(e1, h->stream);
-        hipEventSynchronize(e1);
+        (void)hipEventRecord(e1, h->stream);
+        (void)hipEventSynchronize(e1);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         st->solve_ms = ms;
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
         return MGPS_OK;
     };
     auto precondition = [&](float *dst, const float *src) -> int {
@@ -300,7 +405,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_TRY(reduceToHost(h, 1, 0, b, nullptr, &rhs2));  // CG.h:35
     st->rhs_norm2 = rhs2;
     if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
-    MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, r, x, b, 0.f));  // CG.h:50-51
+    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b));    // CG.h:50-51
     double res2 = 0;
     MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));  // CG.h:57
     const double threshold = tol * tol * rhs2;           // CG.h:58
@@ -322,14 +427,15 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             st->iterations = it;
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
         }
-        MGPS_LAUNCH(h, launchStencil(h->stream, OP_APPLY, F.g, t, p, nullptr, 0.f));  // CG.h:110
+        MGPS_TRY(applyOp(h, OP_APPLY, 0, t, p, nullptr));  // CG.h:110
         double pAp = 0;
         MGPS_TRY(reduceToHost(h, 0, 0, p, t, &pAp));
-        const double alpha = absNew / pAp;                                                // CG.h:121
-        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, x, p, nullptr, float(alpha), 1.f));    // CG.h:132
-        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, r, t, nullptr, float(alpha), -1.f));   // CG.h:143
-        MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));                              // CG.h:153
-        if (h->opt.print_stats) std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
+        const double alpha = absNew / pAp;                                               // CG.h:121
+        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, x, p, nullptr, float(alpha), 1.f));   // CG.h:132
+        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, r, t, nullptr, float(alpha), -1.f));  // CG.h:143
+        MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));                             // CG.h:153
+        if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
+            std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161 -- the counter is not advanced on the exit pass
             converged = true;
             break;
@@ -341,12 +447,145 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, nullptr, float(beta)));  // CG.h:191
     }
     st->iterations = it;
-    st->rel_residual = std::sqrt(res2 / rhs2);                                  // CG.h:199
-    MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, r, x, b, 0.f));  // CG.h:203-204
+    st->rel_residual = std::sqrt(res2 / rhs2);      // CG.h:199
+    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b));  // CG.h:203-204
     double rec2 = 0;
     MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &rec2));
     st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);  // CG.h:205
     return finish(converged ? MGPS_PCG_CONVERGED : MGPS_PCG_MAX_ITERATIONS);
+}
+
+// ---- construction --------------------------------------------------------------------------------
+
+// upload one level built by buildSlabLevel
+int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1, int globalNz, bool withWeights,
+                bool workGrids, bool xbGrids)
+{
+    L.d = HL.d;
+    L.z0 = z0;
+    L.z1 = z1;
+    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    MGPS_TRY(devUpload(h, &L.codes, HL.codes));
+    MGPS_TRY(devUpload(h, &L.band, HL.bandDev));
+    MGPS_TRY(devUpload(h, &L.rows, HL.rows));
+    MGPS_TRY(devUpload(h, &L.bandDiag, HL.bandDiag));
+    L.nband = int(HL.bandDev.size());
+    MGPS_TRY(devAlloc(h, &L.bandTmp, HL.bandDev.size(), false));
+    MGPS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
+    MGPS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
+    MGPS_TRY(devUpload(h, &L.mixed[0], HL.mixedEven));
+    MGPS_TRY(devUpload(h, &L.mixed[1], HL.mixedOdd));
+    L.npure[0] = int(HL.pureEven.size());
+    L.npure[1] = int(HL.pureOdd.size());
+    L.nmixed[0] = int(HL.mixedEven.size());
+    L.nmixed[1] = int(HL.mixedOdd.size());
+    MGPS_TRY(devUpload(h, &L.tileBndStart, HL.tileBndStart));
+    if (xbGrids) {
+        MGPS_TRY(gridAlloc(h, &L.x, L.d));
+        MGPS_TRY(gridAlloc(h, &L.b, L.d));
+    }
+    if (workGrids) {
+        MGPS_TRY(gridAlloc(h, &L.r, L.d));
+        MGPS_TRY(gridAlloc(h, &L.tmp, L.d));
+    }
+    L.g = GridP{L.d.nx,
+                L.d.ny,
+                L.d.nz,
+                L.codes + plane,
+                withWeights ? h->w[0] : nullptr,
+                withWeights ? h->w[1] : nullptr,
+                withWeights ? h->w[2] : nullptr,
+                L.band,
+                L.rows,
+                int(HL.numBoundary),
+                L.bandDiag,
+                (h->dist && z0 > 0) ? 1 : 0,
+                (h->dist && z1 < globalNz) ? 1 : 0};
+    return MGPS_OK;
+}
+
+int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
+{
+    mgps_hierarchy *hier = h->hier;
+    if (needCoarseSolver) {
+        hier->buildDenseInverse();
+        h->cn = hier->coarseN;
+        MGPS_TRY(devUpload(h, &h->cinv, hier->coarseInverse));
+        MGPS_TRY(devUpload(h, &h->ccells, hier->coarseCell));
+        MGPS_TRY(devAlloc(h, &h->cvec, size_t(h->cn), true));
+    }
+    MGPS_TRY(devAlloc(h, &h->partials, size_t(kReducePartials), true));
+    MGPS_TRY(devAlloc(h, &h->resultDev, 1, true));
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->resultHost), sizeof(double)) != hipSuccess)
+        return failH(h, MGPS_ERR_ALLOC, "pinned allocation failed");
+    MGPS_HIP(h, hipDeviceSynchronize());
+    return MGPS_OK;
+}
+
+int pickDevice(const mgps_options &o, int *device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return failH(nullptr, MGPS_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    int dev = o.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= ndev) return failH(nullptr, MGPS_ERR_NO_DEVICE, "device ordinal out of range");
+    if (hipSetDevice(dev) != hipSuccess) return failH(nullptr, MGPS_ERR_NO_DEVICE, "hipSetDevice failed");
+    *device = dev;
+    return MGPS_OK;
+}
+
+int readOptions(const mgps_options *opt, mgps_options *o)
+{
+    mgps_default_options(o);
+    if (opt) {
+        if (opt->struct_size != int(sizeof(mgps_options)))
+            return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options.struct_size mismatch: call mgps_default_options first");
+        *o = *opt;
+    }
+    return MGPS_OK;
+}
+
+// whole-grid solver on one device.  weights may be nullptr (unit weights: the collapsed tail)
+int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const float *wy, const float *wz,
+                bool useGS, const mgps_options &o, int device, bool tailOfSlabRun)
+{
+    auto *h = new mgps_solver();
+    h->hier = hier;
+    h->opt = o;
+    h->useGS = useGS;
+    h->device = device;
+    h->tailOfSlabRun = tailOfSlabRun;
+    h->totalLevels = hier->levels;
+    auto bail = [&](int code) {
+        setLastGlobalError(h->lastError);
+        freeAll(h);
+        return code;
+    };
+    const Dims d0 = hier->lv[0].d;
+    if (wx) {
+        const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz,
+                              size_t(d0.nx) * d0.ny * (d0.nz + 1)};
+        const float *wh[3] = {wx, wy, wz};
+        for (int a = 0; a < 3; ++a) {
+            int rc = devAlloc(h, &h->w[a], wn[a], false);
+            if (rc != MGPS_OK) return bail(rc);
+            if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+                return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
+        }
+    }
+    h->lv.resize(hier->levels);
+    for (int l = 0; l < hier->levels; ++l) {
+        HostLevel HL;
+        const Dims d = hier->lv[l].d;
+        buildSlabLevel(hier->lv[l], 0, d.nz, l == 0 ? wx : nullptr, l == 0 ? wy : nullptr, l == 0 ? wz : nullptr, HL);
+        int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0);
+        if (rc != MGPS_OK) return bail(rc);
+    }
+    int rc = commonDeviceState(h, hier->levels > 1 || tailOfSlabRun);
+    if (rc != MGPS_OK) return bail(rc);
+    *out = h;
+    return MGPS_OK;
 }
 
 }  // namespace
@@ -373,19 +612,9 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
     if (!labels_host || !wx_host || !wy_host || !wz_host)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create: labels and the three weight grids are required");
     mgps_options o;
-    mgps_default_options(&o);
-    if (opt) {
-        if (opt->struct_size != int(sizeof(mgps_options)))
-            return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options.struct_size mismatch");
-        o = *opt;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return failH(nullptr, MGPS_ERR_NO_DEVICE, "mgps_create: no HIP device is visible (this library has no CPU path)");
-    int device = o.device;
-    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
-    if (device >= ndev) return failH(nullptr, MGPS_ERR_NO_DEVICE, "mgps_create: device ordinal out of range");
-
+    MGPS_TRY(readOptions(opt, &o));
+    int device = 0;
+    MGPS_TRY(pickDevice(o, &device));
     mgps_hierarchy *hier = nullptr;
     MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz, labels_host, mg_levels, &o));
     {  // the fine-level invariants the reference asserts in debug builds (MG.cpp:234)
@@ -397,88 +626,117 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
                          "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_set_boundary_labels");
         }
     }
+    return createWhole(out, hier, wx_host, wy_host, wz_host, use_gauss_seidel != 0, o, device, false);
+}
+
+int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
+                     const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
+                     int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm)
+{
+    if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: out is NULL");
+    *out = nullptr;
+    if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: labels, the slab weights and a comm are required");
+    if (comm->struct_size != int(sizeof(mgps_comm)) || !comm->exchange || !comm->allreduce || !comm->gather || !comm->scatter ||
+        comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: incomplete mgps_comm");
+    mgps_options o;
+    MGPS_TRY(readOptions(opt, &o));
+    int device = 0;
+    MGPS_TRY(pickDevice(o, &device));
+    mgps_hierarchy *hier = nullptr;
+    MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o));
+    const int P = comm->size, rank = comm->rank;
+    // distributed levels: per-rank plane count a multiple of 16; the last level is always collapsed
+    int D = 0;
+    if (nz_global % P == 0) {
+        int planes = nz_global / P;
+        while (D < hier->levels - 1 && planes % kTile == 0) {
+            ++D;
+            planes /= 2;
+        }
+    }
+    if (D < 1) {
+        mgps_hierarchy_destroy(hier);
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT,
+                     "mgps_create_slab: nz / ranks must be a multiple of 16 and the hierarchy needs at least 2 levels");
+    }
     auto *h = new mgps_solver();
     h->hier = hier;
     h->opt = o;
     h->useGS = use_gauss_seidel != 0;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess) {
-        freeAll(h);
-        return failH(nullptr, MGPS_ERR_NO_DEVICE, "mgps_create: hipSetDevice failed");
-    }
+    h->dist = true;
+    h->comm = *comm;
+    h->distLevels = D;
+    h->totalLevels = hier->levels;
     auto bail = [&](int code) {
         setLastGlobalError(h->lastError);
         freeAll(h);
         return code;
     };
-#define CREATE_TRY(call)                        \
-    do {                                        \
-        int s_ = (call);                        \
-        if (s_ != MGPS_OK) return bail(s_);     \
-    } while (0)
-
-    const Dims d0{nx, ny, nz};
-    const size_t wn[3] = {size_t(nx + 1) * ny * nz, size_t(nx) * (ny + 1) * nz, size_t(nx) * ny * (nz + 1)};
-    const float *wh[3] = {wx_host, wy_host, wz_host};
+    const int nzl = nz_global / P, z0 = rank * nzl;
+    const size_t wn[3] = {size_t(nx + 1) * ny * nzl, size_t(nx) * (ny + 1) * nzl, size_t(nx) * ny * (nzl + 1)};
+    const float *wh[3] = {wx_slab, wy_slab, wz_slab};
     for (int a = 0; a < 3; ++a) {
-        CREATE_TRY(devAlloc(h, &h->w[a], wn[a], false));
+        int rc = devAlloc(h, &h->w[a], wn[a], false);
+        if (rc != MGPS_OK) return bail(rc);
         if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-            return bail(failH(h, MGPS_ERR_HIP, "mgps_create: weight upload failed"));
+            return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
     }
-    h->lv.resize(hier->levels);
-    buildBoundaryRows(hier->lv[0], wx_host, wy_host, wz_host);  // fine level: the real face weights
-    for (int l = 0; l < hier->levels; ++l) {
-        const HostLevel &HL = hier->lv[l];
-        DevLevel &L = h->lv[l];
-        L.d = HL.d;
-        CREATE_TRY(devUpload(h, &L.lab, HL.codes));
-        CREATE_TRY(devUpload(h, &L.bandDiag, HL.bandDiag));
-        CREATE_TRY(devUpload(h, &L.band, HL.bandDev));
-        CREATE_TRY(devUpload(h, &L.rows, HL.rows));
-        L.nband = int(HL.bandDev.size());
-        CREATE_TRY(devAlloc(h, &L.bandTmp, HL.band.size(), false));
-        CREATE_TRY(devUpload(h, &L.pure[0], HL.pureEven));
-        CREATE_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
-        CREATE_TRY(devUpload(h, &L.mixed[0], HL.mixedEven));
-        CREATE_TRY(devUpload(h, &L.mixed[1], HL.mixedOdd));
-        L.npure[0] = int(HL.pureEven.size());
-        L.npure[1] = int(HL.pureOdd.size());
-        L.nmixed[0] = int(HL.mixedEven.size());
-        L.nmixed[1] = int(HL.mixedOdd.size());
-        CREATE_TRY(devUpload(h, &L.tileBndStart, HL.tileBndStart));
-        if (l > 0) {
-            CREATE_TRY(devAlloc(h, &L.x, L.d.cells(), true));
-            CREATE_TRY(devAlloc(h, &L.b, L.d.cells(), true));
-        }
-        CREATE_TRY(devAlloc(h, &L.r, L.d.cells(), true));
-        CREATE_TRY(devAlloc(h, &L.tmp, L.d.cells(), true));
-        L.g = GridP{L.d.nx, L.d.ny, L.d.nz, L.lab, l == 0 ? h->w[0] : nullptr, l == 0 ? h->w[1] : nullptr,
-                    l == 0 ? h->w[2] : nullptr, L.band, L.rows, int(HL.numBoundary), L.bandDiag};
+    h->lv.resize(D + 1);
+    for (int l = 0; l <= D; ++l) {
+        HostLevel HL;
+        const int gz = hier->lv[l].d.nz, lz0 = z0 >> l, lz1 = (z0 + nzl) >> l;
+        buildSlabLevel(hier->lv[l], lz0, lz1, l == 0 ? wx_slab : nullptr, l == 0 ? wy_slab : nullptr,
+                       l == 0 ? wz_slab : nullptr, HL);
+        int rc = uploadLevel(h, h->lv[l], HL, lz0, lz1, gz, l == 0, l < D, l > 0);
+        if (rc != MGPS_OK) return bail(rc);
     }
-    (void)d0;
-    hier->buildDenseInverse();
-    h->cn = hier->coarseN;
-    CREATE_TRY(devUpload(h, &h->cinv, hier->coarseInverse));
-    CREATE_TRY(devUpload(h, &h->ccells, hier->coarseCell));
-    CREATE_TRY(devAlloc(h, &h->cvec, size_t(h->cn), true));
-    CREATE_TRY(devAlloc(h, &h->partials, size_t(kReducePartials), true));
-    CREATE_TRY(devAlloc(h, &h->resultDev, 1, true));
-    if (hipHostMalloc(reinterpret_cast<void **>(&h->resultHost), sizeof(double)) != hipSuccess)
-        return bail(failH(h, MGPS_ERR_ALLOC, "mgps_create: pinned allocation failed"));
-    if (hipDeviceSynchronize() != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, "mgps_create: device synchronize failed"));
-#undef CREATE_TRY
+    int rc = commonDeviceState(h, false);
+    if (rc != MGPS_OK) return bail(rc);
+    if (rank == 0) {  // the collapsed tail: levels D .. L-1 on the whole grid, unit weights
+        const HostLevel &C = hier->lv[D];
+        mgps_hierarchy *tailHier = nullptr;
+        rc = hierarchyCreate(&tailHier, C.d.nx, C.d.ny, C.d.nz, C.labels.data(), hier->levels - D, &o, true, false);
+        if (rc != MGPS_OK) return bail(failH(h, rc, std::string("collapsed tail hierarchy: ") + lastGlobalError()));
+        rc = createWhole(&h->tail, tailHier, nullptr, nullptr, nullptr, h->useGS, o, device, true);
+        if (rc != MGPS_OK) return bail(failH(h, rc, std::string("collapsed tail: ") + lastGlobalError()));
+        rc = gridAlloc(h->tail, &h->tailX, C.d);
+        if (rc == MGPS_OK) rc = gridAlloc(h->tail, &h->tailB, C.d);
+        if (rc != MGPS_OK) return bail(rc);
+        h->tail->userGrids.push_back(h->tailX - size_t(C.d.nx) * C.d.ny);
+        h->tail->userGrids.push_back(h->tailB - size_t(C.d.nx) * C.d.ny);
+        if (hipDeviceSynchronize() != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, "device synchronize failed"));
+    }
     *out = h;
     return MGPS_OK;
 }
 
 void mgps_destroy(mgps_solver *h) { freeAll(h); }
-int mgps_levels(const mgps_solver *h) { return h ? int(h->lv.size()) : 0; }
+int mgps_levels(const mgps_solver *h) { return h ? h->totalLevels : 0; }
 const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *h) { return h ? h->hier : nullptr; }
+int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
 {
-    if (!h) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_dims: NULL handle");
+    if (!h || !out_dims || level < 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_dims: bad arguments");
+    if (level < int(h->lv.size())) {  // the grids this object works on (the slab in a slab run)
+        out_dims[0] = h->lv[level].d.nx;
+        out_dims[1] = h->lv[level].d.ny;
+        out_dims[2] = h->lv[level].d.nz;
+        return MGPS_OK;
+    }
     return mgps_hierarchy_level_dims(h->hier, level, out_dims);
+}
+
+int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1)
+{
+    if (!h || !z0 || !z1 || level < 0 || level >= int(h->lv.size()))
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_slab_range: bad arguments");
+    *z0 = h->lv[level].z0;
+    *z1 = h->lv[level].z1;
+    return MGPS_OK;
 }
 
 int mgps_set_stream(mgps_solver *h, void *hip_stream)
@@ -499,20 +757,24 @@ int mgps_grid_alloc(mgps_solver *h, int level, float **out_dev)
 {
     MGPS_TRY(checkLevel(h, level, "mgps_grid_alloc"));
     if (!out_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_alloc: out is NULL");
-    MGPS_TRY(devAlloc(h, out_dev, h->lv[level].d.cells(), true));
-    h->userGrids.push_back(*out_dev);
+    MGPS_TRY(gridAlloc(h, out_dev, h->lv[level].d));
+    h->userGrids.push_back(*out_dev - size_t(h->lv[level].d.nx) * h->lv[level].d.ny);
     return MGPS_OK;
 }
 
 int mgps_grid_free(mgps_solver *h, float *dev)
 {
     MGPS_TRY(checkLevel(h, 0, "mgps_grid_free"));
-    auto it = std::find(h->userGrids.begin(), h->userGrids.end(), static_cast<void *>(dev));
-    if (it == h->userGrids.end()) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_free: not a grid of this solver");
-    h->userGrids.erase(it);
-    MGPS_HIP(h, hipStreamSynchronize(h->stream));
-    MGPS_HIP(h, hipFree(dev));
-    return MGPS_OK;
+    for (auto it = h->userGrids.begin(); it != h->userGrids.end(); ++it)
+        for (const DevLevel &L : h->lv)
+            if (static_cast<float *>(*it) + size_t(L.d.nx) * L.d.ny == dev) {
+                void *base = *it;
+                h->userGrids.erase(it);
+                MGPS_HIP(h, hipStreamSynchronize(h->stream));
+                MGPS_HIP(h, hipFree(base));
+                return MGPS_OK;
+            }
+    return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_free: not a grid of this solver");
 }
 
 int mgps_grid_upload(mgps_solver *h, int level, float *dst_dev, const float *src_host)
@@ -533,6 +795,22 @@ int mgps_grid_download(mgps_solver *h, int level, float *dst_host, const float *
     return MGPS_OK;
 }
 
+int mgps_copy_to_host(mgps_solver *h, void *dst_host, const void *src_dev, size_t bytes)
+{
+    MGPS_TRY(checkLevel(h, 0, "mgps_copy_to_host"));
+    MGPS_HIP(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    MGPS_HIP(h, hipStreamSynchronize(h->stream));
+    return MGPS_OK;
+}
+
+int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, size_t bytes)
+{
+    MGPS_TRY(checkLevel(h, 0, "mgps_copy_to_device"));
+    MGPS_HIP(h, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
+    MGPS_HIP(h, hipStreamSynchronize(h->stream));
+    return MGPS_OK;
+}
+
 int mgps_apply_vcycle(mgps_solver *h, float *x_dev, const float *b_dev, int use_initial_guess)
 {
     MGPS_TRY(checkLevel(h, 0, "mgps_apply_vcycle"));
@@ -545,7 +823,8 @@ int mgps_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_d
     MGPS_TRY(checkLevel(h, level, "mgps_jacobi_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_jacobi_smooth: NULL grid");
     DevLevel &L = h->lv[level];
-    MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, L.tmp, x_dev, b_dev, h->opt.jacobi_weight));
+    if (!L.tmp) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_jacobi_smooth: level has no work grids");
+    MGPS_TRY(applyOp(h, OP_JACOBI, level, L.tmp, x_dev, b_dev));
     MGPS_HIP(h, hipMemcpyAsync(x_dev, L.tmp, L.d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return MGPS_OK;
 }
@@ -563,6 +842,7 @@ int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const f
     MGPS_TRY(checkLevel(h, level, "mgps_boundary_jacobi_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_boundary_jacobi_smooth: NULL grid");
     DevLevel &L = h->lv[level];
+    MGPS_TRY(exchangeGhosts(h, level, x_dev));
     MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x_dev, b_dev, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
     return MGPS_OK;
 }
@@ -571,8 +851,7 @@ int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_d
 {
     MGPS_TRY(checkLevel(h, level, "mgps_apply_poisson"));
     if (!y_dev || !x_dev || y_dev == x_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_apply_poisson: bad grid pointers");
-    MGPS_LAUNCH(h, launchStencil(h->stream, OP_APPLY, h->lv[level].g, y_dev, x_dev, nullptr, 0.f));
-    return MGPS_OK;
+    return applyOp(h, OP_APPLY, level, y_dev, const_cast<float *>(x_dev), nullptr);
 }
 
 int mgps_residual(mgps_solver *h, int level, float *r_dev, const float *x_dev, const float *b_dev)
@@ -580,14 +859,14 @@ int mgps_residual(mgps_solver *h, int level, float *r_dev, const float *x_dev, c
     MGPS_TRY(checkLevel(h, level, "mgps_residual"));
     if (!r_dev || !x_dev || !b_dev || r_dev == x_dev)
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_residual: bad grid pointers");
-    MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, h->lv[level].g, r_dev, x_dev, b_dev, 0.f));
-    return MGPS_OK;
+    return applyOp(h, OP_RESIDUAL, level, r_dev, const_cast<float *>(x_dev), b_dev);
 }
 
 int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *fine_dev)
 {
     MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_downsample"));
     if (fine_level < 0 || !coarse_dev || !fine_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_downsample: bad arguments");
+    MGPS_TRY(exchangeGhosts(h, fine_level, const_cast<float *>(fine_dev)));
     MGPS_LAUNCH(h, launchRestrict(h->stream, h->lv[fine_level + 1].g, coarse_dev, fine_dev));
     return MGPS_OK;
 }
@@ -596,6 +875,7 @@ int mgps_upsample_add(mgps_solver *h, int fine_level, float *fine_dev, const flo
 {
     MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_upsample_add"));
     if (fine_level < 0 || !coarse_dev || !fine_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_upsample_add: bad arguments");
+    MGPS_TRY(exchangeGhosts(h, fine_level + 1, const_cast<float *>(coarse_dev)));
     MGPS_LAUNCH(h, launchProlongAdd(h->stream, h->lv[fine_level].g, fine_dev, coarse_dev));
     return MGPS_OK;
 }
@@ -604,6 +884,7 @@ int mgps_coarse_solve(mgps_solver *h, float *x_dev, const float *b_dev)
 {
     MGPS_TRY(checkLevel(h, 0, "mgps_coarse_solve"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_coarse_solve: NULL grid");
+    if (h->dist) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_coarse_solve: not available on a slab solver");
     MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, x_dev, b_dev, h->cvec));
     return MGPS_OK;
 }
@@ -666,7 +947,7 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
     MGPS_TRY(checkLevel(h, 0, "mgps_solve_pcg"));
     if (!x_dev || !b_dev || x_dev == b_dev || !(tolerance >= 0) || max_iterations < 0)
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_solve_pcg: bad arguments");
-    return pcg(h, x_dev, b_dev, tolerance, max_iterations, use_mg_preconditioner != 0, stats);
+    return pcg(h, x_dev, const_cast<float *>(b_dev), tolerance, max_iterations, use_mg_preconditioner != 0, stats);
 }
 
 int mgps_profile_enable(mgps_solver *h, int enable)

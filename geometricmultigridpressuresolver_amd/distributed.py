@@ -1,0 +1,217 @@
+"""Z-slab multi-GPU front end: one process per GPU, torch.distributed for rendezvous.
+
+The orchestration (which operator needs which ghost plane, the collapse of the coarse tail to rank 0)
+lives in the C++ library (csrc/mgps_solver.hip); this module only builds the transport it runs on:
+
+* RcclComm        -- production: the library's own RCCL communicator (ncclSend/ncclRecv over xGMI on
+                     the solver's stream); torch.distributed is used once, to ship the 128-byte
+                     ncclUniqueId from rank 0 to the others.
+* TorchDistComm   -- the same vtable filled with Python callbacks that stage through the host and use
+                     torch.distributed point-to-point / collectives of ANY backend (gloo in the
+                     test-suite, where two ranks may share one GPU, which RCCL does not allow).
+
+The reference is single-process shared memory; nothing here has a counterpart there.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import check, lib
+from .solver import GeometricMultigridPoissonSolver, _np_f32, _np_u8, _p, default_options
+
+_EXCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_ALLR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+_GATH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+_DEST = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class CommStruct(C.Structure):
+    """mgps_comm (include/mgps.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int),
+        ("rank", C.c_int),
+        ("size", C.c_int),
+        ("user", C.c_void_p),
+        ("exchange", _EXCH),
+        ("allreduce", _ALLR),
+        ("gather", _GATH),
+        ("scatter", _GATH),
+        ("destroy", _DEST),
+    ]
+
+
+class RcclComm:
+    """The library's RCCL transport.  Needs an initialised torch.distributed process group (any
+    backend) to broadcast the unique id."""
+
+    def __init__(self, device=None, group=None):
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.cuda.current_device() if device is None else int(device)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            check(lib().mgps_rccl_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.struct = CommStruct()
+        check(lib().mgps_comm_create_rccl(C.byref(self.struct), self.rank, self.size, ident, dev))
+
+    def close(self):
+        if self.struct is not None:
+            lib().mgps_comm_destroy(C.byref(self.struct))
+            self.struct = None
+
+
+class TorchDistComm:
+    """mgps_comm over torch.distributed with host staging (works with gloo; ranks may share a GPU)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self._hip = C.CDLL("libamdhip64.so")  # the runtime torch already loaded
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.exchanges = 0
+        self._cb = (_EXCH(self._exchange), _ALLR(self._allreduce), _GATH(self._gather), _GATH(self._scatter))
+        self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST())
+
+    # -- staging helpers ---------------------------------------------------------------------------
+    def _d2h(self, ptr, nbytes, stream):
+        self._hip.hipStreamSynchronize(stream)
+        t = torch.empty(nbytes, dtype=torch.uint8)
+        assert self._hip.hipMemcpy(t.data_ptr(), ptr, nbytes, 2) == 0
+        return t
+
+    def _h2d(self, ptr, t):
+        assert self._hip.hipMemcpy(ptr, t.data_ptr(), t.numel(), 1) == 0
+
+    def _global(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    # -- vtable ------------------------------------------------------------------------------------
+    def _exchange(self, user, send_lo, recv_lo, send_hi, recv_hi, nbytes, stream):
+        try:
+            self.exchanges += 1
+            ops, recvs = [], []
+            for send, recv, peer in ((send_lo, recv_lo, self.rank - 1), (send_hi, recv_hi, self.rank + 1)):
+                if not send:
+                    continue
+                out = self._d2h(send, nbytes, stream)
+                inc = torch.empty(nbytes, dtype=torch.uint8)
+                ops.append(dist.P2POp(dist.isend, out, self._global(peer), self.group))
+                ops.append(dist.P2POp(dist.irecv, inc, self._global(peer), self.group))
+                recvs.append((recv, inc))
+            for w in dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            for recv, inc in recvs:
+                self._h2d(recv, inc)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("TorchDistComm.exchange failed:", e, flush=True)
+            return 1
+
+    def _allreduce(self, user, values, count, op):
+        try:
+            t = torch.tensor([values[i] for i in range(count)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=self.group)
+            for i in range(count):
+                values[i] = float(t[i])
+            return 0
+        except Exception as e:
+            print("TorchDistComm.allreduce failed:", e, flush=True)
+            return 1
+
+    def _gather(self, user, send, recv, nbytes, root, stream):
+        try:
+            mine = self._d2h(send, nbytes, stream)
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.size)] if self.rank == root else None
+            dist.gather(mine, parts, dst=self._global(root), group=self.group)
+            if self.rank == root:
+                self._h2d(recv, torch.cat(parts))
+            return 0
+        except Exception as e:
+            print("TorchDistComm.gather failed:", e, flush=True)
+            return 1
+
+    def _scatter(self, user, send, recv, nbytes, root, stream):
+        try:
+            parts = None
+            if self.rank == root:
+                whole = self._d2h(send, nbytes * self.size, stream)
+                parts = [p.contiguous() for p in whole.split(nbytes)]
+            mine = torch.empty(nbytes, dtype=torch.uint8)
+            dist.scatter(mine, parts, src=self._global(root), group=self.group)
+            self._h2d(recv, mine)
+            return 0
+        except Exception as e:
+            print("TorchDistComm.scatter failed:", e, flush=True)
+            return 1
+
+    def close(self):
+        pass
+
+
+class SlabSolver(GeometricMultigridPoissonSolver):
+    """GeometricMultigridPoissonSolver on one Z-slab per rank (mgps_create_slab).
+
+    labels: the WHOLE solver grid (nz, ny, nx) uint8; weights: this rank's slab only -- wx, wy with
+    nz/size planes, wz with nz/size + 1.  Grids of this solver hold the rank's owned planes; they
+    come from new_grid()/to_device(), which surround them with the two ghost planes the exchange
+    writes into."""
+
+    def __init__(self, labels, slab_weights, mg_levels, use_gauss_seidel, comm, device=None, options=None):
+        labels = _np_u8(labels)
+        w = [_np_f32(a) for a in slab_weights]
+        nz, ny, nx = labels.shape
+        nzl = nz // comm.size
+        assert nz % comm.size == 0, "nz must divide evenly over the ranks"
+        assert w[0].shape == (nzl, ny, nx + 1) and w[1].shape == (nzl, ny + 1, nx) and w[2].shape == (nzl + 1, ny, nx)
+        opt = options if options is not None else default_options()
+        if device is not None:
+            opt.device = torch.device(device).index if not isinstance(device, int) else device
+        self.comm = comm
+        self.h = C.c_void_p()
+        check(
+            lib().mgps_create_slab(
+                C.byref(self.h), nx, ny, nz, _p(labels), _p(w[0]), _p(w[1]), _p(w[2]), int(mg_levels),
+                int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct),
+            )
+        )
+        self.shape = (nzl, ny, nx)
+        self.global_shape = (nz, ny, nx)
+        self.use_gauss_seidel = bool(use_gauss_seidel)
+        dev_index = opt.device if opt.device >= 0 else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        self.use_torch_stream()
+
+    @property
+    def distributed_levels(self):
+        return lib().mgps_distributed_levels(self.h)
+
+    def slab_range(self, level=0):
+        z0, z1 = C.c_int(), C.c_int()
+        check(lib().mgps_slab_range(self.h, level, C.byref(z0), C.byref(z1)), self.h)
+        return z0.value, z1.value
+
+    def new_grid(self, level=0):
+        nz, ny, nx = self.level_shape(level)
+        padded = torch.zeros((nz + 2, ny, nx), dtype=torch.float32, device=self.device)
+        return padded[1:-1]  # contiguous view; the storage keeps the ghost planes alive
+
+    def to_device(self, a, level=0):
+        g = self.new_grid(level)
+        g.copy_(torch.from_numpy(_np_f32(a)))
+        return g
+
+    def gather_global(self, grid, level=0):
+        """All ranks' owned planes of `grid`, concatenated in z, as a numpy array on every rank."""
+        group = getattr(self.comm, "group", None)
+        local = grid.detach().contiguous()
+        if dist.get_backend(group) != "nccl":
+            local = local.cpu()
+        parts = [torch.empty_like(local) for _ in range(self.comm.size)]
+        dist.all_gather(parts, local, group=group)
+        return torch.cat(parts).cpu().numpy()

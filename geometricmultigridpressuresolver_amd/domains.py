@@ -205,15 +205,45 @@ def expand_domain(base_lab, base_weights, levels=None, solver_shape=None):
     return lab, weights, pad, levels
 
 
+def interior_cube_slab(n, levels, z0, z1, dtype=np.float32):
+    """The interior-liquid cube of BASELINE configs 1, 2, 4 written down directly (no N^3 float
+    temporaries, so it scales to 1024^3): labels of the WHOLE N^3 grid plus the face weights of the
+    planes [z0, z1) only.  Identical to buildSimpleDomain(g = N - 2p, band 1) + expansion +
+    setBoundaryCellLabels: p = 2^(L-1) EXTERIOR cells per side, a one-cell DIRICHLET shell, the
+    outermost liquid layer BOUNDARY (it touches the shell), weight 1 on every face that touches a
+    liquid cell (Test.cpp:597-618)."""
+    pad = 2 ** (levels - 1)
+    assert n - 2 * pad >= 4, "grid too small for this many levels"
+    lo, hi = pad + 1, n - pad - 1  # liquid cells: [lo, hi) on every axis
+    lab = np.full((n, n, n), EXTERIOR, dtype=np.uint8)
+    lab[pad : n - pad, pad : n - pad, pad : n - pad] = DIRICHLET
+    lab[lo:hi, lo:hi, lo:hi] = BOUNDARY
+    lab[lo + 1 : hi - 1, lo + 1 : hi - 1, lo + 1 : hi - 1] = INTERIOR
+    nzl = z1 - z0
+    k0, k1 = max(lo, z0) - z0, min(hi, z1) - z0  # liquid planes of the slab, local indices
+    weights = []
+    for axis in range(3):
+        shape = [nzl, n, n]
+        shape[2 - axis] += 1
+        w = np.zeros(shape, dtype=dtype)
+        if axis == 0:
+            if k1 > k0:
+                w[k0:k1, lo:hi, lo : hi + 1] = 1
+        elif axis == 1:
+            if k1 > k0:
+                w[k0:k1, lo : hi + 1, lo:hi] = 1
+        else:  # z faces: global face planes [lo, hi] intersected with the slab's [z0, z1]
+            f0, f1 = max(lo, z0) - z0, min(hi + 1, z1 + 1) - z0
+            if f1 > f0:
+                w[f0:f1, lo:hi, lo:hi] = 1
+        weights.append(w)
+    return lab, weights, 1.0 / n
+
+
 def interior_cube(n, levels, dtype=np.float32):
     """BASELINE configs 1, 2, 4: N^3 solver grid, 2^(L-1) EXTERIOR cells per side, a one-cell
-    DIRICHLET shell, INTERIOR inside (buildSimpleDomain(g = N - 2p, band 1) + expansion)."""
-    pad = 2 ** (levels - 1)
-    g = n - 2 * pad
-    assert g >= 4, "grid too small for this many levels"
-    base_lab, base_w, _ = build_simple_domain(g, 1, dtype=dtype)
-    lab, w, off, _ = expand_domain(base_lab, base_w, levels=levels, solver_shape=(n, n, n))
-    return lab, w, 1.0 / n
+    DIRICHLET shell, liquid inside (buildSimpleDomain(g = N - 2p, band 1) + expansion)."""
+    return interior_cube_slab(n, levels, 0, n, dtype=dtype)
 
 
 def free_surface_pool(n, levels, use_solid=True, dtype=np.float32):
@@ -230,12 +260,19 @@ def active_mask(lab):
     return (lab == INTERIOR) | (lab == BOUNDARY)
 
 
-def random_rhs(lab, h, seed=RHS_SEED, dtype=np.float32):
-    """U(0,1) * h^2 on active cells, 0 elsewhere (Test.cpp:1180-1194 with a fixed PCG64 seed)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    b = rng.random(lab.shape, dtype=np.float64) * (h * h)
-    b[~active_mask(lab)] = 0.0
-    return b.astype(dtype)
+def random_rhs(lab, h, seed=RHS_SEED, dtype=np.float32, z0=0, z1=None):
+    """U(0,1) * h^2 on active cells, 0 elsewhere (Test.cpp:1180-1194 with fixed PCG64 seeds).  One
+    generator per global z-plane (seed + k), so a Z-slab [z0, z1) of the field can be produced
+    without generating the rest; returns only those planes."""
+    nz = lab.shape[0]
+    z1 = nz if z1 is None else z1
+    out = np.zeros((z1 - z0,) + lab.shape[1:], dtype=dtype)
+    for k in range(z0, z1):
+        act = active_mask(lab[k])
+        if act.any():
+            plane = np.random.Generator(np.random.PCG64(seed + k)).random(lab.shape[1:]) * (h * h)
+            out[k - z0] = np.where(act, plane, 0.0)
+    return out
 
 
 def delta_rhs(lab, grid_size, offset, h, amplitude=1000.0, dtype=np.float32):

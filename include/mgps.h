@@ -194,6 +194,64 @@ int mgps_scale_vector(mgps_solver *h, int level, float *v_dev, double scale);
 int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tolerance,
                    int max_iterations, int use_mg_preconditioner, mgps_pcg_stats *stats);
 
+/* ---- multi-GPU: Z-slab partition of the fine grid -------------------------------------------
+ * The reference is single-process shared memory (TBB over 16^3 tiles); it has no counterpart for
+ * anything in this section.  One process per GPU.  The solver grid is cut along z (the slowest
+ * axis, so a slab and a ghost plane are contiguous) into `size` slabs of nz/size planes; rank r owns
+ * planes [r*nz/size, (r+1)*nz/size).  Level l stays distributed while its per-rank plane count is a
+ * multiple of 16 (keeps the 16^3 Gauss-Seidel tile colouring identical to the single-GPU run and
+ * restriction/prolongation rank-local up to one ghost plane); the first level that is not, and
+ * everything coarser, is gathered to rank 0 and solved there ("collapse").  Before every operator
+ * that reads across the cut one ghost plane per side is exchanged with the two Z-neighbours.
+ *
+ * The transport is a small vtable so that the same orchestration runs over RCCL (production,
+ * mgps_comm_create_rccl: ncclSend/ncclRecv pairs in one group on the solver's stream over xGMI) or
+ * over anything else (the test-suite plugs torch.distributed/gloo in through it).
+ * All pointers handed to exchange / gather / scatter are device pointers; `hip_stream` is the
+ * solver's stream: an implementation either enqueues on it or synchronises it and blocks. */
+typedef struct mgps_comm {
+    int struct_size; /* sizeof(mgps_comm) */
+    int rank, size;
+    void *user;
+    /* send `send_lo` to rank-1 and receive `recv_lo` from it; the same with rank+1 for *_hi.
+     * The lo pair is NULL on rank 0, the hi pair on the last rank. */
+    int (*exchange)(void *user, const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi,
+                    size_t bytes, void *hip_stream);
+    /* in-place all-reduce of `count` host doubles; op 0 = sum, 1 = max */
+    int (*allreduce)(void *user, double *values, int count, int op);
+    /* root receives size*bytes (rank order) into recv_dev; the others pass recv_dev = NULL */
+    int (*gather)(void *user, const void *send_dev, void *recv_dev, size_t bytes, int root, void *hip_stream);
+    /* root sends chunk r of send_dev to rank r; everybody receives `bytes` into recv_dev */
+    int (*scatter)(void *user, const void *send_dev, void *recv_dev, size_t bytes, int root, void *hip_stream);
+    void (*destroy)(void *user);
+} mgps_comm;
+
+/* RCCL transport.  Rank 0 calls mgps_rccl_unique_id and ships the 128 bytes to the other ranks by
+ * any means (the bench uses torch.distributed.broadcast); then every rank calls
+ * mgps_comm_create_rccl, which runs ncclCommInitRank on `device`. */
+int mgps_rccl_unique_id(unsigned char out_id[128]);
+int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned char id[128], int device);
+void mgps_comm_destroy(mgps_comm *comm);
+
+/* The slab form of the constructor.  labels_global_host: the WHOLE solver grid's labels
+ * (nx*ny*nz_global bytes, they are small); the face weights only for this rank's slab: wx / wy hold
+ * the owned planes, wz the owned planes plus the closing face plane (nz_slab + 1 planes).
+ * Grids passed to the operators of a slab solver hold the owned planes and must come from
+ * mgps_grid_alloc (which surrounds them with the two ghost planes).  The vtable is copied; the
+ * transport state behind `comm->user` stays owned by the caller, who destroys it (mgps_comm_destroy)
+ * after the solver. */
+int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
+                     const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
+                     int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm);
+/* owned plane range [z0, z1) of `level` on this rank (levels past the distributed ones: the range
+ * of the collapse level) and the number of distributed levels */
+int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1);
+int mgps_distributed_levels(const mgps_solver *h);
+/* raw copies between host memory and device memory of the solver's device (used by transports
+ * that stage through the host) */
+int mgps_copy_to_host(mgps_solver *h, void *dst_host, const void *src_dev, size_t bytes);
+int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, size_t bytes);
+
 /* ---- measurement hooks (the reference's UT_StopWatch scopes, MG.cpp:461-492 "Smoother time") ----
  * While enabled, HIP events bracket every fine-level full-domain smoother launch group inside
  * mgps_apply_vcycle (the Jacobi sweep, or the two tile-coloured Gauss-Seidel half sweeps).

@@ -1,0 +1,85 @@
+"""Worker of tests/test_distributed.py: run under torch.distributed.run with 2+ ranks.
+
+mode "gpu":  every rank drives a SlabSolver on cuda:0 (ranks share the GPU) over TorchDistComm/gloo
+             and compares V-cycle / operators / MG-PCG with a whole-grid solver on the same device.
+Prints "WORKER_OK <rank>" on success.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+def gpu_mode():
+    import geometricmultigridpressuresolver_amd as G
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd.distributed import SlabSolver, TorchDistComm
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    for kind, g, levels, shape in (("solid", 48, 5, (128, 128, 128)), ("simple", 40, 4, (64, 64, 64))):
+        lab, w, off, lev, dx = make_domain(kind, g, levels, shape)
+        nz = lab.shape[0]
+        nzl = nz // size
+        z0, z1 = rank * nzl, (rank + 1) * nzl
+        slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
+        b_glob = D.random_rhs(lab, dx)
+        for use_gs in (False, True):
+            comm = TorchDistComm()
+            slab = SlabSolver(lab, slab_w, lev, use_gs, comm, device=0)
+            whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
+            assert slab.slab_range(0) == (z0, z1), (slab.slab_range(0), z0, z1)
+            assert slab.getMGLevels() == whole.getMGLevels()
+            assert 1 <= slab.distributed_levels < slab.getMGLevels()
+            bw = whole.to_device(b_glob)
+            bs = slab.to_device(b_glob[z0:z1])
+            # operators across the cut
+            xw, xs = whole.to_device(b_glob * 3.0), slab.to_device(b_glob[z0:z1] * 3.0)
+            yw, ys = whole.new_grid(), slab.new_grid()
+            whole.applyPoissonMatrix(yw, xw)
+            slab.applyPoissonMatrix(ys, xs)
+            assert np.array_equal(slab.gather_global(ys), yw.cpu().numpy())
+            assert abs(slab.dotProduct(xs, bs) - whole.dotProduct(xw, bw)) <= 1e-12 * abs(whole.dotProduct(xw, bw))
+            assert slab.infNorm(xs) == whole.infNorm(xw)
+            # V-cycles: same arithmetic per cell, so the slab run reproduces the single-GPU run
+            xw, xs = whole.new_grid(), slab.new_grid()
+            for it in range(2):
+                whole.applyVCycle(xw, bw, it > 0)
+                slab.applyVCycle(xs, bs, it > 0)
+                err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
+                assert err < 1e-6, (kind, use_gs, it, err)
+            # MG-PCG
+            bd = D.delta_rhs(lab, g, off, dx)
+            xw, xs = whole.new_grid(), slab.new_grid()
+            sw = whole.solveGeometricConjugateGradient(xw, whole.to_device(bd), 1e-5, 200, True)
+            ss = slab.solveGeometricConjugateGradient(xs, slab.to_device(bd[z0:z1]), 1e-5, 200, True)
+            assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+            assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
+            if rank == 0:
+                print(f"  {kind} gs={use_gs}: D={slab.distributed_levels} exchanges={comm.exchanges} pcg it {ss['iterations']}", flush=True)
+            slab.close()
+            whole.close()
+            dist.barrier()
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    if mode == "gpu":
+        gpu_mode()
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    dist.barrier()
+    print(f"WORKER_OK {dist.get_rank()}", flush=True)
+    dist.destroy_process_group()
