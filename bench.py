@@ -5,6 +5,10 @@ fine-level smoother (BASELINE.json metric), on synthetic interior-liquid cubes.
     python bench.py --gpus N --steps K --warmup W [--size 256|512|1024] [--levels L]
                     [--smoother jacobi|gs] [--no-cpu]
 
+Default workload: BASELINE config 4, the 1024^3 interior-liquid cube (7 levels), on every N, so the
+per-N values form the strong-scaling curve the metric asks for; N > 1 splits the grid into Z-slabs
+(one rank per GPU, RCCL ghost-plane exchange, coarse tail collapsed to rank 0).
+
 A "step" is one applyVCycle(useInitialGuess=true) on grids that are already
 resident in HBM.  Rank 0 prints ONE JSON line.  `roofline` is the fine-level full-domain smoother
 (the dominant kernel): algorithmic bytes (13 B per allocated fine cell) over
@@ -32,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=0, help="solver grid edge N (default: 256 = BASELINE config 2)")
+    ap.add_argument("--size", type=int, default=0, help="solver grid edge N (default 1024 = BASELINE config 4; 256 and 512 are the other metric sizes)")
     ap.add_argument("--levels", type=int, default=0, help="multigrid levels (default: coarsest level 16^3)")
     ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -107,35 +111,53 @@ def main():
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
 
-    n = args.size or 256
+    n = args.size or 1024
     levels = args.levels or default_levels(n)
     use_gs = args.smoother == "gs"
-    if world > 1:
-        raise SystemExit("multi-GPU slab path not built yet")
+    assert n % world == 0 and (n // world) % 16 == 0, "grid planes per rank must be a multiple of 16"
+    nzl = n // world
+    z0, z1 = rank * nzl, (rank + 1) * nzl
 
-    lab, w, h = D.interior_cube(n, levels)
-    solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank)
-    b = solver.to_device(D.random_rhs(lab, h))
-    x = solver.new_grid()
+    # every rank: labels of the whole grid (1 byte per cell), weights and rhs of its own Z-slab only
+    lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
+    if world > 1:
+        from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
+
+        comm = RcclComm(device=local_rank)
+        solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank)
+    else:
+        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank)
     del w
+    b = solver.to_device(D.random_rhs(lab, h, z0=z0, z1=z1))
+    x = solver.new_grid()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     solver.applyVCycle(x, b, False)
     for _ in range(args.warmup):
         solver.applyVCycle(x, b, True)
     solver.profile_enable(True)
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.applyVCycle(x, b, True)
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     smooth_ms, smooth_groups = solver.profile_read()
     solver.profile_enable(False)
+    if world > 1:  # the job is as slow as its slowest rank
+        t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, smooth_ms = float(t[0]), float(t[1])
 
-    cells = float(n) ** 3
+    cells = float(n) ** 3  # whole job; every rank sweeps cells / world of them
     sweeps_per_group = 1  # Jacobi: one sweep; GS: two half sweeps touch every tile once = one sweep
     t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group
-    achieved = SMOOTHER_BYTES_PER_CELL * cells / t_sweep / 1e9
+    achieved = SMOOTHER_BYTES_PER_CELL * (cells / world) / t_sweep / 1e9  # per GPU
     vps = args.steps / elapsed
     out = {
         "metric": "V-cycles/sec",
@@ -158,6 +180,7 @@ def main():
             "levels": levels,
             "smoother": "tiled_gs" if use_gs else "jacobi",
             "parallelism": f"zslab{world}",
+            "distributed_levels": solver.distributed_levels if world > 1 else 0,
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
         "roofline": {
@@ -170,6 +193,8 @@ def main():
             "traffic": None,
             "ms_per_launch": t_sweep * 1e3,
             "launches": smooth_groups,
+            "cells_per_launch": cells / world,
+            "note": "per GPU; achieved = 13 B x cells per launch / mean launch time (HIP events on the solver's stream)",
         },
     }
     if not args.no_cpu and rank == 0 and world == 1:

@@ -73,11 +73,42 @@ def gpu_mode():
             dist.barrier()
 
 
+def rccl_single_rank_mode():
+    """World size 1 over the library's own RCCL transport: exercises dlopen(librccl), the unique id,
+    ncclCommInitRank, the all-reduce and the root-only gather / scatter of the collapse."""
+    import geometricmultigridpressuresolver_amd as G
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
+
+    torch.cuda.set_device(0)
+    lab, w, off, lev, dx = make_domain("solid", 48, 5, (128, 128, 128))
+    comm = RcclComm(device=0)
+    b_glob = D.random_rhs(lab, dx)
+    for use_gs in (False, True):
+        slab = SlabSolver(lab, w, lev, use_gs, comm, device=0)
+        whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
+        xs, xw = slab.new_grid(), whole.new_grid()
+        bs, bw = slab.to_device(b_glob), whole.to_device(b_glob)
+        for it in range(2):
+            slab.applyVCycle(xs, bs, it > 0)
+            whole.applyVCycle(xw, bw, it > 0)
+        assert rel_l2(xs.cpu().numpy(), xw.cpu().numpy()) < 1e-6
+        assert abs(slab.dotProduct(xs, bs) - whole.dotProduct(xw, bw)) <= 1e-12 * abs(whole.dotProduct(xw, bw))
+        st = slab.solveGeometricConjugateGradient(slab.new_grid(), bs, 1e-5, 100, True)
+        assert st["outcome"] == "converged"
+        slab.close()
+        whole.close()
+    comm.close()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     dist.init_process_group("gloo")
     if mode == "gpu":
         gpu_mode()
+    elif mode == "rccl1":
+        rccl_single_rank_mode()
     else:
         raise SystemExit(f"unknown mode {mode}")
     dist.barrier()

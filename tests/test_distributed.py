@@ -39,3 +39,9 @@ def run_workers(mode, nproc, timeout):
 def test_two_slabs_match_single_gpu():
     out = run_workers("gpu", 2, 420)
     print(out[-1500:])
+
+
+@pytest.mark.gpu
+def test_rccl_transport_single_rank():
+    """The production transport (librccl through dlopen) with a world of one."""
+    run_workers("rccl1", 1, 300)
