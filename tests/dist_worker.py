@@ -28,9 +28,11 @@ def gpu_mode():
 
     rank, size = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    for kind, g, levels, shape in (("solid", 48, 5, (128, 128, 128)), ("simple", 40, 4, (64, 64, 64))):
+    # liquid must straddle every slab cut, otherwise the exchanges carry nothing
+    for kind, g, levels, shape in (("solid", 96, 5, (128, 128, 128)), ("simple", 40, 4, (64, 64, 64))):
         lab, w, off, lev, dx = make_domain(kind, g, levels, shape)
         nz = lab.shape[0]
+        assert all(D.active_mask(lab[c - 1 : c + 1]).any() for c in range(nz // size, nz, nz // size))
         nzl = nz // size
         z0, z1 = rank * nzl, (rank + 1) * nzl
         slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
@@ -73,6 +75,59 @@ def gpu_mode():
             dist.barrier()
 
 
+def cpu_mode():
+    """Slab emulation on the CPU (no GPU involved): tests/slab_emulation.py over gloo vs the
+    whole-grid oracle."""
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from oracle.mg_oracle import Oracle
+    from slab_emulation import SlabEmulation
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    orc = Oracle()
+    orc.set_threads(2)
+    # liquid must straddle every slab cut (z = 16, 32, 48), otherwise the exchanges carry nothing
+    for kind, g, levels, shape in (("solid", 48, 4, (64, 64, 64)), ("simple", 56, 3, (64, 64, 64))):
+        lab, w, off, lev, dx = make_domain(kind, g, levels, shape, dtype=np.float64)
+        lab32 = lab.astype(np.int32)
+        assert all(D.active_mask(lab[c - 1 : c + 1]).any() for c in range(64 // size, 64, 64 // size))
+        b_glob = D.random_rhs(lab, dx, dtype=np.float64)
+        for use_gs in (False, True):
+            emu = SlabEmulation(orc, lab32, w, lev, use_gs)
+            z0, z1 = emu.z0[0], emu.z1[0]
+            x, b = emu.new(0), emu.new(0)
+            emu.owned(b)[:] = b_glob[z0:z1]
+            whole = orc.solver(lab32, w, lev, use_gs)
+            x_ref = np.zeros(lab.shape)
+            for it in range(2):
+                emu.vcycle(x, b, it > 0)
+                whole.apply_vcycle(x_ref, b_glob, it > 0)
+                err = np.abs(emu.owned(x) - x_ref[z0:z1]).max() / np.abs(x_ref).max()
+                assert err < 1e-13, (kind, use_gs, it, err)
+            if rank == 0:
+                print(f"  cpu emulation {kind} gs={use_gs}: D={emu.D} of {emu.L} levels, {emu.exchanges} exchanges, err {err:.1e}", flush=True)
+            # dropping the exchange in front of the Jacobi sweep / GS passes must break the match:
+            # proves the comparison is sensitive to the schedule
+            broken = SlabEmulation(orc, lab32, w, lev, use_gs)
+            real_exchange, count = broken.exchange, [0]
+
+            def lossy(a):
+                count[0] += 1
+                if count[0] % 4:
+                    real_exchange(a)
+
+            broken.exchange = lossy
+            xb = broken.new(0)
+            broken.vcycle(xb, b, False)
+            x_one = np.zeros(lab.shape)
+            whole.apply_vcycle(x_one, b_glob, False)
+            bad = np.array([np.abs(broken.owned(xb) - x_one[z0:z1]).max()])
+            t = torch.from_numpy(bad)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert t.item() > 1e-9 * np.abs(x_one).max(), "schedule check is not sensitive"
+            dist.barrier()
+
+
 def rccl_single_rank_mode():
     """World size 1 over the library's own RCCL transport: exercises dlopen(librccl), the unique id,
     ncclCommInitRank, the all-reduce and the root-only gather / scatter of the collapse."""
@@ -82,7 +137,7 @@ def rccl_single_rank_mode():
     from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
 
     torch.cuda.set_device(0)
-    lab, w, off, lev, dx = make_domain("solid", 48, 5, (128, 128, 128))
+    lab, w, off, lev, dx = make_domain("solid", 96, 5, (128, 128, 128))
     comm = RcclComm(device=0)
     b_glob = D.random_rhs(lab, dx)
     for use_gs in (False, True):
@@ -109,6 +164,8 @@ if __name__ == "__main__":
         gpu_mode()
     elif mode == "rccl1":
         rccl_single_rank_mode()
+    elif mode == "cpu":
+        cpu_mode()
     else:
         raise SystemExit(f"unknown mode {mode}")
     dist.barrier()

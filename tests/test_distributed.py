@@ -1,5 +1,9 @@
 """Multi-rank tests of the Z-slab path (one process per rank, torch.distributed.run, 127.0.0.1).
 
+* cpu (gloo, world size 2 and 4): the exchange / collapse schedule restated over the oracle's
+  operators (tests/slab_emulation.py) reproduces the whole-grid oracle to round-off, and stops doing so
+  when exchanges are dropped.
+
 * gpu: two ranks share the one GPU of the test box; the slab orchestration of libmgps.so (ghost
   exchange before every operator that reads across the cut, collapse of the coarse tail to rank 0)
   runs over TorchDistComm/gloo and must reproduce the single-GPU solver.  Only the transport differs
@@ -45,3 +49,9 @@ def test_two_slabs_match_single_gpu():
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_slab_schedule_emulation_cpu(nproc):
+    out = run_workers("cpu", nproc, 600)
+    assert "cpu emulation" in out
