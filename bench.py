@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
+                    help="free_surface_pcg = BASELINE config 3 (single GPU): MG-PCG to 1e-5 on the free-surface pool")
     return ap.parse_args()
 
 
@@ -90,8 +92,42 @@ def cpu_baseline(n, levels, use_gs, budget_s):
     }
 
 
+def free_surface_pcg(args):
+    """BASELINE config 3: N^3 free-surface pool (sine liquid surface, ghost-fluid weights up to 1/0.01,
+    solid box with cut-cell weights), MG-preconditioned CG (tiled GS smoother, as the plugin) to 1e-5 on
+    the delta + random rhs.  Not the headline metric; prints its own JSON line."""
+    import numpy as np
+    import torch
+
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    n = args.size or 512
+    levels = args.levels or default_levels(n)
+    torch.cuda.set_device(0)
+    lab, w, h = D.free_surface_pool(n, levels)
+    pad = 2 ** (levels - 1)
+    b = D.delta_rhs(lab, n - 2 * pad, pad, h) + D.random_rhs(lab, h)
+    out = {"metric": "MG-PCG solve", "grid": n, "levels": levels, "tolerance": 1e-5,
+           "active_cells": int(D.active_mask(lab).sum()), "general_boundary_note": "ghost-fluid + cut-cell rows"}
+    for use_gs in (True, False):
+        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=0)
+        bd = solver.to_device(b)
+        best = None
+        for rep in range(3):
+            x = solver.new_grid()
+            st = solver.solveGeometricConjugateGradient(x, bd, 1e-5, 2500, True)
+            if best is None or st["solve_ms"] < best["solve_ms"]:
+                best = st
+        out["tiled_gs" if use_gs else "jacobi"] = {k: best[k] for k in ("outcome", "iterations", "rel_residual_recomputed", "solve_ms")}
+        solver.close()
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload == "free_surface_pcg":
+        return free_surface_pcg(args)
     import numpy as np
     import torch
 
@@ -197,6 +233,17 @@ def main():
             "note": "per GPU; achieved = 13 B x cells per launch / mean launch time (HIP events on the solver's stream)",
         },
     }
+    # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
+    # (profiles/r01_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+        key = [k for k in pmc if k.startswith(f"stencilQuadKernel<0>@{n}^3")]
+        if key and not use_gs and world == 1:
+            out["roofline"]["traffic"] = pmc[key[0]]["traffic_bytes"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch; L2<->fabric bytes incl. Infinity-Cache hits)"
+            out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * cells
+    except Exception:
+        pass
     if not args.no_cpu and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds)
     if rank == 0:
