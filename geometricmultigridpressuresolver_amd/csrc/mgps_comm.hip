@@ -92,20 +92,16 @@ struct RcclState {
         }                                                                            \
     } while (0)
 
-int rcclExchange(void *user, const void *sendLo, void *recvLo, const void *sendHi, void *recvHi, size_t bytes,
-                 void *stream)
+int rcclExchange(void *user, const void *sendLo, size_t sendLoBytes, void *recvLo, size_t recvLoBytes,
+                 const void *sendHi, size_t sendHiBytes, void *recvHi, size_t recvHiBytes, void *stream)
 {
     auto *s = static_cast<RcclState *>(user);
     hipStream_t st = static_cast<hipStream_t>(stream);
     NCCL_TRY(gApi.GroupStart());
-    if (sendLo) {
-        NCCL_TRY(gApi.Send(sendLo, bytes, ncclChar, s->rank - 1, s->comm, st));
-        NCCL_TRY(gApi.Recv(recvLo, bytes, ncclChar, s->rank - 1, s->comm, st));
-    }
-    if (sendHi) {
-        NCCL_TRY(gApi.Send(sendHi, bytes, ncclChar, s->rank + 1, s->comm, st));
-        NCCL_TRY(gApi.Recv(recvHi, bytes, ncclChar, s->rank + 1, s->comm, st));
-    }
+    if (sendLo && sendLoBytes) NCCL_TRY(gApi.Send(sendLo, sendLoBytes, ncclChar, s->rank - 1, s->comm, st));
+    if (recvLo && recvLoBytes) NCCL_TRY(gApi.Recv(recvLo, recvLoBytes, ncclChar, s->rank - 1, s->comm, st));
+    if (sendHi && sendHiBytes) NCCL_TRY(gApi.Send(sendHi, sendHiBytes, ncclChar, s->rank + 1, s->comm, st));
+    if (recvHi && recvHiBytes) NCCL_TRY(gApi.Recv(recvHi, recvHiBytes, ncclChar, s->rank + 1, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
     return 0;
 }

@@ -242,6 +242,19 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
             restDiag.push_back(6);
         }
     }
+    // band cells of the planes a band-only ghost exchange moves (see HostLevel::bandPlane)
+    {
+        const int planes[4] = {z0, z0 - 1, z1 - 1, z1};
+        for (int q = 0; q < 4; ++q) {
+            L.bandPlane[q].clear();
+            if (planes[q] < 0 || planes[q] >= gd.nz) continue;
+            const size_t plo = size_t(planes[q]) * plane, phi = plo + plane;
+            for (int32_t gcI : G.band) {
+                const size_t gc = size_t(gcI);
+                if (gc >= plo && gc < phi) L.bandPlane[q].push_back(int32_t(ptrdiff_t(gc) - ptrdiff_t(lo)));
+            }
+        }
+    }
     L.numBoundary = int32_t(general.size());
     L.bandDev = general;
     L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());

@@ -49,6 +49,11 @@ struct HostLevel {
     // neighbour is not active), q = 6 the diagonal.
     std::vector<float> rows;
     std::vector<uint8_t> codes;      // device cell codes (see kCodeSimple): ghost plane, owned planes, ghost plane
+    // slab runs: band cells of the four planes a band-only ghost exchange touches, as offsets from
+    // owned cell 0 in reference band order (both neighbours derive them from the same global band
+    // list, so sender's pack order == receiver's unpack order): [0] owned plane 0 (sent down),
+    // [1] ghost plane below (received), [2] owned top plane (sent up), [3] ghost plane above (received)
+    std::vector<int32_t> bandPlane[4];
     // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
     // kind: "pure" = all 4096 cells INTERIOR (no label or weight look-ups needed), "mixed" = the rest
     std::vector<int32_t> tilesOdd, tilesEven;          // all active tiles of the colour (API / tests)
@@ -107,6 +112,10 @@ int launchMulMasked(void *stream, const GridP &g, float *dst, const float *a, co
 constexpr int kReducePartials = 2048;
 int launchReduce(void *stream, int kind, const GridP &g, const float *a, const float *b, double *partials,
                  double *resultDev);
+int launchZero(void *stream, float *a, size_t count);
+// buf[t] = a[idx[t]] / a[idx[t]] = buf[t]; idx are offsets from owned cell 0 (negative in the lower ghost plane)
+int launchPack(void *stream, float *buf, const float *a, const int32_t *idx, int n);
+int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, int n);
 
 }  // namespace mgps
 

@@ -779,6 +779,33 @@ __global__ __launch_bounds__(256) void reduceFinalKernel(int nparts, const doubl
     if (threadIdx.x == 0) *result = total;
 }
 
+// plain fill with zeros (grid-stride, 16-byte stores); `a` only needs 4-byte alignment
+__global__ __launch_bounds__(256) void zeroKernel(float *__restrict__ a, size_t n)
+{
+    const size_t head = min(n, (size_t(16) - (reinterpret_cast<size_t>(a) & 15)) / 4 & 3);
+    float4 *v = reinterpret_cast<float4 *>(a + head);
+    const size_t nq = (n - head) >> 2;
+    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x)
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) a[threadIdx.x] = 0.f;
+        const size_t tail = head + (nq << 2);
+        if (tail + threadIdx.x < n) a[tail + threadIdx.x] = 0.f;
+    }
+}
+
+// band-only ghost exchange of a slab run: gather / scatter the band cells of one x-y plane
+__global__ void packKernel(float *__restrict__ buf, const float *__restrict__ a, const int32_t *__restrict__ idx, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) buf[t] = a[ptrdiff_t(idx[t])];
+}
+__global__ void unpackKernel(float *__restrict__ a, const float *__restrict__ buf, const int32_t *__restrict__ idx, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[ptrdiff_t(idx[t])] = buf[t];
+}
+
 inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + per - 1) / per); }
 
 }  // namespace
@@ -924,6 +951,23 @@ int launchDiagInverse(void *stream, const GridP &g, float *dinv)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     diagInverseKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(g, dinv);
+    return int(hipGetLastError());
+}
+
+int launchZero(void *stream, float *a, size_t count)
+{
+    if (!count) return 0;
+    zeroKernel<<<streamingBlocks(count >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(a, count);
+    return int(hipGetLastError());
+}
+int launchPack(void *stream, float *buf, const float *a, const int32_t *idx, int n)
+{
+    if (n > 0) packKernel<<<blocksFor(size_t(n), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(buf, a, idx, n);
+    return int(hipGetLastError());
+}
+int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, int n)
+{
+    if (n > 0) unpackKernel<<<blocksFor(size_t(n), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(a, buf, idx, n);
     return int(hipGetLastError());
 }
 

@@ -39,6 +39,10 @@ struct DevLevel {
     int npure[2] = {0, 0}, nmixed[2] = {0, 0};
     int32_t *tileBndStart = nullptr;
     int z0 = 0, z1 = 0;  // owned global plane range
+    // band-only ghost exchange (slab runs): index lists + staging buffers, see HostLevel::bandPlane
+    int32_t *bandPlane[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nbandPlane[4] = {0, 0, 0, 0};
+    float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -162,6 +166,10 @@ void freeAll(mgps_solver *h)
             (void)hipFree(L.mixed[c]);
         }
         (void)hipFree(L.tileBndStart);
+        for (int q = 0; q < 4; ++q) {
+            (void)hipFree(L.bandPlane[q]);
+            (void)hipFree(L.packBuf[q]);
+        }
     }
     for (int a = 0; a < 3; ++a) (void)hipFree(h->w[a]);
     (void)hipFree(h->cinv);
@@ -191,35 +199,53 @@ int checkLevel(mgps_solver *h, int level, const char *who)
 
 // ---- slab plumbing -------------------------------------------------------------------------------
 
-// refresh the two ghost planes of grid `a` of level l from the Z-neighbours
-int exchangeGhosts(mgps_solver *h, int l, float *a)
+// Refresh the two ghost planes of grid `a` of level l from the Z-neighbours.  GHOST_FULL moves the
+// whole planes; GHOST_BAND only their band cells, packed (valid when nothing but band passes touched
+// `a` since its ghosts were last complete -- a band pass changes band cells only).
+enum GhostMode { GHOST_NONE = 0, GHOST_FULL = 1, GHOST_BAND = 2 };
+
+int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
 {
-    if (!h->dist) return MGPS_OK;
-    const DevLevel &L = h->lv[l];
+    if (!h->dist || mode == GHOST_NONE) return MGPS_OK;
+    DevLevel &L = h->lv[l];
     const size_t plane = size_t(L.d.nx) * L.d.ny;
     const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
-    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, lo ? a - plane : nullptr,
-                                  hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, hi ? a + size_t(L.d.nz) * plane : nullptr,
-                                  plane * sizeof(float), h->stream));
+    if (mode == GHOST_FULL) {
+        const size_t bytes = plane * sizeof(float);
+        MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, bytes, lo ? a - plane : nullptr, bytes,
+                                      hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, bytes,
+                                      hi ? a + size_t(L.d.nz) * plane : nullptr, bytes, h->stream));
+        return MGPS_OK;
+    }
+    const int *n = L.nbandPlane;
+    if (lo) MGPS_LAUNCH(h, launchPack(h->stream, L.packBuf[0], a, L.bandPlane[0], n[0]));
+    if (hi) MGPS_LAUNCH(h, launchPack(h->stream, L.packBuf[2], a, L.bandPlane[2], n[2]));
+    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? L.packBuf[0] : nullptr, size_t(n[0]) * sizeof(float),
+                                  lo ? L.packBuf[1] : nullptr, size_t(n[1]) * sizeof(float),
+                                  hi ? L.packBuf[2] : nullptr, size_t(n[2]) * sizeof(float),
+                                  hi ? L.packBuf[3] : nullptr, size_t(n[3]) * sizeof(float), h->stream));
+    if (lo) MGPS_LAUNCH(h, launchUnpack(h->stream, a, L.packBuf[1], L.bandPlane[1], n[1]));
+    if (hi) MGPS_LAUNCH(h, launchUnpack(h->stream, a, L.packBuf[3], L.bandPlane[3], n[3]));
     return MGPS_OK;
 }
 
 // ---- level operators -----------------------------------------------------------------------------
 
-int bandPasses(mgps_solver *h, int l, float *x, const float *b, bool ghostsFresh)
+// `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
+int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first)
 {
     DevLevel &L = h->lv[l];
     for (int it = 0; it < h->opt.band_iterations; ++it) {
-        if (!(ghostsFresh && it == 0)) MGPS_TRY(exchangeGhosts(h, l, x));
+        MGPS_TRY(exchangeGhosts(h, l, x, it == 0 ? first : GHOST_BAND));
         MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
     }
     return MGPS_OK;
 }
 
-int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward)
+int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL)
 {
     DevLevel &L = h->lv[l];
-    MGPS_TRY(exchangeGhosts(h, l, x));  // the other colour's tiles across the cut changed in the previous pass
+    MGPS_TRY(exchangeGhosts(h, l, x, ghosts));  // the other colour's tiles across the cut changed in the previous pass
     MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
                                  L.tileBndStart, forward));
     return MGPS_OK;
@@ -227,10 +253,16 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
 
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
+// ghostsFresh: the ghosts of `cur` are known to be complete on entry (all zero after a clear).
+// Ghost traffic of a stroke: whole planes after whatever rewrote the whole grid (the caller's
+// prolongation / initial guess, the full-domain smoother), packed band cells after band passes.
 int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh)
 {
     DevLevel &L = h->lv[l];
-    MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh));
+    const bool bands = h->opt.band_iterations > 0;
+    MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
+    // after the band passes only band cells are stale across the cut -- unless there were none
+    const GhostMode afterBands = bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
     if (timed) {
         if (h->profUsed + 2 > h->profEvents.size()) {
@@ -244,14 +276,14 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     }
     if (h->useGS) {
         if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, afterBands));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_FULL));
         } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, afterBands));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_FULL));
         }
     } else {
-        MGPS_TRY(exchangeGhosts(h, l, cur));
+        MGPS_TRY(exchangeGhosts(h, l, cur, afterBands));
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight));
         std::swap(cur, other);
     }
@@ -259,7 +291,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + 1], h->stream));
         h->profUsed += 2;
     }
-    MGPS_TRY(bandPasses(h, l, cur, b, false));
+    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL));  // the full-domain smoother rewrote everything
     return MGPS_OK;
 }
 
@@ -284,8 +316,8 @@ int collapsedTail(mgps_solver *h)
 int zeroGrid(mgps_solver *h, float *a, const Dims &d, bool withGhosts)
 {
     const size_t plane = size_t(d.nx) * d.ny;
-    if (withGhosts) MGPS_HIP(h, hipMemsetAsync(a - plane, 0, (d.cells() + 2 * plane) * sizeof(float), h->stream));
-    else MGPS_HIP(h, hipMemsetAsync(a, 0, d.cells() * sizeof(float), h->stream));
+    if (withGhosts) MGPS_LAUNCH(h, launchZero(h->stream, a - plane, d.cells() + 2 * plane));
+    else MGPS_LAUNCH(h, launchZero(h->stream, a, d.cells()));
     return MGPS_OK;
 }
 
@@ -321,7 +353,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
                 MGPS_TRY(zeroGrid(h, F.x, F.d, true));  // MG.cpp:566
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
-            MGPS_TRY(exchangeGhosts(h, l, cur[l]));
+            MGPS_TRY(exchangeGhosts(h, l, cur[l], h->opt.band_iterations > 0 ? GHOST_BAND : GHOST_FULL));
             MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f));
             MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
@@ -480,6 +512,12 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     L.nmixed[0] = int(HL.mixedEven.size());
     L.nmixed[1] = int(HL.mixedOdd.size());
     MGPS_TRY(devUpload(h, &L.tileBndStart, HL.tileBndStart));
+    if (h->dist)
+        for (int q = 0; q < 4; ++q) {
+            MGPS_TRY(devUpload(h, &L.bandPlane[q], HL.bandPlane[q]));
+            L.nbandPlane[q] = int(HL.bandPlane[q].size());
+            MGPS_TRY(devAlloc(h, &L.packBuf[q], HL.bandPlane[q].size(), true));
+        }
     if (xbGrids) {
         MGPS_TRY(gridAlloc(h, &L.x, L.d));
         MGPS_TRY(gridAlloc(h, &L.b, L.d));

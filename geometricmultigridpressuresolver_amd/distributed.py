@@ -21,7 +21,8 @@ import torch.distributed as dist
 from ._lib import check, lib
 from .solver import GeometricMultigridPoissonSolver, _np_f32, _np_u8, _p, default_options
 
-_EXCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_EXCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                    C.c_void_p, C.c_size_t, C.c_void_p)
 _ALLR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _GATH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 _DEST = C.CFUNCTYPE(None, C.c_void_p)
@@ -75,6 +76,7 @@ class TorchDistComm:
         self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.exchanges = 0
+        self.bytes_sent = 0
         self._cb = (_EXCH(self._exchange), _ALLR(self._allreduce), _GATH(self._gather), _GATH(self._scatter))
         self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST())
 
@@ -92,18 +94,20 @@ class TorchDistComm:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     # -- vtable ------------------------------------------------------------------------------------
-    def _exchange(self, user, send_lo, recv_lo, send_hi, recv_hi, nbytes, stream):
+    def _exchange(self, user, send_lo, send_lo_n, recv_lo, recv_lo_n, send_hi, send_hi_n, recv_hi, recv_hi_n, stream):
         try:
             self.exchanges += 1
+            self.bytes_sent += (send_lo_n if send_lo else 0) + (send_hi_n if send_hi else 0)
             ops, recvs = [], []
-            for send, recv, peer in ((send_lo, recv_lo, self.rank - 1), (send_hi, recv_hi, self.rank + 1)):
-                if not send:
-                    continue
-                out = self._d2h(send, nbytes, stream)
-                inc = torch.empty(nbytes, dtype=torch.uint8)
-                ops.append(dist.P2POp(dist.isend, out, self._global(peer), self.group))
-                ops.append(dist.P2POp(dist.irecv, inc, self._global(peer), self.group))
-                recvs.append((recv, inc))
+            for send, sn, recv, rn, peer in ((send_lo, send_lo_n, recv_lo, recv_lo_n, self.rank - 1),
+                                             (send_hi, send_hi_n, recv_hi, recv_hi_n, self.rank + 1)):
+                if send and sn:
+                    out = self._d2h(send, sn, stream)
+                    ops.append(dist.P2POp(dist.isend, out, self._global(peer), self.group))
+                if recv and rn:
+                    inc = torch.empty(rn, dtype=torch.uint8)
+                    ops.append(dist.P2POp(dist.irecv, inc, self._global(peer), self.group))
+                    recvs.append((recv, inc))
             for w in dist.batch_isend_irecv(ops) if ops else []:
                 w.wait()
             for recv, inc in recvs:

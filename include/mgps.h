@@ -202,7 +202,10 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
  * multiple of 16 (keeps the 16^3 Gauss-Seidel tile colouring identical to the single-GPU run and
  * restriction/prolongation rank-local up to one ghost plane); the first level that is not, and
  * everything coarser, is gathered to rank 0 and solved there ("collapse").  Before every operator
- * that reads across the cut one ghost plane per side is exchanged with the two Z-neighbours.
+ * that reads across the cut the ghost plane on each side is refreshed from the Z-neighbour: the
+ * whole plane after an operator that rewrote the whole grid (Jacobi sweep, Gauss-Seidel colour pass,
+ * prolongation, residual), only the packed band cells of the plane after a band pass (a few percent
+ * of a plane).
  *
  * The transport is a small vtable so that the same orchestration runs over RCCL (production,
  * mgps_comm_create_rccl: ncclSend/ncclRecv pairs in one group on the solver's stream over xGMI) or
@@ -213,10 +216,12 @@ typedef struct mgps_comm {
     int struct_size; /* sizeof(mgps_comm) */
     int rank, size;
     void *user;
-    /* send `send_lo` to rank-1 and receive `recv_lo` from it; the same with rank+1 for *_hi.
-     * The lo pair is NULL on rank 0, the hi pair on the last rank. */
-    int (*exchange)(void *user, const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi,
-                    size_t bytes, void *hip_stream);
+    /* send `send_lo` (send_lo_bytes) to rank-1 and receive recv_lo_bytes from it into `recv_lo`; the
+     * same with rank+1 for *_hi.  The lo pair is NULL on rank 0, the hi pair on the last rank.  The
+     * two directions of a pair may differ in size (packed band cells of two different planes). */
+    int (*exchange)(void *user, const void *send_lo, size_t send_lo_bytes, void *recv_lo, size_t recv_lo_bytes,
+                    const void *send_hi, size_t send_hi_bytes, void *recv_hi, size_t recv_hi_bytes,
+                    void *hip_stream);
     /* in-place all-reduce of `count` host doubles; op 0 = sum, 1 = max */
     int (*allreduce)(void *user, double *values, int count, int op);
     /* root receives size*bytes (rank order) into recv_dev; the others pass recv_dev = NULL */

@@ -69,7 +69,8 @@ def gpu_mode():
             assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             if rank == 0:
-                print(f"  {kind} gs={use_gs}: D={slab.distributed_levels} exchanges={comm.exchanges} pcg it {ss['iterations']}", flush=True)
+                print(f"  {kind} gs={use_gs}: D={slab.distributed_levels} exchanges={comm.exchanges} "
+                      f"({comm.bytes_sent / 1e6:.1f} MB sent) pcg it {ss['iterations']}", flush=True)
             slab.close()
             whole.close()
             dist.barrier()
@@ -105,16 +106,17 @@ def cpu_mode():
                 err = np.abs(emu.owned(x) - x_ref[z0:z1]).max() / np.abs(x_ref).max()
                 assert err < 1e-13, (kind, use_gs, it, err)
             if rank == 0:
-                print(f"  cpu emulation {kind} gs={use_gs}: D={emu.D} of {emu.L} levels, {emu.exchanges} exchanges, err {err:.1e}", flush=True)
+                print(f"  cpu emulation {kind} gs={use_gs}: D={emu.D} of {emu.L} levels, {emu.exchanges} exchanges, "
+                      f"{emu.bytes_sent / 1e6:.2f} MB sent, err {err:.1e}", flush=True)
             # dropping the exchange in front of the Jacobi sweep / GS passes must break the match:
             # proves the comparison is sensitive to the schedule
             broken = SlabEmulation(orc, lab32, w, lev, use_gs)
             real_exchange, count = broken.exchange, [0]
 
-            def lossy(a):
+            def lossy(a, *args, **kw):
                 count[0] += 1
                 if count[0] % 4:
-                    real_exchange(a)
+                    real_exchange(a, *args, **kw)
 
             broken.exchange = lossy
             xb = broken.new(0)

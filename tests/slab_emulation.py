@@ -40,6 +40,7 @@ class SlabEmulation:
         self.z0 = [(self.rank * self.nzl) >> l for l in range(self.D + 1)]
         self.z1 = [((self.rank + 1) * self.nzl) >> l for l in range(self.D + 1)]
         self.exchanges = 0
+        self.bytes_sent = 0
         if self.rank == 0 and self.L - self.D > 1:
             c = self.lab[self.D]
             cz, cy, cx = c.shape  # unit weights == weight 1 on every face (MG.cpp:572-575)
@@ -77,19 +78,48 @@ class SlabEmulation:
         return t, np.ascontiguousarray(lab, dtype=np.int32), w
 
     # -- communication ---------------------------------------------------------------------------
-    def exchange(self, a):
+    def _plane_band(self, level, gz):
+        """(j, i) of the band cells of global plane gz, reference band order"""
+        b = self.band[level]
+        sel = b[b[:, 2] == gz]
+        return sel[:, 1], sel[:, 0]
+
+    def exchange(self, a, level=None, band_only=False):
+        """whole ghost planes, or (band_only) just the band cells of the planes, packed"""
         self.exchanges += 1
         ops, recvs = [], []
-        for peer, send, slot in ((self.rank - 1, a[1], 0), (self.rank + 1, a[-2], -1)):
-            if 0 <= peer < self.size:
-                out = torch.from_numpy(np.ascontiguousarray(send))
+        for peer, slot_send, slot_recv, gz_send, gz_recv in (
+            (self.rank - 1, 1, 0, None, None),
+            (self.rank + 1, -2, -1, None, None),
+        ):
+            if not (0 <= peer < self.size):
+                continue
+            if band_only:
+                lo_side = peer < self.rank
+                gz_send = self.z0[level] if lo_side else self.z1[level] - 1
+                gz_recv = self.z0[level] - 1 if lo_side else self.z1[level]
+                js, is_ = self._plane_band(level, gz_send)
+                jr, ir = self._plane_band(level, gz_recv)
+                out = torch.from_numpy(np.ascontiguousarray(a[slot_send][js, is_]))
+                inc = torch.empty(len(jr), dtype=out.dtype)
+                self.bytes_sent += out.numel() * 8
+                recvs.append((slot_recv, inc, (jr, ir)))
+            else:
+                out = torch.from_numpy(np.ascontiguousarray(a[slot_send]))
                 inc = torch.empty_like(out)
-                ops += [dist.P2POp(dist.isend, out, peer, self.group), dist.P2POp(dist.irecv, inc, peer, self.group)]
-                recvs.append((slot, inc))
+                self.bytes_sent += out.numel() * 8
+                recvs.append((slot_recv, inc, None))
+            if out.numel():
+                ops.append(dist.P2POp(dist.isend, out, peer, self.group))
+            if inc.numel():
+                ops.append(dist.P2POp(dist.irecv, inc, peer, self.group))
         for wk in dist.batch_isend_irecv(ops) if ops else []:
             wk.wait()
-        for slot, inc in recvs:
-            a[slot] = inc.numpy()
+        for slot, inc, where in recvs:
+            if where is None:
+                a[slot] = inc.numpy()
+            else:
+                a[slot][where] = inc.numpy()
 
     # -- operators on slab storage -------------------------------------------------------------------
     def _band_cells(self, level, plo):
@@ -142,22 +172,24 @@ class SlabEmulation:
         fine_x[1:-1] = tf[2:-2]
 
     # -- the schedule of mgps_solver.hip::vcycle -------------------------------------------------------
-    def band_passes(self, level, x, b, fresh):
+    def band_passes(self, level, x, b, first):
+        """first: None (ghosts complete), "full" or "band" -- what the first pass needs"""
         for it in range(3):
-            if not (fresh and it == 0):
-                self.exchange(x)
+            mode = first if it == 0 else "band"
+            if mode is not None:
+                self.exchange(x, level, band_only=(mode == "band"))
             self.band_pass(level, x, b)
 
     def smooth_stroke(self, level, x, b, down, fresh):
-        self.band_passes(level, x, b, fresh)
+        self.band_passes(level, x, b, None if fresh else "full")
         if self.use_gs:
-            for odd, fwd in (((True, True), (False, True)) if down else ((False, False), (True, False))):
-                self.exchange(x)
+            for n, (odd, fwd) in enumerate(((True, True), (False, True)) if down else ((False, False), (True, False))):
+                self.exchange(x, level, band_only=(n == 0))  # after band passes only band cells are stale
                 self.gs_half(level, x, b, odd, fwd)
         else:
-            self.exchange(x)
+            self.exchange(x, level, band_only=True)
             self.jacobi(level, x, b)
-        self.band_passes(level, x, b, False)
+        self.band_passes(level, x, b, "full")  # the full-domain smoother rewrote everything
 
     def collapsed_tail(self, b_c, x_c):
         mine = torch.from_numpy(np.ascontiguousarray(self.owned(b_c)))
@@ -189,7 +221,7 @@ class SlabEmulation:
             if l > 0:
                 xs[l][:] = 0
                 self.smooth_stroke(l, xs[l], bs[l], True, True)
-            self.exchange(xs[l])
+            self.exchange(xs[l], l, band_only=True)  # the stroke ended with band passes
             r = self.new(l)
             self.residual(l, r, xs[l], bs[l])
             self.exchange(r)
