@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--check-oracle", action="store_true",
+                    help="free_surface_pcg only: also solve with the fp64 CPU oracle and report the pressure-field difference")
     ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
                     help="free_surface_pcg = BASELINE config 3 (single GPU): MG-PCG to 1e-5 on the free-surface pool")
     return ap.parse_args()
@@ -119,8 +121,24 @@ def free_surface_pcg(args):
             st = solver.solveGeometricConjugateGradient(x, bd, 1e-5, 2500, True)
             if best is None or st["solve_ms"] < best["solve_ms"]:
                 best = st
-        out["tiled_gs" if use_gs else "jacobi"] = {k: best[k] for k in ("outcome", "iterations", "rel_residual_recomputed", "solve_ms")}
+        out["tiled_gs" if use_gs else "jacobi"] = {k: best[k] for k in ("outcome", "iterations", "rel_residual", "rel_residual_recomputed", "solve_ms")}
+        if use_gs and args.check_oracle:
+            x_gpu = x.cpu().numpy().astype(np.float64)
         solver.close()
+    if args.check_oracle:  # the same solve in fp64 on the host (checker only, never timed as the product)
+        from oracle.mg_oracle import Oracle
+
+        orc = Oracle()
+        t0 = time.time()
+        ref = orc.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, True)
+        x_ref = np.zeros(lab.shape)
+        st = ref.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 2500, True)
+        out["oracle_fp64"] = {
+            "iterations": st["iterations"], "rel_residual_recomputed": st["rel_residual_recomputed"],
+            "seconds": time.time() - t0, "threads": orc.get_threads(),
+            "pressure_rel_l2_diff_gpu_vs_oracle": float(np.linalg.norm(x_gpu - x_ref) / np.linalg.norm(x_ref)),
+            "pressure_rel_max_diff": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max()),
+        }
     print(json.dumps(out))
 
 

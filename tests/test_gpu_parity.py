@@ -30,7 +30,7 @@ def torch_cuda():
 def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None):
     import geometricmultigridpressuresolver_amd as G
 
-    if kind == "wide":
+    if kind in ("wide", "odd"):
         levels, solver_shape = _wide_args(kind)
     lab, w, off, lev, dx = domain_factory(kind, g, levels, solver_shape)
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs)
@@ -49,12 +49,14 @@ def _rand_active(lab, seed, scale=1.0):
     return v
 
 
-DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24)]
+DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24), ("odd", 36)]
 
 
 def _wide_args(kind):
-    """the "wide" domain is a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels)"""
-    return (3, (32, 32, 256)) if kind == "wide" else (None, None)
+    """"wide": a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels) -- the plane-marching sweep;
+    "odd": a 36^3 complex domain in a 44^3 grid (3 levels: 44, 22, 11) -- level 1 has nx % 4 != 0, which
+    takes the scalar sweep and the per-cell band list instead of the quad forms"""
+    return {"wide": (3, (32, 32, 256)), "odd": (3, (44, 44, 44))}.get(kind, (None, None))
 
 
 @pytest.mark.parametrize("kind,g", DOMAINS)
