@@ -208,10 +208,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, smooth_ms = float(t[0]), float(t[1])
 
-    cells = float(n) ** 3  # whole job; every rank sweeps cells / world of them
+    cells = float(n) ** 3  # whole job; a rank holds cells / world of them
+    # the sweep skips chunks / blocks / tiles without active cells (as the reference skips constant tiles):
+    # algorithmic bytes count the cells a launch actually visits on this rank, not the allocation
+    swept = solver.swept_cells(0)[1 if use_gs else 0]
     sweeps_per_group = 1  # Jacobi: one sweep; GS: two half sweeps touch every tile once = one sweep
     t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group
-    achieved = SMOOTHER_BYTES_PER_CELL * (cells / world) / t_sweep / 1e9  # per GPU
+    achieved = SMOOTHER_BYTES_PER_CELL * swept / t_sweep / 1e9  # per GPU
     vps = args.steps / elapsed
     out = {
         "metric": "V-cycles/sec",
@@ -247,19 +250,21 @@ def main():
             "traffic": None,
             "ms_per_launch": t_sweep * 1e3,
             "launches": smooth_groups,
-            "cells_per_launch": cells / world,
-            "note": "per GPU; achieved = 13 B x cells per launch / mean launch time (HIP events on the solver's stream)",
+            "cells_per_launch": swept,
+            "cells_allocated": cells / world,
+            "note": "per GPU; achieved = 13 B x cells the launch visits (active chunks only) / mean launch time (HIP events on the solver's stream)",
         },
     }
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
     # (profiles/r01_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
-        key = [k for k in pmc if k.startswith(f"stencilQuadKernel<0>@{n}^3")]
-        if key and not use_gs and world == 1:
-            out["roofline"]["traffic"] = pmc[key[0]]["traffic_bytes"]
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch; L2<->fabric bytes incl. Infinity-Cache hits)"
-            out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * cells
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["fine_jacobi_sweep"]
+        if str(n) in pmc and not use_gs and world == 1:
+            out["roofline"]["traffic"] = pmc[str(n)]["traffic_bytes"]
+            out["roofline"]["traffic_source"] = (
+                f"profiles/r01_pmc_hbm_traffic.json, {pmc[str(n)]['kernel']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                "per launch; L2<->fabric bytes incl. Infinity-Cache hits)")
+            out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * swept
     except Exception:
         pass
     if not args.no_cpu and rank == 0 and world == 1:

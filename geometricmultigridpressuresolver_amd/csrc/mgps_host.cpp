@@ -255,6 +255,36 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
             }
         }
     }
+    {  // activity lists
+        const size_t n = d.cells();
+        L.chunks.clear();
+        for (size_t c0 = 0; c0 < n; c0 += kChunkCells) {
+            bool act = false;
+            for (size_t c = c0; c < std::min(n, c0 + kChunkCells) && !act; ++c) act = isActive(L.labels[c]);
+            if (act) L.chunks.push_back(int32_t(c0 / kChunkCells));
+        }
+        L.planeBlocks.clear();
+        L.planeZc = planeSweepZc(d.nx, d.ny, d.nz);
+        if (L.planeZc) {
+            const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows, nbz = (d.nz + L.planeZc - 1) / L.planeZc;
+            std::vector<uint8_t> act(size_t(nbx) * nby * nbz, 0);
+            for (int k = 0; k < d.nz; ++k)
+                for (int j = 0; j < d.ny; ++j) {
+                    const uint8_t *row = L.labels.data() + d.idx(0, j, k);
+                    for (int bx = 0; bx < nbx; ++bx) {
+                        uint8_t &a = act[(size_t(k / L.planeZc) * nby + j / kPlaneRows) * nbx + bx];
+                        if (a) continue;
+                        for (int i = bx * 256; i < std::min(d.nx, bx * 256 + 256); ++i)
+                            if (isActive(row[i])) {
+                                a = 1;
+                                break;
+                            }
+                    }
+                }
+            for (size_t q = 0; q < act.size(); ++q)
+                if (act[q]) L.planeBlocks.push_back(int32_t(q));
+        }
+    }
     L.numBoundary = int32_t(general.size());
     L.bandDev = general;
     L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());

@@ -54,6 +54,13 @@ struct HostLevel {
     // list, so sender's pack order == receiver's unpack order): [0] owned plane 0 (sent down),
     // [1] ghost plane below (received), [2] owned top plane (sent up), [3] ghost plane above (received)
     std::vector<int32_t> bandPlane[4];
+    // Activity lists: the reference skips constant (all-EXTERIOR / all-DIRICHLET) 16^3 tiles of its
+    // tile-compressed UT_VoxelArray in every operator (`if (!vit.isTileConstant() || active)`, e.g.
+    // Ops.h:322-324); the flat layout gets the same effect from lists of the 1024-cell chunks (and, for
+    // the plane-marching sweep, of the 256 x 16 x zc blocks) that hold at least one active cell.
+    std::vector<int32_t> chunks;
+    std::vector<int32_t> planeBlocks;
+    int planeZc = 0;
     // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
     // kind: "pure" = all 4096 cells INTERIOR (no label or weight look-ups needed), "mixed" = the rest
     std::vector<int32_t> tilesOdd, tilesEven;          // all active tiles of the colour (API / tests)
@@ -84,12 +91,33 @@ struct GridP {
     // just below (k = -1) / above (k = nz) the owned range is a ghost plane held in the same
     // allocation (every array pointer addresses owned plane 0), filled by the neighbour exchange.
     int ghostLo, ghostHi;
+    // active 1024-cell chunks of the flat array / active blocks of the plane-marching sweep
+    const int32_t *chunks;
+    int nchunks;
+    const int32_t *planeBlocks;
+    int nplaneBlocks, planeZc;
 };
+
+constexpr int kChunkCells = 1024;
+constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
+// does the plane-marching sweep apply to a level of this shape, and with how many planes per block
+inline int planeSweepZc(int nx, int ny, int nz)
+{
+    if ((nx & 3) != 0 || nx < 256 || ny < kPlaneRows) return 0;
+    const size_t nbx = (nx + 255) / 256, nby = (ny + kPlaneRows - 1) / kPlaneRows;
+    int zc = 32;  // fewer planes per workgroup on small grids so that the launch still fills 256 CUs
+    while (zc > 4 && nbx * nby * size_t((nz + zc - 1) / zc) < 1024) zc >>= 1;
+    return zc;
+}
 
 enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };
 
 // All launchers enqueue on `stream` (a hipStream_t passed as void*) and return a hipError_t as int.
-int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega);
+// skipInactive: leave chunks without active cells untouched (callers whose `out` already holds the
+// right values there: 0 for r / y, the unchanged iterate for Jacobi)
+size_t stencilSweptCells(const GridP &g);
+int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
+                  bool skipInactive);
 // band = device-ordered band list (BOUNDARY cells first, g.nbnd of them)
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                      float *bandTmp, float omega);

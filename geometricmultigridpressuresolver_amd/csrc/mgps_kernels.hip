@@ -99,12 +99,14 @@ __device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
 // ---------------------------------------------------------------------------------------------
 template <int OP>
 __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
-                                                          const float *__restrict__ b, float omega, unsigned nblocks)
+                                                          const float *__restrict__ b, float omega, unsigned nblocks,
+                                                          const int32_t *__restrict__ chunks)
 {
     const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
     const size_t rows = size_t(g.ny) * g.nz;
     const size_t totalQuads = size_t(nq) * rows;
-    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    unsigned block = remapBlock(blockIdx.x, nblocks);
+    if (chunks) block = unsigned(chunks[block]);  // only the 1024-cell chunks that hold active cells
     const size_t t = size_t(block) * blockDim.x + threadIdx.x;
     const bool valid = t < totalQuads;
     const size_t tt = valid ? t : totalQuads - 1;
@@ -161,17 +163,18 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
 // plane is computed.  Measured against the cache-only kernel above: HBM-side read traffic 9.2 vs
 // 14.8 B/cell (rocprofv3 FETCH_SIZE), 2.63 vs 2.87 ms at 1024^3.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPlaneRows = 16;
 constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the rows 16-byte aligned
 
 template <int OP>
 __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ b, float omega,
-                                                                      unsigned nbx, unsigned nby, unsigned nbz, int zc)
+                                                                      unsigned nbx, unsigned nby, unsigned nbz, int zc,
+                                                                      const int32_t *__restrict__ blocks)
 {
     __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
-    const unsigned bid = remapBlock(blockIdx.x, nbx * nby * nbz);
+    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    if (blocks) bid = unsigned(blocks[bid]);  // only blocks that hold active cells
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
     const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
     const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
@@ -529,7 +532,9 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
 __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine)
 {
     const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
-    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    // with a chunk list: 4 workgroups of 256 per active 1024-cell chunk; the rest of `coarse` stays 0
+    const size_t c = cg.chunks ? size_t(cg.chunks[blockIdx.x >> 2]) * kChunkCells + (blockIdx.x & 3) * 256 + threadIdx.x
+                               : size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (!activeLabel(cg.lab[c])) {
         coarse[c] = 0.f;
@@ -585,7 +590,9 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
 {
     const unsigned nq = unsigned(fg.nx) >> 2;
     const size_t total = size_t(nq) * fg.ny * fg.nz;
-    const size_t t = size_t(remapBlock(blockIdx.x, nblocks)) * blockDim.x + threadIdx.x;
+    unsigned block = remapBlock(blockIdx.x, nblocks);
+    if (fg.chunks) block = unsigned(fg.chunks[block]);
+    const size_t t = size_t(block) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const unsigned m = unsigned(t % nq);
     const size_t row = t / nq;
@@ -665,13 +672,30 @@ __device__ __forceinline__ float vecOp(float d, float a, float s, float scale)
     return a * s;                              // d = a .* s (diagonal preconditioner)
 }
 
+// quad index of this thread's `it`-th piece of work: plain grid stride, or (chunk list) the thread's quad
+// inside the it-th active chunk of this workgroup; returns false when the thread is done
+__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, size_t nq, size_t it, size_t &q)
+{
+    if (chunks) {
+        const size_t ci = size_t(blockIdx.x) + it * gridDim.x;
+        if (ci >= size_t(nchunks)) return false;
+        q = size_t(chunks[ci]) * (kChunkCells / 4) + threadIdx.x;
+        return true;  // (a ragged last chunk is guarded by q < nq at the use)
+    }
+    q = size_t(blockIdx.x) * blockDim.x + threadIdx.x + it * size_t(gridDim.x) * blockDim.x;
+    return q < nq;
+}
+
 template <int VOP>
 __global__ __launch_bounds__(256) void vecKernel(size_t n, const uint8_t *__restrict__ lab, float *dst, const float *a,
-                                                 const float *s, const float *scaleDev, float scaleHost, float sign)
+                                                 const float *s, const float *scaleDev, float scaleHost, float sign,
+                                                 const int32_t *__restrict__ chunks, int nchunks)
 {
     const float scale = sign * (scaleDev ? *scaleDev : scaleHost);
     const size_t nq = n >> 2;
-    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x) {
+    size_t q;
+    for (size_t it = 0; nextQuad(chunks, nchunks, nq, it, q); ++it) {
+        if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
         float4 d = reinterpret_cast<const float4 *>(dst)[q];
         float4 av = d, sv = d;
@@ -747,11 +771,14 @@ __device__ __forceinline__ double blockReduce(double acc)
 
 template <int KIND>
 __global__ __launch_bounds__(256) void reduceKernel(size_t n, const uint8_t *__restrict__ lab, const float *__restrict__ a,
-                                                    const float *__restrict__ b, double *__restrict__ partials)
+                                                    const float *__restrict__ b, double *__restrict__ partials,
+                                                    const int32_t *__restrict__ chunks, int nchunks)
 {
     double acc = 0.0;  // identity for sums and for max(0, .) / max|.|
     const size_t nq = n >> 2;
-    for (size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x) {
+    size_t q;
+    for (size_t it = 0; nextQuad(chunks, nchunks, nq, it, q); ++it) {
+        if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
         const float4 av = reinterpret_cast<const float4 *>(a)[q];
         float4 bv = av;
@@ -812,37 +839,58 @@ inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + p
 
 // ---- launchers -------------------------------------------------------------------------------
 
-int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega)
+static int forcedStencil()
 {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t n = size_t(g.nx) * g.ny * g.nz;
     static const int forced = [] {  // MGPS_STENCIL=quad|plane: A/B switch for tuning runs
         const char *e = getenv("MGPS_STENCIL");
         return !e ? 0 : (e[0] == 'q' ? 1 : 2);
     }();
-    const bool planeOk = (g.nx & 3) == 0 && g.nx >= 256 && g.ny >= kPlaneRows;
+    return forced;
+}
+
+// Cells one activity-skipping full-domain sweep visits (the denominator of the measured bytes per cell).
+size_t stencilSweptCells(const GridP &g)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const int forced = forcedStencil();
+    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
+    if (g.planeZc && (forced == 2 || (forced == 0 && planeWins)))
+        return g.planeBlocks ? std::min(n, size_t(g.nplaneBlocks) * 256 * kPlaneRows * g.planeZc) : n;
+    if ((g.nx & 3) == 0 && g.chunks) return std::min(n, size_t(g.nchunks) * kChunkCells);
+    return n;
+}
+
+int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
+                  bool skipInactive)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const int forced = forcedStencil();
+    const int zc = g.planeZc;  // 0: the plane-marching sweep does not apply to this shape
     // measured on MI355X (fine Jacobi sweep, plane vs quad kernel): 256^3 42.8 vs 40.8 us, 512^3 367 vs
     // 345 us, 1024^3 2.68 vs 2.95 ms -- the cache-only kernel wins while three x-y planes of x stay in an
     // XCD's L2 share, the register/LDS-marching one beyond that (x-y plane > 2 MiB)
     const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
-    if (planeOk && (forced == 2 || (forced == 0 && planeWins))) {
+    if (zc && (forced == 2 || (forced == 0 && planeWins))) {
         const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows;
-        int zc = 32;  // planes per workgroup: fewer on small grids so that the launch still fills 256 CUs
-        while (zc > 4 && size_t(nbx) * nby * ((g.nz + zc - 1) / zc) < 1024) zc >>= 1;
         const unsigned nbz = (g.nz + zc - 1) / zc;
-        const unsigned nb = nbx * nby * nbz;
-        switch (op) {
-            case OP_JACOBI: stencilPlaneKernel<OP_JACOBI><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
-            case OP_RESIDUAL: stencilPlaneKernel<OP_RESIDUAL><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
-            default: stencilPlaneKernel<OP_APPLY><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc); break;
-        }
+        const bool list = skipInactive && g.planeBlocks != nullptr;
+        const unsigned nb = list ? unsigned(g.nplaneBlocks) : nbx * nby * nbz;
+        const int32_t *blocks = list ? g.planeBlocks : nullptr;
+        if (nb > 0) switch (op) {
+                case OP_JACOBI: stencilPlaneKernel<OP_JACOBI><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
+                case OP_RESIDUAL: stencilPlaneKernel<OP_RESIDUAL><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
+                default: stencilPlaneKernel<OP_APPLY><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
+            }
     } else if ((g.nx & 3) == 0) {
-        const unsigned nb = blocksFor(n >> 2, 256);
-        switch (op) {
-            case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
-            case OP_RESIDUAL: stencilQuadKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
-            default: stencilQuadKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
-        }
+        const bool list = skipInactive && g.chunks != nullptr;
+        const unsigned nb = list ? unsigned(g.nchunks) : blocksFor(n >> 2, 256);
+        const int32_t *chunks = list ? g.chunks : nullptr;
+        if (nb > 0) switch (op) {
+                case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
+                case OP_RESIDUAL: stencilQuadKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
+                default: stencilQuadKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
+            }
     } else {
         const unsigned nb = blocksFor(n, 256);
         switch (op) {
@@ -886,7 +934,8 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine)
 {
     const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
-    restrictKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
+    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * 4 : blocksFor(n, 256);
+    if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
     return int(hipGetLastError());
 }
 
@@ -894,8 +943,8 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
 {
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
     if ((fine.nx & 3) == 0 && fine.nx >= 8) {
-        const unsigned nb = blocksFor(n >> 2, 256);
-        prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
+        const unsigned nb = fine.chunks ? unsigned(fine.nchunks) : blocksFor(n >> 2, 256);
+        if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
     } else
         prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
     return int(hipGetLastError());
@@ -911,6 +960,13 @@ int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *
     return int(hipGetLastError());
 }
 
+// grid of a grid-stride kernel: over all quads, or over the active chunks of g when it carries a list
+static unsigned vecBlocks(const GridP &g, size_t n)
+{
+    if (g.chunks) return unsigned(std::min<size_t>(std::max(1, g.nchunks), 2048));
+    return unsigned(std::min<size_t>(std::max<size_t>(1, ((n >> 2) + 255) / 256), 2048));
+}
+
 static unsigned streamingBlocks(size_t quads)
 {
     // memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8, no more
@@ -921,30 +977,30 @@ int launchAxpy(void *stream, const GridP &g, float *dst, const float *src, const
                float sign)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    vecKernel<V_AXPY><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, src, nullptr,
-                                                                                              scaleDev, scaleHost, sign);
+    vecKernel<V_AXPY><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, src, nullptr,
+                                                                                              scaleDev, scaleHost, sign, g.chunks, g.nchunks);
     return int(hipGetLastError());
 }
 int launchXpay(void *stream, const GridP &g, float *dst, const float *a, const float *sv, const float *scaleDev,
                float scaleHost)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    vecKernel<V_XPAY><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, sv, scaleDev,
-                                                                                              scaleHost, 1.f);
+    vecKernel<V_XPAY><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, sv, scaleDev,
+                                                                                              scaleHost, 1.f, g.chunks, g.nchunks);
     return int(hipGetLastError());
 }
 int launchScale(void *stream, const GridP &g, float *v, float scale)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    vecKernel<V_SCALE><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, v, nullptr, nullptr,
-                                                                                               nullptr, scale, 1.f);
+    vecKernel<V_SCALE><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, v, nullptr, nullptr,
+                                                                                               nullptr, scale, 1.f, g.chunks, g.nchunks);
     return int(hipGetLastError());
 }
 int launchMulMasked(void *stream, const GridP &g, float *dst, const float *a, const float *b)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    vecKernel<V_MUL><<<streamingBlocks(n >> 2), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, b, nullptr, 1.f,
-                                                                                             1.f);
+    vecKernel<V_MUL><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, b, nullptr, 1.f,
+                                                                                             1.f, g.chunks, g.nchunks);
     return int(hipGetLastError());
 }
 int launchDiagInverse(void *stream, const GridP &g, float *dinv)
@@ -976,22 +1032,22 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const unsigned nb = std::min<unsigned>(streamingBlocks(n >> 2), unsigned(kReducePartials));
+    const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
     switch (kind) {
         case 0:
-            reduceKernel<0><<<nb, 256, 0, s>>>(n, g.lab, a, b, partials);
+            reduceKernel<0><<<nb, 256, 0, s>>>(n, g.lab, a, b, partials, g.chunks, g.nchunks);
             reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         case 1:
-            reduceKernel<1><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceKernel<1><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
             reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         case 2:
-            reduceKernel<2><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceKernel<2><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
             reduceFinalKernel<2><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         default:
-            reduceKernel<3><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials);
+            reduceKernel<3><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
             reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
     }

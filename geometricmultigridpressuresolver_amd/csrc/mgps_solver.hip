@@ -43,6 +43,7 @@ struct DevLevel {
     int32_t *bandPlane[4] = {nullptr, nullptr, nullptr, nullptr};
     int nbandPlane[4] = {0, 0, 0, 0};
     float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
 };
 
 }  // namespace
@@ -170,6 +171,8 @@ void freeAll(mgps_solver *h)
             (void)hipFree(L.bandPlane[q]);
             (void)hipFree(L.packBuf[q]);
         }
+        (void)hipFree(L.chunks);
+        (void)hipFree(L.planeBlocks);
     }
     for (int a = 0; a < 3; ++a) (void)hipFree(h->w[a]);
     (void)hipFree(h->cinv);
@@ -284,7 +287,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         }
     } else {
         MGPS_TRY(exchangeGhosts(h, l, cur, afterBands));
-        MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight));
+        MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, true));
         std::swap(cur, other);
     }
     if (timed) {
@@ -354,7 +357,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
             MGPS_TRY(exchangeGhosts(h, l, cur[l], h->opt.band_iterations > 0 ? GHOST_BAND : GHOST_FULL));
-            MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f));
+            MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
             MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
         }
@@ -396,10 +399,12 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
     return MGPS_OK;
 }
 
-int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const float *b)
+// skipInactive: `out` is one of the solver's own grids, already 0 (r, y) / equal to x (Jacobi) on chunks
+// without active cells; the public entry points pass false and get every cell of `out` written
+int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const float *b, bool skipInactive = false)
 {
     MGPS_TRY(exchangeGhosts(h, level, x));
-    MGPS_LAUNCH(h, launchStencil(h->stream, op, h->lv[level].g, out, x, b, h->opt.jacobi_weight));
+    MGPS_LAUNCH(h, launchStencil(h->stream, op, h->lv[level].g, out, x, b, h->opt.jacobi_weight, skipInactive));
     return MGPS_OK;
 }
 
@@ -437,7 +442,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_TRY(reduceToHost(h, 1, 0, b, nullptr, &rhs2));  // CG.h:35
     st->rhs_norm2 = rhs2;
     if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
-    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b));    // CG.h:50-51
+    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:50-51
     double res2 = 0;
     MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));  // CG.h:57
     const double threshold = tol * tol * rhs2;           // CG.h:58
@@ -459,7 +464,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             st->iterations = it;
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
         }
-        MGPS_TRY(applyOp(h, OP_APPLY, 0, t, p, nullptr));  // CG.h:110
+        MGPS_TRY(applyOp(h, OP_APPLY, 0, t, p, nullptr, true));  // CG.h:110
         double pAp = 0;
         MGPS_TRY(reduceToHost(h, 0, 0, p, t, &pAp));
         const double alpha = absNew / pAp;                                               // CG.h:121
@@ -480,7 +485,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     }
     st->iterations = it;
     st->rel_residual = std::sqrt(res2 / rhs2);      // CG.h:199
-    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b));  // CG.h:203-204
+    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:203-204
     double rec2 = 0;
     MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &rec2));
     st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);  // CG.h:205
@@ -518,6 +523,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
             L.nbandPlane[q] = int(HL.bandPlane[q].size());
             MGPS_TRY(devAlloc(h, &L.packBuf[q], HL.bandPlane[q].size(), true));
         }
+    MGPS_TRY(devUpload(h, &L.chunks, HL.chunks));
+    MGPS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
     if (xbGrids) {
         MGPS_TRY(gridAlloc(h, &L.x, L.d));
         MGPS_TRY(gridAlloc(h, &L.b, L.d));
@@ -538,7 +545,12 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 int(HL.numBoundary),
                 L.bandDiag,
                 (h->dist && z0 > 0) ? 1 : 0,
-                (h->dist && z1 < globalNz) ? 1 : 0};
+                (h->dist && z1 < globalNz) ? 1 : 0,
+                L.chunks,
+                int(HL.chunks.size()),
+                HL.planeZc ? L.planeBlocks : nullptr,
+                int(HL.planeBlocks.size()),
+                HL.planeZc};
     return MGPS_OK;
 }
 
@@ -905,6 +917,8 @@ int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const flo
     MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_downsample"));
     if (fine_level < 0 || !coarse_dev || !fine_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_downsample: bad arguments");
     MGPS_TRY(exchangeGhosts(h, fine_level, const_cast<float *>(fine_dev)));
+    // "destination cleared first" (Ops.h:756): the kernel itself only visits chunks with active cells
+    MGPS_LAUNCH(h, launchZero(h->stream, coarse_dev, h->lv[fine_level + 1].d.cells()));
     MGPS_LAUNCH(h, launchRestrict(h->stream, h->lv[fine_level + 1].g, coarse_dev, fine_dev));
     return MGPS_OK;
 }
@@ -1012,6 +1026,15 @@ int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smooth
     *fine_smoother_ms = total;
     *fine_smoother_launches = int(h->profUsed / 2);
     h->profUsed = 0;
+    return MGPS_OK;
+}
+
+int mgps_swept_cells(const mgps_solver *h, int level, long long *stencil_cells, long long *gs_cells)
+{
+    if (!h || level < 0 || level >= int(h->lv.size()) || !stencil_cells || !gs_cells) return MGPS_ERR_INVALID_ARGUMENT;
+    const DevLevel &L = h->lv[level];
+    *stencil_cells = (long long)stencilSweptCells(L.g);
+    *gs_cells = (long long)(L.npure[0] + L.npure[1] + L.nmixed[0] + L.nmixed[1]) * 4096;
     return MGPS_OK;
 }
 

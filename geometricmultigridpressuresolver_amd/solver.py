@@ -330,6 +330,12 @@ class GeometricMultigridPoissonSolver:
         check(lib().mgps_profile_read(self.h, C.byref(ms), C.byref(n)), self.h)
         return ms.value, n.value
 
+    def swept_cells(self, level=0):
+        """(stencil sweep cells, tiled-GS sweep cells) one full-domain pass of `level` visits"""
+        a, b = C.c_longlong(), C.c_longlong()
+        check(lib().mgps_swept_cells(self.h, int(level), C.byref(a), C.byref(b)), self.h)
+        return a.value, b.value
+
     # -- host-buffer forms (what the Houdini shim calls) --------------------------------------------
     def applyVCycleHost(self, solution, rhs, use_initial_guess=False):
         x = _np_f32(solution)

@@ -264,6 +264,11 @@ int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, siz
  * since the last read, and resets both. */
 int mgps_profile_enable(mgps_solver *h, int enable);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
+/* Cells one full-domain sweep of `level` visits: the kernels skip 1024-cell chunks / 256x16xzc blocks /
+ * 16^3 tiles without active cells (the reference skips constant tiles the same way, Ops.h:300-312);
+ * stencil_cells is for the Jacobi / residual / apply sweep, gs_cells for the two tiled-GS half sweeps.
+ * This is the cell count behind bench.py's algorithmic bytes per launch. */
+int mgps_swept_cells(const mgps_solver *h, int level, long long *stencil_cells, long long *gs_cells);
 
 /* Host-buffer convenience forms: what the Houdini shim calls (upload, run, download). */
 int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, int use_initial_guess);
