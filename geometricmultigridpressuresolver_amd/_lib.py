@@ -43,6 +43,7 @@ class Options(C.Structure):
         ("use_graph", C.c_int),
         ("print_stats", C.c_int),
         ("max_coarse_unknowns", C.c_int),
+        ("fuse_band_passes", C.c_int),
         ("interrupt", C.c_void_p),
         ("interrupt_user", C.c_void_p),
     ]

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 #include "mgps_internal.h"
 
@@ -300,6 +301,162 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     }
 }
 
+// ---- fused band passes: group builder (see BandGroups) ----------------------------------------------
+namespace {
+
+struct GroupBuild {
+    std::vector<int32_t> updateEntry, readCell;
+    std::vector<uint16_t> neighbours;
+    int cnt[kBandMaxDepth] = {0, 0, 0, 0};
+};
+
+// breadth-first over band-to-band stencil edges from the owned entries; false = does not fit one workgroup
+bool buildOneGroup(const HostLevel &L, const std::vector<int32_t> &bandIndex, const std::vector<int32_t> &owned, int depth,
+                   GroupBuild &g)
+{
+    const Dims d = L.d;
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
+    const uint8_t *codes = L.codes.data() + sz;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
+    g = GroupBuild();
+    std::unordered_map<int32_t, int32_t> id;  // cell -> node id; read-only nodes as -(r + 2)
+    id.reserve(owned.size() * 4);
+    std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
+    for (int32_t t : owned) {
+        id.emplace(L.bandDev[size_t(t)], int32_t(g.updateEntry.size()));
+        g.updateEntry.push_back(t);
+    }
+    size_t begin = 0;
+    constexpr int32_t kZero = -1;
+    for (int dist = 0; dist < depth; ++dist) {
+        const size_t end = g.updateEntry.size();
+        g.cnt[dist] = int(end);
+        for (size_t n = begin; n < end; ++n) {
+            const ptrdiff_t c = L.bandDev[size_t(g.updateEntry[n])];
+            for (int q = 0; q < 6; ++q) {
+                const ptrdiff_t cq = c + off[q];
+                const uint8_t code = codes[cq];
+                if (!(code == MGPS_INTERIOR_CELL || code >= kCodeGeneral)) {  // inactive: holds exactly 0
+                    nbrTmp.push_back(kZero);
+                    continue;
+                }
+                auto it = id.find(int32_t(cq));
+                if (it == id.end()) {
+                    const int32_t t = bandIndex[size_t(cq)];
+                    int32_t v;
+                    if (t >= 0 && dist + 1 < depth) {
+                        v = int32_t(g.updateEntry.size());
+                        g.updateEntry.push_back(t);
+                    } else {
+                        v = -int32_t(g.readCell.size()) - 2;
+                        g.readCell.push_back(int32_t(cq));
+                    }
+                    it = id.emplace(int32_t(cq), v).first;
+                }
+                nbrTmp.push_back(it->second);
+            }
+            if (g.updateEntry.size() > size_t(kBandMaxUpdate) || g.updateEntry.size() + g.readCell.size() + 1 > size_t(kBandMaxNodes))
+                return false;
+        }
+        begin = end;
+    }
+    for (int dist = depth; dist < kBandMaxDepth; ++dist) g.cnt[dist] = g.cnt[depth - 1];
+    const int32_t nUpd = int32_t(g.updateEntry.size()), nRead = int32_t(g.readCell.size());
+    g.neighbours.resize(nbrTmp.size());
+    for (size_t q = 0; q < nbrTmp.size(); ++q) {
+        const int32_t v = nbrTmp[q];
+        g.neighbours[q] = uint16_t(v >= 0 ? v : (v == kZero ? nUpd + nRead : nUpd + (-v - 2)));
+    }
+    return true;
+}
+
+}  // namespace
+
+void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
+{
+    out = BandGroups();
+    out.depth = depth;
+    const size_t nband = L.bandDev.size();
+    if (depth < 1 || depth > kBandMaxDepth || nband == 0 || nband > size_t(kBandEntryMask)) return;
+    const Dims d = L.d;
+    std::vector<int32_t> bandIndex(d.cells(), -1);
+    for (size_t t = 0; t < nband; ++t) bandIndex[size_t(L.bandDev[t])] = int32_t(t);
+    // initial partition: the band entries of each 16^3 tile
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
+    for (size_t t = 0; t < nband; ++t) {
+        const size_t c = size_t(L.bandDev[t]);
+        const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+        buckets[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile].push_back(int32_t(t));
+    }
+    std::vector<std::vector<int32_t>> work;
+    for (auto &b : buckets)
+        if (!b.empty()) work.push_back(std::move(b));
+    buckets.clear();
+    std::vector<std::vector<GroupBuild>> built(work.size());
+    std::atomic<int64_t> next{0};
+    auto worker = [&] {
+        for (;;) {
+            const int64_t w = next.fetch_add(1);
+            if (w >= int64_t(work.size())) break;
+            std::vector<std::vector<int32_t>> stack;
+            stack.push_back(std::move(work[size_t(w)]));
+            while (!stack.empty()) {
+                std::vector<int32_t> owned = std::move(stack.back());
+                stack.pop_back();
+                GroupBuild g;
+                if (buildOneGroup(L, bandIndex, owned, depth, g)) {
+                    built[size_t(w)].push_back(std::move(g));
+                    continue;
+                }
+                // too many nodes for one workgroup: halve the owned set along the longest axis of its bounding box
+                int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+                auto coord = [&](int32_t t, int a) {
+                    const size_t c = size_t(L.bandDev[size_t(t)]);
+                    return a == 0 ? int(c % d.nx) : a == 1 ? int((c / d.nx) % d.ny) : int(c / (size_t(d.nx) * d.ny));
+                };
+                for (int32_t t : owned)
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = std::min(lo[a], coord(t, a));
+                        hi[a] = std::max(hi[a], coord(t, a));
+                    }
+                int axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                std::vector<int32_t> left, right;
+                if (hi[axis] > lo[axis]) {
+                    const int mid = (lo[axis] + hi[axis] + 1) / 2;
+                    for (int32_t t : owned) (coord(t, axis) < mid ? left : right).push_back(t);
+                } else {  // a single cell column cannot happen with 16^3 buckets; split by count for safety
+                    left.assign(owned.begin(), owned.begin() + owned.size() / 2);
+                    right.assign(owned.begin() + owned.size() / 2, owned.end());
+                }
+                stack.push_back(std::move(right));
+                stack.push_back(std::move(left));
+            }
+        }
+    };
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = int(std::min<size_t>(std::min<unsigned>(hw ? hw : 4, 32), std::max<size_t>(1, work.size() / 64)));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    for (auto &list : built)
+        for (auto &g : list) {
+            const int32_t updStart = int32_t(out.updateEntry.size()), readStart = int32_t(out.readCell.size());
+            out.info.insert(out.info.end(), {updStart, readStart, int32_t(g.readCell.size()), g.cnt[0], g.cnt[1], g.cnt[2], g.cnt[3], 0});
+            for (int32_t t : g.updateEntry) {
+                out.updateEntry.push_back(t | (int32_t(L.bandDiag[size_t(t)]) << kBandDiagShift));
+                out.updateCell.push_back(L.bandDev[size_t(t)]);
+            }
+            out.neighbours.insert(out.neighbours.end(), g.neighbours.begin(), g.neighbours.end());
+            out.readCell.insert(out.readCell.end(), g.readCell.begin(), g.readCell.end());
+        }
+}
+
 // tileZOffset: number of 16-plane tile layers below this slab (the colour uses the global tile index)
 static void buildTileLists(HostLevel &L, int tileZOffset)
 {
@@ -468,6 +625,7 @@ void mgps_default_options(mgps_options *opt)
     opt->struct_size = int(sizeof(mgps_options));
     opt->band_width = 3;               // MG.cpp:141
     opt->band_iterations = 3;          // MG.cpp:142
+    opt->fuse_band_passes = 1;
     opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
     opt->device = -1;
     opt->use_graph = 0;
@@ -792,6 +950,95 @@ int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *ou
         out_ijk[q++] = (c / d.nx) % d.ny;
         out_ijk[q++] = c / (d.nx * d.ny);
     }
+    return MGPS_OK;
+}
+
+// Host check of the fused band stage: builds the level's groups, verifies their structure and replays
+// `depth` passes both ways (pass by pass over the whole band / group by group in local storage) on a
+// seeded grid with the unit-weight operator; the two must agree bit for bit.
+int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
+                                     int64_t *out_nodes)
+{
+    if (!hier || level < 0 || level >= hier->levels || depth < 1 || depth > kBandMaxDepth)
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_check_band_groups: bad arguments");
+    HostLevel L;
+    buildSlabLevel(hier->lv[level], 0, hier->lv[level].d.nz, nullptr, nullptr, nullptr, L);
+    BandGroups bg;
+    buildBandGroups(L, depth, bg);
+    const Dims d = L.d;
+    const size_t nband = L.bandDev.size();
+    if (out_groups) *out_groups = int64_t(bg.groups());
+    if (out_nodes) *out_nodes = int64_t(bg.updateEntry.size() + bg.readCell.size());
+    std::vector<uint8_t> ownedOnce(nband, 0);
+    for (size_t gI = 0; gI < bg.groups(); ++gI) {
+        const int32_t *gi = bg.info.data() + 8 * gI;
+        const int nUpd = gi[3 + depth - 1], nRead = gi[2];
+        if (gi[3] < 1 || nUpd > kBandMaxUpdate || nUpd + nRead + 1 > kBandMaxNodes)
+            return fail(MGPS_ERR_HIERARCHY, "band group exceeds the workgroup budget");
+        for (int q = 1; q < depth; ++q)
+            if (gi[3 + q] < gi[3 + q - 1]) return fail(MGPS_ERR_HIERARCHY, "band group: distance counts not monotone");
+        for (int n = 0; n < gi[3]; ++n) {
+            const int32_t t = bg.updateEntry[size_t(gi[0] + n)] & kBandEntryMask;
+            if (t < 0 || size_t(t) >= nband || ownedOnce[size_t(t)]++) return fail(MGPS_ERR_HIERARCHY, "band entry owned by two groups");
+        }
+        for (size_t q = 0; q < size_t(nUpd) * 6; ++q)
+            if (bg.neighbours[size_t(gi[0]) * 6 + q] > nUpd + nRead) return fail(MGPS_ERR_HIERARCHY, "band group: neighbour id out of range");
+    }
+    for (size_t t = 0; t < nband; ++t)
+        if (!ownedOnce[t]) return fail(MGPS_ERR_HIERARCHY, "band entry owned by no group");
+    // replay
+    const size_t n = d.cells();
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    std::vector<float> x(n, 0.f), b(n, 0.f);
+    uint32_t state = 12345u + uint32_t(level);
+    auto rnd = [&] {
+        state = state * 1664525u + 1013904223u;
+        return float(state >> 8) * (1.f / 16777216.f);
+    };
+    for (size_t c = 0; c < n; ++c)
+        if (isActive(L.labels[c])) {
+            x[c] = rnd();
+            b[c] = rnd();
+        }
+    const float omega = 2.f / 3.f;
+    auto update = [&](float diag, float xc, float bc, float xm, float xp, float ym, float yp, float zm, float zp) {
+        const float lap = diag * xc - (xm + xp + ym + yp + zm + zp);
+        return xc + omega * ((bc - lap) / diag);
+    };
+    auto diagOf = [&](int32_t t) { return float(L.bandDiag[size_t(t)]); };  // unit weights: every cell is simple
+    if (L.numBoundary != 0) return fail(MGPS_ERR_HIERARCHY, "unit-weight level has general BOUNDARY cells");
+    std::vector<float> ref = x, tmp(nband);
+    for (int p = 0; p < depth; ++p) {
+        for (size_t t = 0; t < nband; ++t) {
+            const ptrdiff_t c = L.bandDev[t];
+            tmp[t] = update(diagOf(int32_t(t)), ref[c], b[c], ref[c - 1], ref[c + 1], ref[c - sy], ref[c + sy], ref[c - sz], ref[c + sz]);
+        }
+        for (size_t t = 0; t < nband; ++t) ref[size_t(L.bandDev[t])] = tmp[t];
+    }
+    std::vector<float> fusedOut(nband), v0, v1;
+    for (size_t gI = 0; gI < bg.groups(); ++gI) {
+        const int32_t *gi = bg.info.data() + 8 * gI;
+        const int nUpd = gi[3 + depth - 1], nRead = gi[2];
+        v0.assign(size_t(nUpd + nRead + 1), 0.f);
+        for (int q = 0; q < nUpd; ++q) v0[size_t(q)] = x[size_t(bg.updateCell[size_t(gi[0] + q)])];
+        for (int r = 0; r < nRead; ++r) v0[size_t(nUpd + r)] = x[size_t(bg.readCell[size_t(gi[1] + r)])];
+        v1 = v0;
+        for (int p = 1; p <= depth; ++p) {
+            const std::vector<float> &src = (p & 1) ? v0 : v1;
+            std::vector<float> &dst = (p & 1) ? v1 : v0;
+            for (int q = 0; q < gi[3 + depth - p]; ++q) {
+                const uint16_t *nb = bg.neighbours.data() + 6 * size_t(gi[0] + q);
+                const int32_t e = bg.updateEntry[size_t(gi[0] + q)], t = e & kBandEntryMask;
+                if ((e >> kBandDiagShift) != int32_t(L.bandDiag[size_t(t)])) return fail(MGPS_ERR_HIERARCHY, "band group: packed diagonal mismatch");
+                dst[size_t(q)] = update(diagOf(t), src[size_t(q)], b[size_t(bg.updateCell[size_t(gi[0] + q)])], src[nb[0]], src[nb[1]], src[nb[2]],
+                                        src[nb[3]], src[nb[4]], src[nb[5]]);
+            }
+        }
+        const std::vector<float> &fin = (depth & 1) ? v1 : v0;
+        for (int q = 0; q < gi[3]; ++q) fusedOut[size_t(bg.updateEntry[size_t(gi[0] + q)] & kBandEntryMask)] = fin[size_t(q)];
+    }
+    for (size_t t = 0; t < nband; ++t)
+        if (fusedOut[t] != ref[size_t(L.bandDev[t])]) return fail(MGPS_ERR_HIERARCHY, "fused band replay differs from pass-by-pass replay");
     return MGPS_OK;
 }
 

@@ -69,6 +69,32 @@ struct HostLevel {
     int64_t activeCells = 0;
 };
 
+// Fused band passes (whole-grid levels only).  The band is cut into groups of "owned" cells; a group
+// carries the sub-graph its P consecutive Jacobi passes touch: the band cells within P-1 steps of an
+// owned cell along band-to-band stencil edges ("update nodes", ordered by that distance, owned first)
+// and the cells those read but never write (band cells at distance P, non-band active cells, all
+// frozen during band passes).  One workgroup stages a group's values in LDS, runs the P passes there
+// (pass p recomputes the nodes of distance <= P-p: redundant work instead of P round trips through
+// HBM), and emits the owned cells' final values.  Pure restructuring: every cell sees exactly the
+// arithmetic of P separate compute/scatter passes (Ops.h:524-619).
+constexpr int kBandMaxDepth = 4;
+constexpr int kBandMaxNodes = 4096;   // update + read-only + the shared zero node; two LDS copies
+constexpr int kBandMaxUpdate = 2560;  // a workgroup of 512 threads keeps 5 of them per thread in registers
+constexpr int kBandDiagShift = 28;    // updateEntry = band entry | diagonal << 28 (0: general cell, row list)
+constexpr int kBandEntryMask = (1 << kBandDiagShift) - 1;
+struct BandGroups {
+    int depth = 0;
+    // per group 8 ints: first update node, first read-only node, read-only count,
+    // count of update nodes with distance <= 0 (owned), <= 1, <= 2, <= 3, unused
+    std::vector<int32_t> info;
+    std::vector<int32_t> updateEntry;   // per update node: its index t in bandDev | diagonal << kBandDiagShift
+    std::vector<int32_t> updateCell;    // per update node: linear cell index
+    std::vector<uint16_t> neighbours;   // per update node: 6 group-local node ids (-x,+x,-y,+y,-z,+z)
+    std::vector<int32_t> readCell;      // per read-only node: linear cell index
+    size_t groups() const { return info.size() / 8; }
+};
+void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
+
 void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
                     HostLevel &L);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
@@ -121,6 +147,14 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 // band = device-ordered band list (BOUNDARY cells first, g.nbnd of them)
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                      float *bandTmp, float omega);
+// bg.depth fused band passes (device copy of BandGroups)
+struct BandGroupsDev {
+    int depth = 0, ngroups = 0;
+    int32_t *info = nullptr, *updateEntry = nullptr, *updateCell = nullptr, *readCell = nullptr;
+    uint16_t *neighbours = nullptr;
+};
+int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
+                    float *bandTmp, float omega, const BandGroupsDev &bg);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);

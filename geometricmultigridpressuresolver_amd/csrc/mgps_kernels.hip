@@ -315,6 +315,137 @@ __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restri
     if (t < nband) x[band[t]] = tmp[t];  // Ops.h:604-618
 }
 
+// `depth` consecutive band passes in one launch (BandGroups in mgps_internal.h): a workgroup stages the
+// values of its group's nodes in LDS (two copies: Jacobi reads the previous pass), recomputes the
+// shrinking set of update nodes pass by pass and emits the owned cells' final values into the band
+// list `tmp`; bandScatterKernel then writes them to the grid (other groups still read the old values of
+// these cells while this one runs, so the grid itself must not change in this launch).
+// Every thread keeps the description of its <= kBandSlots update nodes (neighbour ids, rhs, diagonal)
+// in registers, loaded once with all loads in flight together; the passes themselves touch only LDS.
+// general BOUNDARY cell of a band pass (rare: kept out of line so that the common path stays lean)
+__device__ __noinline__ float bandGeneralUpdate(const GridP &g, int t, float xc, float bc, float xm, float xp, float ym,
+                                                float yp, float zm, float zp, float omega)
+{
+    const size_t nb = size_t(g.nbnd);
+    const float *r = g.rows + t;
+    float acc = 0.f;
+    acc -= r[0] * xm;
+    acc -= r[nb] * xp;
+    acc -= r[2 * nb] * ym;
+    acc -= r[3 * nb] * yp;
+    acc -= r[4 * nb] * zm;
+    acc -= r[5 * nb] * zp;
+    const float diag = r[6 * nb];
+    const float lap = acc + diag * xc;
+    return xc + omega * ((bc - lap) / diag);
+}
+
+constexpr int kBandThreads = 512;
+constexpr int kBandSlots = kBandMaxUpdate / kBandThreads;
+static_assert(kBandSlots * kBandThreads == kBandMaxUpdate, "update-node budget must be a whole number of slots");
+
+__global__ __launch_bounds__(kBandThreads) void bandFusedKernel(GridP g, const float *__restrict__ x,
+                                                                const float *__restrict__ b,
+                                                                const int32_t *__restrict__ info,
+                                                                const int32_t *__restrict__ updateEntry,
+                                                                const int32_t *__restrict__ updateCell,
+                                                                const uint16_t *__restrict__ neighbours,
+                                                                const int32_t *__restrict__ readCell,
+                                                                float *__restrict__ tmp, float omega, int depth)
+{
+    __shared__ float val[2][kBandMaxNodes];
+    const int32_t *gi = info + 8 * size_t(blockIdx.x);
+    const int updStart = gi[0], readStart = gi[1], nRead = gi[2];
+    const int cnt[kBandMaxDepth] = {gi[3], gi[4], gi[5], gi[6]};
+    const int nUpd = cnt[depth - 1];
+    const int tid = threadIdx.x;
+
+    int entry[kBandSlots];
+    uint32_t q01[kBandSlots], q23[kBandSlots], q45[kBandSlots];
+    float bv[kBandSlots];
+    {
+        int cell[kBandSlots];
+#pragma unroll
+        for (int m = 0; m < kBandSlots; ++m) {
+            const int n = tid + m * kBandThreads;
+            const size_t at = size_t(updStart) + (n < nUpd ? n : 0);
+            entry[m] = updateEntry[at];
+            cell[m] = updateCell[at];
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(neighbours + 6 * at);
+            q01[m] = q[0];
+            q23[m] = q[1];
+            q45[m] = q[2];
+        }
+        float xv[kBandSlots];
+#pragma unroll
+        for (int m = 0; m < kBandSlots; ++m) {
+            xv[m] = x[cell[m]];
+            bv[m] = b[cell[m]];
+        }
+        // read-only nodes, four loads in flight per thread
+        for (int r0 = tid; r0 < nRead; r0 += 4 * kBandThreads) {
+            int rc[4];
+            float rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * kBandThreads;
+                rc[u] = readCell[readStart + (r < nRead ? r : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rv[u] = x[rc[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * kBandThreads;
+                if (r < nRead) {
+                    val[0][nUpd + r] = rv[u];
+                    val[1][nUpd + r] = rv[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < kBandSlots; ++m) {
+            const int n = tid + m * kBandThreads;
+            if (n < nUpd) {
+                val[0][n] = xv[m];
+                val[1][n] = xv[m];
+            }
+        }
+    }
+    if (tid == 0) {  // every inactive neighbour: grids hold exactly 0 there
+        val[0][nUpd + nRead] = 0.f;
+        val[1][nUpd + nRead] = 0.f;
+    }
+    __syncthreads();
+    for (int p = 1; p <= depth; ++p) {
+        const float *src = val[(p - 1) & 1];
+        float *dst = val[p & 1];
+        const int np = cnt[depth - p];
+#pragma unroll
+        for (int m = 0; m < kBandSlots; ++m) {
+            const int n = tid + m * kBandThreads;
+            if (n < np) {
+                const float xm = src[q01[m] & 0xffffu], xp = src[q01[m] >> 16], ym = src[q23[m] & 0xffffu], yp = src[q23[m] >> 16];
+                const float zm = src[q45[m] & 0xffffu], zp = src[q45[m] >> 16];
+                const float xc = src[n];
+                const int d = entry[m] >> kBandDiagShift;
+                if (d != 0) {  // INTERIOR or simple BOUNDARY cell: the arithmetic of bandComputeKernel
+                    const float diag = float(d);
+                    const float lap = diag * xc - (xm + xp + ym + yp + zm + zp);
+                    dst[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));
+                } else
+                    dst[n] = bandGeneralUpdate(g, entry[m] & kBandEntryMask, xc, bv[m], xm, xp, ym, yp, zm, zp, omega);
+            }
+        }
+        __syncthreads();
+    }
+    const float *fin = val[depth & 1];
+#pragma unroll
+    for (int m = 0; m < kBandSlots; ++m) {
+        const int n = tid + m * kBandThreads;
+        if (n < cnt[0]) tmp[entry[m] & kBandEntryMask] = fin[n];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile-coloured Gauss-Seidel (Ops.h:369-520).  One 256-thread workgroup owns one 16^3 tile of the
 // requested colour: the 18^3 halo cube of x and the 16^3 rhs are staged in LDS, then the tile is
@@ -917,6 +1048,18 @@ int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, con
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned nb = blocksFor(size_t(nband), 256);
     bandComputeKernel<<<nb, 256, 0, s>>>(g, x, b, band, nband, bandTmp, omega, nb);
+    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    return int(hipGetLastError());
+}
+
+int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
+                    float *bandTmp, float omega, const BandGroupsDev &bg)
+{
+    if (nband <= 0 || bg.ngroups <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bandFusedKernel<<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours,
+                                                                  bg.readCell, bandTmp, omega, bg.depth);
+    const unsigned nb = blocksFor(size_t(nband), 256);
     bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());
 }

@@ -44,6 +44,7 @@ struct DevLevel {
     int nbandPlane[4] = {0, 0, 0, 0};
     float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
+    BandGroupsDev bandGroups;  // fused band passes (levels that are not cut into slabs)
 };
 
 }  // namespace
@@ -173,6 +174,11 @@ void freeAll(mgps_solver *h)
         }
         (void)hipFree(L.chunks);
         (void)hipFree(L.planeBlocks);
+        (void)hipFree(L.bandGroups.info);
+        (void)hipFree(L.bandGroups.updateEntry);
+        (void)hipFree(L.bandGroups.updateCell);
+        (void)hipFree(L.bandGroups.readCell);
+        (void)hipFree(L.bandGroups.neighbours);
     }
     for (int a = 0; a < 3; ++a) (void)hipFree(h->w[a]);
     (void)hipFree(h->cinv);
@@ -238,6 +244,10 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
 int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first)
 {
     DevLevel &L = h->lv[l];
+    if (L.bandGroups.ngroups > 0 && L.bandGroups.depth == h->opt.band_iterations) {  // level is not cut: no exchanges
+        MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, L.bandGroups));
+        return MGPS_OK;
+    }
     for (int it = 0; it < h->opt.band_iterations; ++it) {
         MGPS_TRY(exchangeGhosts(h, l, x, it == 0 ? first : GHOST_BAND));
         MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
@@ -525,6 +535,19 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
         }
     MGPS_TRY(devUpload(h, &L.chunks, HL.chunks));
     MGPS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
+    // band passes fuse only where no ghost exchange has to happen between them
+    const bool cut = h->dist && (z0 > 0 || z1 < globalNz);
+    if (!cut && h->opt.fuse_band_passes && h->opt.band_iterations >= 1 && h->opt.band_iterations <= kBandMaxDepth && !HL.bandDev.empty()) {
+        BandGroups bg;
+        buildBandGroups(HL, h->opt.band_iterations, bg);
+        L.bandGroups.depth = bg.depth;
+        L.bandGroups.ngroups = int(bg.groups());
+        MGPS_TRY(devUpload(h, &L.bandGroups.info, bg.info));
+        MGPS_TRY(devUpload(h, &L.bandGroups.updateEntry, bg.updateEntry));
+        MGPS_TRY(devUpload(h, &L.bandGroups.updateCell, bg.updateCell));
+        MGPS_TRY(devUpload(h, &L.bandGroups.readCell, bg.readCell));
+        MGPS_TRY(devUpload(h, &L.bandGroups.neighbours, bg.neighbours));
+    }
     if (xbGrids) {
         MGPS_TRY(gridAlloc(h, &L.x, L.d));
         MGPS_TRY(gridAlloc(h, &L.b, L.d));
@@ -895,6 +918,13 @@ int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const f
     MGPS_TRY(exchangeGhosts(h, level, x_dev));
     MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x_dev, b_dev, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
     return MGPS_OK;
+}
+
+int mgps_boundary_jacobi_stage(mgps_solver *h, int level, float *x_dev, const float *b_dev)
+{
+    MGPS_TRY(checkLevel(h, level, "mgps_boundary_jacobi_stage"));
+    if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_boundary_jacobi_stage: NULL grid");
+    return bandPasses(h, level, x_dev, b_dev, GHOST_FULL);
 }
 
 int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_dev)

@@ -154,6 +154,12 @@ class Hierarchy:
             check(lib().mgps_hierarchy_band_cells(self.h, level, _p(out)))
         return out
 
+    def check_band_groups(self, level, depth=3):
+        """host self-check of the fused band stage; returns (groups, nodes)"""
+        g, n = C.c_int64(), C.c_int64()
+        check(lib().mgps_hierarchy_check_band_groups(self.h, int(level), int(depth), C.byref(g), C.byref(n)))
+        return g.value, n.value
+
     @property
     def coarse_unknowns(self):
         return lib().mgps_hierarchy_coarse_unknowns(self.h)
@@ -252,6 +258,10 @@ class GeometricMultigridPoissonSolver:
 
     def boundaryJacobiPoissonSmoother(self, solution, rhs, level=0):
         check(lib().mgps_boundary_jacobi_smooth(self.h, level, self._g(solution, level), self._g(rhs, level)), self.h)
+
+    def boundaryJacobiStage(self, solution, rhs, level=0):
+        """options.band_iterations band passes, as a smoothing stroke runs them (fused where possible)"""
+        check(lib().mgps_boundary_jacobi_stage(self.h, level, self._g(solution, level), self._g(rhs, level)), self.h)
 
     def applyPoissonMatrix(self, destination, source, level=0):
         check(lib().mgps_apply_poisson(self.h, level, self._g(destination, level), self._g(source, level)), self.h)

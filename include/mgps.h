@@ -70,6 +70,8 @@ typedef struct mgps_options {
     int use_graph;          /* 1 = replay the V-cycle from a captured hipGraph when pointers repeat */
     int print_stats;        /* doPrintStats of MG.h:24: per-stage timings on stdout */
     int max_coarse_unknowns;/* direct-solve cap, default 8192 */
+    int fuse_band_passes;   /* 1 (default) = run the band_iterations band-Jacobi passes of a level that is not cut
+                               into slabs as one launch (same arithmetic per cell); 0 = one launch pair per pass */
     int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
     void *interrupt_user;
 } mgps_options;
@@ -127,6 +129,11 @@ int mgps_hierarchy_level_labels(const mgps_hierarchy *hier, int level, uint8_t *
 int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level);
 /* band cells as (i,j,k) int32 triples, in the reference's order (tile id, k, j, i) */
 int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *out_ijk);
+/* host self-check of the fused band stage (options.fuse_band_passes): builds the level's workgroup
+ * groups for `depth` passes (1..4), verifies their structure and replays the passes group by group and
+ * pass by pass on a seeded grid -- the two must agree bit for bit.  Returns the group and node counts. */
+int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
+                                     int64_t *out_nodes);
 int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier);
 /* x = A_coarsest^{-1} b on the host, grids of the coarsest level's size (MG.cpp:669-692) */
 int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b);
@@ -164,6 +171,10 @@ int mgps_tiled_gs_smooth(mgps_solver *h, int level, float *x_dev, const float *b
                          int smooth_odd_tiles, int smooth_forward);
 /* boundaryJacobiPoissonSmoother over the level's band list (Ops.h:524-619), in place */
 int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev);
+/* the band stage of a smoothing stroke: options.band_iterations of those passes back to back
+ * (MG.cpp:452-458, 483-489), as mgps_apply_vcycle runs them (one fused launch when
+ * options.fuse_band_passes and the level is not cut into slabs) */
+int mgps_boundary_jacobi_stage(mgps_solver *h, int level, float *x_dev, const float *b_dev);
 /* applyPoissonMatrix (Ops.h:621-714).  Inactive cells of y are set to 0. */
 int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_dev);
 /* computePoissonResidual (Ops.h:716-732): r = b - A x, 0 on inactive cells */

@@ -147,6 +147,28 @@ def test_coarse_level_operators(kind, g, domain_factory, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("kind,g", DOMAINS)
+def test_fused_band_stage(kind, g, domain_factory, oracle, torch_cuda):
+    """The band stage of a stroke (three passes fused into one launch on whole-grid levels) against three
+    oracle passes and against three single-pass launches of the same library, on every level."""
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
+    for l in range(orc.levels):
+        ll = orc.level_labels(l)
+        x0 = _rand_active(ll, 30 + l)
+        b0 = _rand_active(ll, 40 + l)
+        bd = gpu.to_device(b0, l)
+        xb = x0.copy()
+        for _ in range(3):
+            oracle.boundary_jacobi(xb, b0, ll, orc.band(l), w64 if l == 0 else None)
+        fused, single = gpu.to_device(x0, l), gpu.to_device(x0, l)
+        gpu.boundaryJacobiStage(fused, bd, level=l)
+        for _ in range(3):
+            gpu.boundaryJacobiPoissonSmoother(single, bd, level=l)
+        assert rel_err(fused.cpu().numpy(), xb) < OP_TOL, l
+        # same arithmetic per cell; allow for a different fused-multiply-add contraction only
+        assert rel_err(fused.cpu().numpy(), single.cpu().numpy().astype(np.float64)) < 1e-6, l
+
+
+@pytest.mark.parametrize("kind,g", DOMAINS)
 def test_transfer_operators(kind, g, domain_factory, oracle, torch_cuda):
     gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
     for l in range(orc.levels - 1):
