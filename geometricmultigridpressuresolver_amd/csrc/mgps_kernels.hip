@@ -34,6 +34,7 @@ constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over t
 // device cell codes (mgps_internal.h): 0 INTERIOR, 1 EXTERIOR, 2 DIRICHLET, 3 general BOUNDARY,
 // 4 + d simple BOUNDARY with diagonal d
 __device__ __forceinline__ bool activeLabel(unsigned l) { return l == MGPS_INTERIOR_CELL || l >= kCodeGeneral; }
+__device__ __forceinline__ bool anyActive(uchar4 l) { return activeLabel(l.x) || activeLabel(l.y) || activeLabel(l.z) || activeLabel(l.w); }
 __device__ __forceinline__ bool simpleCell(unsigned l) { return l == MGPS_INTERIOR_CELL || l > kCodeSimple; }
 __device__ __forceinline__ float simpleDiag(unsigned l) { return l == MGPS_INTERIOR_CELL ? 6.f : float(int(l) - int(kCodeSimple)); }
 // 1/diag of a simple cell: diag is a small integer, one v_rcp_f32 (1 ulp) instead of the ~10-instruction
@@ -764,6 +765,72 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
     *reinterpret_cast<float4 *>(fine + c) = f;
 }
 
+// The same operator with the coarse reads shared: one thread owns the fine quad 4m..4m+3 of the two rows
+// j = 2jp+1, 2jp+2 in the two planes k = 2kp+1, 2kp+2 -- the 16 fine cells that interpolate from the same
+// 2 x 2 coarse rows (bj = jp, jp+1; bk = kp, kp+1) -- so the twelve coarse loads serve 16 cells instead
+// of 4.  Rows 0 / ny-1 are EXTERIOR shell and are never touched; planes -1 / nz exist only as the other
+// rank's cells of a slab run (ghostLo / ghostHi) and are masked.  Same arithmetic per cell as above.
+__global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__restrict__ fine,
+                                                             const float *__restrict__ coarse, unsigned nblocks,
+                                                             int npj, int kp0, size_t total)
+{
+    const unsigned nq = unsigned(fg.nx) >> 2;
+    const size_t t = size_t(remapBlock(blockIdx.x, nblocks)) * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned m = unsigned(t % nq);
+    const size_t rest = t / nq;
+    const int jp = int(rest % unsigned(npj)), kp = kp0 + int(rest / unsigned(npj));
+    const int js[2] = {2 * jp + 1, 2 * jp + 2}, ks[2] = {2 * kp + 1, 2 * kp + 2};
+    const bool kv[2] = {ks[0] >= 0, ks[1] < fg.nz};
+    const size_t sy = size_t(fg.nx), sz = size_t(fg.nx) * fg.ny;
+    size_t c[2][2];
+    uchar4 l[2][2];
+    bool any = false;
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            c[zz][yy] = size_t(kv[zz] ? ks[zz] : 0) * sz + size_t(js[yy]) * sy + (size_t(m) << 2);
+            l[zz][yy] = *reinterpret_cast<const uchar4 *>(fg.lab + c[zz][yy]);
+            any = any || (kv[zz] && anyActive(l[zz][yy]));
+        }
+    if (!any) return;
+    const int cnx = fg.nx >> 1, cny = fg.ny >> 1;
+    const int x0 = max(2 * int(m) - 1, 0), x1 = 2 * int(m), x3 = min(2 * int(m) + 2, cnx - 1);
+    float v[2][2][4];  // [coarse z][coarse y][fine x]
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            const float *r = coarse + (ptrdiff_t(kp + zz) * cny + (jp + yy)) * cnx;  // kp = -1: the lower ghost plane
+            const float c0 = r[x0], c3 = r[x3];
+            const float2 c12 = *reinterpret_cast<const float2 *>(r + x1);
+            v[zz][yy][0] = lerpRef(c0, c12.x, 0.75f);
+            v[zz][yy][1] = lerpRef(c12.x, c12.y, 0.25f);
+            v[zz][yy][2] = lerpRef(c12.x, c12.y, 0.75f);
+            v[zz][yy][3] = lerpRef(c12.y, c3, 0.25f);
+        }
+    const float fs[2] = {0.25f, 0.75f};  // odd index first
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            const uchar4 lab = l[zz][yy];
+            const bool a0 = activeLabel(lab.x), a1 = activeLabel(lab.y), a2 = activeLabel(lab.z), a3 = activeLabel(lab.w);
+            if (!kv[zz] || !anyActive(lab)) continue;
+            float4 f = *reinterpret_cast<const float4 *>(fine + c[zz][yy]);
+            float add[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                add[e] = 4.f * lerpRef(lerpRef(v[0][0][e], v[0][1][e], fs[yy]), lerpRef(v[1][0][e], v[1][1][e], fs[yy]), fs[zz]);
+            if (a0) f.x += add[0];
+            if (a1) f.y += add[1];
+            if (a2) f.z += add[2];
+            if (a3) f.w += add[3];
+            *reinterpret_cast<float4 *>(fine + c[zz][yy]) = f;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Coarsest-level direct solve (MG.cpp:669-692) as x = A^-1 b with the dense inverse built at
 // set-up.  gather b -> v, one wave per row of the mat-vec, scatter into x.
@@ -1085,7 +1152,18 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse)
 {
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
-    if ((fine.nx & 3) == 0 && fine.nx >= 8) {
+    static const bool perCell = [] {  // MGPS_PROLONG=quad: A/B switch for tuning runs
+        const char *e = getenv("MGPS_PROLONG");
+        return e && e[0] == 'q';
+    }();
+    if (!perCell && (fine.nx & 3) == 0 && fine.nx >= 8 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.ny >= 4 && fine.nz >= 2) {
+        const int npj = fine.ny / 2 - 1;  // row pairs (1,2) .. (ny-3, ny-2)
+        const int kp0 = fine.ghostLo ? -1 : 0, kp1 = fine.ghostHi ? fine.nz / 2 - 1 : fine.nz / 2 - 2;
+        const size_t total = size_t(fine.nx >> 2) * npj * size_t(std::max(kp1 - kp0 + 1, 0));
+        const unsigned nb = blocksFor(total, 256);
+        if (nb > 0)
+            prolongAddBlockKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb, npj, kp0, total);
+    } else if ((fine.nx & 3) == 0 && fine.nx >= 8) {
         const unsigned nb = fine.chunks ? unsigned(fine.nchunks) : blocksFor(n >> 2, 256);
         if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
     } else
