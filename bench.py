@@ -241,7 +241,8 @@ def main():
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
         "roofline": {
-            "kernel": "fine-level tiled Gauss-Seidel sweep" if use_gs else "fine-level damped-Jacobi sweep (stencilQuadKernel)",
+            "kernel": "fine-level tiled Gauss-Seidel sweep (tiledGSPureKernel + tiledGSMixedKernel, two colours)" if use_gs
+            else "fine-level damped-Jacobi sweep (%s<OP_JACOBI>)" % ("stencilPlaneKernel" if n >= 256 and n * n * 4 > (2 << 20) else "stencilQuadKernel"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -252,6 +253,7 @@ def main():
             "launches": smooth_groups,
             "cells_per_launch": swept,
             "cells_allocated": cells / world,
+            "achieved_over_allocated_cells": SMOOTHER_BYTES_PER_CELL * (cells / world) / t_sweep / 1e9,
             "note": "per GPU; achieved = 13 B x cells the launch visits (active chunks only) / mean launch time (HIP events on the solver's stream)",
         },
     }

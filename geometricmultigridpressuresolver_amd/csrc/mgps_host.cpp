@@ -626,6 +626,7 @@ void mgps_default_options(mgps_options *opt)
     opt->band_width = 3;               // MG.cpp:141
     opt->band_iterations = 3;          // MG.cpp:142
     opt->fuse_band_passes = 1;
+    opt->min_cells_per_rank = 1 << 21;
     opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
     opt->device = -1;
     opt->use_graph = 0;

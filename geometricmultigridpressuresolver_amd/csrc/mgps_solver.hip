@@ -725,6 +725,8 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
     if (nz_global % P == 0) {
         int planes = nz_global / P;
         while (D < hier->levels - 1 && planes % kTile == 0) {
+            const Dims d = hier->lv[D].d;
+            if (D > 0 && size_t(d.nx) * d.ny * size_t(planes) < size_t(std::max(o.min_cells_per_rank, 0))) break;
             ++D;
             planes /= 2;
         }

@@ -72,6 +72,9 @@ typedef struct mgps_options {
     int max_coarse_unknowns;/* direct-solve cap, default 8192 */
     int fuse_band_passes;   /* 1 (default) = run the band_iterations band-Jacobi passes of a level that is not cut
                                into slabs as one launch (same arithmetic per cell); 0 = one launch pair per pass */
+    int min_cells_per_rank; /* slab runs: a level below the finest stays distributed only while every rank owns at least
+                               this many cells of it (default 2097152 = 128^3); smaller levels are gathered to rank 0,
+                               where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
     int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
     void *interrupt_user;
 } mgps_options;

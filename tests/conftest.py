@@ -33,6 +33,8 @@ def make_domain(kind, g, levels=None, solver_shape=None, dtype=np.float32):
 
     if kind == "wide":  # non-cubic free-surface box, x extent >= 256: exercises the plane-marching sweep
         bl, bw, dx = D.build_complex_domain((g, g, 248), dtype=dtype)
+    elif kind == "wide512":  # x extent 512 (two wavefronts per row in the quad kernels)
+        bl, bw, dx = D.build_complex_domain((g, g, 500), dtype=dtype)
     elif kind == "odd":
         bl, bw, dx = D.build_complex_domain(g, use_solid=True, dtype=dtype)
     elif kind == "simple":

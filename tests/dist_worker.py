@@ -39,7 +39,9 @@ def gpu_mode():
         b_glob = D.random_rhs(lab, dx)
         for use_gs in (False, True):
             comm = TorchDistComm()
-            slab = SlabSolver(lab, slab_w, lev, use_gs, comm, device=0)
+            opt = G.default_options()
+            opt.min_cells_per_rank = 0  # small test grids: keep every level that can be cut distributed
+            slab = SlabSolver(lab, slab_w, lev, use_gs, comm, device=0, options=opt)
             whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
             assert slab.slab_range(0) == (z0, z1), (slab.slab_range(0), z0, z1)
             assert slab.getMGLevels() == whole.getMGLevels()
@@ -143,7 +145,9 @@ def rccl_single_rank_mode():
     comm = RcclComm(device=0)
     b_glob = D.random_rhs(lab, dx)
     for use_gs in (False, True):
-        slab = SlabSolver(lab, w, lev, use_gs, comm, device=0)
+        opt = G.default_options()
+        opt.min_cells_per_rank = 0
+        slab = SlabSolver(lab, w, lev, use_gs, comm, device=0, options=opt)
         whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
         xs, xw = slab.new_grid(), whole.new_grid()
         bs, bw = slab.to_device(b_glob), whole.to_device(b_glob)

@@ -30,7 +30,7 @@ def torch_cuda():
 def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None):
     import geometricmultigridpressuresolver_amd as G
 
-    if kind in ("wide", "odd"):
+    if kind in ("wide", "odd", "wide512"):
         levels, solver_shape = _wide_args(kind)
     lab, w, off, lev, dx = domain_factory(kind, g, levels, solver_shape)
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs)
@@ -56,7 +56,7 @@ def _wide_args(kind):
     """"wide": a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels) -- the plane-marching sweep;
     "odd": a 36^3 complex domain in a 44^3 grid (3 levels: 44, 22, 11) -- level 1 has nx % 4 != 0, which
     takes the scalar sweep and the per-cell band list instead of the quad forms"""
-    return {"wide": (3, (32, 32, 256)), "odd": (3, (44, 44, 44))}.get(kind, (None, None))
+    return {"wide": (3, (32, 32, 256)), "odd": (3, (44, 44, 44)), "wide512": (3, (64, 64, 512))}.get(kind, (None, None))
 
 
 @pytest.mark.parametrize("kind,g", DOMAINS)
@@ -168,7 +168,7 @@ def test_fused_band_stage(kind, g, domain_factory, oracle, torch_cuda):
         assert rel_err(fused.cpu().numpy(), single.cpu().numpy().astype(np.float64)) < 1e-6, l
 
 
-@pytest.mark.parametrize("kind,g", DOMAINS)
+@pytest.mark.parametrize("kind,g", DOMAINS + [("wide512", 40)])
 def test_transfer_operators(kind, g, domain_factory, oracle, torch_cuda):
     gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle)
     for l in range(orc.levels - 1):
@@ -239,7 +239,7 @@ def test_coarse_direct_solve(kind, g, domain_factory, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("use_gs", [False, True])
-@pytest.mark.parametrize("kind,g", DOMAINS)
+@pytest.mark.parametrize("kind,g", DOMAINS + [("wide512", 40)])
 def test_vcycle_matches_oracle(kind, g, use_gs, domain_factory, oracle, torch_cuda):
     gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, use_gs, domain_factory, oracle)
     b = _rand_active(lab, 5, dx * dx)
