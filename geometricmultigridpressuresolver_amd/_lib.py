@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmgps.so")
+LIB_PATH = os.environ.get("MGPS_LIBRARY") or os.path.join(CSRC, "libmgps.so")  # MGPS_LIBRARY: A/B runs of two builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mgps.h")
 
 

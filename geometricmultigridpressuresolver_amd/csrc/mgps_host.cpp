@@ -258,11 +258,22 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     }
     {  // activity lists
         const size_t n = d.cells();
-        L.chunks.clear();
-        for (size_t c0 = 0; c0 < n; c0 += kChunkCells) {
-            bool act = false;
-            for (size_t c = c0; c < std::min(n, c0 + kChunkCells) && !act; ++c) act = isActive(L.labels[c]);
-            if (act) L.chunks.push_back(int32_t(c0 / kChunkCells));
+        auto listOf = [&](int cells) {
+            std::vector<int32_t> list;
+            for (size_t c0 = 0; c0 < n; c0 += size_t(cells)) {
+                bool act = false;
+                for (size_t c = c0; c < std::min(n, c0 + size_t(cells)) && !act; ++c) act = isActive(L.labels[c]);
+                if (act) list.push_back(int32_t(c0 / size_t(cells)));
+            }
+            return list;
+        };
+        L.chunks = listOf(kChunkCells);
+        L.chunkCells = kChunkCells;
+        std::vector<int32_t> fine = listOf(kWaveChunkCells);
+        if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
+            while (fine.size() % 4) fine.push_back(-1);  // a workgroup takes four list entries, one per wavefront
+            L.chunks.swap(fine);
+            L.chunkCells = kWaveChunkCells;
         }
         L.planeBlocks.clear();
         L.planeZc = planeSweepZc(d.nx, d.ny, d.nz);

@@ -13,6 +13,12 @@ namespace mgps {
 
 constexpr int kTile = 16;  // UT_VoxelArray tile edge: decides the Gauss-Seidel colouring (Ops.h:436-448)
 
+// activity-list granularity, chosen per level: 1024 cells (one workgroup of 256 threads x 4 cells) or, where
+// that visits > 10 % more cells (liquid that ends mid-row: free surfaces), 256 cells (one wavefront; the list is
+// then padded with -1 to whole workgroups of four entries)
+constexpr int kChunkCells = 1024;
+constexpr int kWaveChunkCells = 256;
+
 inline bool isActive(uint8_t l) { return l == MGPS_INTERIOR_CELL || l == MGPS_BOUNDARY_CELL; }
 
 // Device-side cell codes.  The kernels read one byte per cell; INTERIOR / EXTERIOR / DIRICHLET keep
@@ -56,9 +62,10 @@ struct HostLevel {
     std::vector<int32_t> bandPlane[4];
     // Activity lists: the reference skips constant (all-EXTERIOR / all-DIRICHLET) 16^3 tiles of its
     // tile-compressed UT_VoxelArray in every operator (`if (!vit.isTileConstant() || active)`, e.g.
-    // Ops.h:322-324); the flat layout gets the same effect from lists of the 1024-cell chunks (and, for
+    // Ops.h:322-324); the flat layout gets the same effect from lists of the 256-cell chunks (and, for
     // the plane-marching sweep, of the 256 x 16 x zc blocks) that hold at least one active cell.
     std::vector<int32_t> chunks;
+    int chunkCells = kChunkCells;
     std::vector<int32_t> planeBlocks;
     int planeZc = 0;
     // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
@@ -117,14 +124,13 @@ struct GridP {
     // just below (k = -1) / above (k = nz) the owned range is a ghost plane held in the same
     // allocation (every array pointer addresses owned plane 0), filled by the neighbour exchange.
     int ghostLo, ghostHi;
-    // active 1024-cell chunks of the flat array / active blocks of the plane-marching sweep
+    // active 256-cell chunks of the flat array (one per wavefront, -1 = padding) / active blocks of the plane-marching sweep
     const int32_t *chunks;
-    int nchunks;
+    int nchunks, chunkCells;
     const int32_t *planeBlocks;
     int nplaneBlocks, planeZc;
 };
 
-constexpr int kChunkCells = 1024;
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
 // does the plane-marching sweep apply to a level of this shape, and with how many planes per block
 inline int planeSweepZc(int nx, int ny, int nz)

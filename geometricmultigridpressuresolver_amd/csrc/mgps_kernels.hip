@@ -106,10 +106,17 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
     const size_t rows = size_t(g.ny) * g.nz;
     const size_t totalQuads = size_t(nq) * rows;
-    unsigned block = remapBlock(blockIdx.x, nblocks);
-    if (chunks) block = unsigned(chunks[block]);  // only the 1024-cell chunks that hold active cells
-    const size_t t = size_t(block) * blockDim.x + threadIdx.x;
-    const bool valid = t < totalQuads;
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    bool valid = true;
+    if (chunks && g.chunkCells == kChunkCells)  // only the chunks that hold active cells: one list entry per workgroup ...
+        t = size_t(chunks[block]) * blockDim.x + threadIdx.x;
+    else if (chunks) {  // ... or per wavefront (wave-uniform index: scalar load)
+        const int ch = chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+        valid = ch >= 0;
+        t = size_t(max(ch, 0)) * kWave + (threadIdx.x & (kWave - 1));
+    }
+    valid = valid && t < totalQuads;
     const size_t tt = valid ? t : totalQuads - 1;
     const unsigned q = unsigned(tt % nq);
     const size_t row = tt / nq;
@@ -664,8 +671,10 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
 __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine)
 {
     const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
-    // with a chunk list: 4 workgroups of 256 per active 1024-cell chunk; the rest of `coarse` stays 0
-    const size_t c = cg.chunks ? size_t(cg.chunks[blockIdx.x >> 2]) * kChunkCells + (blockIdx.x & 3) * 256 + threadIdx.x
+    // with a chunk list: workgroups of 256 over the active chunks (four per 1024-cell chunk); the rest of `coarse` stays 0
+    const int per = cg.chunkCells / 256;
+    if (cg.chunks && cg.chunks[blockIdx.x / per] < 0) return;
+    const size_t c = cg.chunks ? size_t(cg.chunks[blockIdx.x / per]) * cg.chunkCells + (blockIdx.x % per) * 256 + threadIdx.x
                                : size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (!activeLabel(cg.lab[c])) {
@@ -722,9 +731,15 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
 {
     const unsigned nq = unsigned(fg.nx) >> 2;
     const size_t total = size_t(nq) * fg.ny * fg.nz;
-    unsigned block = remapBlock(blockIdx.x, nblocks);
-    if (fg.chunks) block = unsigned(fg.chunks[block]);
-    const size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    if (fg.chunks && fg.chunkCells == kChunkCells)
+        t = size_t(fg.chunks[block]) * blockDim.x + threadIdx.x;
+    else if (fg.chunks) {
+        const int ch = fg.chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+        if (ch < 0) return;
+        t = size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
+    }
     if (t >= total) return;
     const unsigned m = unsigned(t % nq);
     const size_t row = t / nq;
@@ -872,13 +887,20 @@ __device__ __forceinline__ float vecOp(float d, float a, float s, float scale)
 
 // quad index of this thread's `it`-th piece of work: plain grid stride, or (chunk list) the thread's quad
 // inside the it-th active chunk of this workgroup; returns false when the thread is done
-__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, size_t nq, size_t it, size_t &q)
+__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, int chunkCells, size_t nq, size_t it, size_t &q)
 {
-    if (chunks) {
+    if (chunks && chunkCells == kChunkCells) {  // one list entry per workgroup
         const size_t ci = size_t(blockIdx.x) + it * gridDim.x;
         if (ci >= size_t(nchunks)) return false;
         q = size_t(chunks[ci]) * (kChunkCells / 4) + threadIdx.x;
         return true;  // (a ragged last chunk is guarded by q < nq at the use)
+    }
+    if (chunks) {  // nchunks is a multiple of 4: one entry per wavefront of the workgroup
+        const size_t ci = (size_t(blockIdx.x) + it * gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (ci >= size_t(nchunks)) return false;
+        const int ch = chunks[ci];
+        q = ch < 0 ? nq : size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
+        return true;  // (list padding and a ragged last chunk are guarded by q < nq at the use)
     }
     q = size_t(blockIdx.x) * blockDim.x + threadIdx.x + it * size_t(gridDim.x) * blockDim.x;
     return q < nq;
@@ -887,12 +909,12 @@ __device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, siz
 template <int VOP>
 __global__ __launch_bounds__(256) void vecKernel(size_t n, const uint8_t *__restrict__ lab, float *dst, const float *a,
                                                  const float *s, const float *scaleDev, float scaleHost, float sign,
-                                                 const int32_t *__restrict__ chunks, int nchunks)
+                                                 const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
 {
     const float scale = sign * (scaleDev ? *scaleDev : scaleHost);
     const size_t nq = n >> 2;
     size_t q;
-    for (size_t it = 0; nextQuad(chunks, nchunks, nq, it, q); ++it) {
+    for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
         float4 d = reinterpret_cast<const float4 *>(dst)[q];
@@ -970,12 +992,12 @@ __device__ __forceinline__ double blockReduce(double acc)
 template <int KIND>
 __global__ __launch_bounds__(256) void reduceKernel(size_t n, const uint8_t *__restrict__ lab, const float *__restrict__ a,
                                                     const float *__restrict__ b, double *__restrict__ partials,
-                                                    const int32_t *__restrict__ chunks, int nchunks)
+                                                    const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
 {
     double acc = 0.0;  // identity for sums and for max(0, .) / max|.|
     const size_t nq = n >> 2;
     size_t q;
-    for (size_t it = 0; nextQuad(chunks, nchunks, nq, it, q); ++it) {
+    for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
         const float4 av = reinterpret_cast<const float4 *>(a)[q];
@@ -1054,7 +1076,7 @@ size_t stencilSweptCells(const GridP &g)
     const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
     if (g.planeZc && (forced == 2 || (forced == 0 && planeWins)))
         return g.planeBlocks ? std::min(n, size_t(g.nplaneBlocks) * 256 * kPlaneRows * g.planeZc) : n;
-    if ((g.nx & 3) == 0 && g.chunks) return std::min(n, size_t(g.nchunks) * kChunkCells);
+    if ((g.nx & 3) == 0 && g.chunks) return std::min(n, size_t(g.nchunks) * g.chunkCells);
     return n;
 }
 
@@ -1082,7 +1104,7 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
             }
     } else if ((g.nx & 3) == 0) {
         const bool list = skipInactive && g.chunks != nullptr;
-        const unsigned nb = list ? unsigned(g.nchunks) : blocksFor(n >> 2, 256);
+        const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
         const int32_t *chunks = list ? g.chunks : nullptr;
         if (nb > 0) switch (op) {
                 case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
@@ -1144,7 +1166,7 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine)
 {
     const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
-    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * 4 : blocksFor(n, 256);
+    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * unsigned(coarse.chunkCells / 256) : blocksFor(n, 256);
     if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
     return int(hipGetLastError());
 }
@@ -1164,7 +1186,7 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
         if (nb > 0)
             prolongAddBlockKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb, npj, kp0, total);
     } else if ((fine.nx & 3) == 0 && fine.nx >= 8) {
-        const unsigned nb = fine.chunks ? unsigned(fine.nchunks) : blocksFor(n >> 2, 256);
+        const unsigned nb = fine.chunks ? unsigned(fine.nchunks) / unsigned(kChunkCells / fine.chunkCells) : blocksFor(n >> 2, 256);
         if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
     } else
         prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
@@ -1184,7 +1206,7 @@ int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *
 // grid of a grid-stride kernel: over all quads, or over the active chunks of g when it carries a list
 static unsigned vecBlocks(const GridP &g, size_t n)
 {
-    if (g.chunks) return unsigned(std::min<size_t>(std::max(1, g.nchunks), 2048));
+    if (g.chunks) return unsigned(std::min<size_t>(std::max(1, g.nchunks / (kChunkCells / g.chunkCells)), 2048));
     return unsigned(std::min<size_t>(std::max<size_t>(1, ((n >> 2) + 255) / 256), 2048));
 }
 
@@ -1199,7 +1221,7 @@ int launchAxpy(void *stream, const GridP &g, float *dst, const float *src, const
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     vecKernel<V_AXPY><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, src, nullptr,
-                                                                                              scaleDev, scaleHost, sign, g.chunks, g.nchunks);
+                                                                                              scaleDev, scaleHost, sign, g.chunks, g.nchunks, g.chunkCells);
     return int(hipGetLastError());
 }
 int launchXpay(void *stream, const GridP &g, float *dst, const float *a, const float *sv, const float *scaleDev,
@@ -1207,21 +1229,21 @@ int launchXpay(void *stream, const GridP &g, float *dst, const float *a, const f
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     vecKernel<V_XPAY><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, sv, scaleDev,
-                                                                                              scaleHost, 1.f, g.chunks, g.nchunks);
+                                                                                              scaleHost, 1.f, g.chunks, g.nchunks, g.chunkCells);
     return int(hipGetLastError());
 }
 int launchScale(void *stream, const GridP &g, float *v, float scale)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     vecKernel<V_SCALE><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, v, nullptr, nullptr,
-                                                                                               nullptr, scale, 1.f, g.chunks, g.nchunks);
+                                                                                               nullptr, scale, 1.f, g.chunks, g.nchunks, g.chunkCells);
     return int(hipGetLastError());
 }
 int launchMulMasked(void *stream, const GridP &g, float *dst, const float *a, const float *b)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     vecKernel<V_MUL><<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, dst, a, b, nullptr, 1.f,
-                                                                                             1.f, g.chunks, g.nchunks);
+                                                                                             1.f, g.chunks, g.nchunks, g.chunkCells);
     return int(hipGetLastError());
 }
 int launchDiagInverse(void *stream, const GridP &g, float *dinv)
@@ -1256,19 +1278,19 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
     const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
     switch (kind) {
         case 0:
-            reduceKernel<0><<<nb, 256, 0, s>>>(n, g.lab, a, b, partials, g.chunks, g.nchunks);
+            reduceKernel<0><<<nb, 256, 0, s>>>(n, g.lab, a, b, partials, g.chunks, g.nchunks, g.chunkCells);
             reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         case 1:
-            reduceKernel<1><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
+            reduceKernel<1><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks, g.chunkCells);
             reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         case 2:
-            reduceKernel<2><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
+            reduceKernel<2><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks, g.chunkCells);
             reduceFinalKernel<2><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
         default:
-            reduceKernel<3><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks);
+            reduceKernel<3><<<nb, 256, 0, s>>>(n, g.lab, a, nullptr, partials, g.chunks, g.nchunks, g.chunkCells);
             reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
             break;
     }

@@ -571,6 +571,7 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 (h->dist && z1 < globalNz) ? 1 : 0,
                 L.chunks,
                 int(HL.chunks.size()),
+                HL.chunkCells,
                 HL.planeZc ? L.planeBlocks : nullptr,
                 int(HL.planeBlocks.size()),
                 HL.planeZc};
