@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=0, help="multigrid levels (default: coarsest level 16^3)")
     ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--force-slab", action="store_true", help="use the multi-GPU code path (RCCL transport, slab solver) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--check-oracle", action="store_true",
                     help="free_surface_pcg only: also solve with the fp64 CPU oracle and report the pressure-field difference")
@@ -157,10 +158,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    slab_run = world > 1 or args.force_slab  # --force-slab: rehearse the multi-GPU code path with one rank
+    # RCCL prints a version banner on stdout when a communicator comes up; stdout must carry the JSON line only
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if slab_run:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
@@ -174,7 +180,7 @@ def main():
 
     # every rank: labels of the whole grid (1 byte per cell), weights and rhs of its own Z-slab only
     lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
-    if world > 1:
+    if slab_run:
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
 
         comm = RcclComm(device=local_rank)
@@ -187,7 +193,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if slab_run:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -203,7 +209,7 @@ def main():
     elapsed = time.perf_counter() - t0
     smooth_ms, smooth_groups = solver.profile_read()
     solver.profile_enable(False)
-    if world > 1:  # the job is as slow as its slowest rank
+    if slab_run:  # the job is as slow as its slowest rank
         t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, smooth_ms = float(t[0]), float(t[1])
@@ -237,7 +243,7 @@ def main():
             "levels": levels,
             "smoother": "tiled_gs" if use_gs else "jacobi",
             "parallelism": f"zslab{world}",
-            "distributed_levels": solver.distributed_levels if world > 1 else 0,
+            "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
         "roofline": {
@@ -271,8 +277,12 @@ def main():
         pass
     if not args.no_cpu and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if slab_run:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
