@@ -7,6 +7,9 @@
 // MGPS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -505,6 +508,22 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 // ---- construction --------------------------------------------------------------------------------
 
 // upload one level built by buildSlabLevel
+// set-up stage timings on stdout when options.print_stats is set (the reference's ctor prints its four
+// stage times unconditionally, MG.cpp:183, 256, 284, 415)
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageClock(bool enabled) : on(enabled) {}
+    void lap(const char *what, int level = -1)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        if (level >= 0) std::printf("  mgps set-up: %-28s level %d  %8.1f ms\n", what, level, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        else std::printf("  mgps set-up: %-28s          %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    }
+};
+
 int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1, int globalNz, bool withWeights,
                 bool workGrids, bool xbGrids)
 {
@@ -648,13 +667,17 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
                 return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
         }
     }
+    StageClock clock(h->opt.print_stats != 0);
+    clock.lap("weights upload");
     h->lv.resize(hier->levels);
     for (int l = 0; l < hier->levels; ++l) {
         HostLevel HL;
         const Dims d = hier->lv[l].d;
         buildSlabLevel(hier->lv[l], 0, d.nz, l == 0 ? wx : nullptr, l == 0 ? wy : nullptr, l == 0 ? wz : nullptr, HL);
+        clock.lap("codes, rows, lists", l);
         int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0);
         if (rc != MGPS_OK) return bail(rc);
+        clock.lap("band groups + upload", l);
     }
     int rc = commonDeviceState(h, hier->levels > 1 || tailOfSlabRun);
     if (rc != MGPS_OK) return bail(rc);
