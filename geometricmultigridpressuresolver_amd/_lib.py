@@ -44,6 +44,7 @@ class Options(C.Structure):
         ("print_stats", C.c_int),
         ("max_coarse_unknowns", C.c_int),
         ("fuse_band_passes", C.c_int),
+        ("deep_band_halo", C.c_int),
         ("min_cells_per_rank", C.c_int),
         ("interrupt", C.c_void_p),
         ("interrupt_user", C.c_void_p),

@@ -316,87 +316,129 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
 namespace {
 
 struct GroupBuild {
-    std::vector<int32_t> updateEntry, readCell;
+    std::vector<int32_t> updateEntry, updateCell, readCell;
     std::vector<uint16_t> neighbours;
     int cnt[kBandMaxDepth] = {0, 0, 0, 0};
 };
 
-// breadth-first over band-to-band stencil edges from the owned entries; false = does not fit one workgroup
-bool buildOneGroup(const HostLevel &L, const std::vector<int32_t> &bandIndex, const std::vector<int32_t> &owned, int depth,
-                   GroupBuild &g)
+// What the builder walks over: a window of whole x-y planes (the whole grid, or a slab plus the planes of
+// its neighbours that the passes reach), indexed like a grid of extents wd.
+struct BandWindow {
+    Dims wd;
+    const uint8_t *labels = nullptr;     // reference labels or device codes of the window (active: 0 or >= 3)
+    std::vector<int32_t> entryOf;        // window cell -> output entry (>= 0), kDeepBand, or kNoBand
+    std::vector<int32_t> seedCell;       // per output entry: its window cell
+    std::vector<uint8_t> entryDiag;      // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
+    // device address of a window cell: grid offset from owned cell 0 for the planes that live in the grid
+    // allocation, otherwise a slot of the halo buffers (encoded below gridLoCode)
+    int gridPlaneLo = 0, gridPlaneHi = 0;
+    ptrdiff_t cellShift = 0;
+    const std::unordered_map<int64_t, int32_t> *haloSlot = nullptr;
+    int32_t gridLoCode = 0;
+    static constexpr int32_t kNoBand = -1, kDeepBand = -2;  // kDeepBand: a band cell that is nobody's output here
+
+    bool active(size_t wc) const { return labels[wc] == MGPS_INTERIOR_CELL || labels[wc] >= kCodeGeneral; }
+    int diagFromLabels(size_t wc) const  // simple cell: number of non-EXTERIOR face neighbours
+    {
+        const ptrdiff_t sy = wd.nx, sz = ptrdiff_t(wd.nx) * wd.ny, off[6] = {-1, 1, -sy, sy, -sz, sz};
+        int dgn = 0;
+        for (int q = 0; q < 6; ++q) dgn += labels[ptrdiff_t(wc) + off[q]] != MGPS_EXTERIOR_CELL;
+        return dgn;
+    }
+    bool deviceCell(size_t wc, int32_t &code) const
+    {
+        const int k = int(wc / (size_t(wd.nx) * wd.ny));
+        if (k >= gridPlaneLo && k < gridPlaneHi) {
+            code = int32_t(ptrdiff_t(wc) - cellShift);
+            return true;
+        }
+        if (!haloSlot) return false;
+        auto it = haloSlot->find(int64_t(wc));
+        if (it == haloSlot->end()) return false;
+        code = gridLoCode - 1 - it->second;
+        return true;
+    }
+};
+
+// breadth-first over band-to-band stencil edges from the owned entries; 0 = fits one workgroup, 1 = too
+// large (split the owned set), 2 = a cell the passes reach has no device address (builder bug)
+int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int depth, GroupBuild &g)
 {
-    const Dims d = L.d;
-    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    const ptrdiff_t sy = W.wd.nx, sz = ptrdiff_t(W.wd.nx) * W.wd.ny;
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    const uint8_t *codes = L.codes.data() + sz;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
     g = GroupBuild();
-    std::unordered_map<int32_t, int32_t> id;  // cell -> node id; read-only nodes as -(r + 2)
+    std::unordered_map<int64_t, int32_t> id;  // window cell -> node id; read-only nodes as -(r + 2)
     id.reserve(owned.size() * 4);
     std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
+    std::vector<int64_t> updateW, readW;  // window cells of the nodes
     for (int32_t t : owned) {
-        id.emplace(L.bandDev[size_t(t)], int32_t(g.updateEntry.size()));
-        g.updateEntry.push_back(t);
+        id.emplace(int64_t(W.seedCell[size_t(t)]), int32_t(updateW.size()));
+        updateW.push_back(W.seedCell[size_t(t)]);
+        g.updateEntry.push_back(t | (int32_t(W.entryDiag[size_t(t)]) << kBandDiagShift));
     }
     size_t begin = 0;
     constexpr int32_t kZero = -1;
     for (int dist = 0; dist < depth; ++dist) {
-        const size_t end = g.updateEntry.size();
+        const size_t end = updateW.size();
         g.cnt[dist] = int(end);
         for (size_t n = begin; n < end; ++n) {
-            const ptrdiff_t c = L.bandDev[size_t(g.updateEntry[n])];
+            const ptrdiff_t c = ptrdiff_t(updateW[n]);
             for (int q = 0; q < 6; ++q) {
                 const ptrdiff_t cq = c + off[q];
-                const uint8_t code = codes[cq];
-                if (!(code == MGPS_INTERIOR_CELL || code >= kCodeGeneral)) {  // inactive: holds exactly 0
+                if (!W.active(size_t(cq))) {  // inactive: holds exactly 0
                     nbrTmp.push_back(kZero);
                     continue;
                 }
-                auto it = id.find(int32_t(cq));
+                auto it = id.find(int64_t(cq));
                 if (it == id.end()) {
-                    const int32_t t = bandIndex[size_t(cq)];
+                    const int32_t e = W.entryOf[size_t(cq)];
                     int32_t v;
-                    if (t >= 0 && dist + 1 < depth) {
-                        v = int32_t(g.updateEntry.size());
-                        g.updateEntry.push_back(t);
+                    if (e != BandWindow::kNoBand && dist + 1 < depth) {
+                        v = int32_t(updateW.size());
+                        updateW.push_back(cq);
+                        if (e >= 0) g.updateEntry.push_back(e | (int32_t(W.entryDiag[size_t(e)]) << kBandDiagShift));
+                        else g.updateEntry.push_back(int32_t(W.diagFromLabels(size_t(cq))) << kBandDiagShift);  // no output, simple
                     } else {
-                        v = -int32_t(g.readCell.size()) - 2;
-                        g.readCell.push_back(int32_t(cq));
+                        v = -int32_t(readW.size()) - 2;
+                        readW.push_back(cq);
                     }
-                    it = id.emplace(int32_t(cq), v).first;
+                    it = id.emplace(int64_t(cq), v).first;
                 }
                 nbrTmp.push_back(it->second);
             }
-            if (g.updateEntry.size() > size_t(kBandMaxUpdate) || g.updateEntry.size() + g.readCell.size() + 1 > size_t(kBandMaxNodes))
-                return false;
+            if (updateW.size() > size_t(kBandMaxUpdate) || updateW.size() + readW.size() + 1 > size_t(kBandMaxNodes)) return 1;
         }
         begin = end;
     }
     for (int dist = depth; dist < kBandMaxDepth; ++dist) g.cnt[dist] = g.cnt[depth - 1];
-    const int32_t nUpd = int32_t(g.updateEntry.size()), nRead = int32_t(g.readCell.size());
+    const int32_t nUpd = int32_t(updateW.size()), nRead = int32_t(readW.size());
     g.neighbours.resize(nbrTmp.size());
     for (size_t q = 0; q < nbrTmp.size(); ++q) {
         const int32_t v = nbrTmp[q];
         g.neighbours[q] = uint16_t(v >= 0 ? v : (v == kZero ? nUpd + nRead : nUpd + (-v - 2)));
     }
-    return true;
+    g.updateCell.resize(updateW.size());
+    g.readCell.resize(readW.size());
+    for (size_t n = 0; n < updateW.size(); ++n)
+        if (!W.deviceCell(size_t(updateW[n]), g.updateCell[n])) return 2;
+    for (size_t n = 0; n < readW.size(); ++n)
+        if (!W.deviceCell(size_t(readW[n]), g.readCell[n])) return 2;
+    return 0;
 }
 
-}  // namespace
-
-void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
+// groups over all output entries of the window; false = a reached cell had no device address
+bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
 {
     out = BandGroups();
     out.depth = depth;
-    const size_t nband = L.bandDev.size();
-    if (depth < 1 || depth > kBandMaxDepth || nband == 0 || nband > size_t(kBandEntryMask)) return;
-    const Dims d = L.d;
-    std::vector<int32_t> bandIndex(d.cells(), -1);
-    for (size_t t = 0; t < nband; ++t) bandIndex[size_t(L.bandDev[t])] = int32_t(t);
-    // initial partition: the band entries of each 16^3 tile
+    const size_t nent = W.seedCell.size();
+    if (depth < 1 || depth > kBandMaxDepth || nent == 0 || nent > size_t(kBandEntryMask)) return true;
+    const Dims d = W.wd;
+    // initial partition: the output entries of each 16^3 tile of the window
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
-    for (size_t t = 0; t < nband; ++t) {
-        const size_t c = size_t(L.bandDev[t]);
+    for (size_t t = 0; t < nent; ++t) {
+        const size_t c = size_t(W.seedCell[t]);
         const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
         buckets[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile].push_back(int32_t(t));
     }
@@ -406,6 +448,7 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     buckets.clear();
     std::vector<std::vector<GroupBuild>> built(work.size());
     std::atomic<int64_t> next{0};
+    std::atomic<bool> broken{false};
     auto worker = [&] {
         for (;;) {
             const int64_t w = next.fetch_add(1);
@@ -416,14 +459,19 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
                 std::vector<int32_t> owned = std::move(stack.back());
                 stack.pop_back();
                 GroupBuild g;
-                if (buildOneGroup(L, bandIndex, owned, depth, g)) {
+                const int rc = buildOneGroup(W, owned, depth, g);
+                if (rc == 0) {
                     built[size_t(w)].push_back(std::move(g));
                     continue;
+                }
+                if (rc == 2 || owned.size() < 2) {
+                    broken = true;
+                    return;
                 }
                 // too many nodes for one workgroup: halve the owned set along the longest axis of its bounding box
                 int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
                 auto coord = [&](int32_t t, int a) {
-                    const size_t c = size_t(L.bandDev[size_t(t)]);
+                    const size_t c = size_t(W.seedCell[size_t(t)]);
                     return a == 0 ? int(c % d.nx) : a == 1 ? int((c / d.nx) % d.ny) : int(c / (size_t(d.nx) * d.ny));
                 };
                 for (int32_t t : owned)
@@ -455,17 +503,114 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
         worker();
         for (auto &th : pool) th.join();
     }
+    if (broken) {
+        out = BandGroups();
+        return false;
+    }
     for (auto &list : built)
         for (auto &g : list) {
             const int32_t updStart = int32_t(out.updateEntry.size()), readStart = int32_t(out.readCell.size());
             out.info.insert(out.info.end(), {updStart, readStart, int32_t(g.readCell.size()), g.cnt[0], g.cnt[1], g.cnt[2], g.cnt[3], 0});
-            for (int32_t t : g.updateEntry) {
-                out.updateEntry.push_back(t | (int32_t(L.bandDiag[size_t(t)]) << kBandDiagShift));
-                out.updateCell.push_back(L.bandDev[size_t(t)]);
-            }
+            out.updateEntry.insert(out.updateEntry.end(), g.updateEntry.begin(), g.updateEntry.end());
+            out.updateCell.insert(out.updateCell.end(), g.updateCell.begin(), g.updateCell.end());
             out.neighbours.insert(out.neighbours.end(), g.neighbours.begin(), g.neighbours.end());
             out.readCell.insert(out.readCell.end(), g.readCell.begin(), g.readCell.end());
         }
+    return true;
+}
+
+}  // namespace
+
+void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
+{
+    out = BandGroups();
+    out.depth = depth;
+    const size_t nband = L.bandDev.size();
+    if (nband == 0) return;
+    BandWindow W;
+    W.wd = L.d;
+    W.labels = L.codes.data() + size_t(L.d.nx) * L.d.ny;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
+    W.entryOf.assign(L.d.cells(), BandWindow::kNoBand);
+    W.seedCell.assign(L.bandDev.begin(), L.bandDev.end());
+    for (size_t t = 0; t < nband; ++t) W.entryOf[size_t(L.bandDev[t])] = int32_t(t);
+    W.entryDiag = L.bandDiag;
+    W.gridPlaneLo = 0;
+    W.gridPlaneHi = L.d.nz;
+    buildGroupsOverWindow(W, depth, out);
+}
+
+void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out)
+{
+    out = SlabHalo();
+    const Dims gd = G.d;
+    const size_t plane = size_t(gd.nx) * gd.ny;
+    if (depth < 1 || depth > kBandMaxDepth || z1 - z0 < 2 * (depth + 2)) return;
+    // window: the slab, its ghost planes, `depth` closure planes and one more plane for the closure test
+    const int wz0 = std::max(0, z0 - 2 - depth), wz1 = std::min(gd.nz, z1 + 2 + depth);
+    BandWindow W;
+    W.wd = Dims{gd.nx, gd.ny, wz1 - wz0};
+    W.labels = G.labels.data() + size_t(wz0) * plane;
+    const size_t wcells = W.wd.cells(), wlo = size_t(wz0) * plane, whi = size_t(wz1) * plane;
+    std::vector<uint8_t> band(wcells, 0);
+    for (int32_t gcI : G.band) {
+        const size_t gc = size_t(gcI);
+        if (gc >= wlo && gc < whi) band[gc - wlo] = 1;
+    }
+    const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
+    const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
+    // band closure of the global planes [pa, pb), as window cells in increasing order
+    auto closure = [&](int pa, int pb) {
+        std::vector<int64_t> cells;
+        pa = std::max(pa, wz0 + 1);
+        pb = std::min(pb, wz1 - 1);
+        for (int k = pa; k < pb; ++k)
+            for (size_t c = size_t(k - wz0) * plane; c < size_t(k - wz0 + 1) * plane; ++c) {
+                if (!W.active(c)) continue;
+                bool in = band[c] != 0;
+                for (int q = 0; q < 6 && !in; ++q) in = band[size_t(ptrdiff_t(c) + off[q])] != 0;
+                if (in) cells.push_back(int64_t(c));
+            }
+        return cells;
+    };
+    const bool lo = z0 > 0, hi = z1 < gd.nz;
+    const ptrdiff_t ownedShift = ptrdiff_t(z0 - wz0) * ptrdiff_t(plane);  // window cell of owned cell 0
+    std::unordered_map<int64_t, int32_t> slot;
+    if (lo) {
+        for (int64_t c : closure(z0 - 1 - depth, z0 - 1)) slot.emplace(c, int32_t(slot.size()));
+        out.nrecv[0] = int(slot.size());
+        for (int64_t c : closure(z0 + 1, z0 + 1 + depth)) out.sendIdx[0].push_back(int32_t(c - ownedShift));
+    }
+    if (hi) {
+        for (int64_t c : closure(z1 + 1, z1 + 1 + depth)) slot.emplace(c, int32_t(slot.size()));
+        out.nrecv[1] = int(slot.size()) - out.nrecv[0];
+        for (int64_t c : closure(z1 - 1 - depth, z1 - 1)) out.sendIdx[1].push_back(int32_t(c - ownedShift));
+    }
+    // output entries: the owned band cells, then the band cells of the two ghost planes
+    out.bandExt = L.bandDev;
+    out.bandExt.insert(out.bandExt.end(), L.bandPlane[1].begin(), L.bandPlane[1].end());
+    out.bandExt.insert(out.bandExt.end(), L.bandPlane[3].begin(), L.bandPlane[3].end());
+    W.entryOf.assign(wcells, BandWindow::kNoBand);
+    for (size_t c = 0; c < wcells; ++c)
+        if (band[c]) W.entryOf[c] = BandWindow::kDeepBand;
+    W.seedCell.resize(out.bandExt.size());
+    W.entryDiag = L.bandDiag;
+    W.entryDiag.resize(out.bandExt.size(), 0);
+    for (size_t t = 0; t < out.bandExt.size(); ++t) {
+        const size_t wc = size_t(ptrdiff_t(out.bandExt[t]) + ownedShift);
+        W.seedCell[t] = int32_t(wc);
+        W.entryOf[wc] = int32_t(t);
+        if (t >= L.bandDev.size()) W.entryDiag[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
+    }
+    W.gridPlaneLo = z0 - 1 - wz0;  // (a ghost plane outside the domain is never referenced: its cells are not active)
+    W.gridPlaneHi = z1 + 1 - wz0;
+    W.cellShift = ownedShift;
+    W.haloSlot = &slot;
+    W.gridLoCode = -int32_t(plane);
+    if (!buildGroupsOverWindow(W, depth, out.groups)) {  // (a slab without band cells still serves its neighbours' halos)
+        out = SlabHalo();
+        return;
+    }
+    out.depth = depth;
 }
 
 // tileZOffset: number of 16-plane tile layers below this slab (the colour uses the global tile index)
@@ -637,6 +782,7 @@ void mgps_default_options(mgps_options *opt)
     opt->band_width = 3;               // MG.cpp:141
     opt->band_iterations = 3;          // MG.cpp:142
     opt->fuse_band_passes = 1;
+    opt->deep_band_halo = 1;
     opt->min_cells_per_rank = 1 << 21;
     opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
     opt->device = -1;

@@ -102,6 +102,21 @@ struct BandGroups {
 };
 void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
 
+// The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
+// besides its ghost plane a rank receives the *band closure* (band cells and their active face neighbours)
+// of the next `depth` planes of each neighbour, x and rhs, and recomputes the neighbour's band cells it
+// needs itself -- including the band cells of its own ghost planes, whose final values it then holds
+// without a further exchange.  Both neighbours derive the closure lists from the same global labels and
+// band list, so the sender's pack order is the receiver's slot order.
+struct SlabHalo {
+    int depth = 0;                    // 0: not built (level not eligible)
+    std::vector<int32_t> sendIdx[2];  // my cells the lower [0] / upper [1] neighbour needs: offsets from owned cell 0
+    int nrecv[2] = {0, 0};            // closure cells received from the lower / upper neighbour; halo slots: lower first
+    std::vector<int32_t> bandExt;     // bandDev, then the band cells of the lower and of the upper ghost plane
+    BandGroups groups;                // over bandExt; cells outside the grid allocation are encoded as halo slots
+};
+void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out);
+
 void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
                     HostLevel &L);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
@@ -159,8 +174,16 @@ struct BandGroupsDev {
     int32_t *info = nullptr, *updateEntry = nullptr, *updateCell = nullptr, *readCell = nullptr;
     uint16_t *neighbours = nullptr;
 };
+// hx / hb: halo values of x and of the rhs for node cells encoded below gridLo = -(nx*ny) (cut slabs), else nullptr
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg);
+                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr);
+// one message to a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of that plane];
+// the unpack puts the plane into the ghost plane of x, the two lists into the halo arrays and the last
+// part into the band cells of the ghost plane of b (the grids' ghost planes are the solver's scratch)
+int launchHaloPack(void *stream, float *out, const float *x, const float *b, size_t planeStart, size_t plane,
+                   const int32_t *idx, int n, const int32_t *bandIdx, int nb);
+int launchHaloUnpack(void *stream, const float *in, float *x, float *b, ptrdiff_t ghostStart, size_t plane, float *hx, float *hb,
+                     int n, const int32_t *bandIdx, int nb);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);

@@ -359,9 +359,14 @@ __global__ __launch_bounds__(kBandThreads) void bandFusedKernel(GridP g, const f
                                                                 const int32_t *__restrict__ updateCell,
                                                                 const uint16_t *__restrict__ neighbours,
                                                                 const int32_t *__restrict__ readCell,
-                                                                float *__restrict__ tmp, float omega, int depth)
+                                                                float *__restrict__ tmp, float omega, int depth,
+                                                                const float *__restrict__ hx, const float *__restrict__ hb)
 {
     __shared__ float val[2][kBandMaxNodes];
+    // node cells below gridLo are slots of the halo arrays (cells of a neighbouring slab, see SlabHalo)
+    const int gridLo = -(g.nx * g.ny);
+    auto xAt = [&](int c) { return c >= gridLo ? x[c] : hx[gridLo - 1 - c]; };
+    auto bAt = [&](int c) { return c >= gridLo ? b[c] : hb[gridLo - 1 - c]; };
     const int32_t *gi = info + 8 * size_t(blockIdx.x);
     const int updStart = gi[0], readStart = gi[1], nRead = gi[2];
     const int cnt[kBandMaxDepth] = {gi[3], gi[4], gi[5], gi[6]};
@@ -387,8 +392,8 @@ __global__ __launch_bounds__(kBandThreads) void bandFusedKernel(GridP g, const f
         float xv[kBandSlots];
 #pragma unroll
         for (int m = 0; m < kBandSlots; ++m) {
-            xv[m] = x[cell[m]];
-            bv[m] = b[cell[m]];
+            xv[m] = xAt(cell[m]);
+            bv[m] = bAt(cell[m]);
         }
         // read-only nodes, four loads in flight per thread
         for (int r0 = tid; r0 < nRead; r0 += 4 * kBandThreads) {
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(kBandThreads) void bandFusedKernel(GridP g, const f
                 rc[u] = readCell[readStart + (r < nRead ? r : 0)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rv[u] = x[rc[u]];
+            for (int u = 0; u < 4; ++u) rv[u] = xAt(rc[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = r0 + u * kBandThreads;
@@ -1141,13 +1146,50 @@ int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, con
     return int(hipGetLastError());
 }
 
+__global__ void haloPackKernel(float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ b,
+                               size_t planeStart, size_t plane, const int32_t *__restrict__ idx, int n,
+                               const int32_t *__restrict__ bandIdx, int nb)
+{
+    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < plane) out[t] = x[planeStart + t];
+    else if (t < plane + size_t(n)) out[t] = x[idx[t - plane]];
+    else if (t < plane + 2 * size_t(n)) out[t] = b[idx[t - plane - size_t(n)]];
+    else if (t < plane + 2 * size_t(n) + size_t(nb)) out[t] = b[bandIdx[t - plane - 2 * size_t(n)]];
+}
+__global__ void haloUnpackKernel(const float *__restrict__ in, float *__restrict__ x, float *__restrict__ b, ptrdiff_t ghostStart,
+                                 size_t plane, float *__restrict__ hx, float *__restrict__ hb, int n,
+                                 const int32_t *__restrict__ bandIdx, int nb)
+{
+    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < plane) x[ghostStart + ptrdiff_t(t)] = in[t];
+    else if (t < plane + size_t(n)) hx[t - plane] = in[t];
+    else if (t < plane + 2 * size_t(n)) hb[t - plane - size_t(n)] = in[t];
+    else if (t < plane + 2 * size_t(n) + size_t(nb)) b[bandIdx[t - plane - 2 * size_t(n)]] = in[t];
+}
+
+int launchHaloPack(void *stream, float *out, const float *x, const float *b, size_t planeStart, size_t plane,
+                   const int32_t *idx, int n, const int32_t *bandIdx, int nb)
+{
+    const size_t total = plane + 2 * size_t(n) + size_t(nb);
+    haloPackKernel<<<blocksFor(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, b, planeStart, plane, idx, n, bandIdx, nb);
+    return int(hipGetLastError());
+}
+int launchHaloUnpack(void *stream, const float *in, float *x, float *b, ptrdiff_t ghostStart, size_t plane, float *hx, float *hb,
+                     int n, const int32_t *bandIdx, int nb)
+{
+    const size_t total = plane + 2 * size_t(n) + size_t(nb);
+    haloUnpackKernel<<<blocksFor(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, x, b, ghostStart, plane, hx, hb, n, bandIdx,
+                                                                                          nb);
+    return int(hipGetLastError());
+}
+
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg)
+                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb)
 {
     if (nband <= 0 || bg.ngroups <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     bandFusedKernel<<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours,
-                                                                  bg.readCell, bandTmp, omega, bg.depth);
+                                                                  bg.readCell, bandTmp, omega, bg.depth, hx, hb);
     const unsigned nb = blocksFor(size_t(nband), 256);
     bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());

@@ -48,6 +48,18 @@ struct DevLevel {
     float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
     BandGroupsDev bandGroups;  // fused band passes (levels that are not cut into slabs)
+    // fused band stage of a cut level (SlabHalo): one exchange per stage
+    struct Halo {
+        int depth = 0;
+        int32_t *sendIdx[2] = {nullptr, nullptr};
+        int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
+        float *sendBuf[2] = {nullptr, nullptr}, *recvBuf[2] = {nullptr, nullptr};
+        float *hx = nullptr, *hb = nullptr;
+        int32_t *bandExt = nullptr;
+        int nbandExt = 0;
+        float *tmpExt = nullptr;
+        BandGroupsDev groups;
+    } halo;
 };
 
 }  // namespace
@@ -177,6 +189,20 @@ void freeAll(mgps_solver *h)
         }
         (void)hipFree(L.chunks);
         (void)hipFree(L.planeBlocks);
+        for (int q = 0; q < 2; ++q) {
+            (void)hipFree(L.halo.sendIdx[q]);
+            (void)hipFree(L.halo.sendBuf[q]);
+            (void)hipFree(L.halo.recvBuf[q]);
+        }
+        (void)hipFree(L.halo.hx);
+        (void)hipFree(L.halo.hb);
+        (void)hipFree(L.halo.bandExt);
+        (void)hipFree(L.halo.tmpExt);
+        (void)hipFree(L.halo.groups.info);
+        (void)hipFree(L.halo.groups.updateEntry);
+        (void)hipFree(L.halo.groups.updateCell);
+        (void)hipFree(L.halo.groups.readCell);
+        (void)hipFree(L.halo.groups.neighbours);
         (void)hipFree(L.bandGroups.info);
         (void)hipFree(L.bandGroups.updateEntry);
         (void)hipFree(L.bandGroups.updateCell);
@@ -243,10 +269,46 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
 
 // ---- level operators -----------------------------------------------------------------------------
 
+// The band stage of a cut level in one exchange (SlabHalo): ghost plane + band closure of the next planes,
+// x and rhs, in one message per neighbour; then every rank runs the fused stage over its band and the band
+// cells of its ghost planes.  Leaves the ghost planes of x complete.
+int bandStageDeep(mgps_solver *h, int l, float *x, const float *b)
+{
+    DevLevel &L = h->lv[l];
+    DevLevel::Halo &H = L.halo;
+    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
+    // bandPlane: [0] my plane 0, [1] ghost plane below, [2] my top plane, [3] ghost plane above (band cells, same order both sides)
+    const int *nbp = L.nbandPlane;
+    const size_t bytes[2] = {(plane + 2 * size_t(H.nsend[0]) + size_t(nbp[0])) * sizeof(float),
+                             (plane + 2 * size_t(H.nsend[1]) + size_t(nbp[2])) * sizeof(float)};
+    const size_t rbytes[2] = {(plane + 2 * size_t(H.nrecv[0]) + size_t(nbp[1])) * sizeof(float),
+                              (plane + 2 * size_t(H.nrecv[1]) + size_t(nbp[3])) * sizeof(float)};
+    float *bw = const_cast<float *>(b);  // only the ghost planes are written: solver scratch by contract (mgps_grid_alloc)
+    if (lo) MGPS_LAUNCH(h, launchHaloPack(h->stream, H.sendBuf[0], x, b, 0, plane, H.sendIdx[0], H.nsend[0], L.bandPlane[0], nbp[0]));
+    if (hi) MGPS_LAUNCH(h, launchHaloPack(h->stream, H.sendBuf[1], x, b, (size_t(L.d.nz) - 1) * plane, plane, H.sendIdx[1], H.nsend[1],
+                                          L.bandPlane[2], nbp[2]));
+    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
+                                  hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], h->stream));
+    if (lo) MGPS_LAUNCH(h, launchHaloUnpack(h->stream, H.recvBuf[0], x, bw, -ptrdiff_t(plane), plane, H.hx, H.hb, H.nrecv[0],
+                                            L.bandPlane[1], nbp[1]));
+    if (hi) MGPS_LAUNCH(h, launchHaloUnpack(h->stream, H.recvBuf[1], x, bw, ptrdiff_t(size_t(L.d.nz) * plane), plane, H.hx + H.nrecv[0],
+                                            H.hb + H.nrecv[0], H.nrecv[1], L.bandPlane[3], nbp[3]));
+    MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb));
+    return MGPS_OK;
+}
+
+// true: bandPasses leaves the ghost planes of x complete (nothing to exchange before the next operator)
+bool bandStageCompletesGhosts(const mgps_solver *h, int l)
+{
+    return h->dist && h->lv[l].halo.depth > 0 && h->lv[l].halo.depth == h->opt.band_iterations;
+}
+
 // `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
 int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first)
 {
     DevLevel &L = h->lv[l];
+    if (bandStageCompletesGhosts(h, l)) return bandStageDeep(h, l, x, b);
     if (L.bandGroups.ngroups > 0 && L.bandGroups.depth == h->opt.band_iterations) {  // level is not cut: no exchanges
         MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, L.bandGroups));
         return MGPS_OK;
@@ -278,7 +340,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     const bool bands = h->opt.band_iterations > 0;
     MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
     // after the band passes only band cells are stale across the cut -- unless there were none
-    const GhostMode afterBands = bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
+    const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
     if (timed) {
         if (h->profUsed + 2 > h->profEvents.size()) {
@@ -369,7 +431,9 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
                 MGPS_TRY(zeroGrid(h, F.x, F.d, true));  // MG.cpp:566
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
-            MGPS_TRY(exchangeGhosts(h, l, cur[l], h->opt.band_iterations > 0 ? GHOST_BAND : GHOST_FULL));
+            MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
+                                                  : h->opt.band_iterations > 0 ? GHOST_BAND
+                                                                               : GHOST_FULL));
             MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
             MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
@@ -791,6 +855,43 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
                        l == 0 ? wz_slab : nullptr, HL);
         int rc = uploadLevel(h, h->lv[l], HL, lz0, lz1, gz, l == 0, l < D, l > 0);
         if (rc != MGPS_OK) return bail(rc);
+        if (l == D || P == 1 || !o.deep_band_halo || o.band_iterations < 1 || o.band_iterations > kBandMaxDepth) continue;
+        // the one-exchange band stage needs every band cell near a cut to be a simple cell: true on the
+        // unit-weight levels, on the fine level only when no rank holds a general BOUNDARY cell (collective)
+        if (l == 0) {
+            double general = double(HL.numBoundary);
+            if (h->comm.allreduce(h->comm.user, &general, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+            if (general != 0.0) continue;
+        }
+        SlabHalo SH;
+        buildSlabHalo(hier->lv[l], HL, lz0, lz1, o.band_iterations, SH);
+        double failed = SH.depth == 0 ? 1.0 : 0.0;  // every rank must take the same form of the stage
+        if (h->comm.allreduce(h->comm.user, &failed, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+        if (failed != 0.0) continue;
+        DevLevel::Halo &H = h->lv[l].halo;
+        const size_t plane = size_t(nx) * ny >> (2 * l);
+        for (int q = 0; q < 2; ++q) {
+            H.nsend[q] = int(SH.sendIdx[q].size());
+            H.nrecv[q] = SH.nrecv[q];
+            rc = devUpload(h, &H.sendIdx[q], SH.sendIdx[q]);
+            if (rc == MGPS_OK) rc = devAlloc(h, &H.sendBuf[q], plane + 2 * SH.sendIdx[q].size() + HL.bandPlane[2 * q].size(), true);
+            if (rc == MGPS_OK) rc = devAlloc(h, &H.recvBuf[q], plane + 2 * size_t(SH.nrecv[q]) + HL.bandPlane[2 * q + 1].size(), true);
+            if (rc != MGPS_OK) return bail(rc);
+        }
+        rc = devAlloc(h, &H.hx, size_t(SH.nrecv[0]) + SH.nrecv[1], true);
+        if (rc == MGPS_OK) rc = devAlloc(h, &H.hb, size_t(SH.nrecv[0]) + SH.nrecv[1], true);
+        if (rc == MGPS_OK) rc = devUpload(h, &H.bandExt, SH.bandExt);
+        if (rc == MGPS_OK) rc = devAlloc(h, &H.tmpExt, SH.bandExt.size(), true);
+        H.nbandExt = int(SH.bandExt.size());
+        H.groups.depth = SH.groups.depth;
+        H.groups.ngroups = int(SH.groups.groups());
+        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.info, SH.groups.info);
+        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.updateEntry, SH.groups.updateEntry);
+        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.updateCell, SH.groups.updateCell);
+        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.readCell, SH.groups.readCell);
+        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.neighbours, SH.groups.neighbours);
+        if (rc != MGPS_OK) return bail(rc);
+        H.depth = SH.depth;
     }
     int rc = commonDeviceState(h, false);
     if (rc != MGPS_OK) return bail(rc);

@@ -37,10 +37,12 @@ def gpu_mode():
         z0, z1 = rank * nzl, (rank + 1) * nzl
         slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
         b_glob = D.random_rhs(lab, dx)
-        for use_gs in (False, True):
+        counts = {}
+        for use_gs, deep in ((False, 1), (False, 0), (True, 1), (True, 0)):
             comm = TorchDistComm()
             opt = G.default_options()
             opt.min_cells_per_rank = 0  # small test grids: keep every level that can be cut distributed
+            opt.deep_band_halo = deep   # one exchange per band stage / one per band pass
             slab = SlabSolver(lab, slab_w, lev, use_gs, comm, device=0, options=opt)
             whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
             assert slab.slab_range(0) == (z0, z1), (slab.slab_range(0), z0, z1)
@@ -70,12 +72,14 @@ def gpu_mode():
             ss = slab.solveGeometricConjugateGradient(xs, slab.to_device(bd[z0:z1]), 1e-5, 200, True)
             assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
+            counts[(use_gs, deep)] = comm.exchanges
             if rank == 0:
-                print(f"  {kind} gs={use_gs}: D={slab.distributed_levels} exchanges={comm.exchanges} "
+                print(f"  {kind} gs={use_gs} deep={deep}: D={slab.distributed_levels} exchanges={comm.exchanges} "
                       f"({comm.bytes_sent / 1e6:.1f} MB sent) pcg it {ss['iterations']}", flush=True)
             slab.close()
             whole.close()
             dist.barrier()
+        assert counts[(False, 1)] < 0.7 * counts[(False, 0)], counts  # the deep halo must actually cut exchanges
 
 
 def cpu_mode():
