@@ -46,6 +46,14 @@ def test_two_slabs_match_single_gpu():
 
 
 @pytest.mark.gpu
+def test_four_slabs_match_single_gpu():
+    """Four ranks on the one GPU: the two middle ranks exchange with both neighbours (the 2-rank run has edge
+    ranks only), 32 / 16 planes per rank."""
+    out = run_workers("gpu", 4, 600)
+    print(out[-1500:])
+
+
+@pytest.mark.gpu
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)
