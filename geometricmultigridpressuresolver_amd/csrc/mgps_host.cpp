@@ -5,7 +5,10 @@
 // "MG.cpp" = Source/HDK_GeometricMultigridPoissonSolver.cpp.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -43,6 +46,23 @@ static inline int ilog2ceil(int v)
     while ((1 << p) < v) ++p;
     return p;
 }
+
+// MGPS_SETUP_TIMING=1: stage times of the host-side set-up on stderr (tuning aid)
+struct HostLap {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    static bool on()
+    {
+        static const bool v = getenv("MGPS_SETUP_TIMING") != nullptr;
+        return v;
+    }
+    void lap(const char *what)
+    {
+        if (!on()) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "    host set-up: %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    }
+};
 
 // run fn(begin, end) over [0, n) on a handful of host threads
 template <class F>
@@ -165,6 +185,7 @@ static void buildTileLists(HostLevel &L, int tileZOffset);
 void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
                     HostLevel &L)
 {
+    HostLap lap;
     const Dims gd = G.d;
     Dims d = gd;
     d.nz = z1 - z0;
@@ -182,6 +203,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     if (z1 < gd.nz) std::memcpy(L.codes.data() + (size_t(d.nz) + 1) * plane, glab + size_t(z1) * plane, plane);
     uint8_t *codes = L.codes.data() + plane;  // owned plane 0
 
+    lap.lap("slab level: labels + codes copy");
     struct Row {
         float w[6], diag;
         bool simple;
@@ -243,6 +265,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
             restDiag.push_back(6);
         }
     }
+    lap.lap("slab level: band split + rows");
     // band cells of the planes a band-only ghost exchange moves (see HostLevel::bandPlane)
     {
         const int planes[4] = {z0, z0 - 1, z1 - 1, z1};
@@ -256,6 +279,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
             }
         }
     }
+    lap.lap("slab level: band planes");
     {  // activity lists
         const size_t n = d.cells();
         auto listOf = [&](int cells) {
@@ -312,6 +336,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
                 if (act[q]) L.planeBlocks.push_back(int32_t(q));
         }
     }
+    lap.lap("slab level: activity lists");
     L.numBoundary = int32_t(general.size());
     L.bandDev = general;
     L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());
@@ -319,6 +344,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     L.bandDiag.insert(L.bandDiag.end(), restDiag.begin(), restDiag.end());
     buildTileLists(L, z0 / kTile);
     buildTileBoundaryOffsets(L);
+    lap.lap("slab level: tile lists");
     const size_t nb = size_t(L.numBoundary);
     L.rows.assign(7 * nb, 0.f);
     for (size_t t = 0; t < nb; ++t) {
@@ -1032,6 +1058,7 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     if (o.band_width < 1 || o.band_iterations < 0)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: band_width >= 1, band_iterations >= 0");
 
+    HostLap lap;
     auto H = new mgps_hierarchy();
     H->bandWidth = o.band_width;
     H->lv.resize(mg_levels);
@@ -1054,6 +1081,7 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
         delete H;
         return fail(MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain");
     }
+    lap.lap("hierarchy: copy + shell check");
     int levels = mg_levels;
     for (int l = 1; l < levels; ++l) {  // MG.cpp:238-253
         coarsenLabels(H->lv[l - 1], H->lv[l]);
@@ -1068,13 +1096,17 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     }
     H->levels = levels;
     H->lv.resize(levels);
+    lap.lap("hierarchy: coarsen labels");
     for (auto &L : H->lv) {
         buildBand(L, H->bandWidth);  // MG.cpp:279-281
+        lap.lap("hierarchy: band list");
         buildTileLists(L, 0);
+        lap.lap("hierarchy: tile lists");
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.
     const int rc = (levels > 1 || forceCoarseSolver) ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
+    lap.lap("hierarchy: coarse factor");
     if (rc != MGPS_OK) {
         delete H;
         return rc;

@@ -402,16 +402,42 @@ def test_convergence_trace(domain_factory, oracle, torch_cuda):
         prev = cur
 
 
-def test_full_size_properties(torch_cuda):
-    """BASELINE config 2 (256^3 interior cube, 5 levels) through size-independent properties: the
-    oracle is too slow for routine full-size comparison, so check linearity of the V-cycle,
-    zero-outside-active, symmetry and contraction at the benchmark size itself."""
+def test_vcycle_512_matches_oracle(oracle, torch_cuda):
+    """The 512^3 roofline size against the fp64 oracle itself (about 40 s of host time): two chained V-cycles on
+    the interior cube, solution and residual-norm trace."""
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
 
-    lab, w, h = D.interior_cube(256, 5)
-    for use_gs in (False, True):
-        gpu = G.GeometricMultigridPoissonSolver(lab, w, 5, use_gs)
+    n, levels = 512, 6
+    lab, w, h = D.interior_cube(n, levels)
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, False)
+    b32 = D.random_rhs(lab, h, seed=1)
+    bd, xd, rd = gpu.to_device(b32), gpu.new_grid(), gpu.new_grid()
+    lab32 = lab.astype(np.int32)
+    orc = oracle.solver(lab32, [a.astype(np.float64) for a in w], levels, False)
+    b64 = b32.astype(np.float64)
+    x_ref, r_ref = np.zeros(lab.shape), np.zeros(lab.shape)
+    for it in range(2):
+        gpu.applyVCycle(xd, bd, it > 0)
+        orc.apply_vcycle(x_ref, b64, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1)
+        gpu.computePoissonResidual(rd, xd, bd)
+        oracle.residual(r_ref, x_ref, b64, lab32, [a.astype(np.float64) for a in w])
+        assert gpu.l2Norm(rd) == pytest.approx(float(np.sqrt((r_ref * r_ref).sum())), rel=1e-4)
+    gpu.close()
+
+
+@pytest.mark.parametrize("n,levels", [(256, 5), (512, 6), (1024, 7)])
+def test_full_size_properties(n, levels, torch_cuda):
+    """BASELINE configs 2 and 4 and the 512^3 roofline size (interior cubes, coarsest level 16^3) through
+    size-independent properties: the oracle is too slow for routine full-size comparison, so check linearity
+    of the V-cycle, zero-outside-active, symmetry and contraction at the benchmark sizes themselves."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    lab, w, h = D.interior_cube(n, levels)
+    for use_gs in (False, True) if n < 1024 else (False,):
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs)
         a = gpu.to_device(D.random_rhs(lab, h, seed=1))
         b = gpu.to_device(D.random_rhs(lab, h, seed=2))
         xa, xb, xab = gpu.new_grid(), gpu.new_grid(), gpu.new_grid()
@@ -427,9 +453,17 @@ def test_full_size_properties(torch_cuda):
         assert (xa * inactive).abs().max().item() == 0.0
         r = gpu.new_grid()
         norms = [gpu.l2Norm(a)]
-        for it in range(3):  # residual norm falls monotonically over chained V-cycles
+        # chained V-cycles contract the residual (asymptotic factor ~0.7 with one Jacobi sweep per stroke); on
+        # white-noise rhs the first cycles barely move its L2 norm (1.12 |b| after one cycle at 512^3, flat
+        # over the first two at 1024^3 -- the fp64 oracle shows the same trace, test_vcycle_512_matches_oracle),
+        # so monotonicity is required from the third cycle on
+        for it in range(5):
             if it:
                 gpu.applyVCycle(xa, a, True)
             gpu.computePoissonResidual(r, xa, a)
             norms.append(gpu.l2Norm(r))
-            assert norms[-1] < norms[-2]
+            assert it < 2 or norms[-1] < norms[-2]
+        assert norms[-1] < 0.6 * norms[0]
+        gpu.close()
+        del gpu, a, b, xa, xb, xab, ab, r, inactive
+        torch_cuda.cuda.empty_cache()
