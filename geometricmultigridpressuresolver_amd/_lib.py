@@ -40,7 +40,6 @@ class Options(C.Structure):
         ("band_iterations", C.c_int),
         ("jacobi_weight", C.c_float),
         ("device", C.c_int),
-        ("use_graph", C.c_int),
         ("print_stats", C.c_int),
         ("max_coarse_unknowns", C.c_int),
         ("fuse_band_passes", C.c_int),

@@ -827,7 +827,6 @@ void mgps_default_options(mgps_options *opt)
     opt->min_cells_per_rank = 1 << 21;
     opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
     opt->device = -1;
-    opt->use_graph = 0;
     opt->print_stats = 0;
     opt->max_coarse_unknowns = 8192;
     opt->interrupt = nullptr;

@@ -67,7 +67,6 @@ typedef struct mgps_options {
     int band_iterations;    /* 3 */
     float jacobi_weight;    /* 2/3 */
     int device;             /* HIP device ordinal; -1 = current device */
-    int use_graph;          /* 1 = replay the V-cycle from a captured hipGraph when pointers repeat */
     int print_stats;        /* doPrintStats of MG.h:24: per-stage timings on stdout */
     int max_coarse_unknowns;/* direct-solve cap, default 8192 */
     int fuse_band_passes;   /* 1 (default) = run the band_iterations band-Jacobi passes of a level that is not cut
