@@ -1,0 +1,421 @@
+// Plugin-side field pre/post-processing on the device (include/mgps_fields.h).
+// Every pass is one thread per cell or face over a dense x-fastest grid: consecutive lanes read consecutive
+// addresses of every input, HBM-bound streaming kernels with a handful of bytes per cell.  No reference
+// counterpart of the layout: the reference walks 16^3 tiles of UT_VoxelArray on the host (Plug.cpp:716-1207).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "mgps_fields.h"
+#include "mgps_internal.h"
+
+using namespace mgps;
+
+namespace {
+
+enum : int { kSolid = 0, kLiquid = 1, kAir = 2 };  // Util.h:17
+
+struct Box {
+    int gx, gy, gz;
+    __host__ __device__ size_t cells() const { return size_t(gx) * gy * gz; }
+};
+
+__device__ __forceinline__ size_t cellAt(const Box &g, int i, int j, int k) { return (size_t(k) * g.gy + j) * g.gx + i; }
+__device__ __forceinline__ size_t faceAt(const Box &g, int axis, int i, int j, int k)
+{
+    return (size_t(k) * (g.gy + (axis == 1)) + j) * (g.gx + (axis == 0)) + i;
+}
+// cellToFaceMap(cell, axis, dir)
+__device__ __forceinline__ size_t cellFace(const Box &g, int axis, int dir, int i, int j, int k)
+{
+    return faceAt(g, axis, i + (axis == 0 && dir), j + (axis == 1 && dir), k + (axis == 2 && dir));
+}
+__device__ __forceinline__ float ghostFluidTheta(float phi0, float phi1)  // Util.h:25-42 + the clamp of Plug.cpp:850-851
+{
+    float theta = 0.f;
+    if (phi0 < 0.f) theta = phi1 < 0.f ? 1.f : phi0 / (phi0 - phi1);
+    else if (phi1 < 0.f) theta = phi1 / (phi1 - phi0);
+    return fminf(fmaxf(theta, 0.01f), 1.f);
+}
+// thread -> (i, j, k) of a grid of extents (nx, ny, nz); false past the end
+__device__ __forceinline__ bool unflatten(int nx, int ny, int nz, int &i, int &j, int &k)
+{
+    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= size_t(nx) * ny * nz) return false;
+    i = int(t % nx);
+    j = int((t / nx) % ny);
+    k = int(t / (size_t(nx) * ny));
+    return true;
+}
+
+__global__ void materialLabelsKernel(Box g, int32_t *__restrict__ material, const float *__restrict__ phi,
+                                     const float *__restrict__ solidPhi, const float *__restrict__ cwx,
+                                     const float *__restrict__ cwy, const float *__restrict__ cwz)
+{
+    int i, j, k;
+    if (!unflatten(g.gx, g.gy, g.gz, i, j, k)) return;
+    const float *cw[3] = {cwx, cwy, cwz};
+    const int ext[3] = {g.gx, g.gy, g.gz};
+    const size_t c = cellAt(g, i, j, k);
+    bool open[3][2], inFluid = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            open[a][d] = cw[a][cellFace(g, a, d, i, j, k)] > 0.f;
+            inFluid = inFluid || open[a][d];
+        }
+    int label = kSolid;
+    if (inFluid) {
+        bool liquid = phi[c] <= 0.f;
+        if (!liquid && solidPhi[c] >= 0.f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    int n[3] = {i, j, k};
+                    n[a] += d ? 1 : -1;
+                    if (open[a][d] && n[a] >= 0 && n[a] < ext[a] && phi[cellAt(g, n[0], n[1], n[2])] <= 0.f) liquid = true;
+                }
+        }
+        label = liquid ? kLiquid : kAir;
+    }
+    material[c] = label;
+}
+
+__global__ void validFacesKernel(Box g, int axis, uint8_t *__restrict__ valid, const int32_t *__restrict__ material,
+                                 const float *__restrict__ cw)
+{
+    int i, j, k;
+    if (!unflatten(g.gx + (axis == 0), g.gy + (axis == 1), g.gz + (axis == 2), i, j, k)) return;
+    const size_t f = faceAt(g, axis, i, j, k);
+    const int ext[3] = {g.gx, g.gy, g.gz};
+    int b[3] = {i, j, k}, fw[3] = {i, j, k};
+    b[axis] -= 1;
+    uint8_t v = 0;
+    if (cw[f] > 0.f && b[axis] >= 0 && fw[axis] < ext[axis])
+        v = material[cellAt(g, b[0], b[1], b[2])] == kLiquid || material[cellAt(g, fw[0], fw[1], fw[2])] == kLiquid;
+    valid[f] = v;
+}
+
+__global__ void domainLabelsKernel(Box g, Box e, int offset, uint8_t *__restrict__ expanded, const int32_t *__restrict__ material)
+{
+    int i, j, k;
+    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
+    const int bi = i - offset, bj = j - offset, bk = k - offset;
+    uint8_t l = MGPS_EXTERIOR_CELL;
+    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz) {
+        const int m = material[cellAt(g, bi, bj, bk)];
+        l = m == kLiquid ? MGPS_INTERIOR_CELL : m == kAir ? MGPS_DIRICHLET_CELL : MGPS_EXTERIOR_CELL;
+    }
+    expanded[cellAt(e, i, j, k)] = l;
+}
+
+__global__ void boundaryWeightsKernel(Box g, Box e, int offset, int axis, float *__restrict__ expanded, const float *__restrict__ cw,
+                                      const float *__restrict__ phi, const uint8_t *__restrict__ valid,
+                                      const int32_t *__restrict__ material)
+{
+    int i, j, k;
+    if (!unflatten(e.gx + (axis == 0), e.gy + (axis == 1), e.gz + (axis == 2), i, j, k)) return;
+    const int bi = i - offset, bj = j - offset, bk = k - offset;
+    float w = 0.f;
+    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx + (axis == 0) && bj < g.gy + (axis == 1) && bk < g.gz + (axis == 2)) {
+        const size_t f = faceAt(g, axis, bi, bj, bk);
+        if (valid[f]) {  // a valid face has both cells inside the grid
+            int b[3] = {bi, bj, bk};
+            b[axis] -= 1;
+            const size_t cb = cellAt(g, b[0], b[1], b[2]), cf = cellAt(g, bi, bj, bk);
+            const int mb = material[cb], mf = material[cf];
+            w = cw[f];
+            if ((mb == kLiquid && mf == kAir) || (mb == kAir && mf == kLiquid)) w /= ghostFluidTheta(phi[cb], phi[cf]);
+        }
+    }
+    expanded[faceAt(e, axis, i, j, k)] = w;
+}
+
+__global__ void setBoundaryLabelsKernel(Box e, uint8_t *__restrict__ lab, const float *__restrict__ wx,
+                                        const float *__restrict__ wy, const float *__restrict__ wz)
+{
+    int i, j, k;
+    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
+    const size_t c = cellAt(e, i, j, k);
+    // INTERIOR cells have all six neighbours inside the grid (the EXTERIOR shell); BOUNDARY written by another
+    // thread reads as "not DIRICHLET / EXTERIOR" just like INTERIOR, so the in-place update is race-free
+    if (lab[c] != MGPS_INTERIOR_CELL) return;
+    const float *w[3] = {wx, wy, wz};
+    const ptrdiff_t stride[3] = {1, e.gx, ptrdiff_t(e.gx) * e.gy};
+    bool bnd = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint8_t nl = lab[ptrdiff_t(c) + (d ? stride[a] : -stride[a])];
+            bnd = bnd || nl == MGPS_DIRICHLET_CELL || nl == MGPS_EXTERIOR_CELL || w[a][cellFace(e, a, d, i, j, k)] != 1.f;
+        }
+    if (bnd) lab[c] = MGPS_BOUNDARY_CELL;
+}
+
+// weighted divergence of a LIQUID cell; signBackward = +1 gives the right-hand side (Plug.cpp:912), -1 the
+// divergence report (Plug.cpp:1180)
+__device__ __forceinline__ float cellDivergence(const Box &g, int i, int j, int k, float signBackward, const float *const v[3],
+                                                const float *const sv[3], const float *const cw[3])
+{
+    float div = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const size_t f = cellFace(g, a, d, i, j, k);
+            const float sign = d == 0 ? signBackward : -signBackward, w = cw[a][f];
+            if (w > 0.f) div += sign * w * v[a][f];
+            if (sv[a] && w < 1.f) div += sign * (1.f - w) * sv[a][f];
+        }
+    return div;
+}
+
+__global__ void rhsKernel(Box g, Box e, int offset, float *__restrict__ rhs, const int32_t *__restrict__ material, const float *vx,
+                          const float *vy, const float *vz, const float *svx, const float *svy, const float *svz, const float *cwx,
+                          const float *cwy, const float *cwz)
+{
+    int i, j, k;
+    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
+    const int bi = i - offset, bj = j - offset, bk = k - offset;
+    float r = 0.f;
+    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz && material[cellAt(g, bi, bj, bk)] == kLiquid) {
+        const float *v[3] = {vx, vy, vz}, *sv[3] = {svx, svy, svz}, *cw[3] = {cwx, cwy, cwz};
+        r = cellDivergence(g, bi, bj, bk, 1.f, v, sv, cw);
+    }
+    rhs[cellAt(e, i, j, k)] = r;
+}
+
+__global__ void pressureToSolutionKernel(Box g, Box e, int offset, float *__restrict__ x, const float *__restrict__ pressure,
+                                         const int32_t *__restrict__ material)
+{
+    int i, j, k;
+    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
+    const int bi = i - offset, bj = j - offset, bk = k - offset;
+    float v = 0.f;
+    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz) {
+        const size_t c = cellAt(g, bi, bj, bk);
+        if (material[c] == kLiquid) v = pressure[c];
+    }
+    x[cellAt(e, i, j, k)] = v;
+}
+
+__global__ void solutionToPressureKernel(Box g, Box e, int offset, float *__restrict__ pressure, const float *__restrict__ x,
+                                         const int32_t *__restrict__ material)
+{
+    int i, j, k;
+    if (!unflatten(g.gx, g.gy, g.gz, i, j, k)) return;
+    const size_t c = cellAt(g, i, j, k);
+    if (material[c] == kLiquid) pressure[c] = x[cellAt(e, i + offset, j + offset, k + offset)];
+}
+
+__global__ void pressureGradientKernel(Box g, int axis, float *__restrict__ velocity, const float *__restrict__ phi,
+                                       const float *__restrict__ pressure, const uint8_t *__restrict__ valid,
+                                       const int32_t *__restrict__ material)
+{
+    int i, j, k;
+    if (!unflatten(g.gx + (axis == 0), g.gy + (axis == 1), g.gz + (axis == 2), i, j, k)) return;
+    const size_t f = faceAt(g, axis, i, j, k);
+    if (!valid[f]) return;  // valid faces have both cells inside the grid (Plug.cpp:1086-1087 never skips one)
+    int b[3] = {i, j, k};
+    b[axis] -= 1;
+    const size_t cb = cellAt(g, b[0], b[1], b[2]), cf = cellAt(g, i, j, k);
+    float grad = pressure[cf] - pressure[cb];
+    if (material[cb] != kLiquid || material[cf] != kLiquid) grad /= ghostFluidTheta(phi[cb], phi[cf]);
+    velocity[f] -= grad;
+}
+
+constexpr int kDivBlocks = 1024;
+__global__ __launch_bounds__(256) void divergenceKernel(Box g, double *__restrict__ partials, const int32_t *__restrict__ material,
+                                                        const float *vx, const float *vy, const float *vz, const float *svx,
+                                                        const float *svy, const float *svz, const float *cwx, const float *cwy,
+                                                        const float *cwz)
+{
+    const float *v[3] = {vx, vy, vz}, *sv[3] = {svx, svy, svz}, *cw[3] = {cwx, cwy, cwz};
+    double sum = 0.0, mx = 0.0, count = 0.0;
+    const size_t n = g.cells();
+    for (size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n; t += size_t(gridDim.x) * blockDim.x) {
+        if (material[t] != kLiquid) continue;
+        const int i = int(t % g.gx), j = int((t / g.gx) % g.gy), k = int(t / (size_t(g.gx) * g.gy));
+        const double d = double(cellDivergence(g, i, j, k, -1.f, v, sv, cw));
+        sum += d;
+        mx = d > mx ? d : mx;
+        count += 1.0;
+    }
+    __shared__ double s[3][256];
+    s[0][threadIdx.x] = sum;
+    s[1][threadIdx.x] = mx;
+    s[2][threadIdx.x] = count;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (int(threadIdx.x) < off) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + off];
+            s[1][threadIdx.x] = s[1][threadIdx.x] > s[1][threadIdx.x + off] ? s[1][threadIdx.x] : s[1][threadIdx.x + off];
+            s[2][threadIdx.x] += s[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = s[0][0];
+        partials[kDivBlocks + blockIdx.x] = s[1][0];
+        partials[2 * kDivBlocks + blockIdx.x] = s[2][0];
+    }
+}
+
+int bad(const char *what)
+{
+    setLastGlobalError(std::string(what) + ": NULL pointer, axis outside 0..2 or non-positive extent");
+    return MGPS_ERR_INVALID_ARGUMENT;
+}
+int done(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MGPS_OK;
+    setLastGlobalError(std::string(what) + ": " + hipGetErrorString(e));
+    return MGPS_ERR_HIP;
+}
+inline unsigned blocks(size_t n) { return unsigned((n + 255) / 256); }
+inline bool okBox(int x, int y, int z) { return x > 0 && y > 0 && z > 0; }
+inline bool okExpanded(int gx, int gy, int gz, int ex, int ey, int ez, int off)
+{
+    return okBox(ex, ey, ez) && off >= 0 && gx + off <= ex && gy + off <= ey && gz + off <= ez;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgps_fields_material_labels(int32_t *material, const float *liquid_phi, const float *solid_phi, const float *cwx,
+                                const float *cwy, const float *cwz, int gx, int gy, int gz, void *stream)
+{
+    if (!material || !liquid_phi || !solid_phi || !cwx || !cwy || !cwz || !okBox(gx, gy, gz)) return bad("mgps_fields_material_labels");
+    const Box g{gx, gy, gz};
+    materialLabelsKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, material, liquid_phi, solid_phi, cwx, cwy, cwz);
+    return done("mgps_fields_material_labels");
+}
+
+int mgps_fields_valid_faces(int axis, uint8_t *valid, const int32_t *material, const float *cut_weights, int gx, int gy,
+                            int gz, void *stream)
+{
+    if (axis < 0 || axis > 2 || !valid || !material || !cut_weights || !okBox(gx, gy, gz)) return bad("mgps_fields_valid_faces");
+    const Box g{gx, gy, gz};
+    const size_t n = size_t(gx + (axis == 0)) * (gy + (axis == 1)) * (gz + (axis == 2));
+    validFacesKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, axis, valid, material, cut_weights);
+    return done("mgps_fields_valid_faces");
+}
+
+int mgps_fields_domain_labels(uint8_t *expanded_labels, const int32_t *material, int gx, int gy, int gz, int ex, int ey,
+                              int ez, int offset, void *stream)
+{
+    if (!expanded_labels || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
+        return bad("mgps_fields_domain_labels");
+    const Box g{gx, gy, gz}, e{ex, ey, ez};
+    domainLabelsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_labels, material);
+    return done("mgps_fields_domain_labels");
+}
+
+int mgps_fields_boundary_weights(int axis, float *expanded_weights, const float *cut_weights, const float *liquid_phi,
+                                 const uint8_t *valid, const int32_t *material, int gx, int gy, int gz, int ex, int ey,
+                                 int ez, int offset, void *stream)
+{
+    if (axis < 0 || axis > 2 || !expanded_weights || !cut_weights || !liquid_phi || !valid || !material || !okBox(gx, gy, gz) ||
+        !okExpanded(gx, gy, gz, ex, ey, ez, offset))
+        return bad("mgps_fields_boundary_weights");
+    const Box g{gx, gy, gz}, e{ex, ey, ez};
+    const size_t n = size_t(ex + (axis == 0)) * (ey + (axis == 1)) * (ez + (axis == 2));
+    boundaryWeightsKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, axis, expanded_weights, cut_weights,
+                                                                                   liquid_phi, valid, material);
+    return done("mgps_fields_boundary_weights");
+}
+
+int mgps_fields_set_boundary_labels(uint8_t *expanded_labels, const float *wx, const float *wy, const float *wz, int ex,
+                                    int ey, int ez, void *stream)
+{
+    if (!expanded_labels || !wx || !wy || !wz || !okBox(ex, ey, ez)) return bad("mgps_fields_set_boundary_labels");
+    const Box e{ex, ey, ez};
+    setBoundaryLabelsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(e, expanded_labels, wx, wy, wz);
+    return done("mgps_fields_set_boundary_labels");
+}
+
+int mgps_fields_rhs(float *expanded_rhs, const int32_t *material, const float *vx, const float *vy, const float *vz,
+                    const float *svx, const float *svy, const float *svz, const float *cwx, const float *cwy,
+                    const float *cwz, int gx, int gy, int gz, int ex, int ey, int ez, int offset, void *stream)
+{
+    if (!expanded_rhs || !material || !vx || !vy || !vz || !cwx || !cwy || !cwz || !okBox(gx, gy, gz) ||
+        !okExpanded(gx, gy, gz, ex, ey, ez, offset) || ((svx || svy || svz) && !(svx && svy && svz)))
+        return bad("mgps_fields_rhs");
+    const Box g{gx, gy, gz}, e{ex, ey, ez};
+    rhsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_rhs, material, vx, vy, vz, svx, svy,
+                                                                             svz, cwx, cwy, cwz);
+    return done("mgps_fields_rhs");
+}
+
+int mgps_fields_pressure_to_solution(float *expanded_x, const float *pressure, const int32_t *material, int gx, int gy,
+                                     int gz, int ex, int ey, int ez, int offset, void *stream)
+{
+    if (!expanded_x || !pressure || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
+        return bad("mgps_fields_pressure_to_solution");
+    const Box g{gx, gy, gz}, e{ex, ey, ez};
+    pressureToSolutionKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_x, pressure, material);
+    return done("mgps_fields_pressure_to_solution");
+}
+
+int mgps_fields_solution_to_pressure(float *pressure, const float *expanded_x, const int32_t *material, int gx, int gy,
+                                     int gz, int ex, int ey, int ez, int offset, void *stream)
+{
+    if (!pressure || !expanded_x || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
+        return bad("mgps_fields_solution_to_pressure");
+    const Box g{gx, gy, gz}, e{ex, ey, ez};
+    solutionToPressureKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, pressure, expanded_x, material);
+    return done("mgps_fields_solution_to_pressure");
+}
+
+int mgps_fields_pressure_gradient(int axis, float *velocity, const float *liquid_phi, const float *pressure,
+                                  const uint8_t *valid, const int32_t *material, int gx, int gy, int gz, void *stream)
+{
+    if (axis < 0 || axis > 2 || !velocity || !liquid_phi || !pressure || !valid || !material || !okBox(gx, gy, gz))
+        return bad("mgps_fields_pressure_gradient");
+    const Box g{gx, gy, gz};
+    const size_t n = size_t(gx + (axis == 0)) * (gy + (axis == 1)) * (gz + (axis == 2));
+    pressureGradientKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, axis, velocity, liquid_phi, pressure, valid, material);
+    return done("mgps_fields_pressure_gradient");
+}
+
+int mgps_fields_divergence(double out_host[3], const int32_t *material, const float *vx, const float *vy, const float *vz,
+                           const float *svx, const float *svy, const float *svz, const float *cwx, const float *cwy,
+                           const float *cwz, int gx, int gy, int gz, void *stream)
+{
+    if (!out_host || !material || !vx || !vy || !vz || !cwx || !cwy || !cwz || !okBox(gx, gy, gz) ||
+        ((svx || svy || svz) && !(svx && svy && svz)))
+        return bad("mgps_fields_divergence");
+    const Box g{gx, gy, gz};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *partials = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&partials), 3 * kDivBlocks * sizeof(double)) != hipSuccess) {
+        setLastGlobalError("mgps_fields_divergence: hipMalloc failed");
+        return MGPS_ERR_ALLOC;
+    }
+    divergenceKernel<<<kDivBlocks, 256, 0, s>>>(g, partials, material, vx, vy, vz, svx, svy, svz, cwx, cwy, cwz);
+    std::vector<double> host(3 * kDivBlocks);
+    hipError_t e = hipMemcpyAsync(host.data(), partials, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(partials);
+    if (e != hipSuccess) {
+        setLastGlobalError(std::string("mgps_fields_divergence: ") + hipGetErrorString(e));
+        return MGPS_ERR_HIP;
+    }
+    double sum = 0.0, mx = 0.0, count = 0.0;  // fixed order: reproducible
+    for (int b = 0; b < kDivBlocks; ++b) {
+        sum += host[size_t(b)];
+        mx = host[size_t(kDivBlocks + b)] > mx ? host[size_t(kDivBlocks + b)] : mx;
+        count += host[size_t(2 * kDivBlocks + b)];
+    }
+    out_host[0] = sum;
+    out_host[1] = mx;
+    out_host[2] = count;
+    return MGPS_OK;
+}
+
+}  // extern "C"

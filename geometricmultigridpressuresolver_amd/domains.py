@@ -310,3 +310,49 @@ def sine_initial_guess(lab, h, dtype=np.float32):
     ) * np.sin(4 * np.pi * y)
     v[~active_mask(lab)] = 0.0
     return v.astype(dtype)
+
+
+def projection_scene(shape, seed=7, with_solid_velocity=False, dtype=np.float32):
+    """Synthetic inputs of one pressure projection on the BASE grid (Plug.cpp:113-426): a pool with a wavy free
+    surface, closed domain walls and an immersed axis-aligned solid box whose faces cut cells (fractional
+    cut-cell weights = open area fraction of each face, < 0.01 closed).  Returns a dict of numpy arrays:
+    liquid_phi, solid_phi (cell centres; liquid where liquid_phi <= 0, inside the solid where solid_phi >= 0,
+    the conventions of Util.cpp:14, 25), cut_weights[3], velocity[3] (face grids) and solid_velocity[3] or None."""
+    gz, gy, gx = shape
+    dx = 1.0 / max(shape)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    zc, yc, xc = np.meshgrid((np.arange(gz) + 0.5) * dx, (np.arange(gy) + 0.5) * dx, (np.arange(gx) + 0.5) * dx, indexing="ij")
+    top = gz * dx
+    liquid_phi = zc - top * (0.55 + 0.08 * np.sin(2 * np.pi * xc / (gx * dx)) * np.cos(2 * np.pi * yc / (gy * dx)))
+    lo = np.array([0.31 * gx, 0.27 * gy, 0.18 * gz]) * dx  # box corners (x, y, z), off the grid lines
+    hi = np.array([0.62 * gx, 0.71 * gy, 0.44 * gz]) * dx
+    inside = (xc > lo[0]) & (xc < hi[0]) & (yc > lo[1]) & (yc < hi[1]) & (zc > lo[2]) & (zc < hi[2])
+    solid_phi = np.where(inside, dx, -dx)
+
+    def overlap(a0, a1, b0, b1):  # length of [a0, a1] covered by [b0, b1]
+        return np.clip(np.minimum(a1, b1) - np.maximum(a0, b0), 0.0, None)
+
+    cut = []
+    for axis in range(3):  # 0 = x faces
+        fshape = face_shape(gz, gy, gx, axis)
+        n = [gx, gy, gz]
+        idx = np.meshgrid(*[np.arange(fshape[d]) for d in range(3)], indexing="ij")  # k, j, i
+        pos = {0: idx[2], 1: idx[1], 2: idx[0]}  # integer index along x, y, z
+        # in-plane extents of the face and its position along the axis
+        t = [a for a in range(3) if a != axis]
+        area = np.ones(fshape)
+        for a in t:
+            area = area * overlap(pos[a] * dx, (pos[a] + 1) * dx, lo[a], hi[a]) / dx
+        along = pos[axis] * dx
+        closed = np.where((along > lo[axis]) & (along < hi[axis]), area, 0.0)
+        w = 1.0 - closed
+        w[w < 0.01] = 0.0
+        wall = (pos[axis] == 0) | (pos[axis] == n[axis])
+        w[wall] = 0.0
+        cut.append(w.astype(dtype))
+    velocity = [(rng.random(c.shape) * 2 - 1).astype(dtype) for c in cut]
+    solid_velocity = [(0.2 * (rng.random(c.shape) * 2 - 1)).astype(dtype) for c in cut] if with_solid_velocity else None
+    return {
+        "liquid_phi": liquid_phi.astype(dtype), "solid_phi": solid_phi.astype(dtype), "cut_weights": cut,
+        "velocity": velocity, "solid_velocity": solid_velocity, "dx": dx,
+    }

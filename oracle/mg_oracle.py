@@ -23,10 +23,10 @@ INTERIOR, EXTERIOR, DIRICHLET, BOUNDARY = 0, 1, 2, 3
 def build(force=False):
     """Compile the oracle shared libraries in place (gcc, OpenMP)."""
     names = ["libmgoracle.so", "libmgoracle_f32.so"]
-    src = os.path.join(_HERE, "mg_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("mg_oracle.c", "mg_fields_oracle.c")]
     stale = force or any(
         not os.path.exists(os.path.join(_HERE, n))
-        or os.path.getmtime(os.path.join(_HERE, n)) < os.path.getmtime(src)
+        or any(os.path.getmtime(os.path.join(_HERE, n)) < os.path.getmtime(src) for src in srcs)
         for n in names
     )
     if stale:
@@ -291,3 +291,98 @@ class OracleSolver:
         )
         it = int(stats[0])
         return {"status": rc, "iterations": it, "rel_residual": stats[1], "rel_residual_recomputed": stats[2], "history": hist[: it + 1]}
+
+
+class FieldsOracle:
+    """ctypes front end of oracle/mg_fields_oracle.c (fp64): the plugin-side field pre/post-processing
+    (Plug.cpp:716-1207, Util.cpp:5-148).  Grids are numpy [k, j, i] arrays; face grids have one more entry
+    along their axis (axis 0 = x = last array dimension)."""
+
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(os.path.join(_HERE, "libmgoracle.so"))
+
+    @staticmethod
+    def face_shape(shape, axis):
+        s = list(shape)
+        s[2 - axis] += 1
+        return tuple(s)
+
+    @staticmethod
+    def _f64(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+    def material_labels(self, liquid_phi, solid_phi, cw):
+        gz, gy, gx = liquid_phi.shape
+        out = np.empty(liquid_phi.shape, dtype=np.int32)
+        c = [self._f64(a) for a in cw]
+        self.lib.mgf_material_labels(_ptr(out), _ptr(self._f64(liquid_phi)), _ptr(self._f64(solid_phi)), _ptr(c[0]), _ptr(c[1]), _ptr(c[2]), gx, gy, gz)
+        return out
+
+    def valid_faces(self, material, cw):
+        gz, gy, gx = material.shape
+        out = []
+        for a in range(3):
+            v = np.empty(self.face_shape(material.shape, a), dtype=np.uint8)
+            self.lib.mgf_valid_faces(a, _ptr(v), _ptr(material), _ptr(self._f64(cw[a])), gx, gy, gz)
+            out.append(v)
+        return out
+
+    def domain_labels(self, material, eshape, offset):
+        gz, gy, gx = material.shape
+        ez, ey, ex = eshape
+        out = np.empty(eshape, dtype=np.int32)
+        self.lib.mgf_domain_labels(_ptr(out), _ptr(material), gx, gy, gz, ex, ey, ez, int(offset))
+        return out
+
+    def boundary_weights(self, cw, liquid_phi, valid, material, eshape, offset):
+        gz, gy, gx = material.shape
+        ez, ey, ex = eshape
+        out = []
+        phi = self._f64(liquid_phi)
+        for a in range(3):
+            w = np.empty(self.face_shape(eshape, a), dtype=np.float64)
+            self.lib.mgf_boundary_weights(a, _ptr(w), _ptr(self._f64(cw[a])), _ptr(phi), _ptr(valid[a]), _ptr(material), gx, gy, gz, ex, ey, ez, int(offset))
+            out.append(w)
+        return out
+
+    def rhs(self, material, vel, cw, eshape, offset, solid_vel=None):
+        gz, gy, gx = material.shape
+        ez, ey, ex = eshape
+        out = np.empty(eshape, dtype=np.float64)
+        v = [self._f64(a) for a in vel]
+        sv = [self._f64(a) for a in solid_vel] if solid_vel is not None else [None] * 3
+        c = [self._f64(a) for a in cw]
+        self.lib.mgf_rhs(_ptr(out), _ptr(material), *[_ptr(a) for a in v], *[_ptr(a) for a in sv], *[_ptr(a) for a in c], gx, gy, gz, ex, ey, ez, int(offset))
+        return out
+
+    def pressure_to_solution(self, pressure, material, eshape, offset):
+        gz, gy, gx = material.shape
+        ez, ey, ex = eshape
+        out = np.empty(eshape, dtype=np.float64)
+        self.lib.mgf_pressure_to_solution(_ptr(out), _ptr(self._f64(pressure)), _ptr(material), gx, gy, gz, ex, ey, ez, int(offset))
+        return out
+
+    def solution_to_pressure(self, pressure, solution, material, offset):
+        gz, gy, gx = material.shape
+        ez, ey, ex = solution.shape
+        assert pressure.dtype == np.float64 and pressure.flags.c_contiguous
+        self.lib.mgf_solution_to_pressure(_ptr(pressure), _ptr(self._f64(solution)), _ptr(material), gx, gy, gz, ex, ey, ez, int(offset))
+        return pressure
+
+    def pressure_gradient(self, vel, cw, liquid_phi, pressure, valid, material):
+        gz, gy, gx = material.shape
+        for a in range(3):
+            assert vel[a].dtype == np.float64 and vel[a].flags.c_contiguous
+            self.lib.mgf_pressure_gradient(a, _ptr(vel[a]), _ptr(self._f64(cw[a])), _ptr(self._f64(liquid_phi)), _ptr(self._f64(pressure)),
+                                           _ptr(valid[a]), _ptr(material), gx, gy, gz)
+        return vel
+
+    def divergence(self, material, vel, cw, solid_vel=None):
+        gz, gy, gx = material.shape
+        out = np.zeros(3)
+        v = [self._f64(a) for a in vel]
+        sv = [self._f64(a) for a in solid_vel] if solid_vel is not None else [None] * 3
+        c = [self._f64(a) for a in cw]
+        self.lib.mgf_divergence(_ptr(out), _ptr(material), *[_ptr(a) for a in v], *[_ptr(a) for a in sv], *[_ptr(a) for a in c], gx, gy, gz)
+        return float(out[0]), float(out[1]), float(out[2])

@@ -1,0 +1,148 @@
+"""Plugin-side field pre/post-processing (include/mgps_fields.h).
+
+CPU: the oracle pipeline (material labels -> valid faces -> multigrid labels / weights -> right-hand side ->
+MG-PCG -> pressure -> pressure gradient) leaves the liquid divergence-free -- the reference's own end-to-end
+check (Plug.cpp:704-706) -- and its labels / weights satisfy the reference's structural unit tests.
+GPU: every device pass against the oracle on the same inputs, and the same end-to-end property through the
+HIP solver.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import geometricmultigridpressuresolver_amd as G  # noqa: E402
+from geometricmultigridpressuresolver_amd import domains as D  # noqa: E402
+from oracle.mg_oracle import FieldsOracle  # noqa: E402
+
+SHAPE = (40, 32, 48)  # gz, gy, gx
+
+
+@pytest.fixture(scope="module")
+def fo():
+    return FieldsOracle()
+
+
+def _oracle_pipeline(fo, oracle, sc, with_solid):
+    cw, phi = sc["cut_weights"], sc["liquid_phi"]
+    sv = sc["solid_velocity"] if with_solid else None
+    material = fo.material_labels(phi, sc["solid_phi"], cw)
+    valid = fo.valid_faces(material, cw)
+    eshape, offset, levels = G.expanded_layout(SHAPE, 0, power_of_two=False)
+    lab = fo.domain_labels(material, eshape, offset)
+    w = fo.boundary_weights(cw, phi, valid, material, eshape, offset)
+    oracle.set_boundary_labels(lab, w)
+    rhs = fo.rhs(material, sc["velocity"], cw, eshape, offset, sv)
+    return material, valid, eshape, offset, levels, lab, w, rhs
+
+
+@pytest.mark.parametrize("with_solid", [False, True])
+def test_oracle_projection_is_divergence_free(fo, oracle, with_solid):
+    sc = D.projection_scene(SHAPE, with_solid_velocity=with_solid, dtype=np.float64)
+    material, valid, eshape, offset, levels, lab, w, rhs = _oracle_pipeline(fo, oracle, sc, with_solid)
+    sv = sc["solid_velocity"] if with_solid else None
+    assert {0, 1, 2} == set(np.unique(material)) and (material == 1).sum() > 5000
+    assert oracle.unit_test_exterior(lab) and oracle.unit_test_boundary(lab, w)  # Ops.cpp:602, Ops.h:1771
+    # every valid face carries a positive weight; liquid/air faces are scaled by 1/theta >= 1 (Plug.cpp:827-853)
+    for a in range(3):
+        assert (sc["cut_weights"][a][valid[a] == 1] > 0).all()
+    assert max(float(x.max()) for x in w) > 1.0
+    s = oracle.solver(lab, w, levels, True)
+    x = np.zeros(eshape)
+    st = s.solve_pcg(x, rhs, 1e-10, 500, True)
+    assert st["rel_residual_recomputed"] < 1e-9
+    pressure = np.zeros(SHAPE)
+    fo.solution_to_pressure(pressure, x, material, offset)
+    vel = [v.copy() for v in sc["velocity"]]
+    fo.pressure_gradient(vel, sc["cut_weights"], sc["liquid_phi"], pressure, valid, material)
+    before = np.abs(fo.rhs(material, sc["velocity"], sc["cut_weights"], eshape, offset, sv)).max()
+    after = np.abs(fo.rhs(material, vel, sc["cut_weights"], eshape, offset, sv)).max()
+    assert before > 0.1 and after < 1e-8 * before
+    total, mx, count = fo.divergence(material, vel, sc["cut_weights"], sv)
+    assert count == (material == 1).sum() and abs(total) < 1e-8 * count and 0 <= mx < 1e-8
+    # the warm-start copy is the inverse of the pressure copy on liquid cells
+    assert (fo.pressure_to_solution(pressure, material, eshape, offset) == np.where(np.isin(lab, (0, 3)), x, 0)).all()
+
+
+def _dev(a, torch):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_solid", [False, True])
+def test_device_passes_match_oracle(fo, oracle, with_solid):
+    import torch
+
+    from geometricmultigridpressuresolver_amd import fields as F
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=with_solid)
+    material, valid, eshape, offset, levels, lab, w, rhs = _oracle_pipeline(fo, oracle, sc, with_solid)
+    cw = [_dev(a, torch) for a in sc["cut_weights"]]
+    phi, sphi = _dev(sc["liquid_phi"], torch), _dev(sc["solid_phi"], torch)
+    vel = [_dev(a, torch) for a in sc["velocity"]]
+    sv = [_dev(a, torch) for a in sc["solid_velocity"]] if with_solid else None
+    mat_d = F.buildMaterialCellLabels(phi, sphi, cw)
+    assert (mat_d.cpu().numpy() == material).all()
+    valid_d = F.buildValidFaces(mat_d, cw)
+    for a in range(3):
+        assert (valid_d[a].cpu().numpy() == valid[a]).all()
+    lab_d, w_d = F.buildMGDomain(mat_d, cw, phi, valid_d, eshape, offset)
+    assert (lab_d.cpu().numpy() == lab).all()
+    for a in range(3):
+        assert np.abs(w_d[a].cpu().numpy() - w[a]).max() <= 2e-6 * np.abs(w[a]).max()
+    rhs_d = F.buildRHS(mat_d, vel, cw, eshape, offset, sv)
+    assert np.abs(rhs_d.cpu().numpy() - rhs).max() < 1e-5
+    # pressure copy in / out and the gradient update on a seeded pressure field
+    rng = np.random.default_rng(5)
+    p_host = np.where(material == 1, rng.random(SHAPE), 0.0).astype(np.float32)
+    x_d = F.applyOldPressure(_dev(p_host, torch), mat_d, eshape, offset)
+    assert (x_d.cpu().numpy() == fo.pressure_to_solution(p_host, material, eshape, offset).astype(np.float32)).all()
+    p_back = torch.full(SHAPE, 9.0, dtype=torch.float32, device="cuda")
+    F.applySolutionToPressure(p_back, x_d, mat_d, offset)
+    assert (p_back.cpu().numpy() == np.where(material == 1, p_host, 9.0)).all()
+    vel_ref = [v.astype(np.float64) for v in sc["velocity"]]
+    fo.pressure_gradient(vel_ref, sc["cut_weights"], sc["liquid_phi"], p_host, valid, material)
+    vel_d = [v.clone() for v in vel]
+    F.applyPressureGradient(vel_d, phi, _dev(p_host, torch), valid_d, mat_d)
+    for a in range(3):
+        assert np.abs(vel_d[a].cpu().numpy() - vel_ref[a]).max() < 2e-5 * np.abs(vel_ref[a]).max()
+    got = F.computeResultingDivergence(mat_d, vel, cw, sv)
+    ref = fo.divergence(material, sc["velocity"], sc["cut_weights"], sc["solid_velocity"] if with_solid else None)
+    assert got[2] == ref[2] and abs(got[0] - ref[0]) < 1e-4 * ref[2] and got[1] == pytest.approx(ref[1], rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_projection_is_divergence_free():
+    """The whole projection on the device: fields -> multigrid domain -> MG-PCG -> pressure -> velocity; the
+    reference's own end-to-end check is the resulting divergence (Plug.cpp:704-706)."""
+    import torch
+
+    from geometricmultigridpressuresolver_amd import fields as F
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=True)
+    cw = [_dev(a, torch) for a in sc["cut_weights"]]
+    phi, sphi = _dev(sc["liquid_phi"], torch), _dev(sc["solid_phi"], torch)
+    vel = [_dev(a, torch) for a in sc["velocity"]]
+    sv = [_dev(a, torch) for a in sc["solid_velocity"]]
+    eshape, offset, levels = G.expanded_layout(SHAPE, 0, power_of_two=False)
+    material = F.buildMaterialCellLabels(phi, sphi, cw)
+    valid = F.buildValidFaces(material, cw)
+    labels, weights = F.buildMGDomain(material, cw, phi, valid, eshape, offset)
+    rhs = F.buildRHS(material, vel, cw, eshape, offset, sv)
+    # hierarchy set-up still reads labels and weights on the host
+    solver = G.GeometricMultigridPoissonSolver(labels.cpu().numpy(), [a.cpu().numpy() for a in weights], levels, True)
+    x = solver.new_grid()
+    st = solver.solveGeometricConjugateGradient(x, rhs, 1e-6, 200, True)
+    assert st["outcome"] == "converged"
+    pressure = torch.zeros(SHAPE, dtype=torch.float32, device="cuda")
+    F.applySolutionToPressure(pressure, x, material, offset)
+    before = F.buildRHS(material, vel, cw, eshape, offset, sv).abs().max().item()
+    F.applyPressureGradient(vel, phi, pressure, valid, material)
+    after = F.buildRHS(material, vel, cw, eshape, offset, sv).abs().max().item()
+    total, mx, count = F.computeResultingDivergence(material, vel, cw, sv)
+    assert after < 2e-4 * before and mx <= after * 1.0001 and count == (material == 1).sum().item()
+    solver.close()

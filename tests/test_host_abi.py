@@ -20,9 +20,11 @@ KINDS = [("simple", 16), ("complex", 24), ("solid", 24)]
 
 
 def test_library_exports_every_declared_symbol():
-    header = open(os.path.join(ROOT, "include", "mgps.h")).read()
+    import glob
+
+    header = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     names = sorted(set(re.findall(r"\b(mgps_[a-z0-9_]+)\s*\(", header)))
-    assert len(names) >= 45
+    assert len(names) >= 55 and "mgps_fields_rhs" in names
     missing = [n for n in names if not hasattr(lib(), n)]
     assert not missing, missing
 
