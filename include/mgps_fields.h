@@ -11,7 +11,7 @@
  * f - e_a (backward) and f (forward).  Material labels (int32): 0 SOLID, 1 LIQUID, 2 AIR (Util.h:17).
  * HDK samples the solid SDF and the solid velocity by interpolation at a position (Util.cpp:25,
  * Plug.cpp:925); here the caller passes them sampled at cell centres / face centres.
- * `stream` is a hipStream_t (NULL = the null stream).  Return values: mgps_status (mgps.h). */
+ * `stream` is a hipStream_t (NULL = the null stream).  Return values: the status codes of mgps.h. */
 #ifndef MGPS_FIELDS_H
 #define MGPS_FIELDS_H
 
