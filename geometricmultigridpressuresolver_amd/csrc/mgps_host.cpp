@@ -64,12 +64,52 @@ struct HostLap {
     }
 };
 
+// Threads worth starting: the visible cores capped by the cgroup CPU quota (a GPU box shows every host core
+// but grants a share; one thread per visible core there is slower than running serially).
+static int hostThreads()
+{
+    static const int n = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        int v = int(hw ? hw : 4);
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm') v = std::min(v, std::max(1, int(atol(quota) / period)));
+            fclose(f);
+        }
+        return std::max(1, std::min(v, 64));
+    }();
+    return n;
+}
+
+// ordered parallel collect: fn(begin, end, out) appends the items of [begin, end) to out; the pieces are
+// concatenated in range order, so the result equals the serial loop's
+template <class T, class F>
+static void parallelCollect(int64_t n, int64_t minPerThread, std::vector<T> &result, F fn)
+{
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(hostThreads(), n / std::max<int64_t>(1, minPerThread))));
+    std::vector<std::vector<T>> parts{size_t(nt)};
+    const int64_t chunk = (n + nt - 1) / nt;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        if (t + 1 < nt && e < n) pool.emplace_back([&, b, e, t] { fn(b, e, parts[size_t(t)]); });
+        else fn(b, e, parts[size_t(t)]);
+    }
+    for (auto &th : pool) th.join();
+    size_t total = 0;
+    for (auto &v : parts) total += v.size();
+    result.clear();
+    result.reserve(total);
+    for (auto &v : parts) result.insert(result.end(), v.begin(), v.end());
+}
+
 // run fn(begin, end) over [0, n) on a handful of host threads
 template <class F>
 static void parallelFor(int64_t n, F fn)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = int(std::min<int64_t>(hw ? hw : 4, std::max<int64_t>(1, n / 4096)));
+    int nt = int(std::min<int64_t>(hostThreads(), std::max<int64_t>(1, n / 4096)));
     if (nt <= 1) {
         fn(int64_t(0), n);
         return;
@@ -139,11 +179,13 @@ static void buildBand(HostLevel &L, int width)
     const size_t n = d.cells();
     std::vector<uint8_t> mark(n, 0);  // 0 unvisited, 1 in band
     std::vector<size_t> frontier, next;
-    for (size_t c = 0; c < n; ++c)
-        if (lab[c] == MGPS_BOUNDARY_CELL) {
-            frontier.push_back(c);
-            mark[c] = 1;
-        }
+    parallelCollect<size_t>(int64_t(n), 1 << 20, frontier, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
+        for (int64_t c = b; c < e; ++c)
+            if (lab[c] == MGPS_BOUNDARY_CELL) {
+                out.push_back(size_t(c));
+                mark[size_t(c)] = 1;
+            }
+    });
     const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
     for (int ring = 1; ring < width; ++ring) {
         next.clear();
@@ -160,16 +202,18 @@ static void buildBand(HostLevel &L, int width)
     }
     // emit in (tile, k, j, i) order: walk tiles in linear tile order, cells x-fastest inside
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    L.band.clear();
-    for (int t = 0; t < tx * ty * tz; ++t) {
-        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
-        for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
-            for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
-                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i)
-                    if (mark[d.idx(i, j, k)]) L.band.push_back(int32_t(d.idx(i, j, k)));
-    }
+    parallelCollect<int32_t>(int64_t(tx) * ty * tz, 256, L.band, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
+        for (int64_t t = b; t < e; ++t) {
+            const int ti = int(t % tx), tj = int((t / tx) % ty), tk = int(t / (int64_t(tx) * ty));
+            for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
+                for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j) {
+                    const uint8_t *row = mark.data() + d.idx(0, j, k);
+                    for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i)
+                        if (row[i]) out.push_back(int32_t(d.idx(i, j, k)));
+                }
+        }
+    });
 }
-
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
 
@@ -284,11 +328,15 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         const size_t n = d.cells();
         auto listOf = [&](int cells) {
             std::vector<int32_t> list;
-            for (size_t c0 = 0; c0 < n; c0 += size_t(cells)) {
-                bool act = false;
-                for (size_t c = c0; c < std::min(n, c0 + size_t(cells)) && !act; ++c) act = isActive(L.labels[c]);
-                if (act) list.push_back(int32_t(c0 / size_t(cells)));
-            }
+            const int64_t nchunks = int64_t((n + size_t(cells) - 1) / size_t(cells));
+            parallelCollect<int32_t>(nchunks, 4096, list, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
+                for (int64_t q = b; q < e; ++q) {
+                    const size_t c0 = size_t(q) * size_t(cells);
+                    bool act = false;
+                    for (size_t c = c0; c < std::min(n, c0 + size_t(cells)) && !act; ++c) act = isActive(L.labels[c]);
+                    if (act) out.push_back(int32_t(q));
+                }
+            });
             return list;
         };
         L.chunks = listOf(kChunkCells);
@@ -537,8 +585,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
         }
     };
     {
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = int(std::min<size_t>(std::min<unsigned>(hw ? hw : 4, 32), std::max<size_t>(1, work.size() / 64)));
+        const int nt = int(std::min<size_t>(size_t(hostThreads()), std::max<size_t>(1, work.size() / 64)));
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
         worker();
@@ -661,26 +708,34 @@ static void buildTileLists(HostLevel &L, int tileZOffset)
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     for (auto *v : {&L.tilesOdd, &L.tilesEven, &L.pureOdd, &L.pureEven, &L.mixedOdd, &L.mixedEven}) v->clear();
     L.activeCells = 0;
-    for (int t = 0; t < tx * ty * tz; ++t) {
-        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
-        int64_t active = 0, interior = 0;
-        for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
-            for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j)
-                for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) {
-                    const uint8_t l = L.labels[d.idx(i, j, k)];
-                    active += isActive(l);
-                    interior += (l == MGPS_INTERIOR_CELL);
+    // per tile: 0 = no active cell, else (active count << 1) | all-INTERIOR
+    std::vector<int64_t> kind;
+    parallelCollect<int64_t>(int64_t(tx) * ty * tz, 256, kind, [&](int64_t b, int64_t e, std::vector<int64_t> &out) {
+        for (int64_t t = b; t < e; ++t) {
+            const int ti = int(t % tx), tj = int((t / tx) % ty), tk = int(t / (int64_t(tx) * ty));
+            int64_t active = 0, interior = 0;
+            for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
+                for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j) {
+                    const uint8_t *row = L.labels.data() + d.idx(0, j, k);
+                    for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) {
+                        active += isActive(row[i]);
+                        interior += (row[i] == MGPS_INTERIOR_CELL);
+                    }
                 }
+            out.push_back((active << 1) | int64_t(interior == int64_t(kTile) * kTile * kTile));
+        }
+    });
+    for (int t = 0; t < tx * ty * tz; ++t) {
+        const int64_t active = kind[size_t(t)] >> 1;
         if (!active) continue;
+        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
         L.activeCells += active;
         const bool odd = (ti + tj + tk + tileZOffset) & 1;
         (odd ? L.tilesOdd : L.tilesEven).push_back(t);
-        if (interior == int64_t(kTile) * kTile * kTile) (odd ? L.pureOdd : L.pureEven).push_back(t);
+        if (kind[size_t(t)] & 1) (odd ? L.pureOdd : L.pureEven).push_back(t);
         else (odd ? L.mixedOdd : L.mixedEven).push_back(t);
     }
 }
-
-// first BOUNDARY-list entry of every tile (bandDev holds the BOUNDARY cells in tile-major order)
 static void buildTileBoundaryOffsets(HostLevel &L)
 {
     const Dims d = L.d;
@@ -794,8 +849,7 @@ void mgps_hierarchy::buildDenseInverse()
     const int n = coarseN;
     coarseInverse.assign(size_t(n) * n, 0.f);
     std::atomic<int> nextCol{0};
-    unsigned hw = std::thread::hardware_concurrency();
-    const int nt = int(std::min<unsigned>(hw ? hw : 4, unsigned(std::max(1, n / 64))));
+    const int nt = std::min(hostThreads(), std::max(1, n / 64));
     auto work = [&] {
         std::vector<double> v(n);
         for (;;) {
@@ -1099,8 +1153,6 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     for (auto &L : H->lv) {
         buildBand(L, H->bandWidth);  // MG.cpp:279-281
         lap.lap("hierarchy: band list");
-        buildTileLists(L, 0);
-        lap.lap("hierarchy: tile lists");
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.

@@ -22,15 +22,23 @@ INTERIOR, EXTERIOR, DIRICHLET, BOUNDARY = 0, 1, 2, 3
 
 def build(force=False):
     """Compile the oracle shared libraries in place (gcc, OpenMP)."""
-    names = ["libmgoracle.so", "libmgoracle_f32.so"]
-    srcs = [os.path.join(_HERE, f) for f in ("mg_oracle.c", "mg_fields_oracle.c")]
-    stale = force or any(
-        not os.path.exists(os.path.join(_HERE, n))
-        or any(os.path.getmtime(os.path.join(_HERE, n)) < os.path.getmtime(src) for src in srcs)
-        for n in names
-    )
-    if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+    deps = {"libmgoracle.so": ("mg_oracle.c", "mg_fields_oracle.c"), "libmgoracle_f32.so": ("mg_oracle.c",)}
+
+    def stale():
+        return force or any(
+            not os.path.exists(os.path.join(_HERE, lib))
+            or any(os.path.getmtime(os.path.join(_HERE, lib)) < os.path.getmtime(os.path.join(_HERE, src)) for src in srcs)
+            for lib, srcs in deps.items()
+        )
+
+    if stale():
+        import fcntl
+
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # several test ranks may import at once
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+                force = False
 
 
 def _ptr(a):

@@ -70,6 +70,10 @@ class SlabEmulation:
         t = np.zeros((plo + nzo + phi,) + a.shape[1:])
         t[plo - 1 : plo + nzo + 1] = a
         lab = self._slice_global(self.lab[level], self.z0[level] - plo, self.z1[level] + phi, EXTERIOR)
+        # planes beyond the ghost planes are padding: inert, or the oracle would run its stencil on their
+        # active cells and read past the ends of the temporary
+        lab[: plo - 1] = EXTERIOR
+        lab[plo + nzo + 1 :] = EXTERIOR
         w = None
         if level == 0:
             w = [self._slice_global(self.w[0], self.z0[0] - plo, self.z1[0] + phi, 0.0),
