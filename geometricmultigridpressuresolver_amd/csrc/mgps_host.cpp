@@ -6,10 +6,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -415,7 +418,14 @@ struct GroupBuild {
 struct BandWindow {
     Dims wd;
     const uint8_t *labels = nullptr;     // reference labels or device codes of the window (active: 0 or >= 3)
-    std::vector<int32_t> entryOf;        // window cell -> output entry (>= 0), kDeepBand, or kNoBand
+    std::unique_ptr<int32_t[]> entryOf;  // window cell -> output entry (>= 0), kDeepBand, or kNoBand
+    void allocEntryOf()                  // filled with kNoBand by all host threads (0.5 GB at 512^3)
+    {
+        const size_t n = wd.cells();
+        entryOf.reset(new int32_t[n]);
+        int32_t *p = entryOf.get();
+        parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); });
+    }
     std::vector<int32_t> seedCell;       // per output entry: its window cell
     std::vector<uint8_t> entryDiag;      // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
     // device address of a window cell: grid offset from owned cell 0 for the planes that live in the grid
@@ -456,12 +466,30 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
     const ptrdiff_t sy = W.wd.nx, sz = ptrdiff_t(W.wd.nx) * W.wd.ny;
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
     g = GroupBuild();
-    std::unordered_map<int64_t, int32_t> id;  // window cell -> node id; read-only nodes as -(r + 2)
-    id.reserve(owned.size() * 4);
+    // node ids of the cells the passes can reach: a dense array over the bounding box of the owned cells grown
+    // by `depth` (the walk never leaves it); kUnset = not seen, read-only nodes as -(r + 2)
+    constexpr int32_t kUnset = INT32_MIN;
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (int32_t t : owned) {
+        const size_t c = size_t(W.seedCell[size_t(t)]);
+        const int ijk[3] = {int(c % W.wd.nx), int((c / W.wd.nx) % W.wd.ny), int(c / (size_t(W.wd.nx) * W.wd.ny))};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], ijk[a]);
+            hi[a] = std::max(hi[a], ijk[a]);
+        }
+    }
+    const int ext[3] = {hi[0] - lo[0] + 1 + 2 * depth, hi[1] - lo[1] + 1 + 2 * depth, hi[2] - lo[2] + 1 + 2 * depth};
+    static thread_local std::vector<int32_t> id;
+    id.assign(size_t(ext[0]) * ext[1] * ext[2], kUnset);
+    auto slot = [&](ptrdiff_t wc) -> int32_t & {
+        const int i = int(wc % W.wd.nx) - lo[0] + depth, j = int((wc / W.wd.nx) % W.wd.ny) - lo[1] + depth;
+        const int k = int(wc / (ptrdiff_t(W.wd.nx) * W.wd.ny)) - lo[2] + depth;
+        return id[(size_t(k) * ext[1] + j) * ext[0] + i];
+    };
     std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
     std::vector<int64_t> updateW, readW;  // window cells of the nodes
     for (int32_t t : owned) {
-        id.emplace(int64_t(W.seedCell[size_t(t)]), int32_t(updateW.size()));
+        slot(W.seedCell[size_t(t)]) = int32_t(updateW.size());
         updateW.push_back(W.seedCell[size_t(t)]);
         g.updateEntry.push_back(t | (int32_t(W.entryDiag[size_t(t)]) << kBandDiagShift));
     }
@@ -478,10 +506,9 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
                     nbrTmp.push_back(kZero);
                     continue;
                 }
-                auto it = id.find(int64_t(cq));
-                if (it == id.end()) {
+                int32_t &v = slot(cq);
+                if (v == kUnset) {
                     const int32_t e = W.entryOf[size_t(cq)];
-                    int32_t v;
                     if (e != BandWindow::kNoBand && dist + 1 < depth) {
                         v = int32_t(updateW.size());
                         updateW.push_back(cq);
@@ -491,9 +518,8 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
                         v = -int32_t(readW.size()) - 2;
                         readW.push_back(cq);
                     }
-                    it = id.emplace(int64_t(cq), v).first;
                 }
-                nbrTmp.push_back(it->second);
+                nbrTmp.push_back(v);
             }
             if (updateW.size() > size_t(kBandMaxUpdate) || updateW.size() + readW.size() + 1 > size_t(kBandMaxNodes)) return 1;
         }
@@ -618,7 +644,7 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     BandWindow W;
     W.wd = L.d;
     W.labels = L.codes.data() + size_t(L.d.nx) * L.d.ny;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
-    W.entryOf.assign(L.d.cells(), BandWindow::kNoBand);
+    W.allocEntryOf();
     W.seedCell.assign(L.bandDev.begin(), L.bandDev.end());
     for (size_t t = 0; t < nband; ++t) W.entryOf[size_t(L.bandDev[t])] = int32_t(t);
     W.entryDiag = L.bandDiag;
@@ -677,7 +703,7 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     out.bandExt = L.bandDev;
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[1].begin(), L.bandPlane[1].end());
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[3].begin(), L.bandPlane[3].end());
-    W.entryOf.assign(wcells, BandWindow::kNoBand);
+    W.allocEntryOf();
     for (size_t c = 0; c < wcells; ++c)
         if (band[c]) W.entryOf[c] = BandWindow::kDeepBand;
     W.seedCell.resize(out.bandExt.size());

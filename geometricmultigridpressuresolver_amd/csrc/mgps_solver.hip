@@ -621,8 +621,10 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     // band passes fuse only where no ghost exchange has to happen between them
     const bool cut = h->dist && (z0 > 0 || z1 < globalNz);
     if (!cut && h->opt.fuse_band_passes && h->opt.band_iterations >= 1 && h->opt.band_iterations <= kBandMaxDepth && !HL.bandDev.empty()) {
+        StageClock gclock(h->opt.print_stats != 0);
         BandGroups bg;
         buildBandGroups(HL, h->opt.band_iterations, bg);
+        gclock.lap("  (band groups alone)");
         L.bandGroups.depth = bg.depth;
         L.bandGroups.ngroups = int(bg.groups());
         MGPS_TRY(devUpload(h, &L.bandGroups.info, bg.info));
@@ -720,6 +722,7 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         return code;
     };
     const Dims d0 = hier->lv[0].d;
+    StageClock clock(h->opt.print_stats != 0);
     if (wx) {
         const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz,
                               size_t(d0.nx) * d0.ny * (d0.nz + 1)};
@@ -731,7 +734,6 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
                 return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
         }
     }
-    StageClock clock(h->opt.print_stats != 0);
     clock.lap("weights upload");
     h->lv.resize(hier->levels);
     for (int l = 0; l < hier->levels; ++l) {
@@ -745,6 +747,7 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
     }
     int rc = commonDeviceState(h, hier->levels > 1 || tailOfSlabRun);
     if (rc != MGPS_OK) return bail(rc);
+    clock.lap("coarse inverse + scratch");
     *out = h;
     return MGPS_OK;
 }
