@@ -312,7 +312,7 @@ def sine_initial_guess(lab, h, dtype=np.float32):
     return v.astype(dtype)
 
 
-def projection_scene(shape, seed=7, with_solid_velocity=False, dtype=np.float32):
+def projection_scene(shape, seed=7, with_solid_velocity=False, dtype=np.float32, randomize=False):
     """Synthetic inputs of one pressure projection on the BASE grid (Plug.cpp:113-426): a pool with a wavy free
     surface, closed domain walls and an immersed axis-aligned solid box whose faces cut cells (fractional
     cut-cell weights = open area fraction of each face, < 0.01 closed).  Returns a dict of numpy arrays:
@@ -323,9 +323,15 @@ def projection_scene(shape, seed=7, with_solid_velocity=False, dtype=np.float32)
     rng = np.random.Generator(np.random.PCG64(seed))
     zc, yc, xc = np.meshgrid((np.arange(gz) + 0.5) * dx, (np.arange(gy) + 0.5) * dx, (np.arange(gx) + 0.5) * dx, indexing="ij")
     top = gz * dx
-    liquid_phi = zc - top * (0.55 + 0.08 * np.sin(2 * np.pi * xc / (gx * dx)) * np.cos(2 * np.pi * yc / (gy * dx)))
-    lo = np.array([0.31 * gx, 0.27 * gy, 0.18 * gz]) * dx  # box corners (x, y, z), off the grid lines
-    hi = np.array([0.62 * gx, 0.71 * gy, 0.44 * gz]) * dx
+    level, amp, ph = 0.55, 0.08, 0.0
+    lo_f, hi_f = np.array([0.31, 0.27, 0.18]), np.array([0.62, 0.71, 0.44])
+    if randomize:  # geometry drawn from the seed too: fill level, wave, box position and size
+        level, amp, ph = rng.uniform(0.35, 0.8), rng.uniform(0.0, 0.15), rng.uniform(0, 2 * np.pi)
+        lo_f = rng.uniform(0.1, 0.5, 3)
+        hi_f = np.minimum(lo_f + rng.uniform(0.15, 0.4, 3), 0.93)
+    liquid_phi = zc - top * (level + amp * np.sin(2 * np.pi * xc / (gx * dx) + ph) * np.cos(2 * np.pi * yc / (gy * dx)))
+    lo = lo_f * np.array([gx, gy, gz]) * dx  # box corners (x, y, z), off the grid lines
+    hi = hi_f * np.array([gx, gy, gz]) * dx
     inside = (xc > lo[0]) & (xc < hi[0]) & (yc > lo[1]) & (yc < hi[1]) & (zc > lo[2]) & (zc < hi[2])
     solid_phi = np.where(inside, dx, -dx)
 
