@@ -177,13 +177,21 @@ struct BandGroupsDev {
 // hx / hb: halo values of x and of the rhs for node cells encoded below gridLo = -(nx*ny) (cut slabs), else nullptr
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                     float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr);
-// one message to a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of that plane];
-// the unpack puts the plane into the ghost plane of x, the two lists into the halo arrays and the last
-// part into the band cells of the ghost plane of b (the grids' ghost planes are the solver's scratch)
-int launchHaloPack(void *stream, float *out, const float *x, const float *b, size_t planeStart, size_t plane,
-                   const int32_t *idx, int n, const int32_t *bandIdx, int nb);
-int launchHaloUnpack(void *stream, const float *in, float *x, float *b, ptrdiff_t ghostStart, size_t plane, float *hx, float *hb,
-                     int n, const int32_t *bandIdx, int nb);
+// one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
+// that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the
+// two lists into the halo arrays and the last part into the band cells of the ghost plane of b (the grids'
+// ghost planes are the solver's scratch).  buf == nullptr: no neighbour on that side.
+struct HaloSide {
+    float *buf = nullptr;
+    ptrdiff_t planeStart = 0;
+    const int32_t *idx = nullptr;
+    int n = 0;
+    const int32_t *bandIdx = nullptr;
+    int nb = 0;
+    float *hx = nullptr, *hb = nullptr;
+};
+int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane);
+int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);

@@ -1146,40 +1146,45 @@ int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, con
     return int(hipGetLastError());
 }
 
-__global__ void haloPackKernel(float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ b,
-                               size_t planeStart, size_t plane, const int32_t *__restrict__ idx, int n,
-                               const int32_t *__restrict__ bandIdx, int nb)
+// Both neighbours' messages in one launch: blocks [0, blocksLo) serve the lower side, the rest the upper.
+__global__ void haloPackKernel(HaloSide lo, HaloSide hi, unsigned blocksLo, const float *__restrict__ x, const float *__restrict__ b,
+                               size_t plane)
 {
-    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t < plane) out[t] = x[planeStart + t];
-    else if (t < plane + size_t(n)) out[t] = x[idx[t - plane]];
-    else if (t < plane + 2 * size_t(n)) out[t] = b[idx[t - plane - size_t(n)]];
-    else if (t < plane + 2 * size_t(n) + size_t(nb)) out[t] = b[bandIdx[t - plane - 2 * size_t(n)]];
+    const bool upper = blockIdx.x >= blocksLo;
+    const HaloSide &s = upper ? hi : lo;
+    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x;
+    const size_t n = size_t(s.n);
+    if (t < plane) s.buf[t] = x[s.planeStart + ptrdiff_t(t)];
+    else if (t < plane + n) s.buf[t] = x[s.idx[t - plane]];
+    else if (t < plane + 2 * n) s.buf[t] = b[s.idx[t - plane - n]];
+    else if (t < plane + 2 * n + size_t(s.nb)) s.buf[t] = b[s.bandIdx[t - plane - 2 * n]];
 }
-__global__ void haloUnpackKernel(const float *__restrict__ in, float *__restrict__ x, float *__restrict__ b, ptrdiff_t ghostStart,
-                                 size_t plane, float *__restrict__ hx, float *__restrict__ hb, int n,
-                                 const int32_t *__restrict__ bandIdx, int nb)
+__global__ void haloUnpackKernel(HaloSide lo, HaloSide hi, unsigned blocksLo, float *__restrict__ x, float *__restrict__ b, size_t plane)
 {
-    const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t < plane) x[ghostStart + ptrdiff_t(t)] = in[t];
-    else if (t < plane + size_t(n)) hx[t - plane] = in[t];
-    else if (t < plane + 2 * size_t(n)) hb[t - plane - size_t(n)] = in[t];
-    else if (t < plane + 2 * size_t(n) + size_t(nb)) b[bandIdx[t - plane - 2 * size_t(n)]] = in[t];
+    const bool upper = blockIdx.x >= blocksLo;
+    const HaloSide &s = upper ? hi : lo;
+    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x;
+    const size_t n = size_t(s.n);
+    if (t < plane) x[s.planeStart + ptrdiff_t(t)] = s.buf[t];
+    else if (t < plane + n) s.hx[t - plane] = s.buf[t];
+    else if (t < plane + 2 * n) s.hb[t - plane - n] = s.buf[t];
+    else if (t < plane + 2 * n + size_t(s.nb)) b[s.bandIdx[t - plane - 2 * n]] = s.buf[t];
 }
 
-int launchHaloPack(void *stream, float *out, const float *x, const float *b, size_t planeStart, size_t plane,
-                   const int32_t *idx, int n, const int32_t *bandIdx, int nb)
+static unsigned haloBlocks(const HaloSide &s, size_t plane) { return s.buf ? blocksFor(plane + 2 * size_t(s.n) + size_t(s.nb), 256) : 0; }
+
+int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane)
 {
-    const size_t total = plane + 2 * size_t(n) + size_t(nb);
-    haloPackKernel<<<blocksFor(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, b, planeStart, plane, idx, n, bandIdx, nb);
+    const unsigned bl = haloBlocks(lo, plane), bh = haloBlocks(hi, plane);
+    if (bl + bh == 0) return 0;
+    haloPackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, x, b, plane);
     return int(hipGetLastError());
 }
-int launchHaloUnpack(void *stream, const float *in, float *x, float *b, ptrdiff_t ghostStart, size_t plane, float *hx, float *hb,
-                     int n, const int32_t *bandIdx, int nb)
+int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane)
 {
-    const size_t total = plane + 2 * size_t(n) + size_t(nb);
-    haloUnpackKernel<<<blocksFor(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, x, b, ghostStart, plane, hx, hb, n, bandIdx,
-                                                                                          nb);
+    const unsigned bl = haloBlocks(lo, plane), bh = haloBlocks(hi, plane);
+    if (bl + bh == 0) return 0;
+    haloUnpackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, x, b, plane);
     return int(hipGetLastError());
 }
 

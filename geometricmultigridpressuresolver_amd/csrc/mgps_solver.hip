@@ -285,15 +285,20 @@ int bandStageDeep(mgps_solver *h, int l, float *x, const float *b)
     const size_t rbytes[2] = {(plane + 2 * size_t(H.nrecv[0]) + size_t(nbp[1])) * sizeof(float),
                               (plane + 2 * size_t(H.nrecv[1]) + size_t(nbp[3])) * sizeof(float)};
     float *bw = const_cast<float *>(b);  // only the ghost planes are written: solver scratch by contract (mgps_grid_alloc)
-    if (lo) MGPS_LAUNCH(h, launchHaloPack(h->stream, H.sendBuf[0], x, b, 0, plane, H.sendIdx[0], H.nsend[0], L.bandPlane[0], nbp[0]));
-    if (hi) MGPS_LAUNCH(h, launchHaloPack(h->stream, H.sendBuf[1], x, b, (size_t(L.d.nz) - 1) * plane, plane, H.sendIdx[1], H.nsend[1],
-                                          L.bandPlane[2], nbp[2]));
+    HaloSide sLo, sHi, rLo, rHi;  // send / receive descriptions of the two sides
+    if (lo) {
+        sLo = HaloSide{H.sendBuf[0], 0, H.sendIdx[0], H.nsend[0], L.bandPlane[0], nbp[0], nullptr, nullptr};
+        rLo = HaloSide{H.recvBuf[0], -ptrdiff_t(plane), nullptr, H.nrecv[0], L.bandPlane[1], nbp[1], H.hx, H.hb};
+    }
+    if (hi) {
+        sHi = HaloSide{H.sendBuf[1], ptrdiff_t((size_t(L.d.nz) - 1) * plane), H.sendIdx[1], H.nsend[1], L.bandPlane[2], nbp[2], nullptr, nullptr};
+        rHi = HaloSide{H.recvBuf[1], ptrdiff_t(size_t(L.d.nz) * plane), nullptr, H.nrecv[1], L.bandPlane[3], nbp[3], H.hx + H.nrecv[0],
+                       H.hb + H.nrecv[0]};
+    }
+    MGPS_LAUNCH(h, launchHaloPack(h->stream, sLo, sHi, x, b, plane));
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
                                   hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], h->stream));
-    if (lo) MGPS_LAUNCH(h, launchHaloUnpack(h->stream, H.recvBuf[0], x, bw, -ptrdiff_t(plane), plane, H.hx, H.hb, H.nrecv[0],
-                                            L.bandPlane[1], nbp[1]));
-    if (hi) MGPS_LAUNCH(h, launchHaloUnpack(h->stream, H.recvBuf[1], x, bw, ptrdiff_t(size_t(L.d.nz) * plane), plane, H.hx + H.nrecv[0],
-                                            H.hb + H.nrecv[0], H.nrecv[1], L.bandPlane[3], nbp[3]));
+    MGPS_LAUNCH(h, launchHaloUnpack(h->stream, rLo, rHi, x, bw, plane));
     MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb));
     return MGPS_OK;
 }
