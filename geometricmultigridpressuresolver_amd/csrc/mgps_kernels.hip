@@ -352,7 +352,7 @@ constexpr int kBandThreads = 512;
 constexpr int kBandSlots = kBandMaxUpdate / kBandThreads;
 static_assert(kBandSlots * kBandThreads == kBandMaxUpdate, "update-node budget must be a whole number of slots");
 
-__global__ __launch_bounds__(kBandThreads) void bandFusedKernel(GridP g, const float *__restrict__ x,
+__global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, const float *__restrict__ x,
                                                                 const float *__restrict__ b,
                                                                 const int32_t *__restrict__ info,
                                                                 const int32_t *__restrict__ updateEntry,
