@@ -110,9 +110,9 @@ static void parallelCollect(int64_t n, int64_t minPerThread, std::vector<T> &res
 
 // run fn(begin, end) over [0, n) on a handful of host threads
 template <class F>
-static void parallelFor(int64_t n, F fn)
+static void parallelFor(int64_t n, F fn, int64_t grain = 1)  // grain: smallest range worth a thread
 {
-    int nt = int(std::min<int64_t>(hostThreads(), std::max<int64_t>(1, n / 4096)));
+    int nt = int(std::min<int64_t>(hostThreads(), std::max<int64_t>(1, n / std::max<int64_t>(1, grain))));
     if (nt <= 1) {
         fn(int64_t(0), n);
         return;
@@ -240,12 +240,21 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     L.d = d;
     const size_t plane = size_t(gd.nx) * gd.ny;
     const uint8_t *glab = G.labels.data();
-    L.labels.assign(glab + size_t(z0) * plane, glab + size_t(z1) * plane);
+    const size_t ownedBytes = size_t(d.nz) * plane;
+    L.labels.resize(ownedBytes);
+    L.codes.resize((size_t(d.nz) + 2) * plane);  // ghost plane | owned planes | ghost plane
+    std::memset(L.codes.data(), MGPS_EXTERIOR_CELL, plane);
+    std::memset(L.codes.data() + (size_t(d.nz) + 1) * plane, MGPS_EXTERIOR_CELL, plane);
+    {
+        uint8_t *dl = L.labels.data(), *dc = L.codes.data() + plane;
+        const uint8_t *src = glab + size_t(z0) * plane;
+        parallelFor(int64_t(ownedBytes), [=](int64_t b, int64_t e) {
+            std::memcpy(dl + b, src + b, size_t(e - b));
+            std::memcpy(dc + b, src + b, size_t(e - b));
+        }, 1 << 22);
+    }
     const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    // codes: ghost plane | owned planes | ghost plane
-    L.codes.assign((size_t(d.nz) + 2) * plane, MGPS_EXTERIOR_CELL);
-    std::memcpy(L.codes.data() + plane, L.labels.data(), L.labels.size());
     if (z0 > 0) std::memcpy(L.codes.data(), glab + size_t(z0 - 1) * plane, plane);
     if (z1 < gd.nz) std::memcpy(L.codes.data() + (size_t(d.nz) + 1) * plane, glab + size_t(z1) * plane, plane);
     uint8_t *codes = L.codes.data() + plane;  // owned plane 0
@@ -424,7 +433,7 @@ struct BandWindow {
         const size_t n = wd.cells();
         entryOf.reset(new int32_t[n]);
         int32_t *p = entryOf.get();
-        parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); });
+        parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); }, 1 << 20);
     }
     std::vector<int32_t> seedCell;       // per output entry: its window cell
     std::vector<uint8_t> entryDiag;      // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
@@ -549,6 +558,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
     const size_t nent = W.seedCell.size();
     if (depth < 1 || depth > kBandMaxDepth || nent == 0 || nent > size_t(kBandEntryMask)) return true;
     const Dims d = W.wd;
+    HostLap lap;
     // initial partition: the output entries of each 16^3 tile of the window
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
@@ -561,6 +571,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
     for (auto &b : buckets)
         if (!b.empty()) work.push_back(std::move(b));
     buckets.clear();
+    lap.lap("band groups: buckets");
     std::vector<std::vector<GroupBuild>> built(work.size());
     std::atomic<int64_t> next{0};
     std::atomic<bool> broken{false};
@@ -617,6 +628,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
         worker();
         for (auto &th : pool) th.join();
     }
+    lap.lap("band groups: per-bucket walks");
     if (broken) {
         out = BandGroups();
         return false;
@@ -630,6 +642,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
             out.neighbours.insert(out.neighbours.end(), g.neighbours.begin(), g.neighbours.end());
             out.readCell.insert(out.readCell.end(), g.readCell.begin(), g.readCell.end());
         }
+    lap.lap("band groups: concatenate");
     return true;
 }
 
@@ -641,6 +654,7 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     out.depth = depth;
     const size_t nband = L.bandDev.size();
     if (nband == 0) return;
+    HostLap lap0;
     BandWindow W;
     W.wd = L.d;
     W.labels = L.codes.data() + size_t(L.d.nx) * L.d.ny;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
@@ -650,6 +664,7 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     W.entryDiag = L.bandDiag;
     W.gridPlaneLo = 0;
     W.gridPlaneHi = L.d.nz;
+    lap0.lap("band groups: entry map");
     buildGroupsOverWindow(W, depth, out);
 }
 
@@ -1031,16 +1046,20 @@ int mgps_check_exterior_cells(const uint8_t *labels, int nx, int ny, int nz, int
 {
     if (!labels || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_exterior_cells: bad arguments");
     const Dims d{nx, ny, nz};
-    *pass = 1;
+    *pass = 0;
+    auto rowIsExterior = [&](int j, int k, int i0, int i1) {
+        const uint8_t *row = labels + d.idx(0, j, k);
+        for (int i = i0; i < i1; ++i)
+            if (row[i] != MGPS_EXTERIOR_CELL) return false;
+        return true;
+    };
     for (int k = 0; k < nz; ++k)
-        for (int j = 0; j < ny; ++j)
-            for (int i = 0; i < nx; ++i) {
-                const bool shell = i == 0 || j == 0 || k == 0 || i == nx - 1 || j == ny - 1 || k == nz - 1;
-                if (shell && labels[d.idx(i, j, k)] != MGPS_EXTERIOR_CELL) {
-                    *pass = 0;
-                    return MGPS_OK;
-                }
-            }
+        for (int j = 0; j < ny; ++j) {
+            const bool whole = k == 0 || k == nz - 1 || j == 0 || j == ny - 1;  // a face of the box: every cell of the row
+            if (whole ? !rowIsExterior(j, k, 0, nx) : (labels[d.idx(0, j, k)] != MGPS_EXTERIOR_CELL || labels[d.idx(nx - 1, j, k)] != MGPS_EXTERIOR_CELL))
+                return MGPS_OK;
+        }
+    *pass = 1;
     return MGPS_OK;
 }
 
@@ -1142,7 +1161,11 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     H->bandWidth = o.band_width;
     H->lv.resize(mg_levels);
     H->lv[0].d = Dims{nx, ny, nz};
-    H->lv[0].labels.assign(labels, labels + H->lv[0].d.cells());
+    H->lv[0].labels.resize(H->lv[0].d.cells());
+    {
+        uint8_t *dst = H->lv[0].labels.data();
+        parallelFor(int64_t(H->lv[0].d.cells()), [=](int64_t b, int64_t e) { std::memcpy(dst + b, labels + b, size_t(e - b)); }, 1 << 22);
+    }
     {
         int pass = 0;
         mgps_check_exterior_cells(labels, nx, ny, nz, &pass);  // MG.cpp:235
