@@ -1071,28 +1071,30 @@ int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const floa
     const float *w[3] = {wx, wy, wz};
     const bool weighted = wx && wy && wz;
     const ptrdiff_t stride[3] = {1, nx, ptrdiff_t(nx) * ny};
-    *pass = 1;
-    for (int k = 1; k < nz - 1; ++k)
-        for (int j = 1; j < ny - 1; ++j)
-            for (int i = 1; i < nx - 1; ++i) {
-                const size_t c = d.idx(i, j, k);
-                if (labels[c] == MGPS_INTERIOR_CELL) {
-                    for (int a = 0; a < 3; ++a)
-                        for (int p = 0; p < 2; ++p)
-                            if (!isActive(labels[c + (p ? stride[a] : -stride[a])])) *pass = 0;
-                } else if (labels[c] == MGPS_BOUNDARY_CELL) {
-                    bool ok = false;
-                    for (int a = 0; a < 3; ++a)
-                        for (int p = 0; p < 2; ++p) {
-                            const uint8_t nl = labels[c + (p ? stride[a] : -stride[a])];
-                            if (!isActive(nl)) ok = true;
-                            else if (weighted && nl == MGPS_BOUNDARY_CELL && w[a][faceIndex(d, a, i, j, k, p)] != 1.0f)
-                                ok = true;
-                        }
-                    if (!ok) *pass = 0;
+    std::atomic<int> ok{1};
+    parallelFor(int64_t(std::max(nz - 2, 0)), [&](int64_t k0, int64_t k1) {
+        for (int k = int(k0) + 1; k < int(k1) + 1 && ok.load(std::memory_order_relaxed); ++k)
+            for (int j = 1; j < ny - 1; ++j)
+                for (int i = 1; i < nx - 1; ++i) {
+                    const size_t c = d.idx(i, j, k);
+                    if (labels[c] == MGPS_INTERIOR_CELL) {
+                        for (int a = 0; a < 3; ++a)
+                            for (int p = 0; p < 2; ++p)
+                                if (!isActive(labels[c + (p ? stride[a] : -stride[a])])) ok = 0;
+                    } else if (labels[c] == MGPS_BOUNDARY_CELL) {
+                        bool fine = false;
+                        for (int a = 0; a < 3; ++a)
+                            for (int p = 0; p < 2; ++p) {
+                                const uint8_t nl = labels[c + (p ? stride[a] : -stride[a])];
+                                if (!isActive(nl)) fine = true;
+                                else if (weighted && nl == MGPS_BOUNDARY_CELL && w[a][faceIndex(d, a, i, j, k, p)] != 1.0f)
+                                    fine = true;
+                            }
+                        if (!fine) ok = 0;
+                    }
                 }
-                if (!*pass) return MGPS_OK;
-            }
+    });
+    *pass = ok.load();
     return MGPS_OK;
 }
 
