@@ -230,7 +230,7 @@ static void buildTileLists(HostLevel &L, int tileZOffset);
 // face weights of the slab (wz with the closing face plane).  z0 must be a multiple of 16 so that the
 // local 16^3 tiles coincide with the global ones.
 void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
-                    HostLevel &L)
+                    HostLevel &L, const float *rowsIn)
 {
     HostLap lap;
     const Dims gd = G.d;
@@ -301,13 +301,21 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     std::vector<uint8_t> restDiag;
     std::vector<Row> generalRows;
     const size_t lo = size_t(z0) * plane, hi = size_t(z1) * plane;
+    size_t nextRowIn = 0;
     for (int32_t gcI : G.band) {
         const size_t gc = size_t(gcI);
         if (gc < lo || gc >= hi) continue;
         const int32_t c = int32_t(gc - lo);
         L.band.push_back(c);
         if (glab[gc] == MGPS_BOUNDARY_CELL) {
-            const Row r = rowOf(gc);
+            Row r;
+            if (rowsIn) {
+                const float *q = rowsIn + 8 * nextRowIn++;
+                for (int a = 0; a < 6; ++a) r.w[a] = q[a];
+                r.diag = q[6];
+                r.simple = q[7] != 0.f;
+            } else
+                r = rowOf(gc);
             if (r.simple) {
                 codes[c] = uint8_t(kCodeSimple + int(r.diag));
                 rest.push_back(c);
@@ -1097,6 +1105,29 @@ int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const floa
     *pass = ok.load();
     return MGPS_OK;
 }
+
+}  // extern "C"
+
+void mgps::checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int *pass)
+{
+    const Dims d{nx, ny, nz};
+    const ptrdiff_t stride[3] = {1, nx, ptrdiff_t(nx) * ny};
+    std::atomic<int> ok{1};
+    parallelFor(int64_t(std::max(nz - 2, 0)), [&](int64_t k0, int64_t k1) {
+        for (int k = int(k0) + 1; k < int(k1) + 1 && ok.load(std::memory_order_relaxed); ++k)
+            for (int j = 1; j < ny - 1; ++j)
+                for (int i = 1; i < nx - 1; ++i) {
+                    const size_t c = d.idx(i, j, k);
+                    if (labels[c] != MGPS_INTERIOR_CELL) continue;
+                    for (int a = 0; a < 3; ++a)
+                        for (int p = 0; p < 2; ++p)
+                            if (!isActive(labels[c + (p ? stride[a] : -stride[a])])) ok = 0;
+                }
+    });
+    *pass = ok.load();
+}
+
+extern "C" {
 
 int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, int fny, int fnz, int *pass)
 {

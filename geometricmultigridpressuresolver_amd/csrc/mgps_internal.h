@@ -117,8 +117,18 @@ struct SlabHalo {
 };
 void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out);
 
+// rowsIn (optional, instead of wx / wy / wz): the operator rows of the BOUNDARY band cells of the planes
+// [z0, z1) evaluated elsewhere (on the device, mgps_create_device_weights), 8 floats per cell in band order:
+// the six off-diagonal weights, the diagonal, 1 / 0 for simple / general
 void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const float *wy, const float *wz,
-                    HostLevel &L);
+                    HostLevel &L, const float *rowsIn = nullptr);
+// device evaluation of those rows (Ops.h:208-256) for `n` cells of a grid of extents d: labels and weights on
+// the device; rows = 8 floats per cell as above; *violations counts BOUNDARY cells that break the rule of
+// unitTestBoundaryCells (Ops.h:1771-1870: some neighbour inactive, or a BOUNDARY neighbour across a face of weight != 1)
+int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const float *wx, const float *wy, const float *wz,
+                       const int32_t *cells, int n, float *rows, int *violations);
+// the label-only half of unitTestBoundaryCells (Ops.h:1771-1870): every INTERIOR cell has six active neighbours
+void checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int *pass);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
                     const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
 void setLastGlobalError(const std::string &msg);

@@ -1300,6 +1300,57 @@ int launchDiagInverse(void *stream, const GridP &g, float *dinv)
     return int(hipGetLastError());
 }
 
+// Operator rows of BOUNDARY cells (Ops.h:208-256) from device labels / weights, for the set-up path that never
+// brings the weights to the host; the arithmetic of the host's rowOf (mgps_host.cpp) term by term.
+__global__ void boundaryRowsKernel(Dims d, const uint8_t *__restrict__ lab, const float *__restrict__ wx,
+                                   const float *__restrict__ wy, const float *__restrict__ wz, const int32_t *__restrict__ cells,
+                                   int n, float *__restrict__ rows, int *__restrict__ violations)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n) return;
+    const size_t c = size_t(cells[t]);
+    const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+    const size_t plane = size_t(d.nx) * d.ny;
+    const size_t fx = (size_t(k) * d.ny + j) * (d.nx + 1) + i, fy = (size_t(k) * (d.ny + 1) + j) * d.nx + i, fz = c;
+    const float w[6] = {wx[fx], wx[fx + 1], wy[fy], wy[fy + d.nx], wz[fz], wz[fz + plane]};
+    const ptrdiff_t off[6] = {-1, 1, -ptrdiff_t(d.nx), ptrdiff_t(d.nx), -ptrdiff_t(plane), ptrdiff_t(plane)};
+    float r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, diag = 0.f;
+    bool simple = true, ruleOk = false;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const uint8_t nl = lab[ptrdiff_t(c) + off[q]];
+        if (nl == MGPS_INTERIOR_CELL) {
+            r[q] = 1.f;
+            diag += 1.f;
+        } else if (nl == MGPS_BOUNDARY_CELL) {
+            r[q] = w[q];
+            diag += w[q];
+            simple = simple && w[q] == 1.f;
+            ruleOk = ruleOk || w[q] != 1.f;
+        } else if (nl == MGPS_DIRICHLET_CELL) {
+            diag += w[q];
+            simple = simple && w[q] == 1.f;
+            ruleOk = true;
+        } else
+            ruleOk = true;
+    }
+    float *o = rows + 8 * size_t(t);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = r[q];
+    o[6] = diag;
+    o[7] = simple ? 1.f : 0.f;
+    if (!ruleOk) atomicAdd(violations, 1);
+}
+
+int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const float *wx, const float *wy, const float *wz,
+                       const int32_t *cells, int n, float *rows, int *violations)
+{
+    if (n <= 0) return 0;
+    boundaryRowsKernel<<<blocksFor(size_t(n), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(d, labels, wx, wy, wz, cells, n, rows,
+                                                                                          violations);
+    return int(hipGetLastError());
+}
+
 int launchZero(void *stream, float *a, size_t count)
 {
     if (!count) return 0;

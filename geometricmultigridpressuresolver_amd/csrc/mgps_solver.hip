@@ -711,8 +711,11 @@ int readOptions(const mgps_options *opt, mgps_options *o)
 }
 
 // whole-grid solver on one device.  weights may be nullptr (unit weights: the collapsed tail)
+const float kNoRows = 0.f;  // a non-null "no BOUNDARY cells" row array
+
+// rowsL0 != nullptr: wx / wy / wz are DEVICE pointers and the fine level's BOUNDARY rows come precomputed
 int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const float *wy, const float *wz,
-                bool useGS, const mgps_options &o, int device, bool tailOfSlabRun)
+                bool useGS, const mgps_options &o, int device, bool tailOfSlabRun, const float *rowsL0 = nullptr)
 {
     auto *h = new mgps_solver();
     h->hier = hier;
@@ -735,7 +738,7 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         for (int a = 0; a < 3; ++a) {
             int rc = devAlloc(h, &h->w[a], wn[a], false);
             if (rc != MGPS_OK) return bail(rc);
-            if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), rowsL0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
                 return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
         }
     }
@@ -744,7 +747,9 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
     for (int l = 0; l < hier->levels; ++l) {
         HostLevel HL;
         const Dims d = hier->lv[l].d;
-        buildSlabLevel(hier->lv[l], 0, d.nz, l == 0 ? wx : nullptr, l == 0 ? wy : nullptr, l == 0 ? wz : nullptr, HL);
+        const bool hostW = l == 0 && !rowsL0;
+        buildSlabLevel(hier->lv[l], 0, d.nz, hostW ? wx : nullptr, hostW ? wy : nullptr, hostW ? wz : nullptr, HL,
+                       l == 0 ? rowsL0 : nullptr);
         clock.lap("codes, rows, lists", l);
         int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0);
         if (rc != MGPS_OK) return bail(rc);
@@ -796,6 +801,61 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
         }
     }
     return createWhole(out, hier, wx_host, wy_host, wz_host, use_gauss_seidel != 0, o, device, false);
+}
+
+int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const float *wx_dev,
+                               const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
+                               const mgps_options *opt)
+{
+    if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: out is NULL");
+    *out = nullptr;
+    if (!labels_host || !wx_dev || !wy_dev || !wz_dev)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: labels and the three weight grids are required");
+    mgps_options o;
+    MGPS_TRY(readOptions(opt, &o));
+    int device = 0;
+    MGPS_TRY(pickDevice(o, &device));
+    mgps_hierarchy *hier = nullptr;
+    MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz, labels_host, mg_levels, &o));
+    auto drop = [&](int code, const std::string &msg) {
+        mgps_hierarchy_destroy(hier);
+        return failH(nullptr, code, msg);
+    };
+    // the BOUNDARY cells of the fine level in band order (every BOUNDARY cell is a band cell, layer 0 of Ops.cpp:192-224)
+    const HostLevel &G = hier->lv[0];
+    std::vector<int32_t> cells;
+    for (int32_t c : G.band)
+        if (G.labels[size_t(c)] == MGPS_BOUNDARY_CELL) cells.push_back(c);
+    std::vector<float> rows(8 * cells.size());
+    int violations = 0;
+    {
+        uint8_t *labDev = nullptr;
+        int32_t *cellsDev = nullptr;
+        float *rowsDev = nullptr;
+        int *violDev = nullptr;
+        const size_t n = G.d.cells();
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&labDev), n);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cellsDev), std::max<size_t>(1, cells.size()) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rowsDev), std::max<size_t>(1, rows.size()) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&violDev), sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(labDev, G.labels.data(), n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !cells.empty()) e = hipMemcpy(cellsDev, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(violDev, 0, sizeof(int));
+        if (e == hipSuccess) e = hipError_t(launchBoundaryRows(nullptr, G.d, labDev, wx_dev, wy_dev, wz_dev, cellsDev, int(cells.size()), rowsDev, violDev));
+        if (e == hipSuccess && !rows.empty()) e = hipMemcpy(rows.data(), rowsDev, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&violations, violDev, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(labDev);
+        (void)hipFree(cellsDev);
+        (void)hipFree(rowsDev);
+        (void)hipFree(violDev);
+        if (e != hipSuccess) return drop(MGPS_ERR_HIP, std::string("mgps_create_device_weights: ") + hipGetErrorString(e));
+    }
+    int interiorOk = 0;
+    checkInteriorCells(G.labels.data(), nx, ny, nz, &interiorOk);
+    if (violations != 0 || !interiorOk)
+        return drop(MGPS_ERR_HIERARCHY,
+                    "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels");
+    return createWhole(out, hier, wx_dev, wy_dev, wz_dev, use_gauss_seidel != 0, o, device, false, rows.empty() ? &kNoRows : rows.data());
 }
 
 int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,

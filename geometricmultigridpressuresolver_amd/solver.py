@@ -176,20 +176,27 @@ class GeometricMultigridPoissonSolver:
     arrays with one extra entry along their axis."""
 
     def __init__(self, labels, weights, mg_levels, use_gauss_seidel, do_print_stats=False, device=None, options=None):
+        if torch.is_tensor(labels):
+            labels = labels.cpu().numpy()  # the hierarchy is built on the host: 1 byte per cell
         labels = _np_u8(labels)
-        w = [_np_f32(a) for a in weights]
         nz, ny, nx = labels.shape
-        assert w[0].shape == (nz, ny, nx + 1) and w[1].shape == (nz, ny + 1, nx) and w[2].shape == (nz + 1, ny, nx)
+        on_device = all(torch.is_tensor(a) and a.is_cuda for a in weights)
+        if on_device:  # weights written on the device (fields.buildMGDomain) never cross to the host
+            w = [a.contiguous() for a in weights]
+            assert all(a.dtype == torch.float32 for a in w)
+        else:
+            w = [_np_f32(a) for a in weights]
+        assert tuple(w[0].shape) == (nz, ny, nx + 1) and tuple(w[1].shape) == (nz, ny + 1, nx) and tuple(w[2].shape) == (nz + 1, ny, nx)
         opt = options if options is not None else default_options()
         opt.print_stats = int(bool(do_print_stats))
         if device is not None:
             opt.device = torch.device(device).index if not isinstance(device, int) else device
+        elif on_device:
+            opt.device = w[0].device.index
         self.h = C.c_void_p()
-        check(
-            lib().mgps_create(
-                C.byref(self.h), nx, ny, nz, _p(labels), _p(w[0]), _p(w[1]), _p(w[2]), int(mg_levels), int(bool(use_gauss_seidel)), C.byref(opt)
-            )
-        )
+        wp = [C.c_void_p(a.data_ptr()) for a in w] if on_device else [_p(a) for a in w]
+        create = lib().mgps_create_device_weights if on_device else lib().mgps_create
+        check(create(C.byref(self.h), nx, ny, nz, _p(labels), wp[0], wp[1], wp[2], int(mg_levels), int(bool(use_gauss_seidel)), C.byref(opt)))
         self.shape = (nz, ny, nx)
         self.use_gauss_seidel = bool(use_gauss_seidel)
         dev_index = opt.device if opt.device >= 0 else torch.cuda.current_device()

@@ -152,6 +152,13 @@ int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const floa
 int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
                 const float *wx_host, const float *wy_host, const float *wz_host, int mg_levels,
                 int use_gauss_seidel, const mgps_options *opt);
+/* The same solver from face weights that already live on the DEVICE (e.g. written by mgps_fields_boundary_weights):
+ * labels stay a host array (the hierarchy is built on the host from them, 1 byte per cell), the weights never
+ * cross to the host -- the operator rows of the BOUNDARY cells and the weight half of unitTestBoundaryCells are
+ * evaluated by a kernel, the solver keeps a device-to-device copy.  Same results as mgps_create. */
+int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
+                               const float *wx_dev, const float *wy_dev, const float *wz_dev, int mg_levels,
+                               int use_gauss_seidel, const mgps_options *opt);
 void mgps_destroy(mgps_solver *h);
 int mgps_levels(const mgps_solver *h);                       /* getMGLevels(), MG.h:31 */
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3]);

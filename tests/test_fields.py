@@ -171,6 +171,36 @@ def test_random_scenes_match_oracle(seed, fo, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("with_solid", [False, True])
+def test_solver_from_device_weights_equals_host_weights(with_solid, fo, oracle):
+    """mgps_create_device_weights (rows of the BOUNDARY cells evaluated by a kernel, weights never on the host)
+    builds the same solver as mgps_create: identical V-cycle and PCG results; and it rejects inconsistent input."""
+    import torch
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=with_solid)
+    material, valid, eshape, offset, levels, lab, w, rhs = _oracle_pipeline(fo, oracle, sc, with_solid)
+    lab8, w32 = lab.astype(np.uint8), [a.astype(np.float32) for a in w]
+    b = rhs.astype(np.float32)
+    results = []
+    for weights in (w32, [_dev(a, torch) for a in w32]):
+        for use_gs in (False, True):
+            s = G.GeometricMultigridPoissonSolver(lab8, weights, levels, use_gs)
+            x, bd = s.new_grid(), s.to_device(b)
+            s.applyVCycle(x, bd, False)
+            xp = s.new_grid()
+            st = s.solveGeometricConjugateGradient(xp, bd, 1e-6, 200, True)
+            results.append((x.cpu().numpy(), xp.cpu().numpy(), st["iterations"]))
+            s.close()
+    for k in range(2):
+        assert np.array_equal(results[k][0], results[k + 2][0]) and np.array_equal(results[k][1], results[k + 2][1])
+        assert results[k][2] == results[k + 2][2]
+    # every face weight 1: cells that are BOUNDARY only through a cut face between two liquid cells lose their reason
+    bad = [torch.ones_like(_dev(a, torch)) for a in w32]
+    with pytest.raises(G.MgpsError):
+        G.GeometricMultigridPoissonSolver(lab8, bad, levels, False)
+
+
+@pytest.mark.gpu
 def test_device_projection_is_divergence_free():
     """The whole projection on the device: fields -> multigrid domain -> MG-PCG -> pressure -> velocity; the
     reference's own end-to-end check is the resulting divergence (Plug.cpp:704-706)."""
@@ -188,8 +218,8 @@ def test_device_projection_is_divergence_free():
     valid = F.buildValidFaces(material, cw)
     labels, weights = F.buildMGDomain(material, cw, phi, valid, eshape, offset)
     rhs = F.buildRHS(material, vel, cw, eshape, offset, sv)
-    # hierarchy set-up still reads labels and weights on the host
-    solver = G.GeometricMultigridPoissonSolver(labels.cpu().numpy(), [a.cpu().numpy() for a in weights], levels, True)
+    # only the labels (1 byte per cell) cross to the host for the hierarchy; the weights stay on the device
+    solver = G.GeometricMultigridPoissonSolver(labels, weights, levels, True)
     x = solver.new_grid()
     st = solver.solveGeometricConjugateGradient(x, rhs, 1e-6, 200, True)
     assert st["outcome"] == "converged"

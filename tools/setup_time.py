@@ -13,4 +13,8 @@ for gs in (False, True):
     torch.cuda.synchronize(); t = time.time()
     s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs, do_print_stats=True)
     torch.cuda.synchronize(); print("create gs=", gs, round(time.time() - t, 2)); s.close()
+wd = [torch.from_numpy(a).cuda() for a in w]
+torch.cuda.synchronize(); t = time.time()
+s = G.GeometricMultigridPoissonSolver(lab, wd, lev, True)
+torch.cuda.synchronize(); print("create gs= True from device weights", round(time.time() - t, 2)); s.close()
 t = time.time(); H = G.Hierarchy(lab, lev); print("hierarchy only", round(time.time() - t, 2))
