@@ -451,6 +451,10 @@ struct BandWindow {
     ptrdiff_t cellShift = 0;
     const std::unordered_map<int64_t, int32_t> *haloSlot = nullptr;
     int32_t gridLoCode = 0;
+    // band cells of neighbouring slabs that are nobody's output here: their rows (8 floats each, see buildSlabHalo)
+    const std::unordered_map<int64_t, int32_t> *foreignRowOf = nullptr;  // window cell -> row index
+    const float *foreignRows8 = nullptr;
+    int32_t foreignBase = 0;  // band entry that addresses foreign row 0 in the kernel
     static constexpr int32_t kNoBand = -1, kDeepBand = -2;  // kDeepBand: a band cell that is nobody's output here
 
     bool active(size_t wc) const { return labels[wc] == MGPS_INTERIOR_CELL || labels[wc] >= kCodeGeneral; }
@@ -530,7 +534,13 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
                         v = int32_t(updateW.size());
                         updateW.push_back(cq);
                         if (e >= 0) g.updateEntry.push_back(e | (int32_t(W.entryDiag[size_t(e)]) << kBandDiagShift));
-                        else g.updateEntry.push_back(int32_t(W.diagFromLabels(size_t(cq))) << kBandDiagShift);  // no output, simple
+                        else if (!W.foreignRowOf) g.updateEntry.push_back(int32_t(W.diagFromLabels(size_t(cq))) << kBandDiagShift);  // no output, simple
+                        else {  // no output; its entry field addresses its row when it is a general cell
+                            const auto fr = W.foreignRowOf->find(int64_t(cq));
+                            if (fr == W.foreignRowOf->end()) return 2;
+                            const float *row = W.foreignRows8 + 8 * size_t(fr->second);
+                            g.updateEntry.push_back(row[7] != 0.f ? int32_t(row[6]) << kBandDiagShift : W.foreignBase + fr->second);
+                        }
                     } else {
                         v = -int32_t(readW.size()) - 2;
                         readW.push_back(cq);
@@ -676,7 +686,44 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     buildGroupsOverWindow(W, depth, out);
 }
 
-void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out)
+size_t bandCellsInPlane(const HostLevel &G, int p)
+{
+    if (p < 0 || p >= G.d.nz) return 0;
+    const size_t plane = size_t(G.d.nx) * G.d.ny, lo = size_t(p) * plane, hi = lo + plane;
+    size_t n = 0;
+    for (int32_t c : G.band) n += size_t(c) >= lo && size_t(c) < hi;
+    return n;
+}
+
+void slabBandRows(const HostLevel &G, const HostLevel &L, int z0, int p0, int step, int count, std::vector<float> &rows)
+{
+    rows.clear();
+    const size_t plane = size_t(G.d.nx) * G.d.ny;
+    std::unordered_map<int32_t, int32_t> entryOfCell;  // slab-local cell -> bandDev entry, for the planes asked for
+    for (int q = 0; q < count; ++q) {
+        const int p = p0 + q * step - z0;
+        for (size_t t = 0; t < L.bandDev.size(); ++t)
+            if (size_t(L.bandDev[t]) / plane == size_t(p)) entryOfCell.emplace(L.bandDev[t], int32_t(t));
+    }
+    const size_t nb = size_t(L.numBoundary);
+    for (int q = 0; q < count; ++q) {
+        const int p = p0 + q * step;
+        const size_t lo = size_t(p) * plane, hi = lo + plane;
+        for (int32_t gc : G.band) {
+            if (size_t(gc) < lo || size_t(gc) >= hi) continue;
+            const size_t t = size_t(entryOfCell.at(int32_t(size_t(gc) - size_t(z0) * plane)));
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, float(L.bandDiag[t]), 1.f};
+            if (t < nb) {
+                for (int a = 0; a < 7; ++a) r[a] = L.rows[size_t(a) * nb + t];
+                r[7] = 0.f;
+            }
+            rows.insert(rows.end(), r, r + 8);
+        }
+    }
+}
+
+void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out,
+                   const std::vector<float> *foreignRows)
 {
     out = SlabHalo();
     const Dims gd = G.d;
@@ -732,11 +779,43 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     W.seedCell.resize(out.bandExt.size());
     W.entryDiag = L.bandDiag;
     W.entryDiag.resize(out.bandExt.size(), 0);
+    // rows of the neighbours' cells, when given: [ghost below][ghost above][z0-2 .. ][z1+1 ..], each plane in band order
+    std::unordered_map<int64_t, int32_t> foreignRowOf;
+    if (foreignRows) {
+        std::vector<int> planes;
+        if (lo) planes.push_back(z0 - 1);
+        if (hi) planes.push_back(z1);
+        for (int q = 2; lo && q <= depth; ++q) planes.push_back(z0 - q);
+        for (int q = 1; hi && q < depth; ++q) planes.push_back(z1 + q);
+        int32_t next = 0;
+        for (int p : planes) {
+            const size_t plo = size_t(p) * plane, phi = plo + plane;
+            for (int32_t gc : G.band)
+                if (size_t(gc) >= plo && size_t(gc) < phi) foreignRowOf.emplace(int64_t(size_t(gc) - wlo), next++);
+        }
+        if (size_t(next) * 8 != foreignRows->size()) return;  // the neighbours sent something else: leave depth 0
+        out.nForeign = int(next);
+        out.foreignRows.resize(size_t(next) * 7);
+        for (int32_t r = 0; r < next; ++r)
+            for (int a = 0; a < 7; ++a) out.foreignRows[size_t(a) * size_t(next) + size_t(r)] = (*foreignRows)[size_t(r) * 8 + size_t(a)];
+        W.foreignRowOf = &foreignRowOf;
+        W.foreignRows8 = foreignRows->data();
+        W.foreignBase = int32_t(L.bandDev.size());
+    }
     for (size_t t = 0; t < out.bandExt.size(); ++t) {
         const size_t wc = size_t(ptrdiff_t(out.bandExt[t]) + ownedShift);
         W.seedCell[t] = int32_t(wc);
         W.entryOf[wc] = int32_t(t);
-        if (t >= L.bandDev.size()) W.entryDiag[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
+        if (t < L.bandDev.size()) continue;
+        if (!foreignRows) {
+            W.entryDiag[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
+            continue;
+        }
+        // a ghost-plane cell: its row index is t - bandDev.size() by construction of the order above
+        const auto fr = foreignRowOf.find(int64_t(wc));
+        if (fr == foreignRowOf.end() || size_t(fr->second) != t - L.bandDev.size()) return;
+        const float *row = foreignRows->data() + 8 * size_t(fr->second);
+        W.entryDiag[t] = row[7] != 0.f ? uint8_t(int(row[6])) : uint8_t(0);
     }
     W.gridPlaneLo = z0 - 1 - wz0;  // (a ghost plane outside the domain is never referenced: its cells are not active)
     W.gridPlaneHi = z1 + 1 - wz0;

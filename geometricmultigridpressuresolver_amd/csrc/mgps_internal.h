@@ -113,9 +113,20 @@ struct SlabHalo {
     std::vector<int32_t> sendIdx[2];  // my cells the lower [0] / upper [1] neighbour needs: offsets from owned cell 0
     int nrecv[2] = {0, 0};            // closure cells received from the lower / upper neighbour; halo slots: lower first
     std::vector<int32_t> bandExt;     // bandDev, then the band cells of the lower and of the upper ghost plane
+    std::vector<float> foreignRows;   // SoA 7 x nForeign (device layout) of the rows handed to buildSlabHalo; may be empty
+    int nForeign = 0;
     BandGroups groups;                // over bandExt; cells outside the grid allocation are encoded as halo slots
 };
-void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out);
+// foreignRows (optional): operator rows of the neighbours' band cells near the cuts, 8 floats each (six weights,
+// diagonal, 1 / 0 simple / general), ordered [ghost plane below][ghost plane above][planes z0-2 .. z0-depth]
+// [planes z1+1 .. z1+depth-1], each plane in band order (slabBandRows builds the sender's half).  Without them
+// every foreign band cell must be a simple cell (diagonal from the labels).
+void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out,
+                   const std::vector<float> *foreignRows = nullptr);
+// rows (8 floats, as above) of this slab's band cells in the planes [p0, p0 + count * step) walked p0, p0 + step, ...
+void slabBandRows(const HostLevel &G, const HostLevel &L, int z0, int p0, int step, int count, std::vector<float> &rows);
+// number of band cells of level G in plane p
+size_t bandCellsInPlane(const HostLevel &G, int p);
 
 // rowsIn (optional, instead of wx / wy / wz): the operator rows of the BOUNDARY band cells of the planes
 // [z0, z1) evaluated elsewhere (on the device, mgps_create_device_weights), 8 floats per cell in band order:
@@ -185,8 +196,11 @@ struct BandGroupsDev {
     uint16_t *neighbours = nullptr;
 };
 // hx / hb: halo values of x and of the rhs for node cells encoded below gridLo = -(nx*ny) (cut slabs), else nullptr
+// frows (cut slabs with general BOUNDARY cells near the cut): SoA rows 7 x nForeign of the neighbours' cells,
+// addressed by band entry - foreignBase
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr);
+                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr,
+                    const float *frows = nullptr, int foreignBase = 0, int nForeign = 0);
 // one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
 // that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the
 // two lists into the halo arrays and the last part into the band cells of the ghost plane of b (the grids'

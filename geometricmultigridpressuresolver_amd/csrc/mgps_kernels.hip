@@ -331,11 +331,14 @@ __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restri
 // Every thread keeps the description of its <= kBandSlots update nodes (neighbour ids, rhs, diagonal)
 // in registers, loaded once with all loads in flight together; the passes themselves touch only LDS.
 // general BOUNDARY cell of a band pass (rare: kept out of line so that the common path stays lean)
+// t < g.nbnd: a row of this rank's list; otherwise row t - foreignBase of the rows received from the neighbours
 __device__ __noinline__ float bandGeneralUpdate(const GridP &g, int t, float xc, float bc, float xm, float xp, float ym,
-                                                float yp, float zm, float zp, float omega)
+                                                float yp, float zm, float zp, float omega, const float *frows, int foreignBase,
+                                                int nForeign)
 {
-    const size_t nb = size_t(g.nbnd);
-    const float *r = g.rows + t;
+    const bool own = t < g.nbnd;
+    const size_t nb = own ? size_t(g.nbnd) : size_t(nForeign);
+    const float *r = own ? g.rows + t : frows + (t - foreignBase);
     float acc = 0.f;
     acc -= r[0] * xm;
     acc -= r[nb] * xp;
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
                                                                 const uint16_t *__restrict__ neighbours,
                                                                 const int32_t *__restrict__ readCell,
                                                                 float *__restrict__ tmp, float omega, int depth,
-                                                                const float *__restrict__ hx, const float *__restrict__ hb)
+                                                                const float *__restrict__ hx, const float *__restrict__ hb,
+                                                                const float *__restrict__ frows, int foreignBase, int nForeign)
 {
     __shared__ float val[2][kBandMaxNodes];
     // node cells below gridLo are slots of the halo arrays (cells of a neighbouring slab, see SlabHalo)
@@ -446,7 +450,8 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
                     const float lap = diag * xc - (xm + xp + ym + yp + zm + zp);
                     dst[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));
                 } else
-                    dst[n] = bandGeneralUpdate(g, entry[m] & kBandEntryMask, xc, bv[m], xm, xp, ym, yp, zm, zp, omega);
+                    dst[n] = bandGeneralUpdate(g, entry[m] & kBandEntryMask, xc, bv[m], xm, xp, ym, yp, zm, zp, omega, frows, foreignBase,
+                                               nForeign);
             }
         }
         __syncthreads();
@@ -1189,12 +1194,14 @@ int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float
 }
 
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb)
+                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb, const float *frows,
+                    int foreignBase, int nForeign)
 {
     if (nband <= 0 || bg.ngroups <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     bandFusedKernel<<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours,
-                                                                  bg.readCell, bandTmp, omega, bg.depth, hx, hb);
+                                                                  bg.readCell, bandTmp, omega, bg.depth, hx, hb, frows, foreignBase,
+                                                                  nForeign);
     const unsigned nb = blocksFor(size_t(nband), 256);
     bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());

@@ -58,6 +58,8 @@ struct DevLevel {
         int32_t *bandExt = nullptr;
         int nbandExt = 0;
         float *tmpExt = nullptr;
+        float *frows = nullptr;  // rows of the neighbours' band cells near the cuts (levels with general cells)
+        int nForeign = 0;
         BandGroupsDev groups;
     } halo;
 };
@@ -198,6 +200,7 @@ void freeAll(mgps_solver *h)
         (void)hipFree(L.halo.hb);
         (void)hipFree(L.halo.bandExt);
         (void)hipFree(L.halo.tmpExt);
+        (void)hipFree(L.halo.frows);
         (void)hipFree(L.halo.groups.info);
         (void)hipFree(L.halo.groups.updateEntry);
         (void)hipFree(L.halo.groups.updateCell);
@@ -299,7 +302,8 @@ int bandStageDeep(mgps_solver *h, int l, float *x, const float *b)
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
                                   hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], h->stream));
     MGPS_LAUNCH(h, launchHaloUnpack(h->stream, rLo, rHi, x, bw, plane));
-    MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb));
+    MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb,
+                                   H.frows, L.nband, H.nForeign));
     return MGPS_OK;
 }
 
@@ -924,15 +928,53 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
         int rc = uploadLevel(h, h->lv[l], HL, lz0, lz1, gz, l == 0, l < D, l > 0);
         if (rc != MGPS_OK) return bail(rc);
         if (l == D || P == 1 || !o.deep_band_halo || o.band_iterations < 1 || o.band_iterations > kBandMaxDepth) continue;
-        // the one-exchange band stage needs every band cell near a cut to be a simple cell: true on the
-        // unit-weight levels, on the fine level only when no rank holds a general BOUNDARY cell (collective)
+        // The neighbours' band cells near a cut are recomputed here, so their operator rows are needed: on the
+        // unit-weight levels (and on an all-simple fine level) the labels give them; otherwise the ranks
+        // trade the rows of their `band_iterations` planes next to each cut once, now (collective).
+        std::vector<float> foreignRows;
+        bool haveForeign = false;
         if (l == 0) {
             double general = double(HL.numBoundary);
             if (h->comm.allreduce(h->comm.user, &general, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
-            if (general != 0.0) continue;
+            if (general != 0.0) {
+                const int depth = o.band_iterations;
+                const bool lo = rank > 0, hi = rank < P - 1;
+                std::vector<float> send[2], recv[2];
+                if (lo) slabBandRows(hier->lv[0], HL, lz0, lz0, 1, depth, send[0]);
+                if (hi) slabBandRows(hier->lv[0], HL, lz0, lz1 - 1, -1, depth, send[1]);
+                size_t nrecv[2] = {0, 0}, nghost[2] = {0, 0};
+                for (int q = 1; lo && q <= depth; ++q) nrecv[0] += bandCellsInPlane(hier->lv[0], lz0 - q);
+                for (int q = 0; hi && q < depth; ++q) nrecv[1] += bandCellsInPlane(hier->lv[0], lz1 + q);
+                if (lo) nghost[0] = bandCellsInPlane(hier->lv[0], lz0 - 1);
+                if (hi) nghost[1] = bandCellsInPlane(hier->lv[0], lz1);
+                float *sd[2] = {nullptr, nullptr}, *rd[2] = {nullptr, nullptr};
+                for (int q = 0; q < 2; ++q) {
+                    recv[q].resize(nrecv[q] * 8);
+                    rc = devUpload(h, &sd[q], send[q]);
+                    if (rc == MGPS_OK) rc = devAlloc(h, &rd[q], recv[q].size(), true);
+                    if (rc != MGPS_OK) return bail(rc);
+                }
+                (void)hipStreamSynchronize(h->stream);
+                const int crc = h->comm.exchange(h->comm.user, lo ? sd[0] : nullptr, send[0].size() * sizeof(float), lo ? rd[0] : nullptr,
+                                                 recv[0].size() * sizeof(float), hi ? sd[1] : nullptr, send[1].size() * sizeof(float),
+                                                 hi ? rd[1] : nullptr, recv[1].size() * sizeof(float), h->stream);
+                hipError_t e = hipStreamSynchronize(h->stream);
+                for (int q = 0; q < 2 && e == hipSuccess; ++q)
+                    if (!recv[q].empty()) e = hipMemcpy(recv[q].data(), rd[q], recv[q].size() * sizeof(float), hipMemcpyDeviceToHost);
+                for (int q = 0; q < 2; ++q) {
+                    (void)hipFree(sd[q]);
+                    (void)hipFree(rd[q]);
+                }
+                if (crc != 0) return bail(failH(h, MGPS_ERR_COMM, "row exchange failed during set-up"));
+                if (e != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string("row exchange: ") + hipGetErrorString(e)));
+                // storage order of buildSlabHalo: ghost below, ghost above, deeper below, deeper above
+                for (int q = 0; q < 2; ++q) foreignRows.insert(foreignRows.end(), recv[q].begin(), recv[q].begin() + ptrdiff_t(nghost[q] * 8));
+                for (int q = 0; q < 2; ++q) foreignRows.insert(foreignRows.end(), recv[q].begin() + ptrdiff_t(nghost[q] * 8), recv[q].end());
+                haveForeign = true;
+            }
         }
         SlabHalo SH;
-        buildSlabHalo(hier->lv[l], HL, lz0, lz1, o.band_iterations, SH);
+        buildSlabHalo(hier->lv[l], HL, lz0, lz1, o.band_iterations, SH, haveForeign ? &foreignRows : nullptr);
         double failed = SH.depth == 0 ? 1.0 : 0.0;  // every rank must take the same form of the stage
         if (h->comm.allreduce(h->comm.user, &failed, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
         if (failed != 0.0) continue;
@@ -950,6 +992,8 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
         if (rc == MGPS_OK) rc = devAlloc(h, &H.hb, size_t(SH.nrecv[0]) + SH.nrecv[1], true);
         if (rc == MGPS_OK) rc = devUpload(h, &H.bandExt, SH.bandExt);
         if (rc == MGPS_OK) rc = devAlloc(h, &H.tmpExt, SH.bandExt.size(), true);
+        if (rc == MGPS_OK && SH.nForeign > 0) rc = devUpload(h, &H.frows, SH.foreignRows);
+        H.nForeign = SH.nForeign;
         H.nbandExt = int(SH.bandExt.size());
         H.groups.depth = SH.groups.depth;
         H.groups.ngroups = int(SH.groups.groups());

@@ -73,8 +73,9 @@ typedef struct mgps_options {
                                into slabs as one launch (same arithmetic per cell); 0 = one launch pair per pass */
     int deep_band_halo;     /* slab runs, 1 (default): one ghost exchange per band stage -- the message carries the ghost
                                plane plus the band closure of the next band_iterations planes, and each rank recomputes
-                               its neighbours' band cells near the cut -- instead of one exchange per band pass.  Levels
-                               with general BOUNDARY cells (fine level of a free-surface domain) keep the per-pass form */
+                               its neighbours' band cells near the cut -- instead of one exchange per band pass.  On a
+                               fine level with general BOUNDARY cells the ranks trade the operator rows of the cells in
+                               the band_iterations planes next to each cut once, at set-up */
     int min_cells_per_rank; /* slab runs: a level below the finest stays distributed only while every rank owns at least
                                this many cells of it (default 2097152 = 128^3); smaller levels are gathered to rank 0,
                                where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
