@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Compute side of the multi-GPU V-cycle on ONE GPU: rank r of a P-rank slab run with a transport that moves
+nothing (exchanges, gather and scatter return at once; the values in the ghost planes are meaningless, the
+kernels and launches are exactly those of the real run).  What it gives: the per-rank device time of one cycle
+without any communication -- the ceiling of the strong-scaling curve -- for rank 0 (which also runs the collapsed
+tail) and a middle rank.   python tools/slab_compute_bound.py [N]"""
+import ctypes as C
+import json
+import sys
+import time
+
+import torch
+
+from geometricmultigridpressuresolver_amd import domains as D
+from geometricmultigridpressuresolver_amd.distributed import _ALLR, _DEST, _EXCH, _GATH, CommStruct, SlabSolver
+
+
+class NullComm:
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+        self.calls = 0
+
+        def exch(*a):
+            self.calls += 1
+            return 0
+
+        self._cb = (_EXCH(exch), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
+        self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST())
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+levels = 1
+while (n >> (levels - 1)) > 16:
+    levels += 1
+out = {"grid": n, "levels": levels, "ranks": {}}
+for P in (1, 2, 4, 8):
+    for rank in sorted({0, P // 2}):
+        nzl = n // P
+        z0, z1 = rank * nzl, (rank + 1) * nzl
+        lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
+        comm = NullComm(rank, P)
+        s = SlabSolver(lab, w, levels, False, comm, device=0)
+        b = s.to_device(D.random_rhs(lab, h, z0=z0, z1=z1))
+        x = s.new_grid()
+        for _ in range(3):
+            s.applyVCycle(x, b, True)
+        torch.cuda.synchronize()
+        c0, t = comm.calls, time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            s.applyVCycle(x, b, True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / reps * 1e3
+        out["ranks"][f"P={P} rank={rank}"] = {"ms_per_cycle": round(ms, 3), "exchanges_per_cycle": (comm.calls - c0) / reps,
+                                               "distributed_levels": s.distributed_levels}
+        print(f"P={P} rank={rank}: {ms:.3f} ms per cycle, {(comm.calls - c0) / reps:.0f} exchanges, D={s.distributed_levels}", flush=True)
+        s.close()
+        del s, b, x, lab, w
+        torch.cuda.empty_cache()
+print(json.dumps(out))
