@@ -1,16 +1,14 @@
 // The device-resident solver object and the C ABI (include/mgps.h): level storage in HBM, the
 // V-cycle schedule of GeometricMultigridPoissonSolver::applyVCycle (MG.cpp:420-881), the PCG driver
-// of solveGeometricConjugateGradient (CG.h:18-207), and the Z-slab multi-GPU orchestration (ghost
-// plane exchange before every operator that reads across a cut, collapse of the coarse tail to
-// rank 0).  Host orchestration only -- every arithmetic step is a HIP kernel from
+// of solveGeometricConjugateGradient (CG.h:18-207), and the Z-slab multi-GPU orchestration (one ghost
+// exchange per band stage and per whole-grid operator that reads across a cut, collapse of the coarse
+// tail to rank 0).  Host orchestration only -- every arithmetic step is a HIP kernel from
 // mgps_kernels.hip; there is no CPU fallback: without a HIP device the constructors fail with
 // MGPS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
-#include <chrono>
-#include <cstdio>
-
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>

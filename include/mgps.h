@@ -225,12 +225,15 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
  * axis, so a slab and a ghost plane are contiguous) into `size` slabs of nz/size planes; rank r owns
  * planes [r*nz/size, (r+1)*nz/size).  Level l stays distributed while its per-rank plane count is a
  * multiple of 16 (keeps the 16^3 Gauss-Seidel tile colouring identical to the single-GPU run and
- * restriction/prolongation rank-local up to one ghost plane); the first level that is not, and
- * everything coarser, is gathered to rank 0 and solved there ("collapse").  Before every operator
- * that reads across the cut the ghost plane on each side is refreshed from the Z-neighbour: the
- * whole plane after an operator that rewrote the whole grid (Jacobi sweep, Gauss-Seidel colour pass,
- * prolongation, residual), only the packed band cells of the plane after a band pass (a few percent
- * of a plane).
+ * restriction/prolongation rank-local up to one ghost plane) and every rank owns at least
+ * options.min_cells_per_rank cells of it; the first level that fails either test, and everything
+ * coarser, is gathered to rank 0 and solved there ("collapse").  One ghost plane per side.  A band
+ * stage costs one exchange (options.deep_band_halo: ghost plane + the band closure of the next
+ * band_iterations planes, the neighbours' band cells near the cut are recomputed locally and the
+ * stage leaves the ghost planes complete); the whole-grid operators that follow something that rewrote
+ * the grid (a Gauss-Seidel colour pass, the restriction's residual, the prolongation's coarse
+ * correction) refresh the whole ghost plane first.  With deep_band_halo = 0 every band pass is preceded
+ * by an exchange of the packed band cells of the plane (a few percent of it).
  *
  * The transport is a small vtable so that the same orchestration runs over RCCL (production,
  * mgps_comm_create_rccl: ncclSend/ncclRecv pairs in one group on the solver's stream over xGMI) or

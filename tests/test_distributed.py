@@ -4,9 +4,10 @@
   operators (tests/slab_emulation.py) reproduces the whole-grid oracle to round-off, and stops doing so
   when exchanges are dropped.
 
-* gpu: two ranks share the one GPU of the test box; the slab orchestration of libmgps.so (ghost
-  exchange before every operator that reads across the cut, collapse of the coarse tail to rank 0)
-  runs over TorchDistComm/gloo and must reproduce the single-GPU solver.  Only the transport differs
+* gpu: two (and four) ranks share the one GPU of the test box; the slab orchestration of libmgps.so (one
+  ghost exchange per band stage -- or per band pass with deep_band_halo = 0 -- and per whole-grid operator
+  that reads across a cut, collapse of the coarse tail to rank 0) runs over TorchDistComm/gloo and must
+  reproduce the single-GPU solver on three domains (box, cut-cell solid, free-surface scene).  Only the transport differs
   from production (RCCL refuses two ranks on one device).
 """
 import os
