@@ -683,9 +683,10 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float
     const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
     // with a chunk list: workgroups of 256 over the active chunks (four per 1024-cell chunk); the rest of `coarse` stays 0
     const int per = cg.chunkCells / 256;
-    if (cg.chunks && cg.chunks[blockIdx.x / per] < 0) return;
-    const size_t c = cg.chunks ? size_t(cg.chunks[blockIdx.x / per]) * cg.chunkCells + (blockIdx.x % per) * 256 + threadIdx.x
-                               : size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);  // a chiplet's L2 serves a contiguous run of the list
+    if (cg.chunks && cg.chunks[bid / per] < 0) return;
+    const size_t c = cg.chunks ? size_t(cg.chunks[bid / per]) * cg.chunkCells + (bid % per) * 256 + threadIdx.x
+                               : size_t(bid) * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (!activeLabel(cg.lab[c])) {
         coarse[c] = 0.f;
