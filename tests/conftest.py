@@ -11,6 +11,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the product library is built in-tree by __graft_entry__.build(); a tree that arrives without it (or with
+    # sources newer than it) is built here once, with hipcc, before any test imports the package
+    csrc = os.path.join(ROOT, "geometricmultigridpressuresolver_amd", "csrc")
+    lib = os.path.join(csrc, "libmgps.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs):
+        import subprocess
+
+        subprocess.check_call(["make", "-C", csrc, "-j4", "all"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
