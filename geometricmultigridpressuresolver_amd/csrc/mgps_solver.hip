@@ -495,7 +495,6 @@ int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const
 int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
 {
     DevLevel &F = h->lv[0];
-    const size_t bytes = F.d.cells() * sizeof(float);
     mgps_pcg_stats local{};
     if (!st) st = &local;
     std::memset(st, 0, sizeof(*st));
@@ -534,12 +533,12 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         st->rel_residual = st->rel_residual_recomputed = std::sqrt(res2 / rhs2);
         return finish(MGPS_PCG_ALREADY_CONVERGED);
     }
-    MGPS_HIP(h, hipMemsetAsync(p, 0, bytes, h->stream));  // CG.h:69
+    MGPS_LAUNCH(h, launchZero(h->stream, p, F.d.cells()));  // CG.h:69
     MGPS_TRY(precondition(p, r));                         // CG.h:75
     double absNew = 0;
     MGPS_TRY(reduceToHost(h, 0, 0, p, r, &absNew));  // CG.h:86
-    MGPS_HIP(h, hipMemsetAsync(z, 0, bytes, h->stream));
-    MGPS_HIP(h, hipMemsetAsync(t, 0, bytes, h->stream));
+    MGPS_LAUNCH(h, launchZero(h->stream, z, F.d.cells()));
+    MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
     bool converged = false;
     for (; it < maxIt; ++it) {
