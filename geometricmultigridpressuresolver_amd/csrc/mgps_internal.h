@@ -235,6 +235,9 @@ int launchMulMasked(void *stream, const GridP &g, float *dst, const float *a, co
 constexpr int kReducePartials = 2048;
 int launchReduce(void *stream, int kind, const GridP &g, const float *a, const float *b, double *partials,
                  double *resultDev);
+// x += alpha p, r -= alpha t, *resultDev = sum of the new r^2 over active cells (one pass, CG.h:132-153)
+int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
+                   double *resultDev);
 int launchZero(void *stream, float *a, size_t count);
 // buf[t] = a[idx[t]] / a[idx[t]] = buf[t]; idx are offsets from owned cell 0 (negative in the lower ghost plane)
 int launchPack(void *stream, float *buf, const float *a, const int32_t *idx, int n);

@@ -1376,6 +1376,51 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
     return int(hipGetLastError());
 }
 
+// One pass for the two vector updates of a CG iteration and the norm that follows them (CG.h:132-153):
+// x += alpha p, r -= alpha t on active cells, partial sums of the new r^2 -- 25 B per cell instead of 13 + 13 + 5.
+__global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ x,
+                                                      const float *__restrict__ p, float *__restrict__ r,
+                                                      const float *__restrict__ t, float alpha, double *__restrict__ partials,
+                                                      const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
+{
+    double acc = 0.0;
+    const size_t nq = n >> 2;
+    size_t q;
+    for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
+        float4 xv = reinterpret_cast<const float4 *>(x)[q], rv = reinterpret_cast<const float4 *>(r)[q];
+        const float4 pv = reinterpret_cast<const float4 *>(p)[q], tv = reinterpret_cast<const float4 *>(t)[q];
+        if (activeLabel(l.x)) { xv.x = xv.x + alpha * pv.x; rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); }
+        if (activeLabel(l.y)) { xv.y = xv.y + alpha * pv.y; rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); }
+        if (activeLabel(l.z)) { xv.z = xv.z + alpha * pv.z; rv.z = rv.z + (-alpha) * tv.z; acc += double(rv.z) * double(rv.z); }
+        if (activeLabel(l.w)) { xv.w = xv.w + alpha * pv.w; rv.w = rv.w + (-alpha) * tv.w; acc += double(rv.w) * double(rv.w); }
+        reinterpret_cast<float4 *>(x)[q] = xv;
+        reinterpret_cast<float4 *>(r)[q] = rv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t c = (nq << 2) + threadIdx.x;
+        if (activeLabel(lab[c])) {
+            x[c] = x[c] + alpha * p[c];
+            r[c] = r[c] + (-alpha) * t[c];
+            acc += double(r[c]) * double(r[c]);
+        }
+    }
+    const double total = blockReduce<1>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
+                   double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
+    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells);
+    reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+    return int(hipGetLastError());
+}
+
 int launchReduce(void *stream, int kind, const GridP &g, const float *a, const float *b, double *partials,
                  double *resultDev)
 {

@@ -461,15 +461,21 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
     return MGPS_OK;
 }
 
-int reduceToHost(mgps_solver *h, int kind, int level, const float *a, const float *b, double *out)
+// the value a reduction launch left in resultDev, on the host (summed / maximised over the ranks of a slab run)
+int fetchReduction(mgps_solver *h, int kind, double *out)
 {
-    DevLevel &L = h->lv[level];
-    MGPS_LAUNCH(h, launchReduce(h->stream, kind, L.g, a, b, h->partials, h->resultDev));
     MGPS_HIP(h, hipMemcpyAsync(h->resultHost, h->resultDev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     *out = *h->resultHost;
     if (h->dist) MGPS_COMM(h, h->comm.allreduce(h->comm.user, out, 1, kind <= 1 ? 0 : 1));
     return MGPS_OK;
+}
+
+int reduceToHost(mgps_solver *h, int kind, int level, const float *a, const float *b, double *out)
+{
+    DevLevel &L = h->lv[level];
+    MGPS_LAUNCH(h, launchReduce(h->stream, kind, L.g, a, b, h->partials, h->resultDev));
+    return fetchReduction(h, kind, out);
 }
 
 int ensurePcgGrids(mgps_solver *h, bool needDiag)
@@ -551,9 +557,9 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         double pAp = 0;
         MGPS_TRY(reduceToHost(h, 0, 0, p, t, &pAp));
         const double alpha = absNew / pAp;                                               // CG.h:121
-        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, x, p, nullptr, float(alpha), 1.f));   // CG.h:132
-        MGPS_LAUNCH(h, launchAxpy(h->stream, F.g, r, t, nullptr, float(alpha), -1.f));  // CG.h:143
-        MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));                             // CG.h:153
+        // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
+        MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev));
+        MGPS_TRY(fetchReduction(h, 1, &res2));
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161 -- the counter is not advanced on the exit pass
