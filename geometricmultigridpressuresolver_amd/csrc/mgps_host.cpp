@@ -651,15 +651,31 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
         out = BandGroups();
         return false;
     }
+    // concatenate: offsets first, then every group copies itself into place (all host threads)
+    std::vector<const GroupBuild *> flat;
     for (auto &list : built)
-        for (auto &g : list) {
-            const int32_t updStart = int32_t(out.updateEntry.size()), readStart = int32_t(out.readCell.size());
-            out.info.insert(out.info.end(), {updStart, readStart, int32_t(g.readCell.size()), g.cnt[0], g.cnt[1], g.cnt[2], g.cnt[3], 0});
-            out.updateEntry.insert(out.updateEntry.end(), g.updateEntry.begin(), g.updateEntry.end());
-            out.updateCell.insert(out.updateCell.end(), g.updateCell.begin(), g.updateCell.end());
-            out.neighbours.insert(out.neighbours.end(), g.neighbours.begin(), g.neighbours.end());
-            out.readCell.insert(out.readCell.end(), g.readCell.begin(), g.readCell.end());
+        for (auto &g : list) flat.push_back(&g);
+    std::vector<size_t> updAt(flat.size() + 1, 0), readAt(flat.size() + 1, 0);
+    for (size_t q = 0; q < flat.size(); ++q) {
+        updAt[q + 1] = updAt[q] + flat[q]->updateEntry.size();
+        readAt[q + 1] = readAt[q] + flat[q]->readCell.size();
+    }
+    out.info.resize(8 * flat.size());
+    out.updateEntry.resize(updAt.back());
+    out.updateCell.resize(updAt.back());
+    out.neighbours.resize(6 * updAt.back());
+    out.readCell.resize(readAt.back());
+    parallelFor(int64_t(flat.size()), [&](int64_t b, int64_t e) {
+        for (int64_t q = b; q < e; ++q) {
+            const GroupBuild &g = *flat[size_t(q)];
+            const int32_t inf[8] = {int32_t(updAt[size_t(q)]), int32_t(readAt[size_t(q)]), int32_t(g.readCell.size()), g.cnt[0], g.cnt[1], g.cnt[2], g.cnt[3], 0};
+            std::copy(inf, inf + 8, out.info.begin() + 8 * q);
+            std::copy(g.updateEntry.begin(), g.updateEntry.end(), out.updateEntry.begin() + ptrdiff_t(updAt[size_t(q)]));
+            std::copy(g.updateCell.begin(), g.updateCell.end(), out.updateCell.begin() + ptrdiff_t(updAt[size_t(q)]));
+            std::copy(g.neighbours.begin(), g.neighbours.end(), out.neighbours.begin() + ptrdiff_t(6 * updAt[size_t(q)]));
+            std::copy(g.readCell.begin(), g.readCell.end(), out.readCell.begin() + ptrdiff_t(readAt[size_t(q)]));
         }
+    }, 16);
     lap.lap("band groups: concatenate");
     return true;
 }
@@ -678,7 +694,13 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     W.labels = L.codes.data() + size_t(L.d.nx) * L.d.ny;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
     W.allocEntryOf();
     W.seedCell.assign(L.bandDev.begin(), L.bandDev.end());
-    for (size_t t = 0; t < nband; ++t) W.entryOf[size_t(L.bandDev[t])] = int32_t(t);
+    {
+        int32_t *eo = W.entryOf.get();
+        const int32_t *bd = L.bandDev.data();
+        parallelFor(int64_t(nband), [=](int64_t b, int64_t e) {
+            for (int64_t t = b; t < e; ++t) eo[size_t(bd[t])] = int32_t(t);
+        }, 1 << 16);
+    }
     W.entryDiag = L.bandDiag;
     W.gridPlaneLo = 0;
     W.gridPlaneHi = L.d.nz;
