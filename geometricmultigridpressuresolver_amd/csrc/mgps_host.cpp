@@ -190,17 +190,19 @@ static void buildBand(HostLevel &L, int width)
             }
     });
     const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
-    for (int ring = 1; ring < width; ++ring) {
-        next.clear();
-        for (size_t c : frontier)
-            for (int a = 0; a < 3; ++a)
-                for (int s = -1; s <= 1; s += 2) {
-                    const size_t nb = c + s * stride[a];
-                    if (lab[nb] == MGPS_INTERIOR_CELL && !mark[nb]) {
-                        mark[nb] = 1;
-                        next.push_back(nb);
+    for (int ring = 1; ring < width; ++ring) {  // the order inside a ring is irrelevant: the list is re-read from `mark`
+        uint8_t *mk = mark.data();
+        parallelCollect<size_t>(int64_t(frontier.size()), 1 << 14, next, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
+            for (int64_t q = b; q < e; ++q) {
+                const size_t c = frontier[size_t(q)];
+                for (int a = 0; a < 3; ++a)
+                    for (int sgn = -1; sgn <= 1; sgn += 2) {
+                        const size_t nb = c + sgn * stride[a];
+                        if (lab[nb] == MGPS_INTERIOR_CELL && __atomic_exchange_n(&mk[nb], uint8_t(1), __ATOMIC_RELAXED) == 0)
+                            out.push_back(nb);
                     }
-                }
+            }
+        });
         frontier.swap(next);
     }
     // emit in (tile, k, j, i) order: walk tiles in linear tile order, cells x-fastest inside
