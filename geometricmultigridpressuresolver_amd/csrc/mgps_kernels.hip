@@ -29,6 +29,18 @@ namespace mgps {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned char v4b __attribute__((ext_vector_type(4)));
+// streamed inputs (rhs, cell codes): read once per sweep, kept from displacing the x rows the caches re-serve
+__device__ __forceinline__ float4 streamLoad4(const float *p)
+{
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uchar4 streamLoad4(const uint8_t *p)
+{
+    const v4b v = __builtin_nontemporal_load(reinterpret_cast<const v4b *>(p));
+    return make_uchar4(v.x, v.y, v.z, v.w);
+}
 constexpr int kWave = 64;
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
 
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const float4 yp = *reinterpret_cast<const float4 *>(x + cyp);
     const float4 zm = *reinterpret_cast<const float4 *>(x + czm);
     const float4 zp = *reinterpret_cast<const float4 *>(x + czp);
-    const uchar4 lab = *reinterpret_cast<const uchar4 *>(g.lab + c);
+    const uchar4 lab = streamLoad4(g.lab + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP != OP_APPLY) bc = *reinterpret_cast<const float4 *>(b + c);
 
@@ -201,8 +213,8 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     float4 xm = *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c));
     float4 xc = *reinterpret_cast<const float4 *>(x + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY) bc = *reinterpret_cast<const float4 *>(b + c);
-    uchar4 lc = *reinterpret_cast<const uchar4 *>(g.lab + c);
+    if (OP != OP_APPLY) bc = streamLoad4(b + c);
+    uchar4 lc = streamLoad4(g.lab + c);
     float4 hy = make_float4(0.f, 0.f, 0.f, 0.f);  // y-halo row this thread stages (top / bottom rows only)
     if (rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
     if (rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
@@ -225,8 +237,8 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         uchar4 ln = lc;
         float hxn = hx;
         if (k + 1 < k1) {
-            if (OP != OP_APPLY) bn = *reinterpret_cast<const float4 *>(b + cn);
-            ln = *reinterpret_cast<const uchar4 *>(g.lab + cn);
+            if (OP != OP_APPLY) bn = streamLoad4(b + cn);
+            ln = streamLoad4(g.lab + cn);
             if (rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
             if (rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
             if (colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
