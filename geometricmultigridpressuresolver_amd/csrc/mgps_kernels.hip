@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy) {
             c[zz][yy] = size_t(kv[zz] ? ks[zz] : 0) * sz + size_t(js[yy]) * sy + (size_t(m) << 2);
-            l[zz][yy] = *reinterpret_cast<const uchar4 *>(fg.lab + c[zz][yy]);
+            l[zz][yy] = streamLoad4(fg.lab + c[zz][yy]);
             any = any || (kv[zz] && anyActive(l[zz][yy]));
         }
     if (!any) return;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
             const uchar4 lab = l[zz][yy];
             const bool a0 = activeLabel(lab.x), a1 = activeLabel(lab.y), a2 = activeLabel(lab.z), a3 = activeLabel(lab.w);
             if (!kv[zz] || !anyActive(lab)) continue;
-            float4 f = *reinterpret_cast<const float4 *>(fine + c[zz][yy]);
+            float4 f = streamLoad4(fine + c[zz][yy]);  // read-modify-write of a cell nobody else touches in this launch
             float add[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
             if (a1) f.y += add[1];
             if (a2) f.z += add[2];
             if (a3) f.w += add[3];
-            *reinterpret_cast<float4 *>(fine + c[zz][yy]) = f;
+            __builtin_nontemporal_store(v4f{f.x, f.y, f.z, f.w}, reinterpret_cast<v4f *>(fine + c[zz][yy]));
         }
 }
 
