@@ -165,6 +165,10 @@ struct GridP {
     int nchunks, chunkCells;
     const int32_t *planeBlocks;
     int nplaneBlocks, planeZc;
+    // the level's grids do not fit the 256 MiB Infinity Cache: sweeps use nontemporal loads for what they read once
+    // (rhs, codes) and nontemporal stores for their output; smaller levels leave everything cacheable (the next
+    // kernel finds it there)
+    int streaming;
 };
 
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)

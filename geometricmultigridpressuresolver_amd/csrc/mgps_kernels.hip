@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const float4 yp = *reinterpret_cast<const float4 *>(x + cyp);
     const float4 zm = *reinterpret_cast<const float4 *>(x + czm);
     const float4 zp = *reinterpret_cast<const float4 *>(x + czp);
-    const uchar4 lab = streamLoad4(g.lab + c);
+    const uchar4 lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY) bc = *reinterpret_cast<const float4 *>(b + c);
+    if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
 
     // x neighbours across the quad boundary
     const int lane = threadIdx.x & (kWave - 1);
@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
         const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
         res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
     }
-    if (valid)  // streamed out: nothing re-reads the sweep's output before it has left the caches (+5 % at 1024^3)
-            __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
+    if (valid) {
+        if (g.streaming) __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
+        else *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy) {
             c[zz][yy] = size_t(kv[zz] ? ks[zz] : 0) * sz + size_t(js[yy]) * sy + (size_t(m) << 2);
-            l[zz][yy] = streamLoad4(fg.lab + c[zz][yy]);
+            l[zz][yy] = fg.streaming ? streamLoad4(fg.lab + c[zz][yy]) : *reinterpret_cast<const uchar4 *>(fg.lab + c[zz][yy]);
             any = any || (kv[zz] && anyActive(l[zz][yy]));
         }
     if (!any) return;
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
             const uchar4 lab = l[zz][yy];
             const bool a0 = activeLabel(lab.x), a1 = activeLabel(lab.y), a2 = activeLabel(lab.z), a3 = activeLabel(lab.w);
             if (!kv[zz] || !anyActive(lab)) continue;
-            float4 f = streamLoad4(fine + c[zz][yy]);  // read-modify-write of a cell nobody else touches in this launch
+            // read-modify-write of a cell nobody else touches in this launch
+            float4 f = fg.streaming ? streamLoad4(fine + c[zz][yy]) : *reinterpret_cast<const float4 *>(fine + c[zz][yy]);
             float add[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -868,7 +871,8 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
             if (a1) f.y += add[1];
             if (a2) f.z += add[2];
             if (a3) f.w += add[3];
-            __builtin_nontemporal_store(v4f{f.x, f.y, f.z, f.w}, reinterpret_cast<v4f *>(fine + c[zz][yy]));
+            if (fg.streaming) __builtin_nontemporal_store(v4f{f.x, f.y, f.z, f.w}, reinterpret_cast<v4f *>(fine + c[zz][yy]));
+            else *reinterpret_cast<float4 *>(fine + c[zz][yy]) = f;
         }
 }
 

@@ -671,7 +671,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 HL.chunkCells,
                 HL.planeZc ? L.planeBlocks : nullptr,
                 int(HL.planeBlocks.size()),
-                HL.planeZc};
+                HL.planeZc,
+                L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0};
     return MGPS_OK;
 }
 
