@@ -27,7 +27,7 @@ def scene_domain(gz, levels, eshape):
     from oracle.mg_oracle import FieldsOracle, Oracle
 
     shape = (gz, eshape[1] - 16, eshape[2] - 16)
-    sc = D.projection_scene(shape, seed=3, dtype=np.float64)
+    sc = D.projection_scene(shape, seed=int(os.environ.get("MGPS_SCENE_SEED", "3")), dtype=np.float64, randomize="MGPS_SCENE_SEED" in os.environ)
     fo = FieldsOracle()
     material = fo.material_labels(sc["liquid_phi"] - 0.2 * gz * sc["dx"], sc["solid_phi"], sc["cut_weights"])  # raise the fill level
     valid = fo.valid_faces(material, sc["cut_weights"])
