@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "mgps_internal.h"
 
@@ -230,6 +231,50 @@ int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned cha
     out->scatter = rcclScatter;
     out->destroy = rcclDestroy;
     return MGPS_OK;
+}
+
+int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats)
+{
+    // ncclSend + ncclRecv to this rank itself inside one group, the call shape of the ghost exchange: checks on
+    // any box (a single GPU is enough) that librccl's point-to-point path launches, completes in stream order and
+    // delivers the bytes.  Only valid for transports made by mgps_comm_create_rccl.
+    if (!comm || comm->exchange != rcclExchange || floats == 0) {
+        setLastGlobalError("mgps_comm_rccl_selftest: not an RCCL transport");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    auto *s = static_cast<RcclState *>(comm->user);
+    float *src = nullptr, *dst = nullptr;
+    std::vector<float> host(floats);
+    for (size_t i = 0; i < floats; ++i) host[i] = float(i % 977) + 0.5f;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&src), floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dst), floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(src, host.data(), floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dst, 0, floats * sizeof(float));
+    int rc = MGPS_OK;
+    if (e == hipSuccess) {
+        ncclResult_t r = gApi.GroupStart();
+        if (r == ncclSuccess) r = gApi.Send(src, floats * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+        if (r == ncclSuccess) r = gApi.Recv(dst, floats * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+        if (r == ncclSuccess) r = gApi.GroupEnd();
+        if (r != ncclSuccess) {
+            setLastGlobalError(std::string("mgps_comm_rccl_selftest: ") + gApi.GetErrorString(r));
+            rc = MGPS_ERR_COMM;
+        }
+        if (rc == MGPS_OK) e = hipStreamSynchronize(s->own);
+        std::vector<float> back(floats, -1.f);
+        if (rc == MGPS_OK && e == hipSuccess) e = hipMemcpy(back.data(), dst, floats * sizeof(float), hipMemcpyDeviceToHost);
+        if (rc == MGPS_OK && e == hipSuccess && back != host) {
+            setLastGlobalError("mgps_comm_rccl_selftest: received data differ from the data sent");
+            rc = MGPS_ERR_COMM;
+        }
+    }
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (e != hipSuccess) {
+        setLastGlobalError(std::string("mgps_comm_rccl_selftest: ") + hipGetErrorString(e));
+        return MGPS_ERR_HIP;
+    }
+    return rc;
 }
 
 void mgps_comm_destroy(mgps_comm *comm)

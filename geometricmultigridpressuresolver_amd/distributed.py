@@ -60,6 +60,11 @@ class RcclComm:
         self.struct = CommStruct()
         check(lib().mgps_comm_create_rccl(C.byref(self.struct), self.rank, self.size, ident, dev))
 
+    def selftest(self, floats=1 << 20):
+        """send + receive to this rank itself through librccl (mgps_comm_rccl_selftest)"""
+        lib().mgps_comm_rccl_selftest.argtypes = [C.c_void_p, C.c_size_t]
+        check(lib().mgps_comm_rccl_selftest(C.byref(self.struct), floats))
+
     def close(self):
         if self.struct is not None:
             lib().mgps_comm_destroy(C.byref(self.struct))

@@ -264,6 +264,10 @@ typedef struct mgps_comm {
  * mgps_comm_create_rccl, which runs ncclCommInitRank on `device`. */
 int mgps_rccl_unique_id(unsigned char out_id[128]);
 int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned char id[128], int device);
+/* diagnostic: one ncclSend + ncclRecv of `floats` floats from this rank to itself in a single group (the call
+ * shape of the ghost exchange) and a comparison of what arrived -- librccl's point-to-point path checked on any
+ * box, one GPU is enough */
+int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats);
 void mgps_comm_destroy(mgps_comm *comm);
 
 /* The slab form of the constructor.  labels_global_host: the WHOLE solver grid's labels

@@ -173,6 +173,8 @@ def rccl_single_rank_mode():
     torch.cuda.set_device(0)
     lab, w, off, lev, dx = make_domain("solid", 96, 5, (128, 128, 128))
     comm = RcclComm(device=0)
+    comm.selftest(1 << 20)  # ncclSend / ncclRecv to self: the point-to-point path of librccl on this box
+    comm.selftest(3)
     b_glob = D.random_rhs(lab, dx)
     for use_gs in (False, True):
         opt = G.default_options()
