@@ -277,6 +277,52 @@ int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats)
     return rc;
 }
 
+int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *us_per_exchange)
+{
+    // device time of `reps` back-to-back send-to-self + receive-from-self groups of `floats` floats: what one
+    // ghost exchange costs on this box before any link is involved (launch + RCCL's point-to-point kernel)
+    if (!comm || comm->exchange != rcclExchange || floats == 0 || reps < 1 || !us_per_exchange) {
+        setLastGlobalError("mgps_comm_rccl_selfbench: bad arguments");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    auto *s = static_cast<RcclState *>(comm->user);
+    float *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&src), floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dst), floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(src, 0, floats * sizeof(float));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    int rc = MGPS_OK;
+    for (int pass = 0; pass < 2 && e == hipSuccess && rc == MGPS_OK; ++pass) {  // pass 0 warms up
+        if (pass == 1) e = hipEventRecord(e0, s->own);
+        for (int q = 0; q < (pass ? reps : 3) && rc == MGPS_OK; ++q) {
+            ncclResult_t r = gApi.GroupStart();
+            if (r == ncclSuccess) r = gApi.Send(src, floats * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+            if (r == ncclSuccess) r = gApi.Recv(dst, floats * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+            if (r == ncclSuccess) r = gApi.GroupEnd();
+            if (r != ncclSuccess) {
+                setLastGlobalError(std::string("mgps_comm_rccl_selfbench: ") + gApi.GetErrorString(r));
+                rc = MGPS_ERR_COMM;
+            }
+        }
+        if (pass == 1 && e == hipSuccess) e = hipEventRecord(e1, s->own);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->own);
+    }
+    float ms = 0.f;
+    if (e == hipSuccess && rc == MGPS_OK) e = hipEventElapsedTime(&ms, e0, e1);
+    *us_per_exchange = double(ms) * 1e3 / reps;
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) {
+        setLastGlobalError(std::string("mgps_comm_rccl_selfbench: ") + hipGetErrorString(e));
+        return MGPS_ERR_HIP;
+    }
+    return rc;
+}
+
 void mgps_comm_destroy(mgps_comm *comm)
 {
     if (comm && comm->destroy) comm->destroy(comm->user);

@@ -65,6 +65,13 @@ class RcclComm:
         lib().mgps_comm_rccl_selftest.argtypes = [C.c_void_p, C.c_size_t]
         check(lib().mgps_comm_rccl_selftest(C.byref(self.struct), floats))
 
+    def selfbench(self, floats, reps=200):
+        """microseconds per self send + receive group (mgps_comm_rccl_selfbench)"""
+        us = C.c_double()
+        lib().mgps_comm_rccl_selfbench.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        check(lib().mgps_comm_rccl_selfbench(C.byref(self.struct), floats, reps, C.byref(us)))
+        return us.value
+
     def close(self):
         if self.struct is not None:
             lib().mgps_comm_destroy(C.byref(self.struct))

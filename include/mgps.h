@@ -268,6 +268,9 @@ int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned cha
  * shape of the ghost exchange) and a comparison of what arrived -- librccl's point-to-point path checked on any
  * box, one GPU is enough */
 int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats);
+/* diagnostic: device time (microseconds per group, HIP events) of `reps` back-to-back self send + receive
+ * groups of `floats` floats -- the floor of one ghost exchange on this box */
+int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *us_per_exchange);
 void mgps_comm_destroy(mgps_comm *comm);
 
 /* The slab form of the constructor.  labels_global_host: the WHOLE solver grid's labels
