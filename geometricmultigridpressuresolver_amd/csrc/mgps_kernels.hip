@@ -725,6 +725,45 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float
     coarse[c] = acc;
 }
 
+// The same operator marching along z: one thread owns a coarse (I, J) column of kc coarse planes and keeps the
+// in-plane 4 x 4 weighted sums of the last fine planes in registers -- every fine plane's sum is formed once and
+// feeds the two coarse planes it belongs to, where the per-cell kernel above forms it twice (and its z-overlap
+// reads miss the L2 on large planes: 1.6x the algorithmic HBM traffic).  x, then y, then z summation.
+__global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine,
+                                                           int kc, unsigned nbx, unsigned nby)
+{
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int I = int(bx) * 64 + int(threadIdx.x & 63), J = int(by) * 4 + int(threadIdx.x >> 6);
+    const int K0 = int(bz) * kc, K1 = min(K0 + kc, cg.nz);
+    if (I >= cg.nx || J >= cg.ny) return;
+    const size_t cplane = size_t(cg.nx) * cg.ny, col = size_t(J) * cg.nx + I;
+    bool any = false;
+    for (int K = K0; K < K1; ++K) any = any || activeLabel(cg.lab[size_t(K) * cplane + col]);
+    if (!any) return;  // (all columns of the EXTERIOR shell leave here: the loads below stay inside the grid)
+    const int fnx = 2 * cg.nx, fny = 2 * cg.ny;
+    const int kLo = cg.ghostLo ? -1 : 0, kHi = cg.ghostHi ? 2 * cg.nz : 2 * cg.nz - 1;
+    const float w[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    auto planeSum = [&](int fk) {  // planes outside the grid only feed EXTERIOR coarse cells: clamp
+        const float *p = fine + (ptrdiff_t(min(max(fk, kLo), kHi)) * fny + (2 * J - 1)) * fnx + (2 * I - 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int yo = 0; yo < 4; ++yo) {
+            const float *r = p + ptrdiff_t(yo) * fnx;
+            sum += w[yo] * (w[0] * r[0] + w[1] * r[1] + w[2] * r[2] + w[3] * r[3]);
+        }
+        return sum;
+    };
+    float p0 = planeSum(2 * K0 - 1), p1 = planeSum(2 * K0);
+    for (int K = K0; K < K1; ++K) {
+        const float p2 = planeSum(2 * K + 1), p3 = planeSum(2 * K + 2);
+        const size_t c = size_t(K) * cplane + col;
+        coarse[c] = activeLabel(cg.lab[c]) ? w[0] * p0 + w[1] * p1 + w[2] * p2 + w[3] * p3 : 0.f;
+        p0 = p2;
+        p1 = p3;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Prolongation + add (Ops.h:873-972): fine c += 4 * trilerp(coarse) at sample point c/2 - 1/4:
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
@@ -1240,6 +1279,16 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine)
 {
     const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
+    static const bool perCell = [] {  // MGPS_RESTRICT=cell: A/B switch for tuning runs
+        const char *e = getenv("MGPS_RESTRICT");
+        return e && e[0] == 'c';
+    }();
+    if (!perCell && coarse.nx >= 64 && coarse.nz >= 16) {
+        const int kc = 16;
+        const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 3) / 4, nbz = (coarse.nz + kc - 1) / kc;
+        restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
+        return int(hipGetLastError());
+    }
     const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * unsigned(coarse.chunkCells / 256) : blocksFor(n, 256);
     if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
     return int(hipGetLastError());
