@@ -732,33 +732,44 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float
 __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine,
                                                            int kc, unsigned nbx, unsigned nby)
 {
+    // a thread owns the coarse columns (I, J) and (I, J + 1), J even: their fine footprints share two of six rows
     const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
-    const int I = int(bx) * 64 + int(threadIdx.x & 63), J = int(by) * 4 + int(threadIdx.x >> 6);
+    const int I = int(bx) * 64 + int(threadIdx.x & 63), J = 2 * (int(by) * 4 + int(threadIdx.x >> 6));
     const int K0 = int(bz) * kc, K1 = min(K0 + kc, cg.nz);
     if (I >= cg.nx || J >= cg.ny) return;
+    const bool second = J + 1 < cg.ny;
     const size_t cplane = size_t(cg.nx) * cg.ny, col = size_t(J) * cg.nx + I;
     bool any = false;
-    for (int K = K0; K < K1; ++K) any = any || activeLabel(cg.lab[size_t(K) * cplane + col]);
-    if (!any) return;  // (all columns of the EXTERIOR shell leave here: the loads below stay inside the grid)
+    for (int K = K0; K < K1; ++K) {
+        any = any || activeLabel(cg.lab[size_t(K) * cplane + col]);
+        if (second) any = any || activeLabel(cg.lab[size_t(K) * cplane + col + cg.nx]);
+    }
+    if (!any) return;  // (columns made of EXTERIOR shell cells only leave here)
     const int fnx = 2 * cg.nx, fny = 2 * cg.ny;
     const int kLo = cg.ghostLo ? -1 : 0, kHi = cg.ghostHi ? 2 * cg.nz : 2 * cg.nz - 1;
     const float w[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-    auto planeSum = [&](int fk) {  // planes outside the grid only feed EXTERIOR coarse cells: clamp
-        const float *p = fine + (ptrdiff_t(min(max(fk, kLo), kHi)) * fny + (2 * J - 1)) * fnx + (2 * I - 1);
-        float sum = 0.f;
-#pragma unroll
-        for (int yo = 0; yo < 4; ++yo) {
-            const float *r = p + ptrdiff_t(yo) * fnx;
-            sum += w[yo] * (w[0] * r[0] + w[1] * r[1] + w[2] * r[2] + w[3] * r[3]);
-        }
-        return sum;
+    // rows / planes / the column left of the grid only feed EXTERIOR coarse cells: clamp, their results are masked
+    const int xBase = max(2 * I - 1, 0);
+    struct Pair {
+        float a, b;
     };
-    float p0 = planeSum(2 * K0 - 1), p1 = planeSum(2 * K0);
+    auto planeSums = [&](int fk) {
+        const float *p = fine + ptrdiff_t(min(max(fk, kLo), kHi)) * fny * fnx + xBase;
+        float rs[6];
+#pragma unroll
+        for (int yo = 0; yo < 6; ++yo) {
+            const float *r = p + ptrdiff_t(min(max(2 * J - 1 + yo, 0), fny - 1)) * fnx;
+            rs[yo] = w[0] * r[0] + w[1] * r[1] + w[2] * r[2] + w[3] * r[3];
+        }
+        return Pair{w[0] * rs[0] + w[1] * rs[1] + w[2] * rs[2] + w[3] * rs[3], w[0] * rs[2] + w[1] * rs[3] + w[2] * rs[4] + w[3] * rs[5]};
+    };
+    Pair p0 = planeSums(2 * K0 - 1), p1 = planeSums(2 * K0);
     for (int K = K0; K < K1; ++K) {
-        const float p2 = planeSum(2 * K + 1), p3 = planeSum(2 * K + 2);
+        const Pair p2 = planeSums(2 * K + 1), p3 = planeSums(2 * K + 2);
         const size_t c = size_t(K) * cplane + col;
-        coarse[c] = activeLabel(cg.lab[c]) ? w[0] * p0 + w[1] * p1 + w[2] * p2 + w[3] * p3 : 0.f;
+        coarse[c] = activeLabel(cg.lab[c]) ? w[0] * p0.a + w[1] * p1.a + w[2] * p2.a + w[3] * p3.a : 0.f;
+        if (second) coarse[c + cg.nx] = activeLabel(cg.lab[c + cg.nx]) ? w[0] * p0.b + w[1] * p1.b + w[2] * p2.b + w[3] * p3.b : 0.f;
         p0 = p2;
         p1 = p3;
     }
@@ -1285,7 +1296,7 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     }();
     if (!perCell && coarse.nx >= 64 && coarse.nz >= 16) {
         const int kc = 16;
-        const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 3) / 4, nbz = (coarse.nz + kc - 1) / kc;
+        const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8, nbz = (coarse.nz + kc - 1) / kc;
         restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         return int(hipGetLastError());
     }
