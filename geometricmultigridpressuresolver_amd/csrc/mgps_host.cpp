@@ -178,46 +178,71 @@ static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
 static void buildBand(HostLevel &L, int width)
 {
     const Dims d = L.d;
-    const uint8_t *lab = L.labels.data();
+    uint8_t *lab = L.labels.data();
     const size_t n = d.cells();
-    std::vector<uint8_t> mark(n, 0);  // 0 unvisited, 1 in band
+    constexpr uint8_t kMark = 0x80;  // rings are marked in the labels themselves (INTERIOR | kMark) and unmarked at the end
     std::vector<size_t> frontier, next;
-    parallelCollect<size_t>(int64_t(n), 1 << 20, frontier, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
-        for (int64_t c = b; c < e; ++c)
-            if (lab[c] == MGPS_BOUNDARY_CELL) {
-                out.push_back(size_t(c));
-                mark[size_t(c)] = 1;
-            }
+    parallelCollect<size_t>(int64_t(n / 8), 1 << 17, frontier, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
+        // eight labels at a time: most words hold no BOUNDARY cell at all
+        constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
+        for (int64_t w = b; w < e; ++w) {
+            uint64_t v;
+            std::memcpy(&v, lab + 8 * size_t(w), 8);
+            v ^= k01 * uint64_t(MGPS_BOUNDARY_CELL);
+            if (((v - k01) & ~v & k80) == 0) continue;
+            for (size_t c = 8 * size_t(w); c < 8 * size_t(w) + 8; ++c)
+                if (lab[c] == MGPS_BOUNDARY_CELL) out.push_back(c);
+        }
     });
+    for (size_t c = n / 8 * 8; c < n; ++c)
+        if (lab[c] == MGPS_BOUNDARY_CELL) frontier.push_back(c);
+    std::vector<size_t> cells = frontier;  // every band cell, ring by ring
     const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
-    for (int ring = 1; ring < width; ++ring) {  // the order inside a ring is irrelevant: the list is re-read from `mark`
-        uint8_t *mk = mark.data();
+    for (int ring = 1; ring < width; ++ring) {  // the order inside a ring is irrelevant: the list is sorted below
         parallelCollect<size_t>(int64_t(frontier.size()), 1 << 14, next, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
             for (int64_t q = b; q < e; ++q) {
                 const size_t c = frontier[size_t(q)];
                 for (int a = 0; a < 3; ++a)
                     for (int sgn = -1; sgn <= 1; sgn += 2) {
                         const size_t nb = c + sgn * stride[a];
-                        if (lab[nb] == MGPS_INTERIOR_CELL && __atomic_exchange_n(&mk[nb], uint8_t(1), __ATOMIC_RELAXED) == 0)
+                        if (__atomic_load_n(&lab[nb], __ATOMIC_RELAXED) == MGPS_INTERIOR_CELL &&
+                            __atomic_fetch_or(&lab[nb], kMark, __ATOMIC_RELAXED) == MGPS_INTERIOR_CELL)
                             out.push_back(nb);
                     }
             }
         });
+        cells.insert(cells.end(), next.begin(), next.end());
         frontier.swap(next);
     }
-    // emit in (tile, k, j, i) order: walk tiles in linear tile order, cells x-fastest inside
+    // (tile, k, j, i) order: counting sort by tile, then by cell index inside each tile (same tile: k, j, i order)
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    parallelCollect<int32_t>(int64_t(tx) * ty * tz, 256, L.band, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
-        for (int64_t t = b; t < e; ++t) {
-            const int ti = int(t % tx), tj = int((t / tx) % ty), tk = int(t / (int64_t(tx) * ty));
-            for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
-                for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j) {
-                    const uint8_t *row = mark.data() + d.idx(0, j, k);
-                    for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i)
-                        if (row[i]) out.push_back(int32_t(d.idx(i, j, k)));
-                }
+    const size_t ntiles = size_t(tx) * ty * tz, m = cells.size();
+    std::vector<int32_t> tileOf(m);
+    std::vector<int32_t> start(ntiles + 1, 0);
+    parallelFor(int64_t(m), [&](int64_t b, int64_t e) {
+        for (int64_t q = b; q < e; ++q) {
+            const size_t c = cells[size_t(q)];
+            if (lab[c] != MGPS_BOUNDARY_CELL) lab[c] = MGPS_INTERIOR_CELL;  // unmark
+            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+            const int32_t t = int32_t((size_t(k / kTile) * ty + j / kTile) * tx + i / kTile);
+            tileOf[size_t(q)] = t;
+            __atomic_fetch_add(&start[size_t(t) + 1], 1, __ATOMIC_RELAXED);
         }
-    });
+    }, 1 << 15);
+    for (size_t t = 0; t < ntiles; ++t) start[t + 1] += start[t];
+    L.band.resize(m);
+    {
+        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        int32_t *out = L.band.data();
+        parallelFor(int64_t(m), [&](int64_t b, int64_t e) {
+            for (int64_t q = b; q < e; ++q)
+                out[__atomic_fetch_add(&fill[size_t(tileOf[size_t(q)])], 1, __ATOMIC_RELAXED)] = int32_t(cells[size_t(q)]);
+        }, 1 << 15);
+        parallelFor(int64_t(ntiles), [&](int64_t b, int64_t e) {
+            for (int64_t t = b; t < e; ++t)
+                if (start[size_t(t) + 1] - start[size_t(t)] > 1) std::sort(out + start[size_t(t)], out + start[size_t(t) + 1]);
+        }, 64);
+    }
 }
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
@@ -242,26 +267,12 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     L.d = d;
     const size_t plane = size_t(gd.nx) * gd.ny;
     const uint8_t *glab = G.labels.data();
-    const size_t ownedBytes = size_t(d.nz) * plane;
-    L.labels.resize(ownedBytes);
-    L.codes.resize((size_t(d.nz) + 2) * plane);  // ghost plane | owned planes | ghost plane
-    std::memset(L.codes.data(), MGPS_EXTERIOR_CELL, plane);
-    std::memset(L.codes.data() + (size_t(d.nz) + 1) * plane, MGPS_EXTERIOR_CELL, plane);
-    {
-        uint8_t *dl = L.labels.data(), *dc = L.codes.data() + plane;
-        const uint8_t *src = glab + size_t(z0) * plane;
-        parallelFor(int64_t(ownedBytes), [=](int64_t b, int64_t e) {
-            std::memcpy(dl + b, src + b, size_t(e - b));
-            std::memcpy(dc + b, src + b, size_t(e - b));
-        }, 1 << 22);
-    }
+    L.ownedLabels = glab + size_t(z0) * plane;
+    L.ghostLoLabels = z0 > 0 ? glab + size_t(z0 - 1) * plane : nullptr;
+    L.ghostHiLabels = z1 < gd.nz ? glab + size_t(z1) * plane : nullptr;
     const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    if (z0 > 0) std::memcpy(L.codes.data(), glab + size_t(z0 - 1) * plane, plane);
-    if (z1 < gd.nz) std::memcpy(L.codes.data() + (size_t(d.nz) + 1) * plane, glab + size_t(z1) * plane, plane);
-    uint8_t *codes = L.codes.data() + plane;  // owned plane 0
 
-    lap.lap("slab level: labels + codes copy");
     struct Row {
         float w[6], diag;
         bool simple;
@@ -298,39 +309,99 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         }
         return r;
     };
-    // band of the slab in reference order, then split: general BOUNDARY cells first, the rest after
-    std::vector<int32_t> general, rest;
-    std::vector<uint8_t> restDiag;
-    std::vector<Row> generalRows;
+    // band of the slab in reference order, then split: general BOUNDARY cells first, the rest after.  Ranges of the
+    // global band list are classified by the host threads and stitched together in order.
     const size_t lo = size_t(z0) * plane, hi = size_t(z1) * plane;
-    size_t nextRowIn = 0;
-    for (int32_t gcI : G.band) {
-        const size_t gc = size_t(gcI);
-        if (gc < lo || gc >= hi) continue;
-        const int32_t c = int32_t(gc - lo);
-        L.band.push_back(c);
-        if (glab[gc] == MGPS_BOUNDARY_CELL) {
-            Row r;
-            if (rowsIn) {
-                const float *q = rowsIn + 8 * nextRowIn++;
-                for (int a = 0; a < 6; ++a) r.w[a] = q[a];
-                r.diag = q[6];
-                r.simple = q[7] != 0.f;
-            } else
-                r = rowOf(gc);
-            if (r.simple) {
-                codes[c] = uint8_t(kCodeSimple + int(r.diag));
-                rest.push_back(c);
-                restDiag.push_back(uint8_t(int(r.diag)));
-            } else {
-                general.push_back(c);
-                generalRows.push_back(r);
+    struct Part {
+        std::vector<int32_t> band, general, rest;
+        std::vector<uint8_t> restDiag, isGeneral;  // isGeneral: per entry of `band`
+        std::vector<Row> generalRows;
+        size_t boundaryBefore = 0;  // BOUNDARY cells of the slab in earlier ranges (index into rowsIn)
+    };
+    const int64_t nbandG = int64_t(G.band.size());
+    const int nt = int(std::max<int64_t>(1, std::min<int64_t>(hostThreads(), nbandG / (1 << 15))));
+    std::vector<Part> parts{size_t(nt)};
+    const int64_t per = (nbandG + nt - 1) / nt;
+    if (rowsIn) {  // the rows arrive in band order: every range needs the count of BOUNDARY cells before it
+        parallelFor(nt, [&](int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                size_t count = 0;
+                for (int64_t q = t * per; q < std::min(nbandG, (t + 1) * per); ++q) {
+                    const size_t gc = size_t(G.band[size_t(q)]);
+                    count += gc >= lo && gc < hi && glab[gc] == MGPS_BOUNDARY_CELL;
+                }
+                parts[size_t(t)].boundaryBefore = count;
             }
-        } else {
-            rest.push_back(c);
-            restDiag.push_back(6);
+        });
+        size_t run = 0;
+        for (auto &p : parts) {
+            const size_t mine = p.boundaryBefore;
+            p.boundaryBefore = run;
+            run += mine;
         }
     }
+    parallelFor(nt, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            Part &P = parts[size_t(t)];
+            size_t nextRowIn = P.boundaryBefore;
+            for (int64_t q = t * per; q < std::min(nbandG, (t + 1) * per); ++q) {
+                const size_t gc = size_t(G.band[size_t(q)]);
+                if (gc < lo || gc >= hi) continue;
+                const int32_t c = int32_t(gc - lo);
+                P.band.push_back(c);
+                bool general = false;
+                if (glab[gc] == MGPS_BOUNDARY_CELL) {
+                    Row r;
+                    if (rowsIn) {
+                        const float *src = rowsIn + 8 * nextRowIn++;
+                        for (int a = 0; a < 6; ++a) r.w[a] = src[a];
+                        r.diag = src[6];
+                        r.simple = src[7] != 0.f;
+                    } else
+                        r = rowOf(gc);
+                    if (r.simple) {
+                        P.rest.push_back(c);
+                        P.restDiag.push_back(uint8_t(int(r.diag)));
+                    } else {
+                        general = true;
+                        P.general.push_back(c);
+                        P.generalRows.push_back(r);
+                    }
+                } else {
+                    P.rest.push_back(c);
+                    P.restDiag.push_back(6);
+                }
+                P.isGeneral.push_back(uint8_t(general));
+            }
+        }
+    });
+    size_t nGeneral = 0, nRest = 0;
+    for (auto &P : parts) {
+        nGeneral += P.general.size();
+        nRest += P.rest.size();
+    }
+    L.numBoundary = int32_t(nGeneral);
+    L.band.reserve(nGeneral + nRest);
+    L.bandEntry.reserve(nGeneral + nRest);
+    L.bandDev.resize(nGeneral + nRest);
+    L.bandDiag.assign(nGeneral + nRest, 0);
+    std::vector<Row> generalRows;
+    generalRows.reserve(nGeneral);
+    {
+        size_t g = 0, r = nGeneral;
+        for (auto &P : parts) {
+            L.band.insert(L.band.end(), P.band.begin(), P.band.end());
+            size_t gi = g, ri = r;
+            for (uint8_t isG : P.isGeneral) L.bandEntry.push_back(int32_t(isG ? gi++ : ri++));
+            std::copy(P.general.begin(), P.general.end(), L.bandDev.begin() + ptrdiff_t(g));
+            std::copy(P.rest.begin(), P.rest.end(), L.bandDev.begin() + ptrdiff_t(r));
+            std::copy(P.restDiag.begin(), P.restDiag.end(), L.bandDiag.begin() + ptrdiff_t(r));
+            generalRows.insert(generalRows.end(), P.generalRows.begin(), P.generalRows.end());
+            g += P.general.size();
+            r += P.rest.size();
+        }
+    }
+    parts.clear();
     lap.lap("slab level: band split + rows");
     // band cells of the planes a band-only ghost exchange moves (see HostLevel::bandPlane)
     {
@@ -346,24 +417,39 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         }
     }
     lap.lap("slab level: band planes");
+    const uint8_t *labels = L.ownedLabels;
     {  // activity lists
         const size_t n = d.cells();
-        auto listOf = [&](int cells) {
-            std::vector<int32_t> list;
-            const int64_t nchunks = int64_t((n + size_t(cells) - 1) / size_t(cells));
-            parallelCollect<int32_t>(nchunks, 4096, list, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
-                for (int64_t q = b; q < e; ++q) {
-                    const size_t c0 = size_t(q) * size_t(cells);
-                    bool act = false;
-                    for (size_t c = c0; c < std::min(n, c0 + size_t(cells)) && !act; ++c) act = isActive(L.labels[c]);
-                    if (act) out.push_back(int32_t(q));
+        // flags of the 256-cell chunks (eight labels per test: a byte is active iff it is 0 or 3)
+        const int64_t nfine = int64_t((n + kWaveChunkCells - 1) / kWaveChunkCells);
+        std::vector<uint8_t> fineAct(size_t(nfine), 0);
+        parallelFor(nfine, [&](int64_t b, int64_t e) {
+            constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
+            for (int64_t q = b; q < e; ++q) {
+                const size_t c0 = size_t(q) * kWaveChunkCells, c1 = std::min(n, c0 + kWaveChunkCells);
+                bool act = false;
+                size_t c = c0;
+                for (; c + 8 <= c1 && !act; c += 8) {
+                    uint64_t v;
+                    std::memcpy(&v, labels + c, 8);
+                    const uint64_t u = v ^ (k01 * uint64_t(MGPS_BOUNDARY_CELL));
+                    act = (((v - k01) & ~v & k80) | ((u - k01) & ~u & k80)) != 0;
                 }
-            });
-            return list;
-        };
-        L.chunks = listOf(kChunkCells);
+                for (; c < c1 && !act; ++c) act = isActive(labels[c]);
+                fineAct[size_t(q)] = act;
+            }
+        }, 1 << 12);
+        std::vector<int32_t> fine, coarse;
+        for (int64_t q = 0; q < nfine; ++q)
+            if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
+        constexpr int kRatio = kChunkCells / kWaveChunkCells;
+        for (int64_t q = 0; q < nfine; q += kRatio) {
+            bool act = false;
+            for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
+            if (act) coarse.push_back(int32_t(q / kRatio));
+        }
+        L.chunks.swap(coarse);
         L.chunkCells = kChunkCells;
-        std::vector<int32_t> fine = listOf(kWaveChunkCells);
         if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
             L.chunks.swap(fine);
             L.chunkCells = kWaveChunkCells;
@@ -380,7 +466,15 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
                 const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
                 return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
             };
-            std::stable_sort(L.chunks.begin(), L.chunks.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+            // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
+            const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
+            std::vector<std::vector<int32_t>> strips(nstrips);
+            for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
+            size_t at = 0;
+            for (auto &sv : strips) {
+                std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
+                at += sv.size();
+            }
         }
         if (L.chunkCells == kWaveChunkCells)
             while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
@@ -389,29 +483,27 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         if (L.planeZc) {
             const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows, nbz = (d.nz + L.planeZc - 1) / L.planeZc;
             std::vector<uint8_t> act(size_t(nbx) * nby * nbz, 0);
-            for (int k = 0; k < d.nz; ++k)
-                for (int j = 0; j < d.ny; ++j) {
-                    const uint8_t *row = L.labels.data() + d.idx(0, j, k);
-                    for (int bx = 0; bx < nbx; ++bx) {
-                        uint8_t &a = act[(size_t(k / L.planeZc) * nby + j / kPlaneRows) * nbx + bx];
-                        if (a) continue;
-                        for (int i = bx * 256; i < std::min(d.nx, bx * 256 + 256); ++i)
-                            if (isActive(row[i])) {
-                                a = 1;
-                                break;
-                            }
+            const int zc = L.planeZc;
+            parallelFor(nbz, [&](int64_t b0, int64_t b1) {
+                for (int k = int(b0) * zc; k < std::min(d.nz, int(b1) * zc); ++k)
+                    for (int j = 0; j < d.ny; ++j) {
+                        const uint8_t *row = labels + d.idx(0, j, k);
+                        for (int bx = 0; bx < nbx; ++bx) {
+                            uint8_t &a = act[(size_t(k / zc) * nby + j / kPlaneRows) * nbx + bx];
+                            if (a) continue;
+                            for (int i = bx * 256; i < std::min(d.nx, bx * 256 + 256); ++i)
+                                if (isActive(row[i])) {
+                                    a = 1;
+                                    break;
+                                }
+                        }
                     }
-                }
+            });
             for (size_t q = 0; q < act.size(); ++q)
                 if (act[q]) L.planeBlocks.push_back(int32_t(q));
         }
     }
     lap.lap("slab level: activity lists");
-    L.numBoundary = int32_t(general.size());
-    L.bandDev = general;
-    L.bandDev.insert(L.bandDev.end(), rest.begin(), rest.end());
-    L.bandDiag.assign(size_t(L.numBoundary), 0);
-    L.bandDiag.insert(L.bandDiag.end(), restDiag.begin(), restDiag.end());
     buildTileLists(L, z0 / kTile);
     buildTileBoundaryOffsets(L);
     lap.lap("slab level: tile lists");
@@ -445,6 +537,21 @@ struct BandWindow {
         int32_t *p = entryOf.get();
         parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); }, 1 << 20);
     }
+    // whole-grid windows skip the dense map: the reference band order is (tile, k, j, i), so a cell is found by a
+    // binary search among the band cells of its 16^3 tile
+    const int32_t *sortedBand = nullptr;  // band cells in reference order
+    std::vector<int32_t> tileStart;       // per tile (+1): first index of its cells in sortedBand
+    std::vector<int32_t> entryOfSorted;   // per index of sortedBand: the output entry
+    int tilesX = 0, tilesY = 0;
+    int32_t entryAt(size_t wc) const
+    {
+        if (entryOf) return entryOf[wc];
+        const int i = int(wc % wd.nx), j = int((wc / wd.nx) % wd.ny), k = int(wc / (size_t(wd.nx) * wd.ny));
+        const size_t tile = (size_t(k / kTile) * tilesY + j / kTile) * tilesX + i / kTile;
+        const int32_t *lo = sortedBand + tileStart[tile], *hi = sortedBand + tileStart[tile + 1];
+        const int32_t *it = std::lower_bound(lo, hi, int32_t(wc));  // same tile: reference order == cell order
+        return (it != hi && *it == int32_t(wc)) ? entryOfSorted[size_t(it - sortedBand)] : kNoBand;
+    }
     std::vector<int32_t> seedCell;       // per output entry: its window cell
     std::vector<uint8_t> entryDiag;      // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
     // device address of a window cell: grid offset from owned cell 0 for the planes that live in the grid
@@ -459,7 +566,8 @@ struct BandWindow {
     int32_t foreignBase = 0;  // band entry that addresses foreign row 0 in the kernel
     static constexpr int32_t kNoBand = -1, kDeepBand = -2;  // kDeepBand: a band cell that is nobody's output here
 
-    bool active(size_t wc) const { return labels[wc] == MGPS_INTERIOR_CELL || labels[wc] >= kCodeGeneral; }
+    size_t cellLimit = SIZE_MAX;         // whole-grid windows: cells past the array (a level without EXTERIOR shell) are inactive
+    bool active(size_t wc) const { return wc < cellLimit && (labels[wc] == MGPS_INTERIOR_CELL || labels[wc] >= kCodeGeneral); }
     int diagFromLabels(size_t wc) const  // simple cell: number of non-EXTERIOR face neighbours
     {
         const ptrdiff_t sy = wd.nx, sz = ptrdiff_t(wd.nx) * wd.ny, off[6] = {-1, 1, -sy, sy, -sz, sz};
@@ -531,7 +639,7 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
                 }
                 int32_t &v = slot(cq);
                 if (v == kUnset) {
-                    const int32_t e = W.entryOf[size_t(cq)];
+                    const int32_t e = W.entryAt(size_t(cq));
                     if (e != BandWindow::kNoBand && dist + 1 < depth) {
                         v = int32_t(updateW.size());
                         updateW.push_back(cq);
@@ -581,16 +689,21 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
     HostLap lap;
     // initial partition: the output entries of each 16^3 tile of the window
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
-    for (size_t t = 0; t < nent; ++t) {
-        const size_t c = size_t(W.seedCell[t]);
-        const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
-        buckets[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile].push_back(int32_t(t));
-    }
     std::vector<std::vector<int32_t>> work;
-    for (auto &b : buckets)
-        if (!b.empty()) work.push_back(std::move(b));
-    buckets.clear();
+    if (W.sortedBand) {  // the reference order already groups the cells by tile
+        for (size_t t = 0; t + 1 < W.tileStart.size(); ++t)
+            if (W.tileStart[t + 1] > W.tileStart[t])
+                work.emplace_back(W.entryOfSorted.begin() + W.tileStart[t], W.entryOfSorted.begin() + W.tileStart[t + 1]);
+    } else {
+        std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
+        for (size_t t = 0; t < nent; ++t) {
+            const size_t c = size_t(W.seedCell[t]);
+            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+            buckets[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile].push_back(int32_t(t));
+        }
+        for (auto &b : buckets)
+            if (!b.empty()) work.push_back(std::move(b));
+    }
     lap.lap("band groups: buckets");
     std::vector<std::vector<GroupBuild>> built(work.size());
     std::atomic<int64_t> next{0};
@@ -693,15 +806,23 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     HostLap lap0;
     BandWindow W;
     W.wd = L.d;
-    W.labels = L.codes.data() + size_t(L.d.nx) * L.d.ny;  // owned plane 0 (a whole-grid level: ghost planes are EXTERIOR)
-    W.allocEntryOf();
+    W.labels = L.ownedLabels;  // a whole-grid level
+    W.cellLimit = L.d.cells();
     W.seedCell.assign(L.bandDev.begin(), L.bandDev.end());
     {
-        int32_t *eo = W.entryOf.get();
-        const int32_t *bd = L.bandDev.data();
-        parallelFor(int64_t(nband), [=](int64_t b, int64_t e) {
-            for (int64_t t = b; t < e; ++t) eo[size_t(bd[t])] = int32_t(t);
-        }, 1 << 16);
+        const Dims d = L.d;
+        W.tilesX = (d.nx + kTile - 1) / kTile;
+        W.tilesY = (d.ny + kTile - 1) / kTile;
+        const size_t ntiles = size_t(W.tilesX) * W.tilesY * size_t((d.nz + kTile - 1) / kTile);
+        W.sortedBand = L.band.data();
+        W.entryOfSorted = L.bandEntry;
+        W.tileStart.assign(ntiles + 1, 0);
+        for (size_t q = 0; q < nband; ++q) {
+            const size_t c = size_t(L.band[q]);
+            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+            ++W.tileStart[(size_t(k / kTile) * W.tilesY + j / kTile) * W.tilesX + i / kTile + 1];
+        }
+        for (size_t t = 0; t < ntiles; ++t) W.tileStart[t + 1] += W.tileStart[t];
     }
     W.entryDiag = L.bandDiag;
     W.gridPlaneLo = 0;
@@ -868,7 +989,7 @@ static void buildTileLists(HostLevel &L, int tileZOffset)
             int64_t active = 0, interior = 0;
             for (int k = tk * kTile; k < std::min(d.nz, (tk + 1) * kTile); ++k)
                 for (int j = tj * kTile; j < std::min(d.ny, (tj + 1) * kTile); ++j) {
-                    const uint8_t *row = L.labels.data() + d.idx(0, j, k);
+                    const uint8_t *row = L.ownedLabels + d.idx(0, j, k);
                     for (int i = ti * kTile; i < std::min(d.nx, (ti + 1) * kTile); ++i) {
                         active += isActive(row[i]);
                         interior += (row[i] == MGPS_INTERIOR_CELL);
@@ -998,19 +1119,45 @@ void mgps_hierarchy::bandedSolve(double *v) const
 void mgps_hierarchy::buildDenseInverse()
 {
     if (!coarseInverse.empty() || coarseN == 0) return;
-    const int n = coarseN;
+    const int n = coarseN, bw = coarseBW, W = bw + 1;
     coarseInverse.assign(size_t(n) * n, 0.f);
-    std::atomic<int> nextCol{0};
-    const int nt = std::min(hostThreads(), std::max(1, n / 64));
+    // kCols unit vectors per sweep over the factor: the factor (n x W doubles, megabytes) is streamed once per
+    // block instead of once per column, and the inner loops vectorise over the block
+    constexpr int kCols = 8;
+    const int nblocks = (n + kCols - 1) / kCols;
+    std::atomic<int> nextBlock{0};
+    const int nt = std::min(hostThreads(), std::max(1, nblocks / 4));
+    const double *Lm = coarseL.data();
     auto work = [&] {
-        std::vector<double> v(n);
+        std::vector<double> v(size_t(n) * kCols);
         for (;;) {
-            const int col = nextCol.fetch_add(1);
-            if (col >= n) break;
+            const int blk = nextBlock.fetch_add(1);
+            if (blk >= nblocks) break;
+            const int col0 = blk * kCols, ncol = std::min(kCols, n - col0);
             std::fill(v.begin(), v.end(), 0.0);
-            v[col] = 1.0;
-            bandedSolve(v.data());
-            for (int r = 0; r < n; ++r) coarseInverse[size_t(r) * n + col] = float(v[r]);
+            for (int q = 0; q < ncol; ++q) v[size_t(col0 + q) * kCols + q] = 1.0;
+            for (int r = col0; r < n; ++r) {  // rows above col0 stay 0 in the forward sweep
+                double sum[kCols];
+                for (int q = 0; q < kCols; ++q) sum[q] = v[size_t(r) * kCols + q];
+                for (int c = std::max(col0, r - bw); c < r; ++c) {
+                    const double l = Lm[size_t(r) * W + (bw - (r - c))];
+                    for (int q = 0; q < kCols; ++q) sum[q] -= l * v[size_t(c) * kCols + q];
+                }
+                const double inv = Lm[size_t(r) * W + bw];
+                for (int q = 0; q < kCols; ++q) v[size_t(r) * kCols + q] = sum[q] / inv;
+            }
+            for (int r = n - 1; r >= 0; --r) {
+                double sum[kCols];
+                for (int q = 0; q < kCols; ++q) sum[q] = v[size_t(r) * kCols + q];
+                for (int c = r + 1; c <= std::min(n - 1, r + bw); ++c) {
+                    const double l = Lm[size_t(c) * W + (bw - (c - r))];
+                    for (int q = 0; q < kCols; ++q) sum[q] -= l * v[size_t(c) * kCols + q];
+                }
+                const double inv = Lm[size_t(r) * W + bw];
+                for (int q = 0; q < kCols; ++q) v[size_t(r) * kCols + q] = sum[q] / inv;
+            }
+            for (int r = 0; r < n; ++r)
+                for (int q = 0; q < ncol; ++q) coarseInverse[size_t(r) * n + col0 + q] = float(v[size_t(r) * kCols + q]);
         }
     };
     std::vector<std::thread> pool;
@@ -1437,7 +1584,7 @@ int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int 
         return float(state >> 8) * (1.f / 16777216.f);
     };
     for (size_t c = 0; c < n; ++c)
-        if (isActive(L.labels[c])) {
+        if (isActive(L.ownedLabels[c])) {
             x[c] = rnd();
             b[c] = rnd();
         }

@@ -54,7 +54,11 @@ struct HostLevel {
     // rows[q*numBoundary + t], q = 0..5 the off-diagonal weight towards -x,+x,-y,+y,-z,+z (0 when that
     // neighbour is not active), q = 6 the diagonal.
     std::vector<float> rows;
-    std::vector<uint8_t> codes;      // device cell codes (see kCodeSimple): ghost plane, owned planes, ghost plane
+    // slab levels (buildSlabLevel) keep no label copy: views into the hierarchy level they were cut from -- the owned
+    // planes and the plane below / above them (nullptr at the ends of the grid: EXTERIOR).  The device cell codes
+    // (see kCodeSimple) are these labels with the simple BOUNDARY cells patched in by launchPatchSimpleCodes.
+    const uint8_t *ownedLabels = nullptr, *ghostLoLabels = nullptr, *ghostHiLabels = nullptr;
+    std::vector<int32_t> bandEntry;  // per entry of `band`: its index in bandDev
     // slab runs: band cells of the four planes a band-only ghost exchange touches, as offsets from
     // owned cell 0 in reference band order (both neighbours derive them from the same global band
     // list, so sender's pack order == receiver's unpack order): [0] owned plane 0 (sent down),
@@ -223,6 +227,8 @@ int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);
+// codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
+int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, const uint8_t *bandDiag, int nbnd, int nband);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse);
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,

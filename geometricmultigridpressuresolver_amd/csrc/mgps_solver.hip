@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "mgps_internal.h"
@@ -607,11 +609,20 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     L.z0 = z0;
     L.z1 = z1;
     const size_t plane = size_t(L.d.nx) * L.d.ny;
-    MGPS_TRY(devUpload(h, &L.codes, HL.codes));
+    {  // cell codes: ghost plane | owned planes | ghost plane of labels, then the simple BOUNDARY cells patched in
+        const size_t owned = size_t(L.d.nz) * plane;
+        MGPS_TRY(devAlloc(h, &L.codes, owned + 2 * plane, false));
+        MGPS_HIP(h, hipMemcpy(L.codes + plane, HL.ownedLabels, owned, hipMemcpyHostToDevice));
+        if (HL.ghostLoLabels) MGPS_HIP(h, hipMemcpy(L.codes, HL.ghostLoLabels, plane, hipMemcpyHostToDevice));
+        else MGPS_HIP(h, hipMemset(L.codes, MGPS_EXTERIOR_CELL, plane));
+        if (HL.ghostHiLabels) MGPS_HIP(h, hipMemcpy(L.codes + plane + owned, HL.ghostHiLabels, plane, hipMemcpyHostToDevice));
+        else MGPS_HIP(h, hipMemset(L.codes + plane + owned, MGPS_EXTERIOR_CELL, plane));
+    }
     MGPS_TRY(devUpload(h, &L.band, HL.bandDev));
     MGPS_TRY(devUpload(h, &L.rows, HL.rows));
     MGPS_TRY(devUpload(h, &L.bandDiag, HL.bandDiag));
     L.nband = int(HL.bandDev.size());
+    MGPS_LAUNCH(h, launchPatchSimpleCodes(nullptr, L.codes + plane, L.band, L.bandDiag, int(HL.numBoundary), L.nband));
     MGPS_TRY(devAlloc(h, &L.bandTmp, HL.bandDev.size(), false));
     MGPS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
     MGPS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
@@ -739,18 +750,36 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
     };
     const Dims d0 = hier->lv[0].d;
     StageClock clock(h->opt.print_stats != 0);
+    // two jobs nothing below waits for until the end run beside the level set-up: the dense inverse of the coarsest
+    // matrix (host threads) and the copy of the face weights (a blocking hipMemcpy of 3 x 4 B per cell)
+    const bool needCoarse = hier->levels > 1 || tailOfSlabRun;
+    std::thread inverseJob, weightJob;
+    std::atomic<bool> weightsFailed{false};
+    auto joinJobs = [&] {
+        if (inverseJob.joinable()) inverseJob.join();
+        if (weightJob.joinable()) weightJob.join();
+    };
+    if (needCoarse) inverseJob = std::thread([hier] { hier->buildDenseInverse(); });
     if (wx) {
         const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz,
                               size_t(d0.nx) * d0.ny * (d0.nz + 1)};
         const float *wh[3] = {wx, wy, wz};
         for (int a = 0; a < 3; ++a) {
             int rc = devAlloc(h, &h->w[a], wn[a], false);
-            if (rc != MGPS_OK) return bail(rc);
-            if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), rowsL0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
-                return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
+            if (rc != MGPS_OK) {
+                joinJobs();
+                return bail(rc);
+            }
         }
+        float *dst[3] = {h->w[0], h->w[1], h->w[2]};
+        const hipMemcpyKind kind = rowsL0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        weightJob = std::thread([=, &weightsFailed] {
+            if (hipSetDevice(device) != hipSuccess) weightsFailed = true;
+            for (int a = 0; a < 3 && !weightsFailed; ++a)
+                if (hipMemcpy(dst[a], wh[a], wn[a] * sizeof(float), kind) != hipSuccess) weightsFailed = true;
+        });
     }
-    clock.lap("weights upload");
+    clock.lap("weights allocation");
     h->lv.resize(hier->levels);
     for (int l = 0; l < hier->levels; ++l) {
         HostLevel HL;
@@ -760,12 +789,18 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
                        l == 0 ? rowsL0 : nullptr);
         clock.lap("codes, rows, lists", l);
         int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0);
-        if (rc != MGPS_OK) return bail(rc);
+        if (rc != MGPS_OK) {
+            joinJobs();
+            return bail(rc);
+        }
         clock.lap("band groups + upload", l);
     }
-    int rc = commonDeviceState(h, hier->levels > 1 || tailOfSlabRun);
+    joinJobs();
+    if (weightsFailed) return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
+    clock.lap("wait for inverse + weights");
+    int rc = commonDeviceState(h, needCoarse);
     if (rc != MGPS_OK) return bail(rc);
-    clock.lap("coarse inverse + scratch");
+    clock.lap("coarse solver upload + scratch");
     *out = h;
     return MGPS_OK;
 }
