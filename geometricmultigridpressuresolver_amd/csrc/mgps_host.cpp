@@ -177,72 +177,64 @@ static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
 // through face neighbours, ordered by (tile id, k, j, i).
 static void buildBand(HostLevel &L, int width)
 {
+    // Tile by tile, which is the order of the list: a band cell of a 16^3 tile lies within width-1 steps of a
+    // BOUNDARY cell, so the tile plus a halo of width-1 cells decides its part of the list.  Every tile is an
+    // independent piece of work for the host threads and the pieces concatenate into the reference order.
     const Dims d = L.d;
-    uint8_t *lab = L.labels.data();
-    const size_t n = d.cells();
-    constexpr uint8_t kMark = 0x80;  // rings are marked in the labels themselves (INTERIOR | kMark) and unmarked at the end
-    std::vector<size_t> frontier, next;
-    parallelCollect<size_t>(int64_t(n / 8), 1 << 17, frontier, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
-        // eight labels at a time: most words hold no BOUNDARY cell at all
-        constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
-        for (int64_t w = b; w < e; ++w) {
-            uint64_t v;
-            std::memcpy(&v, lab + 8 * size_t(w), 8);
-            v ^= k01 * uint64_t(MGPS_BOUNDARY_CELL);
-            if (((v - k01) & ~v & k80) == 0) continue;
-            for (size_t c = 8 * size_t(w); c < 8 * size_t(w) + 8; ++c)
-                if (lab[c] == MGPS_BOUNDARY_CELL) out.push_back(c);
+    const uint8_t *lab = L.labels.data();
+    const int halo = std::max(0, width - 1), E = kTile + 2 * halo, F = E + 2;  // F: one more EXTERIOR layer, no bounds tests
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    const int64_t ntiles = int64_t(tx) * ty * tz;
+    L.bandTileStart.assign(size_t(ntiles) + 1, 0);
+    int32_t *tileCount = L.bandTileStart.data() + 1;
+    parallelCollect<int32_t>(ntiles, 64, L.band, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
+        // (the outermost layer of blk is never written: it stays EXTERIOR)
+        std::vector<uint8_t> blk(size_t(F) * F * F, uint8_t(MGPS_EXTERIOR_CELL)), dist(size_t(F) * F * F);
+        std::vector<int32_t> cur, nxt;
+        const int off[6] = {-1, 1, -F, F, -F * F, F * F};
+        for (int64_t t = b; t < e; ++t) {
+            const int ti = int(t % tx), tj = int((t / tx) % ty), tk = int(t / (int64_t(tx) * ty));
+            const int oi = ti * kTile - halo - 1, oj = tj * kTile - halo - 1, ok = tk * kTile - halo - 1;  // grid cell of local (0,0,0)
+            // the labels of the block; rows without a BOUNDARY cell leave no trace beyond their copy
+            cur.clear();
+            const int i0 = std::max(0, oi + 1), i1 = std::min(d.nx, oi + 1 + E);
+            for (int lk = 1; lk <= E; ++lk)
+                for (int lj = 1; lj <= E; ++lj) {
+                    uint8_t *row = blk.data() + (size_t(lk) * F + lj) * F;
+                    const int j = oj + lj, k = ok + lk;
+                    std::memset(row, MGPS_EXTERIOR_CELL, size_t(F));
+                    if (j < 0 || j >= d.ny || k < 0 || k >= d.nz) continue;
+                    const uint8_t *src = lab + d.idx(i0, j, k);
+                    std::memcpy(row + (i0 - oi), src, size_t(i1 - i0));
+                    for (int i = i0; i < i1; ++i)
+                        if (src[i - i0] == MGPS_BOUNDARY_CELL) cur.push_back(int32_t((size_t(lk) * F + lj) * F + (i - oi)));
+                }
+            if (cur.empty()) continue;
+            std::fill(dist.begin(), dist.end(), uint8_t(255));
+            for (int32_t c : cur) dist[size_t(c)] = 0;
+            for (int ring = 1; ring < width; ++ring) {
+                nxt.clear();
+                for (int32_t c : cur)
+                    for (int q = 0; q < 6; ++q) {
+                        const int32_t n = c + off[q];
+                        if (blk[size_t(n)] == MGPS_INTERIOR_CELL && dist[size_t(n)] == 255) {
+                            dist[size_t(n)] = uint8_t(ring);
+                            nxt.push_back(n);
+                        }
+                    }
+                cur.swap(nxt);
+            }
+            const size_t before = out.size();
+            for (int lk = halo + 1; lk <= halo + kTile; ++lk)
+                for (int lj = halo + 1; lj <= halo + kTile; ++lj) {
+                    const uint8_t *drow = dist.data() + (size_t(lk) * F + lj) * F;
+                    for (int li = halo + 1; li <= halo + kTile; ++li)
+                        if (drow[li] != 255) out.push_back(int32_t(d.idx(oi + li, oj + lj, ok + lk)));
+                }
+            tileCount[t] = int32_t(out.size() - before);
         }
     });
-    for (size_t c = n / 8 * 8; c < n; ++c)
-        if (lab[c] == MGPS_BOUNDARY_CELL) frontier.push_back(c);
-    std::vector<size_t> cells = frontier;  // every band cell, ring by ring
-    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
-    for (int ring = 1; ring < width; ++ring) {  // the order inside a ring is irrelevant: the list is sorted below
-        parallelCollect<size_t>(int64_t(frontier.size()), 1 << 14, next, [&](int64_t b, int64_t e, std::vector<size_t> &out) {
-            for (int64_t q = b; q < e; ++q) {
-                const size_t c = frontier[size_t(q)];
-                for (int a = 0; a < 3; ++a)
-                    for (int sgn = -1; sgn <= 1; sgn += 2) {
-                        const size_t nb = c + sgn * stride[a];
-                        if (__atomic_load_n(&lab[nb], __ATOMIC_RELAXED) == MGPS_INTERIOR_CELL &&
-                            __atomic_fetch_or(&lab[nb], kMark, __ATOMIC_RELAXED) == MGPS_INTERIOR_CELL)
-                            out.push_back(nb);
-                    }
-            }
-        });
-        cells.insert(cells.end(), next.begin(), next.end());
-        frontier.swap(next);
-    }
-    // (tile, k, j, i) order: counting sort by tile, then by cell index inside each tile (same tile: k, j, i order)
-    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    const size_t ntiles = size_t(tx) * ty * tz, m = cells.size();
-    std::vector<int32_t> tileOf(m);
-    std::vector<int32_t> start(ntiles + 1, 0);
-    parallelFor(int64_t(m), [&](int64_t b, int64_t e) {
-        for (int64_t q = b; q < e; ++q) {
-            const size_t c = cells[size_t(q)];
-            if (lab[c] != MGPS_BOUNDARY_CELL) lab[c] = MGPS_INTERIOR_CELL;  // unmark
-            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
-            const int32_t t = int32_t((size_t(k / kTile) * ty + j / kTile) * tx + i / kTile);
-            tileOf[size_t(q)] = t;
-            __atomic_fetch_add(&start[size_t(t) + 1], 1, __ATOMIC_RELAXED);
-        }
-    }, 1 << 15);
-    for (size_t t = 0; t < ntiles; ++t) start[t + 1] += start[t];
-    L.band.resize(m);
-    {
-        std::vector<int32_t> fill(start.begin(), start.end() - 1);
-        int32_t *out = L.band.data();
-        parallelFor(int64_t(m), [&](int64_t b, int64_t e) {
-            for (int64_t q = b; q < e; ++q)
-                out[__atomic_fetch_add(&fill[size_t(tileOf[size_t(q)])], 1, __ATOMIC_RELAXED)] = int32_t(cells[size_t(q)]);
-        }, 1 << 15);
-        parallelFor(int64_t(ntiles), [&](int64_t b, int64_t e) {
-            for (int64_t t = b; t < e; ++t)
-                if (start[size_t(t) + 1] - start[size_t(t)] > 1) std::sort(out + start[size_t(t)], out + start[size_t(t) + 1]);
-        }, 64);
-    }
+    for (int64_t t = 0; t < ntiles; ++t) L.bandTileStart[size_t(t) + 1] += L.bandTileStart[size_t(t)];
 }
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
@@ -402,6 +394,16 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         }
     }
     parts.clear();
+    if (z0 == 0 && z1 == gd.nz) L.bandTileStart = G.bandTileStart;
+    else {  // the slab's own tiles (z0 is a multiple of 16)
+        const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+        L.bandTileStart.assign(size_t(tx) * ty * tz + 1, 0);
+        for (int32_t c : L.band) {
+            const int i = int(size_t(c) % d.nx), j = int((size_t(c) / d.nx) % d.ny), k = int(size_t(c) / plane);
+            ++L.bandTileStart[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile + 1];
+        }
+        for (size_t t = 0; t + 1 < L.bandTileStart.size(); ++t) L.bandTileStart[t + 1] += L.bandTileStart[t];
+    }
     lap.lap("slab level: band split + rows");
     // band cells of the planes a band-only ghost exchange moves (see HostLevel::bandPlane)
     {
@@ -540,8 +542,9 @@ struct BandWindow {
     // whole-grid windows skip the dense map: the reference band order is (tile, k, j, i), so a cell is found by a
     // binary search among the band cells of its 16^3 tile
     const int32_t *sortedBand = nullptr;  // band cells in reference order
-    std::vector<int32_t> tileStart;       // per tile (+1): first index of its cells in sortedBand
-    std::vector<int32_t> entryOfSorted;   // per index of sortedBand: the output entry
+    const int32_t *tileStart = nullptr;      // per tile (+1): first index of its cells in sortedBand
+    size_t ntiles = 0;
+    const int32_t *entryOfSorted = nullptr;  // per index of sortedBand: the output entry
     int tilesX = 0, tilesY = 0;
     int32_t entryAt(size_t wc) const
     {
@@ -552,8 +555,11 @@ struct BandWindow {
         const int32_t *it = std::lower_bound(lo, hi, int32_t(wc));  // same tile: reference order == cell order
         return (it != hi && *it == int32_t(wc)) ? entryOfSorted[size_t(it - sortedBand)] : kNoBand;
     }
-    std::vector<int32_t> seedCell;       // per output entry: its window cell
-    std::vector<uint8_t> entryDiag;      // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
+    const int32_t *seedCell = nullptr;   // per output entry: its window cell
+    size_t nSeeds = 0;
+    const uint8_t *entryDiag = nullptr;  // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
+    std::vector<int32_t> seedCellOwn;    // (storage of the two when the window is not a level's own band)
+    std::vector<uint8_t> entryDiagOwn;
     // device address of a window cell: grid offset from owned cell 0 for the planes that live in the grid
     // allocation, otherwise a slot of the halo buffers (encoded below gridLoCode)
     int gridPlaneLo = 0, gridPlaneHi = 0;
@@ -683,7 +689,7 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
 {
     out = BandGroups();
     out.depth = depth;
-    const size_t nent = W.seedCell.size();
+    const size_t nent = W.nSeeds;
     if (depth < 1 || depth > kBandMaxDepth || nent == 0 || nent > size_t(kBandEntryMask)) return true;
     const Dims d = W.wd;
     HostLap lap;
@@ -691,9 +697,9 @@ bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     std::vector<std::vector<int32_t>> work;
     if (W.sortedBand) {  // the reference order already groups the cells by tile
-        for (size_t t = 0; t + 1 < W.tileStart.size(); ++t)
+        for (size_t t = 0; t < W.ntiles; ++t)
             if (W.tileStart[t + 1] > W.tileStart[t])
-                work.emplace_back(W.entryOfSorted.begin() + W.tileStart[t], W.entryOfSorted.begin() + W.tileStart[t + 1]);
+                work.emplace_back(W.entryOfSorted + W.tileStart[t], W.entryOfSorted + W.tileStart[t + 1]);
     } else {
         std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
         for (size_t t = 0; t < nent; ++t) {
@@ -808,23 +814,15 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     W.wd = L.d;
     W.labels = L.ownedLabels;  // a whole-grid level
     W.cellLimit = L.d.cells();
-    W.seedCell.assign(L.bandDev.begin(), L.bandDev.end());
-    {
-        const Dims d = L.d;
-        W.tilesX = (d.nx + kTile - 1) / kTile;
-        W.tilesY = (d.ny + kTile - 1) / kTile;
-        const size_t ntiles = size_t(W.tilesX) * W.tilesY * size_t((d.nz + kTile - 1) / kTile);
-        W.sortedBand = L.band.data();
-        W.entryOfSorted = L.bandEntry;
-        W.tileStart.assign(ntiles + 1, 0);
-        for (size_t q = 0; q < nband; ++q) {
-            const size_t c = size_t(L.band[q]);
-            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
-            ++W.tileStart[(size_t(k / kTile) * W.tilesY + j / kTile) * W.tilesX + i / kTile + 1];
-        }
-        for (size_t t = 0; t < ntiles; ++t) W.tileStart[t + 1] += W.tileStart[t];
-    }
-    W.entryDiag = L.bandDiag;
+    W.seedCell = L.bandDev.data();
+    W.nSeeds = nband;
+    W.entryDiag = L.bandDiag.data();
+    W.tilesX = (L.d.nx + kTile - 1) / kTile;
+    W.tilesY = (L.d.ny + kTile - 1) / kTile;
+    W.ntiles = size_t(W.tilesX) * W.tilesY * size_t((L.d.nz + kTile - 1) / kTile);
+    W.sortedBand = L.band.data();
+    W.entryOfSorted = L.bandEntry.data();
+    W.tileStart = L.bandTileStart.data();
     W.gridPlaneLo = 0;
     W.gridPlaneHi = L.d.nz;
     lap0.lap("band groups: entry map");
@@ -921,9 +919,10 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     W.allocEntryOf();
     for (size_t c = 0; c < wcells; ++c)
         if (band[c]) W.entryOf[c] = BandWindow::kDeepBand;
-    W.seedCell.resize(out.bandExt.size());
-    W.entryDiag = L.bandDiag;
-    W.entryDiag.resize(out.bandExt.size(), 0);
+    W.seedCellOwn.resize(out.bandExt.size());
+    W.entryDiagOwn = L.bandDiag;
+    W.entryDiagOwn.resize(out.bandExt.size(), 0);
+    W.nSeeds = out.bandExt.size();
     // rows of the neighbours' cells, when given: [ghost below][ghost above][z0-2 .. ][z1+1 ..], each plane in band order
     std::unordered_map<int64_t, int32_t> foreignRowOf;
     if (foreignRows) {
@@ -949,19 +948,21 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     }
     for (size_t t = 0; t < out.bandExt.size(); ++t) {
         const size_t wc = size_t(ptrdiff_t(out.bandExt[t]) + ownedShift);
-        W.seedCell[t] = int32_t(wc);
+        W.seedCellOwn[t] = int32_t(wc);
         W.entryOf[wc] = int32_t(t);
         if (t < L.bandDev.size()) continue;
         if (!foreignRows) {
-            W.entryDiag[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
+            W.entryDiagOwn[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
             continue;
         }
         // a ghost-plane cell: its row index is t - bandDev.size() by construction of the order above
         const auto fr = foreignRowOf.find(int64_t(wc));
         if (fr == foreignRowOf.end() || size_t(fr->second) != t - L.bandDev.size()) return;
         const float *row = foreignRows->data() + 8 * size_t(fr->second);
-        W.entryDiag[t] = row[7] != 0.f ? uint8_t(int(row[6])) : uint8_t(0);
+        W.entryDiagOwn[t] = row[7] != 0.f ? uint8_t(int(row[6])) : uint8_t(0);
     }
+    W.seedCell = W.seedCellOwn.data();
+    W.entryDiag = W.entryDiagOwn.data();
     W.gridPlaneLo = z0 - 1 - wz0;  // (a ghost plane outside the domain is never referenced: its cells are not active)
     W.gridPlaneHi = z1 + 1 - wz0;
     W.cellShift = ownedShift;

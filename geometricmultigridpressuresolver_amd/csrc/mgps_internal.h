@@ -4,7 +4,9 @@
 
 #include <cstdint>
 #include <cstddef>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mgps.h"
@@ -18,6 +20,24 @@ constexpr int kTile = 16;  // UT_VoxelArray tile edge: decides the Gauss-Seidel 
 // then padded with -1 to whole workgroups of four entries)
 constexpr int kChunkCells = 1024;
 constexpr int kWaveChunkCells = 256;
+
+// std::vector that leaves trivially constructible elements uninitialised on resize(): the big set-up arrays are
+// filled by all host threads right after, and a serial zero-fill of 100+ MB costs more than that fill
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        if constexpr (sizeof...(Args) == 0) ::new (static_cast<void *>(p)) U;
+        else ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using RawVec = std::vector<T, DefaultInitAllocator<T>>;
 
 inline bool isActive(uint8_t l) { return l == MGPS_INTERIOR_CELL || l == MGPS_BOUNDARY_CELL; }
 
@@ -43,8 +63,9 @@ struct Dims {
 // One level of the hierarchy, host side.
 struct HostLevel {
     Dims d;
-    std::vector<uint8_t> labels;
+    RawVec<uint8_t> labels;
     std::vector<int32_t> band;       // linear indices of the band cells, reference order (tile,k,j,i)
+    std::vector<int32_t> bandTileStart;  // hierarchy levels: per 16^3 tile (+1) the first entry of its cells in `band`
     // device order of the same set: the BOUNDARY cells first (each in reference order), then the
     // INTERIOR band cells.  Jacobi on the band is compute-then-scatter, so the order is free.
     std::vector<int32_t> bandDev;
@@ -97,11 +118,11 @@ struct BandGroups {
     int depth = 0;
     // per group 8 ints: first update node, first read-only node, read-only count,
     // count of update nodes with distance <= 0 (owned), <= 1, <= 2, <= 3, unused
-    std::vector<int32_t> info;
-    std::vector<int32_t> updateEntry;   // per update node: its index t in bandDev | diagonal << kBandDiagShift
-    std::vector<int32_t> updateCell;    // per update node: linear cell index
-    std::vector<uint16_t> neighbours;   // per update node: 6 group-local node ids (-x,+x,-y,+y,-z,+z)
-    std::vector<int32_t> readCell;      // per read-only node: linear cell index
+    RawVec<int32_t> info;
+    RawVec<int32_t> updateEntry;   // per update node: its index t in bandDev | diagonal << kBandDiagShift
+    RawVec<int32_t> updateCell;    // per update node: linear cell index
+    RawVec<uint16_t> neighbours;   // per update node: 6 group-local node ids (-x,+x,-y,+y,-z,+z)
+    RawVec<int32_t> readCell;      // per read-only node: linear cell index
     size_t groups() const { return info.size() / 8; }
 };
 void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);

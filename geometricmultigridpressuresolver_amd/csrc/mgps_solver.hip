@@ -34,6 +34,7 @@ struct DevLevel {
     float *r = nullptr, *tmp = nullptr;
     int32_t *band = nullptr;  // device-ordered band list: general BOUNDARY cells first
     int nband = 0;
+    int nbndGeneral = 0;  // general BOUNDARY cells: the first entries of band
     float *bandTmp = nullptr;
     float *rows = nullptr;  // 7 x numBoundary operator rows of the general BOUNDARY cells
     uint8_t *bandDiag = nullptr;
@@ -142,8 +143,8 @@ int devAlloc(mgps_solver *h, T **p, size_t count, bool zero)
     return MGPS_OK;
 }
 
-template <class T>
-int devUpload(mgps_solver *h, T **p, const std::vector<T> &v)
+template <class T, class A>
+int devUpload(mgps_solver *h, T **p, const std::vector<T, A> &v)
 {
     MGPS_TRY(devAlloc(h, p, v.size(), false));
     if (!v.empty()) MGPS_HIP(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -602,14 +603,15 @@ struct StageClock {
     }
 };
 
+// codesPreloaded: the caller allocated L.codes, copies the labels into it itself and patches the simple cells afterwards
 int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1, int globalNz, bool withWeights,
-                bool workGrids, bool xbGrids)
+                bool workGrids, bool xbGrids, bool codesPreloaded = false)
 {
     L.d = HL.d;
     L.z0 = z0;
     L.z1 = z1;
     const size_t plane = size_t(L.d.nx) * L.d.ny;
-    {  // cell codes: ghost plane | owned planes | ghost plane of labels, then the simple BOUNDARY cells patched in
+    if (!codesPreloaded) {  // cell codes: ghost plane | owned planes | ghost plane of labels, then the simple BOUNDARY cells patched in
         const size_t owned = size_t(L.d.nz) * plane;
         MGPS_TRY(devAlloc(h, &L.codes, owned + 2 * plane, false));
         MGPS_HIP(h, hipMemcpy(L.codes + plane, HL.ownedLabels, owned, hipMemcpyHostToDevice));
@@ -622,7 +624,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     MGPS_TRY(devUpload(h, &L.rows, HL.rows));
     MGPS_TRY(devUpload(h, &L.bandDiag, HL.bandDiag));
     L.nband = int(HL.bandDev.size());
-    MGPS_LAUNCH(h, launchPatchSimpleCodes(nullptr, L.codes + plane, L.band, L.bandDiag, int(HL.numBoundary), L.nband));
+    L.nbndGeneral = int(HL.numBoundary);
+    if (!codesPreloaded) MGPS_LAUNCH(h, launchPatchSimpleCodes(nullptr, L.codes + plane, L.band, L.bandDiag, L.nbndGeneral, L.nband));
     MGPS_TRY(devAlloc(h, &L.bandTmp, HL.bandDev.size(), false));
     MGPS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
     MGPS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
@@ -760,6 +763,23 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         if (weightJob.joinable()) weightJob.join();
     };
     if (needCoarse) inverseJob = std::thread([hier] { hier->buildDenseInverse(); });
+    h->lv.resize(hier->levels);
+    struct CodeCopy {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t plane, owned;
+    };
+    std::vector<CodeCopy> codeCopies;
+    for (int l = 0; l < hier->levels; ++l) {  // ghost plane | the level's labels | ghost plane
+        const Dims d = hier->lv[l].d;
+        const size_t plane = size_t(d.nx) * d.ny;
+        int rc = devAlloc(h, &h->lv[l].codes, d.cells() + 2 * plane, false);
+        if (rc != MGPS_OK) {
+            joinJobs();
+            return bail(rc);
+        }
+        codeCopies.push_back({h->lv[l].codes, hier->lv[l].labels.data(), plane, d.cells()});
+    }
     if (wx) {
         const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz,
                               size_t(d0.nx) * d0.ny * (d0.nz + 1)};
@@ -775,12 +795,27 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         const hipMemcpyKind kind = rowsL0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         weightJob = std::thread([=, &weightsFailed] {
             if (hipSetDevice(device) != hipSuccess) weightsFailed = true;
+            for (const CodeCopy &c : codeCopies) {
+                if (weightsFailed) break;
+                if (hipMemset(c.dst, MGPS_EXTERIOR_CELL, c.plane) != hipSuccess || hipMemset(c.dst + c.plane + c.owned, MGPS_EXTERIOR_CELL, c.plane) != hipSuccess ||
+                    hipMemcpy(c.dst + c.plane, c.src, c.owned, hipMemcpyHostToDevice) != hipSuccess)
+                    weightsFailed = true;
+            }
             for (int a = 0; a < 3 && !weightsFailed; ++a)
                 if (hipMemcpy(dst[a], wh[a], wn[a] * sizeof(float), kind) != hipSuccess) weightsFailed = true;
         });
+    } else {
+        weightJob = std::thread([=, &weightsFailed] {
+            if (hipSetDevice(device) != hipSuccess) weightsFailed = true;
+            for (const CodeCopy &c : codeCopies) {
+                if (weightsFailed) break;
+                if (hipMemset(c.dst, MGPS_EXTERIOR_CELL, c.plane) != hipSuccess || hipMemset(c.dst + c.plane + c.owned, MGPS_EXTERIOR_CELL, c.plane) != hipSuccess ||
+                    hipMemcpy(c.dst + c.plane, c.src, c.owned, hipMemcpyHostToDevice) != hipSuccess)
+                    weightsFailed = true;
+            }
+        });
     }
-    clock.lap("weights allocation");
-    h->lv.resize(hier->levels);
+    clock.lap("allocations, copy jobs started");
     for (int l = 0; l < hier->levels; ++l) {
         HostLevel HL;
         const Dims d = hier->lv[l].d;
@@ -788,7 +823,7 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         buildSlabLevel(hier->lv[l], 0, d.nz, hostW ? wx : nullptr, hostW ? wy : nullptr, hostW ? wz : nullptr, HL,
                        l == 0 ? rowsL0 : nullptr);
         clock.lap("codes, rows, lists", l);
-        int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0);
+        int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0, true);
         if (rc != MGPS_OK) {
             joinJobs();
             return bail(rc);
@@ -796,8 +831,13 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         clock.lap("band groups + upload", l);
     }
     joinJobs();
-    if (weightsFailed) return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
-    clock.lap("wait for inverse + weights");
+    if (weightsFailed) return bail(failH(h, MGPS_ERR_HIP, "label / weight upload failed"));
+    for (int l = 0; l < hier->levels; ++l) {
+        DevLevel &L = h->lv[l];
+        int e = launchPatchSimpleCodes(nullptr, L.codes + size_t(L.d.nx) * L.d.ny, L.band, L.bandDiag, L.nbndGeneral, L.nband);
+        if (e != 0) return bail(failH(h, MGPS_ERR_HIP, "launchPatchSimpleCodes failed"));
+    }
+    clock.lap("wait for inverse + copies");
     int rc = commonDeviceState(h, needCoarse);
     if (rc != MGPS_OK) return bail(rc);
     clock.lap("coarse solver upload + scratch");
