@@ -373,25 +373,30 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         nRest += P.rest.size();
     }
     L.numBoundary = int32_t(nGeneral);
-    L.band.reserve(nGeneral + nRest);
-    L.bandEntry.reserve(nGeneral + nRest);
+    L.band.resize(nGeneral + nRest);
+    L.bandEntry.resize(nGeneral + nRest);
     L.bandDev.resize(nGeneral + nRest);
     L.bandDiag.assign(nGeneral + nRest, 0);
-    std::vector<Row> generalRows;
-    generalRows.reserve(nGeneral);
+    std::vector<Row> generalRows(nGeneral);
     {
-        size_t g = 0, r = nGeneral;
-        for (auto &P : parts) {
-            L.band.insert(L.band.end(), P.band.begin(), P.band.end());
-            size_t gi = g, ri = r;
-            for (uint8_t isG : P.isGeneral) L.bandEntry.push_back(int32_t(isG ? gi++ : ri++));
-            std::copy(P.general.begin(), P.general.end(), L.bandDev.begin() + ptrdiff_t(g));
-            std::copy(P.rest.begin(), P.rest.end(), L.bandDev.begin() + ptrdiff_t(r));
-            std::copy(P.restDiag.begin(), P.restDiag.end(), L.bandDiag.begin() + ptrdiff_t(r));
-            generalRows.insert(generalRows.end(), P.generalRows.begin(), P.generalRows.end());
-            g += P.general.size();
-            r += P.rest.size();
+        std::vector<size_t> gAt(parts.size() + 1, 0), rAt(parts.size() + 1, nGeneral), bAt(parts.size() + 1, 0);
+        for (size_t q = 0; q < parts.size(); ++q) {
+            gAt[q + 1] = gAt[q] + parts[q].general.size();
+            rAt[q + 1] = rAt[q] + parts[q].rest.size();
+            bAt[q + 1] = bAt[q] + parts[q].band.size();
         }
+        parallelFor(int64_t(parts.size()), [&](int64_t q0, int64_t q1) {
+            for (int64_t q = q0; q < q1; ++q) {
+                const Part &P = parts[size_t(q)];
+                std::copy(P.band.begin(), P.band.end(), L.band.begin() + ptrdiff_t(bAt[size_t(q)]));
+                size_t gi = gAt[size_t(q)], ri = rAt[size_t(q)], bi = bAt[size_t(q)];
+                for (uint8_t isG : P.isGeneral) L.bandEntry[bi++] = int32_t(isG ? gi++ : ri++);
+                std::copy(P.general.begin(), P.general.end(), L.bandDev.begin() + ptrdiff_t(gAt[size_t(q)]));
+                std::copy(P.rest.begin(), P.rest.end(), L.bandDev.begin() + ptrdiff_t(rAt[size_t(q)]));
+                std::copy(P.restDiag.begin(), P.restDiag.end(), L.bandDiag.begin() + ptrdiff_t(rAt[size_t(q)]));
+                std::copy(P.generalRows.begin(), P.generalRows.end(), generalRows.begin() + ptrdiff_t(gAt[size_t(q)]));
+            }
+        });
     }
     parts.clear();
     if (z0 == 0 && z1 == gd.nz) L.bandTileStart = G.bandTileStart;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -104,6 +105,8 @@ namespace {
 
 int failH(mgps_solver *h, int code, const std::string &msg)
 {
+    static std::mutex guard;  // set-up reports from more than one thread
+    std::lock_guard<std::mutex> lock(guard);
     if (h) h->lastError = msg;
     else setLastGlobalError(msg);
     return code;
@@ -816,19 +819,32 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         });
     }
     clock.lap("allocations, copy jobs started");
-    for (int l = 0; l < hier->levels; ++l) {
+    // the fine level on this thread, the coarser ones (together about a third of its work) on another
+    auto buildLevel = [&](int l, StageClock &clk) {
         HostLevel HL;
         const Dims d = hier->lv[l].d;
         const bool hostW = l == 0 && !rowsL0;
         buildSlabLevel(hier->lv[l], 0, d.nz, hostW ? wx : nullptr, hostW ? wy : nullptr, hostW ? wz : nullptr, HL,
                        l == 0 ? rowsL0 : nullptr);
-        clock.lap("codes, rows, lists", l);
-        int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0, true);
-        if (rc != MGPS_OK) {
-            joinJobs();
-            return bail(rc);
+        clk.lap("codes, rows, lists", l);
+        const int rc = uploadLevel(h, h->lv[l], HL, 0, d.nz, d.nz, l == 0 && wx, true, l > 0, true);
+        clk.lap("band groups + upload", l);
+        return rc;
+    };
+    int rcCoarse = MGPS_OK;
+    std::thread coarseLevels([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            rcCoarse = MGPS_ERR_HIP;
+            return;
         }
-        clock.lap("band groups + upload", l);
+        StageClock clk(h->opt.print_stats != 0);
+        for (int l = 1; l < hier->levels && rcCoarse == MGPS_OK; ++l) rcCoarse = buildLevel(l, clk);
+    });
+    const int rcFine = buildLevel(0, clock);
+    coarseLevels.join();
+    if (rcFine != MGPS_OK || rcCoarse != MGPS_OK) {
+        joinJobs();
+        return bail(rcFine != MGPS_OK ? rcFine : rcCoarse);
     }
     joinJobs();
     if (weightsFailed) return bail(failH(h, MGPS_ERR_HIP, "label / weight upload failed"));
