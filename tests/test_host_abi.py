@@ -132,6 +132,29 @@ def test_hierarchy_non_cubic(oracle):
         assert (H.level_labels(l) == s.level_labels(l)).all() and (H.band_cells(l) == s.band(l)).all()
 
 
+@pytest.mark.parametrize("shape", [(24, 40, 56), (36, 20, 44)])
+@pytest.mark.parametrize("width", [1, 2, 3, 4])
+def test_band_list_random_labels_any_width(shape, width, oracle):
+    """The tile-by-tile band builder (a 16^3 tile + a halo of width-1 cells) against the oracle's grid-wide
+    breadth-first version: random blobs of every label, extents that are not multiples of the tile edge."""
+    rng = np.random.default_rng(7 + width)
+    nz, ny, nx = shape
+    noise = rng.random(shape)
+    for _ in range(2):  # smooth a little so that INTERIOR regions are several cells thick
+        noise = (noise + np.roll(noise, 1, 0) + np.roll(noise, 1, 1) + np.roll(noise, 1, 2) + np.roll(noise, -1, 0)
+                 + np.roll(noise, -1, 1) + np.roll(noise, -1, 2)) / 7
+    lab = np.full(shape, D.INTERIOR, dtype=np.uint8)
+    lab[noise < np.quantile(noise, 0.15)] = D.EXTERIOR
+    lab[noise > np.quantile(noise, 0.85)] = D.DIRICHLET
+    lab[0], lab[-1], lab[:, 0], lab[:, -1], lab[:, :, 0], lab[:, :, -1] = (D.EXTERIOR,) * 6
+    ones = [np.ones(D.face_shape(nz, ny, nx, a), dtype=np.float32) for a in range(3)]
+    D.set_boundary_labels(lab, ones)
+    opt = G.default_options()
+    opt.band_width = width
+    H = G.Hierarchy(lab, 1, options=opt)
+    assert (H.band_cells(0) == oracle.build_boundary_cells(lab.astype(np.int32), width)).all()
+
+
 def test_level_cap_quirk(oracle):
     lab, w, off, lev, dx = make_domain("simple", 16)
     H = G.Hierarchy(lab, 5)
