@@ -623,16 +623,20 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
     const int ext[3] = {hi[0] - lo[0] + 1 + 2 * depth, hi[1] - lo[1] + 1 + 2 * depth, hi[2] - lo[2] + 1 + 2 * depth};
     static thread_local std::vector<int32_t> id;
     id.assign(size_t(ext[0]) * ext[1] * ext[2], kUnset);
-    auto slot = [&](ptrdiff_t wc) -> int32_t & {
+    auto localOf = [&](ptrdiff_t wc) {  // index into `id` (three divisions: only the owned cells pay them)
         const int i = int(wc % W.wd.nx) - lo[0] + depth, j = int((wc / W.wd.nx) % W.wd.ny) - lo[1] + depth;
         const int k = int(wc / (ptrdiff_t(W.wd.nx) * W.wd.ny)) - lo[2] + depth;
-        return id[(size_t(k) * ext[1] + j) * ext[0] + i];
+        return int32_t((size_t(k) * ext[1] + j) * ext[0] + i);
     };
+    const int32_t loff[6] = {-1, 1, -ext[0], ext[0], -ext[0] * ext[1], ext[0] * ext[1]};
     std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
     std::vector<int64_t> updateW, readW;  // window cells of the nodes
+    std::vector<int32_t> updateL;         // and the update nodes' indices into `id`
     for (int32_t t : owned) {
-        slot(W.seedCell[size_t(t)]) = int32_t(updateW.size());
+        const int32_t li = localOf(W.seedCell[size_t(t)]);
+        id[size_t(li)] = int32_t(updateW.size());
         updateW.push_back(W.seedCell[size_t(t)]);
+        updateL.push_back(li);
         g.updateEntry.push_back(t | (int32_t(W.entryDiag[size_t(t)]) << kBandDiagShift));
     }
     size_t begin = 0;
@@ -642,18 +646,20 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
         g.cnt[dist] = int(end);
         for (size_t n = begin; n < end; ++n) {
             const ptrdiff_t c = ptrdiff_t(updateW[n]);
+            const int32_t cl = updateL[n];
             for (int q = 0; q < 6; ++q) {
                 const ptrdiff_t cq = c + off[q];
                 if (!W.active(size_t(cq))) {  // inactive: holds exactly 0
                     nbrTmp.push_back(kZero);
                     continue;
                 }
-                int32_t &v = slot(cq);
+                int32_t &v = id[size_t(cl + loff[q])];
                 if (v == kUnset) {
                     const int32_t e = W.entryAt(size_t(cq));
                     if (e != BandWindow::kNoBand && dist + 1 < depth) {
                         v = int32_t(updateW.size());
                         updateW.push_back(cq);
+                        updateL.push_back(cl + loff[q]);
                         if (e >= 0) g.updateEntry.push_back(e | (int32_t(W.entryDiag[size_t(e)]) << kBandDiagShift));
                         else if (!W.foreignRowOf) g.updateEntry.push_back(int32_t(W.diagFromLabels(size_t(cq))) << kBandDiagShift);  // no output, simple
                         else {  // no output; its entry field addresses its row when it is a general cell
@@ -1473,6 +1479,8 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
         return fail(MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain");
     }
     lap.lap("hierarchy: copy + shell check");
+    // the fine level's band list (the largest single piece, MG.cpp:279-281) beside the coarsening chain
+    std::thread fineBand([H] { buildBand(H->lv[0], H->bandWidth); });
     int levels = mg_levels;
     for (int l = 1; l < levels; ++l) {  // MG.cpp:238-253
         coarsenLabels(H->lv[l - 1], H->lv[l]);
@@ -1481,15 +1489,16 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
             break;
         }
     }
+    fineBand.join();
     if (levels < 1) {
         delete H;
         return fail(MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)");
     }
     H->levels = levels;
     H->lv.resize(levels);
-    lap.lap("hierarchy: coarsen labels");
-    for (auto &L : H->lv) {
-        buildBand(L, H->bandWidth);  // MG.cpp:279-281
+    lap.lap("hierarchy: coarsen labels + fine band list");
+    for (int l = 1; l < levels; ++l) {
+        buildBand(H->lv[size_t(l)], H->bandWidth);  // MG.cpp:279-281
         lap.lap("hierarchy: band list");
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
