@@ -902,14 +902,14 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
     return createWhole(out, hier, wx_host, wy_host, wz_host, use_gauss_seidel != 0, o, device, false);
 }
 
-int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const float *wx_dev,
-                               const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
-                               const mgps_options *opt)
+}  // extern "C"
+
+namespace {
+// labels_dev: the same labels on the device when the caller has them there (mgps_create_device), else nullptr
+int createFromDeviceWeights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const uint8_t *labels_dev,
+                            const float *wx_dev, const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
+                            const mgps_options *opt)
 {
-    if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: out is NULL");
-    *out = nullptr;
-    if (!labels_host || !wx_dev || !wy_dev || !wz_dev)
-        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: labels and the three weight grids are required");
     mgps_options o;
     MGPS_TRY(readOptions(opt, &o));
     int device = 0;
@@ -933,14 +933,14 @@ int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const 
         float *rowsDev = nullptr;
         int *violDev = nullptr;
         const size_t n = G.d.cells();
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&labDev), n);
+        hipError_t e = labels_dev ? hipSuccess : hipMalloc(reinterpret_cast<void **>(&labDev), n);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cellsDev), std::max<size_t>(1, cells.size()) * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rowsDev), std::max<size_t>(1, rows.size()) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&violDev), sizeof(int));
-        if (e == hipSuccess) e = hipMemcpy(labDev, G.labels.data(), n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !labels_dev) e = hipMemcpy(labDev, G.labels.data(), n, hipMemcpyHostToDevice);
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(cellsDev, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(violDev, 0, sizeof(int));
-        if (e == hipSuccess) e = hipError_t(launchBoundaryRows(nullptr, G.d, labDev, wx_dev, wy_dev, wz_dev, cellsDev, int(cells.size()), rowsDev, violDev));
+        if (e == hipSuccess) e = hipError_t(launchBoundaryRows(nullptr, G.d, labels_dev ? labels_dev : labDev, wx_dev, wy_dev, wz_dev, cellsDev, int(cells.size()), rowsDev, violDev));
         if (e == hipSuccess && !rows.empty()) e = hipMemcpy(rows.data(), rowsDev, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(&violations, violDev, sizeof(int), hipMemcpyDeviceToHost);
         (void)hipFree(labDev);
@@ -955,6 +955,38 @@ int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const 
         return drop(MGPS_ERR_HIERARCHY,
                     "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels");
     return createWhole(out, hier, wx_dev, wy_dev, wz_dev, use_gauss_seidel != 0, o, device, false, rows.empty() ? &kNoRows : rows.data());
+}
+}  // namespace
+
+extern "C" {
+
+int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const float *wx_dev,
+                               const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
+                               const mgps_options *opt)
+{
+    if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: out is NULL");
+    *out = nullptr;
+    if (!labels_host || !wx_dev || !wy_dev || !wz_dev)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: labels and the three weight grids are required");
+    return createFromDeviceWeights(out, nx, ny, nz, labels_host, nullptr, wx_dev, wy_dev, wz_dev, mg_levels, use_gauss_seidel, opt);
+}
+
+int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_dev, const float *wx_dev,
+                       const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel, const mgps_options *opt)
+{
+    if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device: out is NULL");
+    *out = nullptr;
+    if (!labels_dev || !wx_dev || !wy_dev || !wz_dev || nx < 1 || ny < 1 || nz < 1)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device: labels and the three weight grids are required");
+    mgps_options o;
+    MGPS_TRY(readOptions(opt, &o));
+    int device = 0;
+    MGPS_TRY(pickDevice(o, &device));
+    // the hierarchy and the lists are built on the host from one byte per cell
+    RawVec<uint8_t> labels(size_t(nx) * ny * nz);
+    if (hipMemcpy(labels.data(), labels_dev, labels.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        return failH(nullptr, MGPS_ERR_HIP, "mgps_create_device: copying the labels to the host failed");
+    return createFromDeviceWeights(out, nx, ny, nz, labels.data(), labels_dev, wx_dev, wy_dev, wz_dev, mg_levels, use_gauss_seidel, opt);
 }
 
 int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,

@@ -176,11 +176,15 @@ class GeometricMultigridPoissonSolver:
     arrays with one extra entry along their axis."""
 
     def __init__(self, labels, weights, mg_levels, use_gauss_seidel, do_print_stats=False, device=None, options=None):
-        if torch.is_tensor(labels):
-            labels = labels.cpu().numpy()  # the hierarchy is built on the host: 1 byte per cell
-        labels = _np_u8(labels)
-        nz, ny, nx = labels.shape
         on_device = all(torch.is_tensor(a) and a.is_cuda for a in weights)
+        labels_on_device = on_device and torch.is_tensor(labels) and labels.is_cuda and labels.dtype == torch.uint8
+        if labels_on_device:  # mgps_create_device: the library fetches its own host copy (1 byte per cell)
+            labels = labels.contiguous()
+        else:
+            if torch.is_tensor(labels):
+                labels = labels.cpu().numpy()
+            labels = _np_u8(labels)
+        nz, ny, nx = labels.shape
         if on_device:  # weights written on the device (fields.buildMGDomain) never cross to the host
             w = [a.contiguous() for a in weights]
             assert all(a.dtype == torch.float32 for a in w)
@@ -195,8 +199,9 @@ class GeometricMultigridPoissonSolver:
             opt.device = w[0].device.index
         self.h = C.c_void_p()
         wp = [C.c_void_p(a.data_ptr()) for a in w] if on_device else [_p(a) for a in w]
-        create = lib().mgps_create_device_weights if on_device else lib().mgps_create
-        check(create(C.byref(self.h), nx, ny, nz, _p(labels), wp[0], wp[1], wp[2], int(mg_levels), int(bool(use_gauss_seidel)), C.byref(opt)))
+        create = lib().mgps_create_device if labels_on_device else lib().mgps_create_device_weights if on_device else lib().mgps_create
+        lp = C.c_void_p(labels.data_ptr()) if labels_on_device else _p(labels)
+        check(create(C.byref(self.h), nx, ny, nz, lp, wp[0], wp[1], wp[2], int(mg_levels), int(bool(use_gauss_seidel)), C.byref(opt)))
         self.shape = (nz, ny, nx)
         self.use_gauss_seidel = bool(use_gauss_seidel)
         dev_index = opt.device if opt.device >= 0 else torch.cuda.current_device()

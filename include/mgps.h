@@ -160,6 +160,11 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
 int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
                                const float *wx_dev, const float *wy_dev, const float *wz_dev, int mg_levels,
                                int use_gauss_seidel, const mgps_options *opt);
+/* As above with the labels on the device too (mgps_fields_domain_labels + mgps_fields_set_boundary_labels write them
+ * there): the library fetches its own host copy of the 1 byte per cell the host-side hierarchy builder needs. */
+int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_dev, const float *wx_dev,
+                       const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
+                       const mgps_options *opt);
 void mgps_destroy(mgps_solver *h);
 int mgps_levels(const mgps_solver *h);                       /* getMGLevels(), MG.h:31 */
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3]);

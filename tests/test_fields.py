@@ -182,9 +182,11 @@ def test_solver_from_device_weights_equals_host_weights(with_solid, fo, oracle):
     lab8, w32 = lab.astype(np.uint8), [a.astype(np.float32) for a in w]
     b = rhs.astype(np.float32)
     results = []
-    for weights in (w32, [_dev(a, torch) for a in w32]):
+    # host labels + host weights (mgps_create), host labels + device weights (mgps_create_device_weights), both on
+    # the device (mgps_create_device)
+    for labels, weights in ((lab8, w32), (lab8, [_dev(a, torch) for a in w32]), (_dev(lab8, torch), [_dev(a, torch) for a in w32])):
         for use_gs in (False, True):
-            s = G.GeometricMultigridPoissonSolver(lab8, weights, levels, use_gs)
+            s = G.GeometricMultigridPoissonSolver(labels, weights, levels, use_gs)
             x, bd = s.new_grid(), s.to_device(b)
             s.applyVCycle(x, bd, False)
             xp = s.new_grid()
@@ -192,8 +194,9 @@ def test_solver_from_device_weights_equals_host_weights(with_solid, fo, oracle):
             results.append((x.cpu().numpy(), xp.cpu().numpy(), st["iterations"]))
             s.close()
     for k in range(2):
-        assert np.array_equal(results[k][0], results[k + 2][0]) and np.array_equal(results[k][1], results[k + 2][1])
-        assert results[k][2] == results[k + 2][2]
+        for other in (k + 2, k + 4):
+            assert np.array_equal(results[k][0], results[other][0]) and np.array_equal(results[k][1], results[other][1])
+            assert results[k][2] == results[other][2]
     # every face weight 1: cells that are BOUNDARY only through a cut face between two liquid cells lose their reason
     bad = [torch.ones_like(_dev(a, torch)) for a in w32]
     with pytest.raises(G.MgpsError):
@@ -218,7 +221,7 @@ def test_device_projection_is_divergence_free():
     valid = F.buildValidFaces(material, cw)
     labels, weights = F.buildMGDomain(material, cw, phi, valid, eshape, offset)
     rhs = F.buildRHS(material, vel, cw, eshape, offset, sv)
-    # only the labels (1 byte per cell) cross to the host for the hierarchy; the weights stay on the device
+    # labels and weights stay where the field passes wrote them (mgps_create_device fetches its own host copy of the labels)
     solver = G.GeometricMultigridPoissonSolver(labels, weights, levels, True)
     x = solver.new_grid()
     st = solver.solveGeometricConjugateGradient(x, rhs, 1e-6, 200, True)
