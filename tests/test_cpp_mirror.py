@@ -45,3 +45,22 @@ def test_mirror_solves_on_gpu():
     res = run()
     assert res.returncode == 0, res.stdout
     assert "iterations" in res.stdout
+
+
+def test_host_setup_under_sanitizers():
+    """The host-side set-up code (hierarchy, tile-local band lists, band groups, slab levels and deep halos)
+    compiled with g++ -fsanitize=address,undefined and driven over noisy domains, all band widths and stage
+    depths: no report, every group replay bit-exact (tests/cpp/host_setup_sanitize.cpp).  GPU code cannot run
+    under a sanitizer on this pool; this is the CPU half."""
+    src = os.path.join(ROOT, "tests", "cpp", "host_setup_sanitize.cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "build", "host_setup_sanitize")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, os.path.join(CSRC, "mgps_host.cpp"), "-o", out, "-lpthread",
+    ])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
+    env.pop("LD_PRELOAD", None)
+    res = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-4000:]
+    assert res.stdout.count(" ok: ") == 6 and "ERROR" not in res.stdout and "runtime error" not in res.stdout, res.stdout[-4000:]
