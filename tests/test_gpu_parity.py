@@ -383,6 +383,49 @@ def test_host_buffer_forms(domain_factory, oracle, torch_cuda):
     assert st["outcome"] == "converged"
 
 
+def test_distinct_handles_are_independent(domain_factory, torch_cuda):
+    """The boundary's threading rule: a handle is not thread-safe, distinct handles are
+    independent.  Two host threads create, use and destroy their own solvers at the same time, each on its own
+    stream; both reproduce what they compute alone (set-up runs its own helper threads: they must not meet)."""
+    import threading
+
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    torch = torch_cuda
+    jobs = [("simple", 64, False), ("solid", 64, True)]
+    inputs = [domain_factory(kind, g) for kind, g, _ in jobs]
+
+    def run(idx, out):
+        lab, w, off, lev, dx = inputs[idx]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            s = G.GeometricMultigridPoissonSolver(lab, w, lev, jobs[idx][2])
+            b = s.to_device(D.random_rhs(lab, dx))
+            x = s.new_grid()
+            for it in range(3):
+                s.applyVCycle(x, b, it > 0)
+            xp = s.new_grid()
+            st = s.solveGeometricConjugateGradient(xp, b, 1e-6, 100, True)
+            s.synchronize()
+            out[idx] = (x.cpu().numpy(), xp.cpu().numpy(), st["iterations"])
+            s.close()
+
+    alone = [None, None]
+    for i in range(2):
+        run(i, alone)
+    for _ in range(3):
+        together = [None, None]
+        threads = [threading.Thread(target=run, args=(i, together)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for i in range(2):
+            assert together[i] is not None
+            assert np.array_equal(together[i][0], alone[i][0]) and np.array_equal(together[i][1], alone[i][1])
+            assert together[i][2] == alone[i][2]
+
+
 def test_convergence_trace(domain_factory, oracle, torch_cuda):
     """testOneLevelVCycle (Test.cpp:1877-1960): b = 0, sine error, Jacobi V-cycles with
     useInitialGuess; the error norm must contract monotonically and track the oracle's trace."""
