@@ -37,6 +37,39 @@ const char *lastGlobalError()
     return copy.c_str();
 }
 
+namespace {
+std::atomic<void *(*)(size_t)> gBigAlloc{nullptr};
+std::atomic<void (*)(void *)> gBigFree{nullptr};
+constexpr size_t kBigHeader = 64;  // keeps the block 64-byte aligned; word 0 = the function that releases it
+}  // namespace
+void *hostBigAlloc(size_t bytes)
+{
+    void *(*alloc)(size_t) = gBigAlloc.load();
+    void (*release)(void *) = gBigFree.load();
+    void *raw = (alloc && release) ? alloc(bytes + kBigHeader) : nullptr;
+    if (!raw) {
+        raw = std::malloc(bytes + kBigHeader);
+        release = nullptr;
+    }
+    if (!raw) throw std::bad_alloc();
+    std::memcpy(raw, &release, sizeof(release));
+    return static_cast<char *>(raw) + kBigHeader;
+}
+void hostBigFree(void *p)
+{
+    if (!p) return;
+    void *raw = static_cast<char *>(p) - kBigHeader;
+    void (*release)(void *) = nullptr;
+    std::memcpy(&release, raw, sizeof(release));
+    if (release) release(raw);
+    else std::free(raw);
+}
+void setHostBigAllocator(void *(*alloc)(size_t), void (*release)(void *))
+{
+    gBigFree = release;
+    gBigAlloc = alloc;
+}
+
 static int fail(int code, const std::string &msg)
 {
     setLastGlobalError(msg);
@@ -136,22 +169,29 @@ static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
     cd.ny = fd.ny / 2;
     cd.nz = fd.nz / 2;
     coarse.d = cd;
-    coarse.labels.assign(cd.cells(), MGPS_EXTERIOR_CELL);
+    coarse.labels.resize(cd.cells());
     const uint8_t *fl = fine.labels.data();
     uint8_t *cl = coarse.labels.data();
     parallelFor(cd.nz, [&](int64_t k0, int64_t k1) {
+        // row-wise so that the compiler vectorises: the four fine rows of a coarse row are folded first, then pairs along x
+        std::vector<uint8_t> dir(size_t(fd.nx)), act(size_t(fd.nx));
         for (int k = int(k0); k < int(k1); ++k)
-            for (int j = 0; j < cd.ny; ++j)
-                for (int i = 0; i < cd.nx; ++i) {
-                    bool dirichlet = false, active = false;
-                    for (int c = 0; c < 8; ++c) {
-                        const uint8_t l = fl[fd.idx(2 * i + (c & 1), 2 * j + ((c >> 1) & 1), 2 * k + (c >> 2))];
-                        dirichlet |= (l == MGPS_DIRICHLET_CELL);
-                        active |= isActive(l);
-                    }
-                    cl[cd.idx(i, j, k)] = dirichlet ? MGPS_DIRICHLET_CELL
-                                                    : (active ? MGPS_INTERIOR_CELL : MGPS_EXTERIOR_CELL);
+            for (int j = 0; j < cd.ny; ++j) {
+                const uint8_t *r0 = fl + fd.idx(0, 2 * j, 2 * k), *r1 = r0 + fd.nx, *r2 = r0 + size_t(fd.nx) * fd.ny, *r3 = r2 + fd.nx;
+                uint8_t *dp = dir.data(), *ap = act.data();
+                for (int i = 0; i < fd.nx; ++i) {
+                    dp[i] = uint8_t((r0[i] == MGPS_DIRICHLET_CELL) | (r1[i] == MGPS_DIRICHLET_CELL) | (r2[i] == MGPS_DIRICHLET_CELL) |
+                                    (r3[i] == MGPS_DIRICHLET_CELL));
+                    ap[i] = uint8_t((r0[i] == MGPS_INTERIOR_CELL) | (r0[i] == MGPS_BOUNDARY_CELL) | (r1[i] == MGPS_INTERIOR_CELL) |
+                                    (r1[i] == MGPS_BOUNDARY_CELL) | (r2[i] == MGPS_INTERIOR_CELL) | (r2[i] == MGPS_BOUNDARY_CELL) |
+                                    (r3[i] == MGPS_INTERIOR_CELL) | (r3[i] == MGPS_BOUNDARY_CELL));
                 }
+                uint8_t *out = cl + cd.idx(0, j, k);
+                for (int i = 0; i < cd.nx; ++i) {
+                    const uint8_t dirichlet = dp[2 * i] | dp[2 * i + 1], active = ap[2 * i] | ap[2 * i + 1];
+                    out[i] = dirichlet ? uint8_t(MGPS_DIRICHLET_CELL) : (active ? uint8_t(MGPS_INTERIOR_CELL) : uint8_t(MGPS_EXTERIOR_CELL));
+                }
+            }
     });
     // second pass on a snapshot of "is this neighbour EXTERIOR or DIRICHLET" -- marking only turns
     // INTERIOR into BOUNDARY, neither of which the test looks for, so reading in place is safe
@@ -924,14 +964,14 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
         for (int64_t c : closure(z1 - 1 - depth, z1 - 1)) out.sendIdx[1].push_back(int32_t(c - ownedShift));
     }
     // output entries: the owned band cells, then the band cells of the two ghost planes
-    out.bandExt = L.bandDev;
+    out.bandExt.assign(L.bandDev.begin(), L.bandDev.end());
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[1].begin(), L.bandPlane[1].end());
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[3].begin(), L.bandPlane[3].end());
     W.allocEntryOf();
     for (size_t c = 0; c < wcells; ++c)
         if (band[c]) W.entryOf[c] = BandWindow::kDeepBand;
     W.seedCellOwn.resize(out.bandExt.size());
-    W.entryDiagOwn = L.bandDiag;
+    W.entryDiagOwn.assign(L.bandDiag.begin(), L.bandDiag.end());
     W.entryDiagOwn.resize(out.bandExt.size(), 0);
     W.nSeeds = out.bandExt.size();
     // rows of the neighbours' cells, when given: [ghost below][ghost above][z0-2 .. ][z1+1 ..], each plane in band order
@@ -1469,9 +1509,19 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
             return fail(MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)");
         }
     }
-    auto solvable = [](const HostLevel &L) {
-        for (uint8_t l : L.labels)
-            if (isActive(l)) return true;
+    auto solvable = [](const HostLevel &L) {  // any INTERIOR (0) or BOUNDARY (3) label; eight at a time through the padding
+        const uint8_t *p = L.labels.data();
+        const size_t n = L.labels.size();
+        constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
+        size_t c = 0;
+        for (; c + 8 <= n; c += 8) {
+            uint64_t v;
+            std::memcpy(&v, p + c, 8);
+            const uint64_t u = v ^ (k01 * uint64_t(MGPS_BOUNDARY_CELL));
+            if ((((v - k01) & ~v & k80) | ((u - k01) & ~u & k80)) != 0) return true;
+        }
+        for (; c < n; ++c)
+            if (isActive(p[c])) return true;
         return false;
     };
     if (!solvable(H->lv[0])) {  // MG.cpp:233

@@ -23,12 +23,30 @@ constexpr int kWaveChunkCells = 256;
 
 // std::vector that leaves trivially constructible elements uninitialised on resize(): the big set-up arrays are
 // filled by all host threads right after, and a serial zero-fill of 100+ MB costs more than that fill
+// Big blocks come from hostBigAlloc: page-locked memory once the solver layer has installed its allocator (a fresh
+// pageable array uploads at ~3 GB/s on this platform, a page-locked one at ~55 GB/s), plain malloc before that and
+// wherever no HIP device exists (the hierarchy alone needs none).
+void *hostBigAlloc(size_t bytes);
+void hostBigFree(void *p);
+void setHostBigAllocator(void *(*alloc)(size_t), void (*release)(void *));
+constexpr size_t kBigBlockBytes = size_t(1) << 20;
+
 template <class T>
 struct DefaultInitAllocator : std::allocator<T> {
     template <class U>
     struct rebind {
         using other = DefaultInitAllocator<U>;
     };
+    T *allocate(size_t n)
+    {
+        if (n * sizeof(T) >= kBigBlockBytes) return static_cast<T *>(hostBigAlloc(n * sizeof(T)));
+        return std::allocator<T>::allocate(n);
+    }
+    void deallocate(T *p, size_t n)
+    {
+        if (n * sizeof(T) >= kBigBlockBytes) hostBigFree(p);
+        else std::allocator<T>::deallocate(p, n);
+    }
     template <class U, class... Args>
     void construct(U *p, Args &&...args)
     {
@@ -68,8 +86,8 @@ struct HostLevel {
     std::vector<int32_t> bandTileStart;  // hierarchy levels: per 16^3 tile (+1) the first entry of its cells in `band`
     // device order of the same set: the BOUNDARY cells first (each in reference order), then the
     // INTERIOR band cells.  Jacobi on the band is compute-then-scatter, so the order is free.
-    std::vector<int32_t> bandDev;
-    std::vector<uint8_t> bandDiag;   // diagonal (1..6) of every bandDev entry that is not a general cell
+    RawVec<int32_t> bandDev;
+    RawVec<uint8_t> bandDiag;        // diagonal (1..6) of every bandDev entry that is not a general cell
     int32_t numBoundary = 0;         // bandDev[0 .. numBoundary) are the *general* BOUNDARY cells
     // operator rows of the general BOUNDARY cells (Ops.h:208-256 evaluated once at set-up), SoA:
     // rows[q*numBoundary + t], q = 0..5 the off-diagonal weight towards -x,+x,-y,+y,-z,+z (0 when that

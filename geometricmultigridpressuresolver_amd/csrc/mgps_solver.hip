@@ -711,8 +711,25 @@ int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
     return MGPS_OK;
 }
 
+// page-locked blocks for the big set-up arrays (see hostBigAlloc); nullptr sends the caller to malloc
+void *pinnedAlloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void pinnedFree(void *p) { (void)hipHostFree(p); }
+
 int pickDevice(const mgps_options &o, int *device)
 {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("MGPS_PINNED_SETUP");  // 0: pageable set-up arrays (A/B timing)
+        if (!e || e[0] != '0') setHostBigAllocator(pinnedAlloc, pinnedFree);
+    });
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return failH(nullptr, MGPS_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
