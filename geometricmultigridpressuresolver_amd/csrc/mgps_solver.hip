@@ -16,6 +16,7 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "mgps_internal.h"
@@ -712,16 +713,74 @@ int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
 }
 
 // page-locked blocks for the big set-up arrays (see hostBigAlloc); nullptr sends the caller to malloc
+// Page-locking costs ~45 us per MB each way, and a time-stepping caller builds a solver of much the same size every
+// step: released blocks are kept (up to a cap, MGPS_PINNED_CACHE_MB, default 4096) and handed out again.
+struct PinnedCache {
+    std::mutex guard;
+    std::vector<std::pair<size_t, void *>> free;                // (bytes, block) not in use
+    std::unordered_map<void *, size_t> size;                     // every live block, in use or cached
+    size_t cached = 0;
+    size_t cap = [] {
+        const char *e = getenv("MGPS_PINNED_CACHE_MB");
+        return size_t(e ? std::max(0, atoi(e)) : 4096) << 20;
+    }();
+};
+PinnedCache &pinnedCache()
+{
+    static PinnedCache *c = new PinnedCache();  // never destroyed: blocks may be released during process tear-down
+    return *c;
+}
 void *pinnedAlloc(size_t bytes)
 {
+    PinnedCache &c = pinnedCache();
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        size_t best = c.free.size();
+        for (size_t q = 0; q < c.free.size(); ++q)  // smallest cached block that fits without wasting more than half
+            if (c.free[q].first >= bytes && c.free[q].first <= bytes + bytes / 2 && (best == c.free.size() || c.free[q].first < c.free[best].first)) best = q;
+        if (best < c.free.size()) {
+            void *p = c.free[best].second;
+            c.cached -= c.free[best].first;
+            c.free.erase(c.free.begin() + ptrdiff_t(best));
+            return p;
+        }
+    }
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
+    std::lock_guard<std::mutex> lock(c.guard);
+    c.size[p] = bytes;
     return p;
 }
-void pinnedFree(void *p) { (void)hipHostFree(p); }
+void pinnedFree(void *p)
+{
+    PinnedCache &c = pinnedCache();
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        const auto it = c.size.find(p);
+        if (it != c.size.end() && c.cached + it->second <= c.cap) {
+            c.free.emplace_back(it->second, p);
+            c.cached += it->second;
+            return;
+        }
+        if (it != c.size.end()) c.size.erase(it);
+    }
+    (void)hipHostFree(p);
+}
+void pinnedTrim()
+{
+    PinnedCache &c = pinnedCache();
+    std::vector<std::pair<size_t, void *>> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        drop.swap(c.free);
+        c.cached = 0;
+        for (auto &b : drop) c.size.erase(b.second);
+    }
+    for (auto &b : drop) (void)hipHostFree(b.second);
+}
 
 int pickDevice(const mgps_options &o, int *device)
 {
@@ -883,6 +942,8 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
 extern "C" {
 
 const char *mgps_last_error(const mgps_solver *h) { return h ? h->lastError.c_str() : lastGlobalError(); }
+
+void mgps_trim_host_cache(void) { pinnedTrim(); }
 
 int mgps_device_count(int *count)
 {

@@ -166,6 +166,10 @@ int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t 
                        const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
                        const mgps_options *opt);
 void mgps_destroy(mgps_solver *h);
+/* Set-up stages its lists through page-locked host blocks and keeps released ones for the next solver (a new one
+ * every sub-step in the reference's use, Plug.cpp:463; cap: MGPS_PINNED_CACHE_MB, default 4096).  This returns
+ * them to the system. */
+void mgps_trim_host_cache(void);
 int mgps_levels(const mgps_solver *h);                       /* getMGLevels(), MG.h:31 */
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3]);
 const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *h);
