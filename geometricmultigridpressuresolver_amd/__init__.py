@@ -18,3 +18,9 @@ from .solver import (  # noqa: E402,F401
     unit_test_coarsening,
     unit_test_exterior_cells,
 )
+
+
+def trim_host_cache():
+    """Return the page-locked staging blocks the set-up keeps between solvers (mgps_trim_host_cache)."""
+    lib().mgps_trim_host_cache.restype = None
+    lib().mgps_trim_host_cache()
