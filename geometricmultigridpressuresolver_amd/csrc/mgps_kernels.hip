@@ -498,7 +498,7 @@ constexpr int kHalo = kTile + 2;
 constexpr int kHalo3 = kHalo * kHalo * kHalo;
 constexpr int kTile3 = kTile * kTile * kTile;
 constexpr int kPlanes = 3 * (kTile - 1) + 1;
-constexpr int kRowPool = 1024;  // BOUNDARY rows of one tile kept in LDS; the rest is read from memory
+constexpr int kRowPool = 240;   // BOUNDARY rows of one tile kept in LDS (the rest is read from memory): 53.3 KB in all, three tiles per CU
 
 __device__ __forceinline__ int haloIdx(int li, int lj, int lk) { return ((lk + 1) * kHalo + (lj + 1)) * kHalo + (li + 1); }
 
@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
                 if (simpleCell(l)) {
                     diag = simpleDiag(l);
                     lap = diag * xc - (xn[0] + xn[1] + xn[2] + xn[3] + xn[4] + xn[5]);
+                    sx[h] = xc + (bc - lap) * simpleRcp(diag);  // undamped, Ops.h:493 (reciprocal as in the Jacobi kernels)
                 } else {
                     const int row = lk * kTile + lj;
                     const int t = int(rowStart[row]) + __popc(unsigned(rowMask[row]) & ((1u << li) - 1u));
@@ -674,19 +675,22 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
                     for (int q = 0; q < 6; ++q) acc -= w[q] * xn[q];
                     diag = w[6];
                     lap = acc + diag * xc;
+                    sx[h] = xc + (bc - lap) / diag;
                 }
-                sx[h] = xc + (bc - lap) / diag;  // undamped, Ops.h:493
             }
         }
         __syncthreads();
     }
-    for (int h = threadIdx.x; h < kTile3; h += blockDim.x) {
-        const int ci = h % kTile, cj = (h / kTile) % kTile, ck = h / (kTile * kTile);
-        const int gi = i0 + ci, gj = j0 + cj, gk = k0 + ck;
-        if (gi < g.nx && gj < g.ny && gk < g.nz) {
-            const int hh = haloIdx(ci, cj, ck);
-            if (activeLabel(sl[hh])) x[(size_t(gk) * g.ny + gj) * g.nx + gi] = sx[hh];
-        }
+    // whole quads where the grid has them (inactive cells still hold the value they were loaded with: exactly 0)
+    for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
+        const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
+        const int gi = i0 + 4 * q, gj = j0 + cj, gk = k0 + ck;
+        if (gj >= g.ny || gk >= g.nz || gi >= g.nx) continue;
+        const float *src = sx + haloIdx(4 * q, cj, ck);
+        float *dst = x + (size_t(gk) * g.ny + gj) * g.nx + gi;
+        if (gi + 3 < g.nx && (g.nx & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+        else
+            for (int e = 0; e < 4 && gi + e < g.nx; ++e) dst[e] = src[e];
     }
 }
 
