@@ -288,6 +288,8 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
                    double *resultDev);
 int launchZero(void *stream, float *a, size_t count);
+// the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)
+int launchZeroActive(void *stream, const GridP &g, float *a);
 // buf[t] = a[idx[t]] / a[idx[t]] = buf[t]; idx are offsets from owned cell 0 (negative in the lower ghost plane)
 int launchPack(void *stream, float *buf, const float *a, const int32_t *idx, int n);
 int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, int n);

@@ -387,7 +387,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     return MGPS_OK;
 }
 
-int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess);
+int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid = false);
 
 // levels distLevels .. totalLevels-1 of a slab run: gather the rhs of the collapse level to rank 0,
 // run the rest of the cycle there on the whole grid, scatter the correction back
@@ -413,7 +413,21 @@ int zeroGrid(mgps_solver *h, float *a, const Dims &d, bool withGhosts)
     return MGPS_OK;
 }
 
-int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
+// a grid of the solver's own (level l): chunks without active cells are never written, they still hold their initial 0
+int zeroOwnGrid(mgps_solver *h, int l, float *a, bool withGhosts)
+{
+    DevLevel &L = h->lv[l];
+    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    MGPS_LAUNCH(h, launchZeroActive(h->stream, L.g, a));
+    if (withGhosts && h->dist) {
+        MGPS_LAUNCH(h, launchZero(h->stream, a - plane, plane));
+        MGPS_LAUNCH(h, launchZero(h->stream, a + L.d.cells(), plane));
+    }
+    return MGPS_OK;
+}
+
+// ownGrid: x is one of the solver's own grids (see zeroOwnGrid)
+int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid)
 {
     const int nlv = int(h->lv.size());
     if (h->tailOfSlabRun && nlv == 1) {  // the tail of a slab run can be the direct solve alone
@@ -430,7 +444,8 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
     other[0] = h->lv[0].tmp;
     bool fresh = false;
     if (!useInitialGuess) {  // MG.cpp:439-440
-        MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
+        if (ownGrid) MGPS_TRY(zeroOwnGrid(h, 0, x, true));
+        else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
     MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh));
@@ -442,7 +457,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
                 cur[l] = F.x;
                 other[l] = F.tmp;
                 rhs = F.b;
-                MGPS_TRY(zeroGrid(h, F.x, F.d, true));  // MG.cpp:566
+                MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
             MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
@@ -529,7 +544,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         return MGPS_OK;
     };
     auto precondition = [&](float *dst, const float *src) -> int {
-        if (useMG) return vcycle(h, dst, src, false);  // Plug.cpp:468-472
+        if (useMG) return vcycle(h, dst, src, false, true);  // Plug.cpp:468-472 (dst = p or z: grids of the solver)
         MGPS_LAUNCH(h, launchMulMasked(h->stream, F.g, dst, src, h->dinv));  // Plug.cpp:555-606
         return MGPS_OK;
     };
