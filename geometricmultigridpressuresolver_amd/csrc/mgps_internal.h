@@ -233,6 +233,10 @@ enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };
 size_t stencilSweptCells(const GridP &g);
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                   bool skipInactive);
+// out = A x and *resultDev = <x, A x> over the active cells of level g in one pass (the CG loop's A.p and its dot);
+// `partials` holds applyDotPartialCount(g) doubles
+size_t applyDotPartialCount(const GridP &g);
+int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, double *partials, double *resultDev);
 // band = device-ordered band list (BOUNDARY cells first, g.nbnd of them)
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                      float *bandTmp, float omega);

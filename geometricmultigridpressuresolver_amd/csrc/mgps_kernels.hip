@@ -94,6 +94,23 @@ __device__ __forceinline__ float inactiveValue(float xc)
     return OP == OP_JACOBI ? xc : 0.f;  // Jacobi leaves inactive cells alone; r and y are 0 there
 }
 
+// Sum of `acc` over the workgroup (up to 1024 threads), left in partials[slot] by thread 0: the A.p launches of the
+// CG loop also deliver their share of <p, A p> (CG.h:110-121) instead of a second pass over p and A p.
+__device__ __forceinline__ void blockDotStore(double acc, double *__restrict__ partials, unsigned slot)
+{
+    __shared__ double part[16];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = part[0];
+        for (int w = 1; w < int((blockDim.x * blockDim.y + kWave - 1) / kWave); ++w) total += part[w];
+        partials[slot] = total;
+    }
+}
+
 // XCD-aware block remap: the hardware deals consecutive block ids round-robin over the 8 XCDs, each
 // with a private 4 MiB L2.  Giving every XCD one contiguous run of logical blocks keeps the y/z
 // neighbour rows a block re-reads inside the L2 that already holds them.  Pure speed: any mapping
@@ -111,10 +128,10 @@ __device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
 // shorter rows).  x-1 / x+1 come from the neighbouring lanes (ds_bpermute), row ends from memory.
 // Requires nx % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int OP>
+template <int OP, bool DOT = false>
 __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
                                                           const float *__restrict__ b, float omega, unsigned nblocks,
-                                                          const int32_t *__restrict__ chunks)
+                                                          const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr)
 {
     const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
     const size_t rows = size_t(g.ny) * g.nz;
@@ -176,6 +193,13 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
         if (g.streaming) __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
         else *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
     }
+    if (DOT) {  // general BOUNDARY cells add theirs in boundaryOpKernel
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (valid && simpleCell(ls[e])) acc += double(xs[e + 1]) * double(res[e]);
+        blockDotStore(acc, dotPartials, blockIdx.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -189,13 +213,15 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
 // ---------------------------------------------------------------------------------------------
 constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the rows 16-byte aligned
 
-template <int OP>
+template <int OP, bool DOT = false>
 __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ b, float omega,
                                                                       unsigned nbx, unsigned nby, unsigned nbz, int zc,
-                                                                      const int32_t *__restrict__ blocks)
+                                                                      const int32_t *__restrict__ blocks,
+                                                                      double *__restrict__ dotPartials = nullptr)
 {
+    double dotAcc = 0.0;
     __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
     unsigned bid = remapBlock(blockIdx.x, gridDim.x);
     if (blocks) bid = unsigned(blocks[bid]);  // only blocks that hold active cells
@@ -263,6 +289,11 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         }
         if (valid)  // streamed out: nothing re-reads the sweep's output before it has left the caches (+5 % at 1024^3)
             __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
+        if (DOT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (valid && simpleCell(ls[e])) dotAcc += double(xs[e + 1]) * double(res[e]);
+        }
         xm = xc;
         xc = xp;
         bc = bn;
@@ -272,40 +303,54 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         c = cn;
         buf ^= 1;
     }
+    if (DOT) {
+        __syncthreads();  // (the LDS planes are done with)
+        blockDotStore(dotAcc, dotPartials, blockIdx.x);
+    }
 }
 
 // Scalar fallback for levels whose nx is not a multiple of 4 (only the tiniest coarse levels).
-template <int OP>
+template <int OP, bool DOT = false>
 __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
-                                    const float *__restrict__ b, float omega)
+                                    const float *__restrict__ b, float omega, double *__restrict__ dotPartials = nullptr)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const unsigned l = g.lab[c];
-    const float xc = x[c];
-    if (!simpleCell(l)) {
-        out[c] = inactiveValue<OP>(xc);
-        return;
+    double acc = 0.0;
+    if (c < n) {
+        const unsigned l = g.lab[c];
+        const float xc = x[c];
+        if (!simpleCell(l)) out[c] = inactiveValue<OP>(xc);
+        else {
+            const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+            const float diag = simpleDiag(l);
+            const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+            const float res = epilogueRcp<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, simpleRcp(diag), omega);
+            out[c] = res;
+            acc = double(xc) * double(res);
+        }
     }
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const float diag = simpleDiag(l);
-    const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-    out[c] = epilogueRcp<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, simpleRcp(diag), omega);
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
 // BOUNDARY cells of a full-domain sweep: one thread per list entry, out of place like the sweep.
-template <int OP>
+template <int OP, bool DOT = false>
 __global__ void boundaryOpKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
-                                 const float *__restrict__ b, float omega, unsigned nblocks)
+                                 const float *__restrict__ b, float omega, unsigned nblocks, double *__restrict__ dotPartials = nullptr)
 {
     const unsigned block = remapBlock(blockIdx.x, nblocks);
     const int t = int(block * blockDim.x + threadIdx.x);
-    if (t >= g.nbnd) return;
-    const size_t c = size_t(g.bnd[t]);
-    float lap, diag;
-    boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
-    out[c] = epilogue<OP>(x[c], OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+    double acc = 0.0;
+    if (t < g.nbnd) {
+        const size_t c = size_t(g.bnd[t]);
+        float lap, diag;
+        boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
+        const float xc = x[c];
+        const float res = epilogue<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+        out[c] = res;
+        acc = double(xc) * double(res);
+    }
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1212,6 +1257,72 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
             default: boundaryOpKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
         }
     }
+    return int(hipGetLastError());
+}
+
+// blocks of the main launch of a sweep over level g (same choice of kernel as launchStencil)
+static unsigned sweepBlocks(const GridP &g, bool skipInactive, int *path)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const int forced = forcedStencil();
+    const int zc = g.planeZc;
+    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
+    if (zc && (forced == 2 || (forced == 0 && planeWins))) {
+        *path = 0;
+        const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;
+        return (skipInactive && g.planeBlocks) ? unsigned(g.nplaneBlocks) : nbx * nby * nbz;
+    }
+    if ((g.nx & 3) == 0) {
+        *path = 1;
+        return (skipInactive && g.chunks) ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
+    }
+    *path = 2;
+    return blocksFor(n, 256);
+}
+
+size_t applyDotPartialCount(const GridP &g)
+{
+    int path;
+    const unsigned a = sweepBlocks(g, true, &path), b = sweepBlocks(g, false, &path);
+    return size_t(std::max(a, b)) + blocksFor(size_t(std::max(g.nbnd, 0)), 256) + 64 + 1;
+}
+
+// stage 1 of the final sum: `nout` workgroups fold contiguous runs of the partials, in a fixed order
+__global__ __launch_bounds__(256) void foldPartialsKernel(int nparts, const double *__restrict__ partials, double *__restrict__ out)
+{
+    const int per = (nparts + int(gridDim.x) - 1) / int(gridDim.x);
+    const int lo = int(blockIdx.x) * per, hi = min(nparts, lo + per);
+    double acc = 0.0;
+    for (int p = lo + int(threadIdx.x); p < hi; p += int(blockDim.x)) acc += partials[p];
+    blockDotStore(acc, out, blockIdx.x);
+}
+
+// out = A x on level g and *resultDev = <x, A x> over the active cells, in one pass over x (CG.h:110-121)
+int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, double *partials, double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int path = 0;
+    const unsigned nb = sweepBlocks(g, true, &path);
+    if (path == 0) {
+        const int zc = g.planeZc;
+        const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;
+        if (nb > 0) stencilPlaneKernel<OP_APPLY, true><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, nullptr, 0.f, nbx, nby, nbz, zc, g.planeBlocks, partials);
+    } else if (path == 1) {
+        if (nb > 0) stencilQuadKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nb, g.chunks, partials);
+    } else
+        stencilScalarKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, partials);
+    unsigned nparts = nb;
+    if (g.nbnd > 0) {
+        const unsigned nbb = blocksFor(size_t(g.nbnd), 256);
+        boundaryOpKernel<OP_APPLY, true><<<nbb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nbb, partials + nparts);
+        nparts += nbb;
+    }
+    if (nparts > 4096) {
+        double *folded = partials + nparts;  // (applyDotPartialCount leaves 64 slots behind the partials)
+        foldPartialsKernel<<<64, 256, 0, s>>>(int(nparts), partials, folded);
+        reduceFinalKernel<0><<<1, 256, 0, s>>>(64, folded, resultDev);
+    } else
+        reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nparts), partials, resultDev);
     return int(hipGetLastError());
 }
 

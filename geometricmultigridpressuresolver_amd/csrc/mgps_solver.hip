@@ -84,6 +84,7 @@ struct mgps_solver {
     bool tailOfSlabRun = false;  // this solver is the collapsed tail owned by rank 0 of a slab run
     // reductions
     double *partials = nullptr, *resultDev = nullptr, *resultHost = nullptr;
+    double *dotPartials = nullptr;  // per-workgroup shares of <p, A p> from the fused A.p launch of the CG loop
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
     float *pcg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *dinv = nullptr;
@@ -223,6 +224,7 @@ void freeAll(mgps_solver *h)
     (void)hipFree(h->ccells);
     (void)hipFree(h->partials);
     (void)hipFree(h->resultDev);
+    (void)hipFree(h->dotPartials);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
     if (!h->lv.empty()) {
         for (int q = 0; q < 4; ++q) gridFree(h->pcg[q], h->lv[0].d);
@@ -504,6 +506,7 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
 {
     for (int q = 0; q < 4; ++q)
         if (!h->pcg[q]) MGPS_TRY(gridAlloc(h, &h->pcg[q], h->lv[0].d));
+    if (!h->dotPartials) MGPS_TRY(devAlloc(h, &h->dotPartials, applyDotPartialCount(h->lv[0].g), true));
     if (needDiag && !h->dinv) {
         MGPS_TRY(gridAlloc(h, &h->dinv, h->lv[0].d));
         MGPS_LAUNCH(h, launchDiagInverse(h->stream, h->lv[0].g, h->dinv));
@@ -575,9 +578,11 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             st->iterations = it;
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
         }
-        MGPS_TRY(applyOp(h, OP_APPLY, 0, t, p, nullptr, true));  // CG.h:110
+        // t = A p (CG.h:110) and <p, A p> (CG.h:121) in one pass over p
+        MGPS_TRY(exchangeGhosts(h, 0, p));
+        MGPS_LAUNCH(h, launchApplyDot(h->stream, F.g, t, p, h->dotPartials, h->resultDev));
         double pAp = 0;
-        MGPS_TRY(reduceToHost(h, 0, 0, p, t, &pAp));
+        MGPS_TRY(fetchReduction(h, 0, &pAp));
         const double alpha = absNew / pAp;                                               // CG.h:121
         // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
         MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev));
