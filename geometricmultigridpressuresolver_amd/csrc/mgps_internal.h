@@ -238,8 +238,14 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 size_t applyDotPartialCount(const GridP &g);
 int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, double *partials, double *resultDev);
 // band = device-ordered band list (BOUNDARY cells first, g.nbnd of them)
+// dotPartials (optional, here and below): the scatter leaves per-workgroup sums of (new - old) * b in
+// bandScatterBlocks(nband) slots (see launchStencilDot)
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                     float *bandTmp, float omega);
+                     float *bandTmp, float omega, double *dotPartials = nullptr);
+unsigned bandScatterBlocks(int nband);
+int launchStencilDot(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
+                     double *partials, unsigned *nparts);
+int launchFoldDot(void *stream, double *partials, unsigned nparts, double *resultDev);
 // bg.depth fused band passes (device copy of BandGroups)
 struct BandGroupsDev {
     int depth = 0, ngroups = 0;
@@ -251,7 +257,7 @@ struct BandGroupsDev {
 // addressed by band entry - foreignBase
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                     float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr,
-                    const float *frows = nullptr, int foreignBase = 0, int nForeign = 0);
+                    const float *frows = nullptr, int foreignBase = 0, int nForeign = 0, double *dotPartials = nullptr);
 // one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
 // that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the
 // two lists into the halo arrays and the last part into the band cells of the ghost plane of b (the grids'
@@ -269,7 +275,7 @@ int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const f
 int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
-                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward);
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials = nullptr);
 // codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
 int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, const uint8_t *bandDiag, int nbnd, int nband);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);

@@ -93,6 +93,13 @@ __device__ __forceinline__ float inactiveValue(float xc)
 {
     return OP == OP_JACOBI ? xc : 0.f;  // Jacobi leaves inactive cells alone; r and y are 0 there
 }
+// what a sweep with the DOT flag sums over the active cells besides its own work: <x, A x> for A.x (the CG loop's
+// <p, A p>), <x', b> for the Jacobi sweep (the last sweep of a preconditioning V-cycle delivers <z, r>, CG.h:86, 180)
+template <int OP>
+__device__ __forceinline__ double dotTerm(float xc, float bc, float res)
+{
+    return OP == OP_JACOBI ? double(res) * double(bc) : double(xc) * double(res);
+}
 
 // Sum of `acc` over the workgroup (up to 1024 threads), left in partials[slot] by thread 0: the A.p launches of the
 // CG loop also deliver their share of <p, A p> (CG.h:110-121) instead of a second pass over p and A p.
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (valid && simpleCell(ls[e])) acc += double(xs[e + 1]) * double(res[e]);
+            if (valid && simpleCell(ls[e])) acc += dotTerm<OP>(xs[e + 1], bs[e], res[e]);
         blockDotStore(acc, dotPartials, blockIdx.x);
     }
 }
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         if (DOT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (valid && simpleCell(ls[e])) dotAcc += double(xs[e + 1]) * double(res[e]);
+                if (valid && simpleCell(ls[e])) dotAcc += dotTerm<OP>(xs[e + 1], bs[e], res[e]);
         }
         xm = xc;
         xc = xp;
@@ -325,9 +332,10 @@ __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const floa
             const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
             const float diag = simpleDiag(l);
             const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-            const float res = epilogueRcp<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, simpleRcp(diag), omega);
+            const float bc = OP == OP_APPLY ? 0.f : b[c];
+            const float res = epilogueRcp<OP>(xc, bc, lap, simpleRcp(diag), omega);
             out[c] = res;
-            acc = double(xc) * double(res);
+            acc = dotTerm<OP>(xc, bc, res);
         }
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
@@ -345,10 +353,10 @@ __global__ void boundaryOpKernel(GridP g, float *__restrict__ out, const float *
         const size_t c = size_t(g.bnd[t]);
         float lap, diag;
         boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
-        const float xc = x[c];
-        const float res = epilogue<OP>(xc, OP == OP_APPLY ? 0.f : b[c], lap, diag, omega);
+        const float xc = x[c], bc = OP == OP_APPLY ? 0.f : b[c];
+        const float res = epilogue<OP>(xc, bc, lap, diag, omega);
         out[c] = res;
-        acc = double(xc) * double(res);
+        acc = dotTerm<OP>(xc, bc, res);
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
@@ -378,11 +386,22 @@ __global__ void bandComputeKernel(GridP g, const float *__restrict__ x, const fl
         tmp[t] = xc + omega * ((b[c] - lap) / diag);
     }
 }
+// DOT: the workgroup also leaves sum (new - old) * b over its cells: the correction that turns <x, b> taken before the
+// band passes into <x, b> after them
+template <bool DOT = false>
 __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restrict__ band, int nband,
-                                  const float *__restrict__ tmp, unsigned nblocks)
+                                  const float *__restrict__ tmp, unsigned nblocks, const float *__restrict__ b = nullptr,
+                                  double *__restrict__ dotPartials = nullptr)
 {
     const int t = int(remapBlock(blockIdx.x, nblocks) * blockDim.x + threadIdx.x);
-    if (t < nband) x[band[t]] = tmp[t];  // Ops.h:604-618
+    double acc = 0.0;
+    if (t < nband) {
+        const int32_t c = band[t];
+        const float v = tmp[t];
+        if (DOT) acc = (double(v) - double(x[c])) * double(b[c]);
+        x[c] = v;  // Ops.h:604-618
+    }
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
 // `depth` consecutive band passes in one launch (BandGroups in mgps_internal.h): a workgroup stages the
@@ -614,8 +633,10 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
     }
 }
 
+template <bool DOT = false>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
 __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
-                                                         const int32_t *__restrict__ tiles, int forward)
+                                                         const int32_t *__restrict__ tiles, int forward,
+                                                         double *__restrict__ dotPartials = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
@@ -637,17 +658,26 @@ __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restr
         }
         __syncthreads();
     }
+    double acc = 0.0;
     for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
         const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
         const float *src = sx + haloIdx(4 * q, cj, ck);
         *reinterpret_cast<float4 *>(x + (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q) =
             make_float4(src[0], src[1], src[2], src[3]);
+        if (DOT) {
+            const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += double(src[e]) * double(bq[e]);
+        }
     }
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
+template <bool DOT = false>
 __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
                                                           const int32_t *__restrict__ tiles,
-                                                          const int32_t *__restrict__ tileBndStart, int forward)
+                                                          const int32_t *__restrict__ tileBndStart, int forward,
+                                                          double *__restrict__ dotPartials = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
@@ -727,6 +757,7 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
         __syncthreads();
     }
     // whole quads where the grid has them (inactive cells still hold the value they were loaded with: exactly 0)
+    double acc = 0.0;
     for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
         const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
         const int gi = i0 + 4 * q, gj = j0 + cj, gk = k0 + ck;
@@ -736,7 +767,14 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
         if (gi + 3 < g.nx && (g.nx & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(src[0], src[1], src[2], src[3]);
         else
             for (int e = 0; e < 4 && gi + e < g.nx; ++e) dst[e] = src[e];
+        if (DOT) {
+            const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
+            const unsigned char *lq = sl + haloIdx(4 * q, cj, ck);
+            for (int e = 0; e < 4 && gi + e < g.nx; ++e)
+                if (activeLabel(lq[e])) acc += double(src[e]) * double(bq[e]);
+        }
     }
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1297,28 +1335,48 @@ __global__ __launch_bounds__(256) void foldPartialsKernel(int nparts, const doub
     blockDotStore(acc, out, blockIdx.x);
 }
 
-// out = A x on level g and *resultDev = <x, A x> over the active cells, in one pass over x (CG.h:110-121)
-int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, double *partials, double *resultDev)
+// A sweep (A.x, or the out-of-place Jacobi sweep) that also leaves its per-workgroup shares of the dot product of
+// dotTerm in partials[0 .. *nparts); launchFoldDot sums them (with whatever other launches appended) in a fixed order
+int launchStencilDot(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
+                     double *partials, unsigned *nparts)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     int path = 0;
     const unsigned nb = sweepBlocks(g, true, &path);
+    const bool jac = op == OP_JACOBI;
     if (path == 0) {
         const int zc = g.planeZc;
         const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;
-        if (nb > 0) stencilPlaneKernel<OP_APPLY, true><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, nullptr, 0.f, nbx, nby, nbz, zc, g.planeBlocks, partials);
+        if (nb > 0) {
+            if (jac) stencilPlaneKernel<OP_JACOBI, true><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, g.planeBlocks, partials);
+            else stencilPlaneKernel<OP_APPLY, true><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, nullptr, 0.f, nbx, nby, nbz, zc, g.planeBlocks, partials);
+        }
     } else if (path == 1) {
-        if (nb > 0) stencilQuadKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nb, g.chunks, partials);
-    } else
-        stencilScalarKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, partials);
-    unsigned nparts = nb;
+        if (nb > 0) {
+            if (jac) stencilQuadKernel<OP_JACOBI, true><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, partials);
+            else stencilQuadKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nb, g.chunks, partials);
+        }
+    } else {
+        if (jac) stencilScalarKernel<OP_JACOBI, true><<<nb, 256, 0, s>>>(g, out, x, b, omega, partials);
+        else stencilScalarKernel<OP_APPLY, true><<<nb, 256, 0, s>>>(g, out, x, nullptr, 0.f, partials);
+    }
+    unsigned used = nb;
     if (g.nbnd > 0) {
         const unsigned nbb = blocksFor(size_t(g.nbnd), 256);
-        boundaryOpKernel<OP_APPLY, true><<<nbb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nbb, partials + nparts);
-        nparts += nbb;
+        if (jac) boundaryOpKernel<OP_JACOBI, true><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, partials + used);
+        else boundaryOpKernel<OP_APPLY, true><<<nbb, 256, 0, s>>>(g, out, x, nullptr, 0.f, nbb, partials + used);
+        used += nbb;
     }
+    *nparts = used;
+    return int(hipGetLastError());
+}
+
+// *resultDev = sum of partials[0 .. nparts); the 64 slots behind them are scratch
+int launchFoldDot(void *stream, double *partials, unsigned nparts, double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (nparts > 4096) {
-        double *folded = partials + nparts;  // (applyDotPartialCount leaves 64 slots behind the partials)
+        double *folded = partials + nparts;
         foldPartialsKernel<<<64, 256, 0, s>>>(int(nparts), partials, folded);
         reduceFinalKernel<0><<<1, 256, 0, s>>>(64, folded, resultDev);
     } else
@@ -1326,14 +1384,23 @@ int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, dou
     return int(hipGetLastError());
 }
 
+// out = A x on level g and *resultDev = <x, A x> over the active cells, in one pass over x (CG.h:110-121)
+int launchApplyDot(void *stream, const GridP &g, float *out, const float *x, double *partials, double *resultDev)
+{
+    unsigned nparts = 0;
+    const int e = launchStencilDot(stream, OP_APPLY, g, out, x, nullptr, 0.f, partials, &nparts);
+    return e ? e : launchFoldDot(stream, partials, nparts, resultDev);
+}
+
 int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                     float *bandTmp, float omega)
+                     float *bandTmp, float omega, double *dotPartials)
 {
     if (nband <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned nb = blocksFor(size_t(nband), 256);
     bandComputeKernel<<<nb, 256, 0, s>>>(g, x, b, band, nband, bandTmp, omega, nb);
-    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    if (dotPartials) bandScatterKernel<true><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb, b, dotPartials);
+    else bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());
 }
 
@@ -1381,7 +1448,7 @@ int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float
 
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                     float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb, const float *frows,
-                    int foreignBase, int nForeign)
+                    int foreignBase, int nForeign, double *dotPartials)
 {
     if (nband <= 0 || bg.ngroups <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1389,15 +1456,23 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
                                                                   bg.readCell, bandTmp, omega, bg.depth, hx, hb, frows, foreignBase,
                                                                   nForeign);
     const unsigned nb = blocksFor(size_t(nband), 256);
-    bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    if (dotPartials) bandScatterKernel<true><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb, b, dotPartials);
+    else bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
     return int(hipGetLastError());
 }
+unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
 
+// dotPartials (optional): nmixed + npure slots, one per tile, mixed tiles first
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
-                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward)
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     // same colour => no two tiles of either launch share a face: the two launches are independent
+    if (dotPartials) {
+        if (nmixed > 0) tiledGSMixedKernel<true><<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, dotPartials);
+        if (npure > 0) tiledGSPureKernel<true><<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, dotPartials + nmixed);
+        return int(hipGetLastError());
+    }
     if (nmixed > 0) tiledGSMixedKernel<<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward);
     if (npure > 0) tiledGSPureKernel<<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward);
     return int(hipGetLastError());

@@ -85,6 +85,10 @@ struct mgps_solver {
     // reductions
     double *partials = nullptr, *resultDev = nullptr, *resultHost = nullptr;
     double *dotPartials = nullptr;  // per-workgroup shares of <p, A p> from the fused A.p launch of the CG loop
+    // the last stroke of a preconditioning V-cycle also gathers <x, b> (= <z, r>, CG.h:86 / 180) when asked to:
+    // the sweep leaves <x', b>, every band scatter after it the correction sum (new - old) b
+    bool gatherDot = false;
+    unsigned dotUsed = 0;
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
     float *pcg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *dinv = nullptr;
@@ -321,27 +325,40 @@ bool bandStageCompletesGhosts(const mgps_solver *h, int l)
 }
 
 // `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
-int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first)
+// dot (single-device runs only): the scatters append their corrections to h->dotPartials (see mgps_solver::gatherDot)
+int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first, bool dot = false)
 {
     DevLevel &L = h->lv[l];
     if (bandStageCompletesGhosts(h, l)) return bandStageDeep(h, l, x, b);
+    auto sink = [&]() -> double * {
+        if (!dot || L.nband <= 0) return nullptr;
+        double *p = h->dotPartials + h->dotUsed;
+        h->dotUsed += bandScatterBlocks(L.nband);
+        return p;
+    };
     if (L.bandGroups.ngroups > 0 && L.bandGroups.depth == h->opt.band_iterations) {  // level is not cut: no exchanges
-        MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, L.bandGroups));
+        MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, L.bandGroups, nullptr,
+                                       nullptr, nullptr, 0, 0, sink()));
         return MGPS_OK;
     }
     for (int it = 0; it < h->opt.band_iterations; ++it) {
         MGPS_TRY(exchangeGhosts(h, l, x, it == 0 ? first : GHOST_BAND));
-        MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
+        MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, sink()));
     }
     return MGPS_OK;
 }
 
-int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL)
+int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL, bool dot = false)
 {
     DevLevel &L = h->lv[l];
     MGPS_TRY(exchangeGhosts(h, l, x, ghosts));  // the other colour's tiles across the cut changed in the previous pass
+    double *sink = nullptr;
+    if (dot) {  // every tile is swept once per sweep: its values after its colour's pass are the sweep's
+        sink = h->dotPartials + h->dotUsed;
+        h->dotUsed += unsigned(L.npure[odd] + L.nmixed[odd]);
+    }
     MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
-                                 L.tileBndStart, forward));
+                                 L.tileBndStart, forward, sink));
     return MGPS_OK;
 }
 
@@ -350,7 +367,8 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
 // ghostsFresh: the ghosts of `cur` are known to be complete on entry (all zero after a clear).
 // Ghost traffic of a stroke: whole planes after whatever rewrote the whole grid (the caller's
 // prolongation / initial guess, the full-domain smoother), packed band cells after band passes.
-int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh)
+// dot: see mgps_solver::gatherDot (the caller folds the partials afterwards)
+int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh, bool dot = false)
 {
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
@@ -370,26 +388,31 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     }
     if (h->useGS) {
         if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, afterBands));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_FULL));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, afterBands, dot));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_FULL, dot));
         } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, afterBands));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_FULL));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, afterBands, dot));
+            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_FULL, dot));
         }
     } else {
         MGPS_TRY(exchangeGhosts(h, l, cur, afterBands));
-        MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, true));
+        if (dot) {
+            unsigned used = 0;
+            MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
+            h->dotUsed += used;
+        } else
+            MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, true));
         std::swap(cur, other);
     }
     if (timed) {
         MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + 1], h->stream));
         h->profUsed += 2;
     }
-    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL));  // the full-domain smoother rewrote everything
+    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot));  // the full-domain smoother rewrote everything
     return MGPS_OK;
 }
 
-int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid = false);
+int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid = false, bool wantDot = false);
 
 // levels distLevels .. totalLevels-1 of a slab run: gather the rhs of the collapse level to rank 0,
 // run the rest of the cycle there on the whole grid, scatter the correction back
@@ -428,9 +451,16 @@ int zeroOwnGrid(mgps_solver *h, int l, float *a, bool withGhosts)
     return MGPS_OK;
 }
 
-// ownGrid: x is one of the solver's own grids (see zeroOwnGrid)
-int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid)
+// ownGrid: x is one of the solver's own grids (see zeroOwnGrid).  wantDot (single-device runs, after ensurePcgGrids):
+// <x, b> of the result is left in h->resultDev as a by-product of the last stroke (mgps_solver::gatherDot)
+int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid, bool wantDot)
 {
+    static const bool gatherAllowed = [] {  // MGPS_GATHER_DOT=0: separate <z, r> reduction (A/B timing)
+        const char *e = getenv("MGPS_GATHER_DOT");
+        return !(e && e[0] == '0');
+    }();
+    h->gatherDot = wantDot && gatherAllowed && !h->dist && h->dotPartials != nullptr;
+    h->dotUsed = 0;
     const int nlv = int(h->lv.size());
     if (h->tailOfSlabRun && nlv == 1) {  // the tail of a slab run can be the direct solve alone
         MGPS_TRY(zeroGrid(h, x, h->lv[0].d, false));
@@ -450,7 +480,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
         else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
-    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh));
+    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom));
     if (hasBottom) {
         const float *rhs = b;
         for (int l = 0; l < nsmooth; ++l) {  // MG.cpp:519-553 (fine), 557-667 (coarser)
@@ -477,11 +507,12 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
             DevLevel &F = h->lv[l];
             MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
             MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
-            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false, false));
+            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false, false, h->gatherDot && l == 0));
         }
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
         MGPS_HIP(h, hipMemcpyAsync(x, cur[0], h->lv[0].d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (h->gatherDot) MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, h->resultDev));
     return MGPS_OK;
 }
 
@@ -506,7 +537,12 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
 {
     for (int q = 0; q < 4; ++q)
         if (!h->pcg[q]) MGPS_TRY(gridAlloc(h, &h->pcg[q], h->lv[0].d));
-    if (!h->dotPartials) MGPS_TRY(devAlloc(h, &h->dotPartials, applyDotPartialCount(h->lv[0].g), true));
+    if (!h->dotPartials) {  // the fused A.p launch, or the last stroke of a V-cycle: sweep workgroups / tiles + band scatters
+        const DevLevel &F = h->lv[0];
+        const size_t tiles = size_t(F.npure[0]) + F.npure[1] + F.nmixed[0] + F.nmixed[1];
+        const size_t scatters = size_t(std::max(1, h->opt.band_iterations)) * bandScatterBlocks(F.nband);
+        MGPS_TRY(devAlloc(h, &h->dotPartials, applyDotPartialCount(F.g) + tiles + scatters + 64, true));
+    }
     if (needDiag && !h->dinv) {
         MGPS_TRY(gridAlloc(h, &h->dinv, h->lv[0].d));
         MGPS_LAUNCH(h, launchDiagInverse(h->stream, h->lv[0].g, h->dinv));
@@ -546,9 +582,31 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         (void)hipEventDestroy(e1);
         return MGPS_OK;
     };
+    // dst = M src; gathered: <dst, src> is already in h->resultDev (a by-product of the V-cycle's last stroke)
+    bool gathered = false;
     auto precondition = [&](float *dst, const float *src) -> int {
-        if (useMG) return vcycle(h, dst, src, false, true);  // Plug.cpp:468-472 (dst = p or z: grids of the solver)
+        gathered = false;
+        if (useMG) {
+            MGPS_TRY(vcycle(h, dst, src, false, true, true));  // Plug.cpp:468-472 (dst = p or z: grids of the solver)
+            gathered = h->gatherDot;
+            return MGPS_OK;
+        }
         MGPS_LAUNCH(h, launchMulMasked(h->stream, F.g, dst, src, h->dinv));  // Plug.cpp:555-606
+        return MGPS_OK;
+    };
+    static const bool checkGathered = [] {  // MGPS_CHECK_FUSED_DOT=1: compare every gathered <z, r> with a separate reduction
+        const char *e = getenv("MGPS_CHECK_FUSED_DOT");
+        return e && e[0] == '1';
+    }();
+    auto dotWithResidual = [&](const float *v, double *out) -> int {  // <v, r> right after precondition(v, r)
+        if (!gathered) return reduceToHost(h, 0, 0, v, r, out);
+        MGPS_TRY(fetchReduction(h, 0, out));
+        if (checkGathered) {
+            double ref = 0;
+            MGPS_TRY(reduceToHost(h, 0, 0, v, r, &ref));
+            if (!(std::fabs(*out - ref) <= 1e-9 * std::fabs(ref) + 1e-300))
+                return failH(h, MGPS_ERR_HIP, "gathered <z, r> = " + std::to_string(*out) + " differs from the separate reduction " + std::to_string(ref));
+        }
         return MGPS_OK;
     };
 
@@ -567,7 +625,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_LAUNCH(h, launchZero(h->stream, p, F.d.cells()));  // CG.h:69
     MGPS_TRY(precondition(p, r));                         // CG.h:75
     double absNew = 0;
-    MGPS_TRY(reduceToHost(h, 0, 0, p, r, &absNew));  // CG.h:86
+    MGPS_TRY(dotWithResidual(p, &absNew));  // CG.h:86
     MGPS_LAUNCH(h, launchZero(h->stream, z, F.d.cells()));
     MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
@@ -595,7 +653,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         }
         MGPS_TRY(precondition(z, r));  // CG.h:168
         const double absOld = absNew;
-        MGPS_TRY(reduceToHost(h, 0, 0, z, r, &absNew));  // CG.h:180
+        MGPS_TRY(dotWithResidual(z, &absNew));  // CG.h:180
         const double beta = absNew / absOld;
         MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, nullptr, float(beta)));  // CG.h:191
     }
