@@ -426,6 +426,37 @@ def test_distinct_handles_are_independent(domain_factory, torch_cuda):
             assert together[i][2] == alone[i][2]
 
 
+def test_gathered_dot_matches_separate_reduction(torch_cuda):
+    """MG-PCG takes <z, r> from the last stroke of the preconditioning V-cycle (sweep partial sums + band-scatter
+    corrections).  With MGPS_CHECK_FUSED_DOT=1 (read once per process, hence the child process) the library compares
+    every such value with a separate reduction and fails the solve on a relative difference above 1e-9: both
+    smoothers, unit-weight and cut-cell / ghost-fluid domains."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np\n"
+        "import geometricmultigridpressuresolver_amd as G\n"
+        "from geometricmultigridpressuresolver_amd import domains as D\n"
+        "from conftest import make_domain\n"
+        "for kind, g in (('simple', 64), ('solid', 64), ('complex', 32)):\n"
+        "    lab, w, off, lev, dx = make_domain(kind, g)\n"
+        "    for gs in (False, True):\n"
+        "        s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)\n"
+        "        x = s.new_grid(); b = s.to_device(D.random_rhs(lab, dx))\n"
+        "        st = s.solveGeometricConjugateGradient(x, b, 1e-6, 200, True)\n"
+        "        assert st['outcome'] == 'converged', st\n"
+        "        s.close()\n"
+        "print('GATHER_OK')\n"
+    ) % (ROOT, ROOT)
+    env = dict(**__import__("os").environ, MGPS_CHECK_FUSED_DOT="1")
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "GATHER_OK" in res.stdout, res.stdout[-3000:]
+
+
 def test_convergence_trace(domain_factory, oracle, torch_cuda):
     """testOneLevelVCycle (Test.cpp:1877-1960): b = 0, sine error, Jacobi V-cycles with
     useInitialGuess; the error norm must contract monotonically and track the oracle's trace."""
