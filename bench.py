@@ -113,8 +113,11 @@ def free_surface_pcg(args):
     b = D.delta_rhs(lab, n - 2 * pad, pad, h) + D.random_rhs(lab, h)
     out = {"metric": "MG-PCG solve", "grid": n, "levels": levels, "tolerance": 1e-5,
            "active_cells": int(D.active_mask(lab).sum()), "general_boundary_note": "ghost-fluid + cut-cell rows"}
-    for use_gs in (True, False):
-        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=0)
+    # the two smoothers with fp32 CG vectors, then the same with the CG vectors in fp64 (options.pcg_fp64_vectors)
+    for use_gs, fp64 in ((True, False), (False, False), (True, True), (False, True)):
+        opt = G.default_options()
+        opt.pcg_fp64_vectors = int(fp64)
+        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=0, options=opt)
         bd = solver.to_device(b)
         best = None
         for rep in range(3):
@@ -122,8 +125,9 @@ def free_surface_pcg(args):
             st = solver.solveGeometricConjugateGradient(x, bd, 1e-5, 2500, True)
             if best is None or st["solve_ms"] < best["solve_ms"]:
                 best = st
-        out["tiled_gs" if use_gs else "jacobi"] = {k: best[k] for k in ("outcome", "iterations", "rel_residual", "rel_residual_recomputed", "solve_ms")}
-        if use_gs and args.check_oracle:
+        key = ("tiled_gs" if use_gs else "jacobi") + ("_fp64_vectors" if fp64 else "")
+        out[key] = {k: best[k] for k in ("outcome", "iterations", "rel_residual", "rel_residual_recomputed", "solve_ms")}
+        if use_gs and not fp64 and args.check_oracle:
             x_gpu = x.cpu().numpy().astype(np.float64)
         solver.close()
     if args.check_oracle:  # the same solve in fp64 on the host (checker only, never timed as the product)

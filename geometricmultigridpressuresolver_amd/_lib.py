@@ -45,6 +45,7 @@ class Options(C.Structure):
         ("fuse_band_passes", C.c_int),
         ("deep_band_halo", C.c_int),
         ("min_cells_per_rank", C.c_int),
+        ("pcg_fp64_vectors", C.c_int),
         ("interrupt", C.c_void_p),
         ("interrupt_user", C.c_void_p),
     ]

@@ -297,6 +297,15 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
 // x += alpha p, r -= alpha t, *resultDev = sum of the new r^2 over active cells (one pass, CG.h:132-153)
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
                    double *resultDev);
+// fp64 CG vectors (options.pcg_fp64_vectors), level g = the fine level of a single-device solver:
+// mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
+int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
+                    double *partials, double *resultDev);
+int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
+                     double *partials, double *resultDev);
+int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first);
+int launchWiden(void *stream, double *dst, const float *src, size_t n);
+int launchNarrow(void *stream, float *dst, const double *src, size_t n);
 int launchZero(void *stream, float *a, size_t count);
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)
 int launchZeroActive(void *stream, const GridP &g, float *a);

@@ -1660,6 +1660,171 @@ __global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, c
     if (q < nq) reinterpret_cast<float4 *>(a)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// CG vectors in fp64 around the fp32 V-cycle (options.pcg_fp64_vectors): the operator, the vector updates and the
+// reductions of CG.h:18-207 on double grids, label-masked like their fp32 forms; face weights, rows and the rhs stay
+// fp32.  One thread = 4 consecutive cells (nextQuad), neighbours from the caches: these passes are a fraction of an
+// iteration next to the V-cycle.
+// ---------------------------------------------------------------------------------------------
+// MODE 0: out = A x (and <x, A x> shares in partials), MODE 1: out = b - A x (and |out|^2 shares), out32 = float(out)
+template <int MODE>
+__global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restrict__ out, const double *__restrict__ x,
+                                                        const float *__restrict__ b, float *__restrict__ out32,
+                                                        double *__restrict__ partials)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz, nq = n >> 2;
+    const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny;
+    double acc = 0.0;
+    size_t q;
+    for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
+        const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t c = (q << 2) + e;
+            double res = 0.0;
+            if (simpleCell(ls[e])) {  // INTERIOR / simple BOUNDARY: all six neighbours exist (EXTERIOR shell)
+                const double xc = x[c];
+                const double lap = double(simpleDiag(ls[e])) * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+                res = MODE == 0 ? lap : double(b[c]) - lap;
+                acc += MODE == 0 ? xc * res : res * res;
+            }
+            out[c] = res;  // general BOUNDARY cells: boundary64Kernel right after
+            if (MODE == 1) out32[c] = float(res);
+        }
+    }
+    const double total = blockReduce<0>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void boundary64Kernel(GridP g, double *__restrict__ out, const double *__restrict__ x,
+                                                         const float *__restrict__ b, float *__restrict__ out32,
+                                                         double *__restrict__ partials)
+{
+    double acc = 0.0;
+    for (int t = int(blockIdx.x * blockDim.x + threadIdx.x); t < g.nbnd; t += int(gridDim.x * blockDim.x)) {
+        const size_t c = size_t(g.bnd[t]), nb = size_t(g.nbnd);
+        const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny;
+        const float *r = g.rows + t;
+        double lap = double(r[6 * nb]) * x[c];
+        lap -= double(r[0]) * x[c - 1];
+        lap -= double(r[nb]) * x[c + 1];
+        lap -= double(r[2 * nb]) * x[c - sy];
+        lap -= double(r[3 * nb]) * x[c + sy];
+        lap -= double(r[4 * nb]) * x[c - sz];
+        lap -= double(r[5 * nb]) * x[c + sz];
+        const double res = MODE == 0 ? lap : double(b[c]) - lap;
+        out[c] = res;
+        if (MODE == 1) out32[c] = float(res);
+        acc += MODE == 0 ? x[c] * res : res * res;
+    }
+    const double total = blockReduce<0>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+// x += alpha p, r -= alpha t, r32 = float(r), shares of |r|^2 (CG.h:132-153)
+__global__ __launch_bounds__(256) void cgUpdate64Kernel(GridP g, double *__restrict__ x, const double *__restrict__ p,
+                                                         double *__restrict__ r, const double *__restrict__ t, double alpha,
+                                                         float *__restrict__ r32, double *__restrict__ partials)
+{
+    const size_t nq = (size_t(g.nx) * g.ny * g.nz) >> 2;
+    double acc = 0.0;
+    size_t q;
+    for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
+        const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t c = (q << 2) + e;
+            if (!activeLabel(ls[e])) continue;
+            x[c] += alpha * p[c];
+            const double rv = r[c] - alpha * t[c];
+            r[c] = rv;
+            r32[c] = float(rv);
+            acc += rv * rv;
+        }
+    }
+    const double total = blockReduce<0>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+// p = z + beta p (CG.h:191); first: p = z
+__global__ __launch_bounds__(256) void xpay64Kernel(GridP g, double *__restrict__ p, const float *__restrict__ z, double beta, int first)
+{
+    const size_t nq = (size_t(g.nx) * g.ny * g.nz) >> 2;
+    size_t q;
+    for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
+        const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t c = (q << 2) + e;
+            if (activeLabel(ls[e])) p[c] = first ? double(z[c]) : double(z[c]) + beta * p[c];
+        }
+    }
+}
+// widen / narrow a whole grid (inactive cells hold 0 on both sides)
+__global__ __launch_bounds__(256) void widenKernel(double *__restrict__ dst, const float *__restrict__ src, size_t n)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < n) dst[c] = double(src[c]);
+}
+__global__ __launch_bounds__(256) void narrowKernel(float *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < n) dst[c] = float(src[c]);
+}
+
+static unsigned cg64Blocks(const GridP &g)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    if (g.chunks) return std::min(unsigned(kReducePartials) / 2, std::max(1u, g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4));
+    return std::min(unsigned(kReducePartials) / 2, std::max(1u, blocksFor(n >> 2, 256)));
+}
+// mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
+int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
+                    double *partials, double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned nb = cg64Blocks(g);
+    if (mode == 0) stencil64Kernel<0><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
+    else stencil64Kernel<1><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
+    unsigned nparts = nb;
+    if (g.nbnd > 0) {
+        const unsigned nbb = std::min(blocksFor(size_t(g.nbnd), 256), unsigned(kReducePartials) - nb);  // grid-stride beyond that
+        if (mode == 0) boundary64Kernel<0><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
+        else boundary64Kernel<1><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
+        nparts += nbb;
+    }
+    reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nparts), partials, resultDev);
+    return int(hipGetLastError());
+}
+int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
+                     double *partials, double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned nb = cg64Blocks(g);
+    cgUpdate64Kernel<<<nb, 256, 0, s>>>(g, x, p, r, t, alpha, r32, partials);
+    reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+    return int(hipGetLastError());
+}
+int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first)
+{
+    xpay64Kernel<<<cg64Blocks(g), 256, 0, static_cast<hipStream_t>(stream)>>>(g, p, z, beta, first);
+    return int(hipGetLastError());
+}
+int launchWiden(void *stream, double *dst, const float *src, size_t n)
+{
+    widenKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
+    return int(hipGetLastError());
+}
+int launchNarrow(void *stream, float *dst, const double *src, size_t n)
+{
+    narrowKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
+    return int(hipGetLastError());
+}
+
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroActive(void *stream, const GridP &g, float *a)
 {

@@ -85,6 +85,7 @@ struct mgps_solver {
     // reductions
     double *partials = nullptr, *resultDev = nullptr, *resultHost = nullptr;
     double *dotPartials = nullptr;  // per-workgroup shares of <p, A p> from the fused A.p launch of the CG loop
+    double *cg64[4] = {nullptr, nullptr, nullptr, nullptr};  // x, r, p, A p in fp64 (options.pcg_fp64_vectors), with ghost planes
     // the last stroke of a preconditioning V-cycle also gathers <x, b> (= <z, r>, CG.h:86 / 180) when asked to:
     // the sweep leaves <x', b>, every band scatter after it the correction sum (new - old) b
     bool gatherDot = false;
@@ -229,6 +230,8 @@ void freeAll(mgps_solver *h)
     (void)hipFree(h->partials);
     (void)hipFree(h->resultDev);
     (void)hipFree(h->dotPartials);
+    for (double *g64 : h->cg64)
+        if (g64) (void)hipFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
     if (!h->lv.empty()) {
         for (int q = 0; q < 4; ++q) gridFree(h->pcg[q], h->lv[0].d);
@@ -559,9 +562,113 @@ int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const
     return MGPS_OK;
 }
 
+// MG-PCG with the CG vectors in fp64 (options.pcg_fp64_vectors): CG.h:18-207 step by step like pcg() below; the
+// preconditioner is the same fp32 V-cycle (or diagonal) applied to float(r), x and b are fp32 at the boundary
+int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
+{
+    DevLevel &F = h->lv[0];
+    const size_t n = F.d.cells(), plane = size_t(F.d.nx) * F.d.ny;
+    MGPS_TRY(ensurePcgGrids(h, !useMG));
+    for (double *&g64 : h->cg64)
+        if (!g64) {
+            double *base = nullptr;
+            MGPS_TRY(devAlloc(h, &base, n + 2 * plane, true));
+            g64 = base + plane;
+        }
+    double *x64 = h->cg64[0], *r64 = h->cg64[1], *p64 = h->cg64[2], *t64 = h->cg64[3];
+    float *r32 = h->pcg[0], *z = h->pcg[2];
+    hipEvent_t e0, e1;
+    MGPS_HIP(h, hipEventCreate(&e0));
+    MGPS_HIP(h, hipEventCreate(&e1));
+    MGPS_HIP(h, hipEventRecord(e0, h->stream));
+    auto finish = [&](int outcome) {
+        st->outcome = outcome;
+        (void)hipEventRecord(e1, h->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        st->solve_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return MGPS_OK;
+    };
+    bool gathered = false;
+    auto precondition = [&]() -> int {  // z = M float(r)
+        gathered = false;
+        if (useMG) {
+            MGPS_TRY(vcycle(h, z, r32, false, true, true));
+            gathered = h->gatherDot;
+            return MGPS_OK;
+        }
+        MGPS_LAUNCH(h, launchMulMasked(h->stream, F.g, z, r32, h->dinv));
+        return MGPS_OK;
+    };
+    auto zDotR = [&](double *out) -> int {  // <z, float(r)>: r enters the V-cycle rounded, the same rounded r is used here
+        if (gathered) return fetchReduction(h, 0, out);
+        return reduceToHost(h, 0, 0, z, r32, out);
+    };
+    double rhs2 = 0;
+    MGPS_TRY(reduceToHost(h, 1, 0, b, nullptr, &rhs2));  // CG.h:35
+    st->rhs_norm2 = rhs2;
+    if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
+    MGPS_LAUNCH(h, launchWiden(h->stream, x64, x, n));
+    double res2 = 0;
+    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->partials, h->resultDev));  // CG.h:50-57
+    MGPS_TRY(fetchReduction(h, 1, &res2));
+    const double threshold = tol * tol * rhs2;  // CG.h:58
+    if (res2 < threshold) {                     // CG.h:60-64
+        st->rel_residual = st->rel_residual_recomputed = std::sqrt(res2 / rhs2);
+        return finish(MGPS_PCG_ALREADY_CONVERGED);
+    }
+    MGPS_TRY(precondition());                                              // CG.h:75
+    MGPS_LAUNCH(h, launchXpay64(h->stream, F.g, p64, z, 0.0, 1));          // p = z
+    double absNew = 0;
+    MGPS_TRY(zDotR(&absNew));                                              // CG.h:86
+    int it = 0;
+    bool converged = false;
+    for (; it < maxIt; ++it) {
+        if (h->opt.interrupt && h->opt.interrupt(h->opt.interrupt_user)) {
+            (void)launchNarrow(h->stream, x, x64, n);  // what the iterations reached so far, as the fp32 loop leaves it
+            finish(MGPS_PCG_MAX_ITERATIONS);
+            st->iterations = it;
+            return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
+        }
+        double pAp = 0;
+        MGPS_LAUNCH(h, launchStencil64(h->stream, 0, F.g, t64, p64, nullptr, nullptr, h->partials, h->resultDev));  // CG.h:110-121
+        MGPS_TRY(fetchReduction(h, 0, &pAp));
+        const double alpha = absNew / pAp;
+        MGPS_LAUNCH(h, launchCgUpdate64(h->stream, F.g, x64, p64, r64, t64, alpha, r32, h->partials, h->resultDev));  // CG.h:132-153
+        MGPS_TRY(fetchReduction(h, 1, &res2));
+        if (h->opt.print_stats) std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
+        if (res2 < threshold) {  // CG.h:161
+            converged = true;
+            break;
+        }
+        MGPS_TRY(precondition());  // CG.h:168
+        const double absOld = absNew;
+        MGPS_TRY(zDotR(&absNew));  // CG.h:180
+        MGPS_LAUNCH(h, launchXpay64(h->stream, F.g, p64, z, absNew / absOld, 0));  // CG.h:191
+    }
+    st->iterations = it;
+    st->rel_residual = std::sqrt(res2 / rhs2);  // CG.h:199
+    double rec2 = 0;
+    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->partials, h->resultDev));  // CG.h:203-205, in fp64
+    MGPS_TRY(fetchReduction(h, 1, &rec2));
+    st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);
+    MGPS_LAUNCH(h, launchNarrow(h->stream, x, x64, n));
+    return finish(converged ? MGPS_PCG_CONVERGED : MGPS_PCG_MAX_ITERATIONS);
+}
+
 int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
 {
     DevLevel &F = h->lv[0];
+    if (h->opt.pcg_fp64_vectors) {
+        if (h->dist) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "options.pcg_fp64_vectors: single-device solvers only");
+        mgps_pcg_stats local64{};
+        if (!st) st = &local64;
+        std::memset(st, 0, sizeof(*st));
+        return pcg64(h, x, b, tol, maxIt, useMG, st);
+    }
     mgps_pcg_stats local{};
     if (!st) st = &local;
     std::memset(st, 0, sizeof(*st));

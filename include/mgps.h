@@ -79,6 +79,11 @@ typedef struct mgps_options {
     int min_cells_per_rank; /* slab runs: a level below the finest stays distributed only while every rank owns at least
                                this many cells of it (default 2097152 = 128^3); smaller levels are gathered to rank 0,
                                where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
+    int pcg_fp64_vectors;   /* 0 (default): the CG vectors x, r, p, A p are fp32 like every grid.  1: mgps_solve_pcg keeps
+                               them in fp64 (the reference's precision, MG.h:14-15) around the unchanged fp32 V-cycle;
+                               x and b stay fp32 at the boundary.  With fp32 vectors the recurrence loses accuracy at
+                               eps * cond: fine at 512^3 (same iteration count as fp64), 36-46 iterations instead of
+                               ~24 at 1024^3.  Single-device solvers only */
     int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
     void *interrupt_user;
 } mgps_options;

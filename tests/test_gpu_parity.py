@@ -344,6 +344,38 @@ def test_mg_pcg_matches_oracle(kind, g, use_gs, domain_factory, oracle, torch_cu
     assert rel_l2(xd.cpu().numpy(), x_ref) < 2e-4
 
 
+@pytest.mark.parametrize("kind,g,use_mg", [("solid", 64, True), ("complex", 32, True), ("complex", 32, False)])
+@pytest.mark.parametrize("use_gs", [True, False])
+def test_pcg_fp64_vectors(kind, g, use_mg, use_gs, domain_factory, oracle, torch_cuda):
+    """options.pcg_fp64_vectors: CG vectors in fp64 around the fp32 preconditioner.  Same iteration count as the fp64
+    oracle (+-2) and as the fp32-vector solve (+-1); the recomputed residual is then a true fp64 residual of the
+    iterate and agrees with the recurrence's; the returned pressure matches the oracle's."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    lab, w, off, lev, dx = domain_factory(kind, g)
+    b = (D.delta_rhs(lab, g, off, dx) + D.random_rhs(lab, dx)).astype(np.float32)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, use_gs)
+    x_ref = np.zeros(lab.shape)
+    tol, cap = (1e-6, 2500) if use_mg else (1e-4, 4000)
+    ref = orc.solve_pcg(x_ref, b.astype(np.float64), tol, cap, use_mg)
+    stats = {}
+    for fp64 in (0, 1):
+        opt = G.default_options()
+        opt.pcg_fp64_vectors = fp64
+        s = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, options=opt)
+        x = s.new_grid()
+        stats[fp64] = s.solveGeometricConjugateGradient(x, s.to_device(b), tol, cap, use_mg)
+        if fp64:
+            x64 = x.cpu().numpy()
+        s.close()
+    st = stats[1]
+    assert st["outcome"] == "converged" and abs(st["iterations"] - ref["iterations"]) <= 2
+    assert abs(st["iterations"] - stats[0]["iterations"]) <= (1 if use_mg else 3)
+    assert st["rel_residual_recomputed"] < tol and abs(st["rel_residual_recomputed"] - st["rel_residual"]) < 1e-3 * st["rel_residual"]
+    assert rel_l2(x64, x_ref) < (2e-5 if use_mg else 2e-3)
+
+
 def test_diagonal_pcg(domain_factory, oracle, torch_cuda):
     """useMGPreconditioner off: Jacobi-preconditioned CG (Plug.cpp:485-618)."""
     from geometricmultigridpressuresolver_amd import domains as D
