@@ -295,8 +295,10 @@ constexpr int kReducePartials = 2048;
 int launchReduce(void *stream, int kind, const GridP &g, const float *a, const float *b, double *partials,
                  double *resultDev);
 // x += alpha p, r -= alpha t, *resultDev = sum of the new r^2 over active cells (one pass, CG.h:132-153)
+// alphaDev (optional): alpha = float(alphaDev[0] / alphaDev[1]) read on the device instead of the host's value
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev);
+                   double *resultDev, const double *alphaDev = nullptr);
+int launchCgScalars(void *stream, double *scal, float *beta, int init);
 // fp64 CG vectors (options.pcg_fp64_vectors), level g = the fine level of a single-device solver:
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
 int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,

@@ -1857,8 +1857,10 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ x,
                                                       const float *__restrict__ p, float *__restrict__ r,
                                                       const float *__restrict__ t, float alpha, double *__restrict__ partials,
-                                                      const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
+                                                      const int32_t *__restrict__ chunks, int nchunks, int chunkCells,
+                                                      const double *__restrict__ alphaDev)
 {
+    if (alphaDev) alpha = float(alphaDev[0] / alphaDev[1]);  // <z, r> / <p, A p> left on the device by the reductions (CG.h:121)
     double acc = 0.0;
     const size_t nq = n >> 2;
     size_t q;
@@ -1887,13 +1889,28 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
 }
 
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev)
+                   double *resultDev, const double *alphaDev)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
-    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells);
+    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev);
     reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+    return int(hipGetLastError());
+}
+
+// The scalars of the CG loop kept on the device so that only the convergence test meets the host:
+// scal[0] = <z, r> of the current direction, scal[1] = <p, A p>, scal[3] = the <z, r> just reduced.
+// init: scal[0] = scal[3]; else *beta = float(scal[3] / scal[0]) (CG.h:180-191), then scal[0] = scal[3]
+__global__ void cgScalarsKernel(double *__restrict__ scal, float *__restrict__ beta, int init)
+{
+    const double fresh = scal[3];
+    if (!init) *beta = float(fresh / scal[0]);
+    scal[0] = fresh;
+}
+int launchCgScalars(void *stream, double *scal, float *beta, int init)
+{
+    cgScalarsKernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(scal, beta, init);
     return int(hipGetLastError());
 }
 

@@ -90,6 +90,8 @@ struct mgps_solver {
     // the sweep leaves <x', b>, every band scatter after it the correction sum (new - old) b
     bool gatherDot = false;
     unsigned dotUsed = 0;
+    double *dotTarget = nullptr;  // where the gathered <x, b> goes (nullptr: resultDev)
+    double *cgScal = nullptr;     // scalars of the CG loop kept on the device (launchCgScalars); [4] holds beta as a float
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
     float *pcg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *dinv = nullptr;
@@ -230,6 +232,7 @@ void freeAll(mgps_solver *h)
     (void)hipFree(h->partials);
     (void)hipFree(h->resultDev);
     (void)hipFree(h->dotPartials);
+    (void)hipFree(h->cgScal);
     for (double *g64 : h->cg64)
         if (g64) (void)hipFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
@@ -515,7 +518,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
         MGPS_HIP(h, hipMemcpyAsync(x, cur[0], h->lv[0].d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    if (h->gatherDot) MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, h->resultDev));
+    if (h->gatherDot) MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, h->dotTarget ? h->dotTarget : h->resultDev));
     return MGPS_OK;
 }
 
@@ -540,6 +543,7 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
 {
     for (int q = 0; q < 4; ++q)
         if (!h->pcg[q]) MGPS_TRY(gridAlloc(h, &h->pcg[q], h->lv[0].d));
+    if (!h->cgScal) MGPS_TRY(devAlloc(h, &h->cgScal, 8, true));
     if (!h->dotPartials) {  // the fused A.p launch, or the last stroke of a V-cycle: sweep workgroups / tiles + band scatters
         const DevLevel &F = h->lv[0];
         const size_t tiles = size_t(F.npure[0]) + F.npure[1] + F.nmixed[0] + F.nmixed[1];
@@ -575,6 +579,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
             MGPS_TRY(devAlloc(h, &base, n + 2 * plane, true));
             g64 = base + plane;
         }
+    h->dotTarget = nullptr;  // (the gathered <z, r> goes to resultDev here)
     double *x64 = h->cg64[0], *r64 = h->cg64[1], *p64 = h->cg64[2], *t64 = h->cg64[3];
     float *r32 = h->pcg[0], *z = h->pcg[2];
     hipEvent_t e0, e1;
@@ -729,10 +734,29 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         st->rel_residual = st->rel_residual_recomputed = std::sqrt(res2 / rhs2);
         return finish(MGPS_PCG_ALREADY_CONVERGED);
     }
+    // Single-device runs keep alpha and beta on the device (launchCgScalars): the reductions leave <p, A p> and
+    // <z, r> there, the update and xpay kernels read them, and only |r|^2 -- the convergence test of CG.h:161 -- is
+    // fetched: one host round trip per iteration instead of three.  Slab runs sum over ranks through the host.
+    static const bool deviceScalarsAllowed = [] {
+        const char *e = getenv("MGPS_CG_DEVICE_SCALARS");  // 0: the host computes alpha and beta (A/B timing)
+        return !(e && e[0] == '0');
+    }();
+    const bool devScal = !h->dist && deviceScalarsAllowed && !checkGathered;
+    double *scal = h->cgScal;
+    float *betaDev = reinterpret_cast<float *>(h->cgScal + 4);
+    auto dotToDevice = [&](const float *v) -> int {  // scal[3] = <v, r> right after precondition(v, r)
+        if (!gathered) MGPS_LAUNCH(h, launchReduce(h->stream, 0, F.g, v, r, h->partials, scal + 3));
+        return MGPS_OK;
+    };
+    h->dotTarget = devScal ? scal + 3 : nullptr;
     MGPS_LAUNCH(h, launchZero(h->stream, p, F.d.cells()));  // CG.h:69
     MGPS_TRY(precondition(p, r));                         // CG.h:75
     double absNew = 0;
-    MGPS_TRY(dotWithResidual(p, &absNew));  // CG.h:86
+    if (devScal) {
+        MGPS_TRY(dotToDevice(p));
+        MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 1));
+    } else
+        MGPS_TRY(dotWithResidual(p, &absNew));  // CG.h:86
     MGPS_LAUNCH(h, launchZero(h->stream, z, F.d.cells()));
     MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
@@ -745,12 +769,15 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         }
         // t = A p (CG.h:110) and <p, A p> (CG.h:121) in one pass over p
         MGPS_TRY(exchangeGhosts(h, 0, p));
-        MGPS_LAUNCH(h, launchApplyDot(h->stream, F.g, t, p, h->dotPartials, h->resultDev));
-        double pAp = 0;
-        MGPS_TRY(fetchReduction(h, 0, &pAp));
-        const double alpha = absNew / pAp;                                               // CG.h:121
+        MGPS_LAUNCH(h, launchApplyDot(h->stream, F.g, t, p, h->dotPartials, devScal ? scal + 1 : h->resultDev));
+        double alpha = 0;
+        if (!devScal) {
+            double pAp = 0;
+            MGPS_TRY(fetchReduction(h, 0, &pAp));
+            alpha = absNew / pAp;  // CG.h:121
+        }
         // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
-        MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev));
+        MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr));
         MGPS_TRY(fetchReduction(h, 1, &res2));
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
@@ -759,11 +786,18 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             break;
         }
         MGPS_TRY(precondition(z, r));  // CG.h:168
-        const double absOld = absNew;
-        MGPS_TRY(dotWithResidual(z, &absNew));  // CG.h:180
-        const double beta = absNew / absOld;
-        MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, nullptr, float(beta)));  // CG.h:191
+        if (devScal) {
+            MGPS_TRY(dotToDevice(z));                                                // CG.h:180
+            MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 0));
+            MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, betaDev, 0.f));       // CG.h:191
+        } else {
+            const double absOld = absNew;
+            MGPS_TRY(dotWithResidual(z, &absNew));  // CG.h:180
+            const double beta = absNew / absOld;
+            MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, nullptr, float(beta)));  // CG.h:191
+        }
     }
+    h->dotTarget = nullptr;
     st->iterations = it;
     st->rel_residual = std::sqrt(res2 / rhs2);      // CG.h:199
     MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:203-204
