@@ -301,10 +301,11 @@ int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float
 int launchCgScalars(void *stream, double *scal, float *beta, int init);
 // fp64 CG vectors (options.pcg_fp64_vectors), level g = the fine level of a single-device solver:
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
+// (`partials` holds `capacity` doubles: the per-workgroup sums and launchFoldDot's scratch)
 int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
-                    double *partials, double *resultDev);
+                    double *partials, size_t capacity, double *resultDev);
 int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
-                     double *partials, double *resultDev);
+                     double *partials, size_t capacity, double *resultDev);
 int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first);
 int launchWiden(void *stream, double *dst, const float *src, size_t n);
 int launchNarrow(void *stream, float *dst, const double *src, size_t n);

@@ -1680,19 +1680,53 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
         if (q >= nq) continue;
         const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
         const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const size_t c0 = q << 2;
+        const bool any = simpleCell(ls[0]) || simpleCell(ls[1]) || simpleCell(ls[2]) || simpleCell(ls[3]);
+        double res[4] = {0.0, 0.0, 0.0, 0.0};  // general BOUNDARY cells: boundary64Kernel right after
+        if (any && (g.nx & 3) == 0) {
+            // the quad lies in one x-row with an active cell in it: the row is not on a grid face, so the four
+            // neighbour rows and the cells left and right of the quad exist (EXTERIOR shell); 16-byte loads
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            auto row = [&](ptrdiff_t at, double *v) {
+                const d2 a = *reinterpret_cast<const d2 *>(x + at), bb = *reinterpret_cast<const d2 *>(x + at + 2);
+                v[0] = a.x;
+                v[1] = a.y;
+                v[2] = bb.x;
+                v[3] = bb.y;
+            };
+            double xs[6], ym[4], yp[4], zm[4], zp[4];
+            row(ptrdiff_t(c0), xs + 1);
+            xs[0] = x[c0 - 1];
+            xs[5] = x[c0 + 4];
+            row(ptrdiff_t(c0) - sy, ym);
+            row(ptrdiff_t(c0) + sy, yp);
+            row(ptrdiff_t(c0) - sz, zm);
+            row(ptrdiff_t(c0) + sz, zp);
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 1) bq = reinterpret_cast<const float4 *>(b)[q];
+            const float bs[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const size_t c = (q << 2) + e;
-            double res = 0.0;
-            if (simpleCell(ls[e])) {  // INTERIOR / simple BOUNDARY: all six neighbours exist (EXTERIOR shell)
-                const double xc = x[c];
-                const double lap = double(simpleDiag(ls[e])) * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-                res = MODE == 0 ? lap : double(b[c]) - lap;
-                acc += MODE == 0 ? xc * res : res * res;
+            for (int e = 0; e < 4; ++e)
+                if (simpleCell(ls[e])) {
+                    const double lap = double(simpleDiag(ls[e])) * xs[e + 1] - (xs[e] + xs[e + 2] + ym[e] + yp[e] + zm[e] + zp[e]);
+                    res[e] = MODE == 0 ? lap : double(bs[e]) - lap;
+                    acc += MODE == 0 ? xs[e + 1] * res[e] : res[e] * res[e];
+                }
+        } else if (any) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t c = c0 + e;
+                if (simpleCell(ls[e])) {  // INTERIOR / simple BOUNDARY: all six neighbours exist (EXTERIOR shell)
+                    const double xc = x[c];
+                    const double lap = double(simpleDiag(ls[e])) * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+                    res[e] = MODE == 0 ? lap : double(b[c]) - lap;
+                    acc += MODE == 0 ? xc * res[e] : res[e] * res[e];
+                }
             }
-            out[c] = res;  // general BOUNDARY cells: boundary64Kernel right after
-            if (MODE == 1) out32[c] = float(res);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[c0 + e] = res[e];
+        if (MODE == 1) reinterpret_cast<float4 *>(out32)[q] = make_float4(float(res[0]), float(res[1]), float(res[2]), float(res[3]));
     }
     const double total = blockReduce<0>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -1776,42 +1810,42 @@ __global__ __launch_bounds__(256) void narrowKernel(float *__restrict__ dst, con
     if (c < n) dst[c] = float(src[c]);
 }
 
-static unsigned cg64Blocks(const GridP &g)
+// workgroups of an fp64 vector pass: one per 1024 cells of the active chunks, capped by the room for their partial sums
+static unsigned cg64Blocks(const GridP &g, size_t capacity)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    if (g.chunks) return std::min(unsigned(kReducePartials) / 2, std::max(1u, g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4));
-    return std::min(unsigned(kReducePartials) / 2, std::max(1u, blocksFor(n >> 2, 256)));
+    const unsigned want = g.chunks ? (g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4) : blocksFor(n >> 2, 256);
+    const unsigned room = unsigned(std::min<size_t>(capacity > 1100 ? capacity - 1100 : 1, 1u << 20));  // 1024 boundary slots + 64 fold slots
+    return std::max(1u, std::min(want, room));
 }
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
 int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
-                    double *partials, double *resultDev)
+                    double *partials, size_t capacity, double *resultDev)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned nb = cg64Blocks(g);
+    const unsigned nb = cg64Blocks(g, capacity);
     if (mode == 0) stencil64Kernel<0><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
     else stencil64Kernel<1><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
     unsigned nparts = nb;
     if (g.nbnd > 0) {
-        const unsigned nbb = std::min(blocksFor(size_t(g.nbnd), 256), unsigned(kReducePartials) - nb);  // grid-stride beyond that
+        const unsigned nbb = std::min(blocksFor(size_t(g.nbnd), 256), 1024u);  // grid-stride beyond that
         if (mode == 0) boundary64Kernel<0><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
         else boundary64Kernel<1><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
         nparts += nbb;
     }
-    reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nparts), partials, resultDev);
-    return int(hipGetLastError());
+    return launchFoldDot(stream, partials, nparts, resultDev);
 }
 int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
-                     double *partials, double *resultDev)
+                     double *partials, size_t capacity, double *resultDev)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned nb = cg64Blocks(g);
+    const unsigned nb = cg64Blocks(g, capacity);
     cgUpdate64Kernel<<<nb, 256, 0, s>>>(g, x, p, r, t, alpha, r32, partials);
-    reduceFinalKernel<0><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
-    return int(hipGetLastError());
+    return launchFoldDot(stream, partials, nb, resultDev);
 }
 int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first)
 {
-    xpay64Kernel<<<cg64Blocks(g), 256, 0, static_cast<hipStream_t>(stream)>>>(g, p, z, beta, first);
+    xpay64Kernel<<<cg64Blocks(g, size_t(1) << 21), 256, 0, static_cast<hipStream_t>(stream)>>>(g, p, z, beta, first);
     return int(hipGetLastError());
 }
 int launchWiden(void *stream, double *dst, const float *src, size_t n)

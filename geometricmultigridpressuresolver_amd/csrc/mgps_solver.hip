@@ -90,6 +90,7 @@ struct mgps_solver {
     // the sweep leaves <x', b>, every band scatter after it the correction sum (new - old) b
     bool gatherDot = false;
     unsigned dotUsed = 0;
+    size_t dotCapacity = 0;       // doubles behind dotPartials
     double *dotTarget = nullptr;  // where the gathered <x, b> goes (nullptr: resultDev)
     double *cgScal = nullptr;     // scalars of the CG loop kept on the device (launchCgScalars); [4] holds beta as a float
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
@@ -548,7 +549,8 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
         const DevLevel &F = h->lv[0];
         const size_t tiles = size_t(F.npure[0]) + F.npure[1] + F.nmixed[0] + F.nmixed[1];
         const size_t scatters = size_t(std::max(1, h->opt.band_iterations)) * bandScatterBlocks(F.nband);
-        MGPS_TRY(devAlloc(h, &h->dotPartials, applyDotPartialCount(F.g) + tiles + scatters + 64, true));
+        h->dotCapacity = applyDotPartialCount(F.g) + tiles + scatters + 64 + 2048;
+        MGPS_TRY(devAlloc(h, &h->dotPartials, h->dotCapacity, true));
     }
     if (needDiag && !h->dinv) {
         MGPS_TRY(gridAlloc(h, &h->dinv, h->lv[0].d));
@@ -618,7 +620,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
     MGPS_LAUNCH(h, launchWiden(h->stream, x64, x, n));
     double res2 = 0;
-    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->partials, h->resultDev));  // CG.h:50-57
+    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:50-57
     MGPS_TRY(fetchReduction(h, 1, &res2));
     const double threshold = tol * tol * rhs2;  // CG.h:58
     if (res2 < threshold) {                     // CG.h:60-64
@@ -639,10 +641,10 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
         }
         double pAp = 0;
-        MGPS_LAUNCH(h, launchStencil64(h->stream, 0, F.g, t64, p64, nullptr, nullptr, h->partials, h->resultDev));  // CG.h:110-121
+        MGPS_LAUNCH(h, launchStencil64(h->stream, 0, F.g, t64, p64, nullptr, nullptr, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:110-121
         MGPS_TRY(fetchReduction(h, 0, &pAp));
         const double alpha = absNew / pAp;
-        MGPS_LAUNCH(h, launchCgUpdate64(h->stream, F.g, x64, p64, r64, t64, alpha, r32, h->partials, h->resultDev));  // CG.h:132-153
+        MGPS_LAUNCH(h, launchCgUpdate64(h->stream, F.g, x64, p64, r64, t64, alpha, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:132-153
         MGPS_TRY(fetchReduction(h, 1, &res2));
         if (h->opt.print_stats) std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161
@@ -657,7 +659,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     st->iterations = it;
     st->rel_residual = std::sqrt(res2 / rhs2);  // CG.h:199
     double rec2 = 0;
-    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->partials, h->resultDev));  // CG.h:203-205, in fp64
+    MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:203-205, in fp64
     MGPS_TRY(fetchReduction(h, 1, &rec2));
     st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);
     MGPS_LAUNCH(h, launchNarrow(h->stream, x, x64, n));
