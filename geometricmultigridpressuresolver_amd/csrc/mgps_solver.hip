@@ -568,6 +568,19 @@ int applyOp(mgps_solver *h, StencilOp op, int level, float *out, float *x, const
     return MGPS_OK;
 }
 
+// whole ghost planes of an fp64 grid of the fine level (slab runs)
+int exchangeGhosts64(mgps_solver *h, double *a)
+{
+    if (!h->dist) return MGPS_OK;
+    DevLevel &L = h->lv[0];
+    const size_t plane = size_t(L.d.nx) * L.d.ny, bytes = plane * sizeof(double);
+    const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
+    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, bytes, lo ? a - plane : nullptr, bytes,
+                                  hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, bytes, hi ? a + size_t(L.d.nz) * plane : nullptr, bytes,
+                                  h->stream));
+    return MGPS_OK;
+}
+
 // MG-PCG with the CG vectors in fp64 (options.pcg_fp64_vectors): CG.h:18-207 step by step like pcg() below; the
 // preconditioner is the same fp32 V-cycle (or diagonal) applied to float(r), x and b are fp32 at the boundary
 int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
@@ -620,6 +633,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
     MGPS_LAUNCH(h, launchWiden(h->stream, x64, x, n));
     double res2 = 0;
+    MGPS_TRY(exchangeGhosts64(h, x64));
     MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:50-57
     MGPS_TRY(fetchReduction(h, 1, &res2));
     const double threshold = tol * tol * rhs2;  // CG.h:58
@@ -641,12 +655,13 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
         }
         double pAp = 0;
+        MGPS_TRY(exchangeGhosts64(h, p64));
         MGPS_LAUNCH(h, launchStencil64(h->stream, 0, F.g, t64, p64, nullptr, nullptr, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:110-121
         MGPS_TRY(fetchReduction(h, 0, &pAp));
         const double alpha = absNew / pAp;
         MGPS_LAUNCH(h, launchCgUpdate64(h->stream, F.g, x64, p64, r64, t64, alpha, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:132-153
         MGPS_TRY(fetchReduction(h, 1, &res2));
-        if (h->opt.print_stats) std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
+        if (h->opt.print_stats && (!h->dist || h->comm.rank == 0)) std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161
             converged = true;
             break;
@@ -659,6 +674,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     st->iterations = it;
     st->rel_residual = std::sqrt(res2 / rhs2);  // CG.h:199
     double rec2 = 0;
+    MGPS_TRY(exchangeGhosts64(h, x64));
     MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, r64, x64, b, r32, h->dotPartials, h->dotCapacity, h->resultDev));  // CG.h:203-205, in fp64
     MGPS_TRY(fetchReduction(h, 1, &rec2));
     st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);
@@ -670,7 +686,6 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 {
     DevLevel &F = h->lv[0];
     if (h->opt.pcg_fp64_vectors) {
-        if (h->dist) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "options.pcg_fp64_vectors: single-device solvers only");
         mgps_pcg_stats local64{};
         if (!st) st = &local64;
         std::memset(st, 0, sizeof(*st));

@@ -81,9 +81,11 @@ typedef struct mgps_options {
                                where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
     int pcg_fp64_vectors;   /* 0 (default): the CG vectors x, r, p, A p are fp32 like every grid.  1: mgps_solve_pcg keeps
                                them in fp64 (the reference's precision, MG.h:14-15) around the unchanged fp32 V-cycle;
-                               x and b stay fp32 at the boundary.  With fp32 vectors the recurrence loses accuracy at
-                               eps * cond: fine at 512^3 (same iteration count as fp64), 36-46 iterations instead of
-                               ~24 at 1024^3.  Single-device solvers only */
+                               x and b stay fp32 at the boundary.  Same iteration counts either way (measured at 512^3
+                               and 1024^3); with fp64 vectors the residual recomputed at the end (CG.h:203-206) is a
+                               true one instead of flooring at eps * cond (3e-3 at 512^3, 2e-2 at 1024^3 on the
+                               free-surface case), for +17..36 % solve time.  Slab runs exchange the ghost planes of
+                               these vectors as doubles */
     int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
     void *interrupt_user;
 } mgps_options;

@@ -97,6 +97,20 @@ def gpu_mode():
             assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
+            if deep == 1:  # the CG vectors in fp64 (options.pcg_fp64_vectors): their ghost planes travel as doubles
+                o64 = G.default_options()
+                o64.min_cells_per_rank, o64.pcg_fp64_vectors = 0, 1
+                slab64 = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=o64)
+                ow = G.default_options()
+                ow.pcg_fp64_vectors = 1
+                whole64 = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0, options=ow)
+                xw, xs = whole64.new_grid(), slab64.new_grid()
+                sw = whole64.solveGeometricConjugateGradient(xw, whole64.to_device(bd), 1e-6, 200, True)
+                ss = slab64.solveGeometricConjugateGradient(xs, slab64.to_device(bd[z0:z1]), 1e-6, 200, True)
+                assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+                assert ss["rel_residual_recomputed"] < 1e-6 and rel_l2(slab64.gather_global(xs), xw.cpu().numpy()) < 1e-5
+                slab64.close()
+                whole64.close()
             if rank == 0:
                 print(f"  {kind} gs={use_gs} deep={deep}: D={slab.distributed_levels} exchanges={comm.exchanges} "
                       f"({comm.bytes_sent / 1e6:.1f} MB sent) pcg it {ss['iterations']}", flush=True)
