@@ -376,6 +376,50 @@ def test_pcg_fp64_vectors(kind, g, use_mg, use_gs, domain_factory, oracle, torch
     assert rel_l2(x64, x_ref) < (2e-5 if use_mg else 2e-3)
 
 
+@pytest.mark.parametrize("fp64", [0, 1])
+def test_pcg_interrupt_callback(fp64, domain_factory, torch_cuda):
+    """options.interrupt (the reference polls UT_Interrupt::opInterrupt in every loop, e.g. Ops.h:319): polled once
+    per CG iteration; a non-zero answer stops the solve with MGPS_ERR_INTERRUPTED and leaves the iterate reached so
+    far in x.  A callback that never fires changes nothing."""
+    import ctypes as C
+
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    lab, w, off, lev, dx = domain_factory("solid", 64)
+    b = D.random_rhs(lab, dx)
+    polls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+    def make(stop_after):
+        def cb(user):
+            polls.append(1)
+            return int(stop_after is not None and len(polls) > stop_after)
+
+        return CB(cb)
+
+    results = {}
+    for stop_after in (None, 3):
+        del polls[:]
+        cb = make(stop_after)
+        opt = G.default_options()
+        opt.pcg_fp64_vectors = fp64
+        opt.interrupt = C.cast(cb, C.c_void_p)
+        s = G.GeometricMultigridPoissonSolver(lab, w, lev, False, options=opt)
+        x = s.new_grid()
+        if stop_after is None:
+            st = s.solveGeometricConjugateGradient(x, s.to_device(b), 1e-6, 200, True)
+            assert st["outcome"] == "converged" and len(polls) == st["iterations"] + 1
+            results["full"] = st["iterations"]
+        else:
+            with pytest.raises(G.MgpsError) as err:
+                s.solveGeometricConjugateGradient(x, s.to_device(b), 1e-6, 200, True)
+            assert err.value.status == 9 and len(polls) == stop_after + 1  # MGPS_ERR_INTERRUPTED
+            assert float(x.abs().max()) > 0  # three iterations' worth of solution is there
+        s.close()
+    assert results["full"] > 3
+
+
 def test_diagonal_pcg(domain_factory, oracle, torch_cuda):
     """useMGPreconditioner off: Jacobi-preconditioned CG (Plug.cpp:485-618)."""
     from geometricmultigridpressuresolver_amd import domains as D
