@@ -420,6 +420,43 @@ def test_pcg_interrupt_callback(fp64, domain_factory, torch_cuda):
     assert results["full"] > 3
 
 
+def test_plain_c_caller_flow(domain_factory, torch_cuda):
+    """What a C caller without any tensor library does: mgps_device_count, mgps_grid_alloc, mgps_copy_to_device, a
+    V-cycle, mgps_copy_to_host, mgps_grid_free -- same numbers as the torch-tensor route."""
+    import ctypes as C
+
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd._lib import check, lib
+
+    L = lib()
+    count = C.c_int()
+    check(L.mgps_device_count(C.byref(count)))
+    assert count.value >= 1
+    lab, w, off, lev, dx = domain_factory("solid", 64)
+    b = np.ascontiguousarray(D.random_rhs(lab, dx), dtype=np.float32)
+    s = G.GeometricMultigridPoissonSolver(lab, w, lev, True)
+    xd, bd = C.c_void_p(), C.c_void_p()
+    check(L.mgps_grid_alloc(s.h, 0, C.byref(xd)), s.h)
+    check(L.mgps_grid_alloc(s.h, 0, C.byref(bd)), s.h)
+    L.mgps_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mgps_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mgps_apply_vcycle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.mgps_grid_free.argtypes = [C.c_void_p, C.c_void_p]
+    check(L.mgps_copy_to_device(s.h, bd, b.ctypes.data_as(C.c_void_p), b.nbytes), s.h)
+    for it in range(2):
+        check(L.mgps_apply_vcycle(s.h, xd, bd, int(it > 0)), s.h)
+    out = np.empty_like(b)
+    check(L.mgps_copy_to_host(s.h, out.ctypes.data_as(C.c_void_p), xd, out.nbytes), s.h)
+    check(L.mgps_grid_free(s.h, xd), s.h)
+    check(L.mgps_grid_free(s.h, bd), s.h)
+    xt, bt = s.new_grid(), s.to_device(b)
+    for it in range(2):
+        s.applyVCycle(xt, bt, it > 0)
+    assert np.array_equal(out, xt.cpu().numpy())
+    s.close()
+
+
 def test_diagonal_pcg(domain_factory, oracle, torch_cuda):
     """useMGPreconditioner off: Jacobi-preconditioned CG (Plug.cpp:485-618)."""
     from geometricmultigridpressuresolver_amd import domains as D
