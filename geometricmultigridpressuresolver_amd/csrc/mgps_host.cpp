@@ -302,6 +302,96 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     L.ownedLabels = glab + size_t(z0) * plane;
     L.ghostLoLabels = z0 > 0 ? glab + size_t(z0 - 1) * plane : nullptr;
     L.ghostHiLabels = z1 < gd.nz ? glab + size_t(z1) * plane : nullptr;
+    // the activity and tile lists only read the labels: they are built beside the band split below
+    std::thread listsJob([&L, d, z0] {
+        const uint8_t *labels = L.ownedLabels;
+        {  // activity lists
+            const size_t n = d.cells();
+            // flags of the 256-cell chunks (eight labels per test: a byte is active iff it is 0 or 3)
+            const int64_t nfine = int64_t((n + kWaveChunkCells - 1) / kWaveChunkCells);
+            std::vector<uint8_t> fineAct(size_t(nfine), 0);
+            parallelFor(nfine, [&](int64_t b, int64_t e) {
+                constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
+                for (int64_t q = b; q < e; ++q) {
+                    const size_t c0 = size_t(q) * kWaveChunkCells, c1 = std::min(n, c0 + kWaveChunkCells);
+                    bool act = false;
+                    size_t c = c0;
+                    for (; c + 8 <= c1 && !act; c += 8) {
+                        uint64_t v;
+                        std::memcpy(&v, labels + c, 8);
+                        const uint64_t u = v ^ (k01 * uint64_t(MGPS_BOUNDARY_CELL));
+                        act = (((v - k01) & ~v & k80) | ((u - k01) & ~u & k80)) != 0;
+                    }
+                    for (; c < c1 && !act; ++c) act = isActive(labels[c]);
+                    fineAct[size_t(q)] = act;
+                }
+            }, 1 << 12);
+            std::vector<int32_t> fine, coarse;
+            for (int64_t q = 0; q < nfine; ++q)
+                if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
+            constexpr int kRatio = kChunkCells / kWaveChunkCells;
+            for (int64_t q = 0; q < nfine; q += kRatio) {
+                bool act = false;
+                for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
+                if (act) coarse.push_back(int32_t(q / kRatio));
+            }
+            L.chunks.swap(coarse);
+            L.chunkCells = kChunkCells;
+            if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
+                L.chunks.swap(fine);
+                L.chunkCells = kWaveChunkCells;
+            }
+            // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
+            // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
+            // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
+            // strip (64 KiB) apart instead.  Pure locality: any order is correct.
+            constexpr int kStripRows = 32;
+            if (size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows) {
+                const size_t cpr = size_t(L.chunkCells);
+                auto key = [&](int32_t c) {
+                    const size_t cell = size_t(c) * cpr;
+                    const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
+                    return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
+                };
+                // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
+                const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
+                std::vector<std::vector<int32_t>> strips(nstrips);
+                for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
+                size_t at = 0;
+                for (auto &sv : strips) {
+                    std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
+                    at += sv.size();
+                }
+            }
+            if (L.chunkCells == kWaveChunkCells)
+                while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
+            L.planeBlocks.clear();
+            L.planeZc = planeSweepZc(d.nx, d.ny, d.nz);
+            if (L.planeZc) {
+                const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows, nbz = (d.nz + L.planeZc - 1) / L.planeZc;
+                std::vector<uint8_t> act(size_t(nbx) * nby * nbz, 0);
+                const int zc = L.planeZc;
+                parallelFor(nbz, [&](int64_t b0, int64_t b1) {
+                    for (int k = int(b0) * zc; k < std::min(d.nz, int(b1) * zc); ++k)
+                        for (int j = 0; j < d.ny; ++j) {
+                            const uint8_t *row = labels + d.idx(0, j, k);
+                            for (int bx = 0; bx < nbx; ++bx) {
+                                uint8_t &a = act[(size_t(k / zc) * nby + j / kPlaneRows) * nbx + bx];
+                                if (a) continue;
+                                for (int i = bx * 256; i < std::min(d.nx, bx * 256 + 256); ++i)
+                                    if (isActive(row[i])) {
+                                        a = 1;
+                                        break;
+                                    }
+                            }
+                        }
+                });
+                for (size_t q = 0; q < act.size(); ++q)
+                    if (act[q]) L.planeBlocks.push_back(int32_t(q));
+            }
+        }
+        buildTileLists(L, z0 / kTile);
+    });
     const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
 
@@ -464,96 +554,9 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         }
     }
     lap.lap("slab level: band planes");
-    const uint8_t *labels = L.ownedLabels;
-    {  // activity lists
-        const size_t n = d.cells();
-        // flags of the 256-cell chunks (eight labels per test: a byte is active iff it is 0 or 3)
-        const int64_t nfine = int64_t((n + kWaveChunkCells - 1) / kWaveChunkCells);
-        std::vector<uint8_t> fineAct(size_t(nfine), 0);
-        parallelFor(nfine, [&](int64_t b, int64_t e) {
-            constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
-            for (int64_t q = b; q < e; ++q) {
-                const size_t c0 = size_t(q) * kWaveChunkCells, c1 = std::min(n, c0 + kWaveChunkCells);
-                bool act = false;
-                size_t c = c0;
-                for (; c + 8 <= c1 && !act; c += 8) {
-                    uint64_t v;
-                    std::memcpy(&v, labels + c, 8);
-                    const uint64_t u = v ^ (k01 * uint64_t(MGPS_BOUNDARY_CELL));
-                    act = (((v - k01) & ~v & k80) | ((u - k01) & ~u & k80)) != 0;
-                }
-                for (; c < c1 && !act; ++c) act = isActive(labels[c]);
-                fineAct[size_t(q)] = act;
-            }
-        }, 1 << 12);
-        std::vector<int32_t> fine, coarse;
-        for (int64_t q = 0; q < nfine; ++q)
-            if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
-        constexpr int kRatio = kChunkCells / kWaveChunkCells;
-        for (int64_t q = 0; q < nfine; q += kRatio) {
-            bool act = false;
-            for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
-            if (act) coarse.push_back(int32_t(q / kRatio));
-        }
-        L.chunks.swap(coarse);
-        L.chunkCells = kChunkCells;
-        if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
-            L.chunks.swap(fine);
-            L.chunkCells = kWaveChunkCells;
-        }
-        // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
-        // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
-        // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
-        // strip (64 KiB) apart instead.  Pure locality: any order is correct.
-        constexpr int kStripRows = 32;
-        if (size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows) {
-            const size_t cpr = size_t(L.chunkCells);
-            auto key = [&](int32_t c) {
-                const size_t cell = size_t(c) * cpr;
-                const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
-                return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
-            };
-            // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
-            const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
-            std::vector<std::vector<int32_t>> strips(nstrips);
-            for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
-            size_t at = 0;
-            for (auto &sv : strips) {
-                std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
-                at += sv.size();
-            }
-        }
-        if (L.chunkCells == kWaveChunkCells)
-            while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
-        L.planeBlocks.clear();
-        L.planeZc = planeSweepZc(d.nx, d.ny, d.nz);
-        if (L.planeZc) {
-            const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows, nbz = (d.nz + L.planeZc - 1) / L.planeZc;
-            std::vector<uint8_t> act(size_t(nbx) * nby * nbz, 0);
-            const int zc = L.planeZc;
-            parallelFor(nbz, [&](int64_t b0, int64_t b1) {
-                for (int k = int(b0) * zc; k < std::min(d.nz, int(b1) * zc); ++k)
-                    for (int j = 0; j < d.ny; ++j) {
-                        const uint8_t *row = labels + d.idx(0, j, k);
-                        for (int bx = 0; bx < nbx; ++bx) {
-                            uint8_t &a = act[(size_t(k / zc) * nby + j / kPlaneRows) * nbx + bx];
-                            if (a) continue;
-                            for (int i = bx * 256; i < std::min(d.nx, bx * 256 + 256); ++i)
-                                if (isActive(row[i])) {
-                                    a = 1;
-                                    break;
-                                }
-                        }
-                    }
-            });
-            for (size_t q = 0; q < act.size(); ++q)
-                if (act[q]) L.planeBlocks.push_back(int32_t(q));
-        }
-    }
-    lap.lap("slab level: activity lists");
-    buildTileLists(L, z0 / kTile);
+    listsJob.join();
+    lap.lap("slab level: activity + tile lists (joined)");
     buildTileBoundaryOffsets(L);
-    lap.lap("slab level: tile lists");
     const size_t nb = size_t(L.numBoundary);
     L.rows.assign(7 * nb, 0.f);
     for (size_t t = 0; t < nb; ++t) {
