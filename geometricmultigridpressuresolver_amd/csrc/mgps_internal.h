@@ -311,7 +311,8 @@ int launchWiden(void *stream, double *dst, const float *src, size_t n);
 int launchNarrow(void *stream, float *dst, const double *src, size_t n);
 int launchZero(void *stream, float *a, size_t count);
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)
-int launchZeroActive(void *stream, const GridP &g, float *a);
+// ghostPlanes: also the plane below and the plane above the grid (slab runs)
+int launchZeroActive(void *stream, const GridP &g, float *a, bool ghostPlanes = false);
 // buf[t] = a[idx[t]] / a[idx[t]] = buf[t]; idx are offsets from owned cell 0 (negative in the lower ghost plane)
 int launchPack(void *stream, float *buf, const float *a, const int32_t *idx, int n);
 int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, int n);

@@ -1648,8 +1648,18 @@ int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const
 
 // zeros on the chunks that hold active cells only: for grids whose other chunks are known to hold 0 already (the
 // solver's own grids: nothing ever writes a chunk without active cells)
-__global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, const int32_t *__restrict__ chunks, int chunkCells, size_t nq)
+// blocks past `listBlocks` clear the two ghost planes (planeQuads quads each, just below and just above the grid)
+__global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, const int32_t *__restrict__ chunks, int chunkCells, size_t nq,
+                                                        unsigned listBlocks, size_t planeQuads)
 {
+    if (blockIdx.x >= listBlocks) {
+        const size_t t = size_t(blockIdx.x - listBlocks) * blockDim.x + threadIdx.x;
+        if (t < 2 * planeQuads) {
+            float4 *dst = t < planeQuads ? reinterpret_cast<float4 *>(a) - planeQuads + t : reinterpret_cast<float4 *>(a) + nq + (t - planeQuads);
+            *dst = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     size_t q;
     if (chunkCells == kChunkCells) q = size_t(chunks[blockIdx.x]) * (kChunkCells / 4) + threadIdx.x;
     else {
@@ -1860,12 +1870,17 @@ int launchNarrow(void *stream, float *dst, const double *src, size_t n)
 }
 
 int launchZero(void *stream, float *a, size_t count);
-int launchZeroActive(void *stream, const GridP &g, float *a)
+int launchZeroActive(void *stream, const GridP &g, float *a, bool ghostPlanes)
 {
-    const size_t n = size_t(g.nx) * g.ny * g.nz;
-    if (!g.chunks || (n & 3) != 0) return launchZero(stream, a, n);
+    const size_t n = size_t(g.nx) * g.ny * g.nz, plane = size_t(g.nx) * g.ny;
+    if (!g.chunks || (n & 3) != 0 || (plane & 3) != 0) {
+        if (ghostPlanes) return launchZero(stream, a - plane, n + 2 * plane);
+        return launchZero(stream, a, n);
+    }
     const unsigned nb = g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4;
-    if (nb > 0) zeroChunksKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(a, g.chunks, g.chunkCells, n >> 2);
+    const unsigned extra = ghostPlanes ? blocksFor(2 * (plane >> 2), 256) : 0;
+    if (nb + extra > 0)
+        zeroChunksKernel<<<nb + extra, 256, 0, static_cast<hipStream_t>(stream)>>>(a, g.chunks, g.chunkCells, n >> 2, nb, plane >> 2);
     return int(hipGetLastError());
 }
 

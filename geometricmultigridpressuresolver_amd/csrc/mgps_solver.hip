@@ -449,12 +449,7 @@ int zeroGrid(mgps_solver *h, float *a, const Dims &d, bool withGhosts)
 int zeroOwnGrid(mgps_solver *h, int l, float *a, bool withGhosts)
 {
     DevLevel &L = h->lv[l];
-    const size_t plane = size_t(L.d.nx) * L.d.ny;
-    MGPS_LAUNCH(h, launchZeroActive(h->stream, L.g, a));
-    if (withGhosts && h->dist) {
-        MGPS_LAUNCH(h, launchZero(h->stream, a - plane, plane));
-        MGPS_LAUNCH(h, launchZero(h->stream, a + L.d.cells(), plane));
-    }
+    MGPS_LAUNCH(h, launchZeroActive(h->stream, L.g, a, withGhosts && h->dist));
     return MGPS_OK;
 }
 
