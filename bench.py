@@ -147,19 +147,45 @@ def free_surface_pcg(args):
     print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (one rank per
+    GPU, 127.0.0.1 rendezvous) and relay rank 0's JSON line.  This parent never touches the GPU (no torch import, no
+    HIP call) and nothing re-execs after GPU initialisation."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    raise SystemExit(res.returncode if res.returncode else (0 if line else 1))
+
+
 def main():
     args = parse()
     if args.workload == "free_surface_pcg":
         return free_surface_pcg(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        return self_launch(args)
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     slab_run = world > 1 or args.force_slab  # --force-slab: rehearse the multi-GPU code path with one rank

@@ -48,6 +48,9 @@ class Options(C.Structure):
         ("pcg_fp64_vectors", C.c_int),
         ("interrupt", C.c_void_p),
         ("interrupt_user", C.c_void_p),
+        ("pre_sweeps", C.c_int),
+        ("post_sweeps", C.c_int),
+        ("stencil_path", C.c_int),
     ]
 
 

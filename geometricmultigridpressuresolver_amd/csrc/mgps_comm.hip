@@ -167,7 +167,7 @@ void rcclDestroy(void *user)
 extern "C" {
 
 int mgps_rccl_unique_id(unsigned char out_id[128])
-{
+try {
     static_assert(sizeof(ncclUniqueId) == 128, "mgps_rccl_unique_id ships 128 bytes");
     if (!out_id) {
         setLastGlobalError("mgps_rccl_unique_id: NULL");
@@ -185,9 +185,10 @@ int mgps_rccl_unique_id(unsigned char out_id[128])
     std::memcpy(out_id, &id, 128);
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned char id[128], int device)
-{
+try {
     if (!out || !id || size < 1 || rank < 0 || rank >= size) {
         setLastGlobalError("mgps_comm_create_rccl: bad arguments");
         return MGPS_ERR_INVALID_ARGUMENT;
@@ -232,9 +233,10 @@ int mgps_comm_create_rccl(mgps_comm *out, int rank, int size, const unsigned cha
     out->destroy = rcclDestroy;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats)
-{
+try {
     // ncclSend + ncclRecv to this rank itself inside one group, the call shape of the ghost exchange: checks on
     // any box (a single GPU is enough) that librccl's point-to-point path launches, completes in stream order and
     // delivers the bytes.  Only valid for transports made by mgps_comm_create_rccl.
@@ -276,9 +278,10 @@ int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats)
     }
     return rc;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *us_per_exchange)
-{
+try {
     // device time of `reps` back-to-back send-to-self + receive-from-self groups of `floats` floats: what one
     // ghost exchange costs on this box before any link is involved (launch + RCCL's point-to-point kernel)
     if (!comm || comm->exchange != rcclExchange || floats == 0 || reps < 1 || !us_per_exchange) {
@@ -322,6 +325,7 @@ int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *u
     }
     return rc;
 }
+MGPS_API_CATCH(nullptr)
 
 void mgps_comm_destroy(mgps_comm *comm)
 {

@@ -289,37 +289,40 @@ extern "C" {
 
 int mgps_fields_material_labels(int32_t *material, const float *liquid_phi, const float *solid_phi, const float *cwx,
                                 const float *cwy, const float *cwz, int gx, int gy, int gz, void *stream)
-{
+try {
     if (!material || !liquid_phi || !solid_phi || !cwx || !cwy || !cwz || !okBox(gx, gy, gz)) return bad("mgps_fields_material_labels");
     const Box g{gx, gy, gz};
     materialLabelsKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, material, liquid_phi, solid_phi, cwx, cwy, cwz);
     return done("mgps_fields_material_labels");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_valid_faces(int axis, uint8_t *valid, const int32_t *material, const float *cut_weights, int gx, int gy,
                             int gz, void *stream)
-{
+try {
     if (axis < 0 || axis > 2 || !valid || !material || !cut_weights || !okBox(gx, gy, gz)) return bad("mgps_fields_valid_faces");
     const Box g{gx, gy, gz};
     const size_t n = size_t(gx + (axis == 0)) * (gy + (axis == 1)) * (gz + (axis == 2));
     validFacesKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, axis, valid, material, cut_weights);
     return done("mgps_fields_valid_faces");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_domain_labels(uint8_t *expanded_labels, const int32_t *material, int gx, int gy, int gz, int ex, int ey,
                               int ez, int offset, void *stream)
-{
+try {
     if (!expanded_labels || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_domain_labels");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
     domainLabelsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_labels, material);
     return done("mgps_fields_domain_labels");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_boundary_weights(int axis, float *expanded_weights, const float *cut_weights, const float *liquid_phi,
                                  const uint8_t *valid, const int32_t *material, int gx, int gy, int gz, int ex, int ey,
                                  int ez, int offset, void *stream)
-{
+try {
     if (axis < 0 || axis > 2 || !expanded_weights || !cut_weights || !liquid_phi || !valid || !material || !okBox(gx, gy, gz) ||
         !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_boundary_weights");
@@ -329,20 +332,22 @@ int mgps_fields_boundary_weights(int axis, float *expanded_weights, const float 
                                                                                    liquid_phi, valid, material);
     return done("mgps_fields_boundary_weights");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_set_boundary_labels(uint8_t *expanded_labels, const float *wx, const float *wy, const float *wz, int ex,
                                     int ey, int ez, void *stream)
-{
+try {
     if (!expanded_labels || !wx || !wy || !wz || !okBox(ex, ey, ez)) return bad("mgps_fields_set_boundary_labels");
     const Box e{ex, ey, ez};
     setBoundaryLabelsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(e, expanded_labels, wx, wy, wz);
     return done("mgps_fields_set_boundary_labels");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_rhs(float *expanded_rhs, const int32_t *material, const float *vx, const float *vy, const float *vz,
                     const float *svx, const float *svy, const float *svz, const float *cwx, const float *cwy,
                     const float *cwz, int gx, int gy, int gz, int ex, int ey, int ez, int offset, void *stream)
-{
+try {
     if (!expanded_rhs || !material || !vx || !vy || !vz || !cwx || !cwy || !cwz || !okBox(gx, gy, gz) ||
         !okExpanded(gx, gy, gz, ex, ey, ez, offset) || ((svx || svy || svz) && !(svx && svy && svz)))
         return bad("mgps_fields_rhs");
@@ -351,30 +356,33 @@ int mgps_fields_rhs(float *expanded_rhs, const int32_t *material, const float *v
                                                                              svz, cwx, cwy, cwz);
     return done("mgps_fields_rhs");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_pressure_to_solution(float *expanded_x, const float *pressure, const int32_t *material, int gx, int gy,
                                      int gz, int ex, int ey, int ez, int offset, void *stream)
-{
+try {
     if (!expanded_x || !pressure || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_pressure_to_solution");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
     pressureToSolutionKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_x, pressure, material);
     return done("mgps_fields_pressure_to_solution");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_solution_to_pressure(float *pressure, const float *expanded_x, const int32_t *material, int gx, int gy,
                                      int gz, int ex, int ey, int ez, int offset, void *stream)
-{
+try {
     if (!pressure || !expanded_x || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_solution_to_pressure");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
     solutionToPressureKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, pressure, expanded_x, material);
     return done("mgps_fields_solution_to_pressure");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_pressure_gradient(int axis, float *velocity, const float *liquid_phi, const float *pressure,
                                   const uint8_t *valid, const int32_t *material, int gx, int gy, int gz, void *stream)
-{
+try {
     if (axis < 0 || axis > 2 || !velocity || !liquid_phi || !pressure || !valid || !material || !okBox(gx, gy, gz))
         return bad("mgps_fields_pressure_gradient");
     const Box g{gx, gy, gz};
@@ -382,11 +390,12 @@ int mgps_fields_pressure_gradient(int axis, float *velocity, const float *liquid
     pressureGradientKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, axis, velocity, liquid_phi, pressure, valid, material);
     return done("mgps_fields_pressure_gradient");
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_fields_divergence(double out_host[3], const int32_t *material, const float *vx, const float *vy, const float *vz,
                            const float *svx, const float *svy, const float *svz, const float *cwx, const float *cwy,
                            const float *cwz, int gx, int gy, int gz, void *stream)
-{
+try {
     if (!out_host || !material || !vx || !vy || !vz || !cwx || !cwy || !cwz || !okBox(gx, gy, gz) ||
         ((svx || svy || svz) && !(svx && svy && svz)))
         return bad("mgps_fields_divergence");
@@ -417,5 +426,6 @@ int mgps_fields_divergence(double out_host[3], const int32_t *material, const fl
     out_host[2] = count;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 }  // extern "C"

@@ -42,6 +42,30 @@ std::atomic<void *(*)(size_t)> gBigAlloc{nullptr};
 std::atomic<void (*)(void *)> gBigFree{nullptr};
 constexpr size_t kBigHeader = 64;  // keeps the block 64-byte aligned; word 0 = the function that releases it
 }  // namespace
+int apiException(const mgps_solver *h) noexcept
+{
+    int code = MGPS_ERR_INTERNAL;
+    const char *text = "unexpected C++ exception at the C ABI";
+    char buf[256];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = MGPS_ERR_ALLOC;
+        text = "out of host memory (std::bad_alloc)";
+    } catch (const std::exception &e) {
+        std::snprintf(buf, sizeof(buf), "internal error: %s", e.what());
+        text = buf;
+    } catch (...) {
+    }
+    if (h) setHandleError(h, text);
+    else {
+        try {
+            setLastGlobalError(text);
+        } catch (...) {
+        }
+    }
+    return code;
+}
 void *hostBigAlloc(size_t bytes)
 {
     void *(*alloc)(size_t) = gBigAlloc.load();
@@ -161,7 +185,10 @@ static void parallelFor(int64_t n, F fn, int64_t grain = 1)  // grain: smallest 
 }
 
 // Coarse labels from the 8 children, then BOUNDARY marking (Ops.cpp:23-163).
-static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
+// Returns false -- before the BOUNDARY marking, which looks at all six neighbours of every INTERIOR cell -- when the
+// coarse level has lost its EXTERIOR shell (the reference asserts unitTestExteriorCells on every level, MG.cpp:252):
+// the fine grid then carries fewer than 2^level EXTERIOR cells on some side.
+static bool coarsenLabels(const HostLevel &fine, HostLevel &coarse)
 {
     const Dims fd = fine.d;
     Dims cd;
@@ -193,6 +220,11 @@ static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
                 }
             }
     });
+    {
+        int shell = 0;
+        mgps_check_exterior_cells(cl, cd.nx, cd.ny, cd.nz, &shell);
+        if (!shell) return false;
+    }
     // second pass on a snapshot of "is this neighbour EXTERIOR or DIRICHLET" -- marking only turns
     // INTERIOR into BOUNDARY, neither of which the test looks for, so reading in place is safe
     const ptrdiff_t stride[3] = {1, cd.nx, ptrdiff_t(cd.nx) * cd.ny};
@@ -211,6 +243,7 @@ static void coarsenLabels(const HostLevel &fine, HostLevel &coarse)
                     if (bnd) cl[c] = MGPS_BOUNDARY_CELL;
                 }
     });
+    return true;
 }
 
 // Band list (Ops.cpp:165-469): BOUNDARY cells plus `width`-1 rings of INTERIOR cells grown
@@ -1240,6 +1273,9 @@ void mgps_default_options(mgps_options *opt)
     opt->max_coarse_unknowns = 8192;
     opt->interrupt = nullptr;
     opt->interrupt_user = nullptr;
+    opt->pre_sweeps = 1;   // MG.cpp:466-486
+    opt->post_sweeps = 1;  // MG.cpp:740-757
+    opt->stencil_path = 0;
 }
 
 const char *mgps_status_string(int status)
@@ -1254,6 +1290,7 @@ const char *mgps_status_string(int status)
         case MGPS_ERR_COARSE_TOO_LARGE: return "coarsest level too large for the direct solver";
         case MGPS_ERR_COARSE_FACTOR: return "coarsest-level factorisation failed";
         case MGPS_ERR_COMM: return "communication error";
+        case MGPS_ERR_INTERNAL: return "internal error (C++ exception caught at the boundary)";
         case MGPS_ERR_INTERRUPTED: return "interrupted";
         default: return "unknown status";
     }
@@ -1261,7 +1298,7 @@ const char *mgps_status_string(int status)
 
 int mgps_expanded_layout(int bnx, int bny, int bnz, int levels_in, int power_of_two, int out_dims[3],
                          int *out_offset, int *out_levels)
-{
+try {
     if (bnx <= 0 || bny <= 0 || bnz <= 0 || !out_dims || !out_offset || !out_levels)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expanded_layout: bad arguments");
     int levels = levels_in;
@@ -1282,10 +1319,11 @@ int mgps_expanded_layout(int bnx, int bny, int bnz, int levels_in, int power_of_
     *out_levels = levels;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_expand_labels(uint8_t *expanded, const uint8_t *base, int bnx, int bny, int bnz, int enx, int eny,
                        int enz, int offset)
-{
+try {
     if (!expanded || !base || offset < 0 || enx < bnx + offset || eny < bny + offset || enz < bnz + offset)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expand_labels: bad arguments");
     const Dims bd{bnx, bny, bnz}, ed{enx, eny, enz};
@@ -1300,10 +1338,11 @@ int mgps_expand_labels(uint8_t *expanded, const uint8_t *base, int bnx, int bny,
         }
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_expand_weights(float *expanded, const float *base, int axis, int bnx, int bny, int bnz, int enx,
                         int eny, int enz, int offset)
-{
+try {
     if (!expanded || !base || axis < 0 || axis > 2)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_expand_weights: bad arguments");
     const Dims bf{bnx + (axis == 0), bny + (axis == 1), bnz + (axis == 2)};
@@ -1319,6 +1358,7 @@ int mgps_expand_weights(float *expanded, const float *base, int axis, int bnx, i
             }
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 static inline size_t faceIndex(const Dims &d, int axis, int i, int j, int k, int plus)
 {
@@ -1331,7 +1371,7 @@ static inline size_t faceIndex(const Dims &d, int axis, int i, int j, int k, int
 
 int mgps_set_boundary_labels(uint8_t *labels, const float *wx, const float *wy, const float *wz, int nx, int ny,
                              int nz)
-{
+try {
     if (!labels || !wx || !wy || !wz || nx < 3 || ny < 3 || nz < 3)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_set_boundary_labels: bad arguments");
     const Dims d{nx, ny, nz};
@@ -1355,9 +1395,10 @@ int mgps_set_boundary_labels(uint8_t *labels, const float *wx, const float *wy, 
     });
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_check_exterior_cells(const uint8_t *labels, int nx, int ny, int nz, int *pass)
-{
+try {
     if (!labels || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_exterior_cells: bad arguments");
     const Dims d{nx, ny, nz};
     *pass = 0;
@@ -1376,10 +1417,11 @@ int mgps_check_exterior_cells(const uint8_t *labels, int nx, int ny, int nz, int
     *pass = 1;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const float *wy, const float *wz, int nx,
                               int ny, int nz, int *pass)
-{
+try {
     if (!labels || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_boundary_cells: bad arguments");
     const Dims d{nx, ny, nz};
     const float *w[3] = {wx, wy, wz};
@@ -1411,6 +1453,7 @@ int mgps_check_boundary_cells(const uint8_t *labels, const float *wx, const floa
     *pass = ok.load();
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 }  // extern "C"
 
@@ -1436,7 +1479,7 @@ void mgps::checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int
 extern "C" {
 
 int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, int fny, int fnz, int *pass)
-{
+try {
     if (!coarse || !fine || !pass) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_check_coarsening: bad arguments");
     const Dims fd{fnx, fny, fnz}, cd{fnx / 2, fny / 2, fnz / 2};
     *pass = 0;
@@ -1460,12 +1503,14 @@ int mgps_check_coarsening(const uint8_t *coarse, const uint8_t *fine, int fnx, i
     *pass = 1;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_hierarchy_create(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
                           const mgps_options *opt)
-{
+try {
     return mgps::hierarchyCreate(out, nx, ny, nz, labels, mg_levels, opt, false, true);
 }
+MGPS_API_CATCH(nullptr)
 
 }  // extern "C"
 
@@ -1536,14 +1581,24 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     // the fine level's band list (the largest single piece, MG.cpp:279-281) beside the coarsening chain
     std::thread fineBand([H] { buildBand(H->lv[0], H->bandWidth); });
     int levels = mg_levels;
+    int shellLost = 0;
     for (int l = 1; l < levels; ++l) {  // MG.cpp:238-253
-        coarsenLabels(H->lv[l - 1], H->lv[l]);
+        if (!coarsenLabels(H->lv[l - 1], H->lv[l])) {  // MG.cpp:252
+            shellLost = l;
+            break;
+        }
         if (!solvable(H->lv[l])) {
             levels = l - 1;  // the reference drops the last solvable level too (MG.cpp:245)
             break;
         }
     }
     fineBand.join();
+    if (shellLost) {
+        delete H;
+        return fail(MGPS_ERR_HIERARCHY, "level " + std::to_string(shellLost) + " has no EXTERIOR shell (unitTestExteriorCells, MG.cpp:252): " +
+                                            std::to_string(mg_levels) + " levels need 2^(levels-1) = " + std::to_string(1 << (mg_levels - 1)) +
+                                            " EXTERIOR cells on every side of the solver grid (mgps_expanded_layout pads that much)");
+    }
     if (levels < 1) {
         delete H;
         return fail(MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)");
@@ -1573,7 +1628,7 @@ void mgps_hierarchy_destroy(mgps_hierarchy *hier) { delete hier; }
 int mgps_hierarchy_levels(const mgps_hierarchy *hier) { return hier ? hier->levels : 0; }
 
 int mgps_hierarchy_level_dims(const mgps_hierarchy *hier, int level, int out_dims[3])
-{
+try {
     if (!hier || level < 0 || level >= hier->levels || !out_dims)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_level_dims: bad arguments");
     out_dims[0] = hier->lv[level].d.nx;
@@ -1581,14 +1636,16 @@ int mgps_hierarchy_level_dims(const mgps_hierarchy *hier, int level, int out_dim
     out_dims[2] = hier->lv[level].d.nz;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_hierarchy_level_labels(const mgps_hierarchy *hier, int level, uint8_t *out)
-{
+try {
     if (!hier || level < 0 || level >= hier->levels || !out)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_level_labels: bad arguments");
     std::memcpy(out, hier->lv[level].labels.data(), hier->lv[level].labels.size());
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level)
 {
@@ -1597,7 +1654,7 @@ int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level)
 }
 
 int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *out_ijk)
-{
+try {
     if (!hier || level < 0 || level >= hier->levels || !out_ijk)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_band_cells: bad arguments");
     const Dims d = hier->lv[level].d;
@@ -1609,13 +1666,14 @@ int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *ou
     }
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 // Host check of the fused band stage: builds the level's groups, verifies their structure and replays
 // `depth` passes both ways (pass by pass over the whole band / group by group in local storage) on a
 // seeded grid with the unit-weight operator; the two must agree bit for bit.
 int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
                                      int64_t *out_nodes)
-{
+try {
     if (!hier || level < 0 || level >= hier->levels || depth < 1 || depth > kBandMaxDepth)
         return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_check_band_groups: bad arguments");
     HostLevel L;
@@ -1698,11 +1756,12 @@ int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int 
         if (fusedOut[t] != ref[size_t(L.bandDev[t])]) return fail(MGPS_ERR_HIERARCHY, "fused band replay differs from pass-by-pass replay");
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier) { return hier ? hier->coarseN : 0; }
 
 int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b)
-{
+try {
     if (!hier || !x || !b) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_coarse_solve: bad arguments");
     std::vector<double> v(hier->coarseN);
     for (int r = 0; r < hier->coarseN; ++r) v[r] = b[hier->coarseCell[r]];
@@ -1710,5 +1769,6 @@ int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const floa
     for (int r = 0; r < hier->coarseN; ++r) x[hier->coarseCell[r]] = float(v[r]);
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 }  // extern "C"

@@ -187,6 +187,12 @@ int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t 
                     const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
 void setLastGlobalError(const std::string &msg);
 const char *lastGlobalError();
+// No C++ exception crosses the C ABI: every extern "C" entry point that can allocate is a function-try-block ending in
+// MGPS_API_CATCH(handle or nullptr).  apiException classifies the exception in flight (std::bad_alloc -> MGPS_ERR_ALLOC,
+// anything else -> MGPS_ERR_INTERNAL) and leaves the text in the handle's (or the global) last-error slot.
+int apiException(const mgps_solver *h) noexcept;
+void setHandleError(const mgps_solver *h, const char *msg) noexcept;  // mgps_solver.hip (the struct is defined there)
+#define MGPS_API_CATCH(h) catch (...) { return ::mgps::apiException(h); }
 
 // ---- device side ------------------------------------------------------------------------------
 // Read-only description of one level handed to the kernels.
@@ -212,6 +218,8 @@ struct GridP {
     // (rhs, codes) and nontemporal stores for their output; smaller levels leave everything cacheable (the next
     // kernel finds it there)
     int streaming;
+    // which sweep kernel launchStencil takes (options.stencil_path): 0 = by size, 1 = quad, 2 = plane-marching where it applies
+    int sweepPath;
 };
 
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
@@ -231,6 +239,8 @@ enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };
 // skipInactive: leave chunks without active cells untouched (callers whose `out` already holds the
 // right values there: 0 for r / y, the unchanged iterate for Jacobi)
 size_t stencilSweptCells(const GridP &g);
+// which kernel launchStencil takes on this level: 1 = stencilQuadKernel, 2 = stencilPlaneKernel, 3 = stencilScalarKernel
+int stencilKernelOf(const GridP &g);
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                   bool skipInactive);
 // out = A x and *resultDev = <x, A x> over the active cells of level g in one pass (the CG loop's A.p and its dot);

@@ -1227,20 +1227,20 @@ inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + p
 
 // ---- launchers -------------------------------------------------------------------------------
 
-static int forcedStencil()
+static int forcedStencil(const GridP &g)
 {
     static const int forced = [] {  // MGPS_STENCIL=quad|plane: A/B switch for tuning runs
         const char *e = getenv("MGPS_STENCIL");
         return !e ? 0 : (e[0] == 'q' ? 1 : 2);
     }();
-    return forced;
+    return g.sweepPath ? g.sweepPath : forced;  // options.stencil_path wins over the environment
 }
 
 // Cells one activity-skipping full-domain sweep visits (the denominator of the measured bytes per cell).
 size_t stencilSweptCells(const GridP &g)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const int forced = forcedStencil();
+    const int forced = forcedStencil(g);
     const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
     if (g.planeZc && (forced == 2 || (forced == 0 && planeWins)))
         return g.planeBlocks ? std::min(n, size_t(g.nplaneBlocks) * 256 * kPlaneRows * g.planeZc) : n;
@@ -1253,7 +1253,7 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const int forced = forcedStencil();
+    const int forced = forcedStencil(g);
     const int zc = g.planeZc;  // 0: the plane-marching sweep does not apply to this shape
     // measured on MI355X (fine Jacobi sweep, plane vs quad kernel): 256^3 42.8 vs 40.8 us, 512^3 367 vs
     // 345 us, 1024^3 2.68 vs 2.95 ms -- the cache-only kernel wins while three x-y planes of x stay in an
@@ -1302,7 +1302,7 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 static unsigned sweepBlocks(const GridP &g, bool skipInactive, int *path)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const int forced = forcedStencil();
+    const int forced = forcedStencil(g);
     const int zc = g.planeZc;
     const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
     if (zc && (forced == 2 || (forced == 0 && planeWins))) {
@@ -1316,6 +1316,13 @@ static unsigned sweepBlocks(const GridP &g, bool skipInactive, int *path)
     }
     *path = 2;
     return blocksFor(n, 256);
+}
+
+int stencilKernelOf(const GridP &g)
+{
+    int path = 0;
+    (void)sweepBlocks(g, true, &path);
+    return path == 0 ? 2 : path == 1 ? 1 : 3;
 }
 
 size_t applyDotPartialCount(const GridP &g)

@@ -108,8 +108,17 @@ struct mgps_solver {
     bool profiling = false;
     std::vector<hipEvent_t> profEvents;
     size_t profUsed = 0;
+    int profSweeps = 0;  // full-domain sweeps the event pairs cover (a Gauss-Seidel sweep is two pairs: one per colour)
     std::string lastError = "";
 };
+
+void mgps::setHandleError(const mgps_solver *h, const char *msg) noexcept
+{
+    try {
+        const_cast<mgps_solver *>(h)->lastError = msg;
+    } catch (...) {
+    }
+}
 
 namespace {
 
@@ -355,7 +364,24 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first,
     return MGPS_OK;
 }
 
-int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL, bool dot = false)
+// measurement hook: an event pair strictly around the launches of a fine-level full-domain sweep (after its ghost
+// exchange, so that on slab runs the figure is kernel time, not kernel + communication time)
+int profMark(mgps_solver *h, bool begin)
+{
+    if (begin && h->profUsed + 2 > h->profEvents.size()) {
+        hipEvent_t e0, e1;
+        MGPS_HIP(h, hipEventCreate(&e0));
+        MGPS_HIP(h, hipEventCreate(&e1));
+        h->profEvents.push_back(e0);
+        h->profEvents.push_back(e1);
+    }
+    MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + (begin ? 0 : 1)], h->stream));
+    if (!begin) h->profUsed += 2;
+    return MGPS_OK;
+}
+
+int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL, bool dot = false,
+                bool timed = false)
 {
     DevLevel &L = h->lv[l];
     MGPS_TRY(exchangeGhosts(h, l, x, ghosts));  // the other colour's tiles across the cut changed in the previous pass
@@ -364,12 +390,15 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
         sink = h->dotPartials + h->dotUsed;
         h->dotUsed += unsigned(L.npure[odd] + L.nmixed[odd]);
     }
+    if (timed) MGPS_TRY(profMark(h, true));
     MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
                                  L.tileBndStart, forward, sink));
+    if (timed) MGPS_TRY(profMark(h, false));
     return MGPS_OK;
 }
 
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
+// The smoother runs options.pre_sweeps (down) / post_sweeps (up) times; the reference's count is one.
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
 // ghostsFresh: the ghosts of `cur` are known to be complete on entry (all zero after a clear).
 // Ghost traffic of a stroke: whole planes after whatever rewrote the whole grid (the caller's
@@ -383,37 +412,31 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     // after the band passes only band cells are stale across the cut -- unless there were none
     const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
-    if (timed) {
-        if (h->profUsed + 2 > h->profEvents.size()) {
-            hipEvent_t e0, e1;
-            MGPS_HIP(h, hipEventCreate(&e0));
-            MGPS_HIP(h, hipEventCreate(&e1));
-            h->profEvents.push_back(e0);
-            h->profEvents.push_back(e1);
+    const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
+    for (int rep = 0; rep < reps; ++rep) {
+        const GhostMode before = rep == 0 ? afterBands : GHOST_FULL;  // a sweep rewrote everything
+        const bool d = dot && rep == reps - 1;  // <x, b> of the stroke's result: the last sweep's values
+        if (h->useGS) {
+            if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, before, d, timed));
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_FULL, d, timed));
+            } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, before, d, timed));
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_FULL, d, timed));
+            }
+        } else {
+            MGPS_TRY(exchangeGhosts(h, l, cur, before));
+            if (timed) MGPS_TRY(profMark(h, true));
+            if (d) {
+                unsigned used = 0;
+                MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
+                h->dotUsed += used;
+            } else
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, true));
+            if (timed) MGPS_TRY(profMark(h, false));
+            std::swap(cur, other);
         }
-        MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed], h->stream));
-    }
-    if (h->useGS) {
-        if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, afterBands, dot));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_FULL, dot));
-        } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, afterBands, dot));
-            MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_FULL, dot));
-        }
-    } else {
-        MGPS_TRY(exchangeGhosts(h, l, cur, afterBands));
-        if (dot) {
-            unsigned used = 0;
-            MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
-            h->dotUsed += used;
-        } else
-            MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, true));
-        std::swap(cur, other);
-    }
-    if (timed) {
-        MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + 1], h->stream));
-        h->profUsed += 2;
+        if (timed) ++h->profSweeps;
     }
     MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot));  // the full-domain smoother rewrote everything
     return MGPS_OK;
@@ -921,7 +944,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 HL.planeZc ? L.planeBlocks : nullptr,
                 int(HL.planeBlocks.size()),
                 HL.planeZc,
-                L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0};
+                L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0,
+                h->opt.stencil_path};
     return MGPS_OK;
 }
 
@@ -1039,6 +1063,8 @@ int readOptions(const mgps_options *opt, mgps_options *o)
             return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options.struct_size mismatch: call mgps_default_options first");
         *o = *opt;
     }
+    if (o->pre_sweeps < 1 || o->post_sweeps < 1 || o->stencil_path < 0 || o->stencil_path > 2)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options: pre_sweeps / post_sweeps must be >= 1 and stencil_path 0, 1 or 2");
     return MGPS_OK;
 }
 
@@ -1177,18 +1203,19 @@ const char *mgps_last_error(const mgps_solver *h) { return h ? h->lastError.c_st
 void mgps_trim_host_cache(void) { pinnedTrim(); }
 
 int mgps_device_count(int *count)
-{
+try {
     if (!count) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_device_count: NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     *count = (e == hipSuccess) ? n : 0;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const float *wx_host,
                 const float *wy_host, const float *wz_host, int mg_levels, int use_gauss_seidel,
                 const mgps_options *opt)
-{
+try {
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create: out is NULL");
     *out = nullptr;
     if (!labels_host || !wx_host || !wy_host || !wz_host)
@@ -1210,6 +1237,7 @@ int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels
     }
     return createWhole(out, hier, wx_host, wy_host, wz_host, use_gauss_seidel != 0, o, device, false);
 }
+MGPS_API_CATCH(nullptr)
 
 }  // extern "C"
 
@@ -1272,17 +1300,18 @@ extern "C" {
 int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host, const float *wx_dev,
                                const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
                                const mgps_options *opt)
-{
+try {
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: out is NULL");
     *out = nullptr;
     if (!labels_host || !wx_dev || !wy_dev || !wz_dev)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: labels and the three weight grids are required");
     return createFromDeviceWeights(out, nx, ny, nz, labels_host, nullptr, wx_dev, wy_dev, wz_dev, mg_levels, use_gauss_seidel, opt);
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_dev, const float *wx_dev,
                        const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel, const mgps_options *opt)
-{
+try {
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device: out is NULL");
     *out = nullptr;
     if (!labels_dev || !wx_dev || !wy_dev || !wz_dev || nx < 1 || ny < 1 || nz < 1)
@@ -1297,11 +1326,12 @@ int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t 
         return failH(nullptr, MGPS_ERR_HIP, "mgps_create_device: copying the labels to the host failed");
     return createFromDeviceWeights(out, nx, ny, nz, labels.data(), labels_dev, wx_dev, wy_dev, wz_dev, mg_levels, use_gauss_seidel, opt);
 }
+MGPS_API_CATCH(nullptr)
 
 int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
                      const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
                      int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm)
-{
+try {
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: out is NULL");
     *out = nullptr;
     if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm)
@@ -1460,6 +1490,7 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
     *out = h;
     return MGPS_OK;
 }
+MGPS_API_CATCH(nullptr)
 
 void mgps_destroy(mgps_solver *h) { freeAll(h); }
 int mgps_levels(const mgps_solver *h) { return h ? h->totalLevels : 0; }
@@ -1467,7 +1498,7 @@ const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *h) { return h ? h->h
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
-{
+try {
     if (!h || !out_dims || level < 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_dims: bad arguments");
     if (level < int(h->lv.size())) {  // the grids this object works on (the slab in a slab run)
         out_dims[0] = h->lv[level].d.nx;
@@ -1477,41 +1508,46 @@ int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
     }
     return mgps_hierarchy_level_dims(h->hier, level, out_dims);
 }
+MGPS_API_CATCH(h)
 
 int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1)
-{
+try {
     if (!h || !z0 || !z1 || level < 0 || level >= int(h->lv.size()))
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_slab_range: bad arguments");
     *z0 = h->lv[level].z0;
     *z1 = h->lv[level].z1;
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_set_stream(mgps_solver *h, void *hip_stream)
-{
+try {
     if (!h) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_set_stream: NULL handle");
     h->stream = static_cast<hipStream_t>(hip_stream);
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_synchronize(mgps_solver *h)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_synchronize"));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_grid_alloc(mgps_solver *h, int level, float **out_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_grid_alloc"));
     if (!out_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_alloc: out is NULL");
     MGPS_TRY(gridAlloc(h, out_dev, h->lv[level].d));
     h->userGrids.push_back(*out_dev - size_t(h->lv[level].d.nx) * h->lv[level].d.ny);
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_grid_free(mgps_solver *h, float *dev)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_grid_free"));
     for (auto it = h->userGrids.begin(); it != h->userGrids.end(); ++it)
         for (const DevLevel &L : h->lv)
@@ -1524,50 +1560,56 @@ int mgps_grid_free(mgps_solver *h, float *dev)
             }
     return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_free: not a grid of this solver");
 }
+MGPS_API_CATCH(h)
 
 int mgps_grid_upload(mgps_solver *h, int level, float *dst_dev, const float *src_host)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_grid_upload"));
     if (!dst_dev || !src_host) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_upload: NULL pointer");
     MGPS_HIP(h, hipMemcpyAsync(dst_dev, src_host, h->lv[level].d.cells() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_grid_download(mgps_solver *h, int level, float *dst_host, const float *src_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_grid_download"));
     if (!dst_host || !src_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_download: NULL pointer");
     MGPS_HIP(h, hipMemcpyAsync(dst_host, src_dev, h->lv[level].d.cells() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_copy_to_host(mgps_solver *h, void *dst_host, const void *src_dev, size_t bytes)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_copy_to_host"));
     MGPS_HIP(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, size_t bytes)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_copy_to_device"));
     MGPS_HIP(h, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_apply_vcycle(mgps_solver *h, float *x_dev, const float *b_dev, int use_initial_guess)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_apply_vcycle"));
     if (!x_dev || !b_dev || x_dev == b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_apply_vcycle: bad grid pointers");
     return vcycle(h, x_dev, b_dev, use_initial_guess != 0);
 }
+MGPS_API_CATCH(h)
 
 int mgps_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_jacobi_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_jacobi_smooth: NULL grid");
     DevLevel &L = h->lv[level];
@@ -1576,17 +1618,19 @@ int mgps_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_d
     MGPS_HIP(h, hipMemcpyAsync(x_dev, L.tmp, L.d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_tiled_gs_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev, int smooth_odd_tiles,
                          int smooth_forward)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_tiled_gs_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_tiled_gs_smooth: NULL grid");
     return gsHalfSweep(h, level, x_dev, b_dev, smooth_odd_tiles ? 1 : 0, smooth_forward != 0);
 }
+MGPS_API_CATCH(h)
 
 int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const float *b_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_boundary_jacobi_smooth"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_boundary_jacobi_smooth: NULL grid");
     DevLevel &L = h->lv[level];
@@ -1594,31 +1638,35 @@ int mgps_boundary_jacobi_smooth(mgps_solver *h, int level, float *x_dev, const f
     MGPS_LAUNCH(h, launchBandJacobi(h->stream, L.g, x_dev, b_dev, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_boundary_jacobi_stage(mgps_solver *h, int level, float *x_dev, const float *b_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_boundary_jacobi_stage"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_boundary_jacobi_stage: NULL grid");
     return bandPasses(h, level, x_dev, b_dev, GHOST_FULL);
 }
+MGPS_API_CATCH(h)
 
 int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_apply_poisson"));
     if (!y_dev || !x_dev || y_dev == x_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_apply_poisson: bad grid pointers");
     return applyOp(h, OP_APPLY, level, y_dev, const_cast<float *>(x_dev), nullptr);
 }
+MGPS_API_CATCH(h)
 
 int mgps_residual(mgps_solver *h, int level, float *r_dev, const float *x_dev, const float *b_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_residual"));
     if (!r_dev || !x_dev || !b_dev || r_dev == x_dev)
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_residual: bad grid pointers");
     return applyOp(h, OP_RESIDUAL, level, r_dev, const_cast<float *>(x_dev), b_dev);
 }
+MGPS_API_CATCH(h)
 
 int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *fine_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_downsample"));
     if (fine_level < 0 || !coarse_dev || !fine_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_downsample: bad arguments");
     MGPS_TRY(exchangeGhosts(h, fine_level, const_cast<float *>(fine_dev)));
@@ -1627,97 +1675,110 @@ int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const flo
     MGPS_LAUNCH(h, launchRestrict(h->stream, h->lv[fine_level + 1].g, coarse_dev, fine_dev));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_upsample_add(mgps_solver *h, int fine_level, float *fine_dev, const float *coarse_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_upsample_add"));
     if (fine_level < 0 || !coarse_dev || !fine_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_upsample_add: bad arguments");
     MGPS_TRY(exchangeGhosts(h, fine_level + 1, const_cast<float *>(coarse_dev)));
     MGPS_LAUNCH(h, launchProlongAdd(h->stream, h->lv[fine_level].g, fine_dev, coarse_dev));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_coarse_solve(mgps_solver *h, float *x_dev, const float *b_dev)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_coarse_solve"));
     if (!x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_coarse_solve: NULL grid");
     if (h->dist) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_coarse_solve: not available on a slab solver");
     MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, x_dev, b_dev, h->cvec));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_dot(mgps_solver *h, int level, const float *a_dev, const float *b_dev, double *out)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_dot"));
     if (!a_dev || !b_dev || !out) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_dot: NULL pointer");
     return reduceToHost(h, 0, level, a_dev, b_dev, out);
 }
+MGPS_API_CATCH(h)
 
 int mgps_squared_l2_norm(mgps_solver *h, int level, const float *a_dev, double *out)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_squared_l2_norm"));
     if (!a_dev || !out) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_squared_l2_norm: NULL pointer");
     return reduceToHost(h, 1, level, a_dev, nullptr, out);
 }
+MGPS_API_CATCH(h)
 
 int mgps_l2_norm(mgps_solver *h, int level, const float *a_dev, double *out)
-{
+try {
     MGPS_TRY(mgps_squared_l2_norm(h, level, a_dev, out));
     *out = std::sqrt(*out);  // Ops.h:1202
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_inf_norm(mgps_solver *h, int level, const float *a_dev, int reference_signed_max, double *out)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_inf_norm"));
     if (!a_dev || !out) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_inf_norm: NULL pointer");
     return reduceToHost(h, reference_signed_max ? 2 : 3, level, a_dev, nullptr, out);
 }
+MGPS_API_CATCH(h)
 
 int mgps_add_to_vector(mgps_solver *h, int level, float *dst_dev, const float *src_dev, double scale)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_add_to_vector"));
     if (!dst_dev || !src_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_add_to_vector: NULL grid");
     MGPS_LAUNCH(h, launchAxpy(h->stream, h->lv[level].g, dst_dev, src_dev, nullptr, float(scale), 1.f));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_add_vectors(mgps_solver *h, int level, float *dst_dev, const float *a_dev, const float *scaled_dev, double scale)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_add_vectors"));
     if (!dst_dev || !a_dev || !scaled_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_add_vectors: NULL grid");
     MGPS_LAUNCH(h, launchXpay(h->stream, h->lv[level].g, dst_dev, a_dev, scaled_dev, nullptr, float(scale)));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_scale_vector(mgps_solver *h, int level, float *v_dev, double scale)
-{
+try {
     MGPS_TRY(checkLevel(h, level, "mgps_scale_vector"));
     if (!v_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_scale_vector: NULL grid");
     MGPS_LAUNCH(h, launchScale(h->stream, h->lv[level].g, v_dev, float(scale)));
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tolerance, int max_iterations,
                    int use_mg_preconditioner, mgps_pcg_stats *stats)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_solve_pcg"));
     if (!x_dev || !b_dev || x_dev == b_dev || !(tolerance >= 0) || max_iterations < 0)
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_solve_pcg: bad arguments");
     return pcg(h, x_dev, const_cast<float *>(b_dev), tolerance, max_iterations, use_mg_preconditioner != 0, stats);
 }
+MGPS_API_CATCH(h)
 
 int mgps_profile_enable(mgps_solver *h, int enable)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_profile_enable"));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     h->profiling = enable != 0;
     h->profUsed = 0;
+    h->profSweeps = 0;
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_profile_read"));
     if (!fine_smoother_ms || !fine_smoother_launches)
         return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_profile_read: NULL pointer");
@@ -1729,19 +1790,30 @@ int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smooth
         total += ms;
     }
     *fine_smoother_ms = total;
-    *fine_smoother_launches = int(h->profUsed / 2);
+    *fine_smoother_launches = h->profSweeps;
     h->profUsed = 0;
+    h->profSweeps = 0;
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
 
 int mgps_swept_cells(const mgps_solver *h, int level, long long *stencil_cells, long long *gs_cells)
-{
+try {
     if (!h || level < 0 || level >= int(h->lv.size()) || !stencil_cells || !gs_cells) return MGPS_ERR_INVALID_ARGUMENT;
     const DevLevel &L = h->lv[level];
     *stencil_cells = (long long)stencilSweptCells(L.g);
     *gs_cells = (long long)(L.npure[0] + L.npure[1] + L.nmixed[0] + L.nmixed[1]) * 4096;
     return MGPS_OK;
 }
+MGPS_API_CATCH(h)
+
+int mgps_stencil_kernel(const mgps_solver *h, int level, int *kernel)
+try {
+    if (!h || level < 0 || level >= int(h->lv.size()) || !kernel) return MGPS_ERR_INVALID_ARGUMENT;
+    *kernel = stencilKernelOf(h->lv[level].g);
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
 
 static int withHostGrids(mgps_solver *h, float *x_host, const float *b_host, bool uploadX,
                          int (*body)(mgps_solver *, float *, const float *, void *), void *ctx)
@@ -1762,7 +1834,7 @@ static int withHostGrids(mgps_solver *h, float *x_host, const float *b_host, boo
 }
 
 int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, int use_initial_guess)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_apply_vcycle_host"));
     int guess = use_initial_guess;
     return withHostGrids(
@@ -1770,6 +1842,7 @@ int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, i
         [](mgps_solver *hh, float *xd, const float *bd, void *c) { return mgps_apply_vcycle(hh, xd, bd, *static_cast<int *>(c)); },
         &guess);
 }
+MGPS_API_CATCH(h)
 
 struct PcgHostCtx {
     double tol;
@@ -1779,7 +1852,7 @@ struct PcgHostCtx {
 
 int mgps_solve_pcg_host(mgps_solver *h, float *x_host, const float *b_host, double tolerance, int max_iterations,
                         int use_mg_preconditioner, mgps_pcg_stats *stats)
-{
+try {
     MGPS_TRY(checkLevel(h, 0, "mgps_solve_pcg_host"));
     PcgHostCtx ctx{tolerance, max_iterations, use_mg_preconditioner, stats};
     return withHostGrids(
@@ -1790,5 +1863,6 @@ int mgps_solve_pcg_host(mgps_solver *h, float *x_host, const float *b_host, doub
         },
         &ctx);
 }
+MGPS_API_CATCH(h)
 
 }  // extern "C"

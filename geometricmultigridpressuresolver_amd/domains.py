@@ -75,20 +75,21 @@ def ghost_fluid_theta(phi0, phi1):
 def _box_face_weights(g, axis, lo, hi, dtype):
     """Open-area fraction of every face of `axis` for a solid box [lo,hi]^3 in the unit cube;
     fractions below 0.01 clamp to 0 (Test.cpp:320)."""
-    dx = 1.0 / g
+    gz, gy, gx = g if isinstance(g, tuple) else (g, g, g)  # a non-cubic box: coordinates normalised per axis
 
     def overlap(n):  # covered length fraction of cell intervals [q dx, (q+1) dx]
+        dx = 1.0 / n
         q = np.arange(n)
         a = np.maximum(q * dx, lo)
         b = np.minimum((q + 1) * dx, hi)
         return np.clip(b - a, 0.0, None) / dx
 
     def inside(n):  # face planes q*dx inside the box
-        q = np.arange(n) * dx
+        q = np.arange(n + 1) / n
         return ((q >= lo) & (q <= hi)).astype(np.float64)
 
-    per_axis = [overlap(g), overlap(g), overlap(g)]
-    per_axis[axis] = inside(g + 1)
+    per_axis = [overlap(gx), overlap(gy), overlap(gz)]
+    per_axis[axis] = inside((gx, gy, gz)[axis])
     covered = per_axis[2][:, None, None] * per_axis[1][None, :, None] * per_axis[0][None, None, :]
     w = 1.0 - covered
     w[w < 0.01] = 0.0
@@ -99,9 +100,9 @@ def build_complex_domain(grid_size, use_solid=False, dtype=np.float64, solid_box
     """Test.cpp:207-464: liquid where phi <= 0 with phi = x - .5 + .25 sin(2 pi y + 4 pi z) sampled
     at cell index * dx; wall faces closed; cells without an open face EXTERIOR; liquid/air faces
     divided by clamp(theta, .01, 1); air/air faces 0.  grid_size may be a (gz, gy, gx) tuple for a
-    non-cubic box (coordinates are then normalised per axis; no solid in that case)."""
+    non-cubic box (coordinates are then normalised per axis, the solid box included)."""
     if isinstance(grid_size, tuple):
-        return _build_complex_box(grid_size, dtype)
+        return _build_complex_box(grid_size, dtype, use_solid, solid_box)
     g = grid_size
     dx = 1.0 / g
     q = np.arange(g) * dx
@@ -110,16 +111,16 @@ def build_complex_domain(grid_size, use_solid=False, dtype=np.float64, solid_box
     return _complex_from_phi(phi, (g, g, g), use_solid, solid_box, dtype, dx)
 
 
-def _build_complex_box(shape, dtype):
+def _build_complex_box(shape, dtype, use_solid=False, solid_box=(0.4, 0.6)):
     gz, gy, gx = shape
     z, y, x = np.meshgrid(np.arange(gz) / gz, np.arange(gy) / gy, np.arange(gx) / gx, indexing="ij")
     phi = x - 0.5 + 0.25 * np.sin(2.0 * np.pi * y + 4.0 * np.pi * z)
-    return _complex_from_phi(phi, shape, False, None, dtype, 1.0 / max(shape))
+    return _complex_from_phi(phi, shape, use_solid, solid_box, dtype, 1.0 / max(shape))
 
 
 def _complex_from_phi(phi, shape, use_solid, solid_box, dtype, dx):
     gz, gy, gx = shape
-    g = gx
+    g = gx if gz == gy == gx else tuple(shape)
     weights = []
     for axis in range(3):
         if use_solid:

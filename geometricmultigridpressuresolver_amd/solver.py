@@ -358,6 +358,12 @@ class GeometricMultigridPoissonSolver:
         check(lib().mgps_swept_cells(self.h, int(level), C.byref(a), C.byref(b)), self.h)
         return a.value, b.value
 
+    def stencil_kernel(self, level=0):
+        """'quad' | 'plane' | 'scalar': the kernel the Jacobi / residual / A.x sweeps of `level` launch"""
+        k = C.c_int()
+        check(lib().mgps_stencil_kernel(self.h, int(level), C.byref(k)), self.h)
+        return {1: "quad", 2: "plane", 3: "scalar"}[k.value]
+
     # -- host-buffer forms (what the Houdini shim calls) --------------------------------------------
     def applyVCycleHost(self, solution, rhs, use_initial_guess=False):
         x = _np_f32(solution)

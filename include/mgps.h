@@ -50,7 +50,9 @@ typedef enum mgps_status {
     MGPS_ERR_COARSE_TOO_LARGE = 6, /* coarsest level has more unknowns than the direct solver takes */
     MGPS_ERR_COARSE_FACTOR = 7,  /* coarsest matrix not positive definite (MG.cpp:411) */
     MGPS_ERR_COMM = 8,           /* multi-GPU exchange failed */
-    MGPS_ERR_INTERRUPTED = 9     /* the interrupt callback asked to stop */
+    MGPS_ERR_INTERRUPTED = 9,    /* the interrupt callback asked to stop */
+    MGPS_ERR_INTERNAL = 10       /* a C++ exception other than std::bad_alloc (which maps to MGPS_ERR_ALLOC) was caught
+                                    at the boundary; the call had no effect the caller can rely on */
 } mgps_status;
 
 /* outcome of mgps_solve_pcg, mirrors the early-outs of HDK_GeometricCGPoissonSolver.h:36-40, 60-64 */
@@ -88,6 +90,17 @@ typedef struct mgps_options {
                                these vectors as doubles */
     int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
     void *interrupt_user;
+    /* full-domain smoother sweeps per stroke.  The reference hard-wires one (MG.cpp:466-486 down, 740-757 up): one
+       damped-Jacobi sweep, or the two tile colours of Gauss-Seidel once each.  pre_sweeps applies to the down-stroke of
+       every level, post_sweeps to the up-stroke; a stroke is band stage, the smoother repeated that many times
+       (Gauss-Seidel keeps its colour / direction order inside each repetition), band stage.  Defaults 1 / 1.
+       BASELINE config 1's "2+2 damped-Jacobi sweeps" is pre_sweeps = post_sweeps = 2 */
+    int pre_sweeps, post_sweeps;
+    /* which full-domain sweep kernel the Jacobi / residual / A.x passes use: 0 (default) = by size (the
+       plane-marching kernel where an x-y plane exceeds 2 MiB, i.e. 1024^2; the cache-served quad kernel below),
+       1 = the quad kernel, 2 = the plane-marching kernel wherever its shape rule allows (nx >= 256, nx % 4 == 0,
+       ny >= 16).  Same arithmetic per cell either way; for tuning and for parity tests of both kernels at small sizes */
+    int stencil_path;
 } mgps_options;
 
 typedef struct mgps_pcg_stats {
@@ -155,7 +168,10 @@ int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const floa
 /* ---- the solver object -------------------------------------------------------------------
  * GeometricMultigridPoissonSolver(labels, weights[3], mgLevels, useGaussSeidel, doPrintStats)
  * (MG.h:20-24, MG.cpp:135-418).  labels / weights are HOST arrays and are copied (MG.cpp:164,
- * 179-180).  use_gauss_seidel selects the tile-coloured Gauss-Seidel smoother (the plugin
+ * 179-180).  Padding contract: every level must keep a shell of EXTERIOR cells on all six sides (the reference
+ * asserts unitTestExteriorCells per level, MG.cpp:235, 252), i.e. the solver grid needs at least 2^(mg_levels-1)
+ * EXTERIOR cells on every side -- what buildExpandedCellLabels / mgps_expanded_layout pad (Ops.h:1347-1351); labels
+ * that break it are refused with MGPS_ERR_HIERARCHY.  use_gauss_seidel selects the tile-coloured Gauss-Seidel smoother (the plugin
  * hard-wires it on, Plug.cpp:466); 0 selects damped Jacobi. */
 int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
                 const float *wx_host, const float *wy_host, const float *wz_host, int mg_levels,
@@ -309,10 +325,11 @@ int mgps_copy_to_host(mgps_solver *h, void *dst_host, const void *src_dev, size_
 int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, size_t bytes);
 
 /* ---- measurement hooks (the reference's UT_StopWatch scopes, MG.cpp:461-492 "Smoother time") ----
- * While enabled, HIP events bracket every fine-level full-domain smoother launch group inside
- * mgps_apply_vcycle (the Jacobi sweep, or the two tile-coloured Gauss-Seidel half sweeps).
- * mgps_profile_read synchronises, returns the accumulated device time and launch-group count
- * since the last read, and resets both. */
+ * While enabled, HIP events bracket the kernels of every fine-level full-domain smoother sweep inside
+ * mgps_apply_vcycle (the Jacobi sweep; each of the two tile-coloured Gauss-Seidel half sweeps) -- the kernels only:
+ * on slab runs the ghost exchange in front of a sweep stays outside the bracket.
+ * mgps_profile_read synchronises, returns the accumulated device time and the number of full sweeps
+ * (a Gauss-Seidel sweep = its two colours) since the last read, and resets both. */
 int mgps_profile_enable(mgps_solver *h, int enable);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
 /* Cells one full-domain sweep of `level` visits: the kernels skip 1024-cell chunks / 256x16xzc blocks /
@@ -320,6 +337,9 @@ int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smooth
  * stencil_cells is for the Jacobi / residual / apply sweep, gs_cells for the two tiled-GS half sweeps.
  * This is the cell count behind bench.py's algorithmic bytes per launch. */
 int mgps_swept_cells(const mgps_solver *h, int level, long long *stencil_cells, long long *gs_cells);
+/* Which kernel the Jacobi / residual / A.x sweeps of `level` launch (options.stencil_path and the level's shape
+ * decide): 1 = the cache-served quad kernel, 2 = the plane-marching kernel, 3 = the scalar kernel (nx % 4 != 0). */
+int mgps_stencil_kernel(const mgps_solver *h, int level, int *kernel);
 
 /* Host-buffer convenience forms: what the Houdini shim calls (upload, run, download). */
 int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, int use_initial_guess);

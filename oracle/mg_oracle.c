@@ -711,6 +711,7 @@ double mgo_ghost_fluid_weight(double phi0, double phi1)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     int levels, alloc_levels, use_gs, band_width, band_iters;
+    int pre_sweeps, post_sweeps; /* full-domain smoother sweeps per stroke; the reference hard-wires 1 (MG.cpp:466-486, 740-757) */
     dims_t *dims;
     int32_t **lab;
     real **x, **b, **r; /* x[0], b[0] unused (caller's grids) */
@@ -852,6 +853,7 @@ mgo_solver *mgo_solver_create(const int32_t *labels, const real *wx, const real 
     s->use_gs = use_gs;
     s->band_width = 3; /* MG.cpp:141 */
     s->band_iters = 3; /* MG.cpp:142 */
+    s->pre_sweeps = s->post_sweeps = 1;
     s->dims = (dims_t *)calloc((size_t)mg_levels, sizeof(dims_t));
     s->lab = (int32_t **)calloc((size_t)mg_levels, sizeof(void *));
     s->x = (real **)calloc((size_t)mg_levels, sizeof(void *));
@@ -941,22 +943,32 @@ void mgo_solver_coarse_solve(const mgo_solver *s, real *x, const real *b)
     free(v);
 }
 
+/* Benchmark variants (BASELINE config 1: "2+2 damped-Jacobi sweeps"): the full-domain smoother of a stroke repeated
+ * `pre` times on the way down and `post` times on the way up.  1 / 1 is the reference's schedule. */
+void mgo_solver_set_sweeps(mgo_solver *s, int pre, int post)
+{
+    s->pre_sweeps = pre > 0 ? pre : 1;
+    s->post_sweeps = post > 0 ? post : 1;
+}
+
 static void smooth_stroke(mgo_solver *s, int l, real *x, const real *b, int down)
 {
     const dims_t d = s->dims[l];
     const real *wx = l == 0 ? s->w[0] : NULL, *wy = l == 0 ? s->w[1] : NULL, *wz = l == 0 ? s->w[2] : NULL;
     for (int it = 0; it < s->band_iters; ++it)
         mgo_boundary_jacobi(x, b, s->lab[l], s->band[l], s->band_n[l], wx, wy, wz, d.nx, d.ny, d.nz);
-    if (s->use_gs) {
-        if (down) { /* MG.cpp:466-479: odd fwd, even fwd */
-            mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 1, 1);
-            mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 0, 1);
-        } else { /* MG.cpp:740-751: even bwd, odd bwd */
-            mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 0, 0);
-            mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 1, 0);
-        }
-    } else
-        mgo_jacobi(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, s->scratch);
+    for (int rep = 0; rep < (down ? s->pre_sweeps : s->post_sweeps); ++rep) {
+        if (s->use_gs) {
+            if (down) { /* MG.cpp:466-479: odd fwd, even fwd */
+                mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 1, 1);
+                mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 0, 1);
+            } else { /* MG.cpp:740-751: even bwd, odd bwd */
+                mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 0, 0);
+                mgo_tiled_gs(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, 1, 0);
+            }
+        } else
+            mgo_jacobi(x, b, s->lab[l], wx, wy, wz, d.nx, d.ny, d.nz, s->scratch);
+    }
     for (int it = 0; it < s->band_iters; ++it)
         mgo_boundary_jacobi(x, b, s->lab[l], s->band[l], s->band_n[l], wx, wy, wz, d.nx, d.ny, d.nz);
 }

@@ -225,14 +225,14 @@ class Oracle:
     def ghost_fluid_weight(self, phi0, phi1):
         return self.lib.mgo_ghost_fluid_weight(C.c_double(phi0), C.c_double(phi1))
 
-    def solver(self, lab, w, levels, use_gs):
-        return OracleSolver(self, lab, w, levels, use_gs)
+    def solver(self, lab, w, levels, use_gs, pre_sweeps=1, post_sweeps=1):
+        return OracleSolver(self, lab, w, levels, use_gs, pre_sweeps, post_sweeps)
 
 
 class OracleSolver:
     """GeometricMultigridPoissonSolver (MG.h:10-53) on flat arrays."""
 
-    def __init__(self, orc, lab, w, levels, use_gs):
+    def __init__(self, orc, lab, w, levels, use_gs, pre_sweeps=1, post_sweeps=1):
         self.o = orc
         self.labels = orc.lab(lab)
         self.w = [orc.arr(a) for a in w]
@@ -243,6 +243,8 @@ class OracleSolver:
         if not self.h:
             raise RuntimeError("oracle: multigrid hierarchy could not be built")
         self.h = C.c_void_p(self.h)
+        if (pre_sweeps, post_sweeps) != (1, 1):  # benchmark variant; the reference's schedule is 1 / 1
+            orc.lib.mgo_solver_set_sweeps(self.h, int(pre_sweeps), int(post_sweeps))
 
     def close(self):
         if self.h:

@@ -41,8 +41,10 @@ def make_domain(kind, g, levels=None, solver_shape=None, dtype=np.float32):
     """kind in {'simple', 'complex', 'solid'} -> (labels uint8, weights[3], offset, levels, dx)."""
     from geometricmultigridpressuresolver_amd import domains as D
 
-    if kind == "wide":  # non-cubic free-surface box, x extent >= 256: exercises the plane-marching sweep
+    if kind == "wide":  # non-cubic free-surface box, 256 cells along x (one wavefront per row; with options.stencil_path = 2: the plane-marching sweep)
         bl, bw, dx = D.build_complex_domain((g, g, 248), dtype=dtype)
+    elif kind == "widesolid":  # free surface + cut-cell solid box, 264 x 40 x 32 solver grid: ragged in x (256 + 8) and y (2 x 16 + 8)
+        bl, bw, dx = D.build_complex_domain((g, g + 8, 256), use_solid=True, dtype=dtype)
     elif kind == "wide512":  # x extent 512 (two wavefronts per row in the quad kernels)
         bl, bw, dx = D.build_complex_domain((g, g, 500), dtype=dtype)
     elif kind == "odd":

@@ -122,6 +122,64 @@ def gpu_mode():
         assert counts[(False, 1)] < 0.6 * counts[(False, 0)] and counts[(True, 1)] < 0.7 * counts[(True, 0)], counts
 
 
+def plane_mode():
+    """The plane-marching sweep (stencilPlaneKernel, the 1024^3 kernel) on cut slabs: its ghostLo / ghostHi reads of the
+    plane below the first and above the last owned plane.  options.stencil_path = 2 forces it onto a 264 x 40/72 x nz
+    free-surface + cut-cell grid; slab runs must reproduce the whole-grid run of the same kernel (A.x bit for bit)."""
+    import geometricmultigridpressuresolver_amd as G
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd.distributed import SlabSolver, TorchDistComm
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    g = 24 if size == 2 else 56
+    shape = (32, 40, 264) if size == 2 else (64, 72, 264)
+    lab, w, off, lev, dx = make_domain("widesolid", g, 3, shape)
+    nz = lab.shape[0]
+    nzl = nz // size
+    z0, z1 = rank * nzl, (rank + 1) * nzl
+    assert all(D.active_mask(lab[c - 1 : c + 1]).any() for c in range(nzl, nz, nzl))
+    slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
+    b_glob = D.random_rhs(lab, dx)
+    for use_gs, deep in ((False, 1), (False, 0)):
+        opt = G.default_options()
+        opt.min_cells_per_rank, opt.deep_band_halo, opt.stencil_path = 0, deep, 2
+        ow = G.default_options()
+        ow.stencil_path = 2
+        slab = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=opt)
+        whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0, options=ow)
+        assert slab.stencil_kernel(0) == "plane" and whole.stencil_kernel(0) == "plane"
+        bw, bs = whole.to_device(b_glob), slab.to_device(b_glob[z0:z1])
+        xw, xs = whole.to_device(b_glob * 3.0), slab.to_device(b_glob[z0:z1] * 3.0)
+        yw, ys = whole.new_grid(), slab.new_grid()
+        whole.applyPoissonMatrix(yw, xw)
+        slab.applyPoissonMatrix(ys, xs)
+        assert np.array_equal(slab.gather_global(ys), yw.cpu().numpy())
+        whole.computePoissonResidual(yw, xw, bw)
+        slab.computePoissonResidual(ys, xs, bs)
+        assert np.array_equal(slab.gather_global(ys), yw.cpu().numpy())
+        whole.jacobiPoissonSmoother(xw, bw)
+        slab.jacobiPoissonSmoother(xs, bs)
+        assert np.array_equal(slab.gather_global(xs), xw.cpu().numpy())
+        xw, xs = whole.new_grid(), slab.new_grid()
+        for it in range(2):
+            whole.applyVCycle(xw, bw, it > 0)
+            slab.applyVCycle(xs, bs, it > 0)
+            err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
+            assert err < 1e-6, (deep, it, err)
+        xw, xs = whole.new_grid(), slab.new_grid()
+        sw = whole.solveGeometricConjugateGradient(xw, bw, 1e-5, 200, True)  # A.p + <p, A p> from the DOT variant on the whole grid
+        ss = slab.solveGeometricConjugateGradient(xs, bs, 1e-5, 200, True)
+        assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+        assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
+        if rank == 0:
+            print(f"  plane sweep on {size} slabs, deep={deep}: D={slab.distributed_levels}, pcg it {ss['iterations']}", flush=True)
+        slab.close()
+        whole.close()
+        dist.barrier()
+
+
 def cpu_mode():
     """Slab emulation on the CPU (no GPU involved): tests/slab_emulation.py over gloo vs the
     whole-grid oracle."""
@@ -214,6 +272,8 @@ if __name__ == "__main__":
     dist.init_process_group("gloo")
     if mode == "gpu":
         gpu_mode()
+    elif mode == "plane":
+        plane_mode()
     elif mode == "rccl1":
         rccl_single_rank_mode()
     elif mode == "cpu":

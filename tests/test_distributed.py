@@ -55,6 +55,15 @@ def test_four_slabs_match_single_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_slabs_plane_marching_sweep(nproc):
+    """stencilPlaneKernel -- the sweep a 1024^3 slab run executes -- on cut slabs (ghost planes below / above): forced
+    onto a small free-surface + cut-cell grid with options.stencil_path = 2; edge ranks (2) and middle ranks (4)."""
+    out = run_workers("plane", nproc, 420)
+    print(out[-800:])
+
+
+@pytest.mark.gpu
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)

@@ -27,13 +27,13 @@ def torch_cuda():
     return torch
 
 
-def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None):
+def _setup(kind, g, use_gs, domain_factory, oracle, levels=None, solver_shape=None, options=None):
     import geometricmultigridpressuresolver_amd as G
 
-    if kind in ("wide", "odd", "wide512"):
+    if kind in ("wide", "odd", "wide512", "widesolid"):
         levels, solver_shape = _wide_args(kind)
     lab, w, off, lev, dx = domain_factory(kind, g, levels, solver_shape)
-    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs)
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, options=options)
     lab32 = lab.astype(np.int32)
     w64 = [a.astype(np.float64) for a in w]
     orc = oracle.solver(lab32, w64, lev, use_gs)
@@ -53,10 +53,13 @@ DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24), ("odd",
 
 
 def _wide_args(kind):
-    """"wide": a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels) -- the plane-marching sweep;
+    """"wide": a 248 x 24 x 24 box in a 256 x 32 x 32 solver grid (3 levels), a row = one wavefront of the quad sweep
+    (by size these grids take the quad kernel; test_plane_sweep_* force the plane-marching one onto them);
     "odd": a 36^3 complex domain in a 44^3 grid (3 levels: 44, 22, 11) -- level 1 has nx % 4 != 0, which
-    takes the scalar sweep and the per-cell band list instead of the quad forms"""
-    return {"wide": (3, (32, 32, 256)), "odd": (3, (44, 44, 44)), "wide512": (3, (64, 64, 512))}.get(kind, (None, None))
+    takes the scalar sweep and the per-cell band list instead of the quad forms;
+    "widesolid": free surface + cut-cell solid in a 264 x 40 x 32 grid: ragged block edges in x and y"""
+    return {"wide": (3, (32, 32, 256)), "odd": (3, (44, 44, 44)), "wide512": (3, (64, 64, 512)),
+            "widesolid": (3, (32, 40, 264))}.get(kind, (None, None))
 
 
 @pytest.mark.parametrize("kind,g", DOMAINS)
@@ -654,3 +657,266 @@ def test_full_size_properties(n, levels, torch_cuda):
         gpu.close()
         del gpu, a, b, xa, xb, xab, ab, r, inactive
         torch_cuda.cuda.empty_cache()
+
+
+# ---- the plane-marching sweep (stencilPlaneKernel): by size it only runs where an x-y plane exceeds 2 MiB (1024^2),
+# which no oracle-sized domain reaches; options.stencil_path = 2 puts it on every level whose shape allows it
+PLANE_DOMAINS = [("wide", 24), ("wide512", 40), ("widesolid", 24)]
+
+
+def _plane_options():
+    import geometricmultigridpressuresolver_amd as G
+
+    opt = G.default_options()
+    opt.stencil_path = 2
+    return opt
+
+
+@pytest.mark.parametrize("kind,g", PLANE_DOMAINS)
+def test_plane_sweep_operators_match_oracle(kind, g, domain_factory, oracle, torch_cuda):
+    """stencilPlaneKernel<JACOBI | RESIDUAL | APPLY> (Ops.h:262-367, 621-732) against the oracle, 5e-6, and bit for bit
+    against the quad kernel of the same library (same arithmetic per cell)."""
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle, options=_plane_options())
+    quad, *_ = _setup(kind, g, False, domain_factory, oracle)
+    assert gpu.stencil_kernel(0) == "plane" and quad.stencil_kernel(0) == "quad"
+    if kind == "widesolid":
+        assert int((gpu.hierarchy().level_labels(0) == 3).sum()) > 1000 and any(((a != 0) & (a != 1)).any() for a in w64)
+    x0 = _rand_active(lab, 1)
+    b0 = _rand_active(lab, 2, dx * dx)
+    xd, bd = gpu.to_device(x0), gpu.to_device(b0)
+    for name, ref_fn, run in (
+        ("apply", lambda out: oracle.apply_poisson(out, x0, lab32, w64), lambda s, out: s.applyPoissonMatrix(out, xd)),
+        ("residual", lambda out: oracle.residual(out, x0, b0, lab32, w64), lambda s, out: s.computePoissonResidual(out, xd, bd)),
+    ):
+        ref = np.zeros_like(x0)
+        ref_fn(ref)
+        out_p, out_q = gpu.new_grid(), quad.new_grid()
+        out_p.fill_(7.0)  # the public forms define every cell of the destination
+        run(gpu, out_p)
+        run(quad, out_q)
+        assert rel_err(out_p.cpu().numpy(), ref) < OP_TOL, name
+        assert np.array_equal(out_p.cpu().numpy(), out_q.cpu().numpy()), name
+    xj = x0.copy()
+    oracle.jacobi(xj, b0, lab32, w64)
+    xp, xq = gpu.to_device(x0), quad.to_device(x0)
+    gpu.jacobiPoissonSmoother(xp, bd)
+    quad.jacobiPoissonSmoother(xq, bd)
+    assert rel_err(xp.cpu().numpy(), xj) < OP_TOL
+    assert np.array_equal(xp.cpu().numpy(), xq.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind,g", PLANE_DOMAINS)
+def test_plane_sweep_vcycle_and_pcg_match_oracle(kind, g, domain_factory, oracle, torch_cuda):
+    """V-cycles (activity-skipping plane blocks, solver-owned grids) and MG-PCG through the plane-marching sweep:
+    the PCG takes <p, A p> from stencilPlaneKernel<APPLY, DOT> and <z, r> from stencilPlaneKernel<JACOBI, DOT>."""
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup(kind, g, False, domain_factory, oracle, options=_plane_options())
+    assert gpu.stencil_kernel(0) == "plane"
+    b = _rand_active(lab, 5, dx * dx)
+    x_ref = np.zeros_like(b)
+    xd, bd = gpu.new_grid(), gpu.to_device(b)
+    b_as_f32 = bd.cpu().numpy().astype(np.float64)
+    for it in range(3):
+        orc.apply_vcycle(x_ref, b_as_f32, it > 0)
+        gpu.applyVCycle(xd, bd, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    assert (xd.cpu().numpy()[~np.isin(lab, (0, 3))] == 0).all()
+    # tolerance 1e-4: on the elongated 512 x 64 x 64 box with only 3 levels fp32 CG vectors reach their rounding floor
+    # near 1e-5 (the fp32 build of the oracle needs 19 iterations there against 16 in fp64, like both GPU kernels)
+    bp = (D.random_rhs(lab, dx, seed=4)).astype(np.float32)
+    x_ref = np.zeros(lab.shape)
+    ref = orc.solve_pcg(x_ref, bp.astype(np.float64), 1e-4, 500, True)
+    xs = gpu.new_grid()
+    st = gpu.solveGeometricConjugateGradient(xs, gpu.to_device(bp), 1e-4, 500, True)
+    assert st["outcome"] == "converged" and abs(st["iterations"] - ref["iterations"]) <= 2
+    assert rel_l2(xs.cpu().numpy(), x_ref) < 1e-3
+    quad, *_ = _setup(kind, g, False, domain_factory, oracle)  # same arithmetic per cell and the same summation order per block? no:
+    xq = quad.new_grid()                                      # the dot partials are grouped differently, so compare to round-off
+    sq = quad.solveGeometricConjugateGradient(xq, quad.to_device(bp), 1e-4, 500, True)
+    assert sq["iterations"] == st["iterations"] and rel_l2(xs.cpu().numpy(), xq.cpu().numpy().astype(np.float64)) < 1e-5
+
+
+def test_plane_sweep_gathered_dots(torch_cuda):
+    """MGPS_CHECK_FUSED_DOT=1 (read once per process, hence the child) with the plane-marching sweep forced: every
+    <z, r> gathered from stencilPlaneKernel<JACOBI, DOT> + band scatters must equal a separate reduction to 1e-9."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np\n"
+        "import geometricmultigridpressuresolver_amd as G\n"
+        "from geometricmultigridpressuresolver_amd import domains as D\n"
+        "from conftest import make_domain\n"
+        "for kind, g, shape in (('wide', 24, (32, 32, 256)), ('widesolid', 24, (32, 40, 264))):\n"
+        "    lab, w, off, lev, dx = make_domain(kind, g, 3, shape)\n"
+        "    s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)\n"
+        "    assert s.stencil_kernel(0) == 'plane'\n"
+        "    x = s.new_grid(); b = s.to_device(D.random_rhs(lab, dx))\n"
+        "    st = s.solveGeometricConjugateGradient(x, b, 1e-6, 200, True)\n"
+        "    assert st['outcome'] == 'converged', st\n"
+        "    s.close()\n"
+        "print('GATHER_OK')\n"
+    ) % (ROOT, ROOT)
+    env = dict(**__import__("os").environ, MGPS_CHECK_FUSED_DOT="1", MGPS_STENCIL="plane")
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "GATHER_OK" in res.stdout, res.stdout[-3000:]
+
+
+def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
+    """The default dispatch (no option, no environment): a 1024 x 1024 x 48 solver grid, 3 levels -- its x-y plane is
+    4 MiB, so launchStencil picks stencilPlaneKernel by size exactly as at 1024^3 -- against the oracle on the same
+    50 M cells: one Jacobi sweep, the residual, and two V-cycles (free surface: general BOUNDARY cells, skipped blocks)."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    bl, bw, dx = D.build_complex_domain((40, 1016, 1016), dtype=np.float32)
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(48, 1024, 1024))
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
+    assert gpu.stencil_kernel(0) == "plane" and gpu.stencil_kernel(1) == "quad"
+    lab32 = lab.astype(np.int32)
+    w64 = [a.astype(np.float64) for a in w]
+    x0 = _rand_active(lab, 1)
+    b0 = _rand_active(lab, 2, dx * dx)
+    xd, bd = gpu.to_device(x0), gpu.to_device(b0)
+    ref = np.zeros_like(x0)
+    oracle.residual(ref, x0, b0, lab32, w64)
+    rd = gpu.new_grid()
+    gpu.computePoissonResidual(rd, xd, bd)
+    assert rel_err(rd.cpu().numpy(), ref) < OP_TOL
+    xj = x0.copy()
+    oracle.jacobi(xj, b0, lab32, w64)
+    gpu.jacobiPoissonSmoother(xd, bd)
+    assert rel_err(xd.cpu().numpy(), xj) < OP_TOL
+    del ref, xj, rd
+    orc = oracle.solver(lab32, w64, lev, False)
+    x_ref = np.zeros(lab.shape)
+    b_as_f32 = bd.cpu().numpy().astype(np.float64)
+    xs = gpu.new_grid()
+    for it in range(2):
+        orc.apply_vcycle(x_ref, b_as_f32, it > 0)
+        gpu.applyVCycle(xs, bd, it > 0)
+        assert rel_l2(xs.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    gpu.close()
+
+
+# ---- BASELINE configs 1 and 3 as stated -----------------------------------------------------------------------------
+def test_config1_128_L4_2plus2(oracle, torch_cuda):
+    """BASELINE config 1: 128^3 interior-liquid cube, 4-level V-cycle, 2+2 damped-Jacobi sweeps (options.pre_sweeps =
+    post_sweeps = 2; the reference's own count is 1+1, MG.cpp:466-486) -- the reference CPU path's leg is the fp64
+    oracle with the same counts.  V-cycle by V-cycle parity, the testMultigrid convergence check (b = 0, sine error,
+    Test.cpp:1877-1960) and the symmetry check (Test.cpp:1808-1841) on this configuration."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    n, levels = 128, 4
+    lab, w, h = D.interior_cube(n, levels)
+    opt = G.default_options()
+    opt.pre_sweeps = opt.post_sweeps = 2
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, False, options=opt)
+    lab32 = lab.astype(np.int32)
+    orc = oracle.solver(lab32, [a.astype(np.float64) for a in w], levels, False, pre_sweeps=2, post_sweeps=2)
+    one = oracle.solver(lab32, [a.astype(np.float64) for a in w], levels, False)
+    b32 = D.random_rhs(lab, h, seed=1)
+    bd, xd = gpu.to_device(b32), gpu.new_grid()
+    b64 = b32.astype(np.float64)
+    x_ref, x_one = np.zeros(lab.shape), np.zeros(lab.shape)
+    for it in range(3):
+        gpu.applyVCycle(xd, bd, it > 0)
+        orc.apply_vcycle(x_ref, b64, it > 0)
+        one.apply_vcycle(x_one, b64, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    assert rel_l2(x_ref, x_one) > 1e-3  # the sweep counts do change the cycle: the comparison above is not vacuous
+    # convergence check: 2+2 contracts the sine error monotonically and at least as fast as 1+1
+    x0 = D.sine_initial_guess(lab, h)
+    xs, zd = gpu.to_device(x0), gpu.new_grid()
+    x_ref, x_one, z = x0.astype(np.float64), x0.astype(np.float64), np.zeros(lab.shape)
+    prev = gpu.l2Norm(xs)
+    for it in range(8):
+        gpu.applyVCycle(xs, zd, True)
+        orc.apply_vcycle(x_ref, z, True)
+        one.apply_vcycle(x_one, z, True)
+        cur = gpu.l2Norm(xs)
+        assert cur < prev and cur == pytest.approx(oracle.l2(x_ref, lab32), rel=1e-3)
+        prev = cur
+    assert oracle.l2(x_ref, lab32) < oracle.l2(x_one, lab32)
+    # symmetry of the 2+2 cycle (fp32 bound 1e-4)
+    a, b = gpu.to_device(D.random_rhs(lab, h, seed=6)), gpu.to_device(D.random_rhs(lab, h, seed=7))
+    xa, xb = gpu.new_grid(), gpu.new_grid()
+    gpu.applyVCycle(xa, a)
+    gpu.applyVCycle(xb, b)
+    da, db = gpu.dotProduct(xa, b), gpu.dotProduct(xb, a)
+    assert abs(da - db) / max(abs(da), abs(db)) < 1e-4
+    gpu.close()
+
+
+@pytest.mark.parametrize("use_gs,pre,post", [(True, 2, 1), (False, 1, 3), (True, 2, 2)])
+def test_sweep_counts_match_oracle(use_gs, pre, post, domain_factory, oracle, torch_cuda):
+    """options.pre_sweeps / post_sweeps on a cut-cell + free-surface domain, both smoothers, V-cycle and PCG (the
+    gathered <z, r> must come from the last repetition only)."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    lab, w, off, lev, dx = domain_factory("solid", 48)
+    opt = G.default_options()
+    opt.pre_sweeps, opt.post_sweeps = pre, post
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, options=opt)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, use_gs, pre_sweeps=pre, post_sweeps=post)
+    b = _rand_active(lab, 5, dx * dx)
+    xd, bd = gpu.new_grid(), gpu.to_device(b)
+    b64 = bd.cpu().numpy().astype(np.float64)
+    x_ref = np.zeros_like(b)
+    for it in range(2):
+        orc.apply_vcycle(x_ref, b64, it > 0)
+        gpu.applyVCycle(xd, bd, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    if pre == post:  # a symmetric cycle is a valid CG preconditioner
+        x_ref = np.zeros(lab.shape)
+        ref = orc.solve_pcg(x_ref, b64, 1e-5, 200, True)
+        xs = gpu.new_grid()
+        st = gpu.solveGeometricConjugateGradient(xs, bd, 1e-5, 200, True)
+        assert st["outcome"] == "converged" and abs(st["iterations"] - ref["iterations"]) <= 2
+        assert rel_l2(xs.cpu().numpy(), x_ref) < 2e-4
+    gpu.close()
+
+
+def test_config3_512_free_surface_pcg(oracle, torch_cuda):
+    """BASELINE config 3: 512^3 free-surface pool (sine liquid surface, ghost-fluid weights up to 1/0.01, cut-cell solid
+    box), MG-preconditioned CG with the plugin's smoother (tiled Gauss-Seidel, Plug.cpp:466) to 1e-5 on the delta +
+    random rhs.  Stated criteria, against the fp64 oracle solving the same system (about 15 s on 16 host cores):
+      * iteration count within +-2 of the oracle's;
+      * pressure field relative L2 difference < 1e-5 (the "same pressure field" criterion of the north star);
+      * fp32 CG vectors: the recurrence residual CG tests is < 1e-5; the residual *recomputed* in fp32 from the fp32
+        iterate floors at eps * cond (ghost-fluid weights of 100 amplify the rounding of x) and is only required < 1e-2;
+      * options.pcg_fp64_vectors: the recomputed residual is a true fp64 residual and must itself be < 1e-5."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    n, levels = 512, 6
+    lab, w, h = D.free_surface_pool(n, levels)
+    pad = 2 ** (levels - 1)
+    b = (D.delta_rhs(lab, n - 2 * pad, pad, h) + D.random_rhs(lab, h)).astype(np.float32)
+    results = {}
+    for fp64 in (0, 1):
+        opt = G.default_options()
+        opt.pcg_fp64_vectors = fp64
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, True, options=opt)
+        xd = gpu.new_grid()
+        st = gpu.solveGeometricConjugateGradient(xd, gpu.to_device(b), 1e-5, 2500, True)
+        results[fp64] = (st, xd.cpu().numpy().astype(np.float64))
+        gpu.close()
+        del gpu, xd
+        torch_cuda.cuda.empty_cache()
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, True)
+    x_ref = np.zeros(lab.shape)
+    ref = orc.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 2500, True)
+    assert ref["rel_residual_recomputed"] < 1e-5
+    for fp64 in (0, 1):
+        st, x = results[fp64]
+        assert st["outcome"] == "converged" and abs(st["iterations"] - ref["iterations"]) <= 2, (fp64, st, ref["iterations"])
+        assert st["rel_residual"] < 1e-5
+        assert rel_l2(x, x_ref) < 1e-5, (fp64, rel_l2(x, x_ref))
+        assert st["rel_residual_recomputed"] < (1e-5 if fp64 else 1e-2), (fp64, st)

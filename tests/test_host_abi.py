@@ -35,6 +35,7 @@ def test_options_struct_matches_header():
     assert (o.band_width, o.band_iterations) == (3, 3)  # MG.cpp:141-142
     assert o.jacobi_weight == pytest.approx(2.0 / 3.0)  # Ops.h:291
     assert o.device == -1 and o.max_coarse_unknowns == 8192
+    assert (o.pre_sweeps, o.post_sweeps, o.stencil_path) == (1, 1, 0)  # MG.cpp:466-486, 740-757: one sweep per stroke
     assert lib().mgps_status_string(0) == b"ok" and lib().mgps_status_string(2) == b"no HIP device"
 
 
@@ -155,11 +156,19 @@ def test_band_list_random_labels_any_width(shape, width, oracle):
     assert (H.band_cells(0) == oracle.build_boundary_cells(lab.astype(np.int32), width)).all()
 
 
-def test_level_cap_quirk(oracle):
-    lab, w, off, lev, dx = make_domain("simple", 16)
-    H = G.Hierarchy(lab, 5)
-    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], 5, False)
-    assert H.levels == s.levels < 5  # MG.cpp:243-248
+@pytest.mark.parametrize("block,expect", [(2, 1), (4, 2)])
+def test_level_cap_quirk(block, expect, oracle):
+    """MG.cpp:243-248: the first level without a solvable cell caps the hierarchy at level - 1 (one more than needed is
+    dropped).  A small liquid block in air: coarsening turns it into DIRICHLET once a coarse cell has an air child."""
+    n = 32
+    lab = np.full((n, n, n), D.EXTERIOR, dtype=np.uint8)
+    lab[8:24, 8:24, 8:24] = D.DIRICHLET
+    lab[12 : 12 + block, 12 : 12 + block, 12 : 12 + block] = D.INTERIOR
+    w = [np.ones(D.face_shape(n, n, n, a), dtype=np.float32) for a in range(3)]
+    D.set_boundary_labels(lab, w)
+    H = G.Hierarchy(lab, 4)
+    s = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], 4, False)
+    assert H.levels == s.levels == expect
 
 
 @pytest.mark.parametrize("kind,g", KINDS)
@@ -209,6 +218,41 @@ def test_error_conventions():
     assert L.mgps_apply_vcycle(None, None, None, 0) == 1
     assert L.mgps_levels(None) == 0
     L.mgps_destroy(None)
+
+
+@pytest.mark.parametrize("n,levels", [(32, 2), (32, 3), (64, 4)])
+def test_thin_exterior_shell_is_refused_on_every_level(n, levels):
+    """The reference asserts unitTestExteriorCells on EVERY level (MG.cpp:235, 252).  A liquid cube behind a 1-cell shell
+    passes the fine-level check, but its coarse levels put active cells on the grid border, which the band builder,
+    the row builder and the transfer kernels would index past: the hierarchy must refuse it (status 5, the message
+    names the padding), never abort or throw across the C ABI; the same labels with 2^(levels-1) cells of padding pass."""
+    L = lib()
+    h = C.c_void_p()
+    lab = np.full((n, n, n), D.EXTERIOR, dtype=np.uint8)
+    lab[1:-1, 1:-1, 1:-1] = D.INTERIOR
+    ones = [np.ones(D.face_shape(n, n, n, a), dtype=np.float32) for a in range(3)]
+    D.set_boundary_labels(lab, ones)
+    assert G.unit_test_exterior_cells(lab)
+    rc = L.mgps_hierarchy_create(C.byref(h), n, n, n, lab.ctypes.data_as(C.c_void_p), levels, None)
+    assert rc == 5 and not h.value
+    msg = L.mgps_last_error(None)
+    assert b"EXTERIOR shell" in msg and str(2 ** (levels - 1)).encode() in msg
+    pad = 2 ** (levels - 1)
+    good = np.full((n, n, n), D.EXTERIOR, dtype=np.uint8)
+    good[pad:-pad, pad:-pad, pad:-pad] = D.INTERIOR
+    D.set_boundary_labels(good, ones)
+    H = G.Hierarchy(good, levels)
+    assert H.levels == levels
+    for l in range(levels):
+        assert G.unit_test_exterior_cells(H.level_labels(l))
+
+
+def test_status_strings_cover_every_code():
+    header = open(os.path.join(ROOT, "include", "mgps.h")).read()
+    codes = dict((name, int(v)) for name, v in re.findall(r"(MGPS_(?:OK|ERR_[A-Z_]+)) = (\d+)", header))
+    assert codes["MGPS_ERR_INTERNAL"] == 10 and len(codes) == 11
+    for name, v in codes.items():
+        assert lib().mgps_status_string(v) != b"unknown status", name
 
 
 def test_create_without_device_fails_loudly():
