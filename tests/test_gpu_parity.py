@@ -767,14 +767,15 @@ def test_plane_sweep_gathered_dots(torch_cuda):
 
 
 def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
-    """The default dispatch (no option, no environment): a 1024 x 1024 x 48 solver grid, 3 levels -- its x-y plane is
-    4 MiB, so launchStencil picks stencilPlaneKernel by size exactly as at 1024^3 -- against the oracle on the same
-    50 M cells: one Jacobi sweep, the residual, and two V-cycles (free surface: general BOUNDARY cells, skipped blocks)."""
+    """The default dispatch (no option, no environment): a 1024 x 1024 x 48 solver grid, 5 levels (coarsest 64 x 64 x 3)
+    -- its x-y plane is 4 MiB, so launchStencil picks stencilPlaneKernel by size exactly as at 1024^3 -- against the
+    oracle on the same 50 M cells: one Jacobi sweep, the residual, and two V-cycles (free surface: general BOUNDARY
+    cells, skipped blocks)."""
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
 
-    bl, bw, dx = D.build_complex_domain((40, 1016, 1016), dtype=np.float32)
-    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(48, 1024, 1024))
+    bl, bw, dx = D.build_complex_domain((16, 992, 992), dtype=np.float32)
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(48, 1024, 1024))
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
     assert gpu.stencil_kernel(0) == "plane" and gpu.stencil_kernel(1) == "quad"
     lab32 = lab.astype(np.int32)
