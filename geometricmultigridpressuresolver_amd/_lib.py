@@ -51,6 +51,7 @@ class Options(C.Structure):
         ("pre_sweeps", C.c_int),
         ("post_sweeps", C.c_int),
         ("stencil_path", C.c_int),
+        ("precision", C.c_int),
     ]
 
 

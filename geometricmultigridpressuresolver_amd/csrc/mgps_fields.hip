@@ -4,7 +4,12 @@
 // counterpart of the layout: the reference walks 16^3 tiles of UT_VoxelArray on the host (Plug.cpp:716-1207).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <new>
 #include <string>
+#include <vector>
 
 #include "mgps_fields.h"
 #include "mgps_internal.h"
@@ -425,6 +430,214 @@ try {
     out_host[1] = mx;
     out_host[2] = count;
     return MGPS_OK;
+}
+MGPS_API_CATCH(nullptr)
+
+}  // extern "C"
+
+// ---- one-call projection (mgps_project_free_surface) --------------------------------------------------------------
+namespace {
+__global__ void narrowRealKernel(float *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < n) dst[c] = float(src[c]);
+}
+__global__ void widenRealKernel(double *__restrict__ dst, const float *__restrict__ src, size_t n)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < n) dst[c] = double(src[c]);
+}
+
+// device buffers of one call; everything is released when the object goes out of scope
+struct DevPool {
+    std::vector<void *> blocks;
+    ~DevPool()
+    {
+        for (void *b : blocks) (void)hipFree(b);
+    }
+    template <class T>
+    T *get(size_t count)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::bad_alloc();
+        blocks.push_back(p);
+        return static_cast<T *>(p);
+    }
+};
+size_t faceCount(int gx, int gy, int gz, int axis) { return size_t(gx + (axis == 0)) * (gy + (axis == 1)) * (gz + (axis == 2)); }
+}  // namespace
+
+extern "C" {
+
+int mgps_project_free_surface(mgps_projection *p, const mgps_options *opt)
+try {
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    if (!p || p->struct_size != int(sizeof(mgps_projection))) {
+        setLastGlobalError("mgps_project_free_surface: NULL or struct_size mismatch");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = p->gx, gy = p->gy, gz = p->gz;
+    bool ok = gx > 0 && gy > 0 && gz > 0 && (p->real_bytes == 4 || p->real_bytes == 8) && p->liquid_phi && p->solid_phi && p->pressure;
+    for (int a = 0; a < 3; ++a) ok = ok && p->cut_weights[a] && p->velocity[a];
+    const bool haveSolidVel = p->solid_velocity[0] && p->solid_velocity[1] && p->solid_velocity[2];
+    if (!ok || (!haveSolidVel && (p->solid_velocity[0] || p->solid_velocity[1] || p->solid_velocity[2]))) {
+        setLastGlobalError("mgps_project_free_surface: missing field or bad extents (solid velocities: all three or none)");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    mgps_options o;
+    mgps_default_options(&o);
+    if (opt) {
+        if (opt->struct_size != int(sizeof(mgps_options))) {
+            setLastGlobalError("mgps_options.struct_size mismatch: call mgps_default_options first");
+            return MGPS_ERR_INVALID_ARGUMENT;
+        }
+        o = *opt;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        setLastGlobalError("no HIP device is visible (this library has no CPU path)");
+        return MGPS_ERR_NO_DEVICE;
+    }
+    if (o.device >= 0 && hipSetDevice(o.device) != hipSuccess) {
+        setLastGlobalError("hipSetDevice failed");
+        return MGPS_ERR_NO_DEVICE;
+    }
+    hipStream_t s = nullptr;
+    DevPool pool;
+    const size_t cells = size_t(gx) * gy * gz;
+    const bool dbl = p->real_bytes == 8;
+    double *stage = nullptr;  // device staging for double host arrays
+    if (dbl) stage = pool.get<double>(faceCount(gx + 1, gy + 1, gz + 1, 3));
+    auto failHip = [&](const char *what, hipError_t e) {
+        setLastGlobalError(std::string("mgps_project_free_surface: ") + what + ": " + hipGetErrorString(e));
+        return int(MGPS_ERR_HIP);
+    };
+    hipError_t he = hipSuccess;
+    auto upload = [&](const void *host, size_t n) -> float * {  // float copy of a host real array on the device
+        float *d = pool.get<float>(n);
+        if (he != hipSuccess) return d;
+        if (!dbl) he = hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice);
+        else {
+            he = hipMemcpy(stage, host, n * sizeof(double), hipMemcpyHostToDevice);
+            if (he == hipSuccess) {
+                narrowRealKernel<<<unsigned((n + 255) / 256), 256, 0, s>>>(d, stage, n);
+                he = hipStreamSynchronize(s);
+            }
+        }
+        return d;
+    };
+    auto download = [&](void *host, const float *d, size_t n) {
+        if (he != hipSuccess) return;
+        if (!dbl) he = hipMemcpy(host, d, n * sizeof(float), hipMemcpyDeviceToHost);
+        else {
+            widenRealKernel<<<unsigned((n + 255) / 256), 256, 0, s>>>(stage, d, n);
+            he = hipMemcpy(host, stage, n * sizeof(double), hipMemcpyDeviceToHost);
+        }
+    };
+    float *phi = upload(p->liquid_phi, cells), *solidPhi = upload(p->solid_phi, cells), *pressure = upload(p->pressure, cells);
+    float *cw[3], *vel[3], *svel[3] = {nullptr, nullptr, nullptr};
+    for (int a = 0; a < 3; ++a) {
+        cw[a] = upload(p->cut_weights[a], faceCount(gx, gy, gz, a));
+        vel[a] = upload(p->velocity[a], faceCount(gx, gy, gz, a));
+        if (haveSolidVel) svel[a] = upload(p->solid_velocity[a], faceCount(gx, gy, gz, a));
+    }
+    if (he != hipSuccess) return failHip("upload", he);
+#define PROJ_TRY(call)               \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != MGPS_OK) return rc_; \
+    } while (0)
+    // Plug.cpp:270, 286
+    int32_t *material = pool.get<int32_t>(cells);
+    PROJ_TRY(mgps_fields_material_labels(material, phi, solidPhi, cw[0], cw[1], cw[2], gx, gy, gz, s));
+    uint8_t *valid[3];
+    for (int a = 0; a < 3; ++a) {
+        valid[a] = pool.get<uint8_t>(faceCount(gx, gy, gz, a));
+        PROJ_TRY(mgps_fields_valid_faces(a, valid[a], material, cw[a], gx, gy, gz, s));
+    }
+    // Plug.cpp:316-362: MG labels and weights at +offset of the expanded grid, then the BOUNDARY labels
+    int dims[3], offset = 0, levels = 0;
+    PROJ_TRY(mgps_expanded_layout(gx, gy, gz, 0, p->power_of_two, dims, &offset, &levels));
+    const int ex = dims[0], ey = dims[1], ez = dims[2];
+    const size_t ecells = size_t(ex) * ey * ez;
+    uint8_t *labels = pool.get<uint8_t>(ecells);
+    PROJ_TRY(mgps_fields_domain_labels(labels, material, gx, gy, gz, ex, ey, ez, offset, s));
+    float *w[3];
+    for (int a = 0; a < 3; ++a) {
+        w[a] = pool.get<float>(faceCount(ex, ey, ez, a));
+        PROJ_TRY(mgps_fields_boundary_weights(a, w[a], cw[a], phi, valid[a], material, gx, gy, gz, ex, ey, ez, offset, s));
+    }
+    PROJ_TRY(mgps_fields_set_boundary_labels(labels, w[0], w[1], w[2], ex, ey, ez, s));
+    p->mg_levels = levels;
+    p->offset = offset;
+    p->expanded[0] = ex;
+    p->expanded[1] = ey;
+    p->expanded[2] = ez;
+    // liquid cell count first: a domain without liquid has nothing to solve (Plug.cpp:270-282 returns there)
+    double div[3] = {0, 0, 0};
+    PROJ_TRY(mgps_fields_divergence(div, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, s));
+    p->liquid_cells = div[2];
+    std::memset(&p->stats, 0, sizeof(p->stats));
+    p->residual_inf = p->residual_l2 = p->divergence_sum = p->divergence_max = 0;
+    if (div[2] == 0) {
+        p->setup_ms = p->total_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
+        p->solve_ms = 0;
+        p->stats.outcome = MGPS_PCG_RHS_ZERO;
+        return MGPS_OK;
+    }
+    // Plug.cpp:386, 413
+    float *rhs = pool.get<float>(ecells), *x = nullptr;
+    PROJ_TRY(mgps_fields_rhs(rhs, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, ex, ey, ez, offset, s));
+    mgps_solver *mg = nullptr;  // Plug.cpp:463-466
+    int rc = mgps_create_device(&mg, ex, ey, ez, labels, w[0], w[1], w[2], levels, p->use_gauss_seidel, &o);
+    if (rc != MGPS_OK) return rc;
+    struct Guard {
+        mgps_solver *h;
+        ~Guard() { mgps_destroy(h); }
+    } guard{mg};
+    rc = mgps_grid_alloc(mg, 0, &x);  // zero-filled
+    if (rc == MGPS_OK && p->use_old_pressure) rc = mgps_fields_pressure_to_solution(x, pressure, material, gx, gy, gz, ex, ey, ez, offset, s);
+    if (rc != MGPS_OK) {
+        setLastGlobalError(mgps_last_error(mg));
+        return rc;
+    }
+    (void)hipDeviceSynchronize();
+    const auto t1 = clock::now();
+    rc = mgps_solve_pcg(mg, x, rhs, p->tolerance, p->max_iterations, p->use_mg_preconditioner, &p->stats);  // Plug.cpp:474-483 / 609-618
+    if (rc == MGPS_OK) {  // Plug.cpp:625-628
+        float *r = nullptr;
+        rc = mgps_grid_alloc(mg, 0, &r);
+        if (rc == MGPS_OK) rc = mgps_residual(mg, 0, r, x, rhs);
+        if (rc == MGPS_OK) rc = mgps_inf_norm(mg, 0, r, 1, &p->residual_inf);
+        if (rc == MGPS_OK) rc = mgps_l2_norm(mg, 0, r, &p->residual_l2);
+    }
+    if (rc != MGPS_OK && rc != MGPS_ERR_INTERRUPTED) {
+        setLastGlobalError(mgps_last_error(mg));
+        return rc;
+    }
+    const int solveRc = rc;
+    (void)hipDeviceSynchronize();
+    const auto t2 = clock::now();
+    // Plug.cpp:644-707
+    PROJ_TRY(mgps_fields_solution_to_pressure(pressure, x, material, gx, gy, gz, ex, ey, ez, offset, s));
+    for (int a = 0; a < 3; ++a) PROJ_TRY(mgps_fields_pressure_gradient(a, vel[a], phi, pressure, valid[a], material, gx, gy, gz, s));
+    PROJ_TRY(mgps_fields_divergence(div, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, s));
+    p->divergence_sum = div[0];
+    p->divergence_max = div[1];
+#undef PROJ_TRY
+    download(p->pressure, pressure, cells);
+    for (int a = 0; a < 3; ++a) {
+        download(p->velocity[a], vel[a], faceCount(gx, gy, gz, a));
+        if (p->valid_faces[a] && he == hipSuccess) he = hipMemcpy(p->valid_faces[a], valid[a], faceCount(gx, gy, gz, a), hipMemcpyDeviceToHost);
+    }
+    if (he != hipSuccess) return failHip("download", he);
+    const auto t3 = clock::now();
+    p->setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    p->solve_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    p->total_ms = std::chrono::duration<double, std::milli>(t3 - t0).count();
+    if (solveRc != MGPS_OK) setLastGlobalError("mgps_project_free_surface: interrupted");
+    return solveRc;
 }
 MGPS_API_CATCH(nullptr)
 

@@ -222,6 +222,15 @@ struct GridP {
     int sweepPath;
 };
 
+// Scales of the mixed-precision V-cycle (options.precision = 1).  The cycle works on the rhs normalised by a power of
+// two, sigma (device scalar: 2^-ceil(log2 max|b|), so that max |sigma b| is in (1/2, 1]); the fine-level iterate is stored
+// in binary16 as x~ = x^ 2^-e (e from the level's size: |A^-1| can reach N^2 / 2) and the fine residual as r~ = 256 r^.
+// A kernel sees the rhs as (*sigma * c1) * b and the operator term as c2 * (A x~).
+struct MixScale {
+    const float *sigma = nullptr;
+    float c1 = 1.f, c2 = 1.f;
+};
+
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
 // does the plane-marching sweep apply to a level of this shape, and with how many planes per block
 inline int planeSweepZc(int nx, int ny, int nz)
@@ -289,6 +298,17 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
 // codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
 int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, const uint8_t *bandDiag, int nbnd, int nband);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);
+// ---- mixed precision (options.precision = 1): binary16 grids of the fine level, passed as void* -----------------------
+bool mixedPrecisionShapeOk(int nx, int ny, int nz);  // the fine level must take the quad sweep and the block prolongation
+int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms);
+int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
+                         const BandGroupsDev &bg, const MixScale &ms);
+int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, const void *fineH, float fm);
+int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const float *coarse, float pm);
+int launchToHalf(void *stream, void *dstH, const float *src, const float *sigmaDev, float mul, size_t cells);  // x~ = (*sigma * mul) x
+int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells);
+int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev);
+int launchZeroActiveHalf(void *stream, const GridP &g, void *aH);
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse);
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
                       float *gathered);

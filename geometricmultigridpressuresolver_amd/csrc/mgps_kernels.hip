@@ -18,9 +18,11 @@
 //    single wavefront);
 //  * arithmetic is fp32; reductions accumulate in fp64.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mgps_internal.h"
 
@@ -41,6 +43,46 @@ __device__ __forceinline__ uchar4 streamLoad4(const uint8_t *p)
     const v4b v = __builtin_nontemporal_load(reinterpret_cast<const v4b *>(p));
     return make_uchar4(v.x, v.y, v.z, v.w);
 }
+// Storage type of a grid: float, or binary16 for the fine-level iterate / residual of the mixed-precision V-cycle
+// (options.precision = 1; arithmetic stays fp32).  Four consecutive cells move as one 16-byte (8-byte) access.
+template <class T>
+struct Cell;
+template <>
+struct Cell<float> {
+    static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ float4 load4nt(const float *p) { return streamLoad4(p); }
+    static __device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ void store4nt(float *p, float4 v) { __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(p)); }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+};
+// binary16 conversions saturate (a value past 65504 must not become inf: the next sweep would turn it into NaNs)
+__device__ __forceinline__ __half toHalfSat(float v) { return __float2half_rn(fminf(fmaxf(v, -65504.f), 65504.f)); }
+template <>
+struct Cell<__half> {
+    static __device__ __forceinline__ float4 load4(const __half *p)
+    {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x)), b = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    static __device__ __forceinline__ float4 load4nt(const __half *p) { return load4(p); }
+    static __device__ __forceinline__ void store4(__half *p, float4 v)
+    {
+        const __half2 a = __halves2half2(toHalfSat(v.x), toHalfSat(v.y)), b = __halves2half2(toHalfSat(v.z), toHalfSat(v.w));
+        uint2 raw;
+        raw.x = *reinterpret_cast<const unsigned *>(&a);
+        raw.y = *reinterpret_cast<const unsigned *>(&b);
+        *reinterpret_cast<uint2 *>(p) = raw;
+    }
+    static __device__ __forceinline__ void store4nt(__half *p, float4 v) { store4(p, v); }
+    static __device__ __forceinline__ float load1(const __half *p) { return __half2float(*p); }
+    static __device__ __forceinline__ void store1(__half *p, float v) { *p = toHalfSat(v); }
+};
+// Scales of the mixed-precision cycle (MixScale in mgps_internal.h): the rhs enters as (*sigma * c1) * b, the operator
+// term as c2 * (A x).  fp32 grids never use them (bit-identical arithmetic to the unscaled kernels).
+__device__ __forceinline__ float mixRhsScale(const MixScale &ms) { return (ms.sigma ? *ms.sigma : 1.f) * ms.c1; }
+
 constexpr int kWave = 64;
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
 
@@ -86,6 +128,14 @@ __device__ __forceinline__ float epilogueRcp(float xc, float bc, float lap, floa
 {
     if (OP == OP_JACOBI) return xc + omega * ((bc - lap) * rdiag);
     if (OP == OP_RESIDUAL) return bc - lap;
+    return lap;
+}
+// mixed precision: rhs scaled by bm, the operator term by c2 (residual only: Jacobi works in the iterate's own units)
+template <int OP>
+__device__ __forceinline__ float epilogueMix(float xc, float bc, float lap, float rdiag, float omega, float bm, float c2)
+{
+    if (OP == OP_JACOBI) return xc + omega * ((bm * bc - lap) * rdiag);
+    if (OP == OP_RESIDUAL) return bm * bc - c2 * lap;
     return lap;
 }
 template <int OP>
@@ -135,11 +185,13 @@ __device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
 // shorter rows).  x-1 / x+1 come from the neighbouring lanes (ds_bpermute), row ends from memory.
 // Requires nx % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int OP, bool DOT = false>
-__global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
+template <int OP, bool DOT = false, class TX = float>
+__global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
                                                           const float *__restrict__ b, float omega, unsigned nblocks,
-                                                          const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr)
+                                                          const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr,
+                                                          MixScale ms = MixScale{})
 {
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
     const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
     const size_t rows = size_t(g.ny) * g.nz;
     const size_t totalQuads = size_t(nq) * rows;
@@ -162,15 +214,15 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
     const size_t c = row * sy + i;
 
-    const float4 xc = *reinterpret_cast<const float4 *>(x + c);
+    const float4 xc = Cell<TX>::load4(x + c);
     // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
     // results are discarded, the loads only have to stay in bounds
     const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
     const size_t czm = (k > 0 || g.ghostLo) ? c - sz : c, czp = (k < g.nz - 1 || g.ghostHi) ? c + sz : c;
-    const float4 ym = *reinterpret_cast<const float4 *>(x + cym);
-    const float4 yp = *reinterpret_cast<const float4 *>(x + cyp);
-    const float4 zm = *reinterpret_cast<const float4 *>(x + czm);
-    const float4 zp = *reinterpret_cast<const float4 *>(x + czp);
+    const float4 ym = Cell<TX>::load4(x + cym);
+    const float4 yp = Cell<TX>::load4(x + cyp);
+    const float4 zm = Cell<TX>::load4(x + czm);
+    const float4 zp = Cell<TX>::load4(x + czp);
     const uchar4 lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
@@ -179,14 +231,15 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     const int lane = threadIdx.x & (kWave - 1);
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
-    if (lane == 0 || q == 0) left = (i > 0) ? x[c - 1] : 0.f;
-    if (lane == kWave - 1 || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? x[c + 4] : 0.f;
+    if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
+    if (lane == kWave - 1 || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
 
     const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
     const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
     const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
     const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
     const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
+    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
     float res[4];
     // INTERIOR and simple BOUNDARY cells; general BOUNDARY cells are patched by boundaryOpKernel
     // right after this launch
@@ -194,11 +247,12 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, float *__restr
     for (int e = 0; e < 4; ++e) {
         const float diag = simpleDiag(ls[e]);
         const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-        res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
+        if (kMixed) res[e] = simpleCell(ls[e]) ? epilogueMix<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega, bm, ms.c2) : inactiveValue<OP>(xs[e + 1]);
+        else res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
     }
     if (valid) {
-        if (g.streaming) __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
-        else *reinterpret_cast<float4 *>(out + c) = make_float4(res[0], res[1], res[2], res[3]);
+        if (g.streaming) Cell<TX>::store4nt(out + c, make_float4(res[0], res[1], res[2], res[3]));
+        else Cell<TX>::store4(out + c, make_float4(res[0], res[1], res[2], res[3]));
     }
     if (DOT) {  // general BOUNDARY cells add theirs in boundaryOpKernel
         double acc = 0.0;
@@ -342,20 +396,27 @@ __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const floa
 }
 
 // BOUNDARY cells of a full-domain sweep: one thread per list entry, out of place like the sweep.
-template <int OP, bool DOT = false>
-__global__ void boundaryOpKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
-                                 const float *__restrict__ b, float omega, unsigned nblocks, double *__restrict__ dotPartials = nullptr)
+template <int OP, bool DOT = false, class TX = float>
+__global__ void boundaryOpKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
+                                 const float *__restrict__ b, float omega, unsigned nblocks, double *__restrict__ dotPartials = nullptr,
+                                 MixScale ms = MixScale{})
 {
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
     const unsigned block = remapBlock(blockIdx.x, nblocks);
     const int t = int(block * blockDim.x + threadIdx.x);
     double acc = 0.0;
     if (t < g.nbnd) {
         const size_t c = size_t(g.bnd[t]);
         float lap, diag;
-        boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
-        const float xc = x[c], bc = OP == OP_APPLY ? 0.f : b[c];
-        const float res = epilogue<OP>(xc, bc, lap, diag, omega);
-        out[c] = res;
+        boundaryRow(g, [&](size_t p) { return Cell<TX>::load1(x + p); }, t, c, lap, diag);
+        const float xc = Cell<TX>::load1(x + c), bc = OP == OP_APPLY ? 0.f : b[c];
+        float res;
+        if (kMixed) {
+            const float bm = mixRhsScale(ms);
+            res = OP == OP_JACOBI ? xc + omega * ((bm * bc - lap) / diag) : OP == OP_RESIDUAL ? bm * bc - ms.c2 * lap : lap;
+        } else
+            res = epilogue<OP>(xc, bc, lap, diag, omega);
+        Cell<TX>::store1(out + c, res);
         acc = dotTerm<OP>(xc, bc, res);
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
@@ -388,8 +449,8 @@ __global__ void bandComputeKernel(GridP g, const float *__restrict__ x, const fl
 }
 // DOT: the workgroup also leaves sum (new - old) * b over its cells: the correction that turns <x, b> taken before the
 // band passes into <x, b> after them
-template <bool DOT = false>
-__global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restrict__ band, int nband,
+template <bool DOT = false, class TX = float>
+__global__ void bandScatterKernel(TX *__restrict__ x, const int32_t *__restrict__ band, int nband,
                                   const float *__restrict__ tmp, unsigned nblocks, const float *__restrict__ b = nullptr,
                                   double *__restrict__ dotPartials = nullptr)
 {
@@ -398,8 +459,8 @@ __global__ void bandScatterKernel(float *__restrict__ x, const int32_t *__restri
     if (t < nband) {
         const int32_t c = band[t];
         const float v = tmp[t];
-        if (DOT) acc = (double(v) - double(x[c])) * double(b[c]);
-        x[c] = v;  // Ops.h:604-618
+        if (DOT) acc = (double(v) - double(Cell<TX>::load1(x + c))) * double(b[c]);
+        Cell<TX>::store1(x + c, v);  // Ops.h:604-618
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
@@ -436,7 +497,8 @@ constexpr int kBandThreads = 512;
 constexpr int kBandSlots = kBandMaxUpdate / kBandThreads;
 static_assert(kBandSlots * kBandThreads == kBandMaxUpdate, "update-node budget must be a whole number of slots");
 
-__global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, const float *__restrict__ x,
+template <class TX = float>
+__global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, const TX *__restrict__ x,
                                                                 const float *__restrict__ b,
                                                                 const int32_t *__restrict__ info,
                                                                 const int32_t *__restrict__ updateEntry,
@@ -445,13 +507,16 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
                                                                 const int32_t *__restrict__ readCell,
                                                                 float *__restrict__ tmp, float omega, int depth,
                                                                 const float *__restrict__ hx, const float *__restrict__ hb,
-                                                                const float *__restrict__ frows, int foreignBase, int nForeign)
+                                                                const float *__restrict__ frows, int foreignBase, int nForeign,
+                                                                MixScale ms = MixScale{})
 {
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
     __shared__ float val[2][kBandMaxNodes];
     // node cells below gridLo are slots of the halo arrays (cells of a neighbouring slab, see SlabHalo)
     const int gridLo = -(g.nx * g.ny);
-    auto xAt = [&](int c) { return c >= gridLo ? x[c] : hx[gridLo - 1 - c]; };
-    auto bAt = [&](int c) { return c >= gridLo ? b[c] : hb[gridLo - 1 - c]; };
+    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
+    auto xAt = [&](int c) { return c >= gridLo ? Cell<TX>::load1(x + c) : hx[gridLo - 1 - c]; };
+    auto bAt = [&](int c) { return kMixed ? bm * b[c] : (c >= gridLo ? b[c] : hb[gridLo - 1 - c]); };
     const int32_t *gi = info + 8 * size_t(blockIdx.x);
     const int updStart = gi[0], readStart = gi[1], nRead = gi[2];
     const int cnt[kBandMaxDepth] = {gi[3], gi[4], gi[5], gi[6]};
@@ -573,47 +638,82 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
 {
     const bool full = i0 + kTile <= g.nx && j0 + kTile <= g.ny && k0 + kTile <= g.nz;
     if (full) {
-        // 18 x 18 rows of the cube; the 16 interior floats of a row as 4 aligned float4, the two x-halo
-        // cells as scalars
-        for (int r = threadIdx.x; r < kHalo * kHalo * 4; r += blockDim.x) {
+        // 18 x 18 rows of the cube: the 16 interior floats of a row as 4 aligned float4, the two x-halo cells as
+        // scalars; 16 x 16 rows of the rhs.  Every global load of the tile is issued before the first LDS write
+        // (13 in flight per thread): with one load per thread in flight the pass ran at 2.2 TB/s of useful bytes, the
+        // memory side of a tile was latency- rather than bandwidth-bound (tools/gsbench: 528 -> 451 us per 512^3 sweep)
+        const int tid = threadIdx.x;  // blockDim.x == 256
+        float4 xv[6], bv[4];
+        uchar4 lv[6];
+        float hv[3];
+        unsigned char hl[3];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const int r = tid + m * 256;
             const int q = r & 3, lj = (r >> 2) % kHalo, lk = (r >> 2) / kHalo;
             const int gj = j0 + lj - 1, gk = k0 + lk - 1;
-            const bool in = gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = r < kHalo * kHalo * 4 && gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
             const ptrdiff_t rowOff = (ptrdiff_t(gk) * g.ny + gj) * g.nx + i0 + 4 * q;
-            if (in) v = *reinterpret_cast<const float4 *>(x + rowOff);
-            float *dst = sx + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
-            dst[0] = v.x;
-            dst[1] = v.y;
-            dst[2] = v.z;
-            dst[3] = v.w;
-            if (LABELS) {
-                uchar4 lv = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-                if (in) lv = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
-                unsigned char *dl = sl + (lk * kHalo + lj) * kHalo + 1 + 4 * q;
-                dl[0] = lv.x;
-                dl[1] = lv.y;
-                dl[2] = lv.z;
-                dl[3] = lv.w;
+            xv[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            lv[m] = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+            if (in) {
+                xv[m] = *reinterpret_cast<const float4 *>(x + rowOff);
+                if (LABELS) lv[m] = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
             }
         }
-        for (int r = threadIdx.x; r < kHalo * kHalo * 2; r += blockDim.x) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int r = tid + m * 256;
             const int side = r & 1, lj = (r >> 1) % kHalo, lk = (r >> 1) / kHalo;
             const int gi = side ? i0 + kTile : i0 - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
-            const bool in = gi >= 0 && gi < g.nx && gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
-            const ptrdiff_t c = in ? (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi : 0;
-            const int h = (lk * kHalo + lj) * kHalo + (side ? kHalo - 1 : 0);
-            sx[h] = in ? x[c] : 0.f;
-            if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
+            const bool in = r < kHalo * kHalo * 2 && gi >= 0 && gi < g.nx && gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
+            const ptrdiff_t c = (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi;
+            hv[m] = 0.f;
+            hl[m] = (unsigned char)MGPS_EXTERIOR_CELL;
+            if (in) {
+                hv[m] = x[c];
+                if (LABELS) hl[m] = g.lab[c];
+            }
         }
-        for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = tid + m * 256;
             const int q = r & 3, lj = (r >> 2) % kTile, lk = (r >> 2) / kTile;
-            const float4 v = *reinterpret_cast<const float4 *>(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q);
-            float *dst = sb + (lk * kTile + lj) * kTile + 4 * q;
-            dst[0] = v.x;
-            dst[1] = v.y;
-            dst[2] = v.z;
-            dst[3] = v.w;
+            bv[m] = *reinterpret_cast<const float4 *>(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q);
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const int r = tid + m * 256;
+            if (r < kHalo * kHalo * 4) {
+                const int at = (r >> 2) * kHalo + 1 + 4 * (r & 3);
+                sx[at] = xv[m].x;
+                sx[at + 1] = xv[m].y;
+                sx[at + 2] = xv[m].z;
+                sx[at + 3] = xv[m].w;
+                if (LABELS) {
+                    sl[at] = lv[m].x;
+                    sl[at + 1] = lv[m].y;
+                    sl[at + 2] = lv[m].z;
+                    sl[at + 3] = lv[m].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int r = tid + m * 256;
+            if (r < kHalo * kHalo * 2) {
+                const int h = (r >> 1) * kHalo + ((r & 1) ? kHalo - 1 : 0);
+                sx[h] = hv[m];
+                if (LABELS) sl[h] = hl[m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float *dst = sb + (tid + m * 256) * 4;
+            dst[0] = bv[m].x;
+            dst[1] = bv[m].y;
+            dst[2] = bv[m].z;
+            dst[3] = bv[m].w;
         }
     } else {  // ragged tile at the end of a grid whose extent is not a multiple of 16
         for (int h = threadIdx.x; h < kHalo3; h += blockDim.x) {
@@ -782,8 +882,10 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
 // 2C-1 with weights {1/8,3/8,3/8,1/8}^3; inactive coarse cells are 0 (destination cleared first,
 // Ops.h:756).  One thread per coarse cell.
 // ---------------------------------------------------------------------------------------------
-__global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine)
+template <class TF = float>
+__global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const TF *__restrict__ fine, float fm = 1.f)
 {
+    constexpr bool kMixed = !std::is_same<TF, float>::value;
     const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
     // with a chunk list: workgroups of 256 over the active chunks (four per 1024-cell chunk); the rest of `coarse` stays 0
     const int per = cg.chunkCells / 256;
@@ -804,21 +906,23 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const float
     for (int zo = 0; zo < 4; ++zo)
 #pragma unroll
         for (int yo = 0; yo < 4; ++yo) {
-            const float *row = fine + (ptrdiff_t(2 * k - 1 + zo) * fny + (2 * j - 1 + yo)) * fnx + (2 * i - 1);
+            const TF *row = fine + (ptrdiff_t(2 * k - 1 + zo) * fny + (2 * j - 1 + yo)) * fnx + (2 * i - 1);
             const float wyz = w[yo] * w[zo];
 #pragma unroll
-            for (int xo = 0; xo < 4; ++xo) acc += (w[xo] * wyz) * row[xo];
+            for (int xo = 0; xo < 4; ++xo) acc += (w[xo] * wyz) * Cell<TF>::load1(row + xo);
         }
-    coarse[c] = acc;
+    coarse[c] = kMixed ? fm * acc : acc;
 }
 
 // The same operator marching along z: one thread owns a coarse (I, J) column of kc coarse planes and keeps the
 // in-plane 4 x 4 weighted sums of the last fine planes in registers -- every fine plane's sum is formed once and
 // feeds the two coarse planes it belongs to, where the per-cell kernel above forms it twice (and its z-overlap
 // reads miss the L2 on large planes: 1.6x the algorithmic HBM traffic).  x, then y, then z summation.
-__global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ fine,
-                                                           int kc, unsigned nbx, unsigned nby)
+template <class TF = float>
+__global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__restrict__ coarse, const TF *__restrict__ fine,
+                                                           int kc, unsigned nbx, unsigned nby, float fm = 1.f)
 {
+    constexpr bool kMixed = !std::is_same<TF, float>::value;
     // a thread owns the coarse columns (I, J) and (I, J + 1), J even: their fine footprints share two of six rows
     const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
@@ -842,12 +946,12 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
         float a, b;
     };
     auto planeSums = [&](int fk) {
-        const float *p = fine + ptrdiff_t(min(max(fk, kLo), kHi)) * fny * fnx + xBase;
+        const TF *p = fine + ptrdiff_t(min(max(fk, kLo), kHi)) * fny * fnx + xBase;
         float rs[6];
 #pragma unroll
         for (int yo = 0; yo < 6; ++yo) {
-            const float *r = p + ptrdiff_t(min(max(2 * J - 1 + yo, 0), fny - 1)) * fnx;
-            rs[yo] = w[0] * r[0] + w[1] * r[1] + w[2] * r[2] + w[3] * r[3];
+            const TF *r = p + ptrdiff_t(min(max(2 * J - 1 + yo, 0), fny - 1)) * fnx;
+            rs[yo] = w[0] * Cell<TF>::load1(r) + w[1] * Cell<TF>::load1(r + 1) + w[2] * Cell<TF>::load1(r + 2) + w[3] * Cell<TF>::load1(r + 3);
         }
         return Pair{w[0] * rs[0] + w[1] * rs[1] + w[2] * rs[2] + w[3] * rs[3], w[0] * rs[2] + w[1] * rs[3] + w[2] * rs[4] + w[3] * rs[5]};
     };
@@ -855,8 +959,9 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
     for (int K = K0; K < K1; ++K) {
         const Pair p2 = planeSums(2 * K + 1), p3 = planeSums(2 * K + 2);
         const size_t c = size_t(K) * cplane + col;
-        coarse[c] = activeLabel(cg.lab[c]) ? w[0] * p0.a + w[1] * p1.a + w[2] * p2.a + w[3] * p3.a : 0.f;
-        if (second) coarse[c + cg.nx] = activeLabel(cg.lab[c + cg.nx]) ? w[0] * p0.b + w[1] * p1.b + w[2] * p2.b + w[3] * p3.b : 0.f;
+        const float va = w[0] * p0.a + w[1] * p1.a + w[2] * p2.a + w[3] * p3.a, vb = w[0] * p0.b + w[1] * p1.b + w[2] * p2.b + w[3] * p3.b;
+        coarse[c] = activeLabel(cg.lab[c]) ? (kMixed ? fm * va : va) : 0.f;
+        if (second) coarse[c + cg.nx] = activeLabel(cg.lab[c + cg.nx]) ? (kMixed ? fm * vb : vb) : 0.f;
         p0 = p2;
         p1 = p3;
     }
@@ -950,10 +1055,12 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
 // 2 x 2 coarse rows (bj = jp, jp+1; bk = kp, kp+1) -- so the twelve coarse loads serve 16 cells instead
 // of 4.  Rows 0 / ny-1 are EXTERIOR shell and are never touched; planes -1 / nz exist only as the other
 // rank's cells of a slab run (ghostLo / ghostHi) and are masked.  Same arithmetic per cell as above.
-__global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__restrict__ fine,
+template <class TX = float>
+__global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, TX *__restrict__ fine,
                                                              const float *__restrict__ coarse, unsigned nblocks,
-                                                             int npj, int kp0, size_t total)
+                                                             int npj, int kp0, size_t total, float pm = 1.f)
 {
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
     const unsigned nq = unsigned(fg.nx) >> 2;
     const size_t t = size_t(remapBlock(blockIdx.x, nblocks)) * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -999,17 +1106,19 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, float *__
             const bool a0 = activeLabel(lab.x), a1 = activeLabel(lab.y), a2 = activeLabel(lab.z), a3 = activeLabel(lab.w);
             if (!kv[zz] || !anyActive(lab)) continue;
             // read-modify-write of a cell nobody else touches in this launch
-            float4 f = fg.streaming ? streamLoad4(fine + c[zz][yy]) : *reinterpret_cast<const float4 *>(fine + c[zz][yy]);
+            float4 f = fg.streaming ? Cell<TX>::load4nt(fine + c[zz][yy]) : Cell<TX>::load4(fine + c[zz][yy]);
             float add[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
                 add[e] = 4.f * lerpRef(lerpRef(v[0][0][e], v[0][1][e], fs[yy]), lerpRef(v[1][0][e], v[1][1][e], fs[yy]), fs[zz]);
+                if (kMixed) add[e] *= pm;
+            }
             if (a0) f.x += add[0];
             if (a1) f.y += add[1];
             if (a2) f.z += add[2];
             if (a3) f.w += add[3];
-            if (fg.streaming) __builtin_nontemporal_store(v4f{f.x, f.y, f.z, f.w}, reinterpret_cast<v4f *>(fine + c[zz][yy]));
-            else *reinterpret_cast<float4 *>(fine + c[zz][yy]) = f;
+            if (fg.streaming) Cell<TX>::store4nt(fine + c[zz][yy], f);
+            else Cell<TX>::store4(fine + c[zz][yy], f);
         }
 }
 
@@ -1469,6 +1578,105 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
 }
 unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
 
+// ---- mixed precision (options.precision = 1): the fine level's iterate and residual live in binary16 ----------------
+// The launchers take the binary16 grids as void* (the solver layer does not see __half).  Solver-owned grids only:
+// chunks without active cells hold 0 and are never visited.
+int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    __half *out = static_cast<__half *>(outH);
+    const __half *x = static_cast<const __half *>(xH);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const bool list = g.chunks != nullptr;
+    const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
+    if (nb > 0) {
+        if (op == OP_JACOBI) stencilQuadKernel<OP_JACOBI, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
+        else stencilQuadKernel<OP_RESIDUAL, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
+    }
+    if (g.nbnd > 0) {
+        const unsigned nbb = blocksFor(size_t(g.nbnd), 256);
+        if (op == OP_JACOBI) boundaryOpKernel<OP_JACOBI, false, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, nullptr, ms);
+        else boundaryOpKernel<OP_RESIDUAL, false, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, nullptr, ms);
+    }
+    return int(hipGetLastError());
+}
+
+int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
+                         const BandGroupsDev &bg, const MixScale &ms)
+{
+    if (nband <= 0 || bg.ngroups <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    __half *x = static_cast<__half *>(xH);
+    bandFusedKernel<__half><<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours, bg.readCell,
+                                                                          bandTmp, omega, bg.depth, nullptr, nullptr, nullptr, 0, 0, ms);
+    const unsigned nb = blocksFor(size_t(nband), 256);
+    bandScatterKernel<false, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    return int(hipGetLastError());
+}
+
+// x~ = mul * x (initial guess) / dst = x~ * (mul / *sigma) (the cycle's result, back in the caller's units), whole grid
+__global__ __launch_bounds__(256) void toHalfKernel(__half *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ sigma, float mul0,
+                                                    size_t nq)
+{
+    const size_t q = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float mul = mul0 * *sigma;
+    const float4 v = reinterpret_cast<const float4 *>(src)[q];
+    Cell<__half>::store4(dst + 4 * q, make_float4(mul * v.x, mul * v.y, mul * v.z, mul * v.w));
+}
+__global__ __launch_bounds__(256) void fromHalfKernel(float *__restrict__ dst, const __half *__restrict__ src, const float *__restrict__ sigma, float mul,
+                                                      size_t nq)
+{
+    const size_t q = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float m = mul / *sigma;
+    const float4 v = Cell<__half>::load4(src + 4 * q);
+    reinterpret_cast<float4 *>(dst)[q] = make_float4(m * v.x, m * v.y, m * v.z, m * v.w);
+}
+int launchToHalf(void *stream, void *dstH, const float *src, const float *sigmaDev, float mul, size_t cells)
+{
+    toHalfKernel<<<blocksFor(cells >> 2, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<__half *>(dstH), src, sigmaDev, mul, cells >> 2);
+    return int(hipGetLastError());
+}
+int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells)
+{
+    fromHalfKernel<<<blocksFor(cells >> 2, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, static_cast<const __half *>(srcH), sigmaDev, mul, cells >> 2);
+    return int(hipGetLastError());
+}
+// *sigma = 2^-ceil(log2(*maxAbs)): the power of two that brings max |b| into (1/2, 1]; 1 for a zero rhs
+__global__ void mixSigmaKernel(const double *__restrict__ maxAbs, float *__restrict__ sigma)
+{
+    const double m = *maxAbs;
+    int e = 0;
+    if (m > 0.0 && m < 1e300) (void)frexp(m, &e);  // m = f 2^e, f in [1/2, 1)
+    *sigma = ldexpf(1.f, -e);
+}
+int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev)
+{
+    mixSigmaKernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(maxAbsDev, sigmaDev);
+    return int(hipGetLastError());
+}
+// zeros on the active chunks of a binary16 grid of level g
+__global__ __launch_bounds__(256) void zeroChunksHalfKernel(__half *__restrict__ a, const int32_t *__restrict__ chunks, int chunkCells, size_t nq)
+{
+    size_t q;
+    if (chunkCells == kChunkCells) q = size_t(chunks[blockIdx.x]) * (kChunkCells / 4) + threadIdx.x;
+    else {
+        const int ch = chunks[blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+        if (ch < 0) return;
+        q = size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
+    }
+    if (q < nq) reinterpret_cast<uint2 *>(a)[q] = make_uint2(0u, 0u);
+}
+int launchZeroActiveHalf(void *stream, const GridP &g, void *aH)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    if (!g.chunks || (n & 3) != 0) return int(hipMemsetAsync(aH, 0, n * sizeof(__half), static_cast<hipStream_t>(stream)));
+    const unsigned nb = g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4;
+    if (nb > 0) zeroChunksHalfKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<__half *>(aH), g.chunks, g.chunkCells, n >> 2);
+    return int(hipGetLastError());
+}
+
 // dotPartials (optional): nmixed + npure slots, one per tile, mixed tiles first
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials)
@@ -1519,6 +1727,34 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
     return int(hipGetLastError());
 }
+
+int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, const void *fineH, float fm)
+{
+    const __half *fine = static_cast<const __half *>(fineH);
+    const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
+    const int kc = 16;
+    const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8, nbz = (coarse.nz + kc - 1) / kc;
+    if (coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
+        restrictMarchKernel<__half><<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby, fm);
+        return int(hipGetLastError());
+    }
+    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * unsigned(coarse.chunkCells / 256) : blocksFor(n, 256);
+    if (nb > 0) restrictKernel<__half><<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, fm);
+    return int(hipGetLastError());
+}
+
+// fine (binary16, stored scaled by pm) += pm * 4 * trilerp(coarse); requires the block kernel's shape rule (mixedPrecisionShapeOk)
+int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const float *coarse, float pm)
+{
+    const int npj = fine.ny / 2 - 1;
+    const int kp0 = 0, kp1 = fine.nz / 2 - 2;
+    const size_t total = size_t(fine.nx >> 2) * npj * size_t(std::max(kp1 - kp0 + 1, 0));
+    const unsigned nb = blocksFor(total, 256);
+    if (nb > 0)
+        prolongAddBlockKernel<__half><<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, static_cast<__half *>(fineH), coarse, nb, npj, kp0, total, pm);
+    return int(hipGetLastError());
+}
+bool mixedPrecisionShapeOk(int nx, int ny, int nz) { return (nx & 3) == 0 && nx >= 8 && (ny & 1) == 0 && (nz & 1) == 0 && ny >= 4 && nz >= 2; }
 
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse)
 {

@@ -96,6 +96,11 @@ struct mgps_solver {
     // PCG work grids (allocated on first use): r, p, z, t (CG.h:43, 67, 92, 96) and 1/diag
     float *pcg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *dinv = nullptr;
+    // mixed precision (options.precision = 1): binary16 grids of the fine level -- iterate, its Jacobi partner, residual --
+    // the power-of-two normalisation of the rhs (device scalar) and the exponent e of the iterate's storage scale 2^-e
+    void *mixX = nullptr, *mixTmp = nullptr, *mixR = nullptr;
+    float *mixSigma = nullptr;
+    int mixExp = 0;
     std::vector<void *> userGrids;  // allocation bases handed out by mgps_grid_alloc (ghost plane first)
     // slab run
     bool dist = false;
@@ -243,6 +248,10 @@ void freeAll(mgps_solver *h)
     (void)hipFree(h->resultDev);
     (void)hipFree(h->dotPartials);
     (void)hipFree(h->cgScal);
+    (void)hipFree(h->mixX);
+    (void)hipFree(h->mixTmp);
+    (void)hipFree(h->mixR);
+    (void)hipFree(h->mixSigma);
     for (double *g64 : h->cg64)
         if (g64) (void)hipFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
@@ -541,6 +550,93 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     return MGPS_OK;
 }
 
+// levels first .. last of a single-device solver: rhs in lv[first].b, *result = the grid that ends up holding the
+// correction (MG.cpp:557-784 from level `first` on)
+int innerCycle(mgps_solver *h, int first, float **result)
+{
+    const int nlv = int(h->lv.size());
+    const int nsmooth = nlv - 1;  // the last level is the direct solve
+    std::vector<float *> cur(nlv, nullptr), other(nlv, nullptr);
+    for (int l = first; l < nsmooth; ++l) {
+        DevLevel &F = h->lv[l], &C = h->lv[l + 1];
+        cur[l] = F.x;
+        other[l] = F.tmp;
+        MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
+        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, true, true));
+        MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], F.b, 0.f, true));
+        MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
+    }
+    DevLevel &B = h->lv[nsmooth];
+    MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, B.x, B.b, h->cvec));  // MG.cpp:669-692
+    cur[nsmooth] = B.x;
+    for (int l = nsmooth - 1; l >= first; --l) {
+        DevLevel &F = h->lv[l];
+        MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
+        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, false, false));
+    }
+    *result = cur[first];
+    return MGPS_OK;
+}
+
+int ensureMixedGrids(mgps_solver *h)
+{
+    if (h->mixX) return MGPS_OK;
+    const size_t n = h->lv[0].d.cells();
+    uint16_t *p[3] = {nullptr, nullptr, nullptr};
+    for (int q = 0; q < 3; ++q) MGPS_TRY(devAlloc(h, &p[q], n, true));
+    h->mixX = p[0];
+    h->mixTmp = p[1];
+    h->mixR = p[2];
+    MGPS_TRY(devAlloc(h, &h->mixSigma, 1, true));
+    // |A^-1| of the h-free operator can reach N^2 / 2 (a column of liquid under a free surface): keep that below 2^14
+    const Dims d = h->lv[0].d;
+    const double bound = 0.5 * double(std::max(d.nx, std::max(d.ny, d.nz))) * double(std::max(d.nx, std::max(d.ny, d.nz)));
+    h->mixExp = std::max(0, int(std::ceil(std::log2(bound / 16384.0))));
+    return MGPS_OK;
+}
+
+// The V-cycle with the fine level's iterate and residual in binary16 (options.precision = 1, BASELINE config 5; Jacobi
+// smoother, single device).  Same schedule as vcycle() (MG.cpp:420-881); x and b are fp32 grids in the caller's units.
+int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
+{
+    MGPS_TRY(ensureMixedGrids(h));
+    DevLevel &F = h->lv[0];
+    const int nlv = int(h->lv.size());
+    const size_t n = F.d.cells();
+    const float xs = std::ldexp(1.f, -h->mixExp), xsInv = std::ldexp(1.f, h->mixExp);
+    const float omega = h->opt.jacobi_weight;
+    // sigma = the power of two that brings max |b| into (1/2, 1]
+    MGPS_LAUNCH(h, launchReduce(h->stream, 3, F.g, b, nullptr, h->partials, h->resultDev));
+    MGPS_LAUNCH(h, launchMixSigma(h->stream, h->resultDev, h->mixSigma));
+    void *cur = h->mixX, *other = h->mixTmp;
+    if (useInitialGuess) MGPS_LAUNCH(h, launchToHalf(h->stream, cur, x, h->mixSigma, xs, n));
+    else MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));  // MG.cpp:439-440
+    const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
+    auto stroke = [&](bool down) -> int {
+        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
+        for (int rep = 0; rep < (down ? h->opt.pre_sweeps : h->opt.post_sweeps); ++rep) {
+            MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, F.g, other, cur, b, omega, smooth));
+            std::swap(cur, other);
+        }
+        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
+        return MGPS_OK;
+    };
+    MGPS_TRY(stroke(true));
+    if (nlv > 1) {
+        DevLevel &C = h->lv[1];
+        // r~ = 256 r^ = 256 sigma b - 256 2^e (A x~); level 1 receives Restrict(r^) in fp32
+        const MixScale res{h->mixSigma, 256.f, 256.f * xsInv};
+        MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_RESIDUAL, F.g, h->mixR, cur, b, 0.f, res));
+        MGPS_LAUNCH(h, launchRestrictMixed(h->stream, C.g, C.b, h->mixR, 1.f / 256.f));
+        float *corr = nullptr;
+        MGPS_TRY(innerCycle(h, 1, &corr));
+        MGPS_LAUNCH(h, launchProlongAddMixed(h->stream, F.g, cur, corr, xs));
+        MGPS_TRY(stroke(false));
+    }
+    MGPS_LAUNCH(h, launchFromHalf(h->stream, x, cur, h->mixSigma, xsInv, n));
+    return MGPS_OK;
+}
+
 // the value a reduction launch left in resultDev, on the host (summed / maximised over the ranks of a slab run)
 int fetchReduction(mgps_solver *h, int kind, double *out)
 {
@@ -633,6 +729,7 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     bool gathered = false;
     auto precondition = [&]() -> int {  // z = M float(r)
         gathered = false;
+        if (useMG && h->opt.precision == 1) return vcycleMixed(h, z, r32, false);
         if (useMG) {
             MGPS_TRY(vcycle(h, z, r32, false, true, true));
             gathered = h->gatherDot;
@@ -733,6 +830,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     bool gathered = false;
     auto precondition = [&](float *dst, const float *src) -> int {
         gathered = false;
+        if (useMG && h->opt.precision == 1) return vcycleMixed(h, dst, src, false);  // <dst, src> by a separate reduction
         if (useMG) {
             MGPS_TRY(vcycle(h, dst, src, false, true, true));  // Plug.cpp:468-472 (dst = p or z: grids of the solver)
             gathered = h->gatherDot;
@@ -1063,8 +1161,9 @@ int readOptions(const mgps_options *opt, mgps_options *o)
             return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options.struct_size mismatch: call mgps_default_options first");
         *o = *opt;
     }
-    if (o->pre_sweeps < 1 || o->post_sweeps < 1 || o->stencil_path < 0 || o->stencil_path > 2)
-        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_options: pre_sweeps / post_sweeps must be >= 1 and stencil_path 0, 1 or 2");
+    if (o->pre_sweeps < 1 || o->post_sweeps < 1 || o->stencil_path < 0 || o->stencil_path > 2 || o->precision < 0 || o->precision > 1)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT,
+                     "mgps_options: pre_sweeps / post_sweeps must be >= 1, stencil_path 0, 1 or 2, precision 0 or 1");
     return MGPS_OK;
 }
 
@@ -1088,6 +1187,14 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
         return code;
     };
     const Dims d0 = hier->lv[0].d;
+    if (tailOfSlabRun) h->opt.precision = 0;
+    if (h->opt.precision == 1) {
+        const bool fused = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
+        if (useGS || !fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
+            return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT,
+                              "options.precision = 1 (mixed precision) needs the Jacobi smoother (use_gauss_seidel = 0), the fused band stage "
+                              "(fuse_band_passes, 1 <= band_iterations <= 4) and a fine grid with nx % 4 == 0 and even ny, nz"));
+    }
     StageClock clock(h->opt.print_stats != 0);
     // two jobs nothing below waits for until the end run beside the level set-up: the dense inverse of the coarsest
     // matrix (host threads) and the copy of the face weights (a blocking hipMemcpy of 3 x 4 B per cell)
@@ -1341,6 +1448,7 @@ try {
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: incomplete mgps_comm");
     mgps_options o;
     MGPS_TRY(readOptions(opt, &o));
+    if (o.precision != 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: options.precision = 1 is for single-device solvers");
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
     mgps_hierarchy *hier = nullptr;
@@ -1604,6 +1712,7 @@ int mgps_apply_vcycle(mgps_solver *h, float *x_dev, const float *b_dev, int use_
 try {
     MGPS_TRY(checkLevel(h, 0, "mgps_apply_vcycle"));
     if (!x_dev || !b_dev || x_dev == b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_apply_vcycle: bad grid pointers");
+    if (h->opt.precision == 1) return vcycleMixed(h, x_dev, b_dev, use_initial_guess != 0);
     return vcycle(h, x_dev, b_dev, use_initial_guess != 0);
 }
 MGPS_API_CATCH(h)

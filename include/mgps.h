@@ -101,6 +101,15 @@ typedef struct mgps_options {
        1 = the quad kernel, 2 = the plane-marching kernel wherever its shape rule allows (nx >= 256, nx % 4 == 0,
        ny >= 16).  Same arithmetic per cell either way; for tuning and for parity tests of both kernels at small sizes */
     int stencil_path;
+    /* 0 (default): every grid of the V-cycle is fp32.  1 = mixed precision (BASELINE config 5; the reference's README
+       TO-DO, README.md:34-35): the fine level of the V-cycle -- 7/8 of its bytes -- keeps its iterate and its residual in
+       binary16 (damped-Jacobi sweeps 9 instead of 13 B per cell, the restriction reads 2 instead of 4, the prolongation
+       updates 4 instead of 8); the rhs, every coarser level, the CG vectors, A.p and all reductions stay fp32 and all
+       arithmetic is fp32.  The cycle runs on the rhs normalised by a power of two (max |b| in (1/2, 1]) with fixed
+       per-grid scales, so that binary16's range is used where the values are; results are returned in the caller's
+       units.  Single-device solvers with the Jacobi smoother (use_gauss_seidel = 0) whose fine nx is a multiple of 4.
+       mgps_solve_pcg then preconditions with this cycle: tolerance and iteration counts against fp32 in DESIGN.md */
+    int precision;
 } mgps_options;
 
 typedef struct mgps_pcg_stats {

@@ -65,6 +65,44 @@ int mgps_fields_divergence(double out_host[3], const int32_t *material, const fl
                            const float *svx, const float *svy, const float *svz, const float *cwx, const float *cwy,
                            const float *cwz, int gx, int gy, int gz, void *stream);
 
+/* ---- the whole of solveGasSubclass between "fields fetched" and "fields written back" in one call ------------------
+ * HDK_GeometricFreeSurfacePressureSolver::solveGasSubclass (Plug.cpp:252-707) on HOST arrays: what the Houdini shim
+ * (host/HDK_GeometricFreeSurfacePressureSolver.cpp) calls after flattening the SIM fields.  Uploads the inputs, runs
+ * the device passes above in the reference's order -- material labels (Plug.cpp:270), valid faces (286), MG domain
+ * labels + boundary weights + expansion + boundary labels (316-362), rhs (386), warm start (413) -- builds the
+ * multigrid solver from the device grids, runs solveGeometricConjugateGradient (426-629), then pressure write-back,
+ * pressure gradient and the divergence report (637-707), and downloads pressure, velocity and the valid-face flags.
+ * Arrays are dense, x fastest, of `real_bytes` = 4 (float) or 8 (double: converted on the device); face grids have one
+ * more entry along their axis.  The solid SDF and the solid velocity are passed sampled at cell / face centres. */
+typedef struct mgps_projection {
+    int struct_size;               /* sizeof(mgps_projection) */
+    int gx, gy, gz;                /* simulation grid */
+    int real_bytes;                /* 4 or 8: the type behind every `void *` real array below */
+    const void *liquid_phi;        /* cell grid: liquid SDF ("surface") */
+    const void *solid_phi;         /* cell grid: solid SDF ("collision") */
+    const void *cut_weights[3];    /* face grids ("cutCellWeights") */
+    void *velocity[3];             /* face grids, in: velocity, out: projected velocity */
+    const void *solid_velocity[3]; /* face grids ("collisionvelocity"), or all NULL */
+    void *pressure;                /* cell grid, in: previous pressure (read when use_old_pressure), out: pressure */
+    uint8_t *valid_faces[3];       /* out, face grids: 1 = valid face (each may be NULL: not wanted) */
+    int use_old_pressure;          /* "useOldPressure" */
+    int use_mg_preconditioner;     /* "useMGPreconditioner" */
+    int use_gauss_seidel;          /* 1 = the plugin's choice (Plug.cpp:466) */
+    double tolerance;              /* SIM_NAME_TOLERANCE */
+    int max_iterations;            /* "maxIterations" */
+    int power_of_two;              /* 1 = the reference's expansion (Ops.h:1353-1360), 0 = tight extents */
+    /* results */
+    mgps_pcg_stats stats;
+    int mg_levels, offset, expanded[3];
+    double liquid_cells;
+    double residual_inf, residual_l2;       /* of the computed solution (Plug.cpp:625-628; infNorm is the signed max) */
+    double divergence_sum, divergence_max;  /* after the projection (Plug.cpp:704-706); divergence_count = liquid_cells */
+    double setup_ms, solve_ms, total_ms;    /* host wall clock: everything before the solve / the solve / the whole call */
+} mgps_projection;
+/* status MGPS_ERR_HIERARCHY with outcome MGPS_PCG_RHS_ZERO-like early outs are reported through stats.outcome; a domain
+ * without liquid returns MGPS_OK with liquid_cells = 0 and leaves velocity and pressure untouched */
+int mgps_project_free_surface(mgps_projection *p, const mgps_options *opt);
+
 #ifdef __cplusplus
 }
 #endif
