@@ -305,7 +305,6 @@ int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b,
                          const BandGroupsDev &bg, const MixScale &ms);
 int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, const void *fineH, float fm);
 int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const float *coarse, float pm);
-int launchToHalf(void *stream, void *dstH, const float *src, const float *sigmaDev, float mul, size_t cells);  // x~ = (*sigma * mul) x
 int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells);
 int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev);
 int launchZeroActiveHalf(void *stream, const GridP &g, void *aH);
@@ -326,8 +325,13 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
                  double *resultDev);
 // x += alpha p, r -= alpha t, *resultDev = sum of the new r^2 over active cells (one pass, CG.h:132-153)
 // alphaDev (optional): alpha = float(alphaDev[0] / alphaDev[1]) read on the device instead of the host's value
+// maxAbsDev (optional; `partials` then holds 2 x kReducePartials doubles): *maxAbsDev = max |r| of the new residual
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev = nullptr);
+                   double *resultDev, const double *alphaDev = nullptr, double *maxAbsDev = nullptr);
+// CG steps that read the mixed-precision V-cycle's binary16 result in place, z = (mul / *sigma) x~ (level g = the fine level;
+// the grid's dimensions need n % 4 == 0): *resultDev = <z, r>; p = z + beta p
+int launchHalfDot(void *stream, const GridP &g, const void *xH, const float *r, const float *sigmaDev, float mul, double *partials, double *resultDev);
+int launchXpayHalf(void *stream, const GridP &g, float *p, const void *xH, const float *sigmaDev, float mul, const float *betaDev, float betaHost);
 int launchCgScalars(void *stream, double *scal, float *beta, int init);
 // fp64 CG vectors (options.pcg_fp64_vectors), level g = the fine level of a single-device solver:
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2

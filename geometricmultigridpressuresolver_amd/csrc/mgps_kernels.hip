@@ -1614,16 +1614,7 @@ int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b,
     return int(hipGetLastError());
 }
 
-// x~ = mul * x (initial guess) / dst = x~ * (mul / *sigma) (the cycle's result, back in the caller's units), whole grid
-__global__ __launch_bounds__(256) void toHalfKernel(__half *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ sigma, float mul0,
-                                                    size_t nq)
-{
-    const size_t q = size_t(blockIdx.x) * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const float mul = mul0 * *sigma;
-    const float4 v = reinterpret_cast<const float4 *>(src)[q];
-    Cell<__half>::store4(dst + 4 * q, make_float4(mul * v.x, mul * v.y, mul * v.z, mul * v.w));
-}
+// dst = x~ * (mul / *sigma): the cycle's result back in the caller's units, whole grid
 __global__ __launch_bounds__(256) void fromHalfKernel(float *__restrict__ dst, const __half *__restrict__ src, const float *__restrict__ sigma, float mul,
                                                       size_t nq)
 {
@@ -1632,11 +1623,6 @@ __global__ __launch_bounds__(256) void fromHalfKernel(float *__restrict__ dst, c
     const float m = mul / *sigma;
     const float4 v = Cell<__half>::load4(src + 4 * q);
     reinterpret_cast<float4 *>(dst)[q] = make_float4(m * v.x, m * v.y, m * v.z, m * v.w);
-}
-int launchToHalf(void *stream, void *dstH, const float *src, const float *sigmaDev, float mul, size_t cells)
-{
-    toHalfKernel<<<blocksFor(cells >> 2, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<__half *>(dstH), src, sigmaDev, mul, cells >> 2);
-    return int(hipGetLastError());
 }
 int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells)
 {
@@ -2150,10 +2136,11 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
                                                       const float *__restrict__ p, float *__restrict__ r,
                                                       const float *__restrict__ t, float alpha, double *__restrict__ partials,
                                                       const int32_t *__restrict__ chunks, int nchunks, int chunkCells,
-                                                      const double *__restrict__ alphaDev)
+                                                      const double *__restrict__ alphaDev, double *__restrict__ maxPartials)
 {
     if (alphaDev) alpha = float(alphaDev[0] / alphaDev[1]);  // <z, r> / <p, A p> left on the device by the reductions (CG.h:121)
     double acc = 0.0;
+    float big = 0.f;  // max |r| of the new residual: the mixed-precision V-cycle normalises its rhs by it
     const size_t nq = n >> 2;
     size_t q;
     for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
@@ -2161,10 +2148,10 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
         float4 xv = reinterpret_cast<const float4 *>(x)[q], rv = reinterpret_cast<const float4 *>(r)[q];
         const float4 pv = reinterpret_cast<const float4 *>(p)[q], tv = reinterpret_cast<const float4 *>(t)[q];
-        if (activeLabel(l.x)) { xv.x = xv.x + alpha * pv.x; rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); }
-        if (activeLabel(l.y)) { xv.y = xv.y + alpha * pv.y; rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); }
-        if (activeLabel(l.z)) { xv.z = xv.z + alpha * pv.z; rv.z = rv.z + (-alpha) * tv.z; acc += double(rv.z) * double(rv.z); }
-        if (activeLabel(l.w)) { xv.w = xv.w + alpha * pv.w; rv.w = rv.w + (-alpha) * tv.w; acc += double(rv.w) * double(rv.w); }
+        if (activeLabel(l.x)) { xv.x = xv.x + alpha * pv.x; rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); big = fmaxf(big, fabsf(rv.x)); }
+        if (activeLabel(l.y)) { xv.y = xv.y + alpha * pv.y; rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); big = fmaxf(big, fabsf(rv.y)); }
+        if (activeLabel(l.z)) { xv.z = xv.z + alpha * pv.z; rv.z = rv.z + (-alpha) * tv.z; acc += double(rv.z) * double(rv.z); big = fmaxf(big, fabsf(rv.z)); }
+        if (activeLabel(l.w)) { xv.w = xv.w + alpha * pv.w; rv.w = rv.w + (-alpha) * tv.w; acc += double(rv.w) * double(rv.w); big = fmaxf(big, fabsf(rv.w)); }
         reinterpret_cast<float4 *>(x)[q] = xv;
         reinterpret_cast<float4 *>(r)[q] = rv;
     }
@@ -2174,20 +2161,93 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
             x[c] = x[c] + alpha * p[c];
             r[c] = r[c] + (-alpha) * t[c];
             acc += double(r[c]) * double(r[c]);
+            big = fmaxf(big, fabsf(r[c]));
         }
     }
     const double total = blockReduce<1>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    if (maxPartials) {  // (uniform branch)
+        __syncthreads();  // blockReduce's scratch is reused
+        const double top = blockReduce<3>(double(big));
+        if (threadIdx.x == 0) maxPartials[blockIdx.x] = top;
+    }
 }
 
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev)
+                   double *resultDev, const double *alphaDev, double *maxAbsDev)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
-    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev);
+    double *maxPartials = maxAbsDev ? partials + kReducePartials : nullptr;  // (`partials` holds 2 x kReducePartials doubles)
+    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
     reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
+    if (maxAbsDev) reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), maxPartials, maxAbsDev);
+    return int(hipGetLastError());
+}
+
+// ---- CG steps on the binary16 result of the mixed-precision V-cycle: z = (mul / *sigma) x~ is never written out ------
+// <z, r> over the active cells
+__global__ __launch_bounds__(256) void halfDotKernel(size_t n, const uint8_t *__restrict__ lab, const __half *__restrict__ xh, const float *__restrict__ r,
+                                                     double *__restrict__ partials, const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
+{
+    double acc = 0.0;
+    const size_t nq = n >> 2;
+    size_t q;
+    for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
+        const float4 xv = Cell<__half>::load4(xh + 4 * q), rv = reinterpret_cast<const float4 *>(r)[q];
+        if (activeLabel(l.x)) acc += double(xv.x) * double(rv.x);
+        if (activeLabel(l.y)) acc += double(xv.y) * double(rv.y);
+        if (activeLabel(l.z)) acc += double(xv.z) * double(rv.z);
+        if (activeLabel(l.w)) acc += double(xv.w) * double(rv.w);
+    }
+    const double total = blockReduce<0>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void reduceFinalScaledKernel(int nparts, const double *__restrict__ partials, double *__restrict__ result,
+                                                               const float *__restrict__ sigma, float mul)
+{
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x) acc += partials[p];
+    const double total = blockReduce<0>(acc);
+    if (threadIdx.x == 0) *result = total * (double(mul) / double(*sigma));
+}
+int launchHalfDot(void *stream, const GridP &g, const void *xH, const float *r, const float *sigmaDev, float mul, double *partials, double *resultDev)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
+    halfDotKernel<<<nb, 256, 0, s>>>(n, g.lab, static_cast<const __half *>(xH), r, partials, g.chunks, g.nchunks, g.chunkCells);
+    reduceFinalScaledKernel<<<1, 256, 0, s>>>(int(nb), partials, resultDev, sigmaDev, mul);
+    return int(hipGetLastError());
+}
+// p = z + beta p on active cells (CG.h:191)
+__global__ __launch_bounds__(256) void xpayHalfKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ p, const __half *__restrict__ xh,
+                                                      const float *__restrict__ sigma, float mul, const float *__restrict__ betaDev, float betaHost,
+                                                      const int32_t *__restrict__ chunks, int nchunks, int chunkCells)
+{
+    const float beta = betaDev ? *betaDev : betaHost, m = mul / *sigma;
+    const size_t nq = n >> 2;
+    size_t q;
+    for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
+        if (q >= nq) continue;
+        const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
+        const float4 xv = Cell<__half>::load4(xh + 4 * q);
+        float4 pv = reinterpret_cast<const float4 *>(p)[q];
+        if (activeLabel(l.x)) pv.x = m * xv.x + beta * pv.x;
+        if (activeLabel(l.y)) pv.y = m * xv.y + beta * pv.y;
+        if (activeLabel(l.z)) pv.z = m * xv.z + beta * pv.z;
+        if (activeLabel(l.w)) pv.w = m * xv.w + beta * pv.w;
+        reinterpret_cast<float4 *>(p)[q] = pv;
+    }
+}
+int launchXpayHalf(void *stream, const GridP &g, float *p, const void *xH, const float *sigmaDev, float mul, const float *betaDev, float betaHost)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    xpayHalfKernel<<<vecBlocks(g, n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, p, static_cast<const __half *>(xH), sigmaDev, mul, betaDev, betaHost,
+                                                                                 g.chunks, g.nchunks, g.chunkCells);
     return int(hipGetLastError());
 }
 

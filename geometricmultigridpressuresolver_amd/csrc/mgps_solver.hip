@@ -101,6 +101,8 @@ struct mgps_solver {
     void *mixX = nullptr, *mixTmp = nullptr, *mixR = nullptr;
     float *mixSigma = nullptr;
     int mixExp = 0;
+    double *mixMax = nullptr;   // max |r| left by the CG update pass: the next preconditioning cycle's normalisation
+    void *mixResult = nullptr;  // the binary16 grid that holds the last cycle's result (scale 2^mixExp / *mixSigma)
     std::vector<void *> userGrids;  // allocation bases handed out by mgps_grid_alloc (ghost plane first)
     // slab run
     bool dist = false;
@@ -252,6 +254,7 @@ void freeAll(mgps_solver *h)
     (void)hipFree(h->mixTmp);
     (void)hipFree(h->mixR);
     (void)hipFree(h->mixSigma);
+    (void)hipFree(h->mixMax);
     for (double *g64 : h->cg64)
         if (g64) (void)hipFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
@@ -588,6 +591,7 @@ int ensureMixedGrids(mgps_solver *h)
     h->mixTmp = p[1];
     h->mixR = p[2];
     MGPS_TRY(devAlloc(h, &h->mixSigma, 1, true));
+    MGPS_TRY(devAlloc(h, &h->mixMax, 1, true));
     // |A^-1| of the h-free operator can reach N^2 / 2 (a column of liquid under a free surface): keep that below 2^14
     const Dims d = h->lv[0].d;
     const double bound = 0.5 * double(std::max(d.nx, std::max(d.ny, d.nz))) * double(std::max(d.nx, std::max(d.ny, d.nz)));
@@ -597,20 +601,33 @@ int ensureMixedGrids(mgps_solver *h)
 
 // The V-cycle with the fine level's iterate and residual in binary16 (options.precision = 1, BASELINE config 5; Jacobi
 // smoother, single device).  Same schedule as vcycle() (MG.cpp:420-881); x and b are fp32 grids in the caller's units.
-int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
+// x == nullptr: the result stays in binary16 (h->mixResult; z = 2^mixExp / *mixSigma times it) for launchHalfDot /
+// launchXpayHalf.  maxAbsDev: max |b| if a previous pass already left it on the device (else a reduction runs here).
+int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, const double *maxAbsDev = nullptr)
 {
     MGPS_TRY(ensureMixedGrids(h));
     DevLevel &F = h->lv[0];
+    if (useInitialGuess && x) {
+        // A cycle from an initial guess is x + M (b - A x) (the cycle is linear).  In that form the residual is taken
+        // in fp32 and only the correction passes through binary16 -- storing the iterate itself there would put rounding
+        // noise of 2^-11 |x| into every residual, which the coarse correction amplifies by |A^-1|: chained cycles would stall
+        MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, x, b, 0.f, true));
+        MGPS_TRY(vcycleMixed(h, nullptr, F.r, false));
+        MGPS_LAUNCH(h, launchXpayHalf(h->stream, F.g, x, h->mixResult, h->mixSigma, std::ldexp(1.f, h->mixExp), nullptr, 1.f));
+        return MGPS_OK;
+    }
     const int nlv = int(h->lv.size());
     const size_t n = F.d.cells();
     const float xs = std::ldexp(1.f, -h->mixExp), xsInv = std::ldexp(1.f, h->mixExp);
     const float omega = h->opt.jacobi_weight;
     // sigma = the power of two that brings max |b| into (1/2, 1]
-    MGPS_LAUNCH(h, launchReduce(h->stream, 3, F.g, b, nullptr, h->partials, h->resultDev));
-    MGPS_LAUNCH(h, launchMixSigma(h->stream, h->resultDev, h->mixSigma));
+    if (!maxAbsDev) {
+        MGPS_LAUNCH(h, launchReduce(h->stream, 3, F.g, b, nullptr, h->partials, h->mixMax));
+        maxAbsDev = h->mixMax;
+    }
+    MGPS_LAUNCH(h, launchMixSigma(h->stream, maxAbsDev, h->mixSigma));
     void *cur = h->mixX, *other = h->mixTmp;
-    if (useInitialGuess) MGPS_LAUNCH(h, launchToHalf(h->stream, cur, x, h->mixSigma, xs, n));
-    else MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));  // MG.cpp:439-440
+    MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));  // MG.cpp:439-440
     const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
     auto stroke = [&](bool down) -> int {
         MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
@@ -633,7 +650,8 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess)
         MGPS_LAUNCH(h, launchProlongAddMixed(h->stream, F.g, cur, corr, xs));
         MGPS_TRY(stroke(false));
     }
-    MGPS_LAUNCH(h, launchFromHalf(h->stream, x, cur, h->mixSigma, xsInv, n));
+    h->mixResult = cur;
+    if (x) MGPS_LAUNCH(h, launchFromHalf(h->stream, x, cur, h->mixSigma, xsInv, n));
     return MGPS_OK;
 }
 
@@ -830,7 +848,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     bool gathered = false;
     auto precondition = [&](float *dst, const float *src) -> int {
         gathered = false;
-        if (useMG && h->opt.precision == 1) return vcycleMixed(h, dst, src, false);  // <dst, src> by a separate reduction
+        if (useMG && h->opt.precision == 1) return vcycleMixed(h, dst, src, false);  // (the first application, p = M r: CG.h:75)
         if (useMG) {
             MGPS_TRY(vcycle(h, dst, src, false, true, true));  // Plug.cpp:468-472 (dst = p or z: grids of the solver)
             gathered = h->gatherDot;
@@ -910,13 +928,30 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             alpha = absNew / pAp;  // CG.h:121
         }
         // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
-        MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr));
+        const bool mixed = useMG && h->opt.precision == 1;  // the pass also leaves max |r| for the cycle's normalisation
+        MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr,
+                                      mixed ? h->mixMax : nullptr));
         MGPS_TRY(fetchReduction(h, 1, &res2));
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161 -- the counter is not advanced on the exit pass
             converged = true;
             break;
+        }
+        if (mixed) {  // z = M r stays in binary16: <z, r> and p = z + beta p read it there (CG.h:168-191)
+            const float zScale = std::ldexp(1.f, h->mixExp);
+            MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax));
+            if (devScal) {
+                MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, scal + 3));
+                MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 0));
+                MGPS_LAUNCH(h, launchXpayHalf(h->stream, F.g, p, h->mixResult, h->mixSigma, zScale, betaDev, 0.f));
+            } else {
+                const double absOld = absNew;
+                MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, h->resultDev));
+                MGPS_TRY(fetchReduction(h, 0, &absNew));
+                MGPS_LAUNCH(h, launchXpayHalf(h->stream, F.g, p, h->mixResult, h->mixSigma, zScale, nullptr, float(absNew / absOld)));
+            }
+            continue;
         }
         MGPS_TRY(precondition(z, r));  // CG.h:168
         if (devScal) {
@@ -1057,7 +1092,7 @@ int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
         MGPS_TRY(devUpload(h, &h->ccells, hier->coarseCell));
         MGPS_TRY(devAlloc(h, &h->cvec, size_t(h->cn), true));
     }
-    MGPS_TRY(devAlloc(h, &h->partials, size_t(kReducePartials), true));
+    MGPS_TRY(devAlloc(h, &h->partials, size_t(2 * kReducePartials), true));
     MGPS_TRY(devAlloc(h, &h->resultDev, 1, true));
     if (hipHostMalloc(reinterpret_cast<void **>(&h->resultHost), sizeof(double)) != hipSuccess)
         return failH(h, MGPS_ERR_ALLOC, "pinned allocation failed");
@@ -1971,6 +2006,66 @@ try {
             return mgps_solve_pcg(hh, xd, bd, p->tol, p->maxIt, p->useMG, p->stats);
         },
         &ctx);
+}
+MGPS_API_CATCH(h)
+
+}  // extern "C"
+
+namespace {
+// double host grids: upload, narrow on the device, run `body` on fp32 device grids, widen, download
+template <class Body>
+int withHostGrids64(mgps_solver *h, double *x_host, const double *b_host, bool uploadX, Body body)
+{
+    if (!x_host || !b_host) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "host form: NULL pointer");
+    const size_t n = h->lv[0].d.cells();
+    float *xd = nullptr, *bd = nullptr;
+    double *stage = nullptr;
+    MGPS_TRY(mgps_grid_alloc(h, 0, &xd));
+    int rc = mgps_grid_alloc(h, 0, &bd);
+    if (rc == MGPS_OK) rc = devAlloc(h, &stage, n, false);
+    auto up = [&](float *dst, const double *src) -> int {
+        MGPS_HIP(h, hipMemcpyAsync(stage, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        MGPS_LAUNCH(h, launchNarrow(h->stream, dst, stage, n));
+        MGPS_HIP(h, hipStreamSynchronize(h->stream));
+        return MGPS_OK;
+    };
+    if (rc == MGPS_OK) rc = up(bd, b_host);
+    if (rc == MGPS_OK && uploadX) rc = up(xd, x_host);
+    if (rc == MGPS_OK) rc = body(xd, bd);
+    if (rc == MGPS_OK) {
+        rc = [&]() -> int {
+            MGPS_LAUNCH(h, launchWiden(h->stream, stage, xd, n));
+            MGPS_HIP(h, hipMemcpyAsync(x_host, stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            MGPS_HIP(h, hipStreamSynchronize(h->stream));
+            return MGPS_OK;
+        }();
+    }
+    const std::string keep = h->lastError;
+    (void)hipFree(stage);
+    if (bd) mgps_grid_free(h, bd);
+    mgps_grid_free(h, xd);
+    if (rc != MGPS_OK) h->lastError = keep;
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int mgps_apply_vcycle_host_f64(mgps_solver *h, double *x_host, const double *b_host, int use_initial_guess)
+try {
+    MGPS_TRY(checkLevel(h, 0, "mgps_apply_vcycle_host_f64"));
+    return withHostGrids64(h, x_host, b_host, use_initial_guess != 0,
+                           [&](float *xd, const float *bd) { return mgps_apply_vcycle(h, xd, bd, use_initial_guess); });
+}
+MGPS_API_CATCH(h)
+
+int mgps_solve_pcg_host_f64(mgps_solver *h, double *x_host, const double *b_host, double tolerance, int max_iterations,
+                            int use_mg_preconditioner, mgps_pcg_stats *stats)
+try {
+    MGPS_TRY(checkLevel(h, 0, "mgps_solve_pcg_host_f64"));
+    return withHostGrids64(h, x_host, b_host, true, [&](float *xd, const float *bd) {
+        return mgps_solve_pcg(h, xd, bd, tolerance, max_iterations, use_mg_preconditioner, stats);
+    });
 }
 MGPS_API_CATCH(h)
 

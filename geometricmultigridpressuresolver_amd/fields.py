@@ -9,6 +9,7 @@ import ctypes as C
 
 import torch
 
+from . import _lib
 from ._lib import check, lib
 
 SOLID_CELL, LIQUID_CELL, AIR_CELL = 0, 1, 2
@@ -123,3 +124,61 @@ def computeResultingDivergence(material, velocity, cut_cell_weights, solid_veloc
     check(lib().mgps_fields_divergence(out, _p(material), *[_p(velocity[a]) for a in range(3)], *[_p(sv[a]) for a in range(3)],
                                        *[_p(cut_cell_weights[a]) for a in range(3)], *_g(shape), _stream()))
     return out[0], out[1], out[2]
+
+
+# ---- the whole projection in one call on host arrays (what the Houdini shim calls) ---------------------------------
+class Projection(C.Structure):
+    """mgps_projection (include/mgps_fields.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int), ("real_bytes", C.c_int),
+        ("liquid_phi", C.c_void_p), ("solid_phi", C.c_void_p), ("cut_weights", C.c_void_p * 3), ("velocity", C.c_void_p * 3),
+        ("solid_velocity", C.c_void_p * 3), ("pressure", C.c_void_p), ("valid_faces", C.c_void_p * 3),
+        ("use_old_pressure", C.c_int), ("use_mg_preconditioner", C.c_int), ("use_gauss_seidel", C.c_int),
+        ("tolerance", C.c_double), ("max_iterations", C.c_int), ("power_of_two", C.c_int),
+        ("stats", _lib.PcgStats), ("mg_levels", C.c_int), ("offset", C.c_int), ("expanded", C.c_int * 3),
+        ("liquid_cells", C.c_double), ("residual_inf", C.c_double), ("residual_l2", C.c_double),
+        ("divergence_sum", C.c_double), ("divergence_max", C.c_double),
+        ("setup_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double),
+    ]
+
+
+def project_free_surface(liquid_phi, solid_phi, cut_weights, velocity, pressure, solid_velocity=None, use_old_pressure=True,
+                         use_mg_preconditioner=True, use_gauss_seidel=True, tolerance=1e-5, max_iterations=2500, power_of_two=True,
+                         options=None):
+    """solveGasSubclass (Plug.cpp:252-707) on numpy host arrays of one dtype (float32 or float64): `velocity` and `pressure`
+    are updated in place; returns (valid_faces[3] uint8, info dict)."""
+    import numpy as np
+
+    dt = np.dtype(pressure.dtype)
+    assert dt in (np.dtype(np.float32), np.dtype(np.float64))
+    shape = tuple(liquid_phi.shape)
+
+    def chk(a, sh):
+        assert a.dtype == dt and a.flags.c_contiguous and tuple(a.shape) == tuple(sh), (a.dtype, a.shape, sh)
+        return a.ctypes.data_as(C.c_void_p)
+
+    pr = Projection()
+    pr.struct_size = C.sizeof(Projection)
+    pr.gz, pr.gy, pr.gx = shape
+    pr.real_bytes = dt.itemsize
+    pr.liquid_phi, pr.solid_phi, pr.pressure = chk(liquid_phi, shape), chk(solid_phi, shape), chk(pressure, shape)
+    valid = []
+    for a in range(3):
+        fs = _face_shape(shape, a)
+        pr.cut_weights[a] = chk(cut_weights[a], fs)
+        pr.velocity[a] = chk(velocity[a], fs)
+        pr.solid_velocity[a] = chk(solid_velocity[a], fs) if solid_velocity is not None else None
+        valid.append(np.zeros(fs, dtype=np.uint8))
+        pr.valid_faces[a] = valid[a].ctypes.data_as(C.c_void_p)
+    pr.use_old_pressure, pr.use_mg_preconditioner, pr.use_gauss_seidel = int(use_old_pressure), int(use_mg_preconditioner), int(use_gauss_seidel)
+    pr.tolerance, pr.max_iterations, pr.power_of_two = float(tolerance), int(max_iterations), int(power_of_two)
+    check(lib().mgps_project_free_surface(C.byref(pr), C.byref(options) if options is not None else None))
+    info = {
+        "iterations": pr.stats.iterations, "outcome": pr.stats.outcome, "rel_residual": pr.stats.rel_residual,
+        "rel_residual_recomputed": pr.stats.rel_residual_recomputed, "mg_levels": pr.mg_levels, "offset": pr.offset,
+        "expanded": (pr.expanded[2], pr.expanded[1], pr.expanded[0]), "liquid_cells": pr.liquid_cells,
+        "residual_inf": pr.residual_inf, "residual_l2": pr.residual_l2, "divergence_sum": pr.divergence_sum,
+        "divergence_max": pr.divergence_max, "setup_ms": pr.setup_ms, "solve_ms": pr.solve_ms, "total_ms": pr.total_ms,
+    }
+    return valid, info

@@ -366,12 +366,24 @@ class GeometricMultigridPoissonSolver:
 
     # -- host-buffer forms (what the Houdini shim calls) --------------------------------------------
     def applyVCycleHost(self, solution, rhs, use_initial_guess=False):
+        if np.asarray(solution).dtype == np.float64:
+            x = np.ascontiguousarray(solution, dtype=np.float64)
+            b = np.ascontiguousarray(rhs, dtype=np.float64)
+            check(lib().mgps_apply_vcycle_host_f64(self.h, _p(x), _p(b), int(bool(use_initial_guess))), self.h)
+            return x
         x = _np_f32(solution)
         b = _np_f32(rhs)
         check(lib().mgps_apply_vcycle_host(self.h, _p(x), _p(b), int(bool(use_initial_guess))), self.h)
         return x
 
     def solvePcgHost(self, solution, rhs, tolerance=1e-5, max_iterations=2500, use_mg_preconditioner=True):
+        if np.asarray(solution).dtype == np.float64:  # the reference's StoreReal: narrowed / widened on the device
+            x = np.ascontiguousarray(solution, dtype=np.float64)
+            b = np.ascontiguousarray(rhs, dtype=np.float64)
+            st = PcgStats()
+            check(lib().mgps_solve_pcg_host_f64(self.h, _p(x), _p(b), C.c_double(tolerance), int(max_iterations), int(bool(use_mg_preconditioner)),
+                                                C.byref(st)), self.h)
+            return x, {"outcome": PCG_OUTCOMES.get(st.outcome, st.outcome), "iterations": st.iterations, "rel_residual": st.rel_residual}
         x = _np_f32(solution)
         b = _np_f32(rhs)
         st = PcgStats()

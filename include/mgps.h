@@ -107,7 +107,8 @@ typedef struct mgps_options {
        updates 4 instead of 8); the rhs, every coarser level, the CG vectors, A.p and all reductions stay fp32 and all
        arithmetic is fp32.  The cycle runs on the rhs normalised by a power of two (max |b| in (1/2, 1]) with fixed
        per-grid scales, so that binary16's range is used where the values are; results are returned in the caller's
-       units.  Single-device solvers with the Jacobi smoother (use_gauss_seidel = 0) whose fine nx is a multiple of 4.
+       units.  A cycle from an initial guess runs as x + M (b - A x) with the residual in fp32 (iterative refinement:
+       only corrections pass through binary16).  Single-device solvers with the Jacobi smoother (use_gauss_seidel = 0) whose fine nx is a multiple of 4.
        mgps_solve_pcg then preconditions with this cycle: tolerance and iteration counts against fp32 in DESIGN.md */
     int precision;
 } mgps_options;
@@ -354,6 +355,12 @@ int mgps_stencil_kernel(const mgps_solver *h, int level, int *kernel);
 int mgps_apply_vcycle_host(mgps_solver *h, float *x_host, const float *b_host, int use_initial_guess);
 int mgps_solve_pcg_host(mgps_solver *h, float *x_host, const float *b_host, double tolerance,
                         int max_iterations, int use_mg_preconditioner, mgps_pcg_stats *stats);
+/* The same with the reference's storage type on the host side (StoreReal = double, MG.h:14-15, Plug.h:18-19): the
+ * doubles cross PCIe as they are and are narrowed / widened on the device, so a Houdini caller hands over its
+ * UT_VoxelArray<double> contents without a host-side conversion pass. */
+int mgps_apply_vcycle_host_f64(mgps_solver *h, double *x_host, const double *b_host, int use_initial_guess);
+int mgps_solve_pcg_host_f64(mgps_solver *h, double *x_host, const double *b_host, double tolerance,
+                            int max_iterations, int use_mg_preconditioner, mgps_pcg_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,52 @@ def test_device_projection_is_divergence_free():
     total, mx, count = F.computeResultingDivergence(material, vel, cw, sv)
     assert after < 2e-4 * before and mx <= after * 1.0001 and count == (material == 1).sum().item()
     solver.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_one_call_projection_matches_the_pass_by_pass_pipeline(dtype):
+    """mgps_project_free_surface -- what the Houdini shim calls with flattened SIM fields (float, or the reference's
+    double: converted on the device) -- gives the same pressure, velocity and valid faces as the device passes driven
+    one by one, and leaves the liquid divergence-free (Plug.cpp:704-706)."""
+    import torch
+
+    from geometricmultigridpressuresolver_amd import fields as F
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=True)
+    # pass by pass (float32 on the device)
+    cw = [_dev(a, torch) for a in sc["cut_weights"]]
+    phi, sphi = _dev(sc["liquid_phi"], torch), _dev(sc["solid_phi"], torch)
+    vel = [_dev(a, torch) for a in sc["velocity"]]
+    sv = [_dev(a, torch) for a in sc["solid_velocity"]]
+    eshape, offset, levels = G.expanded_layout(SHAPE, 0, power_of_two=True)
+    material = F.buildMaterialCellLabels(phi, sphi, cw)
+    valid = F.buildValidFaces(material, cw)
+    labels, weights = F.buildMGDomain(material, cw, phi, valid, eshape, offset)
+    rhs = F.buildRHS(material, vel, cw, eshape, offset, sv)
+    solver = G.GeometricMultigridPoissonSolver(labels, weights, levels, True)
+    x = solver.new_grid()
+    st = solver.solveGeometricConjugateGradient(x, rhs, 1e-6, 200, True)
+    pressure = torch.zeros(SHAPE, dtype=torch.float32, device="cuda")
+    F.applySolutionToPressure(pressure, x, material, offset)
+    F.applyPressureGradient(vel, phi, pressure, valid, material)
+    solver.close()
+    # one call on host arrays
+    h = lambda a: np.array(a, dtype=dtype, order="C", copy=True)  # noqa: E731  (copies: the call updates velocity and pressure in place)
+    vel_h = [h(a) for a in sc["velocity"]]
+    p_h = np.zeros(SHAPE, dtype=dtype)
+    valid_h, info = F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel_h, p_h,
+                                           [h(a) for a in sc["solid_velocity"]], use_old_pressure=False, tolerance=1e-6, max_iterations=200)
+    assert info["iterations"] == st["iterations"] and info["mg_levels"] == levels and info["offset"] == offset and info["expanded"] == tuple(eshape)
+    assert info["liquid_cells"] == (material == 1).sum().item()
+    for a in range(3):
+        assert (valid_h[a] == valid[a].cpu().numpy()).all()
+        assert np.abs(vel_h[a] - vel[a].cpu().numpy()).max() < 1e-6 * max(1.0, np.abs(vel_h[a]).max())
+    assert np.abs(p_h - pressure.cpu().numpy()).max() < 1e-6 * np.abs(p_h).max()
+    before = np.abs(rhs.cpu().numpy()).max()
+    assert info["divergence_max"] < 2e-4 * before and info["residual_l2"] > 0
+    # warm start from the answer: CG leaves at its first test (CG.h:60-64)
+    vel2 = [h(a) for a in sc["velocity"]]
+    _, info2 = F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel2, p_h.copy(),
+                                      [h(a) for a in sc["solid_velocity"]], use_old_pressure=True, tolerance=1e-5, max_iterations=200)
+    assert info2["iterations"] == 0 and info2["outcome"] == 2

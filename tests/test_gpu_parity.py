@@ -497,6 +497,11 @@ def test_host_buffer_forms(domain_factory, oracle, torch_cuda):
     assert rel_l2(x, x_ref) < VCYCLE_TOL
     xs, st = gpu.solvePcgHost(np.zeros_like(b), b, 1e-5, 100, True)
     assert st["outcome"] == "converged"
+    # the double-precision host forms (the reference's StoreReal): same numbers as the float forms of the same values
+    x64 = gpu.applyVCycleHost(np.zeros(b.shape, dtype=np.float64), b.astype(np.float64), False)
+    assert x64.dtype == np.float64 and np.array_equal(x64.astype(np.float32), x)
+    xs64, st64 = gpu.solvePcgHost(np.zeros(b.shape, dtype=np.float64), b.astype(np.float64), 1e-5, 100, True)
+    assert st64["iterations"] == st["iterations"] and np.array_equal(xs64.astype(np.float32), xs)
 
 
 def test_distinct_handles_are_independent(domain_factory, torch_cuda):
