@@ -64,3 +64,33 @@ def test_host_setup_under_sanitizers():
     res = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-4000:]
     assert res.stdout.count(" ok: ") == 6 and "ERROR" not in res.stdout and "runtime error" not in res.stdout, res.stdout[-4000:]
+
+
+def test_flatten_roundtrip_and_cmake_configures_without_houdini(tmp_path):
+    """The HDK-free half of the Houdini shim (geometricmultigridpressuresolver_amd/host/): flattenGrid / unflattenGrid
+    round-trip on a 16^3-tiled stand-in for UT_VoxelArray (tests/cpp/flatten_roundtrip.cpp), and the top-level
+    CMakeLists.txt configures on a machine without Houdini -- the DOP target is skipped with a message, the library,
+    oracle and host-test targets remain (the reference's build fails without $HFS, /root/reference/CMakeLists.txt:10-14)."""
+    import shutil
+
+    out = os.path.join(ROOT, "tests", "cpp", "build", "flatten_roundtrip")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "geometricmultigridpressuresolver_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "flatten_roundtrip.cpp"), "-o", out, "-lpthread"])
+    res = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert res.returncode == 0 and "flatten round trip ok" in res.stdout, res.stdout
+    if shutil.which("cmake") is None:
+        pytest.skip("no cmake")
+    cfg = subprocess.run(["cmake", "-S", ROOT, "-B", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert cfg.returncode == 0, cfg.stdout[-3000:]
+    assert "Houdini not found: the DOP plugin target is skipped" in cfg.stdout
+    targets = subprocess.run(["cmake", "--build", str(tmp_path), "--target", "help"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    assert "mgps_build" in targets and "mgoracle" in targets and "HDK_GeometricFreeSurfacePressureSolver" not in targets
+    # the shim sources keep the reference's node surface: class, node type, description and the twelve parameter tokens
+    shim = open(os.path.join(ROOT, "geometricmultigridpressuresolver_amd", "host", "HDK_GeometricFreeSurfacePressureSolver.cpp")).read()
+    header = open(os.path.join(ROOT, "geometricmultigridpressuresolver_amd", "host", "HDK_GeometricFreeSurfacePressureSolver.h")).read()
+    for token in ('"HDK_GeometricFreeSurfacePressureSolver"', '"HDK Geometric Free Surface Pressure Solver"', "GAS_NAME_SURFACE", "GAS_NAME_VELOCITY",
+                  "GAS_NAME_COLLISION", "GAS_NAME_COLLISIONVELOCITY", '"cutCellWeights"', "GAS_NAME_PRESSURE", '"useOldPressure"', "GAS_NAME_DENSITY",
+                  '"validFaces"', "SIM_NAME_TOLERANCE", '"maxIterations"', '"useMGPreconditioner"', "initializeSIM", "mgps_project_free_surface"):
+        assert token in shim, token
+    assert "DECLARE_DATAFACTORY(HDK_GeometricFreeSurfacePressureSolver, GAS_SubSolver" in header and "solveGasSubclass" in header
