@@ -42,6 +42,8 @@ std::atomic<void *(*)(size_t)> gBigAlloc{nullptr};
 std::atomic<void (*)(void *)> gBigFree{nullptr};
 constexpr size_t kBigHeader = 64;  // keeps the block 64-byte aligned; word 0 = the function that releases it
 }  // namespace
+void (*gSetHandleError)(const mgps_solver *h, const char *msg) noexcept = nullptr;
+
 int apiException(const mgps_solver *h) noexcept
 {
     int code = MGPS_ERR_INTERNAL;
@@ -57,7 +59,7 @@ int apiException(const mgps_solver *h) noexcept
         text = buf;
     } catch (...) {
     }
-    if (h) setHandleError(h, text);
+    if (h && gSetHandleError) gSetHandleError(h, text);
     else {
         try {
             setLastGlobalError(text);

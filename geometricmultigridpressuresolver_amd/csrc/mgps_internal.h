@@ -191,7 +191,9 @@ const char *lastGlobalError();
 // MGPS_API_CATCH(handle or nullptr).  apiException classifies the exception in flight (std::bad_alloc -> MGPS_ERR_ALLOC,
 // anything else -> MGPS_ERR_INTERNAL) and leaves the text in the handle's (or the global) last-error slot.
 int apiException(const mgps_solver *h) noexcept;
-void setHandleError(const mgps_solver *h, const char *msg) noexcept;  // mgps_solver.hip (the struct is defined there)
+// how apiException stores a text in a handle: installed by the solver layer (the struct is defined in mgps_solver.hip;
+// the host-only half of the library links without it)
+extern void (*gSetHandleError)(const mgps_solver *h, const char *msg) noexcept;
 #define MGPS_API_CATCH(h) catch (...) { return ::mgps::apiException(h); }
 
 // ---- device side ------------------------------------------------------------------------------

@@ -119,13 +119,19 @@ struct mgps_solver {
     std::string lastError = "";
 };
 
-void mgps::setHandleError(const mgps_solver *h, const char *msg) noexcept
+namespace {
+void setHandleError(const mgps_solver *h, const char *msg) noexcept
 {
     try {
         const_cast<mgps_solver *>(h)->lastError = msg;
     } catch (...) {
     }
 }
+const bool handleErrorHookInstalled = [] {
+    mgps::gSetHandleError = setHandleError;
+    return true;
+}();
+}  // namespace
 
 namespace {
 
