@@ -40,10 +40,13 @@ def parse():
     ap.add_argument("--levels", type=int, default=0, help="multigrid levels (default: coarsest level 16^3)")
     ap.add_argument("--smoother", choices=["jacobi", "gs"], default="jacobi")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-frac512", action="store_true", help="skip the extra 512^3 smoother measurement (roofline.frac_512)")
     ap.add_argument("--force-slab", action="store_true", help="use the multi-GPU code path (RCCL transport, slab solver) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--check-oracle", action="store_true",
                     help="free_surface_pcg only: also solve with the fp64 CPU oracle and report the pressure-field difference")
+    ap.add_argument("--precision", choices=["fp32", "mixed"], default="fp32",
+                    help="mixed = BASELINE config 5's storage: the fine level's iterate and residual in binary16 (options.precision = 1)")
     ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
                     help="free_surface_pcg = BASELINE config 3 (single GPU): MG-PCG to 1e-5 on the free-surface pool")
     return ap.parse_args()
@@ -84,7 +87,7 @@ def cpu_baseline(n, levels, use_gs, budget_s):
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {
+    out = {
         "value": 1.0 / med,
         "unit": "V-cycles/sec",
         "cores": cores,
@@ -93,6 +96,25 @@ def cpu_baseline(n, levels, use_gs, budget_s):
         f"{'tiled GS' if use_gs else 'Jacobi'} smoother (median {med*1e3:.1f} ms)",
         "grid": sample_n,
     }
+    if sample_n != n:  # not like for like: say what the same port would do on the bench grid (work scales with the cell count)
+        out["same_grid"] = {"grid": n, "status": f"not run: the fp64 port needs about {13 * 8 * n**3 / 1e9:.0f} GB at {n}^3",
+                            "extrapolated_value": (1.0 / med) * (sample_n / n) ** 3}
+    # the optimised CPU variant BASELINE.md section 2 asks for next to the faithful port: the same code built with fp32 storage
+    # (half the bytes of every grid; labels stay 4 bytes), so that the GPU / CPU ratio is not read off the reference's doubles alone
+    try:
+        o32 = Oracle(f32=True)
+        s32 = o32.solver(lab.astype(np.int32), [a.astype(np.float32) for a in w], sample_levels, use_gs)
+        b32, x32 = b.astype(np.float32), np.zeros(b.shape, dtype=np.float32)
+        s32.apply_vcycle(x32, b32, False)
+        t32 = []
+        for _ in range(3):
+            t0 = time.time()
+            s32.apply_vcycle(x32, b32, True)
+            t32.append(time.time() - t0)
+        out["optimised_variant"] = {"value": 1.0 / sorted(t32)[1], "unit": "V-cycles/sec", "what": f"same port, fp32 storage, {sample_n}^3"}
+    except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
+        out["optimised_variant"] = {"error": str(e)}
+    return out
 
 
 def free_surface_pcg(args):
@@ -210,13 +232,15 @@ def main():
 
     # every rank: labels of the whole grid (1 byte per cell), weights and rhs of its own Z-slab only
     lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
+    opt = G.default_options()
+    opt.precision = 1 if args.precision == "mixed" else 0
     if slab_run:
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
 
         comm = RcclComm(device=local_rank)
-        solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank)
+        solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt)
     else:
-        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank)
+        solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank, options=opt)
     del w
     b = solver.to_device(D.random_rhs(lab, h, z0=z0, z1=z1))
     x = solver.new_grid()
@@ -238,6 +262,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     smooth_ms, smooth_groups = solver.profile_read()
+    stages = solver.stage_times()
     solver.profile_enable(False)
     if slab_run:  # the job is as slow as its slowest rank
         t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cuda")
@@ -263,12 +288,12 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "fp32" else "f32 arithmetic, f16 storage of the fine-level iterate and residual",
         "data": "synthetic",
         "config": {
             "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
             f"(3 band Jacobi + {'2 tiled-GS half sweeps' if use_gs else '1 damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
-            "useInitialGuess=true, fp32 storage",
+            "useInitialGuess=true, " + ("fp32 storage" if args.precision == "fp32" else "mixed precision (options.precision = 1)"),
             "grid": n,
             "levels": levels,
             "smoother": "tiled_gs" if use_gs else "jacobi",
@@ -276,6 +301,8 @@ def main():
             "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
+        # device time per cycle by stage, all levels (the reference's stopwatch scopes, MG.cpp:436-878; rank 0's figures)
+        "stages_ms_per_cycle": {k: v / max(stages["cycles"], 1) for k, v in stages.items() if k != "cycles"},
         "roofline": {
             "kernel": "fine-level tiled Gauss-Seidel sweep (tiledGSPureKernel + tiledGSMixedKernel, two colours)" if use_gs
             else "fine-level damped-Jacobi sweep (%s<OP_JACOBI>)" % ("stencilPlaneKernel" if n >= 256 and n * n * 4 > (2 << 20) else "stencilQuadKernel"),
@@ -295,16 +322,40 @@ def main():
     }
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
     # (profiles/r01_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["fine_jacobi_sweep"]
-        if str(n) in pmc and not use_gs and world == 1:
-            out["roofline"]["traffic"] = pmc[str(n)]["traffic_bytes"]
-            out["roofline"]["traffic_source"] = (
-                f"profiles/r01_pmc_hbm_traffic.json, {pmc[str(n)]['kernel']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                "per launch; L2<->fabric bytes incl. Infinity-Cache hits)")
-            out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * swept
-    except Exception:
-        pass
+    for pmc_file in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["fine_jacobi_sweep"]
+            if str(n) in pmc and not use_gs and world == 1 and args.precision == "fp32":
+                out["roofline"]["traffic"] = pmc[str(n)]["traffic_bytes"]
+                out["roofline"]["traffic_source"] = (
+                    f"profiles/{pmc_file}, {pmc[str(n)]['kernel']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                    "per launch; L2<->fabric bytes incl. Infinity-Cache hits)")
+                out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * swept
+                break
+        except Exception:
+            pass
+    # the north-star target is quoted on the 512^3 fine smoother: measure it beside the bench grid (N = 1 default runs)
+    if n != 512 and world == 1 and not args.force_slab and not args.no_frac512:
+        try:
+            solver.close()
+            del solver, x, b
+            torch.cuda.empty_cache()
+            lab5, w5, h5 = D.interior_cube(512, default_levels(512))
+            s5 = G.GeometricMultigridPoissonSolver(lab5, w5, default_levels(512), use_gs, device=local_rank, options=opt)
+            b5, x5 = s5.to_device(D.random_rhs(lab5, h5)), s5.new_grid()
+            for _ in range(5):
+                s5.applyVCycle(x5, b5, True)
+            s5.profile_enable(True)
+            for _ in range(20):
+                s5.applyVCycle(x5, b5, True)
+            ms5, groups5 = s5.profile_read()
+            swept5 = s5.swept_cells(0)[1 if use_gs else 0]
+            t5 = ms5 * 1e-3 / max(groups5, 1)
+            out["roofline"]["frac_512"] = SMOOTHER_BYTES_PER_CELL * swept5 / t5 / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["ms_per_launch_512"] = t5 * 1e3
+            s5.close()
+        except Exception as e:
+            out["roofline"]["frac_512_error"] = str(e)
     if not args.no_cpu and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds)
     sys.stdout.flush()

@@ -116,6 +116,15 @@ struct mgps_solver {
     std::vector<hipEvent_t> profEvents;
     size_t profUsed = 0;
     int profSweeps = 0;  // full-domain sweeps the event pairs cover (a Gauss-Seidel sweep is two pairs: one per colour)
+    // per-stage timing of the V-cycle (the reference's UT_StopWatch scopes, MG.cpp:436-878): event pairs per (stage, level),
+    // read back at the end of the cycle; on while options.print_stats or mgps_profile_enable
+    struct StageMark {
+        int stage, level;
+    };
+    std::vector<StageMark> stageMarks;
+    std::vector<hipEvent_t> stageEvents;  // 2 per mark
+    double stageMs[6] = {0, 0, 0, 0, 0, 0};
+    int stageCycles = 0;
     std::string lastError = "";
 };
 
@@ -270,6 +279,7 @@ void freeAll(mgps_solver *h)
     }
     for (void *p : h->userGrids) (void)hipFree(p);
     for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->stageEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
     delete h;
 }
@@ -382,6 +392,55 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first,
     return MGPS_OK;
 }
 
+// ---- per-stage timing (doPrintStats, MG.h:24 / MG.cpp:436-878) --------------------------------------------------------
+enum Stage { ST_BAND = 0, ST_SMOOTH = 1, ST_RESIDUAL = 2, ST_RESTRICT = 3, ST_COARSE = 4, ST_PROLONG = 5 };
+const char *const kStageNames[6] = {"Boundary smoother time", "Smoother time", "Compute residual time", "Downsample time", "Direct solve time",
+                                    "Upsample and add time"};
+inline bool stageTimingOn(const mgps_solver *h) { return (h->opt.print_stats || h->profiling) && !h->tailOfSlabRun; }
+void stageFlush(mgps_solver *h);
+// RAII scope: records an event pair around the launches of one stage of one level
+struct StageScope {
+    mgps_solver *h;
+    bool on;
+    size_t slot = 0;
+    StageScope(mgps_solver *hh, int stage, int level) : h(hh), on(stageTimingOn(hh))
+    {
+        if (!on) return;
+        if (h->stageMarks.size() >= 65536) stageFlush(h);  // nobody reads them: fold into the totals
+        slot = h->stageMarks.size();
+        while (h->stageEvents.size() < 2 * (slot + 1)) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) {
+                on = false;
+                return;
+            }
+            h->stageEvents.push_back(e);
+        }
+        h->stageMarks.push_back({stage, level});
+        (void)hipEventRecord(h->stageEvents[2 * slot], h->stream);
+    }
+    ~StageScope()
+    {
+        if (on) (void)hipEventRecord(h->stageEvents[2 * slot + 1], h->stream);
+    }
+};
+// end of a cycle: read the marks back (synchronises the stream), print them in the reference's wording when print_stats is
+// set, add them to the per-stage totals that mgps_stage_times returns
+void stageFlush(mgps_solver *h)
+{
+    if (h->stageMarks.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (size_t q = 0; q < h->stageMarks.size(); ++q) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->stageEvents[2 * q], h->stageEvents[2 * q + 1]) != hipSuccess) continue;
+        h->stageMs[h->stageMarks[q].stage] += ms;
+        if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
+            std::printf("      level %d  %s: %.4f ms\n", h->stageMarks[q].level, kStageNames[h->stageMarks[q].stage], double(ms));
+    }
+    h->stageMarks.clear();
+    ++h->stageCycles;
+}
+
 // measurement hook: an event pair strictly around the launches of a fine-level full-domain sweep (after its ghost
 // exchange, so that on slab runs the figure is kernel time, not kernel + communication time)
 int profMark(mgps_solver *h, bool begin)
@@ -426,12 +485,16 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
 {
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
-    MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
+    {
+        StageScope scope(h, ST_BAND, l);
+        MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
+    }
     // after the band passes only band cells are stale across the cut -- unless there were none
     const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
     const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
     for (int rep = 0; rep < reps; ++rep) {
+        StageScope scope(h, ST_SMOOTH, l);
         const GhostMode before = rep == 0 ? afterBands : GHOST_FULL;  // a sweep rewrote everything
         const bool d = dot && rep == reps - 1;  // <x, b> of the stroke's result: the last sweep's values
         if (h->useGS) {
@@ -456,6 +519,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         }
         if (timed) ++h->profSweeps;
     }
+    StageScope scope(h, ST_BAND, l);
     MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot));  // the full-domain smoother rewrote everything
     return MGPS_OK;
 }
@@ -535,27 +599,38 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
-            MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
-                                                  : h->opt.band_iterations > 0 ? GHOST_BAND
-                                                                               : GHOST_FULL));
-            MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
+            {
+                StageScope scope(h, ST_RESIDUAL, l);
+                MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
+                                                      : h->opt.band_iterations > 0 ? GHOST_BAND
+                                                                                   : GHOST_FULL));
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
+            }
+            StageScope scope(h, ST_RESTRICT, l);
             MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
         }
         DevLevel &B = h->lv[nsmooth];
-        if (h->dist) MGPS_TRY(collapsedTail(h));
-        else MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, B.x, B.b, h->cvec));  // MG.cpp:669-692
+        {
+            StageScope scope(h, ST_COARSE, nsmooth);
+            if (h->dist) MGPS_TRY(collapsedTail(h));
+            else MGPS_LAUNCH(h, launchCoarseSolve(h->stream, h->cn, h->cinv, h->ccells, B.x, B.b, h->cvec));  // MG.cpp:669-692
+        }
         cur[nsmooth] = B.x;
         for (int l = nsmooth - 1; l >= 0; --l) {  // MG.cpp:695-784 (coarser), 787-880 (fine)
             DevLevel &F = h->lv[l];
-            MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
-            MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
+            {
+                StageScope scope(h, ST_PROLONG, l);
+                MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
+                MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
+            }
             MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false, false, h->gatherDot && l == 0));
         }
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
         MGPS_HIP(h, hipMemcpyAsync(x, cur[0], h->lv[0].d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (h->gatherDot) MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, h->dotTarget ? h->dotTarget : h->resultDev));
+    if (h->opt.print_stats) stageFlush(h);  // (profiling without print_stats: the marks pile up until mgps_stage_times reads them)
     return MGPS_OK;
 }
 
@@ -1923,6 +1998,9 @@ try {
     h->profiling = enable != 0;
     h->profUsed = 0;
     h->profSweeps = 0;
+    h->stageMarks.clear();
+    for (double &ms : h->stageMs) ms = 0;
+    h->stageCycles = 0;
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)
@@ -1953,6 +2031,24 @@ try {
     const DevLevel &L = h->lv[level];
     *stencil_cells = (long long)stencilSweptCells(L.g);
     *gs_cells = (long long)(L.npure[0] + L.npure[1] + L.nmixed[0] + L.nmixed[1]) * 4096;
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
+
+int mgps_stage_times(mgps_solver *h, double out_ms[6], int *cycles)
+try {
+    MGPS_TRY(checkLevel(h, 0, "mgps_stage_times"));
+    if (!out_ms) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_stage_times: NULL pointer");
+    stageFlush(h);
+    if (h->tail) {  // (rank 0 of a slab run: the collapsed tail is inside the coarse-solve stage)
+        h->tail->stageMarks.clear();
+    }
+    for (int q = 0; q < 6; ++q) {
+        out_ms[q] = h->stageMs[q];
+        h->stageMs[q] = 0;
+    }
+    if (cycles) *cycles = h->stageCycles;
+    h->stageCycles = 0;
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)

@@ -352,6 +352,16 @@ class GeometricMultigridPoissonSolver:
         check(lib().mgps_profile_read(self.h, C.byref(ms), C.byref(n)), self.h)
         return ms.value, n.value
 
+    def stage_times(self):
+        """{stage: ms} summed over levels and cycles since the last call (mgps_stage_times), plus 'cycles'"""
+        ms = (C.c_double * 6)()
+        n = C.c_int()
+        check(lib().mgps_stage_times(self.h, ms, C.byref(n)), self.h)
+        names = ("boundary_smoother", "smoother", "residual", "downsample", "direct_solve", "upsample_add")
+        out = {k: ms[i] for i, k in enumerate(names)}
+        out["cycles"] = n.value
+        return out
+
     def swept_cells(self, level=0):
         """(stencil sweep cells, tiled-GS sweep cells) one full-domain pass of `level` visits"""
         a, b = C.c_longlong(), C.c_longlong()

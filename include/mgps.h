@@ -341,6 +341,13 @@ int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, siz
  * mgps_profile_read synchronises, returns the accumulated device time and the number of full sweeps
  * (a Gauss-Seidel sweep = its two colours) since the last read, and resets both. */
 int mgps_profile_enable(mgps_solver *h, int enable);
+/* Per-stage device time of the V-cycles run since the last call (or since mgps_profile_enable), summed over levels, the
+ * reference's stopwatch scopes (MG.cpp:436-878): [0] boundary smoother, [1] smoother, [2] compute residual, [3] downsample,
+ * [4] direct solve (slab runs: gather + collapsed tail + scatter), [5] upsample-and-add; *cycles = marks flushed.  Recorded
+ * while mgps_profile_enable is on or options.print_stats is set (print_stats also prints every stage of every level per
+ * cycle, as doPrintStats does).  Synchronises the stream.  Each stage is bracketed by an event pair, so on small levels the
+ * figures include the few microseconds between dependent launches. */
+int mgps_stage_times(mgps_solver *h, double out_ms[6], int *cycles);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
 /* Cells one full-domain sweep of `level` visits: the kernels skip 1024-cell chunks / 256x16xzc blocks /
  * 16^3 tiles without active cells (the reference skips constant tiles the same way, Ops.h:300-312);
