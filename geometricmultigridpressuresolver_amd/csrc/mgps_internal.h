@@ -346,6 +346,7 @@ int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double
 int launchWiden(void *stream, double *dst, const float *src, size_t n);
 int launchNarrow(void *stream, float *dst, const double *src, size_t n);
 int launchZero(void *stream, float *a, size_t count);
+int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)
 // ghostPlanes: also the plane below and the plane above the grid (slab runs)
 int launchZeroActive(void *stream, const GridP &g, float *a, bool ghostPlanes = false);

@@ -2098,6 +2098,20 @@ int launchNarrow(void *stream, float *dst, const double *src, size_t n)
     return int(hipGetLastError());
 }
 
+// a[c] = 0 wherever the cell is not active (whole grid): restores the "exactly 0 outside active cells" invariant on a
+// caller grid that carries values in air / solid cells
+__global__ __launch_bounds__(256) void zeroInactiveKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ a)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < n && !activeLabel(lab[c])) a[c] = 0.f;
+}
+int launchZeroInactive(void *stream, const GridP &g, float *a)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    zeroInactiveKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, a);
+    return int(hipGetLastError());
+}
+
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroActive(void *stream, const GridP &g, float *a, bool ghostPlanes)
 {

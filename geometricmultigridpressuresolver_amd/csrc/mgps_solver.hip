@@ -590,8 +590,12 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom));
     if (hasBottom) {
         const float *rhs = b;
+        // options.interrupt is also polled once per level and stroke of a single-device cycle (the reference polls inside
+        // every operator loop, e.g. Ops.h:319); slab runs poll between CG iterations only, where the ranks can agree
+        auto stopRequested = [&] { return !h->dist && !h->tailOfSlabRun && h->opt.interrupt && h->opt.interrupt(h->opt.interrupt_user); };
         for (int l = 0; l < nsmooth; ++l) {  // MG.cpp:519-553 (fine), 557-667 (coarser)
             DevLevel &F = h->lv[l], &C = h->lv[l + 1];
+            if (l > 0 && stopRequested()) return failH(h, MGPS_ERR_INTERRUPTED, "mgps_apply_vcycle: interrupted");
             if (l > 0) {
                 cur[l] = F.x;
                 other[l] = F.tmp;
@@ -619,6 +623,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
         cur[nsmooth] = B.x;
         for (int l = nsmooth - 1; l >= 0; --l) {  // MG.cpp:695-784 (coarser), 787-880 (fine)
             DevLevel &F = h->lv[l];
+            if (stopRequested()) return failH(h, MGPS_ERR_INTERRUPTED, "mgps_apply_vcycle: interrupted");
             {
                 StageScope scope(h, ST_PROLONG, l);
                 MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
@@ -794,6 +799,31 @@ int exchangeGhosts64(mgps_solver *h, double *a)
     return MGPS_OK;
 }
 
+int interruptRequested(mgps_solver *h, bool *stop);
+
+// device time of a solve: an event pair whose lifetime is the scope's (every early return of pcg / pcg64 passes through it)
+struct SolveClock {
+    mgps_solver *h;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = false;
+    explicit SolveClock(mgps_solver *hh) : h(hh)
+    {
+        ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess;
+    }
+    double stop()
+    {
+        float ms = 0.f;
+        if (ok && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        return ms;
+    }
+    ~SolveClock()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        h->dotTarget = nullptr;
+    }
+};
+
 // MG-PCG with the CG vectors in fp64 (options.pcg_fp64_vectors): CG.h:18-207 step by step like pcg() below; the
 // preconditioner is the same fp32 V-cycle (or diagonal) applied to float(r), x and b are fp32 at the boundary
 int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
@@ -810,19 +840,11 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     h->dotTarget = nullptr;  // (the gathered <z, r> goes to resultDev here)
     double *x64 = h->cg64[0], *r64 = h->cg64[1], *p64 = h->cg64[2], *t64 = h->cg64[3];
     float *r32 = h->pcg[0], *z = h->pcg[2];
-    hipEvent_t e0, e1;
-    MGPS_HIP(h, hipEventCreate(&e0));
-    MGPS_HIP(h, hipEventCreate(&e1));
-    MGPS_HIP(h, hipEventRecord(e0, h->stream));
+    SolveClock clock(h);  // (destroys its events and resets h->dotTarget on every way out)
+    if (!clock.ok) return failH(h, MGPS_ERR_HIP, "hipEventCreate failed");
     auto finish = [&](int outcome) {
         st->outcome = outcome;
-        (void)hipEventRecord(e1, h->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        st->solve_ms = ms;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        st->solve_ms = clock.stop();
         return MGPS_OK;
     };
     bool gathered = false;
@@ -862,7 +884,9 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     int it = 0;
     bool converged = false;
     for (; it < maxIt; ++it) {
-        if (h->opt.interrupt && h->opt.interrupt(h->opt.interrupt_user)) {
+        bool stop = false;
+        MGPS_TRY(interruptRequested(h, &stop));
+        if (stop) {
             (void)launchNarrow(h->stream, x, x64, n);  // what the iterations reached so far, as the fp32 loop leaves it
             finish(MGPS_PCG_MAX_ITERATIONS);
             st->iterations = it;
@@ -896,6 +920,18 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
     return finish(converged ? MGPS_PCG_CONVERGED : MGPS_PCG_MAX_ITERATIONS);
 }
 
+// options.interrupt, polled once per CG iteration; in a slab run the ranks agree (max over ranks) so that nobody is left
+// waiting in an exchange for a neighbour that stopped
+int interruptRequested(mgps_solver *h, bool *stop)
+{
+    *stop = false;
+    if (!h->opt.interrupt) return MGPS_OK;
+    double flag = h->opt.interrupt(h->opt.interrupt_user) ? 1.0 : 0.0;
+    if (h->dist) MGPS_COMM(h, h->comm.allreduce(h->comm.user, &flag, 1, 1));
+    *stop = flag != 0.0;
+    return MGPS_OK;
+}
+
 int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
 {
     DevLevel &F = h->lv[0];
@@ -910,19 +946,11 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     std::memset(st, 0, sizeof(*st));
     MGPS_TRY(ensurePcgGrids(h, !useMG));
     float *r = h->pcg[0], *p = h->pcg[1], *z = h->pcg[2], *t = h->pcg[3];
-    hipEvent_t e0, e1;
-    MGPS_HIP(h, hipEventCreate(&e0));
-    MGPS_HIP(h, hipEventCreate(&e1));
-    MGPS_HIP(h, hipEventRecord(e0, h->stream));
+    SolveClock clock(h);  // (destroys its events and resets h->dotTarget on every way out)
+    if (!clock.ok) return failH(h, MGPS_ERR_HIP, "hipEventCreate failed");
     auto finish = [&](int outcome) {
         st->outcome = outcome;
-        (void)hipEventRecord(e1, h->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        st->solve_ms = ms;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        st->solve_ms = clock.stop();
         return MGPS_OK;
     };
     // dst = M src; gathered: <dst, src> is already in h->resultDev (a by-product of the V-cycle's last stroke)
@@ -994,7 +1022,9 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     int it = 0;
     bool converged = false;
     for (; it < maxIt; ++it) {
-        if (h->opt.interrupt && h->opt.interrupt(h->opt.interrupt_user)) {
+        bool stop = false;
+        MGPS_TRY(interruptRequested(h, &stop));
+        if (stop) {
             finish(MGPS_PCG_MAX_ITERATIONS);
             st->iterations = it;
             return failH(h, MGPS_ERR_INTERRUPTED, "mgps_solve_pcg: interrupted");
@@ -1697,19 +1727,30 @@ try {
     }
     int rc = commonDeviceState(h, false);
     if (rc != MGPS_OK) return bail(rc);
+    int tailRc = MGPS_OK;
     if (rank == 0) {  // the collapsed tail: levels D .. L-1 on the whole grid, unit weights
-        const HostLevel &C = hier->lv[D];
-        mgps_hierarchy *tailHier = nullptr;
-        rc = hierarchyCreate(&tailHier, C.d.nx, C.d.ny, C.d.nz, C.labels.data(), hier->levels - D, &o, true, false);
-        if (rc != MGPS_OK) return bail(failH(h, rc, std::string("collapsed tail hierarchy: ") + lastGlobalError()));
-        rc = createWhole(&h->tail, tailHier, nullptr, nullptr, nullptr, h->useGS, o, device, true);
-        if (rc != MGPS_OK) return bail(failH(h, rc, std::string("collapsed tail: ") + lastGlobalError()));
-        rc = gridAlloc(h->tail, &h->tailX, C.d);
-        if (rc == MGPS_OK) rc = gridAlloc(h->tail, &h->tailB, C.d);
-        if (rc != MGPS_OK) return bail(rc);
-        h->tail->userGrids.push_back(h->tailX - size_t(C.d.nx) * C.d.ny);
-        h->tail->userGrids.push_back(h->tailB - size_t(C.d.nx) * C.d.ny);
-        if (hipDeviceSynchronize() != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, "device synchronize failed"));
+        tailRc = [&]() -> int {
+            const HostLevel &C = hier->lv[D];
+            mgps_hierarchy *tailHier = nullptr;
+            int trc = hierarchyCreate(&tailHier, C.d.nx, C.d.ny, C.d.nz, C.labels.data(), hier->levels - D, &o, true, false);
+            if (trc != MGPS_OK) return failH(h, trc, std::string("collapsed tail hierarchy: ") + lastGlobalError());
+            trc = createWhole(&h->tail, tailHier, nullptr, nullptr, nullptr, h->useGS, o, device, true);
+            if (trc != MGPS_OK) return failH(h, trc, std::string("collapsed tail: ") + lastGlobalError());
+            trc = gridAlloc(h->tail, &h->tailX, C.d);
+            if (trc == MGPS_OK) trc = gridAlloc(h->tail, &h->tailB, C.d);
+            if (trc != MGPS_OK) return trc;
+            h->tail->userGrids.push_back(h->tailX - size_t(C.d.nx) * C.d.ny);
+            h->tail->userGrids.push_back(h->tailB - size_t(C.d.nx) * C.d.ny);
+            if (hipDeviceSynchronize() != hipSuccess) return failH(h, MGPS_ERR_HIP, "device synchronize failed");
+            return MGPS_OK;
+        }();
+    }
+    // every rank leaves with the same verdict: rank 0 failing alone would leave the others waiting in the first gather
+    double failed = tailRc != MGPS_OK ? double(tailRc) : 0.0;
+    if (h->comm.allreduce(h->comm.user, &failed, 1, 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+    if (failed != 0.0) {
+        if (tailRc == MGPS_OK) failH(h, int(failed), "the collapsed tail could not be built on rank 0 (status " + std::to_string(int(failed)) + ")");
+        return bail(tailRc != MGPS_OK ? tailRc : int(failed));
     }
     *out = h;
     return MGPS_OK;
@@ -1977,6 +2018,15 @@ try {
     MGPS_TRY(checkLevel(h, level, "mgps_scale_vector"));
     if (!v_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_scale_vector: NULL grid");
     MGPS_LAUNCH(h, launchScale(h->stream, h->lv[level].g, v_dev, float(scale)));
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
+
+int mgps_zero_inactive(mgps_solver *h, int level, float *grid_dev)
+try {
+    MGPS_TRY(checkLevel(h, level, "mgps_zero_inactive"));
+    if (!grid_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_zero_inactive: NULL grid");
+    MGPS_LAUNCH(h, launchZeroInactive(h->stream, h->lv[level].g, grid_dev));
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)

@@ -325,6 +325,10 @@ class GeometricMultigridPoissonSolver:
     def scaleVector(self, vector, scale, level=0):
         check(lib().mgps_scale_vector(self.h, level, self._g(vector, level), C.c_double(scale)), self.h)
 
+    def zeroInactive(self, grid, level=0):
+        """grid = 0 outside active cells (the invariant every operator relies on; see mgps_zero_inactive)"""
+        check(lib().mgps_zero_inactive(self.h, level, self._g(grid, level)), self.h)
+
     # -- CG.h ------------------------------------------------------------------------------------
     def solveGeometricConjugateGradient(self, solution, rhs, tolerance=1e-5, max_iterations=2500, use_mg_preconditioner=True):
         st = PcgStats()

@@ -88,7 +88,10 @@ typedef struct mgps_options {
                                true one instead of flooring at eps * cond (3e-3 at 512^3, 2e-2 at 1024^3 on the
                                free-surface case), for +17..36 % solve time.  Slab runs exchange the ghost planes of
                                these vectors as doubles */
-    int (*interrupt)(void *user); /* polled between PCG iterations; non-zero stops (UT_Interrupt::opInterrupt) */
+    int (*interrupt)(void *user); /* non-zero stops the call with MGPS_ERR_INTERRUPTED (UT_Interrupt::opInterrupt, which the
+                                     reference polls in every operator loop, e.g. Ops.h:319).  Polled before every PCG
+                                     iteration and, on single-device solvers, before every level of both strokes of a
+                                     V-cycle (host side: the device runs at most one cycle behind) */
     void *interrupt_user;
     /* full-domain smoother sweeps per stroke.  The reference hard-wires one (MG.cpp:466-486 down, 740-757 up): one
        damped-Jacobi sweep, or the two tile colours of Gauss-Seidel once each.  pre_sweeps applies to the down-stroke of
@@ -254,6 +257,13 @@ int mgps_add_to_vector(mgps_solver *h, int level, float *dst_dev, const float *s
 int mgps_add_vectors(mgps_solver *h, int level, float *dst_dev, const float *a_dev,
                      const float *scaled_dev, double scale);
 int mgps_scale_vector(mgps_solver *h, int level, float *v_dev, double scale);
+
+/* The operators sum neighbour values without looking at the neighbours' labels wherever the weights allow it (INTERIOR
+ * and unit-weight BOUNDARY cells): they rely on the invariant stated at the top -- every grid handed in holds exactly 0
+ * outside active cells (the reference asserts the same of its grids, Ops.h:821-823, 950-953, and builds them that way,
+ * Plug.cpp:380, 406).  A caller whose field carries values in air or solid cells (a pressure field used as the initial
+ * guess, say) restores it with this call first: grid = 0 on every cell of `level` that is not INTERIOR / BOUNDARY. */
+int mgps_zero_inactive(mgps_solver *h, int level, float *grid_dev);
 
 /* solveGeometricConjugateGradient (CG.h:18-207) with A = applyPoissonMatrix and
  * M^-1 = applyVCycle (use_mg_preconditioner != 0; Plug.cpp:461-484) or the diagonal

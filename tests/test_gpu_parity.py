@@ -381,9 +381,10 @@ def test_pcg_fp64_vectors(kind, g, use_mg, use_gs, domain_factory, oracle, torch
 
 @pytest.mark.parametrize("fp64", [0, 1])
 def test_pcg_interrupt_callback(fp64, domain_factory, torch_cuda):
-    """options.interrupt (the reference polls UT_Interrupt::opInterrupt in every loop, e.g. Ops.h:319): polled once
-    per CG iteration; a non-zero answer stops the solve with MGPS_ERR_INTERRUPTED and leaves the iterate reached so
-    far in x.  A callback that never fires changes nothing."""
+    """options.interrupt (the reference polls UT_Interrupt::opInterrupt in every loop, e.g. Ops.h:319): polled before
+    every CG iteration and before every level of both strokes of the preconditioning V-cycle; a non-zero answer stops
+    the solve with MGPS_ERR_INTERRUPTED and leaves the iterate reached so far in x.  A callback that never fires changes
+    nothing."""
     import ctypes as C
 
     import geometricmultigridpressuresolver_amd as G
@@ -402,7 +403,7 @@ def test_pcg_interrupt_callback(fp64, domain_factory, torch_cuda):
         return CB(cb)
 
     results = {}
-    for stop_after in (None, 3):
+    for stop_after in (None, 25):  # 25 polls: about three iterations in
         del polls[:]
         cb = make(stop_after)
         opt = G.default_options()
@@ -412,13 +413,13 @@ def test_pcg_interrupt_callback(fp64, domain_factory, torch_cuda):
         x = s.new_grid()
         if stop_after is None:
             st = s.solveGeometricConjugateGradient(x, s.to_device(b), 1e-6, 200, True)
-            assert st["outcome"] == "converged" and len(polls) == st["iterations"] + 1
+            assert st["outcome"] == "converged" and len(polls) > 3 * (st["iterations"] + 1)  # per iteration + per level and stroke
             results["full"] = st["iterations"]
         else:
             with pytest.raises(G.MgpsError) as err:
                 s.solveGeometricConjugateGradient(x, s.to_device(b), 1e-6, 200, True)
             assert err.value.status == 9 and len(polls) == stop_after + 1  # MGPS_ERR_INTERRUPTED
-            assert float(x.abs().max()) > 0  # three iterations' worth of solution is there
+            assert float(x.abs().max()) > 0  # the iterations' worth of solution is there
         s.close()
     assert results["full"] > 3
 
@@ -486,6 +487,24 @@ def test_pcg_early_outs(domain_factory, oracle, torch_cuda):
     assert st["outcome"] == "converged"
     st2 = gpu.solveGeometricConjugateGradient(xd, bd, 1e-4, 100, True)
     assert st2["outcome"] == "already_converged" and st2["iterations"] == 0  # CG.h:60-64
+
+
+def test_zero_inactive_restores_the_invariant(domain_factory, oracle, torch_cuda):
+    """An initial guess that carries values in air / solid cells changes the operator of the cells next to them (the
+    sweeps sum neighbours unmasked, relying on the zero invariant of Ops.h:821-823); mgps_zero_inactive restores the
+    invariant and the solve then equals the one from the clean guess."""
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    gpu, orc, lab, lab32, w64, off, lev, dx = _setup("solid", 48, True, domain_factory, oracle)
+    b = gpu.to_device(D.random_rhs(lab, dx))
+    guess = _rand_active(lab, 12)
+    dirty = guess + 5.0 * (~D.active_mask(lab))
+    xc, xd = gpu.to_device(guess), gpu.to_device(dirty)
+    gpu.zeroInactive(xd)
+    assert np.array_equal(xd.cpu().numpy(), xc.cpu().numpy())
+    gpu.applyVCycle(xc, b, True)
+    gpu.applyVCycle(xd, b, True)
+    assert np.array_equal(xd.cpu().numpy(), xc.cpu().numpy())
 
 
 def test_host_buffer_forms(domain_factory, oracle, torch_cuda):
