@@ -262,6 +262,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     smooth_ms, smooth_groups = solver.profile_read()
+    solver.profile_enable(2)  # stage breakdown: a few extra cycles outside the timed region (its event records cost a few %)
+    for _ in range(min(args.steps, 5)):
+        solver.applyVCycle(x, b, True)
     stages = solver.stage_times()
     solver.profile_enable(False)
     if slab_run:  # the job is as slow as its slowest rank

@@ -113,6 +113,7 @@ struct mgps_solver {
     float *tailX = nullptr, *tailB = nullptr;
     // measurement hooks: event pairs around the fine-level full-domain smoother
     bool profiling = false;
+    bool stageProfiling = false;  // mgps_profile_enable(h, 2): also an event pair around every stage of every level
     std::vector<hipEvent_t> profEvents;
     size_t profUsed = 0;
     int profSweeps = 0;  // full-domain sweeps the event pairs cover (a Gauss-Seidel sweep is two pairs: one per colour)
@@ -396,7 +397,7 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first,
 enum Stage { ST_BAND = 0, ST_SMOOTH = 1, ST_RESIDUAL = 2, ST_RESTRICT = 3, ST_COARSE = 4, ST_PROLONG = 5 };
 const char *const kStageNames[6] = {"Boundary smoother time", "Smoother time", "Compute residual time", "Downsample time", "Direct solve time",
                                     "Upsample and add time"};
-inline bool stageTimingOn(const mgps_solver *h) { return (h->opt.print_stats || h->profiling) && !h->tailOfSlabRun; }
+inline bool stageTimingOn(const mgps_solver *h) { return (h->opt.print_stats || h->stageProfiling) && !h->tailOfSlabRun; }
 void stageFlush(mgps_solver *h);
 // RAII scope: records an event pair around the launches of one stage of one level
 struct StageScope {
@@ -438,7 +439,6 @@ void stageFlush(mgps_solver *h)
             std::printf("      level %d  %s: %.4f ms\n", h->stageMarks[q].level, kStageNames[h->stageMarks[q].stage], double(ms));
     }
     h->stageMarks.clear();
-    ++h->stageCycles;
 }
 
 // measurement hook: an event pair strictly around the launches of a fine-level full-domain sweep (after its ghost
@@ -635,6 +635,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
         MGPS_HIP(h, hipMemcpyAsync(x, cur[0], h->lv[0].d.cells() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (h->gatherDot) MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, h->dotTarget ? h->dotTarget : h->resultDev));
+    if (stageTimingOn(h)) ++h->stageCycles;
     if (h->opt.print_stats) stageFlush(h);  // (profiling without print_stats: the marks pile up until mgps_stage_times reads them)
     return MGPS_OK;
 }
@@ -904,7 +905,14 @@ int pcg64(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool 
             converged = true;
             break;
         }
-        MGPS_TRY(precondition());  // CG.h:168
+        if (const int prc = precondition()) {  // CG.h:168
+            if (prc == MGPS_ERR_INTERRUPTED) {  // (polled inside the V-cycle): hand back what the iterations reached
+                (void)launchNarrow(h->stream, x, x64, n);
+                finish(MGPS_PCG_MAX_ITERATIONS);
+                st->iterations = it;
+            }
+            return prc;
+        }
         const double absOld = absNew;
         MGPS_TRY(zDotR(&absNew));  // CG.h:180
         MGPS_LAUNCH(h, launchXpay64(h->stream, F.g, p64, z, absNew / absOld, 0));  // CG.h:191
@@ -2046,6 +2054,7 @@ try {
     MGPS_TRY(checkLevel(h, 0, "mgps_profile_enable"));
     MGPS_HIP(h, hipStreamSynchronize(h->stream));
     h->profiling = enable != 0;
+    h->stageProfiling = enable >= 2;
     h->profUsed = 0;
     h->profSweeps = 0;
     h->stageMarks.clear();

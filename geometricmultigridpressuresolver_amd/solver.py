@@ -349,7 +349,8 @@ class GeometricMultigridPoissonSolver:
 
     # -- measurement hooks ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        check(lib().mgps_profile_enable(self.h, int(bool(on))), self.h)
+        """on: False / True (fine-smoother events) / 2 (also per-stage events, see stage_times)"""
+        check(lib().mgps_profile_enable(self.h, int(on)), self.h)
 
     def profile_read(self):
         ms, n = C.c_double(), C.c_int()

@@ -350,12 +350,13 @@ int mgps_copy_to_device(mgps_solver *h, void *dst_dev, const void *src_host, siz
  * on slab runs the ghost exchange in front of a sweep stays outside the bracket.
  * mgps_profile_read synchronises, returns the accumulated device time and the number of full sweeps
  * (a Gauss-Seidel sweep = its two colours) since the last read, and resets both. */
-int mgps_profile_enable(mgps_solver *h, int enable);
+int mgps_profile_enable(mgps_solver *h, int enable);  /* 0 off, 1 fine-smoother events, 2 = 1 + per-stage events */
 /* Per-stage device time of the V-cycles run since the last call (or since mgps_profile_enable), summed over levels, the
  * reference's stopwatch scopes (MG.cpp:436-878): [0] boundary smoother, [1] smoother, [2] compute residual, [3] downsample,
- * [4] direct solve (slab runs: gather + collapsed tail + scatter), [5] upsample-and-add; *cycles = marks flushed.  Recorded
- * while mgps_profile_enable is on or options.print_stats is set (print_stats also prints every stage of every level per
- * cycle, as doPrintStats does).  Synchronises the stream.  Each stage is bracketed by an event pair, so on small levels the
+ * [4] direct solve (slab runs: gather + collapsed tail + scatter), [5] upsample-and-add; *cycles = cycles they cover.  Recorded
+ * after mgps_profile_enable(h, 2) or while options.print_stats is set (print_stats also prints every stage of every level
+ * per cycle, as doPrintStats does); about 160 event records per cycle, which cost a cycle a few percent -- keep it out of
+ * timed regions.  Synchronises the stream.  Each stage is bracketed by an event pair, so on small levels the
  * figures include the few microseconds between dependent launches. */
 int mgps_stage_times(mgps_solver *h, double out_ms[6], int *cycles);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
