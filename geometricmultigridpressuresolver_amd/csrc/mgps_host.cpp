@@ -580,7 +580,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         const int planes[4] = {z0, z0 - 1, z1 - 1, z1};
         for (int q = 0; q < 4; ++q) {
             L.bandPlane[q].clear();
-            if (planes[q] < 0 || planes[q] >= gd.nz) continue;
+            if (planes[q] < 0 || planes[q] >= gd.nz || (z0 == 0 && z1 == gd.nz)) continue;  // (a whole grid exchanges nothing)
             const size_t plo = size_t(planes[q]) * plane, phi = plo + plane;
             for (int32_t gcI : G.band) {
                 const size_t gc = size_t(gcI);
