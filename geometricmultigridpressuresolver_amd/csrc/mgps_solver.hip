@@ -1463,6 +1463,24 @@ const char *mgps_last_error(const mgps_solver *h) { return h ? h->lastError.c_st
 
 void mgps_trim_host_cache(void) { pinnedTrim(); }
 
+void *mgps_host_alloc(size_t bytes)
+try {
+    int ndev = 0;
+    if (bytes == 0 || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return pinnedAlloc(bytes);
+} catch (...) {
+    return nullptr;
+}
+
+void mgps_host_free(void *p)
+try {
+    if (p) pinnedFree(p);
+} catch (...) {
+}
+
 int mgps_device_count(int *count)
 try {
     if (!count) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_device_count: NULL");

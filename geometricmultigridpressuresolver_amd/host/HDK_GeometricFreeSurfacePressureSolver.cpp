@@ -14,10 +14,11 @@
 #include <UT/UT_Interrupt.h>
 #include <UT/UT_PerfMonAutoEvent.h>
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <iostream>
-#include <vector>
 
 #include "mgps_fields.h"
 #include "mgps_voxel_flatten.hpp"
@@ -77,9 +78,50 @@ const SIM_DopDescription *HDK_GeometricFreeSurfacePressureSolver::getDopDescript
 
 namespace {
 
+// A flattened field in page-locked memory (mgps_host_alloc): the upload of the ten field arrays is what a sub-step spends
+// most of its PCIe time on, and a pageable source runs at a twentieth of the link's rate.  Falls back to plain memory.
+template <class T>
+struct Staging {
+    T *p = nullptr;
+    size_t n = 0;
+    bool pinned = false;
+    Staging() = default;
+    Staging(const Staging &) = delete;
+    Staging &operator=(const Staging &) = delete;
+    ~Staging() { release(); }
+    void release()
+    {
+        if (p && pinned) mgps_host_free(p);
+        else if (p) std::free(p);
+        p = nullptr;
+        n = 0;
+    }
+    void resize(size_t count)
+    {
+        release();
+        n = count;
+        p = static_cast<T *>(mgps_host_alloc(count * sizeof(T)));
+        pinned = p != nullptr;
+        if (!p) p = static_cast<T *>(std::malloc(count * sizeof(T) + 1));
+    }
+    void assign(size_t count, T value)
+    {
+        resize(count);
+        std::fill(p, p + count, value);
+    }
+    T *data() { return p; }
+    size_t size() const { return n; }
+};
+template <class T, class VoxelArray>
+void flattenInto(Staging<T> &dst, const VoxelArray &grid)
+{
+    dst.resize(size_t(grid.getXRes()) * grid.getYRes() * grid.getZRes());
+    mgps::flattenGrid(dst.data(), grid);
+}
+
 // a SIM_RawField sampled at the sample positions of `like` (the solver wants the solid SDF at cell centres and the solid
 // velocity at the liquid's face centres; the reference interpolates them at those positions, Util.cpp:25, Plug.cpp:925)
-void sampleAt(std::vector<float> &flat, const SIM_RawField &source, const SIM_RawField &like)
+void sampleAt(Staging<float> &flat, const SIM_RawField &source, const SIM_RawField &like)
 {
     int nx, ny, nz;
     like.getVoxelRes(nx, ny, nz);
@@ -166,20 +208,20 @@ bool HDK_GeometricFreeSurfacePressureSolver::solveGasSubclass(SIM_Engine &, SIM_
     std::cout << "//\n//\n// Starting free surface pressure solver (mgps, MI355X)\n//\n//" << std::endl;
 
     // ---- flatten (SIM fields are fpreal32 voxel arrays: float is their own precision) ----------------------------------
-    std::vector<float> phi, solidPhi, p, cw[3], vel[3], solidVel[3];
-    std::vector<uint8_t> valid[3];
+    Staging<float> phi, solidPhi, p, cw[3], vel[3], solidVel[3];
+    Staging<uint8_t> valid[3];
     {
         UT_PerfMonAutoSolveEvent event(this, "Flatten fields");
-        mgps::flattenGrid(phi, *liquidSurface.field());
-        mgps::flattenGrid(p, *pressure->field());
+        flattenInto(phi, *liquidSurface.field());
+        flattenInto(p, *pressure->field());
         if (solidField) sampleAt(solidPhi, *solidField->getField(), liquidSurface);
         else {  // no collision field: all fluid.  Houdini's solid SDF is positive inside (Plug.cpp:214-225)
             const fpreal dx = velocity->getVoxelSize().maxComponent();
             solidPhi.assign(phi.size(), float(-10. * dx));
         }
         for (int axis : {0, 1, 2}) {
-            mgps::flattenGrid(cw[axis], *cutCellWeights->getField(axis)->field());
-            mgps::flattenGrid(vel[axis], *velocity->getField(axis)->field());
+            flattenInto(cw[axis], *cutCellWeights->getField(axis)->field());
+            flattenInto(vel[axis], *velocity->getField(axis)->field());
             if (solidVelocity) sampleAt(solidVel[axis], *solidVelocity->getField(axis), *velocity->getField(axis));
             valid[axis].resize(vel[axis].size());
         }
@@ -232,12 +274,11 @@ bool HDK_GeometricFreeSurfacePressureSolver::solveGasSubclass(SIM_Engine &, SIM_
     // ---- write back (Plug.cpp:637-713) ------------------------------------------------------------------------------------------
     {
         UT_PerfMonAutoSolveEvent event(this, "Write fields back");
-        mgps::unflattenGrid(*pressure->fieldNC(), p);
-        std::vector<float> flags;
+        mgps::unflattenGrid(*pressure->fieldNC(), p.data(), p.size());
         for (int axis : {0, 1, 2}) {
-            mgps::unflattenGrid(*velocity->getField(axis)->fieldNC(), vel[axis]);
-            flags.assign(valid[axis].begin(), valid[axis].end());  // 1 = valid face, 0 = invalid (HDK::Utilities VALID_FACE / INVALID_FACE)
-            mgps::unflattenGrid(*validFaces->getField(axis)->fieldNC(), flags);
+            mgps::unflattenGrid(*velocity->getField(axis)->fieldNC(), vel[axis].data(), vel[axis].size());
+            // 1 = valid face, 0 = invalid (HDK::Utilities VALID_FACE / INVALID_FACE); the voxel array converts uint8 -> fpreal32
+            mgps::unflattenGrid(*validFaces->getField(axis)->fieldNC(), valid[axis].data(), valid[axis].size());
         }
     }
     if (pressureField) pressureField->pubHandleModification();

@@ -38,14 +38,13 @@ inline void forEachPlaneRange(int nz, Fn fn)
     for (auto &th : pool) th.join();
 }
 
-// flat[(k*ny + j)*nx + i] = U(grid(i, j, k)); `flat` is resized.  U may differ from the array's value type
-// (int labels -> uint8_t, double -> float).
+// out[(k*ny + j)*nx + i] = U(grid(i, j, k)) into a buffer of nx*ny*nz entries the caller provides (e.g. page-locked memory
+// from mgps_host_alloc: uploads from it run at PCIe speed).  U may differ from the array's value type (int labels ->
+// uint8_t, double -> float).
 template <class U, class VoxelArray>
-inline void flattenGrid(std::vector<U> &flat, const VoxelArray &grid)
+inline void flattenGrid(U *out, const VoxelArray &grid)
 {
     const int nx = grid.getXRes(), ny = grid.getYRes(), nz = grid.getZRes();
-    flat.resize(size_t(nx) * ny * nz);
-    U *out = flat.data();
     forEachPlaneRange(nz, [&grid, out, nx, ny](int k0, int k1) {
         for (int k = k0; k < k1; ++k)
             for (int j = 0; j < ny; ++j) {
@@ -54,17 +53,23 @@ inline void flattenGrid(std::vector<U> &flat, const VoxelArray &grid)
             }
     });
 }
+// the same into a vector, which is resized
+template <class U, class VoxelArray>
+inline void flattenGrid(std::vector<U> &flat, const VoxelArray &grid)
+{
+    flat.resize(size_t(grid.getXRes()) * grid.getYRes() * grid.getZRes());
+    flattenGrid(flat.data(), grid);
+}
 
 // the inverse: grid(i, j, k) = T(flat[(k*ny + j)*nx + i]).  The array must already have the extents of `flat`
 // (nx * ny * nz entries); returns false, touching nothing, if it does not.  Writes go plane range by plane range: a
 // 16^3 tile of UT_VoxelArray spans 16 planes, so ranges are cut at multiples of 16 -- two threads never write one tile
 // (UT_VoxelArray::setValue may decompress the tile it writes into).
 template <class VoxelArray, class U>
-inline bool unflattenGrid(VoxelArray &grid, const std::vector<U> &flat)
+inline bool unflattenGrid(VoxelArray &grid, const U *in, size_t count)
 {
     const int nx = grid.getXRes(), ny = grid.getYRes(), nz = grid.getZRes();
-    if (flat.size() != size_t(nx) * ny * nz) return false;
-    const U *in = flat.data();
+    if (count != size_t(nx) * ny * nz) return false;
     using T = decltype(grid.getValue(0, 0, 0));
     const int tilePlanes = 16, ntiles = (nz + tilePlanes - 1) / tilePlanes;
     forEachPlaneRange(ntiles, [&grid, in, nx, ny, nz, tilePlanes](int t0, int t1) {
@@ -76,6 +81,11 @@ inline bool unflattenGrid(VoxelArray &grid, const std::vector<U> &flat)
             }
     });
     return true;
+}
+template <class VoxelArray, class U>
+inline bool unflattenGrid(VoxelArray &grid, const std::vector<U> &flat)
+{
+    return unflattenGrid(grid, flat.data(), flat.size());
 }
 
 }  // namespace mgps

@@ -278,6 +278,30 @@ def test_one_call_projection_matches_the_pass_by_pass_pipeline(dtype):
     assert np.abs(p_h - pressure.cpu().numpy()).max() < 1e-6 * np.abs(p_h).max()
     before = np.abs(rhs.cpu().numpy()).max()
     assert info["divergence_max"] < 2e-4 * before and info["residual_l2"] > 0
+    # staging buffers from mgps_host_alloc (page-locked): same answer, and released blocks are handed out again
+    if dtype == np.float32:
+        import ctypes as C
+
+        from geometricmultigridpressuresolver_amd._lib import lib
+
+        L = lib()
+        L.mgps_host_alloc.restype = C.c_void_p
+        L.mgps_host_alloc.argtypes = [C.c_size_t]
+        L.mgps_host_free.argtypes = [C.c_void_p]
+        nbytes = int(np.prod(SHAPE)) * 4
+        ptr = L.mgps_host_alloc(nbytes)
+        assert ptr
+        pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=SHAPE)
+        pinned[...] = 0
+        vel3 = [h(a) for a in sc["velocity"]]
+        F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel3, pinned,
+                               [h(a) for a in sc["solid_velocity"]], use_old_pressure=False, tolerance=1e-6, max_iterations=200)
+        assert np.array_equal(pinned, p_h)
+        del pinned
+        L.mgps_host_free(ptr)
+        again = L.mgps_host_alloc(nbytes)
+        assert again == ptr
+        L.mgps_host_free(again)
     # warm start from the answer: CG leaves at its first test (CG.h:60-64)
     vel2 = [h(a) for a in sc["velocity"]]
     _, info2 = F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel2, p_h.copy(),

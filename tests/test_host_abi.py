@@ -255,6 +255,22 @@ def test_status_strings_cover_every_code():
         assert lib().mgps_status_string(v) != b"unknown status", name
 
 
+def test_host_alloc_without_device_returns_null():
+    import torch
+
+    L = lib()
+    L.mgps_host_alloc.restype = C.c_void_p
+    L.mgps_host_alloc.argtypes = [C.c_size_t]
+    L.mgps_host_free.argtypes = [C.c_void_p]
+    p = L.mgps_host_alloc(1 << 20)
+    if torch.cuda.is_available():
+        assert p
+        L.mgps_host_free(p)
+    else:
+        assert not p  # callers fall back to ordinary memory (the Houdini shim's Staging does)
+    L.mgps_host_free(None)
+
+
 def test_create_without_device_fails_loudly():
     """The product has no CPU path: on a box without a HIP device the constructor reports it."""
     import torch
