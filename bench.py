@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-frac512", action="store_true", help="skip the extra 512^3 smoother measurement (roofline.frac_512)")
     ap.add_argument("--force-slab", action="store_true", help="use the multi-GPU code path (RCCL transport, slab solver) even with one rank")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N-rank path on a box with fewer GPUs: ranks share the GPUs there are, gloo process group, "
+                    "host-staged transport (RCCL refuses two ranks on one device).  The line it prints is marked and is not a measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--check-oracle", action="store_true",
                     help="free_surface_pcg only: also solve with the fp64 CPU oracle and report the pressure-field difference")
@@ -209,6 +212,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if args.rehearse_gloo:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     slab_run = world > 1 or args.force_slab  # --force-slab: rehearse the multi-GPU code path with one rank
     # RCCL prints a version banner on stdout when a communicator comes up; stdout must carry the JSON line only
@@ -218,7 +223,10 @@ def main():
     if slab_run:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
@@ -235,9 +243,9 @@ def main():
     opt = G.default_options()
     opt.precision = 1 if args.precision == "mixed" else 0
     if slab_run:
-        from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver
+        from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
-        comm = RcclComm(device=local_rank)
+        comm = TorchDistComm() if args.rehearse_gloo else RcclComm(device=local_rank)
         solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt)
     else:
         solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank, options=opt)
@@ -268,7 +276,7 @@ def main():
     stages = solver.stage_times()
     solver.profile_enable(False)
     if slab_run:  # the job is as slow as its slowest rank
-        t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, smooth_ms = float(t[0]), float(t[1])
 
@@ -292,7 +300,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 arithmetic, f16 storage of the fine-level iterate and residual",
-        "data": "synthetic",
+        "data": "synthetic" if not args.rehearse_gloo else "synthetic; REHEARSAL over gloo with ranks sharing a GPU -- not a measurement",
         "config": {
             "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
             f"(3 band Jacobi + {'2 tiled-GS half sweeps' if use_gs else '1 damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
