@@ -302,9 +302,11 @@ int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, co
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);
 // ---- mixed precision (options.precision = 1): binary16 grids of the fine level, passed as void* -----------------------
 bool mixedPrecisionShapeOk(int nx, int ny, int nz);  // the fine level must take the quad sweep and the block prolongation
-int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms);
+int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms,
+                       double *dotPartials = nullptr, unsigned *nparts = nullptr);
 int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
-                         const BandGroupsDev &bg, const MixScale &ms);
+                         const BandGroupsDev &bg, const MixScale &ms, double *dotPartials = nullptr);
+int launchScaleResult(void *stream, double *resultDev, const float *sigmaDev, float mul);  // *result *= mul / *sigma
 int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, const void *fineH, float fm);
 int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const float *coarse, float pm);
 int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (valid && simpleCell(ls[e])) acc += dotTerm<OP>(xs[e + 1], bs[e], res[e]);
+            if (valid && simpleCell(ls[e])) acc += dotTerm<OP>(xs[e + 1], bs[e], kMixed ? __half2float(toHalfSat(res[e])) : res[e]);  // (the value as stored)
         blockDotStore(acc, dotPartials, blockIdx.x);
     }
 }
@@ -417,7 +417,7 @@ __global__ void boundaryOpKernel(GridP g, TX *__restrict__ out, const TX *__rest
         } else
             res = epilogue<OP>(xc, bc, lap, diag, omega);
         Cell<TX>::store1(out + c, res);
-        acc = dotTerm<OP>(xc, bc, res);
+        acc = dotTerm<OP>(xc, bc, kMixed ? __half2float(toHalfSat(res)) : res);
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
@@ -459,7 +459,10 @@ __global__ void bandScatterKernel(TX *__restrict__ x, const int32_t *__restrict_
     if (t < nband) {
         const int32_t c = band[t];
         const float v = tmp[t];
-        if (DOT) acc = (double(v) - double(Cell<TX>::load1(x + c))) * double(b[c]);
+        if (DOT) {
+            const float stored = std::is_same<TX, float>::value ? v : __half2float(toHalfSat(v));
+            acc = (double(stored) - double(Cell<TX>::load1(x + c))) * double(b[c]);
+        }
         Cell<TX>::store1(x + c, v);  // Ops.h:604-618
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
@@ -1581,7 +1584,10 @@ unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nban
 // ---- mixed precision (options.precision = 1): the fine level's iterate and residual live in binary16 ----------------
 // The launchers take the binary16 grids as void* (the solver layer does not see __half).  Solver-owned grids only:
 // chunks without active cells hold 0 and are never visited.
-int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms)
+// dotPartials / nparts (Jacobi only, optional): the sweep also leaves its per-workgroup shares of sum x~' b (the stored,
+// rounded x~'; the unscaled rhs) in dotPartials[0 .. *nparts)
+int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms,
+                       double *dotPartials, unsigned *nparts)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     __half *out = static_cast<__half *>(outH);
@@ -1589,20 +1595,26 @@ int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, c
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const bool list = g.chunks != nullptr;
     const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
+    const bool dot = dotPartials != nullptr && op == OP_JACOBI;
     if (nb > 0) {
-        if (op == OP_JACOBI) stencilQuadKernel<OP_JACOBI, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
+        if (dot) stencilQuadKernel<OP_JACOBI, true, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, dotPartials, ms);
+        else if (op == OP_JACOBI) stencilQuadKernel<OP_JACOBI, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
         else stencilQuadKernel<OP_RESIDUAL, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
     }
+    unsigned used = dot ? nb : 0;
     if (g.nbnd > 0) {
         const unsigned nbb = blocksFor(size_t(g.nbnd), 256);
-        if (op == OP_JACOBI) boundaryOpKernel<OP_JACOBI, false, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, nullptr, ms);
+        if (dot) boundaryOpKernel<OP_JACOBI, true, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, dotPartials + used, ms);
+        else if (op == OP_JACOBI) boundaryOpKernel<OP_JACOBI, false, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, nullptr, ms);
         else boundaryOpKernel<OP_RESIDUAL, false, __half><<<nbb, 256, 0, s>>>(g, out, x, b, omega, nbb, nullptr, ms);
+        if (dot) used += nbb;
     }
+    if (nparts) *nparts = used;
     return int(hipGetLastError());
 }
 
 int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
-                         const BandGroupsDev &bg, const MixScale &ms)
+                         const BandGroupsDev &bg, const MixScale &ms, double *dotPartials)
 {
     if (nband <= 0 || bg.ngroups <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1610,7 +1622,15 @@ int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b,
     bandFusedKernel<__half><<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours, bg.readCell,
                                                                           bandTmp, omega, bg.depth, nullptr, nullptr, nullptr, 0, 0, ms);
     const unsigned nb = blocksFor(size_t(nband), 256);
-    bandScatterKernel<false, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    if (dotPartials) bandScatterKernel<true, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb, b, dotPartials);  // sum (new - old) b shares
+    else bandScatterKernel<false, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
+    return int(hipGetLastError());
+}
+// *result *= mul / *sigma: turns the gathered sum x~ b of the mixed cycle into <z, b>
+__global__ void scaleResultKernel(double *__restrict__ result, const float *__restrict__ sigma, float mul) { *result *= double(mul) / double(*sigma); }
+int launchScaleResult(void *stream, double *resultDev, const float *sigmaDev, float mul)
+{
+    scaleResultKernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(resultDev, sigmaDev, mul);
     return int(hipGetLastError());
 }
 

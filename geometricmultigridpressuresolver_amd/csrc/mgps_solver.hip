@@ -690,7 +690,9 @@ int ensureMixedGrids(mgps_solver *h)
 // smoother, single device).  Same schedule as vcycle() (MG.cpp:420-881); x and b are fp32 grids in the caller's units.
 // x == nullptr: the result stays in binary16 (h->mixResult; z = 2^mixExp / *mixSigma times it) for launchHalfDot /
 // launchXpayHalf.  maxAbsDev: max |b| if a previous pass already left it on the device (else a reduction runs here).
-int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, const double *maxAbsDev = nullptr)
+// dotDev (x == nullptr only): *dotDev = <z, b> gathered on the way by the last stroke (the last Jacobi sweep leaves
+// sum x~' b, the band scatters after it the corrections), as vcycle() does for the fp32 cycle
+int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, const double *maxAbsDev = nullptr, double *dotDev = nullptr)
 {
     MGPS_TRY(ensureMixedGrids(h));
     DevLevel &F = h->lv[0];
@@ -716,16 +718,27 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
     void *cur = h->mixX, *other = h->mixTmp;
     MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));  // MG.cpp:439-440
     const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
-    auto stroke = [&](bool down) -> int {
+    const bool gather = dotDev != nullptr && h->dotPartials != nullptr;
+    h->dotUsed = 0;
+    auto stroke = [&](bool down, bool dot) -> int {
         MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
-        for (int rep = 0; rep < (down ? h->opt.pre_sweeps : h->opt.post_sweeps); ++rep) {
-            MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, F.g, other, cur, b, omega, smooth));
+        const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
+        for (int rep = 0; rep < reps; ++rep) {
+            unsigned used = 0;
+            const bool d = dot && rep == reps - 1;
+            MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, F.g, other, cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
+            h->dotUsed += used;
             std::swap(cur, other);
         }
-        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
+        double *sink = nullptr;
+        if (dot && F.nband > 0) {
+            sink = h->dotPartials + h->dotUsed;
+            h->dotUsed += bandScatterBlocks(F.nband);
+        }
+        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth, sink));
         return MGPS_OK;
     };
-    MGPS_TRY(stroke(true));
+    MGPS_TRY(stroke(true, gather && nlv == 1));
     if (nlv > 1) {
         DevLevel &C = h->lv[1];
         // r~ = 256 r^ = 256 sigma b - 256 2^e (A x~); level 1 receives Restrict(r^) in fp32
@@ -735,7 +748,11 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         float *corr = nullptr;
         MGPS_TRY(innerCycle(h, 1, &corr));
         MGPS_LAUNCH(h, launchProlongAddMixed(h->stream, F.g, cur, corr, xs));
-        MGPS_TRY(stroke(false));
+        MGPS_TRY(stroke(false, gather));
+    }
+    if (gather) {
+        MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, dotDev));
+        MGPS_LAUNCH(h, launchScaleResult(h->stream, dotDev, h->mixSigma, xsInv));
     }
     h->mixResult = cur;
     if (x) MGPS_LAUNCH(h, launchFromHalf(h->stream, x, cur, h->mixSigma, xsInv, n));
@@ -1059,12 +1076,17 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         }
         if (mixed) {  // z = M r stays in binary16: <z, r> and p = z + beta p read it there (CG.h:168-191)
             const float zScale = std::ldexp(1.f, h->mixExp);
-            MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax));
-            if (devScal) {
-                MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, scal + 3));
+            if (devScal) {  // <z, r> gathered by the cycle's last stroke (MGPS_GATHER_DOT=0: a separate pass over x~ and r)
+                static const bool gatherMixed = [] {
+                    const char *e = getenv("MGPS_GATHER_DOT");
+                    return !(e && e[0] == '0');
+                }();
+                MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax, gatherMixed ? scal + 3 : nullptr));
+                if (!gatherMixed) MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, scal + 3));
                 MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 0));
                 MGPS_LAUNCH(h, launchXpayHalf(h->stream, F.g, p, h->mixResult, h->mixSigma, zScale, betaDev, 0.f));
             } else {
+                MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax));
                 const double absOld = absNew;
                 MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, h->resultDev));
                 MGPS_TRY(fetchReduction(h, 0, &absNew));
