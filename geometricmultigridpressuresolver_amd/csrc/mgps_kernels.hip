@@ -661,7 +661,9 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             lv[m] = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
             if (in) {
                 xv[m] = *reinterpret_cast<const float4 *>(x + rowOff);
-                if (LABELS) lv[m] = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
+                // labels of the tile's own rows only: the sweep never looks at a halo cell's label (a 16-byte label row is
+                // an eighth of a line: 68 halo rows would be 68 more lines per tile)
+                if (LABELS && lj >= 1 && lj <= kTile && lk >= 1 && lk <= kTile) lv[m] = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
             }
         }
 #pragma unroll
@@ -672,11 +674,8 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             const bool in = r < kHalo * kHalo * 2 && gi >= 0 && gi < g.nx && gj >= 0 && gk >= -g.ghostLo && gj < g.ny && gk < g.nz + g.ghostHi;
             const ptrdiff_t c = (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi;
             hv[m] = 0.f;
-            hl[m] = (unsigned char)MGPS_EXTERIOR_CELL;
-            if (in) {
-                hv[m] = x[c];
-                if (LABELS) hl[m] = g.lab[c];
-            }
+            hl[m] = (unsigned char)MGPS_EXTERIOR_CELL;  // (x-halo labels are never read either)
+            if (in) hv[m] = x[c];
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -801,7 +800,7 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
         srow[q * kRowPool + t] = g.rows[q * nb + bndBase + t];
     }
     __syncthreads();
-    {  // per x-row BOUNDARY mask and exclusive prefix over the 256 rows in (k, j) order = list order
+    if (bndCount > 0) {  // per x-row BOUNDARY mask and exclusive prefix over the 256 rows in (k, j) order = list order (uniform branch)
         const int rj = threadIdx.x % kTile, rk = threadIdx.x / kTile;
         unsigned m = 0;
         for (int i = 0; i < kTile; ++i) m |= (sl[haloIdx(i, rj, rk)] == kCodeGeneral) ? (1u << i) : 0u;
@@ -827,34 +826,33 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
         const int lk = s - li - lj;
         if (lk >= 0 && lk < kTile) {
             const int h = haloIdx(li, lj, lk);
+            // label, rhs and the seven values are read together (one LDS round trip per step, not label -> branch -> values:
+            // a step is a barrier-to-barrier latency chain); inactive cells read them for nothing
             const unsigned l = sl[h];
-            if (activeLabel(l)) {
-                const float xc = sx[h];
-                const float bc = sb[(lk * kTile + lj) * kTile + li];
-                const float xn[6] = {sx[h - 1], sx[h + 1], sx[h - kHalo], sx[h + kHalo], sx[h - kHalo * kHalo], sx[h + kHalo * kHalo]};
-                float lap, diag;
-                if (simpleCell(l)) {
-                    diag = simpleDiag(l);
-                    lap = diag * xc - (xn[0] + xn[1] + xn[2] + xn[3] + xn[4] + xn[5]);
-                    sx[h] = xc + (bc - lap) * simpleRcp(diag);  // undamped, Ops.h:493 (reciprocal as in the Jacobi kernels)
+            const float xc = sx[h];
+            const float bc = sb[(lk * kTile + lj) * kTile + li];
+            const float xn[6] = {sx[h - 1], sx[h + 1], sx[h - kHalo], sx[h + kHalo], sx[h - kHalo * kHalo], sx[h + kHalo * kHalo]};
+            if (simpleCell(l)) {
+                const float diag = simpleDiag(l);
+                const float lap = diag * xc - (xn[0] + xn[1] + xn[2] + xn[3] + xn[4] + xn[5]);
+                sx[h] = xc + (bc - lap) * simpleRcp(diag);  // undamped, Ops.h:493 (reciprocal as in the Jacobi kernels)
+            } else if (l == kCodeGeneral) {
+                const int row = lk * kTile + lj;
+                const int t = int(rowStart[row]) + __popc(unsigned(rowMask[row]) & ((1u << li) - 1u));
+                float w[7];
+                if (t < kRowPool) {
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) w[q] = srow[q * kRowPool + t];
                 } else {
-                    const int row = lk * kTile + lj;
-                    const int t = int(rowStart[row]) + __popc(unsigned(rowMask[row]) & ((1u << li) - 1u));
-                    float w[7];
-                    if (t < kRowPool) {
 #pragma unroll
-                        for (int q = 0; q < 7; ++q) w[q] = srow[q * kRowPool + t];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) w[q] = g.rows[q * nb + bndBase + t];
-                    }
-                    float acc = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) acc -= w[q] * xn[q];
-                    diag = w[6];
-                    lap = acc + diag * xc;
-                    sx[h] = xc + (bc - lap) / diag;
+                    for (int q = 0; q < 7; ++q) w[q] = g.rows[q * nb + bndBase + t];
                 }
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc -= w[q] * xn[q];
+                const float diag = w[6];
+                const float lap = acc + diag * xc;
+                sx[h] = xc + (bc - lap) / diag;
             }
         }
         __syncthreads();
