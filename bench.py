@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--check-oracle", action="store_true",
                     help="free_surface_pcg only: also solve with the fp64 CPU oracle and report the pressure-field difference")
+    ap.add_argument("--sweeps", type=int, default=1, help="full-domain smoother sweeps per stroke (options.pre_sweeps = post_sweeps); "
+                    "1 = the reference's schedule, 2 = BASELINE config 1's '2+2'")
     ap.add_argument("--precision", choices=["fp32", "mixed"], default="fp32",
                     help="mixed = BASELINE config 5's storage: the fine level's iterate and residual in binary16 (options.precision = 1)")
     ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
@@ -62,7 +64,7 @@ def default_levels(n):
     return lev  # 256 -> 5 (BASELINE config 2), 512 -> 6, 1024 -> 7
 
 
-def cpu_baseline(n, levels, use_gs, budget_s):
+def cpu_baseline(n, levels, use_gs, budget_s, sweeps=1):
     """fp64 oracle V-cycle on the host cores.  Bounded: shrink the grid until one V-cycle fits the
     budget; the unit stays V-cycles/sec of *that* grid and the sample string says which."""
     import numpy as np
@@ -78,7 +80,7 @@ def cpu_baseline(n, levels, use_gs, budget_s):
         sample_n //= 2
         sample_levels = max(2, sample_levels - 1)
     lab, w, h = D.interior_cube(sample_n, sample_levels, dtype=np.float64)
-    s = orc.solver(lab.astype(np.int32), w, sample_levels, use_gs)
+    s = orc.solver(lab.astype(np.int32), w, sample_levels, use_gs, pre_sweeps=sweeps, post_sweeps=sweeps)
     b = D.random_rhs(lab, h, dtype=np.float64)
     x = np.zeros_like(b)
     s.apply_vcycle(x, b, False)  # warm-up (page faults, first touch)
@@ -106,7 +108,7 @@ def cpu_baseline(n, levels, use_gs, budget_s):
     # (half the bytes of every grid; labels stay 4 bytes), so that the GPU / CPU ratio is not read off the reference's doubles alone
     try:
         o32 = Oracle(f32=True)
-        s32 = o32.solver(lab.astype(np.int32), [a.astype(np.float32) for a in w], sample_levels, use_gs)
+        s32 = o32.solver(lab.astype(np.int32), [a.astype(np.float32) for a in w], sample_levels, use_gs, pre_sweeps=sweeps, post_sweeps=sweeps)
         b32, x32 = b.astype(np.float32), np.zeros(b.shape, dtype=np.float32)
         s32.apply_vcycle(x32, b32, False)
         t32 = []
@@ -242,6 +244,7 @@ def main():
     lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
     opt = G.default_options()
     opt.precision = 1 if args.precision == "mixed" else 0
+    opt.pre_sweeps = opt.post_sweeps = args.sweeps
     if slab_run:
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
@@ -285,7 +288,7 @@ def main():
     # algorithmic bytes count the cells a launch actually visits on this rank, not the allocation
     swept = solver.swept_cells(0)[1 if use_gs else 0]
     sweeps_per_group = 1  # Jacobi: one sweep; GS: two half sweeps touch every tile once = one sweep
-    t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group
+    t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group  # (profile_read counts sweeps: --sweeps 2 doubles the count)
     achieved = SMOOTHER_BYTES_PER_CELL * swept / t_sweep / 1e9  # per GPU
     vps = args.steps / elapsed
     out = {
@@ -303,7 +306,7 @@ def main():
         "data": "synthetic" if not args.rehearse_gloo else "synthetic; REHEARSAL over gloo with ranks sharing a GPU -- not a measurement",
         "config": {
             "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
-            f"(3 band Jacobi + {'2 tiled-GS half sweeps' if use_gs else '1 damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
+            f"(3 band Jacobi + {args.sweeps} x {'2 tiled-GS half sweeps' if use_gs else 'damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
             "useInitialGuess=true, " + ("fp32 storage" if args.precision == "fp32" else "mixed precision (options.precision = 1)"),
             "grid": n,
             "levels": levels,
@@ -368,7 +371,7 @@ def main():
         except Exception as e:
             out["roofline"]["frac_512_error"] = str(e)
     if not args.no_cpu and rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(n, levels, use_gs, args.cpu_seconds, args.sweeps)
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     if rank == 0:
