@@ -168,6 +168,20 @@ def test_random_scenes_match_oracle(seed, fo, oracle):
         sg = gpu.solveGeometricConjugateGradient(xg, rhs_d, 1e-5, 300, True)
         assert sg["outcome"] == "converged" and abs(sg["iterations"] - so["iterations"]) <= 2, (shape, so, sg)
         gpu.close()
+        if not use_gs:  # the mixed-precision cycle (binary16 fine-level iterate / residual) on the same scene
+            opt = G.default_options()
+            opt.precision = 1
+            mix = G.GeometricMultigridPoissonSolver(lab_d.cpu().numpy(), w32, levels, False, options=opt)
+            xm = mix.new_grid()
+            mix.applyVCycle(xm, rhs_d, False)
+            x1 = np.zeros(eshape)
+            orc.apply_vcycle(x1, b64, False)
+            assert np.linalg.norm(xm.cpu().numpy() - x1) <= 2e-3 * max(np.linalg.norm(x1), 1e-300), (shape, "mixed cycle")
+            xm = mix.new_grid()
+            sm = mix.solveGeometricConjugateGradient(xm, rhs_d, 1e-5, 300, True)
+            assert sm["outcome"] == "converged" and sm["iterations"] <= 1.5 * sg["iterations"] + 1, (shape, sm, sg)
+            assert np.linalg.norm(xm.cpu().numpy() - xo) <= 5e-5 * max(np.linalg.norm(xo), 1e-300), (shape, "mixed pcg")
+            mix.close()
 
 
 @pytest.mark.gpu
