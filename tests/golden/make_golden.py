@@ -113,6 +113,34 @@ def main():
         print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+def write_sweeps():
+    """Benchmark schedule of BASELINE config 1 (pre_sweeps = post_sweeps = 2; the reference's own count is 1) on the
+    cut-cell + free-surface domain: one and three chained cycles per smoother, MG-PCG iteration count.  Only what the
+    labels / weights / rhs of golden_solid24.npz do not already hold."""
+    orc = Oracle()
+    kind, g = "solid", 24
+    lab, w, off, lev, dx = make_domain(kind, g, dtype=np.float32)
+    lab32, w64 = lab.astype(np.int32), [a.astype(np.float64) for a in w]
+    b = D.random_rhs(lab, dx, dtype=np.float32).astype(np.float64)
+    delta = D.delta_rhs(lab, g, off, dx, dtype=np.float32).astype(np.float64)
+    out = {"grid_size": g, "pre_sweeps": 2, "post_sweeps": 2}
+    for use_gs in (False, True):
+        tag = "gs" if use_gs else "jacobi"
+        s = orc.solver(lab32, w64, lev, use_gs, pre_sweeps=2, post_sweeps=2)
+        x = np.zeros(lab.shape)
+        s.apply_vcycle(x, b, False)
+        out[f"vcycle1_{tag}"] = x.copy()
+        for _ in range(2):
+            s.apply_vcycle(x, b, True)
+        out[f"vcycle3_{tag}"] = x.copy()
+        xs = np.zeros(lab.shape)
+        st = s.solve_pcg(xs, delta, 1e-5, 500, True)
+        out[f"pcg_{tag}_iterations"] = st["iterations"]
+    path = os.path.join(HERE, "sweeps22_solid24.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def write_fields():
     path = os.path.join(HERE, "fields_scene20.npz")
     np.savez_compressed(path, **build_fields_case())
@@ -121,4 +149,5 @@ def write_fields():
 
 if __name__ == "__main__":
     write_fields()
+    write_sweeps()
     main()
