@@ -135,6 +135,38 @@ int rcclGather(void *user, const void *send, void *recv, size_t bytes, int root,
     return 0;
 }
 
+int rcclGatherv(void *user, const void *send, size_t sendBytes, void *recv, const size_t *counts, const size_t *displs, int root, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->rank == root && sendBytes)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + displs[root], send, sendBytes, hipMemcpyDeviceToDevice, st));
+    NCCL_TRY(gApi.GroupStart());
+    if (s->rank == root) {
+        for (int r = 0; r < s->size; ++r)
+            if (r != root && counts[r]) NCCL_TRY(gApi.Recv(static_cast<char *>(recv) + displs[r], counts[r], ncclChar, r, s->comm, st));
+    } else if (sendBytes)
+        NCCL_TRY(gApi.Send(send, sendBytes, ncclChar, root, s->comm, st));
+    NCCL_TRY(gApi.GroupEnd());
+    return 0;
+}
+
+int rcclScatterv(void *user, const void *send, const size_t *counts, const size_t *displs, void *recv, size_t recvBytes, int root, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->rank == root && recvBytes)
+        HIP_TRY(hipMemcpyAsync(recv, static_cast<const char *>(send) + displs[root], recvBytes, hipMemcpyDeviceToDevice, st));
+    NCCL_TRY(gApi.GroupStart());
+    if (s->rank == root) {
+        for (int r = 0; r < s->size; ++r)
+            if (r != root && counts[r]) NCCL_TRY(gApi.Send(static_cast<const char *>(send) + displs[r], counts[r], ncclChar, r, s->comm, st));
+    } else if (recvBytes)
+        NCCL_TRY(gApi.Recv(recv, recvBytes, ncclChar, root, s->comm, st));
+    NCCL_TRY(gApi.GroupEnd());
+    return 0;
+}
+
 int rcclScatter(void *user, const void *send, void *recv, size_t bytes, int root, void *stream)
 {
     auto *s = static_cast<RcclState *>(user);
@@ -231,6 +263,8 @@ try {
     out->gather = rcclGather;
     out->scatter = rcclScatter;
     out->destroy = rcclDestroy;
+    out->gatherv = rcclGatherv;
+    out->scatterv = rcclScatterv;
     return MGPS_OK;
 }
 MGPS_API_CATCH(nullptr)

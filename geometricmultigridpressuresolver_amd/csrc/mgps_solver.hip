@@ -107,6 +107,7 @@ struct mgps_solver {
     // slab run
     bool dist = false;
     mgps_comm comm{};
+    std::vector<int> splits;       // slab run: rank r owns the fine planes [splits[r], splits[r + 1])
     int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
     int totalLevels = 0;           // levels of the whole hierarchy
     mgps_solver *tail = nullptr;   // rank 0: solver of levels distLevels .. totalLevels-1 on the whole grid
@@ -532,13 +533,26 @@ int collapsedTail(mgps_solver *h)
 {
     DevLevel &C = h->lv[h->distLevels];
     const size_t bytes = C.d.cells() * sizeof(float);
-    MGPS_COMM(h, h->comm.gather(h->comm.user, C.b, h->comm.rank == 0 ? h->tailB : nullptr, bytes, 0, h->stream));
+    const int P = h->comm.size;
+    bool uniform = true;
+    for (int r = 1; r < P; ++r) uniform = uniform && (h->splits[size_t(r) + 1] - h->splits[size_t(r)]) == (h->splits[1] - h->splits[0]);
+    std::vector<size_t> counts, displs;
+    if (!uniform) {  // slabs balanced by active planes: rank r's share of the collapse level is its planes of that level
+        const size_t planeBytes = size_t(C.d.nx) * C.d.ny * sizeof(float);
+        for (int r = 0; r < P; ++r) {
+            displs.push_back(size_t(h->splits[size_t(r)] >> h->distLevels) * planeBytes);
+            counts.push_back(size_t((h->splits[size_t(r) + 1] - h->splits[size_t(r)]) >> h->distLevels) * planeBytes);
+        }
+    }
+    if (uniform) MGPS_COMM(h, h->comm.gather(h->comm.user, C.b, h->comm.rank == 0 ? h->tailB : nullptr, bytes, 0, h->stream));
+    else MGPS_COMM(h, h->comm.gatherv(h->comm.user, C.b, bytes, h->comm.rank == 0 ? h->tailB : nullptr, counts.data(), displs.data(), 0, h->stream));
     if (h->comm.rank == 0) {
         h->tail->stream = h->stream;
         const int rc = vcycle(h->tail, h->tailX, h->tailB, false);
         if (rc != MGPS_OK) return failH(h, rc, "collapsed tail: " + h->tail->lastError);
     }
-    MGPS_COMM(h, h->comm.scatter(h->comm.user, h->comm.rank == 0 ? h->tailX : nullptr, C.x, bytes, 0, h->stream));
+    if (uniform) MGPS_COMM(h, h->comm.scatter(h->comm.user, h->comm.rank == 0 ? h->tailX : nullptr, C.x, bytes, 0, h->stream));
+    else MGPS_COMM(h, h->comm.scatterv(h->comm.user, h->comm.rank == 0 ? h->tailX : nullptr, counts.data(), displs.data(), C.x, bytes, 0, h->stream));
     return MGPS_OK;
 }
 
@@ -1629,17 +1643,127 @@ try {
 }
 MGPS_API_CATCH(nullptr)
 
-int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
-                     const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
-                     int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm)
+}  // extern "C"
+
+namespace {
+// How many levels of a hierarchy of `levels` levels stay distributed for the cuts `splits` (fine planes, size + 1 entries).
+// Level l stays distributed while every cut is a whole plane of level l + 1 (restriction / prolongation stay rank-local up to
+// one ghost plane), every rank owns at least 16 planes of it, with Gauss-Seidel every cut is a multiple of 16 planes of
+// level l (the 16^3 tile colouring of the single-GPU run), and -- below the finest -- the ranks own min_cells_per_rank
+// cells of it on average.  The last level is always collapsed.  0: the cuts do not allow a slab run.
+int distributedLevelsFor(const int *splits, int size, int nx, int ny, int levels, bool useGS, const mgps_options &o)
+{
+    int D = 0;
+    const int nz = splits[size];
+    for (int l = 0; l < levels - 1; ++l) {
+        bool ok = true;
+        for (int r = 0; r <= size && ok; ++r) {
+            ok = splits[r] % (2 << l) == 0;
+            if (ok && useGS) ok = (splits[r] >> l) % kTile == 0;
+            if (ok && r < size) ok = ((splits[r + 1] - splits[r]) >> l) >= kTile;
+        }
+        if (ok && l > 0) ok = (size_t(nx >> l) * size_t(ny >> l) * size_t(nz >> l)) / size_t(size) >= size_t(std::max(o.min_cells_per_rank, 0));
+        if (!ok) break;
+        ++D;
+    }
+    return D;
+}
+}  // namespace
+
+extern "C" {
+
+int mgps_slab_partition(int nx, int ny, int nz, const uint8_t *labels, int mg_levels, int size, int use_gauss_seidel,
+                        const mgps_options *opt, int *out_splits)
+try {
+    if (!labels || !out_splits || size < 1 || nx < 1 || ny < 1 || nz < 1 || mg_levels < 1)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_slab_partition: bad arguments");
+    mgps_options o;
+    MGPS_TRY(readOptions(opt, &o));
+    auto uniform = [&] {
+        for (int r = 0; r <= size; ++r) out_splits[r] = int(int64_t(nz) * r / size);
+    };
+    uniform();
+    if (size == 1 || nz % size != 0) return MGPS_OK;  // (a grid that does not divide is refused by the constructor)
+    // depth of the distributed part as the even cut gives it; the balanced cuts keep it
+    const int D = distributedLevelsFor(out_splits, size, nx, ny, mg_levels, use_gauss_seidel != 0, o);
+    if (D < 1 || use_gauss_seidel) return MGPS_OK;  // Gauss-Seidel: cuts on multiples of 16 planes of EVERY distributed level -- the even cut
+    const int unit = std::max(kTile, 1 << D);        // Jacobi: whole planes of the collapse level, at least 16 fine planes
+    if (nz % unit != 0) return MGPS_OK;
+    const int units = nz / unit, minUnits = std::max(1, (kTile << (D - 1)) / unit);
+    if (units < size * minUnits) return MGPS_OK;
+    // active cells per unit of planes
+    std::vector<double> load(size_t(units), 0.0);
+    const size_t plane = size_t(nx) * ny;
+    {
+        std::vector<std::thread> pool;
+        const int nt = std::max(1, std::min(units, int(std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4)));
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] {
+                for (int u = t; u < units; u += nt) {
+                    const uint8_t *p = labels + size_t(u) * unit * plane;
+                    size_t n = 0;
+                    for (size_t c = 0; c < size_t(unit) * plane; ++c) n += isActive(p[c]);
+                    load[size_t(u)] = double(n);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    double total = 0;
+    for (double v : load) total += v;
+    if (total == 0) return MGPS_OK;
+    // the cuts that minimise the largest per-rank load (dynamic programme over unit boundaries: units <= nz / 16, ranks <= 8),
+    // every rank at least minUnits; ties go to the more even plane counts
+    std::vector<double> prefix(size_t(units) + 1, 0.0);
+    for (int u = 0; u < units; ++u) prefix[size_t(u) + 1] = prefix[size_t(u)] + load[size_t(u)];
+    const double kInf = 1e300;
+    std::vector<std::vector<double>> best(size_t(size) + 1, std::vector<double>(size_t(units) + 1, kInf));
+    std::vector<std::vector<int>> from(size_t(size) + 1, std::vector<int>(size_t(units) + 1, -1));
+    best[0][0] = 0.0;
+    for (int r = 1; r <= size; ++r)
+        for (int u = r * minUnits; u <= units - (size - r) * minUnits; ++u)
+            for (int v = (r - 1) * minUnits; v <= u - minUnits; ++v) {
+                if (best[size_t(r) - 1][size_t(v)] >= kInf) continue;
+                // (a whisker per plane keeps slabs of equal load equal in size as well)
+                const double cost = std::max(best[size_t(r) - 1][size_t(v)], prefix[size_t(u)] - prefix[size_t(v)] + 1e-9 * total * double(u - v) / units);
+                if (cost < best[size_t(r)][size_t(u)]) {
+                    best[size_t(r)][size_t(u)] = cost;
+                    from[size_t(r)][size_t(u)] = v;
+                }
+            }
+    if (best[size_t(size)][size_t(units)] >= kInf) return MGPS_OK;
+    double evenWorst = 0.0;  // what the even cut costs
+    for (int r = 0; r < size; ++r) evenWorst = std::max(evenWorst, prefix[size_t(out_splits[r + 1] / unit)] - prefix[size_t(out_splits[r] / unit)]);
+    if (best[size_t(size)][size_t(units)] >= 0.98 * evenWorst) return MGPS_OK;  // nothing to gain: keep the even cut
+    for (int r = size, u = units; r > 0; --r) {
+        out_splits[r] = u * unit;
+        u = from[size_t(r)][size_t(u)];
+    }
+    out_splits[0] = 0;
+    if (distributedLevelsFor(out_splits, size, nx, ny, mg_levels, false, o) != D) uniform();  // (never observed; the even cut always stands)
+    return MGPS_OK;
+}
+MGPS_API_CATCH(nullptr)
+
+int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab,
+                            const float *wy_slab, const float *wz_slab, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
+                            const mgps_comm *comm, const int *splits)
 try {
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: out is NULL");
     *out = nullptr;
-    if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm)
-        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: labels, the slab weights and a comm are required");
+    if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm || !splits)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: labels, the slab weights, a comm and the cuts are required");
     if (comm->struct_size != int(sizeof(mgps_comm)) || !comm->exchange || !comm->allreduce || !comm->gather || !comm->scatter ||
         comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: incomplete mgps_comm");
+    const int P = comm->size, rank = comm->rank;
+    bool cutsOk = splits[0] == 0 && splits[P] == nz_global, even = true;
+    for (int r = 0; r < P && cutsOk; ++r) {
+        cutsOk = splits[r + 1] > splits[r];
+        even = even && (splits[r + 1] - splits[r]) == (splits[1] - splits[0]);
+    }
+    if (!cutsOk) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: the cuts must run from 0 to nz, increasing");
+    if (!even && (!comm->gatherv || !comm->scatterv))
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: slabs of different sizes need a transport with gatherv / scatterv");
     mgps_options o;
     MGPS_TRY(readOptions(opt, &o));
     if (o.precision != 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: options.precision = 1 is for single-device solvers");
@@ -1647,22 +1771,13 @@ try {
     MGPS_TRY(pickDevice(o, &device));
     mgps_hierarchy *hier = nullptr;
     MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o));
-    const int P = comm->size, rank = comm->rank;
-    // distributed levels: per-rank plane count a multiple of 16; the last level is always collapsed
-    int D = 0;
-    if (nz_global % P == 0) {
-        int planes = nz_global / P;
-        while (D < hier->levels - 1 && planes % kTile == 0) {
-            const Dims d = hier->lv[D].d;
-            if (D > 0 && size_t(d.nx) * d.ny * size_t(planes) < size_t(std::max(o.min_cells_per_rank, 0))) break;
-            ++D;
-            planes /= 2;
-        }
-    }
+    // distributed levels (distributedLevelsFor); the last level is always collapsed
+    const int D = distributedLevelsFor(splits, P, nx, ny, hier->levels, use_gauss_seidel != 0, o);
     if (D < 1) {
         mgps_hierarchy_destroy(hier);
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT,
-                     "mgps_create_slab: nz / ranks must be a multiple of 16 and the hierarchy needs at least 2 levels");
+                     "mgps_create_slab: every rank needs at least 16 planes cut on even planes (multiples of 16 with Gauss-Seidel) and the "
+                     "hierarchy at least 2 levels");
     }
     auto *h = new mgps_solver();
     h->hier = hier;
@@ -1671,6 +1786,7 @@ try {
     h->device = device;
     h->dist = true;
     h->comm = *comm;
+    h->splits.assign(splits, splits + P + 1);
     h->distLevels = D;
     h->totalLevels = hier->levels;
     auto bail = [&](int code) {
@@ -1678,7 +1794,7 @@ try {
         freeAll(h);
         return code;
     };
-    const int nzl = nz_global / P, z0 = rank * nzl;
+    const int z0 = splits[rank], nzl = splits[rank + 1] - z0;
     const size_t wn[3] = {size_t(nx + 1) * ny * nzl, size_t(nx) * (ny + 1) * nzl, size_t(nx) * ny * (nzl + 1)};
     const float *wh[3] = {wx_slab, wy_slab, wz_slab};
     for (int a = 0; a < 3; ++a) {
@@ -1802,6 +1918,20 @@ try {
     }
     *out = h;
     return MGPS_OK;
+}
+MGPS_API_CATCH(nullptr)
+
+int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab,
+                     const float *wy_slab, const float *wz_slab, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
+                     const mgps_comm *comm)
+try {
+    if (!comm || comm->size < 1) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: a comm is required");
+    if (nz_global % comm->size != 0)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: nz must divide evenly over the ranks (or pass cuts to mgps_create_slab_ranges)");
+    std::vector<int> cuts(size_t(comm->size) + 1);
+    for (int r = 0; r <= comm->size; ++r) cuts[size_t(r)] = nz_global / comm->size * r;
+    return mgps_create_slab_ranges(out, nx, ny, nz_global, labels_global_host, wx_slab, wy_slab, wz_slab, mg_levels, use_gauss_seidel, opt, comm,
+                                   cuts.data());
 }
 MGPS_API_CATCH(nullptr)
 

@@ -26,6 +26,8 @@ _EXCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c
 _ALLR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _GATH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 _DEST = C.CFUNCTYPE(None, C.c_void_p)
+_GATHV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
+_SCATV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 class CommStruct(C.Structure):
@@ -41,6 +43,8 @@ class CommStruct(C.Structure):
         ("gather", _GATH),
         ("scatter", _GATH),
         ("destroy", _DEST),
+        ("gatherv", _GATHV),
+        ("scatterv", _SCATV),
     ]
 
 
@@ -90,7 +94,8 @@ class TorchDistComm:
         self.exchanges = 0
         self.bytes_sent = 0
         self._cb = (_EXCH(self._exchange), _ALLR(self._allreduce), _GATH(self._gather), _GATH(self._scatter))
-        self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST())
+        self._cbv = (_GATHV(self._gatherv), _SCATV(self._scatterv))
+        self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST(), *self._cbv)
 
     # -- staging helpers ---------------------------------------------------------------------------
     def _d2h(self, ptr, nbytes, stream):
@@ -166,8 +171,56 @@ class TorchDistComm:
             print("TorchDistComm.scatter failed:", e, flush=True)
             return 1
 
+    def _gatherv(self, user, send, send_bytes, recv, counts, displs, root, stream):
+        try:
+            mine = self._d2h(send, send_bytes, stream) if send_bytes else torch.empty(0, dtype=torch.uint8)
+            if self.rank == root:
+                for r in range(self.size):
+                    part = mine if r == root else torch.empty(counts[r], dtype=torch.uint8)
+                    if r != root and counts[r]:
+                        dist.recv(part, src=self._global(r), group=self.group)
+                    if part.numel():
+                        self._h2d(recv + displs[r], part)
+            elif send_bytes:
+                dist.send(mine, dst=self._global(root), group=self.group)
+            return 0
+        except Exception as e:
+            print("TorchDistComm.gatherv failed:", e, flush=True)
+            return 1
+
+    def _scatterv(self, user, send, counts, displs, recv, recv_bytes, root, stream):
+        try:
+            if self.rank == root:
+                for r in range(self.size):
+                    if not counts[r]:
+                        continue
+                    part = self._d2h(send + displs[r], counts[r], stream)
+                    if r == root:
+                        self._h2d(recv, part)
+                    else:
+                        dist.send(part, dst=self._global(r), group=self.group)
+            elif recv_bytes:
+                mine = torch.empty(recv_bytes, dtype=torch.uint8)
+                dist.recv(mine, src=self._global(root), group=self.group)
+                self._h2d(recv, mine)
+            return 0
+        except Exception as e:
+            print("TorchDistComm.scatterv failed:", e, flush=True)
+            return 1
+
     def close(self):
         pass
+
+
+def slab_partition(labels, mg_levels, size, use_gauss_seidel, options=None):
+    """mgps_slab_partition: the cuts of a `size`-rank slab run, balanced by active cells where the smoother allows it.
+    Returns a list of size + 1 plane indices; rank r owns [cuts[r], cuts[r + 1])."""
+    labels = _np_u8(labels)
+    nz, ny, nx = labels.shape
+    cuts = (C.c_int * (size + 1))()
+    opt = options if options is not None else default_options()
+    check(lib().mgps_slab_partition(nx, ny, nz, _p(labels), int(mg_levels), int(size), int(bool(use_gauss_seidel)), C.byref(opt), cuts))
+    return [int(v) for v in cuts]
 
 
 class SlabSolver(GeometricMultigridPoissonSolver):
@@ -178,22 +231,28 @@ class SlabSolver(GeometricMultigridPoissonSolver):
     come from new_grid()/to_device(), which surround them with the two ghost planes the exchange
     writes into."""
 
-    def __init__(self, labels, slab_weights, mg_levels, use_gauss_seidel, comm, device=None, options=None):
+    def __init__(self, labels, slab_weights, mg_levels, use_gauss_seidel, comm, device=None, options=None, splits=None):
+        """splits: the cuts (slab_partition); None = nz / size planes per rank"""
         labels = _np_u8(labels)
         w = [_np_f32(a) for a in slab_weights]
         nz, ny, nx = labels.shape
-        nzl = nz // comm.size
-        assert nz % comm.size == 0, "nz must divide evenly over the ranks"
+        if splits is None:
+            assert nz % comm.size == 0, "nz must divide evenly over the ranks"
+            splits = [nz // comm.size * r for r in range(comm.size + 1)]
+        assert len(splits) == comm.size + 1
+        nzl = splits[comm.rank + 1] - splits[comm.rank]
         assert w[0].shape == (nzl, ny, nx + 1) and w[1].shape == (nzl, ny + 1, nx) and w[2].shape == (nzl + 1, ny, nx)
+        self.splits = [int(v) for v in splits]
         opt = options if options is not None else default_options()
         if device is not None:
             opt.device = torch.device(device).index if not isinstance(device, int) else device
         self.comm = comm
         self.h = C.c_void_p()
+        cuts = (C.c_int * (comm.size + 1))(*self.splits)
         check(
-            lib().mgps_create_slab(
+            lib().mgps_create_slab_ranges(
                 C.byref(self.h), nx, ny, nz, _p(labels), _p(w[0]), _p(w[1]), _p(w[2]), int(mg_levels),
-                int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct),
+                int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct), cuts,
             )
         )
         self.shape = (nzl, ny, nx)
@@ -228,6 +287,10 @@ class SlabSolver(GeometricMultigridPoissonSolver):
         local = grid.detach().contiguous()
         if dist.get_backend(group) != "nccl":
             local = local.cpu()
-        parts = [torch.empty_like(local) for _ in range(self.comm.size)]
-        dist.all_gather(parts, local, group=group)
-        return torch.cat(parts).cpu().numpy()
+        planes = [(self.splits[r + 1] - self.splits[r]) >> level for r in range(self.comm.size)]
+        most = max(planes)
+        padded = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+        parts = [torch.empty_like(padded) for _ in range(self.comm.size)]
+        dist.all_gather(parts, padded, group=group)
+        return torch.cat([p[:n] for p, n in zip(parts, planes)]).cpu().numpy()

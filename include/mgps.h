@@ -316,6 +316,14 @@ typedef struct mgps_comm {
     /* root sends chunk r of send_dev to rank r; everybody receives `bytes` into recv_dev */
     int (*scatter)(void *user, const void *send_dev, void *recv_dev, size_t bytes, int root, void *hip_stream);
     void (*destroy)(void *user);
+    /* The same two with a share per rank (slabs balanced by active planes differ in size; NULL is allowed as long as all
+     * slabs are equal).  gatherv: every rank sends send_bytes; root receives counts[r] bytes from rank r at byte offset
+     * displs[r] of recv_dev (counts / displs are host arrays, read on root only).  scatterv: root sends counts[r] bytes from
+     * offset displs[r] of send_dev to rank r; every rank receives recv_bytes into recv_dev. */
+    int (*gatherv)(void *user, const void *send_dev, size_t send_bytes, void *recv_dev, const size_t *counts, const size_t *displs,
+                   int root, void *hip_stream);
+    int (*scatterv)(void *user, const void *send_dev, const size_t *counts, const size_t *displs, void *recv_dev, size_t recv_bytes,
+                    int root, void *hip_stream);
 } mgps_comm;
 
 /* RCCL transport.  Rank 0 calls mgps_rccl_unique_id and ships the 128 bytes to the other ranks by
@@ -342,6 +350,20 @@ void mgps_comm_destroy(mgps_comm *comm);
 int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
                      const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
                      int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm);
+/* The cuts of a slab run.  out_splits[0 .. size]: rank r owns the fine planes [out_splits[r], out_splits[r + 1]).  With the
+ * Jacobi smoother the cuts are placed so that every rank gets the same number of ACTIVE cells (whole planes of the collapse
+ * level, at least 16 fine planes apiece): the EXTERIOR padding of the expanded grid (2^(levels-1) planes at either end) would
+ * otherwise leave the first and the last rank half empty -- at 1024^3 on 8 ranks the busiest rank owns 112 instead of 128
+ * planes.  With Gauss-Seidel every cut must be a multiple of 16 planes of EVERY distributed level (the tile colouring), which
+ * leaves the even cut.  Every rank must pass the same arguments and gets the same cuts. */
+int mgps_slab_partition(int nx, int ny, int nz, const uint8_t *labels_global_host, int mg_levels, int size, int use_gauss_seidel,
+                        const mgps_options *opt, int *out_splits);
+/* mgps_create_slab with explicit cuts (from mgps_slab_partition, or the caller's own: every cut an even plane count, a
+ * multiple of 16 with Gauss-Seidel, at least 16 planes per rank).  The slab weights cover this rank's planes
+ * [splits[rank], splits[rank + 1]).  Slabs of different sizes need comm->gatherv / scatterv. */
+int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
+                            const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
+                            int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm, const int *splits);
 /* owned plane range [z0, z1) of `level` on this rank (levels past the distributed ones: the range
  * of the collapse level) and the number of distributed levels */
 int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1);

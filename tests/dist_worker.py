@@ -180,6 +180,72 @@ def plane_mode():
         dist.barrier()
 
 
+def balanced_mode():
+    """Slabs of different sizes (mgps_slab_partition / explicit cuts): the liquid sits at the low end of a long grid, the
+    balanced cuts give the ranks equal active cells instead of equal planes, the collapse gathers / scatters shares of
+    different sizes (gatherv / scatterv).  Must reproduce the whole-grid solver like the even cut does."""
+    import geometricmultigridpressuresolver_amd as G
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd.distributed import SlabSolver, TorchDistComm, slab_partition
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    if size == 2:
+        lab, w, off, lev, dx = make_domain("simple", 40, 4, (128, 64, 64))
+        min_cells = 10000
+    else:
+        bl, bw, dx = D.build_complex_domain((184, 48, 48), dtype=np.float32)
+        lab, w, off, lev = D.expand_domain(bl, bw, levels=4, solver_shape=(256, 64, 64))
+        min_cells = 10000
+    # (min_cells_per_rank = 10000 keeps two levels distributed on these grids: every rank then needs 32 fine planes, the rest is free)
+    opt = G.default_options()
+    opt.min_cells_per_rank = min_cells
+    nz = lab.shape[0]
+    b_glob = D.random_rhs(lab, dx)
+    cases = [(False, slab_partition(lab, lev, size, False, opt))]
+    if size == 2:
+        cases.append((True, [0, 32, nz]))  # Gauss-Seidel with the caller's own cuts (multiples of 16 on both distributed levels)
+    assert slab_partition(lab, lev, size, True, opt) == [nz // size * r for r in range(size + 1)]  # GS: the even cut
+    for use_gs, cuts in cases:
+        planes = [cuts[r + 1] - cuts[r] for r in range(size)]
+        assert len(set(planes)) > 1, cuts  # really uneven
+        active = [int(D.active_mask(lab[cuts[r] : cuts[r + 1]]).sum()) for r in range(size)]
+        even = [int(D.active_mask(lab[nz // size * r : nz // size * (r + 1)]).sum()) for r in range(size)]
+        assert max(active) < max(even), (active, even)
+        z0, z1 = cuts[rank], cuts[rank + 1]
+        slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
+        for deep in (1, 0):
+            o = G.default_options()
+            o.min_cells_per_rank, o.deep_band_halo = min_cells, deep
+            slab = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=o, splits=cuts)
+            whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0)
+            assert slab.slab_range(0) == (z0, z1) and slab.distributed_levels == 2, (slab.slab_range(0), slab.distributed_levels)
+            bw, bs = whole.to_device(b_glob), slab.to_device(b_glob[z0:z1])
+            xw, xs = whole.to_device(b_glob * 3.0), slab.to_device(b_glob[z0:z1] * 3.0)
+            yw, ys = whole.new_grid(), slab.new_grid()
+            whole.applyPoissonMatrix(yw, xw)
+            slab.applyPoissonMatrix(ys, xs)
+            assert np.array_equal(slab.gather_global(ys), yw.cpu().numpy())
+            assert abs(slab.dotProduct(xs, bs) - whole.dotProduct(xw, bw)) <= 1e-12 * abs(whole.dotProduct(xw, bw))
+            xw, xs = whole.new_grid(), slab.new_grid()
+            for it in range(2):
+                whole.applyVCycle(xw, bw, it > 0)
+                slab.applyVCycle(xs, bs, it > 0)
+                err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
+                assert err < 1e-6, (use_gs, deep, it, err)
+            xw, xs = whole.new_grid(), slab.new_grid()
+            sw = whole.solveGeometricConjugateGradient(xw, bw, 1e-5, 200, True)
+            ss = slab.solveGeometricConjugateGradient(xs, bs, 1e-5, 200, True)
+            assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+            assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
+            if rank == 0:
+                print(f"  balanced cuts {cuts} gs={use_gs} deep={deep}: active per rank {active} (even cut {even}), pcg it {ss['iterations']}", flush=True)
+            slab.close()
+            whole.close()
+            dist.barrier()
+
+
 def cpu_mode():
     """Slab emulation on the CPU (no GPU involved): tests/slab_emulation.py over gloo vs the
     whole-grid oracle."""
@@ -274,6 +340,8 @@ if __name__ == "__main__":
         gpu_mode()
     elif mode == "plane":
         plane_mode()
+    elif mode == "balanced":
+        balanced_mode()
     elif mode == "rccl1":
         rccl_single_rank_mode()
     elif mode == "cpu":

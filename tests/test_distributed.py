@@ -64,6 +64,15 @@ def test_slabs_plane_marching_sweep(nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_slabs_balanced_by_active_cells(nproc):
+    """mgps_slab_partition + mgps_create_slab_ranges: slabs of different sizes (equal active cells instead of equal planes),
+    the collapse through gatherv / scatterv; Jacobi with the library's cuts, Gauss-Seidel with the caller's own."""
+    out = run_workers("balanced", nproc, 420)
+    print(out[-800:])
+
+
+@pytest.mark.gpu
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)
