@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-frac512", action="store_true", help="skip the extra 512^3 smoother measurement (roofline.frac_512)")
     ap.add_argument("--force-slab", action="store_true", help="use the multi-GPU code path (RCCL transport, slab solver) even with one rank")
+    ap.add_argument("--even-slabs", action="store_true", help="multi-GPU: nz / N planes per rank instead of cuts balanced by active cells")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N-rank path on a box with fewer GPUs: ranks share the GPUs there are, gloo process group, "
                     "host-staged transport (RCCL refuses two ranks on one device).  The line it prints is marked and is not a measurement")
@@ -237,19 +238,24 @@ def main():
     levels = args.levels or default_levels(n)
     use_gs = args.smoother == "gs"
     assert n % world == 0 and (n // world) % 16 == 0, "grid planes per rank must be a multiple of 16"
-    nzl = n // world
-    z0, z1 = rank * nzl, (rank + 1) * nzl
-
-    # every rank: labels of the whole grid (1 byte per cell), weights and rhs of its own Z-slab only
-    lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
     opt = G.default_options()
     opt.precision = 1 if args.precision == "mixed" else 0
     opt.pre_sweeps = opt.post_sweeps = args.sweeps
+    # the cuts: even, or (Jacobi) balanced by active cells -- the EXTERIOR padding leaves the end ranks half empty otherwise
+    cuts = [n // world * r for r in range(world + 1)]
+    if slab_run and world > 1 and not args.even_slabs:
+        from geometricmultigridpressuresolver_amd.distributed import slab_partition
+
+        cuts = slab_partition(D.interior_cube_slab(n, levels, 0, 1)[0], levels, world, use_gs, opt)
+    z0, z1 = cuts[rank], cuts[rank + 1]
+
+    # every rank: labels of the whole grid (1 byte per cell), weights and rhs of its own Z-slab only
+    lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
     if slab_run:
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
         comm = TorchDistComm() if args.rehearse_gloo else RcclComm(device=local_rank)
-        solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt)
+        solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt, splits=cuts)
     else:
         solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank, options=opt)
     del w
@@ -312,6 +318,7 @@ def main():
             "levels": levels,
             "smoother": "tiled_gs" if use_gs else "jacobi",
             "parallelism": f"zslab{world}",
+            "slab_cuts": cuts,
             "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
@@ -329,8 +336,8 @@ def main():
             "ms_per_launch": t_sweep * 1e3,
             "launches": smooth_groups,
             "cells_per_launch": swept,
-            "cells_allocated": cells / world,
-            "achieved_over_allocated_cells": SMOOTHER_BYTES_PER_CELL * (cells / world) / t_sweep / 1e9,
+            "cells_allocated": float(n) * n * (z1 - z0),
+            "achieved_over_allocated_cells": SMOOTHER_BYTES_PER_CELL * (float(n) * n * (z1 - z0)) / t_sweep / 1e9,
             "note": "per GPU; achieved = 13 B x cells the launch visits (active chunks only) / mean launch time (HIP events on the solver's stream)",
         },
     }

@@ -1691,7 +1691,12 @@ try {
     if (nz % unit != 0) return MGPS_OK;
     const int units = nz / unit, minUnits = std::max(1, (kTile << (D - 1)) / unit);
     if (units < size * minUnits) return MGPS_OK;
-    // active cells per unit of planes
+    // Load of a unit of planes: active cells + 30 x BOUNDARY cells.  The weights are measured (tools/slab_compute_bound.py, 1024^3,
+    // one rank at a time with a null transport): a rank's cycle costs 0.0103 ms per million active cells and 0.101 ms per
+    // million band cells (four fused band stages of three passes each, gather-bound) -- and the band is three cells deep,
+    // i.e. about 3 x the BOUNDARY cells (all this function sees are labels); rank 0 also runs the collapsed tail, about
+    // 0.2 ms of launch-bound small levels = 2e7 active cells' worth, which everybody waits for
+    constexpr double kBoundaryWeight = 30.0, kTailLoad = 2.0e7;
     std::vector<double> load(size_t(units), 0.0);
     const size_t plane = size_t(nx) * ny;
     {
@@ -1701,9 +1706,12 @@ try {
             pool.emplace_back([&, t] {
                 for (int u = t; u < units; u += nt) {
                     const uint8_t *p = labels + size_t(u) * unit * plane;
-                    size_t n = 0;
-                    for (size_t c = 0; c < size_t(unit) * plane; ++c) n += isActive(p[c]);
-                    load[size_t(u)] = double(n);
+                    size_t n = 0, nb = 0;
+                    for (size_t c = 0; c < size_t(unit) * plane; ++c) {
+                        n += isActive(p[c]);
+                        nb += p[c] == MGPS_BOUNDARY_CELL;
+                    }
+                    load[size_t(u)] = double(n) + kBoundaryWeight * double(nb);
                 }
             });
         for (auto &th : pool) th.join();
@@ -1724,7 +1732,8 @@ try {
             for (int v = (r - 1) * minUnits; v <= u - minUnits; ++v) {
                 if (best[size_t(r) - 1][size_t(v)] >= kInf) continue;
                 // (a whisker per plane keeps slabs of equal load equal in size as well)
-                const double cost = std::max(best[size_t(r) - 1][size_t(v)], prefix[size_t(u)] - prefix[size_t(v)] + 1e-9 * total * double(u - v) / units);
+                const double cost = std::max(best[size_t(r) - 1][size_t(v)], prefix[size_t(u)] - prefix[size_t(v)] + (r == 1 ? kTailLoad : 0.0) +
+                                                                                1e-9 * total * double(u - v) / units);
                 if (cost < best[size_t(r)][size_t(u)]) {
                     best[size_t(r)][size_t(u)] = cost;
                     from[size_t(r)][size_t(u)] = v;
@@ -1732,7 +1741,8 @@ try {
             }
     if (best[size_t(size)][size_t(units)] >= kInf) return MGPS_OK;
     double evenWorst = 0.0;  // what the even cut costs
-    for (int r = 0; r < size; ++r) evenWorst = std::max(evenWorst, prefix[size_t(out_splits[r + 1] / unit)] - prefix[size_t(out_splits[r] / unit)]);
+    for (int r = 0; r < size; ++r)
+        evenWorst = std::max(evenWorst, prefix[size_t(out_splits[r + 1] / unit)] - prefix[size_t(out_splits[r] / unit)] + (r == 0 ? kTailLoad : 0.0));
     if (best[size_t(size)][size_t(units)] >= 0.98 * evenWorst) return MGPS_OK;  // nothing to gain: keep the even cut
     for (int r = size, u = units; r > 0; --r) {
         out_splits[r] = u * unit;

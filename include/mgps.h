@@ -351,10 +351,10 @@ int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uin
                      const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
                      int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm);
 /* The cuts of a slab run.  out_splits[0 .. size]: rank r owns the fine planes [out_splits[r], out_splits[r + 1]).  With the
- * Jacobi smoother the cuts are placed so that every rank gets the same number of ACTIVE cells (whole planes of the collapse
- * level, at least 16 fine planes apiece): the EXTERIOR padding of the expanded grid (2^(levels-1) planes at either end) would
- * otherwise leave the first and the last rank half empty -- at 1024^3 on 8 ranks the busiest rank owns 112 instead of 128
- * planes.  With Gauss-Seidel every cut must be a multiple of 16 planes of EVERY distributed level (the tile colouring), which
+ * Jacobi smoother the cuts minimise the largest per-rank load (whole planes of the collapse level, at least 16 fine planes
+ * apiece), load = active cells + 30 x BOUNDARY cells (the three-deep band costs ten times a cell of the full sweeps) + the
+ * collapsed tail on rank 0: the EXTERIOR padding of the expanded grid (2^(levels-1) planes at either end) would otherwise
+ * leave the first and the last rank half empty and the middle ranks with 1 / (size - 1) of the work each.  With Gauss-Seidel every cut must be a multiple of 16 planes of EVERY distributed level (the tile colouring), which
  * leaves the even cut.  Every rank must pass the same arguments and gets the same cuts. */
 int mgps_slab_partition(int nx, int ny, int nz, const uint8_t *labels_global_host, int mg_levels, int size, int use_gauss_seidel,
                         const mgps_options *opt, int *out_splits);
