@@ -1695,8 +1695,8 @@ try {
     // one rank at a time with a null transport): a rank's cycle costs 0.0103 ms per million active cells and 0.101 ms per
     // million band cells (four fused band stages of three passes each, gather-bound) -- and the band is three cells deep,
     // i.e. about 3 x the BOUNDARY cells (all this function sees are labels); rank 0 also runs the collapsed tail, about
-    // 0.2 ms of launch-bound small levels = 2e7 active cells' worth, which everybody waits for
-    constexpr double kBoundaryWeight = 30.0, kTailLoad = 2.0e7;
+    // 0.2 ms of launch-bound small levels there = 2.3 % of the whole load, which everybody waits for
+    constexpr double kBoundaryWeight = 30.0, kTailShare = 0.023;
     std::vector<double> load(size_t(units), 0.0);
     const size_t plane = size_t(nx) * ny;
     {
@@ -1719,6 +1719,7 @@ try {
     double total = 0;
     for (double v : load) total += v;
     if (total == 0) return MGPS_OK;
+    const double kTailLoad = kTailShare * total;
     // the cuts that minimise the largest per-rank load (dynamic programme over unit boundaries: units <= nz / 16, ranks <= 8),
     // every rank at least minUnits; ties go to the more even plane counts
     std::vector<double> prefix(size_t(units) + 1, 0.0);
