@@ -24,3 +24,9 @@ def trim_host_cache():
     """Return the page-locked staging blocks the set-up keeps between solvers (mgps_trim_host_cache)."""
     lib().mgps_trim_host_cache.restype = None
     lib().mgps_trim_host_cache()
+
+
+def trim_device_cache():
+    """Return the device blocks released solvers left for the next one (mgps_trim_device_cache)."""
+    lib().mgps_trim_device_cache.restype = None
+    lib().mgps_trim_device_cache()

@@ -52,6 +52,7 @@ class Options(C.Structure):
         ("post_sweeps", C.c_int),
         ("stencil_path", C.c_int),
         ("precision", C.c_int),
+        ("host_setup", C.c_int),
     ]
 
 

@@ -453,13 +453,14 @@ struct DevPool {
     std::vector<void *> blocks;
     ~DevPool()
     {
-        for (void *b : blocks) (void)hipFree(b);
+        (void)hipDeviceSynchronize();  // (deviceFree keeps the blocks for the next call and does not wait for queued kernels)
+        for (void *b : blocks) (void)mgps::deviceFree(b);
     }
     template <class T>
     T *get(size_t count)
     {
         void *p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::bad_alloc();
+        if (mgps::deviceAlloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != 0) throw std::bad_alloc();
         blocks.push_back(p);
         return static_cast<T *>(p);
     }

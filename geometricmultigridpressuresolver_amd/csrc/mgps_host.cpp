@@ -314,6 +314,51 @@ static void buildBand(HostLevel &L, int width)
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
 
+// The chunk list of a level (HostLevel::chunks, chunkCells) from the activity flags of its runs of 256 cells.
+void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine)
+{
+    const Dims d = L.d;
+    std::vector<int32_t> fine, coarse;
+    for (int64_t q = 0; q < nfine; ++q)
+        if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
+    constexpr int kRatio = kChunkCells / kWaveChunkCells;
+    for (int64_t q = 0; q < nfine; q += kRatio) {
+        bool act = false;
+        for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
+        if (act) coarse.push_back(int32_t(q / kRatio));
+    }
+    L.chunks.swap(coarse);
+    L.chunkCells = kChunkCells;
+    if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
+        L.chunks.swap(fine);
+        L.chunkCells = kWaveChunkCells;
+    }
+    // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
+    // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
+    // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
+    // strip (64 KiB) apart instead.  Pure locality: any order is correct.
+    constexpr int kStripRows = 32;
+    if (size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows) {
+        const size_t cpr = size_t(L.chunkCells);
+        auto key = [&](int32_t c) {
+            const size_t cell = size_t(c) * cpr;
+            const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
+            return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
+        };
+        // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
+        const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
+        std::vector<std::vector<int32_t>> strips(nstrips);
+        for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
+        size_t at = 0;
+        for (auto &sv : strips) {
+            std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
+            at += sv.size();
+        }
+    }
+    if (L.chunkCells == kWaveChunkCells)
+        while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
+}
+
 // Everything the device needs for the planes [z0, z1) of level G (the whole level when z0 = 0,
 // z1 = nz): local labels, band list, cell codes (with one ghost plane of plain labels on each side),
 // the operator rows of the general BOUNDARY cells and the Gauss-Seidel tile lists.
@@ -361,45 +406,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
                     fineAct[size_t(q)] = act;
                 }
             }, 1 << 12);
-            std::vector<int32_t> fine, coarse;
-            for (int64_t q = 0; q < nfine; ++q)
-                if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
-            constexpr int kRatio = kChunkCells / kWaveChunkCells;
-            for (int64_t q = 0; q < nfine; q += kRatio) {
-                bool act = false;
-                for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
-                if (act) coarse.push_back(int32_t(q / kRatio));
-            }
-            L.chunks.swap(coarse);
-            L.chunkCells = kChunkCells;
-            if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
-                L.chunks.swap(fine);
-                L.chunkCells = kWaveChunkCells;
-            }
-            // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
-            // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
-            // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
-            // strip (64 KiB) apart instead.  Pure locality: any order is correct.
-            constexpr int kStripRows = 32;
-            if (size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows) {
-                const size_t cpr = size_t(L.chunkCells);
-                auto key = [&](int32_t c) {
-                    const size_t cell = size_t(c) * cpr;
-                    const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
-                    return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
-                };
-                // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
-                const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
-                std::vector<std::vector<int32_t>> strips(nstrips);
-                for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
-                size_t at = 0;
-                for (auto &sv : strips) {
-                    std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
-                    at += sv.size();
-                }
-            }
-            if (L.chunkCells == kWaveChunkCells)
-                while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
+            chunkListsFromFlags(L, fineAct.data(), nfine);
             L.planeBlocks.clear();
             L.planeZc = planeSweepZc(d.nx, d.ny, d.nz);
             if (L.planeZc) {
@@ -709,7 +716,7 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
     const int32_t loff[6] = {-1, 1, -ext[0], ext[0], -ext[0] * ext[1], ext[0] * ext[1]};
     std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
     std::vector<int64_t> updateW, readW;  // window cells of the nodes
-    std::vector<int32_t> updateL;         // and the update nodes' indices into `id`
+    std::vector<int32_t> updateL, readL;  // and the nodes' indices into `id`
     for (int32_t t : owned) {
         const int32_t li = localOf(W.seedCell[size_t(t)]);
         id[size_t(li)] = int32_t(updateW.size());
@@ -749,6 +756,7 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
                     } else {
                         v = -int32_t(readW.size()) - 2;
                         readW.push_back(cq);
+                        readL.push_back(cl + loff[q]);
                     }
                 }
                 nbrTmp.push_back(v);
@@ -759,17 +767,39 @@ int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int de
     }
     for (int dist = depth; dist < kBandMaxDepth; ++dist) g.cnt[dist] = g.cnt[depth - 1];
     const int32_t nUpd = int32_t(updateW.size()), nRead = int32_t(readW.size());
+    // Canonical node order (the walk's discovery order is an accident of the queue; the device-side builder, which has no
+    // queue, produces this one): the owned nodes as given, the nodes of every further distance and the read-only nodes by
+    // their position in the dilated bounding box (k, j, i).  The kernel computes every node on its own: order is free.
+    const size_t nU = size_t(nUpd), nR = size_t(nRead);
+    std::vector<int32_t> updOrder(nU), readOrder(nR), updNew(nU), readNew(nR);
+    for (int32_t n = 0; n < nUpd; ++n) updOrder[size_t(n)] = n;
+    for (int32_t n = 0; n < nRead; ++n) readOrder[size_t(n)] = n;
+    for (int dist = 1; dist < depth; ++dist)
+        std::sort(updOrder.begin() + g.cnt[dist - 1], updOrder.begin() + (dist + 1 < depth ? g.cnt[dist] : nUpd),
+                  [&](int32_t a, int32_t b) { return updateL[size_t(a)] < updateL[size_t(b)]; });
+    std::sort(readOrder.begin(), readOrder.end(), [&](int32_t a, int32_t b) { return readL[size_t(a)] < readL[size_t(b)]; });
+    for (int32_t n = 0; n < nUpd; ++n) updNew[size_t(updOrder[size_t(n)])] = n;
+    for (int32_t n = 0; n < nRead; ++n) readNew[size_t(readOrder[size_t(n)])] = n;
     g.neighbours.resize(nbrTmp.size());
-    for (size_t q = 0; q < nbrTmp.size(); ++q) {
-        const int32_t v = nbrTmp[q];
-        g.neighbours[q] = uint16_t(v >= 0 ? v : (v == kZero ? nUpd + nRead : nUpd + (-v - 2)));
+    {
+        std::vector<int32_t> entryOld;
+        entryOld.swap(g.updateEntry);
+        g.updateEntry.resize(size_t(nUpd));
+        for (int32_t n = 0; n < nUpd; ++n) {
+            const int32_t o = updOrder[size_t(n)];
+            g.updateEntry[size_t(n)] = entryOld[size_t(o)];
+            for (int q = 0; q < 6; ++q) {
+                const int32_t v = nbrTmp[6 * size_t(o) + q];
+                g.neighbours[6 * size_t(n) + q] = uint16_t(v >= 0 ? updNew[size_t(v)] : (v == kZero ? nUpd + nRead : nUpd + readNew[size_t(-v - 2)]));
+            }
+        }
     }
     g.updateCell.resize(updateW.size());
     g.readCell.resize(readW.size());
-    for (size_t n = 0; n < updateW.size(); ++n)
-        if (!W.deviceCell(size_t(updateW[n]), g.updateCell[n])) return 2;
-    for (size_t n = 0; n < readW.size(); ++n)
-        if (!W.deviceCell(size_t(readW[n]), g.readCell[n])) return 2;
+    for (int32_t n = 0; n < nUpd; ++n)
+        if (!W.deviceCell(size_t(updateW[size_t(updOrder[size_t(n)])]), g.updateCell[size_t(n)])) return 2;
+    for (int32_t n = 0; n < nRead; ++n)
+        if (!W.deviceCell(size_t(readW[size_t(readOrder[size_t(n)])]), g.readCell[size_t(n)])) return 2;
     return 0;
 }
 
@@ -1069,8 +1099,6 @@ static void buildTileLists(HostLevel &L, int tileZOffset)
 {
     const Dims d = L.d;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    for (auto *v : {&L.tilesOdd, &L.tilesEven, &L.pureOdd, &L.pureEven, &L.mixedOdd, &L.mixedEven}) v->clear();
-    L.activeCells = 0;
     // per tile: 0 = no active cell, else (active count << 1) | all-INTERIOR
     std::vector<int64_t> kind;
     parallelCollect<int64_t>(int64_t(tx) * ty * tz, 256, kind, [&](int64_t b, int64_t e, std::vector<int64_t> &out) {
@@ -1088,8 +1116,18 @@ static void buildTileLists(HostLevel &L, int tileZOffset)
             out.push_back((active << 1) | int64_t(interior == int64_t(kTile) * kTile * kTile));
         }
     });
+    tileListsFromKinds(L, kind.data(), tileZOffset);
+}
+// per tile `kind`: 0 = no active cell, else (active cells << 1) | all 4096 cells INTERIOR
+template <class K>
+void tileListsFromKindsT(HostLevel &L, const K *kind, int tileZOffset)
+{
+    const Dims d = L.d;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    for (auto *v : {&L.tilesOdd, &L.tilesEven, &L.pureOdd, &L.pureEven, &L.mixedOdd, &L.mixedEven}) v->clear();
+    L.activeCells = 0;
     for (int t = 0; t < tx * ty * tz; ++t) {
-        const int64_t active = kind[size_t(t)] >> 1;
+        const int64_t active = int64_t(kind[size_t(t)]) >> 1;
         if (!active) continue;
         const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
         L.activeCells += active;
@@ -1099,6 +1137,8 @@ static void buildTileLists(HostLevel &L, int tileZOffset)
         else (odd ? L.mixedOdd : L.mixedEven).push_back(t);
     }
 }
+void tileListsFromKinds(HostLevel &L, const int64_t *kind, int tileZOffset) { tileListsFromKindsT(L, kind, tileZOffset); }
+void tileListsFromKinds(HostLevel &L, const int32_t *kind, int tileZOffset) { tileListsFromKindsT(L, kind, tileZOffset); }
 static void buildTileBoundaryOffsets(HostLevel &L)
 {
     const Dims d = L.d;
@@ -1616,6 +1656,27 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.
     const int rc = (levels > 1 || forceCoarseSolver) ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
     lap.lap("hierarchy: coarse factor");
+    if (rc != MGPS_OK) {
+        delete H;
+        return rc;
+    }
+    *out = H;
+    return MGPS_OK;
+}
+
+int mgps::hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int levels, const uint8_t *coarsestLabels, const mgps_options &o,
+                         bool needCoarseSolver)
+{
+    auto H = new mgps_hierarchy();
+    H->light = true;
+    H->bandWidth = o.band_width;
+    H->levels = levels;
+    H->lv.resize(size_t(levels));
+    for (int l = 0; l < levels; ++l) H->lv[size_t(l)].d = Dims{nx >> l, ny >> l, nz >> l};
+    HostLevel &C = H->lv[size_t(levels - 1)];
+    C.labels.resize(C.d.cells());
+    std::memcpy(C.labels.data(), coarsestLabels, C.d.cells());
+    const int rc = needCoarseSolver ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
     if (rc != MGPS_OK) {
         delete H;
         return rc;

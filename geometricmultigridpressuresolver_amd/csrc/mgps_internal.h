@@ -185,6 +185,15 @@ int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const
 void checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int *pass);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
                     const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
+// pieces of the host builder the device-side set-up shares: the chunk list of a level from the activity flags of its
+// runs of 256 cells, and the Gauss-Seidel tile lists from the per-tile kinds ((active cells << 1) | all INTERIOR)
+void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine);
+void tileListsFromKinds(HostLevel &L, const int64_t *kind, int tileZOffset);
+void tileListsFromKinds(HostLevel &L, const int32_t *kind, int tileZOffset);
+// A hierarchy that knows the extents of its levels and the labels of the coarsest one only (device-side set-up: the
+// labels of the other levels live on the device) -- what the coarsest level's direct solver needs (MG.cpp:288-411).
+int hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int levels, const uint8_t *coarsestLabels, const mgps_options &o,
+                   bool needCoarseSolver);
 void setLastGlobalError(const std::string &msg);
 const char *lastGlobalError();
 // No C++ exception crosses the C ABI: every extern "C" entry point that can allocate is a function-try-block ending in
@@ -347,6 +356,32 @@ int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, d
 int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first);
 int launchWiden(void *stream, double *dst, const float *src, size_t n);
 int launchNarrow(void *stream, float *dst, const double *src, size_t n);
+// device memory with a per-device cache of released blocks (mgps_solver.hip); both return a hipError_t as int;
+// deviceFree does not synchronise
+int deviceAlloc(void **p, size_t bytes);
+int deviceFree(void *p);
+void deviceTrim();
+// ---- device-side set-up (mgps_setup.hip): see the kernels there ------------------------------------------------------
+int launchCoarsenLabels(void *stream, const Dims &fine, const uint8_t *fineLab, uint8_t *coarseLab, int *activeFlag);
+int launchAnyActive(void *stream, const Dims &d, const uint8_t *lab, int *activeFlag);
+int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
+int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab);
+int launchInteriorCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
+size_t scanScratchInts(size_t n);
+int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch);  // out: n + 1 entries
+int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind);
+int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band);
+int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
+                       uint8_t *diagS, int32_t *general, int *violations);
+int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
+                    const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows);
+int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out);
+int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t *chunkFlags, uint8_t *planeFlags, int zc);
+int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
+                          int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken);
+int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *groupAt, const int32_t *updateAt, const int32_t *readAt,
+                         int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours, int32_t *readCell, int *broken);
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)
@@ -362,6 +397,7 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 struct mgps_hierarchy {
     int levels = 0;
     int bandWidth = 3;
+    bool light = false;  // hierarchyLight: only the extents of the levels and the labels of the coarsest one
     std::vector<mgps::HostLevel> lv;
     // coarsest-level direct solver
     int coarseN = 0;

@@ -1,0 +1,778 @@
+// mgps_setup.hip -- the multigrid hierarchy and every list of a whole-grid level, built on the device.
+//
+// What the reference's constructor does on the host (HDK_GeometricMultigridPoissonSolver.cpp:141-431 = "MG.cpp":
+// buildCoarseCellLabels MG.cpp:238-253 / Ops.cpp:23-163, buildBoundaryCells MG.cpp:279-281 / Ops.cpp:165-469) and what
+// this library adds around it (operator rows, cell codes, activity lists, Gauss-Seidel tile lists, the groups of the fused
+// band stage) as kernels over device labels: a plugin that rebuilds its solver every sub-step (Plug.cpp:463) then never
+// moves a label across PCIe.  Every array equals the host builder's (mgps_host.cpp) entry for entry -- that builder stays
+// as the checker (tests/test_device_setup.py) and as the builder of slab runs.
+//
+// Labels are read as the reference's values (0 INTERIOR, 1 EXTERIOR, 2 DIRICHLET, 3 BOUNDARY); every test also accepts
+// the patched device codes (>= 4: simple BOUNDARY cells) as BOUNDARY.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "mgps_internal.h"
+
+namespace mgps {
+
+namespace {
+
+inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + per - 1) / per); }
+inline hipStream_t S(void *stream) { return static_cast<hipStream_t>(stream); }
+
+__device__ __forceinline__ bool activeCode(unsigned c) { return c == MGPS_INTERIOR_CELL || c >= MGPS_BOUNDARY_CELL; }
+__device__ __forceinline__ size_t cellIdx(const Dims &d, int i, int j, int k) { return (size_t(k) * d.ny + j) * d.nx + i; }
+__device__ __forceinline__ size_t cellCount(const Dims &d) { return size_t(d.nx) * d.ny * d.nz; }
+
+// ---- labels of the coarser levels (Ops.cpp:23-163) -------------------------------------------------------------------
+
+// a coarse cell is DIRICHLET if any of its 8 children is, else INTERIOR if any child is active, else EXTERIOR
+// flags[0] = 1 when the coarse level holds an active cell ("solvable", MG.cpp:241-246)
+__global__ __launch_bounds__(256) void coarsenLabelsKernel(Dims fd, Dims cd, const uint8_t *__restrict__ fine, uint8_t *__restrict__ coarse,
+                                                           int *__restrict__ flags)
+{
+    const size_t c = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    bool active = false;
+    if (c < cellCount(cd)) {
+        const int i = int(c % cd.nx), j = int((c / cd.nx) % cd.ny), k = int(c / (size_t(cd.nx) * cd.ny));
+        const uint8_t *r0 = fine + cellIdx(fd, 2 * i, 2 * j, 2 * k);
+        const size_t plane = size_t(fd.nx) * fd.ny;
+        const unsigned v[4] = {*reinterpret_cast<const uint16_t *>(r0), *reinterpret_cast<const uint16_t *>(r0 + fd.nx),
+                               *reinterpret_cast<const uint16_t *>(r0 + plane), *reinterpret_cast<const uint16_t *>(r0 + plane + fd.nx)};
+        bool dir = false, act = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned a = v[q] & 0xffu, b = v[q] >> 8;
+            dir = dir || a == MGPS_DIRICHLET_CELL || b == MGPS_DIRICHLET_CELL;
+            act = act || activeCode(a) || activeCode(b);
+        }
+        coarse[c] = dir ? uint8_t(MGPS_DIRICHLET_CELL) : (act ? uint8_t(MGPS_INTERIOR_CELL) : uint8_t(MGPS_EXTERIOR_CELL));
+        active = !dir && act;
+    }
+    if (__any(active) && (threadIdx.x & 63) == 0) flags[0] = 1;
+}
+
+// flags[0] = 1 when some cell is active (the fine level's "solvable" test, MG.cpp:233)
+__global__ __launch_bounds__(256) void anyActiveKernel(const uint32_t *__restrict__ lab4, size_t nq, int *__restrict__ flags)
+{
+    bool any = false;
+    for (size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x; q < nq; q += size_t(gridDim.x) * blockDim.x) {
+        const uint32_t v = lab4[q];
+        any = any || activeCode(v & 0xffu) || activeCode((v >> 8) & 0xffu) || activeCode((v >> 16) & 0xffu) || activeCode(v >> 24);
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) flags[0] = 1;
+}
+
+// flags[0] = 1 when a cell of the outermost layer is not EXTERIOR (unitTestExteriorCells, MG.cpp:235, 252)
+__global__ __launch_bounds__(256) void shellCheckKernel(Dims d, const uint8_t *__restrict__ lab, int *__restrict__ flags)
+{
+    const size_t fz = size_t(d.nx) * d.ny, fy = size_t(d.nx) * d.nz, fx = size_t(d.ny) * d.nz;
+    size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    int i, j, k;
+    if (t < 2 * fz) {
+        k = t < fz ? 0 : d.nz - 1;
+        t %= fz;
+        i = int(t % d.nx);
+        j = int(t / d.nx);
+    } else if (t < 2 * fz + 2 * fy) {
+        t -= 2 * fz;
+        j = t < fy ? 0 : d.ny - 1;
+        t %= fy;
+        i = int(t % d.nx);
+        k = int(t / d.nx);
+    } else if (t < 2 * fz + 2 * fy + 2 * fx) {
+        t -= 2 * fz + 2 * fy;
+        i = t < fx ? 0 : d.nx - 1;
+        t %= fx;
+        j = int(t % d.ny);
+        k = int(t / d.ny);
+    } else
+        return;
+    if (lab[cellIdx(d, i, j, k)] != MGPS_EXTERIOR_CELL) flags[0] = 1;
+}
+
+// coarse levels (unit weights): an INTERIOR cell with an EXTERIOR or DIRICHLET face neighbour becomes BOUNDARY
+// (Ops.cpp:112-160).  In place: the marking turns INTERIOR into BOUNDARY, neither of which the test looks for.
+__global__ __launch_bounds__(256) void markBoundaryKernel(Dims d, uint8_t *__restrict__ lab)
+{
+    const size_t c = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (c >= cellCount(d) || lab[c] != MGPS_INTERIOR_CELL) return;
+    const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    auto outside = [&](bool inGrid, ptrdiff_t off) {  // past the grid counts as EXTERIOR (a level without shell is refused anyway)
+        if (!inGrid) return true;
+        const uint8_t l = lab[ptrdiff_t(c) + off];
+        return l == MGPS_EXTERIOR_CELL || l == MGPS_DIRICHLET_CELL;
+    };
+    if (outside(i > 0, -1) || outside(i + 1 < d.nx, 1) || outside(j > 0, -sy) || outside(j + 1 < d.ny, sy) || outside(k > 0, -sz) ||
+        outside(k + 1 < d.nz, sz))
+        lab[c] = MGPS_BOUNDARY_CELL;
+}
+
+// the label-only half of unitTestBoundaryCells (Ops.h:1771-1870): every INTERIOR cell has six active neighbours
+__global__ __launch_bounds__(256) void interiorCheckKernel(Dims d, const uint8_t *__restrict__ lab, int *__restrict__ flags)
+{
+    const size_t c = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (c >= cellCount(d) || lab[c] != MGPS_INTERIOR_CELL) return;
+    const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    auto bad = [&](bool inGrid, ptrdiff_t off) { return !inGrid || !activeCode(lab[ptrdiff_t(c) + off]); };
+    if (bad(i > 0, -1) || bad(i + 1 < d.nx, 1) || bad(j > 0, -sy) || bad(j + 1 < d.ny, sy) || bad(k > 0, -sz) || bad(k + 1 < d.nz, sz)) flags[0] = 1;
+}
+
+// ---- exclusive scan of int32 (n + 1 outputs: out[n] = the total) ------------------------------------------------------
+constexpr int kScanThreads = 256, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
+
+__device__ __forceinline__ int waveInclusiveScan(int v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int u = __shfl_up(v, s);
+        if (int(threadIdx.x & 63) >= s) v += u;
+    }
+    return v;
+}
+// exclusive prefix of v over the 256 threads of a workgroup; *total = the sum (every thread gets it)
+__device__ __forceinline__ int blockExclusiveScan(int v, int *total, int *scratch /* 4 ints of LDS */)
+{
+    const int inc = waveInclusiveScan(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 63) scratch[w] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = scratch[q];
+        before += q < w ? s : 0;
+        all += s;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scanReduceKernel(const int32_t *__restrict__ in, size_t n, int32_t *__restrict__ blockSums)
+{
+    __shared__ int scratch[4];
+    const size_t base = size_t(blockIdx.x) * kScanTile + size_t(threadIdx.x) * kScanPer;
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) s += base + q < n ? in[base + q] : 0;
+    int total;
+    blockExclusiveScan(s, &total, scratch);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+// one workgroup: exclusive scan of the nb block sums in place, blockSums[nb] = the total
+__global__ __launch_bounds__(kScanThreads) void scanSumsKernel(int32_t *__restrict__ blockSums, size_t nb)
+{
+    __shared__ int scratch[4];
+    int carry = 0;
+    for (size_t b0 = 0; b0 < nb; b0 += kScanThreads) {
+        const size_t q = b0 + threadIdx.x;
+        const int v = q < nb ? blockSums[q] : 0;
+        int total;
+        const int ex = blockExclusiveScan(v, &total, scratch);
+        if (q < nb) blockSums[q] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blockSums[nb] = carry;
+}
+__global__ __launch_bounds__(kScanThreads) void scanDownKernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, size_t n,
+                                                               const int32_t *__restrict__ blockSums, size_t nb)
+{
+    __shared__ int scratch[4];
+    const size_t base = size_t(blockIdx.x) * kScanTile + size_t(threadIdx.x) * kScanPer;
+    int v[kScanPer], s = 0;
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+        v[q] = base + q < n ? in[base + q] : 0;
+        s += v[q];
+    }
+    int total;
+    int run = blockSums[blockIdx.x] + blockExclusiveScan(s, &total, scratch);
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+        if (base + q < n) out[base + q] = run;
+        run += v[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = blockSums[nb];
+}
+
+// ---- band list (Ops.cpp:165-469) -------------------------------------------------------------------------------------
+
+// One workgroup per 16^3 tile: the BOUNDARY cells of the tile and its halo of width-1 cells seed width-1 rings grown
+// through INTERIOR face neighbours; what lands inside the tile is the tile's share of the band.  Left behind per tile:
+// the 4096-bit membership mask (bit (k*16+j)*16+i, 128 words), the exclusive prefix count of every word, the count, and
+// the tile's kind for the Gauss-Seidel lists ((active cells << 1) | all 4096 cells INTERIOR).
+__global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__restrict__ lab, int width, int tx, int ty, uint32_t *__restrict__ mask,
+                                                      uint16_t *__restrict__ prefix, int32_t *__restrict__ tileCount, int32_t *__restrict__ tileKind)
+{
+    extern __shared__ uint8_t sm[];
+    const int halo = width - 1, E = kTile + 2 * halo, E3 = E * E * E;
+    uint8_t *sl = sm, *mk = sm + E3;
+    __shared__ uint16_t rowBits[256];
+    __shared__ int wordCount[128];
+    __shared__ int sSeeds, sActive, sInterior;
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x, ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    const int oi = ti * kTile - halo, oj = tj * kTile - halo, ok = tk * kTile - halo;
+    if (tid == 0) sSeeds = sActive = sInterior = 0;
+    __syncthreads();
+    bool seeds = false;
+    for (int c = tid; c < E3; c += 256) {
+        const int li = c % E, lj = (c / E) % E, lk = c / (E * E);
+        const int gi = oi + li, gj = oj + lj, gk = ok + lk;
+        uint8_t v = MGPS_EXTERIOR_CELL;
+        if (gi >= 0 && gi < d.nx && gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz) v = lab[cellIdx(d, gi, gj, gk)];
+        sl[c] = v;
+        const bool seed = v >= MGPS_BOUNDARY_CELL;
+        mk[c] = seed ? 1 : 0;
+        seeds = seeds || seed;
+    }
+    if (seeds) sSeeds = 1;
+    __syncthreads();
+    if (sSeeds)
+        for (int ring = 1; ring < width; ++ring) {  // a cell marked in this ring carries ring + 1: readers of this ring skip it
+            for (int c = tid; c < E3; c += 256) {
+                if (sl[c] != MGPS_INTERIOR_CELL || mk[c] != 0) continue;
+                const int li = c % E, lj = (c / E) % E, lk = c / (E * E);
+                auto hit = [&](bool in, int off) {
+                    if (!in) return false;
+                    const unsigned m = mk[c + off];
+                    return m != 0 && m <= unsigned(ring);
+                };
+                if (hit(li > 0, -1) || hit(li + 1 < E, 1) || hit(lj > 0, -E) || hit(lj + 1 < E, E) || hit(lk > 0, -E * E) || hit(lk + 1 < E, E * E))
+                    mk[c] = uint8_t(ring + 1);
+            }
+            __syncthreads();
+        }
+    {  // thread = one x-row of the tile
+        const int lk = tid >> 4, lj = tid & 15;
+        const int c0 = ((lk + halo) * E + (lj + halo)) * E + halo;
+        unsigned bits = 0;
+        int act = 0, inter = 0;
+#pragma unroll
+        for (int li = 0; li < kTile; ++li) {
+            bits |= (mk[c0 + li] != 0 ? 1u : 0u) << li;
+            const unsigned v = sl[c0 + li];
+            act += activeCode(v);
+            inter += v == MGPS_INTERIOR_CELL;
+        }
+        rowBits[tid] = uint16_t(bits);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            act += __shfl_down(act, s);
+            inter += __shfl_down(inter, s);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&sActive, act);
+            atomicAdd(&sInterior, inter);
+        }
+    }
+    __syncthreads();
+    uint32_t word = 0;
+    if (tid < 128) {
+        word = uint32_t(rowBits[2 * tid]) | (uint32_t(rowBits[2 * tid + 1]) << 16);
+        wordCount[tid] = __popc(word);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        int before = 0;
+        for (int q = 0; q < tid; ++q) before += wordCount[q];
+        mask[size_t(t) * 128 + tid] = word;
+        prefix[size_t(t) * 128 + tid] = uint16_t(before);
+        if (tid == 127) {
+            tileCount[t] = before + wordCount[127];
+            tileKind[t] = (sActive << 1) | (sInterior == kTile * kTile * kTile ? 1 : 0);
+        }
+    }
+}
+
+// the band list in the reference order (tile, k, j, i) from the masks and the scanned tile counts
+__global__ __launch_bounds__(256) void bandFillKernel(Dims d, int tx, int ty, const uint32_t *__restrict__ mask, const uint16_t *__restrict__ prefix,
+                                                      const int32_t *__restrict__ tileStart, int32_t *__restrict__ band)
+{
+    const int t = blockIdx.x;
+    if (tileStart[t + 1] == tileStart[t]) return;
+    const int tid = threadIdx.x, ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    const uint32_t word = mask[size_t(t) * 128 + (tid >> 1)];
+    unsigned bits = (tid & 1) ? word >> 16 : word & 0xffffu;
+    int at = tileStart[t] + prefix[size_t(t) * 128 + (tid >> 1)] + ((tid & 1) ? __popc(word & 0xffffu) : 0);
+    const int lk = tid >> 4, lj = tid & 15;
+    const size_t row = cellIdx(d, ti * kTile, tj * kTile + lj, tk * kTile + lk);
+    while (bits) {
+        const int li = __ffs(bits) - 1;
+        bits &= bits - 1;
+        band[at++] = int32_t(row + li);
+    }
+}
+
+// ---- band split: general BOUNDARY cells first (their operator rows kept), the rest after ------------------------------
+
+struct RowEval {
+    float w[6], diag;
+    bool simple, ruleOk;
+};
+// the host's rowOf (mgps_host.cpp) / boundaryRowsKernel term by term (Ops.h:208-256); wx == nullptr: unit weights
+__device__ __forceinline__ RowEval evalRow(const Dims &d, const uint8_t *__restrict__ lab, const float *__restrict__ wx, const float *__restrict__ wy,
+                                           const float *__restrict__ wz, size_t c)
+{
+    const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+    const size_t plane = size_t(d.nx) * d.ny;
+    float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (wx) {
+        const size_t fx = (size_t(k) * d.ny + j) * (d.nx + 1) + i, fy = (size_t(k) * (d.ny + 1) + j) * d.nx + i;
+        w[0] = wx[fx];
+        w[1] = wx[fx + 1];
+        w[2] = wy[fy];
+        w[3] = wy[fy + d.nx];
+        w[4] = wz[c];
+        w[5] = wz[c + plane];
+    }
+    const ptrdiff_t off[6] = {-1, 1, -ptrdiff_t(d.nx), ptrdiff_t(d.nx), -ptrdiff_t(plane), ptrdiff_t(plane)};
+    RowEval r;
+    r.diag = 0.f;
+    r.simple = true;
+    r.ruleOk = false;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const uint8_t nl = lab[ptrdiff_t(c) + off[q]];
+        r.w[q] = 0.f;
+        if (nl == MGPS_INTERIOR_CELL) {
+            r.w[q] = 1.f;
+            r.diag += 1.f;
+        } else if (nl >= MGPS_BOUNDARY_CELL) {
+            r.w[q] = w[q];
+            r.diag += w[q];
+            r.simple = r.simple && w[q] == 1.f;
+            r.ruleOk = r.ruleOk || w[q] != 1.f;
+        } else if (nl == MGPS_DIRICHLET_CELL) {
+            r.diag += w[q];
+            r.simple = r.simple && w[q] == 1.f;
+            r.ruleOk = true;
+        } else
+            r.ruleOk = true;
+    }
+    return r;
+}
+
+// per entry s of the sorted band list: diagS = 0 for a general BOUNDARY cell, else the diagonal (6 for INTERIOR cells);
+// general[s] = 1 / 0; *violations counts BOUNDARY cells that break the weight half of unitTestBoundaryCells
+__global__ __launch_bounds__(256) void bandClassifyKernel(Dims d, const uint8_t *__restrict__ lab, const float *__restrict__ wx,
+                                                          const float *__restrict__ wy, const float *__restrict__ wz, const int32_t *__restrict__ band,
+                                                          int n, uint8_t *__restrict__ diagS, int32_t *__restrict__ general, int *__restrict__ violations)
+{
+    const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= n) return;
+    const size_t c = size_t(band[s]);
+    uint8_t dg = 6;
+    int gen = 0;
+    if (lab[c] >= MGPS_BOUNDARY_CELL) {
+        const RowEval r = evalRow(d, lab, wx, wy, wz, c);
+        if (r.simple) dg = uint8_t(int(r.diag));
+        else {
+            dg = 0;
+            gen = 1;
+        }
+        if (!r.ruleOk && violations) atomicAdd(violations, 1);
+    }
+    diagS[s] = dg;
+    general[s] = gen;
+}
+
+// the device order: entry = rank among the general cells, or nGeneral + rank among the rest
+__global__ __launch_bounds__(256) void bandSplitKernel(Dims d, const uint8_t *__restrict__ lab, const float *__restrict__ wx, const float *__restrict__ wy,
+                                                       const float *__restrict__ wz, const int32_t *__restrict__ band, int n,
+                                                       const uint8_t *__restrict__ diagS, const int32_t *__restrict__ genRank, int32_t *__restrict__ bandDev,
+                                                       uint8_t *__restrict__ bandDiag, int32_t *__restrict__ bandEntry, float *__restrict__ rows)
+{
+    const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= n) return;
+    const int nGen = genRank[n], g = genRank[s];
+    const bool gen = genRank[s + 1] != g;
+    const int entry = gen ? g : nGen + (s - g);
+    const int32_t c = band[s];
+    bandDev[entry] = c;
+    bandDiag[entry] = diagS[s];
+    bandEntry[s] = entry;
+    if (gen) {
+        const RowEval r = evalRow(d, lab, wx, wy, wz, size_t(c));
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rows[size_t(q) * nGen + g] = r.w[q];
+        rows[size_t(6) * nGen + g] = r.diag;
+    }
+}
+
+// out[t] = rank[start[t]] (per tile: first entry of its general BOUNDARY cells in the device order)
+__global__ __launch_bounds__(256) void gatherKernel(const int32_t *__restrict__ rank, const int32_t *__restrict__ start, int n, int32_t *__restrict__ out)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) out[t] = rank[start[t]];
+}
+
+// ---- activity flags --------------------------------------------------------------------------------------------------
+
+// chunkFlags[q] = the q-th run of 256 cells holds an active cell (one wavefront per run); planeFlags (optional, nx % 4 == 0):
+// per block of the plane-marching sweep (256 cells in x, kPlaneRows rows, zc planes)
+__global__ __launch_bounds__(256) void activityFlagsKernel(Dims d, const uint32_t *__restrict__ lab4, size_t nq, uint8_t *__restrict__ chunkFlags,
+                                                           uint8_t *__restrict__ planeFlags, int zc, int nbx, int nby)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    bool any = false;
+    if (q < nq) {
+        const uint32_t v = lab4[q];
+        any = activeCode(v & 0xffu) || activeCode((v >> 8) & 0xffu) || activeCode((v >> 16) & 0xffu) || activeCode(v >> 24);
+        if (any && planeFlags) {
+            const size_t c = q * 4;
+            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
+            planeFlags[(size_t(k / zc) * nby + j / kPlaneRows) * nbx + i / 256] = 1;
+        }
+    }
+    const bool waveAny = __any(any);
+    if ((threadIdx.x & 63) == 0 && q < nq) chunkFlags[q >> 6] = waveAny ? 1 : 0;
+}
+
+// ---- groups of the fused band stage (BandGroups in mgps_internal.h) --------------------------------------------------
+
+// One workgroup per 16^3 tile walks the recursion of the host builder (buildGroupsOverWindow): the owned set starts as the
+// tile's band cells; the sub-graph of a set is found by dilating it depth-1 times through band-to-band stencil edges inside
+// the set's bounding box grown by depth (LDS), plus the active cells those nodes read; a set whose sub-graph exceeds one
+// workgroup of the band kernel is halved along the longest axis of its bounding box.  Nodes are numbered owned first, then
+// by distance, inside a distance (and the read-only nodes) by position in the box -- the host builder's canonical order.
+// FILL = false: per tile the number of groups, update nodes and read-only nodes; FILL = true: the arrays, at the tile's
+// scanned offsets.
+constexpr int kGroupThreads = 256;
+constexpr uint8_t kNodeNone = 255, kNodeRead = 200;
+
+struct Box {
+    int8_t lo[3], hi[3];
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const uint8_t *__restrict__ lab, int tx, int ty, const uint32_t *__restrict__ mask,
+                                                                  const uint16_t *__restrict__ prefix, const int32_t *__restrict__ tileStart,
+                                                                  const int32_t *__restrict__ bandEntry, const uint8_t *__restrict__ bandDiag, int depth,
+                                                                  int32_t *__restrict__ nGroups, int32_t *__restrict__ nUpdate, int32_t *__restrict__ nReadOnly,
+                                                                  const int32_t *__restrict__ groupAt, const int32_t *__restrict__ updateAt,
+                                                                  const int32_t *__restrict__ readAt, int32_t *__restrict__ info,
+                                                                  int32_t *__restrict__ updateEntry, int32_t *__restrict__ updateCell,
+                                                                  uint16_t *__restrict__ neighbours, int32_t *__restrict__ readCell, int *__restrict__ broken)
+{
+    const int t = blockIdx.x;
+    if (tileStart[t + 1] == tileStart[t]) {
+        if (!FILL && threadIdx.x == 0) nGroups[t] = nUpdate[t] = nReadOnly[t] = 0;
+        return;
+    }
+    extern __shared__ uint8_t sm[];
+    const int EM = kTile + 2 * depth, EM3 = EM * EM * EM;
+    uint8_t *fl = sm;                                                  // bit 0 active, bit 1 band
+    uint8_t *node = sm + EM3;                                          // kNodeNone, distance 0 .. depth-1, kNodeRead
+    uint16_t *id = reinterpret_cast<uint16_t *>(sm + 2 * size_t(EM3) + (size_t(EM3) & 1));  // FILL: node numbers
+    __shared__ uint32_t tmask[128];
+    __shared__ Box stack[48];
+    __shared__ int sp;
+    __shared__ int bb[6];
+    __shared__ int waveTot[5][4];
+    __shared__ int scratch[4];
+    const int tid = threadIdx.x;
+    const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    if (tid < 128) tmask[tid] = mask[size_t(t) * 128 + tid];
+    if (tid == 0) {
+        sp = 1;
+        for (int a = 0; a < 3; ++a) {
+            stack[0].lo[a] = 0;
+            stack[0].hi[a] = kTile - 1;
+        }
+    }
+    int groups = 0, upd = 0, rd = 0;  // running totals of this tile (uniform across the workgroup)
+    const int gBase = FILL ? groupAt[t] : 0, uBase = FILL ? updateAt[t] : 0, rBase = FILL ? readAt[t] : 0;
+    __syncthreads();
+    while (true) {
+        __syncthreads();
+        if (sp == 0) break;
+        const Box B = stack[sp - 1];
+        __syncthreads();
+        if (tid == 0) {
+            --sp;
+            bb[0] = bb[1] = bb[2] = 99;
+            bb[3] = bb[4] = bb[5] = -1;
+        }
+        __syncthreads();
+        // tight bounding box of the owned cells: the tile's band cells inside B (thread = one x-row of the tile)
+        int owned = 0;
+        {
+            const int lk = tid >> 4, lj = tid & 15;
+            unsigned bits = 0;
+            if (lk >= B.lo[2] && lk <= B.hi[2] && lj >= B.lo[1] && lj <= B.hi[1]) {
+                const uint32_t word = tmask[tid >> 1];
+                bits = (tid & 1) ? word >> 16 : word & 0xffffu;
+                bits &= (0xffffu >> (15 - B.hi[0])) & (0xffffu << B.lo[0]);
+            }
+            if (bits) {
+                atomicMin(&bb[0], __ffs(bits) - 1);
+                atomicMax(&bb[3], 31 - __clz(bits));
+                atomicMin(&bb[1], lj);
+                atomicMax(&bb[4], lj);
+                atomicMin(&bb[2], lk);
+                atomicMax(&bb[5], lk);
+            }
+            blockExclusiveScan(__popc(bits), &owned, scratch);
+        }
+        __syncthreads();
+        if (owned == 0) continue;
+        const int lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[3], bb[4], bb[5]};
+        const int ex = hi[0] - lo[0] + 1 + 2 * depth, ey = hi[1] - lo[1] + 1 + 2 * depth, ez = hi[2] - lo[2] + 1 + 2 * depth;
+        const int N = ex * ey * ez;
+        const int oi = ti * kTile + lo[0] - depth, oj = tj * kTile + lo[1] - depth, ok = tk * kTile + lo[2] - depth;  // grid cell of box cell (0,0,0)
+        // flags of the box: activity from the labels, band membership from the masks of the tiles the box touches
+        for (int c = tid; c < N; c += kGroupThreads) {
+            const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
+            const int gi = oi + li, gj = oj + lj, gk = ok + lk;
+            uint8_t f = 0;
+            if (gi >= 0 && gi < d.nx && gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz && activeCode(lab[cellIdx(d, gi, gj, gk)])) {
+                f = 1;
+                const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
+                const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
+                const uint32_t w = tile == t ? tmask[b >> 5] : mask[size_t(tile) * 128 + (b >> 5)];
+                if ((w >> (b & 31)) & 1u) f = 3;
+            }
+            fl[c] = f;
+            // distance 0: the owned cells (band cells of this tile inside the tight box)
+            const bool own = f == 3 && li >= depth && li < ex - depth && lj >= depth && lj < ey - depth && lk >= depth && lk < ez - depth;
+            node[c] = own ? 0 : kNodeNone;
+        }
+        __syncthreads();
+        for (int ring = 1; ring <= depth; ++ring) {  // ring == depth: the read-only nodes (any active cell next to an update node)
+            const bool reads = ring == depth;
+            for (int c = tid; c < N; c += kGroupThreads) {
+                if (node[c] != kNodeNone || (reads ? fl[c] == 0 : fl[c] != 3)) continue;
+                const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
+                auto hit = [&](bool in, int off) { return in && (reads ? node[c + off] < depth : node[c + off] == ring - 1); };
+                if (hit(li > 0, -1) || hit(li + 1 < ex, 1) || hit(lj > 0, -ex) || hit(lj + 1 < ey, ex) || hit(lk > 0, -ex * ey) || hit(lk + 1 < ez, ex * ey))
+                    node[c] = reads ? kNodeRead : uint8_t(ring);
+            }
+            __syncthreads();
+        }
+        // class counts: thread = a run of consecutive box cells, so that numbering by (thread, position) is the box order
+        const int per = (N + kGroupThreads - 1) / kGroupThreads, c0 = tid * per, c1 = min(N, c0 + per);
+        int cnt[5] = {0, 0, 0, 0, 0};
+        for (int c = c0; c < c1; ++c) {
+            const unsigned v = node[c];
+            if (v < kBandMaxDepth) ++cnt[v];
+            else if (v == kNodeRead) ++cnt[4];
+        }
+        int before[5], total[5];
+        {
+            int inc[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) inc[q] = waveInclusiveScan(cnt[q]);
+            if ((tid & 63) == 63)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) waveTot[q][tid >> 6] = inc[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                int b4 = 0, all = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int s = waveTot[q][w];
+                    b4 += w < (tid >> 6) ? s : 0;
+                    all += s;
+                }
+                before[q] = b4 + inc[q] - cnt[q];
+                total[q] = all;
+            }
+        }
+        const int nUpd = total[0] + total[1] + total[2] + total[3], nRead = total[4];
+        if (nUpd > kBandMaxUpdate || nUpd + nRead + 1 > kBandMaxNodes) {
+            __syncthreads();
+            if (tid == 0) {
+                if (owned < 2 || sp + 2 > 48) *broken = 1;
+                else {
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a)
+                        if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                    const int mid = (lo[axis] + hi[axis] + 1) / 2;
+                    Box L, R;
+                    for (int a = 0; a < 3; ++a) {
+                        L.lo[a] = R.lo[a] = int8_t(lo[a]);
+                        L.hi[a] = R.hi[a] = int8_t(hi[a]);
+                    }
+                    L.hi[axis] = int8_t(mid - 1);
+                    R.lo[axis] = int8_t(mid);
+                    stack[sp++] = R;  // the left half is walked first
+                    stack[sp++] = L;
+                }
+            }
+            continue;
+        }
+        if (FILL) {
+            const int ringBase[4] = {0, total[0], total[0] + total[1], total[0] + total[1] + total[2]};
+            int run[5] = {before[0], before[1], before[2], before[3], before[4]};
+            for (int c = c0; c < c1; ++c) {
+                const unsigned v = node[c];
+                if (v < kBandMaxDepth) id[c] = uint16_t(ringBase[v] + run[v]++);
+                else if (v == kNodeRead) id[c] = uint16_t(nUpd + run[4]++);
+            }
+            __syncthreads();
+            const int uAt = uBase + upd, rAt = rBase + rd;
+            for (int c = tid; c < N; c += kGroupThreads) {
+                const unsigned v = node[c];
+                if (v == kNodeNone) continue;
+                const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
+                const int gi = oi + li, gj = oj + lj, gk = ok + lk;
+                const int32_t cell = int32_t(cellIdx(d, gi, gj, gk));
+                const int n = id[c];
+                if (v == kNodeRead) {
+                    readCell[rAt + (n - nUpd)] = cell;
+                    continue;
+                }
+                updateCell[uAt + n] = cell;
+                const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
+                const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
+                const uint32_t w = mask[size_t(tile) * 128 + (b >> 5)];
+                const int sorted = tileStart[tile] + prefix[size_t(tile) * 128 + (b >> 5)] + __popc(w & ((1u << (b & 31)) - 1u));
+                const int e = bandEntry[sorted];
+                updateEntry[uAt + n] = e | (int32_t(bandDiag[e]) << kBandDiagShift);
+                const int off[6] = {-1, 1, -ex, ex, -ex * ey, ex * ey};
+                uint16_t q6[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) q6[q] = fl[c + off[q]] ? id[c + off[q]] : uint16_t(nUpd + nRead);  // (an update node is never on the box's rim)
+                uint16_t *dst = neighbours + 6 * size_t(uAt + n);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) dst[q] = q6[q];
+            }
+            if (tid == 0) {
+                int32_t *gi8 = info + 8 * size_t(gBase + groups);
+                const int c1n = total[0] + total[1], c2n = c1n + total[2], c3n = c2n + total[3];
+                const int cum[4] = {total[0], c1n, c2n, c3n};
+                gi8[0] = uAt;
+                gi8[1] = rAt;
+                gi8[2] = nRead;
+                for (int q = 0; q < kBandMaxDepth; ++q) gi8[3 + q] = cum[q < depth ? q : depth - 1];
+                gi8[7] = 0;
+            }
+        }
+        ++groups;
+        upd += nUpd;
+        rd += nRead;
+    }
+    if (!FILL && tid == 0) {
+        nGroups[t] = groups;
+        nUpdate[t] = upd;
+        nReadOnly[t] = rd;
+    }
+}
+
+}  // namespace
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+
+int launchCoarsenLabels(void *stream, const Dims &fine, const uint8_t *fineLab, uint8_t *coarseLab, int *activeFlag)
+{
+    const Dims cd{fine.nx / 2, fine.ny / 2, fine.nz / 2};
+    coarsenLabelsKernel<<<blocksFor(cd.cells(), 256), 256, 0, S(stream)>>>(fine, cd, fineLab, coarseLab, activeFlag);
+    return int(hipGetLastError());
+}
+int launchAnyActive(void *stream, const Dims &d, const uint8_t *lab, int *activeFlag)
+{
+    const size_t nq = d.cells() / 4;  // extents are even: cells() is a multiple of 8
+    anyActiveKernel<<<unsigned(std::min<size_t>(blocksFor(nq, 256), 8192)), 256, 0, S(stream)>>>(reinterpret_cast<const uint32_t *>(lab), nq, activeFlag);
+    return int(hipGetLastError());
+}
+int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag)
+{
+    const size_t n = 2 * (size_t(d.nx) * d.ny + size_t(d.nx) * d.nz + size_t(d.ny) * d.nz);
+    shellCheckKernel<<<blocksFor(n, 256), 256, 0, S(stream)>>>(d, lab, badFlag);
+    return int(hipGetLastError());
+}
+int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab)
+{
+    markBoundaryKernel<<<blocksFor(d.cells(), 256), 256, 0, S(stream)>>>(d, lab);
+    return int(hipGetLastError());
+}
+int launchInteriorCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag)
+{
+    interiorCheckKernel<<<blocksFor(d.cells(), 256), 256, 0, S(stream)>>>(d, lab, badFlag);
+    return int(hipGetLastError());
+}
+
+size_t scanScratchInts(size_t n) { return (n + kScanTile - 1) / kScanTile + 2; }
+int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch)
+{
+    const size_t nb = std::max<size_t>(1, (n + kScanTile - 1) / kScanTile);
+    scanReduceKernel<<<unsigned(nb), kScanThreads, 0, S(stream)>>>(in, n, scratch);
+    scanSumsKernel<<<1, kScanThreads, 0, S(stream)>>>(scratch, nb);
+    scanDownKernel<<<unsigned(nb), kScanThreads, 0, S(stream)>>>(in, out, n, scratch, nb);
+    return int(hipGetLastError());
+}
+
+int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    const int E = kTile + 2 * (width - 1);
+    const size_t lds = 2 * size_t(E) * E * E;
+    if (lds > size_t(60) << 10) return int(hipErrorInvalidValue);  // band_width <= 8
+    bandMaskKernel<<<unsigned(tx * ty * tz), 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind);
+    return int(hipGetLastError());
+}
+int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    bandFillKernel<<<unsigned(tx * ty * tz), 256, 0, S(stream)>>>(d, tx, ty, mask, prefix, tileStart, band);
+    return int(hipGetLastError());
+}
+int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
+                       uint8_t *diagS, int32_t *general, int *violations)
+{
+    if (n > 0) bandClassifyKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wx, wy, wz, band, n, diagS, general, violations);
+    return int(hipGetLastError());
+}
+int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
+                    const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows)
+{
+    if (n > 0) bandSplitKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wx, wy, wz, band, n, diagS, genRank, bandDev, bandDiag, bandEntry, rows);
+    return int(hipGetLastError());
+}
+int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out)
+{
+    if (n > 0) gatherKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(rank, start, n, out);
+    return int(hipGetLastError());
+}
+int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t *chunkFlags, uint8_t *planeFlags, int zc)
+{
+    const size_t nq = d.cells() / 4;
+    const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows;
+    activityFlagsKernel<<<blocksFor(nq, 256), 256, 0, S(stream)>>>(d, reinterpret_cast<const uint32_t *>(lab), nq, chunkFlags, zc ? planeFlags : nullptr, zc ? zc : 1,
+                                                                 nbx, nby);
+    return int(hipGetLastError());
+}
+
+static size_t groupLds(int depth)
+{
+    const size_t EM = size_t(kTile + 2 * depth), EM3 = EM * EM * EM;
+    return 2 * EM3 + (EM3 & 1) + 2 * EM3;
+}
+int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
+                          int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    bandGroupsKernel<false><<<unsigned(tx * ty * tz), kGroupThreads, groupLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, nullptr, nullptr, depth,
+                                                                                                 nGroups, nUpdate, nReadOnly, nullptr, nullptr, nullptr, nullptr,
+                                                                                                 nullptr, nullptr, nullptr, nullptr, broken);
+    return int(hipGetLastError());
+}
+int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *groupAt, const int32_t *updateAt, const int32_t *readAt,
+                         int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours, int32_t *readCell, int *broken)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    bandGroupsKernel<true><<<unsigned(tx * ty * tz), kGroupThreads, groupLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth,
+                                                                                                nullptr, nullptr, nullptr, groupAt, updateAt, readAt, info,
+                                                                                                updateEntry, updateCell, neighbours, readCell, broken);
+    return int(hipGetLastError());
+}
+
+}  // namespace mgps

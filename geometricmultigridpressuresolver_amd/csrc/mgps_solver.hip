@@ -17,11 +17,18 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <map>
 #include <vector>
 
 #include "mgps_internal.h"
 
 using namespace mgps;
+
+namespace {
+// the library's device memory (deviceAlloc / deviceFree below: released blocks are cached) behind hipMalloc's signature
+inline hipError_t cacheMalloc(void **p, size_t bytes) { return hipError_t(mgps::deviceAlloc(p, bytes)); }
+inline hipError_t cacheFree(void *p) { return hipError_t(mgps::deviceFree(p)); }
+}  // namespace
 
 namespace {
 
@@ -110,6 +117,7 @@ struct mgps_solver {
     std::vector<int> splits;       // slab run: rank r owns the fine planes [splits[r], splits[r + 1])
     int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
     int totalLevels = 0;           // levels of the whole hierarchy
+    int requestedLevels = 0;       // device-side set-up: mg_levels as asked for (the host hierarchy is built on demand)
     mgps_solver *tail = nullptr;   // rank 0: solver of levels distLevels .. totalLevels-1 on the whole grid
     float *tailX = nullptr, *tailB = nullptr;
     // measurement hooks: event pairs around the fine-level full-domain smoother
@@ -178,12 +186,119 @@ int failH(mgps_solver *h, int code, const std::string &msg)
         if (s_ != 0) return failH(h, MGPS_ERR_COMM, std::string(#call) + " failed"); \
     } while (0)
 
+
+// ---- device memory of the library -------------------------------------------------------------------------------------
+// hipMalloc is cheap while the process holds little (0.3 ms for 4 GiB) and expensive once it holds much: ten 4 GiB blocks
+// cost 0.6-1.3 s on this platform (tools/allocbench.hip), and every hipFree of a block >= 16 MiB 0.2 ms -- a solver of a
+// 1024^3 grid holds ~45 GiB in ~300 blocks, and a plugin that rebuilds it every sub-step (Plug.cpp:463) would pay more for
+// memory than for the solve.  Released blocks are therefore kept, per device, and handed to the next solver (sizes are
+// rounded up by at most 1/8 so that lists whose length moves with the liquid find their block again); the cap is
+// MGPS_DEVICE_CACHE_MB (default 98304 of the 288 GiB), mgps_trim_device_cache returns everything, and an allocation that
+// fails trims the cache and tries again.
+struct DeviceCache {
+    std::mutex guard;
+    std::multimap<std::pair<int, size_t>, void *> free;          // (device, bytes) -> block not in use
+    std::unordered_map<void *, std::pair<int, size_t>> live;     // every block of the library, in use or cached
+    size_t cached = 0;
+    size_t cap = [] {
+        const char *e = getenv("MGPS_DEVICE_CACHE_MB");
+        return size_t(e ? std::max(0, atoi(e)) : 98304) << 20;
+    }();
+};
+DeviceCache &deviceCache()
+{
+    static DeviceCache *c = new DeviceCache();  // never destroyed (process tear-down order)
+    return *c;
+}
+size_t deviceRounded(size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 256);
+    size_t p2 = 256;
+    while (p2 * 2 <= bytes) p2 *= 2;
+    const size_t step = std::max<size_t>(256, p2 / 8);
+    return (bytes + step - 1) / step * step;
+}
+void deviceTrimLocked(DeviceCache &c, std::vector<void *> &drop)
+{
+    for (auto &b : c.free) {
+        drop.push_back(b.second);
+        c.live.erase(b.second);
+    }
+    c.free.clear();
+    c.cached = 0;
+}
+}  // namespace
+namespace mgps {
+int deviceAlloc(void **p, size_t bytes)
+{
+    DeviceCache &c = deviceCache();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t want = deviceRounded(bytes);
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        const auto it = c.free.find({dev, want});
+        if (it != c.free.end()) {
+            *p = it->second;
+            c.cached -= want;
+            c.free.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {  // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(c.guard);
+            deviceTrimLocked(c, drop);
+        }
+        for (void *b : drop) (void)hipFree(b);
+        e = hipMalloc(p, want);
+    }
+    if (e != hipSuccess) return int(e);
+    std::lock_guard<std::mutex> lock(c.guard);
+    c.live[*p] = {dev, want};
+    return hipSuccess;
+}
+// (unlike hipFree this does not wait for the device: callers release only what no queued kernel touches any more)
+int deviceFree(void *p)
+{
+    if (!p) return hipSuccess;
+    DeviceCache &c = deviceCache();
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        const auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            if (c.cached + it->second.second <= c.cap) {
+                c.free.emplace(it->second, p);
+                c.cached += it->second.second;
+                return hipSuccess;
+            }
+            c.live.erase(it);
+        }
+    }
+    return int(hipFree(p));
+}
+void deviceTrim()
+{
+    DeviceCache &c = deviceCache();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.guard);
+        deviceTrimLocked(c, drop);
+    }
+    for (void *b : drop) (void)hipFree(b);
+}
+}  // namespace mgps
+namespace {
+
 template <class T>
 int devAlloc(mgps_solver *h, T **p, size_t count, bool zero)
 {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+    hipError_t e = cacheMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
     if (e != hipSuccess) return failH(h, MGPS_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
     if (zero) MGPS_HIP(h, hipMemsetAsync(*p, 0, count * sizeof(T), h->stream));
     return MGPS_OK;
@@ -208,7 +323,7 @@ int gridAlloc(mgps_solver *h, float **p, const Dims &d)
 }
 void gridFree(float *p, const Dims &d)
 {
-    if (p) (void)hipFree(p - size_t(d.nx) * d.ny);
+    if (p) (void)cacheFree(p - size_t(d.nx) * d.ny);
 }
 
 void freeAll(mgps_solver *h)
@@ -218,68 +333,68 @@ void freeAll(mgps_solver *h)
     (void)hipDeviceSynchronize();
     if (h->tail) freeAll(h->tail);
     for (auto &L : h->lv) {
-        (void)hipFree(L.codes);
+        (void)cacheFree(L.codes);
         gridFree(L.x, L.d);
         gridFree(L.b, L.d);
         gridFree(L.r, L.d);
         gridFree(L.tmp, L.d);
-        (void)hipFree(L.band);
-        (void)hipFree(L.bandTmp);
-        (void)hipFree(L.rows);
-        (void)hipFree(L.bandDiag);
+        (void)cacheFree(L.band);
+        (void)cacheFree(L.bandTmp);
+        (void)cacheFree(L.rows);
+        (void)cacheFree(L.bandDiag);
         for (int c = 0; c < 2; ++c) {
-            (void)hipFree(L.pure[c]);
-            (void)hipFree(L.mixed[c]);
+            (void)cacheFree(L.pure[c]);
+            (void)cacheFree(L.mixed[c]);
         }
-        (void)hipFree(L.tileBndStart);
+        (void)cacheFree(L.tileBndStart);
         for (int q = 0; q < 4; ++q) {
-            (void)hipFree(L.bandPlane[q]);
-            (void)hipFree(L.packBuf[q]);
+            (void)cacheFree(L.bandPlane[q]);
+            (void)cacheFree(L.packBuf[q]);
         }
-        (void)hipFree(L.chunks);
-        (void)hipFree(L.planeBlocks);
+        (void)cacheFree(L.chunks);
+        (void)cacheFree(L.planeBlocks);
         for (int q = 0; q < 2; ++q) {
-            (void)hipFree(L.halo.sendIdx[q]);
-            (void)hipFree(L.halo.sendBuf[q]);
-            (void)hipFree(L.halo.recvBuf[q]);
+            (void)cacheFree(L.halo.sendIdx[q]);
+            (void)cacheFree(L.halo.sendBuf[q]);
+            (void)cacheFree(L.halo.recvBuf[q]);
         }
-        (void)hipFree(L.halo.hx);
-        (void)hipFree(L.halo.hb);
-        (void)hipFree(L.halo.bandExt);
-        (void)hipFree(L.halo.tmpExt);
-        (void)hipFree(L.halo.frows);
-        (void)hipFree(L.halo.groups.info);
-        (void)hipFree(L.halo.groups.updateEntry);
-        (void)hipFree(L.halo.groups.updateCell);
-        (void)hipFree(L.halo.groups.readCell);
-        (void)hipFree(L.halo.groups.neighbours);
-        (void)hipFree(L.bandGroups.info);
-        (void)hipFree(L.bandGroups.updateEntry);
-        (void)hipFree(L.bandGroups.updateCell);
-        (void)hipFree(L.bandGroups.readCell);
-        (void)hipFree(L.bandGroups.neighbours);
+        (void)cacheFree(L.halo.hx);
+        (void)cacheFree(L.halo.hb);
+        (void)cacheFree(L.halo.bandExt);
+        (void)cacheFree(L.halo.tmpExt);
+        (void)cacheFree(L.halo.frows);
+        (void)cacheFree(L.halo.groups.info);
+        (void)cacheFree(L.halo.groups.updateEntry);
+        (void)cacheFree(L.halo.groups.updateCell);
+        (void)cacheFree(L.halo.groups.readCell);
+        (void)cacheFree(L.halo.groups.neighbours);
+        (void)cacheFree(L.bandGroups.info);
+        (void)cacheFree(L.bandGroups.updateEntry);
+        (void)cacheFree(L.bandGroups.updateCell);
+        (void)cacheFree(L.bandGroups.readCell);
+        (void)cacheFree(L.bandGroups.neighbours);
     }
-    for (int a = 0; a < 3; ++a) (void)hipFree(h->w[a]);
-    (void)hipFree(h->cinv);
-    (void)hipFree(h->cvec);
-    (void)hipFree(h->ccells);
-    (void)hipFree(h->partials);
-    (void)hipFree(h->resultDev);
-    (void)hipFree(h->dotPartials);
-    (void)hipFree(h->cgScal);
-    (void)hipFree(h->mixX);
-    (void)hipFree(h->mixTmp);
-    (void)hipFree(h->mixR);
-    (void)hipFree(h->mixSigma);
-    (void)hipFree(h->mixMax);
+    for (int a = 0; a < 3; ++a) (void)cacheFree(h->w[a]);
+    (void)cacheFree(h->cinv);
+    (void)cacheFree(h->cvec);
+    (void)cacheFree(h->ccells);
+    (void)cacheFree(h->partials);
+    (void)cacheFree(h->resultDev);
+    (void)cacheFree(h->dotPartials);
+    (void)cacheFree(h->cgScal);
+    (void)cacheFree(h->mixX);
+    (void)cacheFree(h->mixTmp);
+    (void)cacheFree(h->mixR);
+    (void)cacheFree(h->mixSigma);
+    (void)cacheFree(h->mixMax);
     for (double *g64 : h->cg64)
-        if (g64) (void)hipFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
+        if (g64) (void)cacheFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
     if (!h->lv.empty()) {
         for (int q = 0; q < 4; ++q) gridFree(h->pcg[q], h->lv[0].d);
         gridFree(h->dinv, h->lv[0].d);
     }
-    for (void *p : h->userGrids) (void)hipFree(p);
+    for (void *p : h->userGrids) (void)cacheFree(p);
     for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->stageEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
@@ -1357,6 +1472,16 @@ int readOptions(const mgps_options *opt, mgps_options *o)
     return MGPS_OK;
 }
 
+// options.host_setup, or MGPS_HOST_SETUP=1 in the environment (A/B timing of the two builders)
+bool hostSetup(const mgps_options &o)
+{
+    static const bool env = [] {
+        const char *e = getenv("MGPS_HOST_SETUP");
+        return e && e[0] == '1';
+    }();
+    return o.host_setup != 0 || env;
+}
+
 // whole-grid solver on one device.  weights may be nullptr (unit weights: the collapsed tail)
 const float kNoRows = 0.f;  // a non-null "no BOUNDARY cells" row array
 
@@ -1491,6 +1616,355 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
     return MGPS_OK;
 }
 
+
+// ---- the same solver with the hierarchy and every list built on the device (mgps_setup.hip) ---------------------------
+// labels: nx*ny*nz bytes, weights: the three face grids; `kind` says where they live (hipMemcpyHostToDevice or
+// hipMemcpyDeviceToDevice).  The labels of all levels stay on the device; the host sees per-level counts, the activity
+// flags (one byte per 256 cells), the tile kinds and the coarsest level's labels (for the direct solver) -- nothing of
+// O(cells).  mgps_get_hierarchy builds the host-side hierarchy on demand from the fine labels.
+struct DevScratch {
+    std::vector<void *> ptrs;
+    template <class T>
+    int get(mgps_solver *h, T **p, size_t count)
+    {
+        MGPS_TRY(devAlloc(h, p, count, false));
+        ptrs.push_back(*p);
+        return MGPS_OK;
+    }
+    ~DevScratch()
+    {
+        (void)hipDeviceSynchronize();  // (deviceFree does not wait for the kernels that still use a block)
+        for (void *p : ptrs) (void)cacheFree(p);
+    }
+};
+
+void fillGridP(mgps_solver *h, DevLevel &L, bool withWeights, int nchunks, int chunkCells, int nplaneBlocks, int planeZc)
+{
+    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    L.g = GridP{L.d.nx,
+                L.d.ny,
+                L.d.nz,
+                L.codes + plane,
+                withWeights ? h->w[0] : nullptr,
+                withWeights ? h->w[1] : nullptr,
+                withWeights ? h->w[2] : nullptr,
+                L.band,
+                L.rows,
+                L.nbndGeneral,
+                L.bandDiag,
+                0,
+                0,
+                L.chunks,
+                nchunks,
+                chunkCells,
+                planeZc ? L.planeBlocks : nullptr,
+                nplaneBlocks,
+                planeZc,
+                L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0,
+                h->opt.stencil_path};
+}
+
+int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels, const float *wx, const float *wy, const float *wz,
+                        hipMemcpyKind kind, int mgLevels, bool useGS, const mgps_options &o, int device)
+{
+    // the argument rules of mgps_hierarchy_create (MG.cpp:159-161)
+    if (mgLevels < 1 || nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1))
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: extents must be even and >= 2, mg_levels >= 1");
+    if (size_t(nx) * ny * nz > size_t(0x7fffffff)) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: more than 2^31-1 cells per grid");
+    for (int l = 1; l < mgLevels; ++l)
+        if (((nx >> (l - 1)) & 1) || ((ny >> (l - 1)) & 1) || ((nz >> (l - 1)) & 1) || (nx >> l) < 1 || (ny >> l) < 1 || (nz >> l) < 1)
+            return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: extents are not divisible by 2^(levels-1)");
+    if (o.band_width < 1 || o.band_width > 8 || o.band_iterations < 0)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: band_width >= 1 (device-side set-up: <= 8), band_iterations >= 0");
+    auto *h = new mgps_solver();
+    h->opt = o;
+    h->useGS = useGS;
+    h->device = device;
+    h->requestedLevels = mgLevels;
+    std::thread inverseJob;  // the coarsest level's direct solver, on host threads beside the device work
+    auto bail = [&](int code) {
+        if (inverseJob.joinable()) inverseJob.join();
+        setLastGlobalError(h->lastError);
+        freeAll(h);
+        return code;
+    };
+    const Dims d0{nx, ny, nz};
+    if (h->opt.precision == 1) {
+        const bool fused = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
+        if (useGS || !fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
+            return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT,
+                              "options.precision = 1 (mixed precision) needs the Jacobi smoother (use_gauss_seidel = 0), the fused band stage "
+                              "(fuse_band_passes, 1 <= band_iterations <= 4) and a fine grid with nx % 4 == 0 and even ny, nz"));
+    }
+    StageClock clock(h->opt.print_stats != 0);
+    DevScratch tmp;
+#define ODS_TRY(call)                        \
+    do {                                     \
+        int s_ = (call);                     \
+        if (s_ != MGPS_OK) return bail(s_);  \
+    } while (0)
+#define ODS_HIP(call)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)));  \
+    } while (0)
+#define ODS_LAUNCH(call)                                                                                                       \
+    do {                                                                                                                       \
+        int e_ = (call);                                                                                                       \
+        if (e_ != 0) return bail(failH(h, MGPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(hipError_t(e_))));       \
+    } while (0)
+
+    // ---- labels of every level: ghost plane | the level | ghost plane
+    h->lv.resize(size_t(mgLevels));
+    for (int l = 0; l < mgLevels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        L.d = Dims{nx >> l, ny >> l, nz >> l};
+        L.z0 = 0;
+        L.z1 = L.d.nz;
+        const size_t plane = size_t(L.d.nx) * L.d.ny;
+        ODS_TRY(devAlloc(h, &L.codes, L.d.cells() + 2 * plane, false));
+        ODS_HIP(hipMemsetAsync(L.codes, MGPS_EXTERIOR_CELL, plane, nullptr));
+        ODS_HIP(hipMemsetAsync(L.codes + plane + L.d.cells(), MGPS_EXTERIOR_CELL, plane, nullptr));
+    }
+    auto labOf = [&](int l) { return h->lv[size_t(l)].codes + size_t(h->lv[size_t(l)].d.nx) * h->lv[size_t(l)].d.ny; };
+    if (labels != labOf(0)) ODS_HIP(hipMemcpy(labOf(0), labels, d0.cells(), kind));
+    // flags per level: [0] shell broken, [1] holds an active cell; then [2 L] interior rule broken, [2 L + 1] weight rule broken,
+    // [2 L + 2 ...] band groups broken per level
+    int *flags = nullptr;
+    const size_t nflags = size_t(3 * mgLevels + 2);
+    ODS_TRY(tmp.get(h, &flags, nflags));
+    ODS_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), nullptr));
+    ODS_LAUNCH(launchShellCheck(nullptr, d0, labOf(0), flags));
+    ODS_LAUNCH(launchAnyActive(nullptr, d0, labOf(0), flags + 1));
+    ODS_LAUNCH(launchInteriorCheck(nullptr, d0, labOf(0), flags + 2 * mgLevels));
+    for (int l = 1; l < mgLevels; ++l) {
+        ODS_LAUNCH(launchCoarsenLabels(nullptr, h->lv[size_t(l - 1)].d, labOf(l - 1), labOf(l), flags + 2 * l + 1));
+        ODS_LAUNCH(launchShellCheck(nullptr, h->lv[size_t(l)].d, labOf(l), flags + 2 * l));
+        ODS_LAUNCH(launchMarkBoundary(nullptr, h->lv[size_t(l)].d, labOf(l)));
+    }
+    std::vector<int> hflags(nflags);
+    ODS_HIP(hipMemcpy(hflags.data(), flags, nflags * sizeof(int), hipMemcpyDeviceToHost));
+    if (hflags[0]) return bail(failH(h, MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)"));
+    if (!hflags[1]) return bail(failH(h, MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain"));
+    int levels = mgLevels;
+    for (int l = 1; l < mgLevels; ++l) {  // MG.cpp:238-253
+        if (hflags[size_t(2 * l)])
+            return bail(failH(h, MGPS_ERR_HIERARCHY,
+                              "level " + std::to_string(l) + " has no EXTERIOR shell (unitTestExteriorCells, MG.cpp:252): " + std::to_string(mgLevels) +
+                                  " levels need 2^(levels-1) = " + std::to_string(1 << (mgLevels - 1)) +
+                                  " EXTERIOR cells on every side of the solver grid (mgps_expanded_layout pads that much)"));
+        if (!hflags[size_t(2 * l + 1)]) {
+            levels = l - 1;  // the reference drops the last solvable level too (MG.cpp:245)
+            break;
+        }
+    }
+    if (levels < 1) return bail(failH(h, MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)"));
+    if (hflags[size_t(2 * mgLevels)])
+        return bail(failH(h, MGPS_ERR_HIERARCHY,
+                          "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
+    for (int l = levels; l < mgLevels; ++l) {
+        (void)cacheFree(h->lv[size_t(l)].codes);
+        h->lv[size_t(l)].codes = nullptr;
+    }
+    h->lv.resize(size_t(levels));
+    h->totalLevels = levels;
+    clock.lap("labels of all levels (device)");
+
+    // ---- the coarsest level's direct solver on host threads, beside everything below
+    const bool needCoarse = levels > 1;
+    int rcInverse = MGPS_OK;
+    {
+        const Dims cd = h->lv[size_t(levels - 1)].d;
+        std::vector<uint8_t> coarsest(cd.cells());
+        ODS_HIP(hipMemcpy(coarsest.data(), labOf(levels - 1), cd.cells(), hipMemcpyDeviceToHost));
+        inverseJob = std::thread([h, nx, ny, nz, levels, needCoarse, &rcInverse, lab = std::move(coarsest)] {
+            rcInverse = hierarchyLight(&h->hier, nx, ny, nz, levels, lab.data(), h->opt, needCoarse);
+            if (rcInverse == MGPS_OK && needCoarse) h->hier->buildDenseInverse();
+        });
+    }
+    // ---- face weights
+    {
+        const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz, size_t(d0.nx) * d0.ny * (d0.nz + 1)};
+        const float *src[3] = {wx, wy, wz};
+        for (int a = 0; a < 3; ++a) {
+            ODS_TRY(devAlloc(h, &h->w[a], wn[a], false));
+            ODS_HIP(hipMemcpyAsync(h->w[a], src[a], wn[a] * sizeof(float), kind, nullptr));
+        }
+    }
+
+    // ---- band masks and tile counts of every level, then one round of counts to the host
+    struct LevelTmp {
+        int nt = 0, tx = 0, ty = 0, tz = 0;
+        uint32_t *mask = nullptr;
+        uint16_t *prefix = nullptr;
+        int32_t *tileCount = nullptr, *tileKind = nullptr, *tileStart = nullptr, *scan = nullptr;
+        int32_t *sorted = nullptr, *general = nullptr, *genRank = nullptr, *bandEntry = nullptr;
+        uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
+        int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
+        int nband = 0, nGen = 0, planeZc = 0;
+        size_t nfine = 0, nplane = 0;
+    };
+    std::vector<LevelTmp> T{size_t(levels)};
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        t.tx = (L.d.nx + kTile - 1) / kTile;
+        t.ty = (L.d.ny + kTile - 1) / kTile;
+        t.tz = (L.d.nz + kTile - 1) / kTile;
+        t.nt = t.tx * t.ty * t.tz;
+        ODS_TRY(tmp.get(h, &t.mask, size_t(t.nt) * 128));
+        ODS_TRY(tmp.get(h, &t.prefix, size_t(t.nt) * 128));
+        ODS_TRY(tmp.get(h, &t.tileCount, size_t(t.nt)));
+        ODS_TRY(tmp.get(h, &t.tileKind, size_t(t.nt)));
+        ODS_TRY(tmp.get(h, &t.tileStart, size_t(t.nt) + 1));
+        ODS_TRY(tmp.get(h, &t.scan, scanScratchInts(L.d.cells())));
+        ODS_LAUNCH(launchBandMasks(nullptr, L.d, labOf(l), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind));
+        ODS_LAUNCH(launchExclusiveScan(nullptr, t.tileCount, t.tileStart, size_t(t.nt), t.scan));
+    }
+    for (int l = 0; l < levels; ++l) ODS_HIP(hipMemcpy(&T[size_t(l)].nband, T[size_t(l)].tileStart + T[size_t(l)].nt, sizeof(int), hipMemcpyDeviceToHost));
+    clock.lap("band masks + counts");
+
+    // ---- band lists in reference order, classification, scan of the general cells
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        const size_t nb = size_t(t.nband);
+        L.nband = t.nband;
+        ODS_TRY(tmp.get(h, &t.sorted, nb));
+        ODS_TRY(tmp.get(h, &t.general, nb));
+        ODS_TRY(tmp.get(h, &t.genRank, nb + 1));
+        ODS_TRY(tmp.get(h, &t.bandEntry, nb));
+        ODS_TRY(tmp.get(h, &t.diagS, nb));
+        ODS_TRY(devAlloc(h, &L.band, nb, false));
+        ODS_TRY(devAlloc(h, &L.bandDiag, nb, false));
+        ODS_TRY(devAlloc(h, &L.bandTmp, nb, false));
+        if (t.nband > 0) {
+            ODS_LAUNCH(launchBandFill(nullptr, L.d, t.mask, t.prefix, t.tileStart, t.sorted));
+            ODS_LAUNCH(launchBandClassify(nullptr, L.d, labOf(l), l == 0 ? h->w[0] : nullptr, l == 0 ? h->w[1] : nullptr, l == 0 ? h->w[2] : nullptr, t.sorted,
+                                          t.nband, t.diagS, t.general, l == 0 ? flags + 2 * mgLevels + 1 : nullptr));
+        }
+        ODS_LAUNCH(launchExclusiveScan(nullptr, t.general, t.genRank, nb, t.scan));
+    }
+    for (int l = 0; l < levels; ++l) ODS_HIP(hipMemcpy(&T[size_t(l)].nGen, T[size_t(l)].genRank + T[size_t(l)].nband, sizeof(int), hipMemcpyDeviceToHost));
+    {
+        int violations = 0;
+        ODS_HIP(hipMemcpy(&violations, flags + 2 * mgLevels + 1, sizeof(int), hipMemcpyDeviceToHost));
+        if (violations)
+            return bail(failH(h, MGPS_ERR_HIERARCHY,
+                              "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
+    }
+    clock.lap("band lists + classification");
+
+    // ---- device order, rows, codes, activity flags
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        L.nbndGeneral = t.nGen;
+        ODS_TRY(devAlloc(h, &L.rows, size_t(7) * size_t(t.nGen), false));
+        ODS_TRY(devAlloc(h, &L.tileBndStart, size_t(t.nt) + 1, false));
+        ODS_LAUNCH(launchBandSplit(nullptr, L.d, labOf(l), l == 0 ? h->w[0] : nullptr, l == 0 ? h->w[1] : nullptr, l == 0 ? h->w[2] : nullptr, t.sorted, t.nband,
+                                   t.diagS, t.genRank, L.band, L.bandDiag, t.bandEntry, L.rows));
+        ODS_LAUNCH(launchGather(nullptr, t.genRank, t.tileStart, t.nt + 1, L.tileBndStart));
+        t.nfine = (L.d.cells() + kWaveChunkCells - 1) / kWaveChunkCells;
+        t.planeZc = planeSweepZc(L.d.nx, L.d.ny, L.d.nz);
+        ODS_TRY(tmp.get(h, &t.chunkFlags, t.nfine));
+        if (t.planeZc) {
+            t.nplane = size_t((L.d.nx + 255) / 256) * size_t((L.d.ny + kPlaneRows - 1) / kPlaneRows) * size_t((L.d.nz + t.planeZc - 1) / t.planeZc);
+            ODS_TRY(tmp.get(h, &t.planeFlags, t.nplane));
+            ODS_HIP(hipMemsetAsync(t.planeFlags, 0, t.nplane, nullptr));
+        }
+        ODS_LAUNCH(launchActivityFlags(nullptr, L.d, labOf(l), t.chunkFlags, t.planeFlags, t.planeZc));
+        // (the groups below read the labels for activity only: patched or not makes no difference)
+        ODS_LAUNCH(launchPatchSimpleCodes(nullptr, labOf(l), L.band, L.bandDiag, L.nbndGeneral, L.nband));
+    }
+    // ---- groups of the fused band stage: counts
+    const bool wantGroups = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
+    std::vector<int> haveGroups(size_t(levels), 0);
+    for (int l = 0; l < levels && wantGroups; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        if (t.nband == 0 || size_t(t.nband) > size_t(kBandEntryMask)) continue;
+        haveGroups[size_t(l)] = 1;
+        for (int q = 0; q < 3; ++q) {
+            ODS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nt)));
+            ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nt) + 1));
+        }
+        ODS_LAUNCH(launchBandGroupsCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, o.band_iterations, t.gcount[0], t.gcount[1], t.gcount[2],
+                                         flags + 2 * mgLevels + 2 + l));
+        for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nt), t.scan));
+    }
+    // ---- host side of the lists: flags and kinds come back, lists go up
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        std::vector<uint8_t> fineAct(t.nfine), planeAct(t.nplane);
+        std::vector<int32_t> kinds(size_t(t.nt));
+        ODS_HIP(hipMemcpy(fineAct.data(), t.chunkFlags, t.nfine, hipMemcpyDeviceToHost));
+        if (t.nplane) ODS_HIP(hipMemcpy(planeAct.data(), t.planeFlags, t.nplane, hipMemcpyDeviceToHost));
+        ODS_HIP(hipMemcpy(kinds.data(), t.tileKind, size_t(t.nt) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HostLevel HL;
+        HL.d = L.d;
+        chunkListsFromFlags(HL, fineAct.data(), int64_t(t.nfine));
+        for (size_t q = 0; q < planeAct.size(); ++q)
+            if (planeAct[q]) HL.planeBlocks.push_back(int32_t(q));
+        tileListsFromKinds(HL, kinds.data(), 0);
+        ODS_TRY(devUpload(h, &L.chunks, HL.chunks));
+        ODS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
+        ODS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
+        ODS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
+        ODS_TRY(devUpload(h, &L.mixed[0], HL.mixedEven));
+        ODS_TRY(devUpload(h, &L.mixed[1], HL.mixedOdd));
+        L.npure[0] = int(HL.pureEven.size());
+        L.npure[1] = int(HL.pureOdd.size());
+        L.nmixed[0] = int(HL.mixedEven.size());
+        L.nmixed[1] = int(HL.mixedOdd.size());
+        if (l > 0) {
+            ODS_TRY(gridAlloc(h, &L.x, L.d));
+            ODS_TRY(gridAlloc(h, &L.b, L.d));
+        }
+        ODS_TRY(gridAlloc(h, &L.r, L.d));
+        ODS_TRY(gridAlloc(h, &L.tmp, L.d));
+        fillGridP(h, L, l == 0, int(HL.chunks.size()), HL.chunkCells, int(HL.planeBlocks.size()), t.planeZc);
+    }
+    clock.lap("device order, codes, activity + tile lists");
+    // ---- groups: totals to the host, arrays filled
+    for (int l = 0; l < levels; ++l) {
+        if (!haveGroups[size_t(l)]) continue;
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        int tot[3] = {0, 0, 0}, brokenL = 0;
+        for (int q = 0; q < 3; ++q) ODS_HIP(hipMemcpy(&tot[q], t.gat[q] + t.nt, sizeof(int), hipMemcpyDeviceToHost));
+        ODS_HIP(hipMemcpy(&brokenL, flags + 2 * mgLevels + 2 + l, sizeof(int), hipMemcpyDeviceToHost));
+        if (brokenL || tot[0] == 0) continue;  // (the level then runs its band passes one by one)
+        L.bandGroups.depth = o.band_iterations;
+        L.bandGroups.ngroups = tot[0];
+        ODS_TRY(devAlloc(h, &L.bandGroups.info, size_t(8) * size_t(tot[0]), false));
+        ODS_TRY(devAlloc(h, &L.bandGroups.updateEntry, size_t(tot[1]), false));
+        ODS_TRY(devAlloc(h, &L.bandGroups.updateCell, size_t(tot[1]), false));
+        ODS_TRY(devAlloc(h, &L.bandGroups.neighbours, size_t(6) * size_t(tot[1]), false));
+        ODS_TRY(devAlloc(h, &L.bandGroups.readCell, size_t(tot[2]), false));
+        ODS_LAUNCH(launchBandGroupsFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.gat[0], t.gat[1], t.gat[2],
+                                        L.bandGroups.info, L.bandGroups.updateEntry, L.bandGroups.updateCell, L.bandGroups.neighbours, L.bandGroups.readCell,
+                                        flags + 2 * mgLevels + 2 + l));
+    }
+    ODS_HIP(hipDeviceSynchronize());
+    clock.lap("band groups");
+    inverseJob.join();
+    if (rcInverse != MGPS_OK) {
+        h->lastError = lastGlobalError();
+        return bail(rcInverse);
+    }
+    clock.lap("wait for the coarse inverse");
+    int rc = commonDeviceState(h, needCoarse);
+    if (rc != MGPS_OK) return bail(rc);
+    clock.lap("coarse solver upload + scratch");
+#undef ODS_TRY
+#undef ODS_HIP
+#undef ODS_LAUNCH
+    *out = h;
+    return MGPS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1498,6 +1972,11 @@ extern "C" {
 const char *mgps_last_error(const mgps_solver *h) { return h ? h->lastError.c_str() : lastGlobalError(); }
 
 void mgps_trim_host_cache(void) { pinnedTrim(); }
+void mgps_trim_device_cache(void)
+{
+    (void)hipDeviceSynchronize();
+    deviceTrim();
+}
 
 void *mgps_host_alloc(size_t bytes)
 try {
@@ -1539,6 +2018,7 @@ try {
     MGPS_TRY(readOptions(opt, &o));
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
+    if (!hostSetup(o)) return createWholeOnDevice(out, nx, ny, nz, labels_host, wx_host, wy_host, wz_host, hipMemcpyHostToDevice, mg_levels, use_gauss_seidel != 0, o, device);
     mgps_hierarchy *hier = nullptr;
     MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz, labels_host, mg_levels, &o));
     {  // the fine-level invariants the reference asserts in debug builds (MG.cpp:234)
@@ -1585,20 +2065,20 @@ int createFromDeviceWeights(mgps_solver **out, int nx, int ny, int nz, const uin
         float *rowsDev = nullptr;
         int *violDev = nullptr;
         const size_t n = G.d.cells();
-        hipError_t e = labels_dev ? hipSuccess : hipMalloc(reinterpret_cast<void **>(&labDev), n);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cellsDev), std::max<size_t>(1, cells.size()) * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rowsDev), std::max<size_t>(1, rows.size()) * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&violDev), sizeof(int));
+        hipError_t e = labels_dev ? hipSuccess : cacheMalloc(reinterpret_cast<void **>(&labDev), n);
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&cellsDev), std::max<size_t>(1, cells.size()) * sizeof(int32_t));
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&rowsDev), std::max<size_t>(1, rows.size()) * sizeof(float));
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&violDev), sizeof(int));
         if (e == hipSuccess && !labels_dev) e = hipMemcpy(labDev, G.labels.data(), n, hipMemcpyHostToDevice);
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(cellsDev, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(violDev, 0, sizeof(int));
         if (e == hipSuccess) e = hipError_t(launchBoundaryRows(nullptr, G.d, labels_dev ? labels_dev : labDev, wx_dev, wy_dev, wz_dev, cellsDev, int(cells.size()), rowsDev, violDev));
         if (e == hipSuccess && !rows.empty()) e = hipMemcpy(rows.data(), rowsDev, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(&violations, violDev, sizeof(int), hipMemcpyDeviceToHost);
-        (void)hipFree(labDev);
-        (void)hipFree(cellsDev);
-        (void)hipFree(rowsDev);
-        (void)hipFree(violDev);
+        (void)cacheFree(labDev);
+        (void)cacheFree(cellsDev);
+        (void)cacheFree(rowsDev);
+        (void)cacheFree(violDev);
         if (e != hipSuccess) return drop(MGPS_ERR_HIP, std::string("mgps_create_device_weights: ") + hipGetErrorString(e));
     }
     int interiorOk = 0;
@@ -1620,6 +2100,23 @@ try {
     *out = nullptr;
     if (!labels_host || !wx_dev || !wy_dev || !wz_dev)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_device_weights: labels and the three weight grids are required");
+    {
+        mgps_options o;
+        MGPS_TRY(readOptions(opt, &o));
+        if (!hostSetup(o)) {  // the labels go up once (1 B per cell), everything else happens where the weights are
+            int device = 0;
+            MGPS_TRY(pickDevice(o, &device));
+            uint8_t *lab = nullptr;
+            const size_t n = size_t(nx) * ny * nz;
+            if (nx < 1 || ny < 1 || nz < 1 || cacheMalloc(reinterpret_cast<void **>(&lab), n) != hipSuccess)
+                return failH(nullptr, MGPS_ERR_ALLOC, "mgps_create_device_weights: label staging allocation failed");
+            int rc = hipMemcpy(lab, labels_host, n, hipMemcpyHostToDevice) == hipSuccess
+                         ? createWholeOnDevice(out, nx, ny, nz, lab, wx_dev, wy_dev, wz_dev, hipMemcpyDeviceToDevice, mg_levels, use_gauss_seidel != 0, o, device)
+                         : failH(nullptr, MGPS_ERR_HIP, "mgps_create_device_weights: label upload failed");
+            (void)cacheFree(lab);
+            return rc;
+        }
+    }
     return createFromDeviceWeights(out, nx, ny, nz, labels_host, nullptr, wx_dev, wy_dev, wz_dev, mg_levels, use_gauss_seidel, opt);
 }
 MGPS_API_CATCH(nullptr)
@@ -1635,7 +2132,8 @@ try {
     MGPS_TRY(readOptions(opt, &o));
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
-    // the hierarchy and the lists are built on the host from one byte per cell
+    if (!hostSetup(o)) return createWholeOnDevice(out, nx, ny, nz, labels_dev, wx_dev, wy_dev, wz_dev, hipMemcpyDeviceToDevice, mg_levels, use_gauss_seidel != 0, o, device);
+    // options.host_setup: the hierarchy and the lists are built on the host from one byte per cell
     RawVec<uint8_t> labels(size_t(nx) * ny * nz);
     if (hipMemcpy(labels.data(), labels_dev, labels.size(), hipMemcpyDeviceToHost) != hipSuccess)
         return failH(nullptr, MGPS_ERR_HIP, "mgps_create_device: copying the labels to the host failed");
@@ -1857,8 +2355,8 @@ try {
                 for (int q = 0; q < 2 && e == hipSuccess; ++q)
                     if (!recv[q].empty()) e = hipMemcpy(recv[q].data(), rd[q], recv[q].size() * sizeof(float), hipMemcpyDeviceToHost);
                 for (int q = 0; q < 2; ++q) {
-                    (void)hipFree(sd[q]);
-                    (void)hipFree(rd[q]);
+                    (void)cacheFree(sd[q]);
+                    (void)cacheFree(rd[q]);
                 }
                 if (crc != 0) return bail(failH(h, MGPS_ERR_COMM, "row exchange failed during set-up"));
                 if (e != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string("row exchange: ") + hipGetErrorString(e)));
@@ -1948,7 +2446,78 @@ MGPS_API_CATCH(nullptr)
 
 void mgps_destroy(mgps_solver *h) { freeAll(h); }
 int mgps_levels(const mgps_solver *h) { return h ? h->totalLevels : 0; }
-const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *h) { return h ? h->hier : nullptr; }
+// A solver set up on the device holds only the extents of its levels on the host; the first caller who asks for the
+// hierarchy gets the host builder's, made from the fine labels (the device codes with the simple cells folded back).
+const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *hc)
+try {
+    auto *h = const_cast<mgps_solver *>(hc);
+    if (!h || !h->hier || !h->hier->light) return h ? h->hier : nullptr;
+    (void)hipSetDevice(h->device);
+    const Dims d = h->lv[0].d;
+    RawVec<uint8_t> labels(d.cells());
+    if (hipMemcpy(labels.data(), h->lv[0].g.lab, d.cells(), hipMemcpyDeviceToHost) != hipSuccess) {
+        failH(h, MGPS_ERR_HIP, "mgps_get_hierarchy: copying the labels to the host failed");
+        return nullptr;
+    }
+    for (uint8_t &l : labels)
+        if (l > MGPS_BOUNDARY_CELL) l = MGPS_BOUNDARY_CELL;
+    mgps_hierarchy *full = nullptr;
+    if (hierarchyCreate(&full, d.nx, d.ny, d.nz, labels.data(), h->requestedLevels, &h->opt, false, true) != MGPS_OK) {
+        failH(h, MGPS_ERR_HIERARCHY, std::string("mgps_get_hierarchy: ") + lastGlobalError());
+        return nullptr;
+    }
+    mgps_hierarchy_destroy(h->hier);
+    h->hier = full;
+    return full;
+} catch (...) {
+    return nullptr;
+}
+
+int mgps_level_array(mgps_solver *h, int level, int which, void *out, int64_t *count)
+try {
+    MGPS_TRY(checkLevel(h, level, "mgps_level_array"));
+    if (!count) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: count is NULL");
+    const DevLevel &L = h->lv[level];
+    const int nt = ((L.d.nx + kTile - 1) / kTile) * ((L.d.ny + kTile - 1) / kTile) * ((L.d.nz + kTile - 1) / kTile);
+    const void *src = nullptr;
+    size_t n = 0, elem = 4;
+    switch (which) {
+    case 0: src = L.g.lab, n = L.d.cells(), elem = 1; break;
+    case 1: src = L.band, n = size_t(L.nband); break;
+    case 2: src = L.bandDiag, n = size_t(L.nband), elem = 1; break;
+    case 3: src = L.rows, n = size_t(7) * size_t(L.nbndGeneral); break;
+    case 4: src = L.chunks, n = size_t(L.g.nchunks); break;
+    case 5: src = L.planeBlocks, n = size_t(L.g.nplaneBlocks); break;
+    case 6: src = L.pure[0], n = size_t(L.npure[0]); break;
+    case 7: src = L.pure[1], n = size_t(L.npure[1]); break;
+    case 8: src = L.mixed[0], n = size_t(L.nmixed[0]); break;
+    case 9: src = L.mixed[1], n = size_t(L.nmixed[1]); break;
+    case 10: src = L.tileBndStart, n = size_t(nt) + 1; break;
+    case 11: src = L.bandGroups.info, n = size_t(8) * size_t(L.bandGroups.ngroups); break;
+    case 12:
+    case 13:
+    case 14:
+    case 15: {
+        if (L.bandGroups.ngroups == 0) break;
+        int32_t last[8];  // the last group's offsets + sizes give the totals
+        MGPS_HIP(h, hipMemcpy(last, L.bandGroups.info + 8 * size_t(L.bandGroups.ngroups - 1), sizeof(last), hipMemcpyDeviceToHost));
+        const size_t nUpd = size_t(last[0]) + size_t(last[3 + L.bandGroups.depth - 1]), nRead = size_t(last[1]) + size_t(last[2]);
+        if (which == 12) src = L.bandGroups.updateEntry, n = nUpd;
+        else if (which == 13) src = L.bandGroups.updateCell, n = nUpd;
+        else if (which == 14) src = L.bandGroups.neighbours, n = 6 * nUpd, elem = 2;
+        else src = L.bandGroups.readCell, n = nRead;
+        break;
+    }
+    default: return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: unknown array");
+    }
+    *count = int64_t(n);
+    if (out && n) {
+        MGPS_HIP(h, hipStreamSynchronize(h->stream));
+        MGPS_HIP(h, hipMemcpy(out, src, n * elem, hipMemcpyDeviceToHost));
+    }
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
@@ -2009,7 +2578,7 @@ try {
                 void *base = *it;
                 h->userGrids.erase(it);
                 MGPS_HIP(h, hipStreamSynchronize(h->stream));
-                MGPS_HIP(h, hipFree(base));
+                MGPS_HIP(h, cacheFree(base));
                 return MGPS_OK;
             }
     return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_free: not a grid of this solver");
@@ -2383,7 +2952,7 @@ int withHostGrids64(mgps_solver *h, double *x_host, const double *b_host, bool u
         }();
     }
     const std::string keep = h->lastError;
-    (void)hipFree(stage);
+    (void)cacheFree(stage);
     if (bd) mgps_grid_free(h, bd);
     mgps_grid_free(h, xd);
     if (rc != MGPS_OK) h->lastError = keep;

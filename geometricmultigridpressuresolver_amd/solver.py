@@ -231,6 +231,21 @@ class GeometricMultigridPoissonSolver:
     def hierarchy(self):
         return Hierarchy(_borrowed=lib().mgps_get_hierarchy(self.h))
 
+    LEVEL_ARRAYS = {"codes": (0, np.uint8), "band": (1, np.int32), "band_diag": (2, np.uint8), "rows": (3, np.float32), "chunks": (4, np.int32),
+                    "plane_blocks": (5, np.int32), "pure_even": (6, np.int32), "pure_odd": (7, np.int32), "mixed_even": (8, np.int32),
+                    "mixed_odd": (9, np.int32), "tile_bnd_start": (10, np.int32), "group_info": (11, np.int32), "group_update_entry": (12, np.int32),
+                    "group_update_cell": (13, np.int32), "group_neighbours": (14, np.uint16), "group_read_cell": (15, np.int32)}
+
+    def level_array(self, level, name):
+        """mgps_level_array: one of the set-up arrays of a level as it sits on the device (tests / tools)."""
+        which, dt = self.LEVEL_ARRAYS[name]
+        n = C.c_int64()
+        check(lib().mgps_level_array(self.h, int(level), which, None, C.byref(n)), self.h)
+        out = np.empty(n.value, dtype=dt)
+        if n.value:
+            check(lib().mgps_level_array(self.h, int(level), which, _p(out), C.byref(n)), self.h)
+        return out
+
     def level_shape(self, level):
         d = (C.c_int * 3)()
         check(lib().mgps_level_dims(self.h, level, d), self.h)

@@ -114,6 +114,11 @@ typedef struct mgps_options {
        only corrections pass through binary16).  Single-device solvers with the Jacobi smoother (use_gauss_seidel = 0) whose fine nx is a multiple of 4.
        mgps_solve_pcg then preconditions with this cycle: tolerance and iteration counts against fp32 in DESIGN.md */
     int precision;
+    /* 0 (default): single-device solvers build the hierarchy (coarse labels MG.cpp:238-253, band lists MG.cpp:279-281) and
+       every list the kernels use on the device, from labels that never cross PCIe again -- the reference rebuilds its solver
+       every sub-step (Plug.cpp:463), so set-up is on the critical path.  1 = the host builder (threads; the builder of slab
+       runs, and the checker the tests compare the device arrays with, entry for entry).  Same solver either way */
+    int host_setup;
 } mgps_options;
 
 typedef struct mgps_pcg_stats {
@@ -131,6 +136,13 @@ const char *mgps_status_string(int status);
  * failed call that had no handle (mgps_create, mgps_hierarchy_create, domain helpers). */
 const char *mgps_last_error(const mgps_solver *h);
 int mgps_device_count(int *count);
+/* Introspection for tests and tools: the set-up arrays of level `level` as they sit on the device.  `which`:
+ * 0 cell codes (u8, nx*ny*nz), 1 band list in device order (i32), 2 band diagonals (u8), 3 operator rows of the general
+ * BOUNDARY cells (f32, 7 x count SoA), 4 activity chunks (i32), 5 plane blocks (i32), 6 / 7 pure tiles even / odd (i32),
+ * 8 / 9 mixed tiles even / odd (i32), 10 per-tile start of the general BOUNDARY cells (i32), 11..15 the groups of the fused
+ * band stage: info (i32, 8 per group), update entries (i32), update cells (i32), neighbours (u16, 6 per update node),
+ * read-only cells (i32).  *count = number of elements; out == NULL asks for the count only. */
+int mgps_level_array(mgps_solver *h, int level, int which, void *out, int64_t *count);
 
 /* ---- domain expansion: host arrays --------------------------------------------------------
  * buildExpandedCellLabels sizing rule (Ops.h:1340-1362).  levels_in = 0 applies the reference rule
@@ -197,7 +209,8 @@ int mgps_create_device_weights(mgps_solver **out, int nx, int ny, int nz, const 
                                const float *wx_dev, const float *wy_dev, const float *wz_dev, int mg_levels,
                                int use_gauss_seidel, const mgps_options *opt);
 /* As above with the labels on the device too (mgps_fields_domain_labels + mgps_fields_set_boundary_labels write them
- * there): the library fetches its own host copy of the 1 byte per cell the host-side hierarchy builder needs. */
+ * there): nothing of the size of the grid crosses PCIe -- the hierarchy and every list are built on the device
+ * (options.host_setup = 1: the library fetches a host copy of the 1 byte per cell for the host-side builder). */
 int mgps_create_device(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_dev, const float *wx_dev,
                        const float *wy_dev, const float *wz_dev, int mg_levels, int use_gauss_seidel,
                        const mgps_options *opt);
@@ -206,6 +219,11 @@ void mgps_destroy(mgps_solver *h);
  * every sub-step in the reference's use, Plug.cpp:463; cap: MGPS_PINNED_CACHE_MB, default 4096).  This returns
  * them to the system. */
 void mgps_trim_host_cache(void);
+/* Device memory released by a solver (or by mgps_project_free_surface) is kept for the next one: once a process holds
+ * tens of GiB, hipMalloc costs 60-130 ms per 4 GiB block and every hipFree 0.2 ms on this platform, more than the solve
+ * (cap: MGPS_DEVICE_CACHE_MB, default 98304; an allocation that fails trims the cache and tries again).  This returns
+ * the cached blocks to the system, e.g. before another library needs the memory. */
+void mgps_trim_device_cache(void);
 /* Page-locked host memory for the caller's staging buffers (the flattened fields a Houdini shim uploads every
  * sub-step).  On this platform a hipMemcpy out of a fresh pageable array runs at about 3 GB/s, out of a page-locked one
  * at about 55 GB/s; blocks come from (and return to) the same cache as the library's own set-up arrays, so a

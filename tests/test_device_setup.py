@@ -1,0 +1,145 @@
+"""Device-side hierarchy set-up (csrc/mgps_setup.hip) against the host builder
+(csrc/mgps_host.cpp, options.host_setup = 1): the coarse labels (Ops.cpp:23-163), the band lists in the reference's order
+(Ops.cpp:165-469), the operator rows (Ops.h:208-256), the cell codes, the activity and tile lists and the groups of the fused
+band stage must be equal entry for entry on every level, and the solvers built from them must produce the same bits."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from conftest import make_domain  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+import geometricmultigridpressuresolver_amd as G  # noqa: E402
+from geometricmultigridpressuresolver_amd import domains as D  # noqa: E402
+
+
+def _pair(lab, w, lev, gs, **opts):
+    out = []
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        for k, v in opts.items():
+            setattr(o, k, v)
+        out.append(G.GeometricMultigridPoissonSolver(lab, w, lev, gs, options=o))
+    return out
+
+
+def _compare(sh, sd):
+    assert sh.getMGLevels() == sd.getMGLevels()
+    for l in range(sh.getMGLevels()):
+        assert sh.level_shape(l) == sd.level_shape(l)
+        for name in sh.LEVEL_ARRAYS:
+            a, b = sh.level_array(l, name), sd.level_array(l, name)
+            assert a.shape == b.shape, (l, name, a.shape, b.shape)
+            if not np.array_equal(a, b):
+                bad = np.flatnonzero(a != b)
+                raise AssertionError(f"level {l} array {name}: {bad.size} of {a.size} entries differ, first at {bad[:5]}: host {a[bad[:5]]} device {b[bad[:5]]}")
+
+
+CASES = [("simple", 32, None), ("complex", 48, None), ("solid", 64, None), ("odd", 40, None), ("wide", 32, None), ("widesolid", 32, None), ("solid", 96, None)]
+
+
+@pytest.mark.parametrize("kind,g,levels", CASES)
+@pytest.mark.parametrize("gs", [False, True])
+def test_arrays_equal_host_builder(kind, g, levels, gs):
+    lab, w, off, lev, dx = make_domain(kind, g, levels)
+    sh, sd = _pair(lab, w, lev, gs)
+    try:
+        _compare(sh, sd)
+        # and the cycles agree to the bit
+        rhs = D.random_rhs(lab, dx)
+        outs = []
+        for s in (sh, sd):
+            x, b = s.new_grid(), s.to_device(rhs)
+            s.applyVCycle(x, b, False)
+            s.applyVCycle(x, b, True)
+            outs.append(x.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+    finally:
+        sh.close()
+        sd.close()
+
+
+@pytest.mark.parametrize("width,depth", [(1, 1), (2, 2), (4, 4), (3, 1), (5, 3)])
+def test_band_width_and_depth(width, depth):
+    lab, w, off, lev, dx = make_domain("solid", 48)
+    sh, sd = _pair(lab, w, lev, False, band_width=width, band_iterations=depth)
+    try:
+        _compare(sh, sd)
+    finally:
+        sh.close()
+        sd.close()
+
+
+def test_tight_expansion_and_device_inputs():
+    """labels and weights already on the device (mgps_create_device), tight (non power-of-two) extents"""
+    bl, bw, dx = D.build_complex_domain(40, use_solid=True, dtype=np.float32)
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(48, 48, 48))
+    o = G.default_options()
+    o.host_setup = 1
+    sh = G.GeometricMultigridPoissonSolver(lab, w, lev, True, options=o)
+    sd = G.GeometricMultigridPoissonSolver(torch.from_numpy(lab).cuda(), [torch.from_numpy(a).cuda() for a in w], lev, True)
+    try:
+        _compare(sh, sd)
+        # the host-side hierarchy of a device-built solver is made on demand and is the host builder's
+        hh, hd = sh.hierarchy(), sd.hierarchy()
+        for l in range(sh.getMGLevels()):
+            assert np.array_equal(hh.level_labels(l), hd.level_labels(l))
+            assert np.array_equal(hh.band_cells(l), hd.band_cells(l))
+    finally:
+        sh.close()
+        sd.close()
+
+
+def test_errors_match_host_builder():
+    lab, w, off, lev, dx = make_domain("solid", 32)
+    bad = lab.copy()
+    bad[0, 5, 5] = 0  # the shell is broken
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        with pytest.raises(G.MgpsError) as e:
+            G.GeometricMultigridPoissonSolver(bad, w, lev, False, options=o)
+        assert "EXTERIOR shell" in str(e.value), (host, str(e.value))
+    # an INTERIOR cell next to an inactive one (the BOUNDARY marking was skipped)
+    raw = lab.copy()
+    raw[raw == 3] = 0
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        with pytest.raises(G.MgpsError) as e:
+            G.GeometricMultigridPoissonSolver(raw, w, lev, False, options=o)
+        assert "unitTestBoundaryCells" in str(e.value), (host, str(e.value))
+    # too many levels for the padding: a coarse level loses its shell
+    lab2, w2, off2, lev2, dx2 = make_domain("simple", 32, levels=2)
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        with pytest.raises(G.MgpsError) as e:
+            G.GeometricMultigridPoissonSolver(lab2, w2, lev2 + 3, False, options=o)
+        assert "EXTERIOR" in str(e.value) or "divisible" in str(e.value), (host, str(e.value))
+
+
+def test_level_cap_quirk_on_device():
+    """MG.cpp:241-246: the level count drops to l - 1 at the first level without a solvable cell -- same on both builders"""
+    n = 64
+    lab = np.full((n, n, n), 1, dtype=np.uint8)
+    w = [np.zeros(D.face_shape(n, n, n, a), dtype=np.float32) for a in range(3)]
+    lab[30:34, 30:34, 30:34] = 2  # a DIRICHLET block: coarse levels hold no active cell
+    lab[31, 31, 31] = 0
+    lab = D.set_boundary_labels(lab, w)
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        try:
+            s = G.GeometricMultigridPoissonSolver(lab, w, 4, False, options=o)
+            lev = s.getMGLevels()
+            s.close()
+        except G.MgpsError as e:
+            lev = str(e)
+        if host:
+            ref = lev
+        else:
+            assert lev == ref, (ref, lev)

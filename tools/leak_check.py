@@ -26,6 +26,7 @@ for it in range(cycles):
         del x, s
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    G.trim_device_cache()  # the library keeps released device blocks for the next solver: hand them back before measuring
     free, total = torch.cuda.mem_get_info()
     rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024
     used = (total - free) >> 20
