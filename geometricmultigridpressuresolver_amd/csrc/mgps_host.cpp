@@ -1676,10 +1676,58 @@ int mgps::hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int level
     HostLevel &C = H->lv[size_t(levels - 1)];
     C.labels.resize(C.d.cells());
     std::memcpy(C.labels.data(), coarsestLabels, C.d.cells());
-    const int rc = needCoarseSolver ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
-    if (rc != MGPS_OK) {
-        delete H;
-        return rc;
+    if (needCoarseSolver) {
+        // A time-stepping caller builds a solver per sub-step and the coarsest labels rarely change between two of them:
+        // the last few factorisations and dense inverses (10 ms of host threads at 14^3 unknowns) are kept by label pattern.
+        struct Kept {
+            Dims d;
+            std::vector<uint8_t> labels;
+            int n = 0, bw = 0;
+            std::vector<int32_t> cell, index;
+            std::vector<double> factor;
+            std::vector<float> inverse;
+        };
+        static std::mutex guard;
+        static std::vector<std::shared_ptr<Kept>> kept;  // most recent first
+        std::shared_ptr<Kept> hit;
+        {
+            std::lock_guard<std::mutex> lock(guard);
+            for (auto &k : kept)
+                if (k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->n <= o.max_coarse_unknowns &&
+                    std::memcmp(k->labels.data(), coarsestLabels, C.d.cells()) == 0) {
+                    hit = k;
+                    break;
+                }
+        }
+        if (hit) {
+            H->coarseN = hit->n;
+            H->coarseBW = hit->bw;
+            H->coarseCell = hit->cell;
+            H->coarseIndex = hit->index;
+            H->coarseL = hit->factor;
+            H->coarseInverse = hit->inverse;
+        } else {
+            const int rc = buildCoarseSolver(*H, o.max_coarse_unknowns);
+            if (rc != MGPS_OK) {
+                delete H;
+                return rc;
+            }
+            H->buildDenseInverse();
+            if (size_t(H->coarseN) * H->coarseN * sizeof(float) <= (size_t(64) << 20)) {
+                auto k = std::make_shared<Kept>();
+                k->d = C.d;
+                k->labels.assign(coarsestLabels, coarsestLabels + C.d.cells());
+                k->n = H->coarseN;
+                k->bw = H->coarseBW;
+                k->cell = H->coarseCell;
+                k->index = H->coarseIndex;
+                k->factor = H->coarseL;
+                k->inverse = H->coarseInverse;
+                std::lock_guard<std::mutex> lock(guard);
+                kept.insert(kept.begin(), k);
+                if (kept.size() > 4) kept.pop_back();
+            }
+        }
     }
     *out = H;
     return MGPS_OK;
