@@ -53,6 +53,7 @@ class Options(C.Structure):
         ("stencil_path", C.c_int),
         ("precision", C.c_int),
         ("host_setup", C.c_int),
+        ("borrow_device_weights", C.c_int),
     ]
 
 

@@ -591,6 +591,7 @@ try {
     float *rhs = pool.get<float>(ecells), *x = nullptr;
     PROJ_TRY(mgps_fields_rhs(rhs, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, ex, ey, ez, offset, s));
     mgps_solver *mg = nullptr;  // Plug.cpp:463-466
+    o.borrow_device_weights = 1;  // (the pool outlives the solver: `guard` below is destroyed first)
     int rc = mgps_create_device(&mg, ex, ey, ez, labels, w[0], w[1], w[2], levels, p->use_gauss_seidel, &o);
     if (rc != MGPS_OK) return rc;
     struct Guard {

@@ -369,7 +369,8 @@ int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab);
 int launchInteriorCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
 size_t scanScratchInts(size_t n);
 int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch);  // out: n + 1 entries
-int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind);
+int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
+                    int *interiorBad);  // interiorBad (optional): set when an INTERIOR cell has an inactive neighbour
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band);
 int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                        uint8_t *diagS, int32_t *general, int *violations);
@@ -377,11 +378,14 @@ int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float
                     const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows);
 int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out);
 int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t *chunkFlags, uint8_t *planeFlags, int zc);
+int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
+// the group kernels run over the list of tiles that hold band cells; counts and offsets are indexed by list position
 int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
-                          int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken);
+                          const int32_t *bandTiles, int nBandTiles, int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken);
 int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *groupAt, const int32_t *updateAt, const int32_t *readAt,
-                         int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours, int32_t *readCell, int *broken);
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *bandTiles, int nBandTiles, const int32_t *groupAt,
+                         const int32_t *updateAt, const int32_t *readAt, int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours,
+                         int32_t *readCell, int *broken);
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)

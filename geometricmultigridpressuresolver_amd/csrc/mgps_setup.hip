@@ -205,12 +205,15 @@ __global__ __launch_bounds__(kScanThreads) void scanDownKernel(const int32_t *__
 // One workgroup per 16^3 tile: the BOUNDARY cells of the tile and its halo of width-1 cells seed width-1 rings grown
 // through INTERIOR face neighbours; what lands inside the tile is the tile's share of the band.  Left behind per tile:
 // the 4096-bit membership mask (bit (k*16+j)*16+i, 128 words), the exclusive prefix count of every word, the count, and
-// the tile's kind for the Gauss-Seidel lists ((active cells << 1) | all 4096 cells INTERIOR).
+// the tile's kind for the Gauss-Seidel lists ((active cells << 1) | all 4096 cells INTERIOR).  With the block in LDS the
+// label half of unitTestBoundaryCells comes for free (interiorBad != nullptr: every INTERIOR cell of the tile must have
+// six active neighbours, Ops.h:1771-1870).
 __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__restrict__ lab, int width, int tx, int ty, uint32_t *__restrict__ mask,
-                                                      uint16_t *__restrict__ prefix, int32_t *__restrict__ tileCount, int32_t *__restrict__ tileKind)
+                                                      uint16_t *__restrict__ prefix, int32_t *__restrict__ tileCount, int32_t *__restrict__ tileKind,
+                                                      int *__restrict__ interiorBad)
 {
     extern __shared__ uint8_t sm[];
-    const int halo = width - 1, E = kTile + 2 * halo, E3 = E * E * E;
+    const int halo = max(width - 1, 1), E = kTile + 2 * halo, E2 = E * E, E3 = E2 * E;
     uint8_t *sl = sm, *mk = sm + E3;
     __shared__ uint16_t rowBits[256];
     __shared__ int wordCount[128];
@@ -220,31 +223,55 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
     const int oi = ti * kTile - halo, oj = tj * kTile - halo, ok = tk * kTile - halo;
     if (tid == 0) sSeeds = sActive = sInterior = 0;
     __syncthreads();
+    // the block of labels: EXTERIOR everywhere, then the part inside the grid row by row as aligned 4-byte words (eight
+    // or sixteen consecutive lanes share a row: whole cache lines per wave instruction instead of 64 rows of one byte)
+    for (int q = tid; q < E3 / 4; q += 256) reinterpret_cast<uint32_t *>(sl)[q] = 0x01010101u * MGPS_EXTERIOR_CELL;
+    __syncthreads();
+    {
+        const int dshift = E + 7 <= 32 ? 3 : 4;  // words a row can touch: (E + 3) / 4 + 1 <= 8 up to E = 24, <= 16 beyond
+        for (int w = tid; w < (E2 << dshift); w += 256) {
+            const int r = w >> dshift, q = w & ((1 << dshift) - 1);
+            const int lj = r % E, lk = r / E, gj = oj + lj, gk = ok + lk;
+            if (gj < 0 || gj >= d.ny || gk < 0 || gk >= d.nz) continue;
+            const ptrdiff_t rowBase = ptrdiff_t(cellIdx(d, 0, gj, gk));
+            const ptrdiff_t a0 = rowBase + max(oi, 0), a1 = rowBase + min(oi + E, d.nx);
+            const ptrdiff_t addr = (a0 & ~ptrdiff_t(3)) + 4 * q;
+            if (addr >= a1) continue;
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(lab + addr);  // (the allocation has a spare plane on each side)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const ptrdiff_t at = addr + b;
+                if (at >= a0 && at < a1) sl[r * E + int(at - rowBase) - oi] = uint8_t(word >> (8 * b));
+            }
+        }
+    }
+    __syncthreads();
     bool seeds = false;
-    for (int c = tid; c < E3; c += 256) {
-        const int li = c % E, lj = (c / E) % E, lk = c / (E * E);
-        const int gi = oi + li, gj = oj + lj, gk = ok + lk;
-        uint8_t v = MGPS_EXTERIOR_CELL;
-        if (gi >= 0 && gi < d.nx && gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz) v = lab[cellIdx(d, gi, gj, gk)];
-        sl[c] = v;
-        const bool seed = v >= MGPS_BOUNDARY_CELL;
-        mk[c] = seed ? 1 : 0;
-        seeds = seeds || seed;
+    for (int q = tid; q < E3 / 4; q += 256) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(sl)[q];
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m |= (((v >> (8 * b)) & 0xffu) >= MGPS_BOUNDARY_CELL ? 1u : 0u) << (8 * b);
+        reinterpret_cast<uint32_t *>(mk)[q] = m;
+        seeds = seeds || m != 0;
     }
     if (seeds) sSeeds = 1;
     __syncthreads();
     if (sSeeds)
         for (int ring = 1; ring < width; ++ring) {  // a cell marked in this ring carries ring + 1: readers of this ring skip it
-            for (int c = tid; c < E3; c += 256) {
-                if (sl[c] != MGPS_INTERIOR_CELL || mk[c] != 0) continue;
-                const int li = c % E, lj = (c / E) % E, lk = c / (E * E);
-                auto hit = [&](bool in, int off) {
-                    if (!in) return false;
-                    const unsigned m = mk[c + off];
-                    return m != 0 && m <= unsigned(ring);
-                };
-                if (hit(li > 0, -1) || hit(li + 1 < E, 1) || hit(lj > 0, -E) || hit(lj + 1 < E, E) || hit(lk > 0, -E * E) || hit(lk + 1 < E, E * E))
-                    mk[c] = uint8_t(ring + 1);
+            for (int r = tid; r < E2; r += 256) {
+                const int lj = r % E, lk = r / E;
+                for (int li = 0; li < E; ++li) {
+                    const int c = r * E + li;
+                    if (sl[c] != MGPS_INTERIOR_CELL || mk[c] != 0) continue;
+                    auto hit = [&](bool in, int off) {
+                        if (!in) return false;
+                        const unsigned m = mk[c + off];
+                        return m != 0 && m <= unsigned(ring);
+                    };
+                    if (hit(li > 0, -1) || hit(li + 1 < E, 1) || hit(lj > 0, -E) || hit(lj + 1 < E, E) || hit(lk > 0, -E2) || hit(lk + 1 < E, E2))
+                        mk[c] = uint8_t(ring + 1);
+                }
             }
             __syncthreads();
         }
@@ -253,13 +280,19 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
         const int c0 = ((lk + halo) * E + (lj + halo)) * E + halo;
         unsigned bits = 0;
         int act = 0, inter = 0;
+        bool bad = false;
 #pragma unroll
         for (int li = 0; li < kTile; ++li) {
-            bits |= (mk[c0 + li] != 0 ? 1u : 0u) << li;
-            const unsigned v = sl[c0 + li];
+            const int c = c0 + li;
+            bits |= (mk[c] != 0 ? 1u : 0u) << li;
+            const unsigned v = sl[c];
             act += activeCode(v);
             inter += v == MGPS_INTERIOR_CELL;
+            if (interiorBad && v == MGPS_INTERIOR_CELL)  // (cells past the grid read EXTERIOR: not active)
+                bad = bad || !activeCode(sl[c - 1]) || !activeCode(sl[c + 1]) || !activeCode(sl[c - E]) || !activeCode(sl[c + E]) ||
+                      !activeCode(sl[c - E2]) || !activeCode(sl[c + E2]);
         }
+        if (bad) *interiorBad = 1;
         rowBits[tid] = uint16_t(bits);
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
@@ -412,6 +445,18 @@ __global__ __launch_bounds__(256) void gatherKernel(const int32_t *__restrict__ 
     if (t < n) out[t] = rank[start[t]];
 }
 
+// flags[t] = tile t holds band cells; then list[rank[t]] = t
+__global__ __launch_bounds__(256) void tileFlagKernel(const int32_t *__restrict__ tileStart, int n, int32_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) flags[t] = tileStart[t + 1] > tileStart[t] ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void tileListKernel(const int32_t *__restrict__ rank, int n, int32_t *__restrict__ list)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n && rank[t + 1] != rank[t]) list[rank[t]] = t;
+}
+
 // ---- activity flags --------------------------------------------------------------------------------------------------
 
 // chunkFlags[q] = the q-th run of 256 cells holds an active cell (one wavefront per run); planeFlags (optional, nx % 4 == 0):
@@ -444,6 +489,7 @@ __global__ __launch_bounds__(256) void activityFlagsKernel(Dims d, const uint32_
 // FILL = false: per tile the number of groups, update nodes and read-only nodes; FILL = true: the arrays, at the tile's
 // scanned offsets.
 constexpr int kGroupThreads = 256;
+constexpr int kGroupMaxE = kTile + 2 * kBandMaxDepth;  // longest x-row of a box
 constexpr uint8_t kNodeNone = 255, kNodeRead = 200;
 
 struct Box {
@@ -458,13 +504,10 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
                                                                   const int32_t *__restrict__ groupAt, const int32_t *__restrict__ updateAt,
                                                                   const int32_t *__restrict__ readAt, int32_t *__restrict__ info,
                                                                   int32_t *__restrict__ updateEntry, int32_t *__restrict__ updateCell,
-                                                                  uint16_t *__restrict__ neighbours, int32_t *__restrict__ readCell, int *__restrict__ broken)
+                                                                  uint16_t *__restrict__ neighbours, int32_t *__restrict__ readCell, int *__restrict__ broken,
+                                                                  const int32_t *__restrict__ bandTiles)
 {
-    const int t = blockIdx.x;
-    if (tileStart[t + 1] == tileStart[t]) {
-        if (!FILL && threadIdx.x == 0) nGroups[t] = nUpdate[t] = nReadOnly[t] = 0;
-        return;
-    }
+    const int t = bandTiles[blockIdx.x];  // the tiles that hold band cells; counts and offsets are indexed by list position
     extern __shared__ uint8_t sm[];
     const int EM = kTile + 2 * depth, EM3 = EM * EM * EM;
     uint8_t *fl = sm;                                                  // bit 0 active, bit 1 band
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
         }
     }
     int groups = 0, upd = 0, rd = 0;  // running totals of this tile (uniform across the workgroup)
-    const int gBase = FILL ? groupAt[t] : 0, uBase = FILL ? updateAt[t] : 0, rBase = FILL ? readAt[t] : 0;
+    const int gBase = FILL ? groupAt[blockIdx.x] : 0, uBase = FILL ? updateAt[blockIdx.x] : 0, rBase = FILL ? readAt[blockIdx.x] : 0;
     __syncthreads();
     while (true) {
         __syncthreads();
@@ -524,39 +567,65 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
         if (owned == 0) continue;
         const int lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[3], bb[4], bb[5]};
         const int ex = hi[0] - lo[0] + 1 + 2 * depth, ey = hi[1] - lo[1] + 1 + 2 * depth, ez = hi[2] - lo[2] + 1 + 2 * depth;
-        const int N = ex * ey * ez;
         const int oi = ti * kTile + lo[0] - depth, oj = tj * kTile + lo[1] - depth, ok = tk * kTile + lo[2] - depth;  // grid cell of box cell (0,0,0)
-        // flags of the box: activity from the labels, band membership from the masks of the tiles the box touches
-        for (int c = tid; c < N; c += kGroupThreads) {
-            const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
-            const int gi = oi + li, gj = oj + lj, gk = ok + lk;
-            uint8_t f = 0;
-            if (gi >= 0 && gi < d.nx && gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz && activeCode(lab[cellIdx(d, gi, gj, gk)])) {
-                f = 1;
-                const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
-                const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
-                const uint32_t w = tile == t ? tmask[b >> 5] : mask[size_t(tile) * 128 + (b >> 5)];
-                if ((w >> (b & 31)) & 1u) f = 3;
+        // A thread owns a run of consecutive x-rows of the box (row r = lk * ey + lj): one division per row, the loads of a
+        // row issued together, and numbering by (thread, position) is the box order (k, j, i).
+        const int R = ey * ez, rp = (R + kGroupThreads - 1) / kGroupThreads, r0 = min(R, tid * rp), r1 = min(R, r0 + rp);
+        // flags of the box: activity from the labels, band membership from the masks of the (up to three) tiles a row crosses
+        for (int r = r0; r < r1; ++r) {
+            const int lj = r % ey, lk = r / ey, gj = oj + lj, gk = ok + lk;
+            const bool rowIn = gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz;
+            uint8_t v[kGroupMaxE];
+            uint32_t w0 = 0, w1 = 0, w2 = 0;
+            const int tix0 = max(oi, 0) >> 4;
+            if (rowIn) {
+                const uint8_t *src = lab + cellIdx(d, 0, gj, gk);
+#pragma unroll
+                for (int li = 0; li < kGroupMaxE; ++li) {
+                    const int gi = oi + li;
+                    v[li] = (li < ex && gi >= 0 && gi < d.nx) ? src[gi] : uint8_t(MGPS_EXTERIOR_CELL);
+                }
+                const size_t trow = size_t((gk >> 4) * ty + (gj >> 4)) * tx;
+                const int word = (((gk & 15) << 4) | (gj & 15)) >> 1, sh = (gj & 1) << 4;
+                w0 = (mask[(trow + tix0) * 128 + word] >> sh) & 0xffffu;
+                if (tix0 + 1 < tx) w1 = (mask[(trow + tix0 + 1) * 128 + word] >> sh) & 0xffffu;
+                if (tix0 + 2 < tx) w2 = (mask[(trow + tix0 + 2) * 128 + word] >> sh) & 0xffffu;
+            } else {
+#pragma unroll
+                for (int li = 0; li < kGroupMaxE; ++li) v[li] = MGPS_EXTERIOR_CELL;
             }
-            fl[c] = f;
-            // distance 0: the owned cells (band cells of this tile inside the tight box)
-            const bool own = f == 3 && li >= depth && li < ex - depth && lj >= depth && lj < ey - depth && lk >= depth && lk < ez - depth;
-            node[c] = own ? 0 : kNodeNone;
+            const bool rowOwn = lj >= depth && lj < ey - depth && lk >= depth && lk < ez - depth;
+#pragma unroll
+            for (int li = 0; li < kGroupMaxE; ++li)
+                if (li < ex) {
+                    const int gi = oi + li, q = (gi >> 4) - tix0;
+                    uint8_t f = 0;
+                    if (activeCode(v[li])) {  // (a cell past the grid read EXTERIOR)
+                        const uint32_t w = q == 0 ? w0 : (q == 1 ? w1 : w2);
+                        f = ((w >> (gi & 15)) & 1u) ? 3 : 1;
+                    }
+                    fl[r * ex + li] = f;
+                    // distance 0: the owned cells (band cells of this tile inside the tight box)
+                    node[r * ex + li] = (f == 3 && rowOwn && li >= depth && li < ex - depth) ? 0 : kNodeNone;
+                }
         }
         __syncthreads();
         for (int ring = 1; ring <= depth; ++ring) {  // ring == depth: the read-only nodes (any active cell next to an update node)
             const bool reads = ring == depth;
-            for (int c = tid; c < N; c += kGroupThreads) {
-                if (node[c] != kNodeNone || (reads ? fl[c] == 0 : fl[c] != 3)) continue;
-                const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
-                auto hit = [&](bool in, int off) { return in && (reads ? node[c + off] < depth : node[c + off] == ring - 1); };
-                if (hit(li > 0, -1) || hit(li + 1 < ex, 1) || hit(lj > 0, -ex) || hit(lj + 1 < ey, ex) || hit(lk > 0, -ex * ey) || hit(lk + 1 < ez, ex * ey))
-                    node[c] = reads ? kNodeRead : uint8_t(ring);
+            for (int r = r0; r < r1; ++r) {
+                const int lj = r % ey, lk = r / ey;
+                for (int li = 0; li < ex; ++li) {
+                    const int c = r * ex + li;
+                    if (node[c] != kNodeNone || (reads ? fl[c] == 0 : fl[c] != 3)) continue;
+                    auto hit = [&](bool in, int off) { return in && (reads ? node[c + off] < depth : node[c + off] == ring - 1); };
+                    if (hit(li > 0, -1) || hit(li + 1 < ex, 1) || hit(lj > 0, -ex) || hit(lj + 1 < ey, ex) || hit(lk > 0, -ex * ey) || hit(lk + 1 < ez, ex * ey))
+                        node[c] = reads ? kNodeRead : uint8_t(ring);
+                }
             }
             __syncthreads();
         }
-        // class counts: thread = a run of consecutive box cells, so that numbering by (thread, position) is the box order
-        const int per = (N + kGroupThreads - 1) / kGroupThreads, c0 = tid * per, c1 = min(N, c0 + per);
+        // class counts of this thread's rows
+        const int c0 = r0 * ex, c1 = r1 * ex;
         int cnt[5] = {0, 0, 0, 0, 0};
         for (int c = c0; c < c1; ++c) {
             const unsigned v = node[c];
@@ -618,31 +687,35 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
             }
             __syncthreads();
             const int uAt = uBase + upd, rAt = rBase + rd;
-            for (int c = tid; c < N; c += kGroupThreads) {
-                const unsigned v = node[c];
-                if (v == kNodeNone) continue;
-                const int li = c % ex, lj = (c / ex) % ey, lk = c / (ex * ey);
-                const int gi = oi + li, gj = oj + lj, gk = ok + lk;
-                const int32_t cell = int32_t(cellIdx(d, gi, gj, gk));
-                const int n = id[c];
-                if (v == kNodeRead) {
-                    readCell[rAt + (n - nUpd)] = cell;
-                    continue;
+            for (int r = r0; r < r1; ++r) {
+                const int lj = r % ey, lk = r / ey, gj = oj + lj, gk = ok + lk;
+                for (int li = 0; li < ex; ++li) {
+                    const int c = r * ex + li;
+                    const unsigned v = node[c];
+                    if (v == kNodeNone) continue;
+                    const int gi = oi + li;
+                    const int32_t cell = int32_t(cellIdx(d, gi, gj, gk));
+                    const int n = id[c];
+                    if (v == kNodeRead) {
+                        readCell[rAt + (n - nUpd)] = cell;
+                        continue;
+                    }
+                    updateCell[uAt + n] = cell;
+                    const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
+                    const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
+                    const uint32_t w = mask[size_t(tile) * 128 + (b >> 5)];
+                    const int sorted = tileStart[tile] + prefix[size_t(tile) * 128 + (b >> 5)] + __popc(w & ((1u << (b & 31)) - 1u));
+                    const int e = bandEntry[sorted];
+                    updateEntry[uAt + n] = e | (int32_t(bandDiag[e]) << kBandDiagShift);
+                    const int off[6] = {-1, 1, -ex, ex, -ex * ey, ex * ey};
+                    uint16_t q6[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) q6[q] = fl[c + off[q]] ? id[c + off[q]] : uint16_t(nUpd + nRead);  // (an update node is never on the box's rim)
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(neighbours + 6 * size_t(uAt + n));
+                    dst[0] = uint32_t(q6[0]) | (uint32_t(q6[1]) << 16);
+                    dst[1] = uint32_t(q6[2]) | (uint32_t(q6[3]) << 16);
+                    dst[2] = uint32_t(q6[4]) | (uint32_t(q6[5]) << 16);
                 }
-                updateCell[uAt + n] = cell;
-                const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
-                const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
-                const uint32_t w = mask[size_t(tile) * 128 + (b >> 5)];
-                const int sorted = tileStart[tile] + prefix[size_t(tile) * 128 + (b >> 5)] + __popc(w & ((1u << (b & 31)) - 1u));
-                const int e = bandEntry[sorted];
-                updateEntry[uAt + n] = e | (int32_t(bandDiag[e]) << kBandDiagShift);
-                const int off[6] = {-1, 1, -ex, ex, -ex * ey, ex * ey};
-                uint16_t q6[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) q6[q] = fl[c + off[q]] ? id[c + off[q]] : uint16_t(nUpd + nRead);  // (an update node is never on the box's rim)
-                uint16_t *dst = neighbours + 6 * size_t(uAt + n);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) dst[q] = q6[q];
             }
             if (tid == 0) {
                 int32_t *gi8 = info + 8 * size_t(gBase + groups);
@@ -660,9 +733,9 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
         rd += nRead;
     }
     if (!FILL && tid == 0) {
-        nGroups[t] = groups;
-        nUpdate[t] = upd;
-        nReadOnly[t] = rd;
+        nGroups[blockIdx.x] = groups;
+        nUpdate[blockIdx.x] = upd;
+        nReadOnly[blockIdx.x] = rd;
     }
 }
 
@@ -709,13 +782,14 @@ int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n,
     return int(hipGetLastError());
 }
 
-int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind)
+int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
+                    int *interiorBad)
 {
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    const int E = kTile + 2 * (width - 1);
+    if (width < 1 || width > 8) return int(hipErrorInvalidValue);
+    const int E = kTile + 2 * std::max(width - 1, 1);
     const size_t lds = 2 * size_t(E) * E * E;
-    if (lds > size_t(60) << 10) return int(hipErrorInvalidValue);  // band_width <= 8
-    bandMaskKernel<<<unsigned(tx * ty * tz), 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind);
+    bandMaskKernel<<<unsigned(tx * ty * tz), 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind, interiorBad);
     return int(hipGetLastError());
 }
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band)
@@ -750,28 +824,40 @@ int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t
     return int(hipGetLastError());
 }
 
-static size_t groupLds(int depth)
+static size_t groupLds(int depth, bool fill)
 {
     const size_t EM = size_t(kTile + 2 * depth), EM3 = EM * EM * EM;
-    return 2 * EM3 + (EM3 & 1) + 2 * EM3;
+    return 2 * EM3 + (EM3 & 1) + (fill ? 2 * EM3 : 0);  // flags + node classes (+ node numbers)
+}
+// flags / rank: nt and nt + 1 ints of scratch; list: room for nt entries; rank[nt] = the number of band tiles afterwards
+int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch)
+{
+    tileFlagKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(tileStart, nt, flags);
+    int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
+    if (e != 0) return e;
+    tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
+    return int(hipGetLastError());
 }
 int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
-                          int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken)
+                          const int32_t *bandTiles, int nBandTiles, int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken)
 {
-    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    bandGroupsKernel<false><<<unsigned(tx * ty * tz), kGroupThreads, groupLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, nullptr, nullptr, depth,
-                                                                                                 nGroups, nUpdate, nReadOnly, nullptr, nullptr, nullptr, nullptr,
-                                                                                                 nullptr, nullptr, nullptr, nullptr, broken);
+    if (nBandTiles <= 0) return 0;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
+    bandGroupsKernel<false><<<unsigned(nBandTiles), kGroupThreads, groupLds(depth, false), S(stream)>>>(
+        d, lab, tx, ty, mask, prefix, tileStart, nullptr, nullptr, depth, nGroups, nUpdate, nReadOnly, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        nullptr, nullptr, broken, bandTiles);
     return int(hipGetLastError());
 }
 int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *groupAt, const int32_t *updateAt, const int32_t *readAt,
-                         int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours, int32_t *readCell, int *broken)
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *bandTiles, int nBandTiles, const int32_t *groupAt,
+                         const int32_t *updateAt, const int32_t *readAt, int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours,
+                         int32_t *readCell, int *broken)
 {
-    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    bandGroupsKernel<true><<<unsigned(tx * ty * tz), kGroupThreads, groupLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth,
-                                                                                                nullptr, nullptr, nullptr, groupAt, updateAt, readAt, info,
-                                                                                                updateEntry, updateCell, neighbours, readCell, broken);
+    if (nBandTiles <= 0) return 0;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
+    bandGroupsKernel<true><<<unsigned(nBandTiles), kGroupThreads, groupLds(depth, true), S(stream)>>>(
+        d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, nullptr, nullptr, nullptr, groupAt, updateAt, readAt, info, updateEntry, updateCell,
+        neighbours, readCell, broken, bandTiles);
     return int(hipGetLastError());
 }
 

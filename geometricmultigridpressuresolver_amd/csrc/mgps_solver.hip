@@ -84,6 +84,7 @@ struct mgps_solver {
     hipStream_t stream = nullptr;
     std::vector<DevLevel> lv;  // single GPU: all levels; slab run: the distributed levels + the collapse level
     float *w[3] = {nullptr, nullptr, nullptr};
+    bool weightsBorrowed = false;  // options.borrow_device_weights: w[] are the caller's arrays
     // coarsest-level dense inverse
     int cn = 0;
     float *cinv = nullptr, *cvec = nullptr;
@@ -374,7 +375,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.bandGroups.readCell);
         (void)cacheFree(L.bandGroups.neighbours);
     }
-    for (int a = 0; a < 3; ++a) (void)cacheFree(h->w[a]);
+    for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
     (void)cacheFree(h->cinv);
     (void)cacheFree(h->cvec);
     (void)cacheFree(h->ccells);
@@ -1736,7 +1737,6 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     ODS_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), nullptr));
     ODS_LAUNCH(launchShellCheck(nullptr, d0, labOf(0), flags));
     ODS_LAUNCH(launchAnyActive(nullptr, d0, labOf(0), flags + 1));
-    ODS_LAUNCH(launchInteriorCheck(nullptr, d0, labOf(0), flags + 2 * mgLevels));
     for (int l = 1; l < mgLevels; ++l) {
         ODS_LAUNCH(launchCoarsenLabels(nullptr, h->lv[size_t(l - 1)].d, labOf(l - 1), labOf(l), flags + 2 * l + 1));
         ODS_LAUNCH(launchShellCheck(nullptr, h->lv[size_t(l)].d, labOf(l), flags + 2 * l));
@@ -1759,9 +1759,6 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         }
     }
     if (levels < 1) return bail(failH(h, MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)"));
-    if (hflags[size_t(2 * mgLevels)])
-        return bail(failH(h, MGPS_ERR_HIERARCHY,
-                          "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
     for (int l = levels; l < mgLevels; ++l) {
         (void)cacheFree(h->lv[size_t(l)].codes);
         h->lv[size_t(l)].codes = nullptr;
@@ -1786,7 +1783,12 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     {
         const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz, size_t(d0.nx) * d0.ny * (d0.nz + 1)};
         const float *src[3] = {wx, wy, wz};
+        h->weightsBorrowed = kind == hipMemcpyDeviceToDevice && o.borrow_device_weights != 0;
         for (int a = 0; a < 3; ++a) {
+            if (h->weightsBorrowed) {
+                h->w[a] = const_cast<float *>(src[a]);
+                continue;
+            }
             ODS_TRY(devAlloc(h, &h->w[a], wn[a], false));
             ODS_HIP(hipMemcpyAsync(h->w[a], src[a], wn[a] * sizeof(float), kind, nullptr));
         }
@@ -1801,7 +1803,8 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         int32_t *sorted = nullptr, *general = nullptr, *genRank = nullptr, *bandEntry = nullptr;
         uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
         int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
-        int nband = 0, nGen = 0, planeZc = 0;
+        int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr;
+        int nband = 0, nGen = 0, planeZc = 0, nBandTiles = 0;
         size_t nfine = 0, nplane = 0;
     };
     std::vector<LevelTmp> T{size_t(levels)};
@@ -1818,10 +1821,24 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         ODS_TRY(tmp.get(h, &t.tileKind, size_t(t.nt)));
         ODS_TRY(tmp.get(h, &t.tileStart, size_t(t.nt) + 1));
         ODS_TRY(tmp.get(h, &t.scan, scanScratchInts(L.d.cells())));
-        ODS_LAUNCH(launchBandMasks(nullptr, L.d, labOf(l), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind));
+        ODS_LAUNCH(launchBandMasks(nullptr, L.d, labOf(l), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind, l == 0 ? flags + 2 * mgLevels : nullptr));
         ODS_LAUNCH(launchExclusiveScan(nullptr, t.tileCount, t.tileStart, size_t(t.nt), t.scan));
+        ODS_TRY(tmp.get(h, &t.tileFlags, size_t(t.nt)));
+        ODS_TRY(tmp.get(h, &t.tileRank, size_t(t.nt) + 1));
+        ODS_TRY(tmp.get(h, &t.bandTiles, size_t(t.nt)));
+        ODS_LAUNCH(launchBandTileList(nullptr, t.tileStart, t.nt, t.tileFlags, t.tileRank, t.bandTiles, t.scan));
     }
-    for (int l = 0; l < levels; ++l) ODS_HIP(hipMemcpy(&T[size_t(l)].nband, T[size_t(l)].tileStart + T[size_t(l)].nt, sizeof(int), hipMemcpyDeviceToHost));
+    for (int l = 0; l < levels; ++l) {
+        ODS_HIP(hipMemcpy(&T[size_t(l)].nband, T[size_t(l)].tileStart + T[size_t(l)].nt, sizeof(int), hipMemcpyDeviceToHost));
+        ODS_HIP(hipMemcpy(&T[size_t(l)].nBandTiles, T[size_t(l)].tileRank + T[size_t(l)].nt, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    {
+        int interiorBad = 0;  // (the mask kernel of the fine level checks the INTERIOR cells on the way)
+        ODS_HIP(hipMemcpy(&interiorBad, flags + 2 * mgLevels, sizeof(int), hipMemcpyDeviceToHost));
+        if (interiorBad)
+            return bail(failH(h, MGPS_ERR_HIERARCHY,
+                              "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
+    }
     clock.lap("band masks + counts");
 
     // ---- band lists in reference order, classification, scan of the general cells
@@ -1886,12 +1903,12 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         if (t.nband == 0 || size_t(t.nband) > size_t(kBandEntryMask)) continue;
         haveGroups[size_t(l)] = 1;
         for (int q = 0; q < 3; ++q) {
-            ODS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nt)));
-            ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nt) + 1));
+            ODS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nBandTiles)));
+            ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nBandTiles) + 1));
         }
-        ODS_LAUNCH(launchBandGroupsCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, o.band_iterations, t.gcount[0], t.gcount[1], t.gcount[2],
-                                         flags + 2 * mgLevels + 2 + l));
-        for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nt), t.scan));
+        ODS_LAUNCH(launchBandGroupsCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, o.band_iterations, t.bandTiles, t.nBandTiles, t.gcount[0],
+                                         t.gcount[1], t.gcount[2], flags + 2 * mgLevels + 2 + l));
+        for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nBandTiles), t.scan));
     }
     // ---- host side of the lists: flags and kinds come back, lists go up
     for (int l = 0; l < levels; ++l) {
@@ -1933,7 +1950,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
         int tot[3] = {0, 0, 0}, brokenL = 0;
-        for (int q = 0; q < 3; ++q) ODS_HIP(hipMemcpy(&tot[q], t.gat[q] + t.nt, sizeof(int), hipMemcpyDeviceToHost));
+        for (int q = 0; q < 3; ++q) ODS_HIP(hipMemcpy(&tot[q], t.gat[q] + t.nBandTiles, sizeof(int), hipMemcpyDeviceToHost));
         ODS_HIP(hipMemcpy(&brokenL, flags + 2 * mgLevels + 2 + l, sizeof(int), hipMemcpyDeviceToHost));
         if (brokenL || tot[0] == 0) continue;  // (the level then runs its band passes one by one)
         L.bandGroups.depth = o.band_iterations;
@@ -1943,7 +1960,8 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         ODS_TRY(devAlloc(h, &L.bandGroups.updateCell, size_t(tot[1]), false));
         ODS_TRY(devAlloc(h, &L.bandGroups.neighbours, size_t(6) * size_t(tot[1]), false));
         ODS_TRY(devAlloc(h, &L.bandGroups.readCell, size_t(tot[2]), false));
-        ODS_LAUNCH(launchBandGroupsFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.gat[0], t.gat[1], t.gat[2],
+        ODS_LAUNCH(launchBandGroupsFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.bandTiles, t.nBandTiles,
+                                        t.gat[0], t.gat[1], t.gat[2],
                                         L.bandGroups.info, L.bandGroups.updateEntry, L.bandGroups.updateCell, L.bandGroups.neighbours, L.bandGroups.readCell,
                                         flags + 2 * mgLevels + 2 + l));
     }

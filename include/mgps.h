@@ -119,6 +119,10 @@ typedef struct mgps_options {
        every sub-step (Plug.cpp:463), so set-up is on the critical path.  1 = the host builder (threads; the builder of slab
        runs, and the checker the tests compare the device arrays with, entry for entry).  Same solver either way */
     int host_setup;
+    /* mgps_create_device / mgps_create_device_weights, 1: the solver reads the caller's three weight arrays in place --
+       they must stay valid and unchanged until mgps_destroy -- instead of keeping its own copy (12 B per cell, 13 GB and
+       5 ms at 1024^3).  0 (default): copy; the caller may release them right after the constructor returns */
+    int borrow_device_weights;
 } mgps_options;
 
 typedef struct mgps_pcg_stats {

@@ -143,3 +143,27 @@ def test_level_cap_quirk_on_device():
             ref = lev
         else:
             assert lev == ref, (ref, lev)
+
+
+def test_borrowed_weights_give_the_same_solver():
+    """options.borrow_device_weights: the solver reads the caller's device weights in place"""
+    lab, w, off, lev, dx = make_domain("solid", 48)
+    wd = [torch.from_numpy(a).cuda() for a in w]
+    labd = torch.from_numpy(lab).cuda()
+    o = G.default_options()
+    o.borrow_device_weights = 1
+    sb = G.GeometricMultigridPoissonSolver(labd, wd, lev, True, options=o)
+    sc = G.GeometricMultigridPoissonSolver(labd, wd, lev, True)
+    try:
+        _compare(sc, sb)
+        rhs = D.random_rhs(lab, dx)
+        outs = []
+        for s in (sc, sb):
+            x, b = s.new_grid(), s.to_device(rhs)
+            st = s.solveGeometricConjugateGradient(x, b, 1e-6, 50, True)
+            assert st["outcome"] == "converged"
+            outs.append(x.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+    finally:
+        sb.close()
+        sc.close()

@@ -15,8 +15,9 @@ lab, w, h = D.interior_cube(n, lev) if kind == "cube" else D.free_surface_pool(n
 print("domain build", round(time.time() - t, 2), flush=True)
 labd = torch.from_numpy(lab).cuda()
 wd = [torch.from_numpy(a).cuda() for a in w]
+only_device = len(sys.argv) > 5
 for gs in (False, True):
-    for host in (1, 0, 0, 1, 0):
+    for host in ((0, 0, 0) if only_device else (1, 0, 0, 1, 0)):
         o = G.default_options()
         o.host_setup = host
         torch.cuda.synchronize(); t = time.time()
