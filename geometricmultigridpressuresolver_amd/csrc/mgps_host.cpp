@@ -318,43 +318,67 @@ static void buildTileLists(HostLevel &L, int tileZOffset);
 void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine)
 {
     const Dims d = L.d;
-    std::vector<int32_t> fine, coarse;
-    for (int64_t q = 0; q < nfine; ++q)
-        if (fineAct[size_t(q)]) fine.push_back(int32_t(q));
     constexpr int kRatio = kChunkCells / kWaveChunkCells;
-    for (int64_t q = 0; q < nfine; q += kRatio) {
+    const int64_t ncoarse = (nfine + kRatio - 1) / kRatio;
+    auto coarseAct = [&](int64_t q) {
         bool act = false;
-        for (int64_t r = q; r < std::min(nfine, q + kRatio); ++r) act = act || fineAct[size_t(r)];
-        if (act) coarse.push_back(int32_t(q / kRatio));
-    }
-    L.chunks.swap(coarse);
-    L.chunkCells = kChunkCells;
-    if (double(fine.size()) * kWaveChunkCells < 0.9 * double(L.chunks.size()) * kChunkCells) {
-        L.chunks.swap(fine);
-        L.chunkCells = kWaveChunkCells;
-    }
+        for (int64_t r = q * kRatio; r < std::min(nfine, (q + 1) * kRatio); ++r) act = act || fineAct[size_t(r)];
+        return act;
+    };
+    // granularity: 1024-cell chunks unless 256-cell chunks visit > 10 % fewer cells (all host threads count)
+    std::atomic<int64_t> nFineAct{0}, nCoarseAct{0};
+    parallelFor(ncoarse, [&](int64_t b, int64_t e) {
+        int64_t f = 0, c = 0;
+        for (int64_t q = b; q < e; ++q) {
+            int64_t here = 0;
+            for (int64_t r = q * kRatio; r < std::min(nfine, (q + 1) * kRatio); ++r) here += fineAct[size_t(r)] != 0;
+            f += here;
+            c += here != 0;
+        }
+        nFineAct += f;
+        nCoarseAct += c;
+    }, 1 << 16);
+    const bool fine = double(nFineAct.load()) * kWaveChunkCells < 0.9 * double(nCoarseAct.load()) * kChunkCells;
+    L.chunkCells = fine ? kWaveChunkCells : kChunkCells;
+    const int64_t nq = fine ? nfine : ncoarse, nact = fine ? nFineAct.load() : nCoarseAct.load();
+    auto active = [&](int64_t q) { return fine ? fineAct[size_t(q)] != 0 : coarseAct(q); };
     // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
     // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
     // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
-    // strip (64 KiB) apart instead.  Pure locality: any order is correct.
+    // strip (64 KiB) apart instead: the list is ordered by (strip of the chunk's first cell, chunk index).
+    // Pure locality: any order is correct.
     constexpr int kStripRows = 32;
-    if (size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows) {
-        const size_t cpr = size_t(L.chunkCells);
-        auto key = [&](int32_t c) {
-            const size_t cell = size_t(c) * cpr;
-            const size_t j = (cell / d.nx) % d.ny, k = cell / (size_t(d.nx) * d.ny);
-            return (uint64_t(j / kStripRows) << 40) | (uint64_t(k) << 20) | uint64_t(cell % (size_t(d.nx) * d.ny) / cpr);
-        };
-        // the list is sorted by (k, in-plane position); bucket by strip, keeping that order inside each strip
-        const size_t nstrips = (size_t(d.ny) + kStripRows - 1) / kStripRows;
-        std::vector<std::vector<int32_t>> strips(nstrips);
-        for (int32_t c : L.chunks) strips[size_t(key(c) >> 40)].push_back(c);
-        size_t at = 0;
-        for (auto &sv : strips) {
-            std::copy(sv.begin(), sv.end(), L.chunks.begin() + ptrdiff_t(at));
-            at += sv.size();
+    const bool strips = size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows;
+    const size_t nstrips = strips ? (size_t(d.ny) + kStripRows - 1) / kStripRows : 1;
+    const size_t cpr = size_t(L.chunkCells);
+    auto stripOf = [&](int64_t q) { return strips ? ((size_t(q) * cpr / d.nx) % d.ny) / kStripRows : size_t(0); };
+    // contiguous parts of the chunk range: counts per (part, strip), offsets strip-major, then every part writes its own
+    const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(int64_t(hostThreads()) * 4, nq / (1 << 14)));
+    const int64_t per = (nq + parts - 1) / parts;
+    std::vector<int64_t> count(size_t(parts) * nstrips, 0);
+    parallelFor(parts, [&](int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            int64_t *c = count.data() + size_t(p) * nstrips;
+            for (int64_t q = p * per; q < std::min(nq, (p + 1) * per); ++q)
+                if (active(q)) ++c[stripOf(q)];
         }
-    }
+    });
+    std::vector<int64_t> at(size_t(parts) * nstrips, 0);
+    int64_t run = 0;
+    for (size_t sidx = 0; sidx < nstrips; ++sidx)
+        for (int64_t p = 0; p < parts; ++p) {
+            at[size_t(p) * nstrips + sidx] = run;
+            run += count[size_t(p) * nstrips + sidx];
+        }
+    (void)nact;
+    L.chunks.assign(size_t(run), 0);
+    parallelFor(parts, [&](int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            int64_t *a = at.data() + size_t(p) * nstrips;
+            for (int64_t q = p * per; q < std::min(nq, (p + 1) * per); ++q)
+                if (active(q)) L.chunks[size_t(a[stripOf(q)]++)] = int32_t(q);
+        }
+    });
     if (L.chunkCells == kWaveChunkCells)
         while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
 }

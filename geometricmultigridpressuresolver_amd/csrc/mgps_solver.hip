@@ -1914,8 +1914,8 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     for (int l = 0; l < levels; ++l) {
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
-        std::vector<uint8_t> fineAct(t.nfine), planeAct(t.nplane);
-        std::vector<int32_t> kinds(size_t(t.nt));
+        RawVec<uint8_t> fineAct(t.nfine), planeAct(t.nplane);  // (page-locked above 1 MB: the copies below run at PCIe speed)
+        RawVec<int32_t> kinds(size_t(t.nt));
         ODS_HIP(hipMemcpy(fineAct.data(), t.chunkFlags, t.nfine, hipMemcpyDeviceToHost));
         if (t.nplane) ODS_HIP(hipMemcpy(planeAct.data(), t.planeFlags, t.nplane, hipMemcpyDeviceToHost));
         ODS_HIP(hipMemcpy(kinds.data(), t.tileKind, size_t(t.nt) * sizeof(int32_t), hipMemcpyDeviceToHost));
