@@ -314,52 +314,63 @@ static void buildBand(HostLevel &L, int width)
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
 
-// The chunk list of a level (HostLevel::chunks, chunkCells) from the activity flags of its runs of 256 cells.
-void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine)
+// The activity list of a level (HostLevel::chunks, chunkCells) from the flags of its runs of kSegCells cells.
+void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
 {
     const Dims d = L.d;
-    constexpr int kRatio = kChunkCells / kWaveChunkCells;
-    const int64_t ncoarse = (nfine + kRatio - 1) / kRatio;
-    auto coarseAct = [&](int64_t q) {
+    // granularity: 1024-cell runs; 256, 64, 32 in turn where the finer runs visit > 10 % fewer cells (all host threads count)
+    constexpr int kSizes[4] = {kChunkCells, kWaveChunkCells, 64, kSegCells};
+    constexpr int kPerChunk = kChunkCells / kSegCells;
+    const int64_t ncoarse = (nseg + kPerChunk - 1) / kPerChunk;
+    std::atomic<int64_t> nAct[4];
+    for (auto &a : nAct) a = 0;
+    parallelFor(ncoarse, [&](int64_t b, int64_t e) {
+        int64_t cnt[4] = {0, 0, 0, 0};
+        for (int64_t q = b; q < e; ++q) {
+            const int64_t s0 = q * kPerChunk, s1 = std::min(nseg, s0 + kPerChunk);
+            for (int z = 0; z < 4; ++z) {
+                const int per = kSizes[z] / kSegCells;
+                for (int64_t r0 = s0; r0 < s1; r0 += per) {
+                    bool any = false;
+                    for (int64_t r = r0; r < std::min(s1, r0 + per); ++r) any = any || segAct[size_t(r)];
+                    cnt[z] += any;
+                }
+            }
+        }
+        for (int z = 0; z < 4; ++z) nAct[z] += cnt[z];
+    }, 1 << 12);
+    L.chunkCells = kSizes[0];
+    double visited = double(nAct[0].load()) * kSizes[0];
+    for (int z = 1; z < 4; ++z)
+        if (double(nAct[z].load()) * kSizes[z] < 0.9 * visited) {
+            L.chunkCells = kSizes[z];
+            visited = double(nAct[z].load()) * kSizes[z];
+        }
+    const int per = L.chunkCells / kSegCells;  // flags per list entry
+    const int64_t nq = (nseg + per - 1) / per;
+    auto active = [&](int64_t q) {
         bool act = false;
-        for (int64_t r = q * kRatio; r < std::min(nfine, (q + 1) * kRatio); ++r) act = act || fineAct[size_t(r)];
+        for (int64_t r = q * per; r < std::min(nseg, (q + 1) * per); ++r) act = act || segAct[size_t(r)];
         return act;
     };
-    // granularity: 1024-cell chunks unless 256-cell chunks visit > 10 % fewer cells (all host threads count)
-    std::atomic<int64_t> nFineAct{0}, nCoarseAct{0};
-    parallelFor(ncoarse, [&](int64_t b, int64_t e) {
-        int64_t f = 0, c = 0;
-        for (int64_t q = b; q < e; ++q) {
-            int64_t here = 0;
-            for (int64_t r = q * kRatio; r < std::min(nfine, (q + 1) * kRatio); ++r) here += fineAct[size_t(r)] != 0;
-            f += here;
-            c += here != 0;
-        }
-        nFineAct += f;
-        nCoarseAct += c;
-    }, 1 << 16);
-    const bool fine = double(nFineAct.load()) * kWaveChunkCells < 0.9 * double(nCoarseAct.load()) * kChunkCells;
-    L.chunkCells = fine ? kWaveChunkCells : kChunkCells;
-    const int64_t nq = fine ? nfine : ncoarse, nact = fine ? nFineAct.load() : nCoarseAct.load();
-    auto active = [&](int64_t q) { return fine ? fineAct[size_t(q)] != 0 : coarseAct(q); };
     // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
     // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
     // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
-    // strip (64 KiB) apart instead: the list is ordered by (strip of the chunk's first cell, chunk index).
+    // strip (64 KiB) apart instead: the list is ordered by (strip of the run's first cell, run index).
     // Pure locality: any order is correct.
     constexpr int kStripRows = 32;
     const bool strips = size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows;
     const size_t nstrips = strips ? (size_t(d.ny) + kStripRows - 1) / kStripRows : 1;
     const size_t cpr = size_t(L.chunkCells);
     auto stripOf = [&](int64_t q) { return strips ? ((size_t(q) * cpr / d.nx) % d.ny) / kStripRows : size_t(0); };
-    // contiguous parts of the chunk range: counts per (part, strip), offsets strip-major, then every part writes its own
+    // contiguous parts of the run range: counts per (part, strip), offsets strip-major, then every part writes its own
     const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(int64_t(hostThreads()) * 4, nq / (1 << 14)));
-    const int64_t per = (nq + parts - 1) / parts;
+    const int64_t perPart = (nq + parts - 1) / parts;
     std::vector<int64_t> count(size_t(parts) * nstrips, 0);
     parallelFor(parts, [&](int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             int64_t *c = count.data() + size_t(p) * nstrips;
-            for (int64_t q = p * per; q < std::min(nq, (p + 1) * per); ++q)
+            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q)
                 if (active(q)) ++c[stripOf(q)];
         }
     });
@@ -370,17 +381,16 @@ void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine)
             at[size_t(p) * nstrips + sidx] = run;
             run += count[size_t(p) * nstrips + sidx];
         }
-    (void)nact;
     L.chunks.assign(size_t(run), 0);
     parallelFor(parts, [&](int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             int64_t *a = at.data() + size_t(p) * nstrips;
-            for (int64_t q = p * per; q < std::min(nq, (p + 1) * per); ++q)
+            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q)
                 if (active(q)) L.chunks[size_t(a[stripOf(q)]++)] = int32_t(q);
         }
     });
-    if (L.chunkCells == kWaveChunkCells)
-        while (L.chunks.size() % 4) L.chunks.push_back(-1);  // a workgroup takes four list entries, one per wavefront
+    // a workgroup takes kChunkCells / chunkCells list entries (one per wavefront, or one per 16 lanes)
+    while (L.chunks.size() % size_t(kChunkCells / L.chunkCells)) L.chunks.push_back(-1);
 }
 
 // Everything the device needs for the planes [z0, z1) of level G (the whole level when z0 = 0,
@@ -411,13 +421,13 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
         const uint8_t *labels = L.ownedLabels;
         {  // activity lists
             const size_t n = d.cells();
-            // flags of the 256-cell chunks (eight labels per test: a byte is active iff it is 0 or 3)
-            const int64_t nfine = int64_t((n + kWaveChunkCells - 1) / kWaveChunkCells);
+            // flags of the runs of kSegCells cells (eight labels per test: a byte is active iff it is 0 or 3)
+            const int64_t nfine = int64_t((n + kSegCells - 1) / kSegCells);
             std::vector<uint8_t> fineAct(size_t(nfine), 0);
             parallelFor(nfine, [&](int64_t b, int64_t e) {
                 constexpr uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
                 for (int64_t q = b; q < e; ++q) {
-                    const size_t c0 = size_t(q) * kWaveChunkCells, c1 = std::min(n, c0 + kWaveChunkCells);
+                    const size_t c0 = size_t(q) * kSegCells, c1 = std::min(n, c0 + kSegCells);
                     bool act = false;
                     size_t c = c0;
                     for (; c + 8 <= c1 && !act; c += 8) {

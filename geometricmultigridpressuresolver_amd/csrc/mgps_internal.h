@@ -20,6 +20,11 @@ constexpr int kTile = 16;  // UT_VoxelArray tile edge: decides the Gauss-Seidel 
 // then padded with -1 to whole workgroups of four entries)
 constexpr int kChunkCells = 1024;
 constexpr int kWaveChunkCells = 256;
+// ... or, where that again visits > 10 % fewer cells, 64 and then 32 cells (16 / 8 lanes of a wavefront; the list is padded
+// to whole workgroups): a free surface that cuts the x-rows -- the reference's own test domain,
+// HDK_TestGeometricMultigrid.cpp:235, has its surface along x -- leaves most of a 256-cell run in the air.  The activity
+// flags are kept per kSegCells cells.
+constexpr int kSegCells = 32;
 
 // std::vector that leaves trivially constructible elements uninitialised on resize(): the big set-up arrays are
 // filled by all host threads right after, and a serial zero-fill of 100+ MB costs more than that fill
@@ -185,9 +190,9 @@ int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const
 void checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int *pass);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
                     const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
-// pieces of the host builder the device-side set-up shares: the chunk list of a level from the activity flags of its
-// runs of 256 cells, and the Gauss-Seidel tile lists from the per-tile kinds ((active cells << 1) | all INTERIOR)
-void chunkListsFromFlags(HostLevel &L, const uint8_t *fineAct, int64_t nfine);
+// pieces of the host builder the device-side set-up shares: the activity list of a level from the flags of its
+// runs of 64 cells, and the Gauss-Seidel tile lists from the per-tile kinds ((active cells << 1) | all INTERIOR)
+void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg);
 void tileListsFromKinds(HostLevel &L, const int64_t *kind, int tileZOffset);
 void tileListsFromKinds(HostLevel &L, const int32_t *kind, int tileZOffset);
 // A hierarchy that knows the extents of its levels and the labels of the coarsest one only (device-side set-up: the

@@ -185,6 +185,29 @@ __device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
 // shorter rows).  x-1 / x+1 come from the neighbouring lanes (ds_bpermute), row ends from memory.
 // Requires nx % 4 == 0.
 // ---------------------------------------------------------------------------------------------
+// The quad (4 cells) this thread owns in share `block` of a level's activity list -- the list entries are runs of
+// chunkCells consecutive cells that hold an active cell: 1024 = one entry per workgroup, 256 = one per wavefront, 64 / 32 =
+// one per 16 / 8 lanes (free surfaces that cut the x-rows: most of a 256-cell run would be air).  false: list padding (-1).
+__device__ __forceinline__ bool listQuad(const int32_t *__restrict__ chunks, int chunkCells, size_t block, size_t &t)
+{
+    if (chunkCells == kChunkCells) {
+        t = size_t(chunks[block]) * 256 + threadIdx.x;
+        return true;
+    }
+    int ch;
+    if (chunkCells == kWaveChunkCells) {  // wave-uniform index: a scalar load
+        ch = chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+        t = size_t(max(ch, 0)) * kWave + (threadIdx.x & (kWave - 1));
+    } else {
+        const int lanes = chunkCells >> 2, shift = __ffs(lanes) - 1;  // 16 or 8 lanes per run
+        ch = chunks[(block << (8 - shift)) + (threadIdx.x >> shift)];
+        t = (size_t(max(ch, 0)) << shift) + (threadIdx.x & (lanes - 1));
+    }
+    return ch >= 0;
+}
+// lanes whose x-neighbour quad lives in another lane's registers: all but the ends of a run
+__device__ __forceinline__ int listRunMask(const int32_t *chunks, int chunkCells) { return (chunks && chunkCells < kWaveChunkCells) ? (chunkCells >> 2) - 1 : kWave - 1; }
+
 template <int OP, bool DOT = false, class TX = float>
 __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
                                                           const float *__restrict__ b, float omega, unsigned nblocks,
@@ -198,13 +221,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const unsigned block = remapBlock(blockIdx.x, nblocks);
     size_t t = size_t(block) * blockDim.x + threadIdx.x;
     bool valid = true;
-    if (chunks && g.chunkCells == kChunkCells)  // only the chunks that hold active cells: one list entry per workgroup ...
-        t = size_t(chunks[block]) * blockDim.x + threadIdx.x;
-    else if (chunks) {  // ... or per wavefront (wave-uniform index: scalar load)
-        const int ch = chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-        valid = ch >= 0;
-        t = size_t(max(ch, 0)) * kWave + (threadIdx.x & (kWave - 1));
-    }
+    if (chunks) valid = listQuad(chunks, g.chunkCells, block, t);  // only the runs that hold active cells
     valid = valid && t < totalQuads;
     const size_t tt = valid ? t : totalQuads - 1;
     const unsigned q = unsigned(tt % nq);
@@ -228,11 +245,11 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
 
     // x neighbours across the quad boundary
-    const int lane = threadIdx.x & (kWave - 1);
+    const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
     if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
-    if (lane == kWave - 1 || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
+    if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
 
     const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
     const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
@@ -889,11 +906,21 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const TF *_
     constexpr bool kMixed = !std::is_same<TF, float>::value;
     const size_t n = size_t(cg.nx) * cg.ny * cg.nz;
     // with a chunk list: workgroups of 256 over the active chunks (four per 1024-cell chunk); the rest of `coarse` stays 0
-    const int per = cg.chunkCells / 256;
     const unsigned bid = remapBlock(blockIdx.x, gridDim.x);  // a chiplet's L2 serves a contiguous run of the list
-    if (cg.chunks && cg.chunks[bid / per] < 0) return;
-    const size_t c = cg.chunks ? size_t(cg.chunks[bid / per]) * cg.chunkCells + (bid % per) * 256 + threadIdx.x
-                               : size_t(bid) * blockDim.x + threadIdx.x;
+    size_t c = size_t(bid) * blockDim.x + threadIdx.x;
+    if (cg.chunks) {  // 256 threads = a quarter of a 1024-cell run, a 256-cell run, or four 64-cell / eight 32-cell runs
+        int ch;
+        if (cg.chunkCells >= 256) {
+            const int per = cg.chunkCells / 256;
+            ch = cg.chunks[bid / per];
+            c = size_t(max(ch, 0)) * cg.chunkCells + (bid % per) * 256 + threadIdx.x;
+        } else {
+            const int shift = __ffs(cg.chunkCells) - 1;
+            ch = cg.chunks[(size_t(bid) << (8 - shift)) + (threadIdx.x >> shift)];
+            c = size_t(max(ch, 0)) * cg.chunkCells + (threadIdx.x & (cg.chunkCells - 1));
+        }
+        if (ch < 0) return;
+    }
     if (c >= n) return;
     if (!activeLabel(cg.lab[c])) {
         coarse[c] = 0.f;
@@ -1004,13 +1031,7 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
     const size_t total = size_t(nq) * fg.ny * fg.nz;
     const unsigned block = remapBlock(blockIdx.x, nblocks);
     size_t t = size_t(block) * blockDim.x + threadIdx.x;
-    if (fg.chunks && fg.chunkCells == kChunkCells)
-        t = size_t(fg.chunks[block]) * blockDim.x + threadIdx.x;
-    else if (fg.chunks) {
-        const int ch = fg.chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-        if (ch < 0) return;
-        t = size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
-    }
+    if (fg.chunks && !listQuad(fg.chunks, fg.chunkCells, block, t)) return;
     if (t >= total) return;
     const unsigned m = unsigned(t % nq);
     const size_t row = t / nq;
@@ -1172,11 +1193,10 @@ __device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, int
         q = size_t(chunks[ci]) * (kChunkCells / 4) + threadIdx.x;
         return true;  // (a ragged last chunk is guarded by q < nq at the use)
     }
-    if (chunks) {  // nchunks is a multiple of 4: one entry per wavefront of the workgroup
-        const size_t ci = (size_t(blockIdx.x) + it * gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (ci >= size_t(nchunks)) return false;
-        const int ch = chunks[ci];
-        q = ch < 0 ? nq : size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
+    if (chunks) {  // one entry per wavefront / per 16 lanes: nchunks is a multiple of 4 / 16
+        const size_t share = size_t(blockIdx.x) + it * gridDim.x;
+        if (share * size_t(kChunkCells / chunkCells) >= size_t(nchunks)) return false;
+        if (!listQuad(chunks, chunkCells, share, q)) q = nq;
         return true;  // (list padding and a ragged last chunk are guarded by q < nq at the use)
     }
     q = size_t(blockIdx.x) * blockDim.x + threadIdx.x + it * size_t(gridDim.x) * blockDim.x;
@@ -1664,19 +1684,14 @@ int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev)
 __global__ __launch_bounds__(256) void zeroChunksHalfKernel(__half *__restrict__ a, const int32_t *__restrict__ chunks, int chunkCells, size_t nq)
 {
     size_t q;
-    if (chunkCells == kChunkCells) q = size_t(chunks[blockIdx.x]) * (kChunkCells / 4) + threadIdx.x;
-    else {
-        const int ch = chunks[blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-        if (ch < 0) return;
-        q = size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
-    }
+    if (!listQuad(chunks, chunkCells, blockIdx.x, q)) return;
     if (q < nq) reinterpret_cast<uint2 *>(a)[q] = make_uint2(0u, 0u);
 }
 int launchZeroActiveHalf(void *stream, const GridP &g, void *aH)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     if (!g.chunks || (n & 3) != 0) return int(hipMemsetAsync(aH, 0, n * sizeof(__half), static_cast<hipStream_t>(stream)));
-    const unsigned nb = g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4;
+    const unsigned nb = unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells);
     if (nb > 0) zeroChunksHalfKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<__half *>(aH), g.chunks, g.chunkCells, n >> 2);
     return int(hipGetLastError());
 }
@@ -1727,7 +1742,7 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
         restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         return int(hipGetLastError());
     }
-    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * unsigned(coarse.chunkCells / 256) : blocksFor(n, 256);
+    const unsigned nb = coarse.chunks ? unsigned(size_t(coarse.nchunks) * size_t(coarse.chunkCells) / 256) : blocksFor(n, 256);
     if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
     return int(hipGetLastError());
 }
@@ -1742,7 +1757,7 @@ int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, con
         restrictMarchKernel<__half><<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby, fm);
         return int(hipGetLastError());
     }
-    const unsigned nb = coarse.chunks ? unsigned(coarse.nchunks) * unsigned(coarse.chunkCells / 256) : blocksFor(n, 256);
+    const unsigned nb = coarse.chunks ? unsigned(size_t(coarse.nchunks) * size_t(coarse.chunkCells) / 256) : blocksFor(n, 256);
     if (nb > 0) restrictKernel<__half><<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, fm);
     return int(hipGetLastError());
 }
@@ -1908,12 +1923,7 @@ __global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, c
         return;
     }
     size_t q;
-    if (chunkCells == kChunkCells) q = size_t(chunks[blockIdx.x]) * (kChunkCells / 4) + threadIdx.x;
-    else {
-        const int ch = chunks[blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-        if (ch < 0) return;
-        q = size_t(ch) * kWave + (threadIdx.x & (kWave - 1));
-    }
+    if (!listQuad(chunks, chunkCells, blockIdx.x, q)) return;
     if (q < nq) reinterpret_cast<float4 *>(a)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -2071,7 +2081,7 @@ __global__ __launch_bounds__(256) void narrowKernel(float *__restrict__ dst, con
 static unsigned cg64Blocks(const GridP &g, size_t capacity)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const unsigned want = g.chunks ? (g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4) : blocksFor(n >> 2, 256);
+    const unsigned want = g.chunks ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
     const unsigned room = unsigned(std::min<size_t>(capacity > 1100 ? capacity - 1100 : 1, 1u << 20));  // 1024 boundary slots + 64 fold slots
     return std::max(1u, std::min(want, room));
 }
@@ -2138,7 +2148,7 @@ int launchZeroActive(void *stream, const GridP &g, float *a, bool ghostPlanes)
         if (ghostPlanes) return launchZero(stream, a - plane, n + 2 * plane);
         return launchZero(stream, a, n);
     }
-    const unsigned nb = g.chunkCells == kChunkCells ? unsigned(g.nchunks) : unsigned(g.nchunks) / 4;
+    const unsigned nb = unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells);
     const unsigned extra = ghostPlanes ? blocksFor(2 * (plane >> 2), 256) : 0;
     if (nb + extra > 0)
         zeroChunksKernel<<<nb + extra, 256, 0, static_cast<hipStream_t>(stream)>>>(a, g.chunks, g.chunkCells, n >> 2, nb, plane >> 2);

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void tileListKernel(const int32_t *__restrict_
 
 // ---- activity flags --------------------------------------------------------------------------------------------------
 
-// chunkFlags[q] = the q-th run of 256 cells holds an active cell (one wavefront per run); planeFlags (optional, nx % 4 == 0):
+// chunkFlags[q] = the q-th run of kSegCells = 32 cells holds an active cell (8 lanes per run); planeFlags (optional, nx % 4 == 0):
 // per block of the plane-marching sweep (256 cells in x, kPlaneRows rows, zc planes)
 __global__ __launch_bounds__(256) void activityFlagsKernel(Dims d, const uint32_t *__restrict__ lab4, size_t nq, uint8_t *__restrict__ chunkFlags,
                                                            uint8_t *__restrict__ planeFlags, int zc, int nbx, int nby)
@@ -475,8 +475,9 @@ __global__ __launch_bounds__(256) void activityFlagsKernel(Dims d, const uint32_
             planeFlags[(size_t(k / zc) * nby + j / kPlaneRows) * nbx + i / 256] = 1;
         }
     }
-    const bool waveAny = __any(any);
-    if ((threadIdx.x & 63) == 0 && q < nq) chunkFlags[q >> 6] = waveAny ? 1 : 0;
+    const unsigned long long votes = __ballot(any);
+    static_assert(kSegCells == 32, "eight lanes of four cells per flag");
+    if ((threadIdx.x & 7) == 0 && q < nq) chunkFlags[q >> 3] = ((votes >> (threadIdx.x & 56)) & 0xffull) ? 1 : 0;
 }
 
 // ---- groups of the fused band stage (BandGroups in mgps_internal.h) --------------------------------------------------

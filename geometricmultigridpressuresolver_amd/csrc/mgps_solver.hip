@@ -1683,6 +1683,13 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     h->device = device;
     h->requestedLevels = mgLevels;
     std::thread inverseJob;  // the coarsest level's direct solver, on host threads beside the device work
+    struct Joiner {          // (an exception on the way out -- std::bad_alloc -- must not meet a joinable thread)
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{inverseJob};
     auto bail = [&](int code) {
         if (inverseJob.joinable()) inverseJob.join();
         setLastGlobalError(h->lastError);
@@ -1882,7 +1889,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         ODS_LAUNCH(launchBandSplit(nullptr, L.d, labOf(l), l == 0 ? h->w[0] : nullptr, l == 0 ? h->w[1] : nullptr, l == 0 ? h->w[2] : nullptr, t.sorted, t.nband,
                                    t.diagS, t.genRank, L.band, L.bandDiag, t.bandEntry, L.rows));
         ODS_LAUNCH(launchGather(nullptr, t.genRank, t.tileStart, t.nt + 1, L.tileBndStart));
-        t.nfine = (L.d.cells() + kWaveChunkCells - 1) / kWaveChunkCells;
+        t.nfine = (L.d.cells() + kSegCells - 1) / kSegCells;
         t.planeZc = planeSweepZc(L.d.nx, L.d.ny, L.d.nz);
         ODS_TRY(tmp.get(h, &t.chunkFlags, t.nfine));
         if (t.planeZc) {
