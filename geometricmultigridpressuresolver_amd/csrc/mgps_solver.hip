@@ -1248,6 +1248,22 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 
 // ---- construction --------------------------------------------------------------------------------
 
+// The plane-marching sweep visits blocks of 256 x 16 x zc cells, the quad sweep runs of 1024 .. 32 cells: where the liquid
+// fills a small part of the grid (a 480^3 simulation inside the reference's 1024^3 power-of-two expansion: 57 M of 1074 M
+// cells) the blocks hold three times the cells of the runs, and the 9 % the plane kernel gains on a full grid (2.63 vs
+// 2.87 ms at 1024^3) are lost many times over.  0 = leave the level to the quad sweep (options.stencil_path = 2 still forces
+// the plane kernel).
+int planeZcFor(const mgps_options &o, int planeZc, size_t nplaneBlocks, size_t nchunks, int chunkCells)
+{
+    static const bool envPlane = [] {  // MGPS_STENCIL=plane: the A/B switch of launchStencil
+        const char *e = getenv("MGPS_STENCIL");
+        return e && e[0] == 'p';
+    }();
+    if (!planeZc || o.stencil_path == 2 || envPlane) return planeZc;
+    const double blockCells = double(nplaneBlocks) * 256.0 * kPlaneRows * planeZc, runCells = double(nchunks) * chunkCells;
+    return blockCells > 1.15 * runCells ? 0 : planeZc;
+}
+
 // upload one level built by buildSlabLevel
 // set-up stage timings on stdout when options.print_stats is set (the reference's ctor prints its four
 // stage times unconditionally, MG.cpp:183, 256, 284, 415)
@@ -1350,6 +1366,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 HL.planeZc,
                 L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0,
                 h->opt.stencil_path};
+    L.g.planeZc = planeZcFor(h->opt, HL.planeZc, HL.planeBlocks.size(), HL.chunks.size(), HL.chunkCells);
+    if (!L.g.planeZc) L.g.planeBlocks = nullptr;
     return MGPS_OK;
 }
 
@@ -1663,6 +1681,8 @@ void fillGridP(mgps_solver *h, DevLevel &L, bool withWeights, int nchunks, int c
                 planeZc,
                 L.d.cells() * 3 * sizeof(float) > (size_t(256) << 20) ? 1 : 0,
                 h->opt.stencil_path};
+    L.g.planeZc = planeZcFor(h->opt, planeZc, size_t(nplaneBlocks), size_t(nchunks), chunkCells);
+    if (!L.g.planeZc) L.g.planeBlocks = nullptr;
 }
 
 int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels, const float *wx, const float *wy, const float *wz,

@@ -800,6 +800,21 @@ def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
 
     bl, bw, dx = D.build_complex_domain((16, 992, 992), dtype=np.float32)
     lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(48, 1024, 1024))
+    # The reference's test surface lies along x (HDK_TestGeometricMultigrid.cpp:235) and cuts every x-row: there the runs of the
+    # quad sweep visit far fewer cells than the 256-wide blocks of the plane sweep, and the dispatch takes the quad kernel ...
+    cut = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
+    assert cut.stencil_kernel(0) == "quad"
+    cut.close()
+    # ... with the surface across y and rippled along z only (cut-cell solid box inside) every x-row is liquid or air as a
+    # whole, and the size rule decides: plane
+    shape = (16, 992, 992)
+    z, y, x = np.meshgrid(np.arange(16) / 16, np.arange(992) / 992, np.arange(992) / 992, indexing="ij")
+    phi = y - 0.5 + 0.02 * np.sin(4.0 * np.pi * z) + 0.0 * x
+    del z, y, x
+    bl, bw, dx = D._complex_from_phi(phi, shape, True, (0.4, 0.6), np.float32, 1.0 / 992)
+    del phi
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(48, 1024, 1024))
+    assert int((lab == 3).sum()) > 100000
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
     assert gpu.stencil_kernel(0) == "plane" and gpu.stencil_kernel(1) == "quad"
     lab32 = lab.astype(np.int32)
