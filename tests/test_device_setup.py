@@ -167,3 +167,60 @@ def test_borrowed_weights_give_the_same_solver():
     finally:
         sb.close()
         sc.close()
+
+
+@pytest.mark.parametrize("shape,levels", [((24, 40, 56), 2), ((36, 20, 44), 1), ((48, 64, 32), 3), ((64, 64, 96), 3)])
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_labels_and_weights(shape, levels, seed):
+    """Random blobs of every label and random face weights (closed, fractional, open): dense bands that the group builder has
+    to split, general BOUNDARY cells everywhere, extents that are not multiples of the tile edge, thin liquid sheets whose
+    coarse levels turn DIRICHLET (level cap)."""
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    noise = rng.random(shape)
+    for _ in range(2):
+        noise = (noise + np.roll(noise, 1, 0) + np.roll(noise, 1, 1) + np.roll(noise, 1, 2) + np.roll(noise, -1, 0)
+                 + np.roll(noise, -1, 1) + np.roll(noise, -1, 2)) / 7
+    lab = np.full(shape, D.INTERIOR, dtype=np.uint8)
+    lab[noise < np.quantile(noise, 0.12)] = D.EXTERIOR
+    lab[noise > np.quantile(noise, 0.9)] = D.DIRICHLET
+    pad = 2 ** (levels - 1)
+    for ax in range(3):  # the shell every level needs
+        sl = [slice(None)] * 3
+        sl[ax] = slice(0, pad)
+        lab[tuple(sl)] = D.EXTERIOR
+        sl[ax] = slice(-pad, None)
+        lab[tuple(sl)] = D.EXTERIOR
+    w = []
+    for a in range(3):
+        v = rng.random(D.face_shape(nz, ny, nx, a)).astype(np.float32)
+        wa = np.ones_like(v)
+        wa[v < 0.1] = 0.0
+        frac = (v > 0.1) & (v < 0.3)
+        wa[frac] = v[frac] * 2 + 0.2
+        w.append(wa)
+    # faces towards EXTERIOR cells are closed, as the reference's domains have them (an INTERIOR cell must not see them open)
+    for a in range(3):
+        ax = 2 - a
+        ext = lab == D.EXTERIOR
+        lo = [slice(None)] * 3
+        hi = [slice(None)] * 3
+        lo[ax], hi[ax] = slice(0, shape[ax]), slice(1, shape[ax] + 1)
+        w[a][tuple(lo)][ext] = 0.0
+        w[a][tuple(hi)][ext] = 0.0
+    D.set_boundary_labels(lab, w)
+    results = []
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        try:
+            results.append(G.GeometricMultigridPoissonSolver(lab, w, levels, bool(seed & 1), options=o))
+        except G.MgpsError as e:
+            results.append(str(e))
+    try:
+        assert not isinstance(results[0], str) and not isinstance(results[1], str), results  # (these seeds give valid domains)
+        _compare(results[0], results[1])
+    finally:
+        for r in results:
+            if not isinstance(r, str):
+                r.close()
