@@ -314,45 +314,25 @@ static void buildBand(HostLevel &L, int width)
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
 
-// The activity list of a level (HostLevel::chunks, chunkCells) from the flags of its runs of kSegCells cells.
-void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
+// Run length of a level's activity list from the number of active runs of 1024, 256, 64 and 32 cells: 1024-cell runs, a
+// finer length in turn where it visits > 10 % fewer cells.
+int chooseRunCells(const int64_t nAct[4])
+{
+    int cells = kRunSizes[0];
+    double visited = double(nAct[0]) * kRunSizes[0];
+    for (int z = 1; z < 4; ++z)
+        if (double(nAct[z]) * kRunSizes[z] < 0.9 * visited) {
+            cells = kRunSizes[z];
+            visited = double(nAct[z]) * kRunSizes[z];
+        }
+    return cells;
+}
+
+// The activity list of a level (HostLevel::chunks, chunkCells) from the flags of its n runs of runCells cells.
+void runListFromFlags(HostLevel &L, const uint8_t *runAct, int64_t nq, int runCells)
 {
     const Dims d = L.d;
-    // granularity: 1024-cell runs; 256, 64, 32 in turn where the finer runs visit > 10 % fewer cells (all host threads count)
-    constexpr int kSizes[4] = {kChunkCells, kWaveChunkCells, 64, kSegCells};
-    constexpr int kPerChunk = kChunkCells / kSegCells;
-    const int64_t ncoarse = (nseg + kPerChunk - 1) / kPerChunk;
-    std::atomic<int64_t> nAct[4];
-    for (auto &a : nAct) a = 0;
-    parallelFor(ncoarse, [&](int64_t b, int64_t e) {
-        int64_t cnt[4] = {0, 0, 0, 0};
-        for (int64_t q = b; q < e; ++q) {
-            const int64_t s0 = q * kPerChunk, s1 = std::min(nseg, s0 + kPerChunk);
-            for (int z = 0; z < 4; ++z) {
-                const int per = kSizes[z] / kSegCells;
-                for (int64_t r0 = s0; r0 < s1; r0 += per) {
-                    bool any = false;
-                    for (int64_t r = r0; r < std::min(s1, r0 + per); ++r) any = any || segAct[size_t(r)];
-                    cnt[z] += any;
-                }
-            }
-        }
-        for (int z = 0; z < 4; ++z) nAct[z] += cnt[z];
-    }, 1 << 12);
-    L.chunkCells = kSizes[0];
-    double visited = double(nAct[0].load()) * kSizes[0];
-    for (int z = 1; z < 4; ++z)
-        if (double(nAct[z].load()) * kSizes[z] < 0.9 * visited) {
-            L.chunkCells = kSizes[z];
-            visited = double(nAct[z].load()) * kSizes[z];
-        }
-    const int per = L.chunkCells / kSegCells;  // flags per list entry
-    const int64_t nq = (nseg + per - 1) / per;
-    auto active = [&](int64_t q) {
-        bool act = false;
-        for (int64_t r = q * per; r < std::min(nseg, (q + 1) * per); ++r) act = act || segAct[size_t(r)];
-        return act;
-    };
+    L.chunkCells = runCells;
     // Launch order = list order.  Walking the grid plane by plane puts the z+-1 rows a sweep re-reads one
     // whole x-y plane apart -- 1 MiB at 512^2, three arrays of it overflow a chiplet's 4 MiB L2 (measured:
     // 1.36x the algorithmic HBM traffic).  Strips of kStripRows rows walked through all planes keep them a
@@ -361,17 +341,40 @@ void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
     constexpr int kStripRows = 32;
     const bool strips = size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > kStripRows;
     const size_t nstrips = strips ? (size_t(d.ny) + kStripRows - 1) / kStripRows : 1;
-    const size_t cpr = size_t(L.chunkCells);
-    auto stripOf = [&](int64_t q) { return strips ? ((size_t(q) * cpr / d.nx) % d.ny) / kStripRows : size_t(0); };
+    const size_t cpr = size_t(runCells);
+    // the strip of run q's first cell, for q walking upwards from q0 (no division per run: three of them cost more than
+    // everything else in this function)
+    struct StripWalk {
+        size_t rem, j, cpr, nx, ny;
+        bool strips;
+        StripWalk(int64_t q0, size_t cpr_, const Dims &d, bool strips_) : cpr(cpr_), nx(size_t(d.nx)), ny(size_t(d.ny)), strips(strips_)
+        {
+            const size_t c = size_t(q0) * cpr;
+            rem = c % nx;
+            j = (c / nx) % ny;
+        }
+        size_t strip() const { return strips ? j / kStripRows : 0; }
+        void next()
+        {
+            rem += cpr;
+            while (rem >= nx) {
+                rem -= nx;
+                if (++j == ny) j = 0;
+            }
+        }
+    };
     // contiguous parts of the run range: counts per (part, strip), offsets strip-major, then every part writes its own
-    const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(int64_t(hostThreads()) * 4, nq / (1 << 14)));
+    // (below a few million runs one thread is faster than starting several: measured 1.8 ms per million serially against
+    // 2.8-3.2 ms on eight threads here and 25 ms on the GPU box's sixteen)
+    const int64_t parts = nq < (int64_t(1) << 22) ? 1 : std::min<int64_t>(int64_t(hostThreads()), nq / (1 << 21));
     const int64_t perPart = (nq + parts - 1) / parts;
     std::vector<int64_t> count(size_t(parts) * nstrips, 0);
     parallelFor(parts, [&](int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             int64_t *c = count.data() + size_t(p) * nstrips;
-            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q)
-                if (active(q)) ++c[stripOf(q)];
+            StripWalk w(p * perPart, cpr, d, strips);
+            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q, w.next())
+                if (runAct[size_t(q)]) ++c[w.strip()];
         }
     });
     std::vector<int64_t> at(size_t(parts) * nstrips, 0);
@@ -381,16 +384,68 @@ void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
             at[size_t(p) * nstrips + sidx] = run;
             run += count[size_t(p) * nstrips + sidx];
         }
-    L.chunks.assign(size_t(run), 0);
+    // The scattered writes (one stream per strip) go to an ordinary buffer that this thread keeps; the list itself is a
+    // page-locked block (RawVec above 1 MB) filled by one sequential copy.  Measured at 1024^3 inside the solver process on
+    // the GPU box, this function: 23 ms with a fresh std::vector as the target (fresh pages are slow in a process that holds
+    // GPU mappings), 7.5 ms writing the streams straight into the page-locked block, against 1.3 ms for the same code in a
+    // process without the runtime.
+    static thread_local std::vector<int32_t> work;
+    if (work.size() < size_t(run)) work.resize(size_t(run));
+    int32_t *out = work.data();
     parallelFor(parts, [&](int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             int64_t *a = at.data() + size_t(p) * nstrips;
-            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q)
-                if (active(q)) L.chunks[size_t(a[stripOf(q)]++)] = int32_t(q);
+            StripWalk w(p * perPart, cpr, d, strips);
+            for (int64_t q = p * perPart; q < std::min(nq, (p + 1) * perPart); ++q, w.next())
+                if (runAct[size_t(q)]) out[size_t(a[w.strip()]++)] = int32_t(q);
         }
     });
-    // a workgroup takes kChunkCells / chunkCells list entries (one per wavefront, or one per 16 lanes)
+    L.chunks.resize(size_t(run));
+    if (run) std::memcpy(L.chunks.data(), out, size_t(run) * sizeof(int32_t));
+    if (work.size() > (size_t(16) << 20)) std::vector<int32_t>().swap(work);  // (64 MB and more: give it back)
+    // a workgroup takes kChunkCells / chunkCells list entries (one per wavefront, or one per 16 / 8 lanes)
     while (L.chunks.size() % size_t(kChunkCells / L.chunkCells)) L.chunks.push_back(-1);
+}
+
+// The same from the flags of the runs of kSegCells cells (the host builder's path): count, choose, fold, list.
+void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
+{
+    constexpr int kPerChunk = kChunkCells / kSegCells;
+    const int64_t ncoarse = (nseg + kPerChunk - 1) / kPerChunk;
+    std::atomic<int64_t> nAct[4];
+    for (auto &a : nAct) a = 0;
+    parallelFor(ncoarse, [&](int64_t b, int64_t e) {
+        int64_t cnt[4] = {0, 0, 0, 0};
+        for (int64_t q = b; q < e; ++q) {
+            const int64_t s0 = q * kPerChunk, s1 = std::min(nseg, s0 + kPerChunk);
+            for (int z = 0; z < 4; ++z) {
+                const int per = kRunSizes[z] / kSegCells;
+                for (int64_t r0 = s0; r0 < s1; r0 += per) {
+                    bool any = false;
+                    for (int64_t r = r0; r < std::min(s1, r0 + per); ++r) any = any || segAct[size_t(r)];
+                    cnt[z] += any;
+                }
+            }
+        }
+        for (int z = 0; z < 4; ++z) nAct[z] += cnt[z];
+    }, 1 << 12);
+    const int64_t counts[4] = {nAct[0].load(), nAct[1].load(), nAct[2].load(), nAct[3].load()};
+    const int runCells = chooseRunCells(counts);
+    const int per = runCells / kSegCells;
+    if (per == 1) {
+        runListFromFlags(L, segAct, nseg, runCells);
+        return;
+    }
+    const int64_t nq = (nseg + per - 1) / per;
+    std::vector<uint8_t> folded(size_t(nq), 0);
+    parallelFor(nq, [&](int64_t b, int64_t e) {
+        for (int64_t q = b; q < e; ++q) {
+            bool any = false;
+            for (int64_t r = q * per; r < std::min(nseg, (q + 1) * per); ++r) any = any || segAct[size_t(r)];
+            folded[size_t(q)] = any;
+        }
+    }, 1 << 14);
+    runListFromFlags(L, folded.data(), nq, runCells);
 }
 
 // Everything the device needs for the planes [z0, z1) of level G (the whole level when z0 = 0,

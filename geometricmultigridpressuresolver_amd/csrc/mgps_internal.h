@@ -112,7 +112,7 @@ struct HostLevel {
     // tile-compressed UT_VoxelArray in every operator (`if (!vit.isTileConstant() || active)`, e.g.
     // Ops.h:322-324); the flat layout gets the same effect from lists of the 256-cell chunks (and, for
     // the plane-marching sweep, of the 256 x 16 x zc blocks) that hold at least one active cell.
-    std::vector<int32_t> chunks;
+    RawVec<int32_t> chunks;  // (page-locked and reused above 1 MB: in a process that holds GPU mappings fresh pages are slow, see runListFromFlags)
     int chunkCells = kChunkCells;
     std::vector<int32_t> planeBlocks;
     int planeZc = 0;
@@ -193,6 +193,9 @@ int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t 
 // pieces of the host builder the device-side set-up shares: the activity list of a level from the flags of its
 // runs of 64 cells, and the Gauss-Seidel tile lists from the per-tile kinds ((active cells << 1) | all INTERIOR)
 void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg);
+constexpr int kRunSizes[4] = {kChunkCells, kWaveChunkCells, 64, kSegCells};  // the run lengths a level's list can have
+int chooseRunCells(const int64_t nAct[4]);                                    // from the active runs of each length
+void runListFromFlags(HostLevel &L, const uint8_t *runAct, int64_t nq, int runCells);
 void tileListsFromKinds(HostLevel &L, const int64_t *kind, int tileZOffset);
 void tileListsFromKinds(HostLevel &L, const int32_t *kind, int tileZOffset);
 // A hierarchy that knows the extents of its levels and the labels of the coarsest one only (device-side set-up: the
@@ -383,6 +386,13 @@ int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float
                     const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows);
 int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out);
 int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t *chunkFlags, uint8_t *planeFlags, int zc);
+// counts[z] += the runs of kRunSizes[z] cells that hold an active cell (counts zeroed by the caller); then the flags folded
+// to runs of runCells cells
+int launchCountRuns(void *stream, const uint8_t *segFlags, size_t nseg, int *counts);
+int launchFoldRunFlags(void *stream, const uint8_t *segFlags, size_t nseg, int runCells, uint8_t *runFlags);
+// the activity list itself (launch order of runListFromFlags), listLen = active runs rounded up to whole workgroups
+int launchRunList(void *stream, const Dims &d, const uint8_t *runFlags, size_t nq, int runCells, int32_t *tmpFlags, int32_t *rank, int32_t *scanScratch,
+                  int32_t *base, int32_t *list, int listLen);
 int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
 // the group kernels run over the list of tiles that hold band cells; counts and offsets are indexed by list position
 int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,

@@ -480,6 +480,68 @@ __global__ __launch_bounds__(256) void activityFlagsKernel(Dims d, const uint32_
     if ((threadIdx.x & 7) == 0 && q < nq) chunkFlags[q >> 3] = ((votes >> (threadIdx.x & 56)) & 0xffull) ? 1 : 0;
 }
 
+// a thread takes the 32 flags of one 1024-cell run: how many of its runs of 1024 / 256 / 64 / 32 cells hold an active cell
+__global__ __launch_bounds__(256) void countRunsKernel(const uint8_t *__restrict__ segFlags, size_t nseg, int *__restrict__ counts)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // 1024-cell run
+    int c[4] = {0, 0, 0, 0};
+    const size_t s0 = q * 32;
+    if (s0 < nseg) {
+        unsigned bits = 0;  // bit r = flag of the r-th 32-cell run
+        for (int r = 0; r < 32; ++r)
+            if (s0 + r < nseg && segFlags[s0 + r]) bits |= 1u << r;
+        c[3] = __popc(bits);
+        unsigned b64 = (bits | (bits >> 1)) & 0x55555555u;
+        c[2] = __popc(b64);
+        unsigned b256 = 0;
+        for (int w = 0; w < 4; ++w) b256 |= ((bits >> (8 * w)) & 0xffu) ? 1u << w : 0u;
+        c[1] = __popc(b256);
+        c[0] = bits != 0;
+    }
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        int v = c[z];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + z, v);
+    }
+}
+__global__ __launch_bounds__(256) void foldRunFlagsKernel(const uint8_t *__restrict__ segFlags, size_t nseg, int per, size_t nq, uint8_t *__restrict__ runFlags)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (q >= nq) return;
+    bool any = false;
+    for (int r = 0; r < per; ++r) any = any || (q * per + r < nseg && segFlags[q * per + r]);
+    runFlags[q] = any ? 1 : 0;
+}
+
+// The activity list in launch order (runListFromFlags in mgps_host.cpp: by strip of 32 rows of the run's first cell, then by
+// run index): one stable compaction per strip -- flags of the strip's active runs, scan, scatter behind the strips before.
+__global__ __launch_bounds__(256) void stripFlagKernel(const uint8_t *__restrict__ runFlags, size_t nq, size_t cpr, size_t nx, size_t ny, int strip,
+                                                       int32_t *__restrict__ out)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (q >= nq) return;
+    bool on = runFlags[q] != 0;
+    if (on && strip >= 0) on = int(((q * cpr / nx) % ny) >> 5) == strip;
+    out[q] = on ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void stripScatterKernel(const int32_t *__restrict__ rank, size_t nq, const int32_t *__restrict__ base,
+                                                          int32_t *__restrict__ list)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (q < nq && rank[q + 1] != rank[q]) list[size_t(*base) + size_t(rank[q])] = int32_t(q);
+}
+// *base += total; when `last`, the tail of the list up to listLen is padding (-1)
+__global__ void stripAdvanceKernel(int32_t *__restrict__ base, const int32_t *__restrict__ total, int32_t *__restrict__ list, int listLen, int last)
+{
+    const int b = *base + *total;
+    if (last)
+        for (int t = b + int(threadIdx.x); t < listLen; t += int(blockDim.x)) list[t] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) *base = b;
+}
+
 // ---- groups of the fused band stage (BandGroups in mgps_internal.h) --------------------------------------------------
 
 // One workgroup per 16^3 tile walks the recursion of the host builder (buildGroupsOverWindow): the owned set starts as the
@@ -822,6 +884,40 @@ int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t
     const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows;
     activityFlagsKernel<<<blocksFor(nq, 256), 256, 0, S(stream)>>>(d, reinterpret_cast<const uint32_t *>(lab), nq, chunkFlags, zc ? planeFlags : nullptr, zc ? zc : 1,
                                                                  nbx, nby);
+    return int(hipGetLastError());
+}
+
+int launchCountRuns(void *stream, const uint8_t *segFlags, size_t nseg, int *counts)
+{
+    static_assert(kSegCells == 32 && kChunkCells == 1024, "countRunsKernel folds 32 flags per 1024-cell run");
+    const size_t n1024 = (nseg + 31) / 32;
+    countRunsKernel<<<blocksFor(n1024, 256), 256, 0, S(stream)>>>(segFlags, nseg, counts);
+    return int(hipGetLastError());
+}
+int launchFoldRunFlags(void *stream, const uint8_t *segFlags, size_t nseg, int runCells, uint8_t *runFlags)
+{
+    const int per = runCells / kSegCells;
+    const size_t nq = (nseg + per - 1) / per;
+    foldRunFlagsKernel<<<blocksFor(nq, 256), 256, 0, S(stream)>>>(segFlags, nseg, per, nq, runFlags);
+    return int(hipGetLastError());
+}
+
+// runFlags: nq flags of the runs of runCells cells; tmpFlags: nq ints, rank: nq + 1 ints, base: one int (scratch); list: listLen
+// entries = the active runs in launch order, padded with -1
+int launchRunList(void *stream, const Dims &d, const uint8_t *runFlags, size_t nq, int runCells, int32_t *tmpFlags, int32_t *rank, int32_t *scanScratch,
+                  int32_t *base, int32_t *list, int listLen)
+{
+    const bool strips = size_t(d.nx) * d.ny * sizeof(float) > (size_t(256) << 10) && d.ny > 32;  // (the rule of runListFromFlags)
+    const int nstrips = strips ? (d.ny + 31) / 32 : 1;
+    hipError_t e = hipMemsetAsync(base, 0, sizeof(int32_t), S(stream));
+    if (e != hipSuccess) return int(e);
+    for (int sidx = 0; sidx < nstrips; ++sidx) {
+        stripFlagKernel<<<blocksFor(nq, 256), 256, 0, S(stream)>>>(runFlags, nq, size_t(runCells), size_t(d.nx), size_t(d.ny), strips ? sidx : -1, tmpFlags);
+        const int rc = launchExclusiveScan(stream, tmpFlags, rank, nq, scanScratch);
+        if (rc != 0) return rc;
+        stripScatterKernel<<<blocksFor(nq, 256), 256, 0, S(stream)>>>(rank, nq, base, list);
+        stripAdvanceKernel<<<1, 256, 0, S(stream)>>>(base, rank + nq, list, listLen, sidx + 1 == nstrips ? 1 : 0);
+    }
     return int(hipGetLastError());
 }
 

@@ -1831,6 +1831,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
         int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
         int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr;
+        int *runCounts = nullptr;
         int nband = 0, nGen = 0, planeZc = 0, nBandTiles = 0;
         size_t nfine = 0, nplane = 0;
     };
@@ -1918,6 +1919,9 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
             ODS_HIP(hipMemsetAsync(t.planeFlags, 0, t.nplane, nullptr));
         }
         ODS_LAUNCH(launchActivityFlags(nullptr, L.d, labOf(l), t.chunkFlags, t.planeFlags, t.planeZc));
+        ODS_TRY(tmp.get(h, &t.runCounts, 4));
+        ODS_HIP(hipMemsetAsync(t.runCounts, 0, 4 * sizeof(int), nullptr));
+        ODS_LAUNCH(launchCountRuns(nullptr, t.chunkFlags, t.nfine, t.runCounts));
         // (the groups below read the labels for activity only: patched or not makes no difference)
         ODS_LAUNCH(launchPatchSimpleCodes(nullptr, labOf(l), L.band, L.bandDiag, L.nbndGeneral, L.nband));
     }
@@ -1941,18 +1945,45 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     for (int l = 0; l < levels; ++l) {
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
-        RawVec<uint8_t> fineAct(t.nfine), planeAct(t.nplane);  // (page-locked above 1 MB: the copies below run at PCIe speed)
+        StageClock sub(h->opt.print_stats > 1);
+        // run length of the activity list from the device's counts; the flags come back folded to that length
+        int rc4[4] = {0, 0, 0, 0};
+        ODS_HIP(hipMemcpy(rc4, t.runCounts, sizeof(rc4), hipMemcpyDeviceToHost));
+        const int64_t rc64[4] = {rc4[0], rc4[1], rc4[2], rc4[3]};
+        const int runCells = chooseRunCells(rc64);
+        const size_t nruns = (t.nfine + size_t(runCells / kSegCells) - 1) / size_t(runCells / kSegCells);
+        uint8_t *runFlags = t.chunkFlags;
+        if (runCells != kSegCells) {
+            ODS_TRY(tmp.get(h, &runFlags, nruns));
+            ODS_LAUNCH(launchFoldRunFlags(nullptr, t.chunkFlags, t.nfine, runCells, runFlags));
+        }
+        // the list on the device: its length is the count of active runs, rounded up to whole workgroups
+        int activeRuns = 0;
+        for (int z = 0; z < 4; ++z)
+            if (kRunSizes[z] == runCells) activeRuns = rc4[z];
+        const int perGroup = kChunkCells / runCells, listLen = (activeRuns + perGroup - 1) / perGroup * perGroup;
+        {
+            int32_t *tmpFlags = nullptr, *rank = nullptr, *base = nullptr;
+            ODS_TRY(tmp.get(h, &tmpFlags, nruns));
+            ODS_TRY(tmp.get(h, &rank, nruns + 1));
+            ODS_TRY(tmp.get(h, &base, 1));
+            ODS_TRY(devAlloc(h, &L.chunks, size_t(listLen), false));
+            ODS_LAUNCH(launchRunList(nullptr, L.d, runFlags, nruns, runCells, tmpFlags, rank, t.scan, base, L.chunks, listLen));
+        }
+        RawVec<uint8_t> planeAct(t.nplane);
         RawVec<int32_t> kinds(size_t(t.nt));
-        ODS_HIP(hipMemcpy(fineAct.data(), t.chunkFlags, t.nfine, hipMemcpyDeviceToHost));
         if (t.nplane) ODS_HIP(hipMemcpy(planeAct.data(), t.planeFlags, t.nplane, hipMemcpyDeviceToHost));
         ODS_HIP(hipMemcpy(kinds.data(), t.tileKind, size_t(t.nt) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        sub.lap("   lists: counts + flags to the host", l);
         HostLevel HL;
         HL.d = L.d;
-        chunkListsFromFlags(HL, fineAct.data(), int64_t(t.nfine));
+        HL.chunkCells = runCells;
+        sub.lap("   lists: runs", l);
         for (size_t q = 0; q < planeAct.size(); ++q)
             if (planeAct[q]) HL.planeBlocks.push_back(int32_t(q));
+        sub.lap("   lists: plane blocks", l);
         tileListsFromKinds(HL, kinds.data(), 0);
-        ODS_TRY(devUpload(h, &L.chunks, HL.chunks));
+        sub.lap("   lists: built", l);
         ODS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
         ODS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
         ODS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
@@ -1962,13 +1993,15 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         L.npure[1] = int(HL.pureOdd.size());
         L.nmixed[0] = int(HL.mixedEven.size());
         L.nmixed[1] = int(HL.mixedOdd.size());
+        sub.lap("   lists: uploaded", l);
         if (l > 0) {
             ODS_TRY(gridAlloc(h, &L.x, L.d));
             ODS_TRY(gridAlloc(h, &L.b, L.d));
         }
         ODS_TRY(gridAlloc(h, &L.r, L.d));
         ODS_TRY(gridAlloc(h, &L.tmp, L.d));
-        fillGridP(h, L, l == 0, int(HL.chunks.size()), HL.chunkCells, int(HL.planeBlocks.size()), t.planeZc);
+        fillGridP(h, L, l == 0, listLen, runCells, int(HL.planeBlocks.size()), t.planeZc);
+        sub.lap("   lists: grids", l);
     }
     clock.lap("device order, codes, activity + tile lists");
     // ---- groups: totals to the host, arrays filled

@@ -192,7 +192,7 @@ class GeometricMultigridPoissonSolver:
             w = [_np_f32(a) for a in weights]
         assert tuple(w[0].shape) == (nz, ny, nx + 1) and tuple(w[1].shape) == (nz, ny + 1, nx) and tuple(w[2].shape) == (nz + 1, ny, nx)
         opt = options if options is not None else default_options()
-        opt.print_stats = int(bool(do_print_stats))
+        opt.print_stats = int(do_print_stats) if not isinstance(do_print_stats, bool) else int(do_print_stats)
         if device is not None:
             opt.device = torch.device(device).index if not isinstance(device, int) else device
         elif on_device:

@@ -21,6 +21,6 @@ for gs in (False, True):
         o = G.default_options()
         o.host_setup = host
         torch.cuda.synchronize(); t = time.time()
-        s = G.GeometricMultigridPoissonSolver(labd, wd, lev, gs, options=o, do_print_stats=(len(sys.argv) > 4))
+        s = G.GeometricMultigridPoissonSolver(labd, wd, lev, gs, options=o, do_print_stats=(2 if len(sys.argv) > 4 else 0))
         torch.cuda.synchronize(); print("create gs=%d %s builder: %.1f ms" % (gs, "host  " if host else "device", (time.time() - t) * 1e3), flush=True)
         s.close()
