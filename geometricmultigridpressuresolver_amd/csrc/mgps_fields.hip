@@ -448,6 +448,15 @@ __global__ void widenRealKernel(double *__restrict__ dst, const float *__restric
     if (c < n) dst[c] = double(src[c]);
 }
 
+// number of LIQUID cells (material label 1, Util.h:17)
+__global__ void countLiquidKernel(const int32_t *__restrict__ material, size_t n, unsigned long long *__restrict__ count)
+{
+    unsigned long long mine = 0;
+    for (size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x; c < n; c += size_t(gridDim.x) * blockDim.x) mine += material[c] == 1;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
 // device buffers of one call; everything is released when the object goes out of scope
 struct DevPool {
     std::vector<void *> blocks;
@@ -536,12 +545,33 @@ try {
             he = hipMemcpy(host, stage, n * sizeof(double), hipMemcpyDeviceToHost);
         }
     };
-    float *phi = upload(p->liquid_phi, cells), *solidPhi = upload(p->solid_phi, cells), *pressure = upload(p->pressure, cells);
+    // What the labels and weights are made from goes up first; the velocities, the solid velocities and the old pressure --
+    // needed from the right-hand side on -- follow on a copy stream while the passes below and the solver's set-up run
+    // (float arrays in page-locked memory, mgps_host_alloc: from pageable memory the call degrades to a blocking copy).
+    struct CopyStream {
+        hipStream_t s = nullptr;
+        ~CopyStream()
+        {
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamDestroy(s);
+            }
+        }
+    } copy;
+    if (!dbl && hipStreamCreateWithFlags(&copy.s, hipStreamNonBlocking) != hipSuccess) copy.s = nullptr;
+    auto uploadLater = [&](const void *host, size_t n) -> float * {
+        if (!copy.s) return upload(host, n);
+        float *d = pool.get<float>(n);
+        if (he == hipSuccess) he = hipMemcpyAsync(d, host, n * sizeof(float), hipMemcpyHostToDevice, copy.s);
+        return d;
+    };
+    float *phi = upload(p->liquid_phi, cells), *solidPhi = upload(p->solid_phi, cells);
     float *cw[3], *vel[3], *svel[3] = {nullptr, nullptr, nullptr};
+    for (int a = 0; a < 3; ++a) cw[a] = upload(p->cut_weights[a], faceCount(gx, gy, gz, a));
+    float *pressure = uploadLater(p->pressure, cells);
     for (int a = 0; a < 3; ++a) {
-        cw[a] = upload(p->cut_weights[a], faceCount(gx, gy, gz, a));
-        vel[a] = upload(p->velocity[a], faceCount(gx, gy, gz, a));
-        if (haveSolidVel) svel[a] = upload(p->solid_velocity[a], faceCount(gx, gy, gz, a));
+        vel[a] = uploadLater(p->velocity[a], faceCount(gx, gy, gz, a));
+        if (haveSolidVel) svel[a] = uploadLater(p->solid_velocity[a], faceCount(gx, gy, gz, a));
     }
     if (he != hipSuccess) return failHip("upload", he);
 #define PROJ_TRY(call)               \
@@ -577,7 +607,16 @@ try {
     p->expanded[2] = ez;
     // liquid cell count first: a domain without liquid has nothing to solve (Plug.cpp:270-282 returns there)
     double div[3] = {0, 0, 0};
-    PROJ_TRY(mgps_fields_divergence(div, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, s));
+    {
+        unsigned long long *count = pool.get<unsigned long long>(1), liquid = 0;
+        he = hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+        if (he == hipSuccess) {
+            countLiquidKernel<<<unsigned(std::min<size_t>((cells + 255) / 256, 4096)), 256, 0, s>>>(material, cells, count);
+            he = hipMemcpy(&liquid, count, sizeof(liquid), hipMemcpyDeviceToHost);
+        }
+        if (he != hipSuccess) return failHip("liquid cell count", he);
+        div[2] = double(liquid);
+    }
     p->liquid_cells = div[2];
     std::memset(&p->stats, 0, sizeof(p->stats));
     p->residual_inf = p->residual_l2 = p->divergence_sum = p->divergence_max = 0;
@@ -587,10 +626,7 @@ try {
         p->stats.outcome = MGPS_PCG_RHS_ZERO;
         return MGPS_OK;
     }
-    // Plug.cpp:386, 413
-    float *rhs = pool.get<float>(ecells), *x = nullptr;
-    PROJ_TRY(mgps_fields_rhs(rhs, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, ex, ey, ez, offset, s));
-    mgps_solver *mg = nullptr;  // Plug.cpp:463-466
+    mgps_solver *mg = nullptr;  // Plug.cpp:463-466 (before the right-hand side here: the velocities may still be on their way)
     o.borrow_device_weights = 1;  // (the pool outlives the solver: `guard` below is destroyed first)
     int rc = mgps_create_device(&mg, ex, ey, ez, labels, w[0], w[1], w[2], levels, p->use_gauss_seidel, &o);
     if (rc != MGPS_OK) return rc;
@@ -598,6 +634,10 @@ try {
         mgps_solver *h;
         ~Guard() { mgps_destroy(h); }
     } guard{mg};
+    if (copy.s && (he = hipStreamSynchronize(copy.s)) != hipSuccess) return failHip("upload", he);
+    // Plug.cpp:386, 413
+    float *rhs = pool.get<float>(ecells), *x = nullptr;
+    PROJ_TRY(mgps_fields_rhs(rhs, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, ex, ey, ez, offset, s));
     rc = mgps_grid_alloc(mg, 0, &x);  // zero-filled
     if (rc == MGPS_OK && p->use_old_pressure) rc = mgps_fields_pressure_to_solution(x, pressure, material, gx, gy, gz, ex, ey, ez, offset, s);
     if (rc != MGPS_OK) {
