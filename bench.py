@@ -53,6 +53,9 @@ def parse():
                     "1 = the reference's schedule, 2 = BASELINE config 1's '2+2'")
     ap.add_argument("--precision", choices=["fp32", "mixed"], default="fp32",
                     help="mixed = BASELINE config 5's storage: the fine level's iterate and residual in binary16 (options.precision = 1)")
+    ap.add_argument("--zero-guess", action="store_true",
+                    help="time applyVCycle(useInitialGuess=false): the cycle as the CG preconditioner runs it (CG.h:86, 180). The mixed-precision "
+                         "cycle is built for this form; from an initial guess it adds an fp32 residual and a correction pass")
     ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
                     help="free_surface_pcg = BASELINE config 3 (single GPU): MG-PCG to 1e-5 on the free-surface pool")
     return ap.parse_args()
@@ -269,19 +272,20 @@ def main():
             torch.cuda.synchronize()
 
     solver.applyVCycle(x, b, False)
+    guess = not args.zero_guess
     for _ in range(args.warmup):
-        solver.applyVCycle(x, b, True)
+        solver.applyVCycle(x, b, guess)
     solver.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver.applyVCycle(x, b, True)
+        solver.applyVCycle(x, b, guess)
     barrier()
     elapsed = time.perf_counter() - t0
     smooth_ms, smooth_groups = solver.profile_read()
     solver.profile_enable(2)  # stage breakdown: a few extra cycles outside the timed region (its event records cost a few %)
     for _ in range(min(args.steps, 5)):
-        solver.applyVCycle(x, b, True)
+        solver.applyVCycle(x, b, guess)
     stages = solver.stage_times()
     solver.profile_enable(False)
     if slab_run:  # the job is as slow as its slowest rank
@@ -295,7 +299,11 @@ def main():
     swept = solver.swept_cells(0)[1 if use_gs else 0]
     sweeps_per_group = 1  # Jacobi: one sweep; GS: two half sweeps touch every tile once = one sweep
     t_sweep = smooth_ms * 1e-3 / max(smooth_groups, 1) / sweeps_per_group  # (profile_read counts sweeps: --sweeps 2 doubles the count)
-    achieved = SMOOTHER_BYTES_PER_CELL * swept / t_sweep / 1e9  # per GPU
+    # mixed precision: the binary16 sweep moves 9 B per cell (iterate 2 + rhs 4 + code 1 + new iterate 2) instead of 13
+    sweep_bytes = 9.0 if args.precision == "mixed" else SMOOTHER_BYTES_PER_CELL
+    if t_sweep <= 0:
+        raise SystemExit("bench.py: the fine-level sweep was not timed (no event pairs came back from mgps_profile_read)")
+    achieved = sweep_bytes * swept / t_sweep / 1e9  # per GPU
     vps = args.steps / elapsed
     out = {
         "metric": "V-cycles/sec",
@@ -313,7 +321,7 @@ def main():
         "config": {
             "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
             f"(3 band Jacobi + {args.sweeps} x {'2 tiled-GS half sweeps' if use_gs else 'damped-Jacobi sweep'} + 3 band Jacobi per stroke), "
-            "useInitialGuess=true, " + ("fp32 storage" if args.precision == "fp32" else "mixed precision (options.precision = 1)"),
+            "useInitialGuess=%s, " % ("true" if guess else "false (the preconditioner's form)") + ("fp32 storage" if args.precision == "fp32" else "mixed precision (options.precision = 1)"),
             "grid": n,
             "levels": levels,
             "smoother": "tiled_gs" if use_gs else "jacobi",
@@ -337,8 +345,8 @@ def main():
             "launches": smooth_groups,
             "cells_per_launch": swept,
             "cells_allocated": float(n) * n * (z1 - z0),
-            "achieved_over_allocated_cells": SMOOTHER_BYTES_PER_CELL * (float(n) * n * (z1 - z0)) / t_sweep / 1e9,
-            "note": "per GPU; achieved = 13 B x cells the launch visits (active chunks only) / mean launch time (HIP events on the solver's stream)",
+            "achieved_over_allocated_cells": sweep_bytes * (float(n) * n * (z1 - z0)) / t_sweep / 1e9,
+            "note": "per GPU; achieved = %g B x cells the launch visits (active runs only) / mean launch time (HIP events on the solver's stream)" % sweep_bytes,
         },
     }
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
@@ -351,7 +359,7 @@ def main():
                 out["roofline"]["traffic_source"] = (
                     f"profiles/{pmc_file}, {pmc[str(n)]['kernel']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                     "per launch; L2<->fabric bytes incl. Infinity-Cache hits)")
-                out["roofline"]["algorithmic_bytes"] = SMOOTHER_BYTES_PER_CELL * swept
+                out["roofline"]["algorithmic_bytes"] = sweep_bytes * swept
                 break
         except Exception:
             pass

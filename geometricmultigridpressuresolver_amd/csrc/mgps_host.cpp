@@ -314,17 +314,29 @@ static void buildBand(HostLevel &L, int width)
 static void buildTileBoundaryOffsets(HostLevel &L);
 static void buildTileLists(HostLevel &L, int tileZOffset);
 
-// Run length of a level's activity list from the number of active runs of 1024, 256, 64 and 32 cells: 1024-cell runs, a
-// finer length in turn where it visits > 10 % fewer cells.
+// Run length of a level's activity list from the number of active runs of 1024, 256, 64 and 32 cells: the length whose runs
+// cost least, cells visited x cost per visited cell.  The costs are measured on the 512^3 cube's fine Jacobi sweep with the
+// length forced (MGPS_RUN_CELLS): 2.41 / 2.46 / 2.72 / 2.94 ps per visited cell -- shorter runs mean more list entries, more
+// run ends that fetch their x-neighbour from memory, and waves that gather from eight places.  A shorter length has to win by
+// 3 % to be taken.  (The cube keeps 1024-cell runs although 32-cell runs would skip its 33-cell padding: 540 against 528
+// V-cycles/s; the reference's free-surface test domain goes to 32: MG-PCG 79.8 / 69.7 / 65.2 ms with 256 / 64 / 32.)
 int chooseRunCells(const int64_t nAct[4])
 {
+    static const int forced = [] {  // MGPS_RUN_CELLS=1024|256|64|32: A/B switch for tuning runs
+        const char *e = getenv("MGPS_RUN_CELLS");
+        return e ? atoi(e) : 0;
+    }();
+    for (int z = 0; z < 4; ++z)
+        if (forced == kRunSizes[z]) return forced;
     int cells = kRunSizes[0];
-    double visited = double(nAct[0]) * kRunSizes[0];
-    for (int z = 1; z < 4; ++z)
-        if (double(nAct[z]) * kRunSizes[z] < 0.9 * visited) {
+    double best = double(nAct[0]) * kRunSizes[0] * runCostFactor(kRunSizes[0]);
+    for (int z = 1; z < 4; ++z) {
+        const double c = double(nAct[z]) * kRunSizes[z] * runCostFactor(kRunSizes[z]);
+        if (c < 0.97 * best) {
             cells = kRunSizes[z];
-            visited = double(nAct[z]) * kRunSizes[z];
+            best = c;
         }
+    }
     return cells;
 }
 

@@ -16,11 +16,11 @@ namespace mgps {
 constexpr int kTile = 16;  // UT_VoxelArray tile edge: decides the Gauss-Seidel colouring (Ops.h:436-448)
 
 // activity-list granularity, chosen per level: 1024 cells (one workgroup of 256 threads x 4 cells) or, where
-// that visits > 10 % more cells (liquid that ends mid-row: free surfaces), 256 cells (one wavefront; the list is
-// then padded with -1 to whole workgroups of four entries)
+// that costs more (liquid that ends mid-row: free surfaces; chooseRunCells weighs the cells a length visits by its measured
+// cost per cell), 256 cells (one wavefront; the list is then padded with -1 to whole workgroups of four entries)
 constexpr int kChunkCells = 1024;
 constexpr int kWaveChunkCells = 256;
-// ... or, where that again visits > 10 % fewer cells, 64 and then 32 cells (16 / 8 lanes of a wavefront; the list is padded
+// ... or 64 or 32 cells (16 / 8 lanes of a wavefront; the list is padded
 // to whole workgroups): a free surface that cuts the x-rows -- the reference's own test domain,
 // HDK_TestGeometricMultigrid.cpp:235, has its surface along x -- leaves most of a 256-cell run in the air.  The activity
 // flags are kept per kSegCells cells.
@@ -195,6 +195,8 @@ int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t 
 void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg);
 constexpr int kRunSizes[4] = {kChunkCells, kWaveChunkCells, 64, kSegCells};  // the run lengths a level's list can have
 int chooseRunCells(const int64_t nAct[4]);                                    // from the active runs of each length
+// cost per visited cell of a sweep over runs of that length, relative to 1024-cell runs (measured: see chooseRunCells)
+inline double runCostFactor(int cells) { return cells >= kChunkCells ? 1.0 : cells >= kWaveChunkCells ? 1.02 : cells >= 64 ? 1.13 : 1.22; }
 void runListFromFlags(HostLevel &L, const uint8_t *runAct, int64_t nq, int runCells);
 void tileListsFromKinds(HostLevel &L, const int64_t *kind, int tileZOffset);
 void tileListsFromKinds(HostLevel &L, const int32_t *kind, int tileZOffset);

@@ -856,7 +856,12 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         for (int rep = 0; rep < reps; ++rep) {
             unsigned used = 0;
             const bool d = dot && rep == reps - 1;
+            if (h->profiling) MGPS_TRY(profMark(h, true));  // the measurement hook of smoothStroke: event pair around the fine sweep
             MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, F.g, other, cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
+            if (h->profiling) {
+                MGPS_TRY(profMark(h, false));
+                ++h->profSweeps;
+            }
             h->dotUsed += used;
             std::swap(cur, other);
         }
@@ -1250,9 +1255,10 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 
 // The plane-marching sweep visits blocks of 256 x 16 x zc cells, the quad sweep runs of 1024 .. 32 cells: where the liquid
 // fills a small part of the grid (a 480^3 simulation inside the reference's 1024^3 power-of-two expansion: 57 M of 1074 M
-// cells) the blocks hold three times the cells of the runs, and the 9 % the plane kernel gains on a full grid (2.63 vs
-// 2.87 ms at 1024^3) are lost many times over.  0 = leave the level to the quad sweep (options.stencil_path = 2 still forces
-// the plane kernel).
+// cells) the blocks hold twice the cells of the runs, and the 9 % the plane kernel gains per visited cell (2.63 vs 2.87 ms
+// at 1024^3) are lost many times over: measured there, V-cycle 2.48 ms through the quad kernel, 3.07 ms through the plane
+// kernel.  The level goes to whichever costs less, cells visited x cost per cell (runCostFactor; plane 0.92).  0 = the quad
+// sweep (options.stencil_path = 2 still forces the plane kernel).
 int planeZcFor(const mgps_options &o, int planeZc, size_t nplaneBlocks, size_t nchunks, int chunkCells)
 {
     static const bool envPlane = [] {  // MGPS_STENCIL=plane: the A/B switch of launchStencil
@@ -1260,8 +1266,8 @@ int planeZcFor(const mgps_options &o, int planeZc, size_t nplaneBlocks, size_t n
         return e && e[0] == 'p';
     }();
     if (!planeZc || o.stencil_path == 2 || envPlane) return planeZc;
-    const double blockCells = double(nplaneBlocks) * 256.0 * kPlaneRows * planeZc, runCells = double(nchunks) * chunkCells;
-    return blockCells > 1.15 * runCells ? 0 : planeZc;
+    const double planeCost = double(nplaneBlocks) * 256.0 * kPlaneRows * planeZc * 0.92, runCost = double(nchunks) * chunkCells * runCostFactor(chunkCells);
+    return planeCost > runCost ? 0 : planeZc;
 }
 
 // upload one level built by buildSlabLevel

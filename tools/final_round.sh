@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/final_round.sh r02 -> gpurun_out/<round>_*: everything kept under profiles/ for a round
+round=${1:-r02}
+export TMPDIR=/tmp PYTHONPATH=$PWD
+mkdir -p gpurun_out
+bash tools/refresh_profiles.sh $round > gpurun_out/refresh.log 2>&1 || { tail -5 gpurun_out/refresh.log; exit 1; }
+echo "profiles refreshed"
+python bench.py > gpurun_out/${round}_bench1024_jacobi_1gpu.json 2> gpurun_out/bench1024.err || exit 1
+python bench.py --size 512 > gpurun_out/${round}_bench512_jacobi.json 2>/dev/null || exit 1
+python bench.py --size 256 > gpurun_out/${round}_bench256_jacobi.json 2>/dev/null || exit 1
+python bench.py --size 512 --smoother gs --no-frac512 > gpurun_out/${round}_bench512_gs.json 2>/dev/null || exit 1
+python bench.py --size 256 --smoother gs --no-frac512 > gpurun_out/${round}_bench256_gs.json 2>/dev/null || exit 1
+python bench.py --size 128 --levels 4 --sweeps 2 --no-frac512 > gpurun_out/${round}_bench128_L4_2plus2.json 2>/dev/null || exit 1
+# BASELINE config 5: the cycle in the preconditioner's form (zero initial guess), fp32 beside mixed precision
+for sz in 512 1024; do
+  python bench.py --size $sz --zero-guess --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_fp32.json 2>/dev/null || exit 1
+  python bench.py --size $sz --zero-guess --precision mixed --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_mixed.json 2>/dev/null || exit 1
+done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("gpurun_out/${round}_bench*.json")):
+    d = json.load(open(f)); r = d["roofline"]
+    print(f.split("/")[-1], round(d["value"], 1), "V/s", round(r["achieved"]), "GB/s frac", round(r["frac"], 3), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+PY
+echo final-round-done
