@@ -158,6 +158,14 @@ def free_surface_pcg(args):
                 best = st
         key = ("tiled_gs" if use_gs else "jacobi") + ("_fp64_vectors" if fp64 else "")
         out[key] = {k: best[k] for k in ("outcome", "iterations", "rel_residual", "rel_residual_recomputed", "solve_ms")}
+        if not fp64:
+            # roofline of the whole iteration, Jacobi form: 132 algorithmic B per ACTIVE cell and iteration (DESIGN.md section 11:
+            # V-cycle 60.7 B per fine cell x 8/7 for the coarser levels + band stages, A.p + dot 9, update 25, xpay 13) against
+            # 8 TB/s; the cells a launch visits beyond the active ones (run ends, padding) are overhead, not work
+            gbps = 132.0 * out["active_cells"] * best["iterations"] / (best["solve_ms"] * 1e-3) / 1e9
+            out[key]["algorithmic_GBps"] = gbps
+            out[key]["frac_of_hbm_peak"] = gbps / HBM_PEAK_GBS
+            out[key]["visited_cells_fine_sweep"] = solver.swept_cells(0)[1 if use_gs else 0]
         if use_gs and not fp64 and args.check_oracle:
             x_gpu = x.cpu().numpy().astype(np.float64)
         solver.close()

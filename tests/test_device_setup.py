@@ -170,7 +170,7 @@ def test_borrowed_weights_give_the_same_solver():
 
 
 @pytest.mark.parametrize("shape,levels", [((24, 40, 56), 2), ((36, 20, 44), 1), ((48, 64, 32), 3), ((64, 64, 96), 3)])
-@pytest.mark.parametrize("seed", [3, 4])
+@pytest.mark.parametrize("seed", [3, 4] + list(range(100, 100 + int(__import__("os").environ.get("MGPS_FUZZ_SEEDS", "0")))))
 def test_random_labels_and_weights(shape, levels, seed):
     """Random blobs of every label and random face weights (closed, fractional, open): dense bands that the group builder has
     to split, general BOUNDARY cells everywhere, extents that are not multiples of the tile edge, thin liquid sheets whose
@@ -218,8 +218,12 @@ def test_random_labels_and_weights(shape, levels, seed):
         except G.MgpsError as e:
             results.append(str(e))
     try:
-        assert not isinstance(results[0], str) and not isinstance(results[1], str), results  # (these seeds give valid domains)
-        _compare(results[0], results[1])
+        if seed < 100:
+            assert not isinstance(results[0], str) and not isinstance(results[1], str), results  # (these seeds give valid domains)
+        if isinstance(results[0], str) or isinstance(results[1], str):
+            assert isinstance(results[0], str) and isinstance(results[1], str) and results[0] == results[1], results
+        else:
+            _compare(results[0], results[1])
     finally:
         for r in results:
             if not isinstance(r, str):
