@@ -105,26 +105,22 @@ __global__ void validFacesKernel(Box g, int axis, uint8_t *__restrict__ valid, c
 
 __global__ void domainLabelsKernel(Box g, Box e, int offset, uint8_t *__restrict__ expanded, const int32_t *__restrict__ material)
 {
-    int i, j, k;
-    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
-    const int bi = i - offset, bj = j - offset, bk = k - offset;
-    uint8_t l = MGPS_EXTERIOR_CELL;
-    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz) {
-        const int m = material[cellAt(g, bi, bj, bk)];
-        l = m == kLiquid ? MGPS_INTERIOR_CELL : m == kAir ? MGPS_DIRICHLET_CELL : MGPS_EXTERIOR_CELL;
-    }
-    expanded[cellAt(e, i, j, k)] = l;
+    int bi, bj, bk;  // (the base box only: the launcher has filled the expanded grid with EXTERIOR)
+    if (!unflatten(g.gx, g.gy, g.gz, bi, bj, bk)) return;
+    const int m = material[cellAt(g, bi, bj, bk)];
+    expanded[cellAt(e, bi + offset, bj + offset, bk + offset)] =
+        m == kLiquid ? MGPS_INTERIOR_CELL : m == kAir ? MGPS_DIRICHLET_CELL : MGPS_EXTERIOR_CELL;
 }
 
 __global__ void boundaryWeightsKernel(Box g, Box e, int offset, int axis, float *__restrict__ expanded, const float *__restrict__ cw,
                                       const float *__restrict__ phi, const uint8_t *__restrict__ valid,
                                       const int32_t *__restrict__ material)
 {
-    int i, j, k;
-    if (!unflatten(e.gx + (axis == 0), e.gy + (axis == 1), e.gz + (axis == 2), i, j, k)) return;
-    const int bi = i - offset, bj = j - offset, bk = k - offset;
+    int bi, bj, bk;  // (the faces of the base box only: the launcher has zeroed the expanded face grid)
+    if (!unflatten(g.gx + (axis == 0), g.gy + (axis == 1), g.gz + (axis == 2), bi, bj, bk)) return;
+    const int i = bi + offset, j = bj + offset, k = bk + offset;
     float w = 0.f;
-    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx + (axis == 0) && bj < g.gy + (axis == 1) && bk < g.gz + (axis == 2)) {
+    {
         const size_t f = faceAt(g, axis, bi, bj, bk);
         if (valid[f]) {  // a valid face has both cells inside the grid
             int b[3] = {bi, bj, bk};
@@ -182,29 +178,20 @@ __global__ void rhsKernel(Box g, Box e, int offset, float *__restrict__ rhs, con
                           const float *vy, const float *vz, const float *svx, const float *svy, const float *svz, const float *cwx,
                           const float *cwy, const float *cwz)
 {
-    int i, j, k;
-    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
-    const int bi = i - offset, bj = j - offset, bk = k - offset;
-    float r = 0.f;
-    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz && material[cellAt(g, bi, bj, bk)] == kLiquid) {
-        const float *v[3] = {vx, vy, vz}, *sv[3] = {svx, svy, svz}, *cw[3] = {cwx, cwy, cwz};
-        r = cellDivergence(g, bi, bj, bk, 1.f, v, sv, cw);
-    }
-    rhs[cellAt(e, i, j, k)] = r;
+    int bi, bj, bk;  // (the base box only: the launcher has zeroed the expanded grid)
+    if (!unflatten(g.gx, g.gy, g.gz, bi, bj, bk)) return;
+    if (material[cellAt(g, bi, bj, bk)] != kLiquid) return;
+    const float *v[3] = {vx, vy, vz}, *sv[3] = {svx, svy, svz}, *cw[3] = {cwx, cwy, cwz};
+    rhs[cellAt(e, bi + offset, bj + offset, bk + offset)] = cellDivergence(g, bi, bj, bk, 1.f, v, sv, cw);
 }
 
 __global__ void pressureToSolutionKernel(Box g, Box e, int offset, float *__restrict__ x, const float *__restrict__ pressure,
                                          const int32_t *__restrict__ material)
 {
-    int i, j, k;
-    if (!unflatten(e.gx, e.gy, e.gz, i, j, k)) return;
-    const int bi = i - offset, bj = j - offset, bk = k - offset;
-    float v = 0.f;
-    if (bi >= 0 && bj >= 0 && bk >= 0 && bi < g.gx && bj < g.gy && bk < g.gz) {
-        const size_t c = cellAt(g, bi, bj, bk);
-        if (material[c] == kLiquid) v = pressure[c];
-    }
-    x[cellAt(e, i, j, k)] = v;
+    int bi, bj, bk;  // (the base box only: the launcher has zeroed the expanded grid)
+    if (!unflatten(g.gx, g.gy, g.gz, bi, bj, bk)) return;
+    const size_t c = cellAt(g, bi, bj, bk);
+    if (material[c] == kLiquid) x[cellAt(e, bi + offset, bj + offset, bk + offset)] = pressure[c];
 }
 
 __global__ void solutionToPressureKernel(Box g, Box e, int offset, float *__restrict__ pressure, const float *__restrict__ x,
@@ -319,7 +306,10 @@ try {
     if (!expanded_labels || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_domain_labels");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
-    domainLabelsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_labels, material);
+    // fill + a kernel over the base box: the reference's power-of-two expansion makes the solver grid up to ten times the
+    // simulation grid (480^3 -> 1024^3), and one thread per expanded cell spent 2.5-4 ms per pass there
+    if (hipMemsetAsync(expanded_labels, MGPS_EXTERIOR_CELL, e.cells(), static_cast<hipStream_t>(stream)) != hipSuccess) return bad("mgps_fields_domain_labels");
+    domainLabelsKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_labels, material);
     return done("mgps_fields_domain_labels");
 }
 MGPS_API_CATCH(nullptr)
@@ -333,8 +323,10 @@ try {
         return bad("mgps_fields_boundary_weights");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
     const size_t n = size_t(ex + (axis == 0)) * (ey + (axis == 1)) * (ez + (axis == 2));
-    boundaryWeightsKernel<<<blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, axis, expanded_weights, cut_weights,
-                                                                                   liquid_phi, valid, material);
+    const size_t nb = size_t(gx + (axis == 0)) * (gy + (axis == 1)) * (gz + (axis == 2));
+    if (hipMemsetAsync(expanded_weights, 0, n * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess) return bad("mgps_fields_boundary_weights");
+    boundaryWeightsKernel<<<blocks(nb), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, axis, expanded_weights, cut_weights,
+                                                                                    liquid_phi, valid, material);
     return done("mgps_fields_boundary_weights");
 }
 MGPS_API_CATCH(nullptr)
@@ -357,7 +349,8 @@ try {
         !okExpanded(gx, gy, gz, ex, ey, ez, offset) || ((svx || svy || svz) && !(svx && svy && svz)))
         return bad("mgps_fields_rhs");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
-    rhsKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_rhs, material, vx, vy, vz, svx, svy,
+    if (hipMemsetAsync(expanded_rhs, 0, e.cells() * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess) return bad("mgps_fields_rhs");
+    rhsKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_rhs, material, vx, vy, vz, svx, svy,
                                                                              svz, cwx, cwy, cwz);
     return done("mgps_fields_rhs");
 }
@@ -369,7 +362,8 @@ try {
     if (!expanded_x || !pressure || !material || !okBox(gx, gy, gz) || !okExpanded(gx, gy, gz, ex, ey, ez, offset))
         return bad("mgps_fields_pressure_to_solution");
     const Box g{gx, gy, gz}, e{ex, ey, ez};
-    pressureToSolutionKernel<<<blocks(e.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_x, pressure, material);
+    if (hipMemsetAsync(expanded_x, 0, e.cells() * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess) return bad("mgps_fields_pressure_to_solution");
+    pressureToSolutionKernel<<<blocks(g.cells()), 256, 0, static_cast<hipStream_t>(stream)>>>(g, e, offset, expanded_x, pressure, material);
     return done("mgps_fields_pressure_to_solution");
 }
 MGPS_API_CATCH(nullptr)
