@@ -376,7 +376,6 @@ int launchCoarsenLabels(void *stream, const Dims &fine, const uint8_t *fineLab, 
 int launchAnyActive(void *stream, const Dims &d, const uint8_t *lab, int *activeFlag);
 int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
 int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab);
-int launchInteriorCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
 size_t scanScratchInts(size_t n);
 int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch);  // out: n + 1 entries
 int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,

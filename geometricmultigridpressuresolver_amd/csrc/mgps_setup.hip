@@ -111,17 +111,6 @@ __global__ __launch_bounds__(256) void markBoundaryKernel(Dims d, uint8_t *__res
         lab[c] = MGPS_BOUNDARY_CELL;
 }
 
-// the label-only half of unitTestBoundaryCells (Ops.h:1771-1870): every INTERIOR cell has six active neighbours
-__global__ __launch_bounds__(256) void interiorCheckKernel(Dims d, const uint8_t *__restrict__ lab, int *__restrict__ flags)
-{
-    const size_t c = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-    if (c >= cellCount(d) || lab[c] != MGPS_INTERIOR_CELL) return;
-    const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
-    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
-    auto bad = [&](bool inGrid, ptrdiff_t off) { return !inGrid || !activeCode(lab[ptrdiff_t(c) + off]); };
-    if (bad(i > 0, -1) || bad(i + 1 < d.nx, 1) || bad(j > 0, -sy) || bad(j + 1 < d.ny, sy) || bad(k > 0, -sz) || bad(k + 1 < d.nz, sz)) flags[0] = 1;
-}
-
 // ---- exclusive scan of int32 (n + 1 outputs: out[n] = the total) ------------------------------------------------------
 constexpr int kScanThreads = 256, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
 
@@ -827,11 +816,6 @@ int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFl
 int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab)
 {
     markBoundaryKernel<<<blocksFor(d.cells(), 256), 256, 0, S(stream)>>>(d, lab);
-    return int(hipGetLastError());
-}
-int launchInteriorCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag)
-{
-    interiorCheckKernel<<<blocksFor(d.cells(), 256), 256, 0, S(stream)>>>(d, lab, badFlag);
     return int(hipGetLastError());
 }
 
