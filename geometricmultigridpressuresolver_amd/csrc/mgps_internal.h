@@ -395,6 +395,11 @@ int launchFoldRunFlags(void *stream, const uint8_t *segFlags, size_t nseg, int r
 int launchRunList(void *stream, const Dims &d, const uint8_t *runFlags, size_t nq, int runCells, int32_t *tmpFlags, int32_t *rank, int32_t *scanScratch,
                   int32_t *base, int32_t *list, int listLen);
 int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
+// one Gauss-Seidel tile list (colour parity `odd`, pure or mixed tiles) from the per-tile kinds; the active plane blocks
+// from their flags: list entries ascending, rank[n] = the count
+int launchTileClassList(void *stream, const Dims &d, const int32_t *kind, int odd, int mixed, int32_t *flags, int32_t *rank, int32_t *list,
+                        int32_t *scanScratch);
+int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
 // the group kernels run over the list of tiles that hold band cells; counts and offsets are indexed by list position
 int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
                           const int32_t *bandTiles, int nBandTiles, int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken);

@@ -446,6 +446,23 @@ __global__ __launch_bounds__(256) void tileListKernel(const int32_t *__restrict_
     if (t < n && rank[t + 1] != rank[t]) list[rank[t]] = t;
 }
 
+// flags[t] = 1 for the tiles of one Gauss-Seidel list: active, of colour parity `odd` ((ti + tj + tk) & 1), pure (all 4096
+// cells INTERIOR, kind bit 0) or mixed; which = 0 pure, 1 mixed (buildTileLists / tileListsFromKinds in mgps_host.cpp)
+__global__ __launch_bounds__(256) void tileClassFlagKernel(const int32_t *__restrict__ kind, int n, int tx, int ty, int odd, int mixed,
+                                                           int32_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n) return;
+    const int kd = kind[t], ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    flags[t] = ((kd >> 1) != 0 && ((ti + tj + tk) & 1) == odd && ((kd & 1) == 0) == (mixed != 0)) ? 1 : 0;
+}
+// flags of bytes (plane blocks) as ints for the scan
+__global__ __launch_bounds__(256) void byteFlagKernel(const uint8_t *__restrict__ in, int n, int32_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) flags[t] = in[t] ? 1 : 0;
+}
+
 // ---- activity flags --------------------------------------------------------------------------------------------------
 
 // chunkFlags[q] = the q-th run of kSegCells = 32 cells holds an active cell (8 lanes per run); planeFlags (optional, nx % 4 == 0):
@@ -917,6 +934,27 @@ int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *
     int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
     if (e != 0) return e;
     tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
+    return int(hipGetLastError());
+}
+// list = the tiles t with (kind[t] >> 1) != 0 of one colour and class, ascending; rank[nt] = their number afterwards
+int launchTileClassList(void *stream, const Dims &d, const int32_t *kind, int odd, int mixed, int32_t *flags, int32_t *rank, int32_t *list,
+                        int32_t *scanScratch)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile, nt = tx * ty * tz;
+    tileClassFlagKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(kind, nt, tx, ty, odd, mixed, flags);
+    const int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
+    if (e != 0) return e;
+    tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
+    return int(hipGetLastError());
+}
+// list = the indices of the non-zero bytes, ascending (the active blocks of the plane-marching sweep); rank[n] = their number
+int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch)
+{
+    if (n <= 0) return 0;
+    byteFlagKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(bytes, n, flags);
+    const int e = launchExclusiveScan(stream, flags, rank, size_t(n), scanScratch);
+    if (e != 0) return e;
+    tileListKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(rank, n, list);
     return int(hipGetLastError());
 }
 int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,

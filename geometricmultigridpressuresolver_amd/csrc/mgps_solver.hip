@@ -1838,6 +1838,8 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
         int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr;
         int *runCounts = nullptr;
+        int32_t *listCounts = nullptr;  // pure even / odd, mixed even / odd tiles, plane blocks
+        int runCells = 0, listLen = 0;
         int nband = 0, nGen = 0, planeZc = 0, nBandTiles = 0;
         size_t nfine = 0, nplane = 0;
     };
@@ -1976,38 +1978,46 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
             ODS_TRY(devAlloc(h, &L.chunks, size_t(listLen), false));
             ODS_LAUNCH(launchRunList(nullptr, L.d, runFlags, nruns, runCells, tmpFlags, rank, t.scan, base, L.chunks, listLen));
         }
-        RawVec<uint8_t> planeAct(t.nplane);
-        RawVec<int32_t> kinds(size_t(t.nt));
-        if (t.nplane) ODS_HIP(hipMemcpy(planeAct.data(), t.planeFlags, t.nplane, hipMemcpyDeviceToHost));
-        ODS_HIP(hipMemcpy(kinds.data(), t.tileKind, size_t(t.nt) * sizeof(int32_t), hipMemcpyDeviceToHost));
-        sub.lap("   lists: counts + flags to the host", l);
-        HostLevel HL;
-        HL.d = L.d;
-        HL.chunkCells = runCells;
-        sub.lap("   lists: runs", l);
-        for (size_t q = 0; q < planeAct.size(); ++q)
-            if (planeAct[q]) HL.planeBlocks.push_back(int32_t(q));
-        sub.lap("   lists: plane blocks", l);
-        tileListsFromKinds(HL, kinds.data(), 0);
-        sub.lap("   lists: built", l);
-        ODS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
-        ODS_TRY(devUpload(h, &L.pure[0], HL.pureEven));
-        ODS_TRY(devUpload(h, &L.pure[1], HL.pureOdd));
-        ODS_TRY(devUpload(h, &L.mixed[0], HL.mixedEven));
-        ODS_TRY(devUpload(h, &L.mixed[1], HL.mixedOdd));
-        L.npure[0] = int(HL.pureEven.size());
-        L.npure[1] = int(HL.pureOdd.size());
-        L.nmixed[0] = int(HL.mixedEven.size());
-        L.nmixed[1] = int(HL.mixedOdd.size());
-        sub.lap("   lists: uploaded", l);
+        // the four Gauss-Seidel tile lists and the plane-block list: compacted on the device too; the five counts come back
+        // together below
+        ODS_TRY(tmp.get(h, &t.listCounts, 5));
+        ODS_HIP(hipMemsetAsync(t.listCounts, 0, 5 * sizeof(int32_t), nullptr));
+        {
+            int32_t **cls[4] = {&L.pure[0], &L.pure[1], &L.mixed[0], &L.mixed[1]};  // pure even, pure odd, mixed even, mixed odd
+            for (int q = 0; q < 4; ++q) {
+                ODS_TRY(devAlloc(h, cls[q], size_t(t.nt) / 2 + 1, false));
+                ODS_LAUNCH(launchTileClassList(nullptr, L.d, t.tileKind, q & 1, q >> 1, t.tileFlags, t.tileRank, *cls[q], t.scan));
+                ODS_HIP(hipMemcpyAsync(t.listCounts + q, t.tileRank + t.nt, sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+            }
+            if (t.nplane) {
+                int32_t *pf = nullptr, *pr = nullptr;
+                ODS_TRY(tmp.get(h, &pf, t.nplane));
+                ODS_TRY(tmp.get(h, &pr, t.nplane + 1));
+                ODS_TRY(devAlloc(h, &L.planeBlocks, t.nplane, false));
+                ODS_LAUNCH(launchByteList(nullptr, t.planeFlags, int(t.nplane), pf, pr, L.planeBlocks, t.scan));
+                ODS_HIP(hipMemcpyAsync(t.listCounts + 4, pr + t.nplane, sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+            }
+        }
+        t.runCells = runCells;
+        t.listLen = listLen;
+        sub.lap("   lists: enqueued", l);
         if (l > 0) {
             ODS_TRY(gridAlloc(h, &L.x, L.d));
             ODS_TRY(gridAlloc(h, &L.b, L.d));
         }
         ODS_TRY(gridAlloc(h, &L.r, L.d));
         ODS_TRY(gridAlloc(h, &L.tmp, L.d));
-        fillGridP(h, L, l == 0, listLen, runCells, int(HL.planeBlocks.size()), t.planeZc);
-        sub.lap("   lists: grids", l);
+    }
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        int32_t counts[5] = {0, 0, 0, 0, 0};
+        ODS_HIP(hipMemcpy(counts, t.listCounts, sizeof(counts), hipMemcpyDeviceToHost));
+        L.npure[0] = counts[0];
+        L.npure[1] = counts[1];
+        L.nmixed[0] = counts[2];
+        L.nmixed[1] = counts[3];
+        fillGridP(h, L, l == 0, t.listLen, t.runCells, counts[4], t.planeZc);
     }
     clock.lap("device order, codes, activity + tile lists");
     // ---- groups: totals to the host, arrays filled
