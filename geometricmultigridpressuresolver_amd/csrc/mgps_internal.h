@@ -378,8 +378,10 @@ int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFl
 int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab);
 size_t scanScratchInts(size_t n);
 int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch);  // out: n + 1 entries
+int launchBandCandidates(void *stream, const Dims &d, const uint8_t *lab, int32_t *tileKind, uint8_t *tileBits, int32_t *flags, int32_t *rank,
+                         int32_t *list, int32_t *scanScratch);  // the tiles that can hold band cells (or need the INTERIOR check)
 int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
-                    int *interiorBad);  // interiorBad (optional): set when an INTERIOR cell has an inactive neighbour
+                    int *interiorBad, const int32_t *tiles, int ntiles);  // interiorBad (optional): set when an INTERIOR cell has an inactive neighbour
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band);
 int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                        uint8_t *diagS, int32_t *general, int *violations);

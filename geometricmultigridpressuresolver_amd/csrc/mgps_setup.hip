@@ -189,6 +189,78 @@ __global__ __launch_bounds__(kScanThreads) void scanDownKernel(const int32_t *__
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = blockSums[nb];
 }
 
+// ---- which tiles need the band kernel ---------------------------------------------------------------------------------
+
+// A streaming pass over the labels: per 16^3 tile its kind for the Gauss-Seidel lists ((active cells << 1) | all 4096
+// cells INTERIOR) and three bits -- 1: holds a BOUNDARY cell, 2: holds an inactive cell (or reaches past the grid), 4: holds
+// an INTERIOR cell.  One workgroup per row of tiles along x, a thread per tile: the lanes of a wave read consecutive
+// 16-byte pieces of a grid row.
+__global__ __launch_bounds__(64) void tileStatsKernel(Dims d, const uint8_t *__restrict__ lab, int tx, int ty, int32_t *__restrict__ tileKind,
+                                                      uint8_t *__restrict__ tileBits)
+{
+    const int tj = blockIdx.x % ty, tk = blockIdx.x / ty;
+    const bool wide = (d.nx & 15) == 0;
+    for (int ti = threadIdx.x; ti < tx; ti += 64) {
+        const int i0 = ti * kTile, w = min(kTile, d.nx - i0);
+        int act = 0, inter = 0, bnd = 0;
+        const int nk = min(kTile, d.nz - tk * kTile), nj = min(kTile, d.ny - tj * kTile);
+        for (int lk = 0; lk < nk; ++lk) {
+            const uint8_t *plane = lab + cellIdx(d, i0, tj * kTile, tk * kTile + lk);
+            if (wide && nj == kTile) {
+                uint4 v[kTile];
+#pragma unroll
+                for (int lj = 0; lj < kTile; ++lj) v[lj] = *reinterpret_cast<const uint4 *>(plane + size_t(lj) * d.nx);
+#pragma unroll
+                for (int lj = 0; lj < kTile; ++lj) {
+                    const uint32_t q[4] = {v[lj].x, v[lj].y, v[lj].z, v[lj].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const unsigned c = (q[e] >> (8 * b)) & 0xffu;
+                            inter += c == MGPS_INTERIOR_CELL;
+                            bnd += c >= MGPS_BOUNDARY_CELL;
+                        }
+                }
+            } else
+                for (int lj = 0; lj < nj; ++lj)
+                    for (int li = 0; li < w; ++li) {
+                        const unsigned c = plane[size_t(lj) * d.nx + li];
+                        inter += c == MGPS_INTERIOR_CELL;
+                        bnd += c >= MGPS_BOUNDARY_CELL;
+                    }
+        }
+        act = inter + bnd;
+        const int cells = w * nj * nk, t = (tk * ty + tj) * tx + ti;
+        tileKind[t] = (act << 1) | (inter == kTile * kTile * kTile ? 1 : 0);
+        tileBits[t] = uint8_t((bnd ? 1 : 0) | ((act < cells || cells < kTile * kTile * kTile) ? 2 : 0) | (inter ? 4 : 0));
+    }
+}
+// flags[t] = 1: the tile goes through bandMaskKernel -- a BOUNDARY cell in it or in one of its 26 neighbours can seed band
+// cells in it (band_width - 1 <= 7 cells of reach), or it holds an INTERIOR cell that may touch an inactive one (its own or a
+// face neighbour's: the INTERIOR rule of unitTestBoundaryCells is checked there).  Every other tile has no band cells.
+__global__ __launch_bounds__(256) void tileCandidateKernel(int tx, int ty, int tz, const uint8_t *__restrict__ bits, int32_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= tx * ty * tz) return;
+    const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    bool seed = false, inactive = false;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ni = ti + dx, nj = tj + dy, nk = tk + dz;
+                const bool face = (dx != 0) + (dy != 0) + (dz != 0) <= 1;
+                if (ni < 0 || nj < 0 || nk < 0 || ni >= tx || nj >= ty || nk >= tz) {
+                    inactive = inactive || face;  // past the grid: EXTERIOR
+                    continue;
+                }
+                const unsigned b = bits[(nk * ty + nj) * tx + ni];
+                seed = seed || (b & 1u);
+                inactive = inactive || (face && (b & 2u));
+            }
+    flags[t] = (seed || ((bits[t] & 4u) && inactive)) ? 1 : 0;
+}
+
 // ---- band list (Ops.cpp:165-469) -------------------------------------------------------------------------------------
 
 // One workgroup per 16^3 tile: the BOUNDARY cells of the tile and its halo of width-1 cells seed width-1 rings grown
@@ -199,7 +271,7 @@ __global__ __launch_bounds__(kScanThreads) void scanDownKernel(const int32_t *__
 // six active neighbours, Ops.h:1771-1870).
 __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__restrict__ lab, int width, int tx, int ty, uint32_t *__restrict__ mask,
                                                       uint16_t *__restrict__ prefix, int32_t *__restrict__ tileCount, int32_t *__restrict__ tileKind,
-                                                      int *__restrict__ interiorBad)
+                                                      int *__restrict__ interiorBad, const int32_t *__restrict__ tiles)
 {
     extern __shared__ uint8_t sm[];
     const int halo = max(width - 1, 1), E = kTile + 2 * halo, E2 = E * E, E3 = E2 * E;
@@ -208,7 +280,7 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
     __shared__ int wordCount[128];
     __shared__ int sSeeds, sActive, sInterior;
     const int tid = threadIdx.x;
-    const int t = blockIdx.x, ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    const int t = tiles ? tiles[blockIdx.x] : int(blockIdx.x), ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
     const int oi = ti * kTile - halo, oj = tj * kTile - halo, ok = tk * kTile - halo;
     if (tid == 0) sSeeds = sActive = sInterior = 0;
     __syncthreads();
@@ -307,7 +379,7 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
         prefix[size_t(t) * 128 + tid] = uint16_t(before);
         if (tid == 127) {
             tileCount[t] = before + wordCount[127];
-            tileKind[t] = (sActive << 1) | (sInterior == kTile * kTile * kTile ? 1 : 0);
+            if (!tiles) tileKind[t] = (sActive << 1) | (sInterior == kTile * kTile * kTile ? 1 : 0);  // (with a list: tileStatsKernel's)
         }
     }
 }
@@ -846,14 +918,29 @@ int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n,
     return int(hipGetLastError());
 }
 
+// tileKind and tileBits of every tile, then flags / rank / list: the tiles that go through the band kernel (rank[nt] = count)
+int launchBandCandidates(void *stream, const Dims &d, const uint8_t *lab, int32_t *tileKind, uint8_t *tileBits, int32_t *flags, int32_t *rank,
+                         int32_t *list, int32_t *scanScratch)
+{
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile, nt = tx * ty * tz;
+    tileStatsKernel<<<unsigned(ty * tz), 64, 0, S(stream)>>>(d, lab, tx, ty, tileKind, tileBits);
+    tileCandidateKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(tx, ty, tz, tileBits, flags);
+    const int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
+    if (e != 0) return e;
+    tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
+    return int(hipGetLastError());
+}
+// tiles == nullptr: every tile (and the kernel fills tileKind); else the ntiles listed ones -- mask / prefix / tileCount of
+// the others must have been zeroed, their tileKind set by launchBandCandidates
 int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
-                    int *interiorBad)
+                    int *interiorBad, const int32_t *tiles, int ntiles)
 {
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     if (width < 1 || width > 8) return int(hipErrorInvalidValue);
     const int E = kTile + 2 * std::max(width - 1, 1);
     const size_t lds = 2 * size_t(E) * E * E;
-    bandMaskKernel<<<unsigned(tx * ty * tz), 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind, interiorBad);
+    const unsigned nb = tiles ? unsigned(ntiles) : unsigned(tx * ty * tz);
+    if (nb > 0) bandMaskKernel<<<nb, 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind, interiorBad, tiles);
     return int(hipGetLastError());
 }
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band)

@@ -1837,6 +1837,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
         int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
         int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr;
+        uint8_t *tileBits = nullptr;
         int *runCounts = nullptr;
         int32_t *listCounts = nullptr;  // pure even / odd, mixed even / odd tiles, plane blocks
         int runCells = 0, listLen = 0;
@@ -1857,11 +1858,24 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         ODS_TRY(tmp.get(h, &t.tileKind, size_t(t.nt)));
         ODS_TRY(tmp.get(h, &t.tileStart, size_t(t.nt) + 1));
         ODS_TRY(tmp.get(h, &t.scan, scanScratchInts(L.d.cells())));
-        ODS_LAUNCH(launchBandMasks(nullptr, L.d, labOf(l), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind, l == 0 ? flags + 2 * mgLevels : nullptr));
-        ODS_LAUNCH(launchExclusiveScan(nullptr, t.tileCount, t.tileStart, size_t(t.nt), t.scan));
         ODS_TRY(tmp.get(h, &t.tileFlags, size_t(t.nt)));
         ODS_TRY(tmp.get(h, &t.tileRank, size_t(t.nt) + 1));
         ODS_TRY(tmp.get(h, &t.bandTiles, size_t(t.nt)));
+        ODS_TRY(tmp.get(h, &t.tileBits, size_t(t.nt)));
+        // which tiles can hold band cells at all: a streaming pass over the labels; the band kernel then runs on those only
+        ODS_HIP(hipMemsetAsync(t.mask, 0, size_t(t.nt) * 128 * sizeof(uint32_t), nullptr));
+        ODS_HIP(hipMemsetAsync(t.prefix, 0, size_t(t.nt) * 128 * sizeof(uint16_t), nullptr));
+        ODS_HIP(hipMemsetAsync(t.tileCount, 0, size_t(t.nt) * sizeof(int32_t), nullptr));
+        ODS_LAUNCH(launchBandCandidates(nullptr, L.d, labOf(l), t.tileKind, t.tileBits, t.tileFlags, t.tileRank, t.bandTiles, t.scan));
+    }
+    for (int l = 0; l < levels; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        LevelTmp &t = T[size_t(l)];
+        int ncand = 0;
+        ODS_HIP(hipMemcpy(&ncand, t.tileRank + t.nt, sizeof(int), hipMemcpyDeviceToHost));
+        ODS_LAUNCH(launchBandMasks(nullptr, L.d, labOf(l), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind, l == 0 ? flags + 2 * mgLevels : nullptr,
+                                   t.bandTiles, ncand));
+        ODS_LAUNCH(launchExclusiveScan(nullptr, t.tileCount, t.tileStart, size_t(t.nt), t.scan));
         ODS_LAUNCH(launchBandTileList(nullptr, t.tileStart, t.nt, t.tileFlags, t.tileRank, t.bandTiles, t.scan));
     }
     for (int l = 0; l < levels; ++l) {
