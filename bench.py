@@ -216,8 +216,8 @@ def main():
     if args.workload == "free_surface_pcg":
         return free_surface_pcg(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
-        return self_launch(args)
+    if (args.gpus > 1 or args.force_slab) and world == 1 and "RANK" not in os.environ:
+        return self_launch(args)  # (--force-slab with one rank needs the rendezvous too: the RCCL transport is initialised through it)
     import numpy as np
     import torch
 
