@@ -460,6 +460,44 @@ void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg)
     runListFromFlags(L, folded.data(), nq, runCells);
 }
 
+// A cut level sends the planes next to its cuts to the neighbours after every full-domain sweep.  Its lists are walked edge
+// first -- the runs / plane blocks that touch the kSlabEdgePlanes planes at either end of the slab (the ghost exchange of a band
+// stage reads the band closure of that many planes), then the rest, each part in its launch order -- so that a sweep can be
+// launched in two parts with the exchange of the first under way while the second runs.  Order is free: same results.
+void edgeFirst(HostLevel &L)
+{
+    const Dims d = L.d;
+    const size_t plane = size_t(d.nx) * d.ny;
+    const int E = std::min(kSlabEdgePlanes, std::max(1, d.nz / 2));
+    {
+        const size_t cpr = size_t(L.chunkCells), perGroup = size_t(kChunkCells / L.chunkCells);
+        RawVec<int32_t> edge, rest;
+        for (int32_t q : L.chunks) {
+            if (q < 0) continue;  // padding
+            const size_t c0 = size_t(q) * cpr, c1 = std::min(d.cells(), c0 + cpr) - 1;
+            const int k0 = int(c0 / plane), k1 = int(c1 / plane);
+            (k0 < E || k1 >= d.nz - E ? edge : rest).push_back(q);
+        }
+        while (edge.size() % perGroup) edge.push_back(-1);
+        while (rest.size() % perGroup) rest.push_back(-1);
+        L.edgeChunks = int32_t(edge.size());
+        L.chunks.swap(edge);
+        L.chunks.insert(L.chunks.end(), rest.begin(), rest.end());
+    }
+    if (L.planeZc) {
+        const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows, nbz = (d.nz + L.planeZc - 1) / L.planeZc;
+        std::vector<int32_t> edge, rest;
+        for (int32_t b : L.planeBlocks) {
+            const int bz = b / (nbx * nby), k0 = bz * L.planeZc, k1 = std::min(d.nz, k0 + L.planeZc) - 1;
+            (void)nbz;
+            (k0 < E || k1 >= d.nz - E ? edge : rest).push_back(b);
+        }
+        L.edgePlaneBlocks = int32_t(edge.size());
+        L.planeBlocks.swap(edge);
+        L.planeBlocks.insert(L.planeBlocks.end(), rest.begin(), rest.end());
+    }
+}
+
 // Everything the device needs for the planes [z0, z1) of level G (the whole level when z0 = 0,
 // z1 = nz): local labels, band list, cell codes (with one ghost plane of plain labels on each side),
 // the operator rows of the general BOUNDARY cells and the Gauss-Seidel tile lists.
@@ -699,6 +737,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     lap.lap("slab level: band planes");
     listsJob.join();
     lap.lap("slab level: activity + tile lists (joined)");
+    if (!(z0 == 0 && z1 == gd.nz)) edgeFirst(L);
     buildTileBoundaryOffsets(L);
     const size_t nb = size_t(L.numBoundary);
     L.rows.assign(7 * nb, 0.f);

@@ -116,6 +116,8 @@ struct HostLevel {
     int chunkCells = kChunkCells;
     std::vector<int32_t> planeBlocks;
     int planeZc = 0;
+    // cut slab levels: the first edgeChunks / edgePlaneBlocks entries of the two lists touch the planes next to a cut (edgeFirst)
+    int32_t edgeChunks = 0, edgePlaneBlocks = 0;
     // 16^3 tiles holding active cells, split by Gauss-Seidel colour ((tx+ty+tz) odd / even) and by
     // kind: "pure" = all 4096 cells INTERIOR (no label or weight look-ups needed), "mixed" = the rest
     std::vector<int32_t> tilesOdd, tilesEven;          // all active tiles of the colour (API / tests)
@@ -253,6 +255,7 @@ struct MixScale {
 };
 
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
+constexpr int kSlabEdgePlanes = kBandMaxDepth + 1;  // planes at either end of a slab whose sweep goes first: the band closure a stage message carries reaches band_iterations planes in, its face neighbours one more
 // does the plane-marching sweep apply to a level of this shape, and with how many planes per block
 inline int planeSweepZc(int nx, int ny, int nz)
 {

@@ -57,6 +57,7 @@ struct DevLevel {
     int nbandPlane[4] = {0, 0, 0, 0};
     float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
+    int edgeChunks = 0, edgePlaneBlocks = 0;            // cut slab levels: the leading entries that touch the planes next to a cut
     BandGroupsDev bandGroups;  // fused band passes (levels that are not cut into slabs)
     // fused band stage of a cut level (SlabHalo): one exchange per stage
     struct Halo {
@@ -115,6 +116,11 @@ struct mgps_solver {
     // slab run
     bool dist = false;
     mgps_comm comm{};
+    // slab runs: the exchanges that follow a full-domain sweep run on their own stream while the sweep's interior part is
+    // still under way (edgeFirst in mgps_host.cpp); MGPS_OVERLAP=0 keeps everything on the solver's stream
+    hipStream_t commStream = nullptr;
+    hipEvent_t evEdge = nullptr, evComm = nullptr;
+    int64_t overlappedExchanges = 0;
     std::vector<int> splits;       // slab run: rank r owns the fine planes [splits[r], splits[r + 1])
     int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
     int totalLevels = 0;           // levels of the whole hierarchy
@@ -396,6 +402,9 @@ void freeAll(mgps_solver *h)
         gridFree(h->dinv, h->lv[0].d);
     }
     for (void *p : h->userGrids) (void)cacheFree(p);
+    if (h->evEdge) (void)hipEventDestroy(h->evEdge);
+    if (h->evComm) (void)hipEventDestroy(h->evComm);
+    if (h->commStream) (void)hipStreamDestroy(h->commStream);
     for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->stageEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
@@ -418,7 +427,8 @@ int checkLevel(mgps_solver *h, int level, const char *who)
 // `a` since its ghosts were last complete -- a band pass changes band cells only).
 enum GhostMode { GHOST_NONE = 0, GHOST_FULL = 1, GHOST_BAND = 2 };
 
-int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
+// on: the stream the transfer is queued on (nullptr: the solver's)
+int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL, hipStream_t on = nullptr)
 {
     if (!h->dist || mode == GHOST_NONE) return MGPS_OK;
     DevLevel &L = h->lv[l];
@@ -428,7 +438,7 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
         const size_t bytes = plane * sizeof(float);
         MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, bytes, lo ? a - plane : nullptr, bytes,
                                       hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, bytes,
-                                      hi ? a + size_t(L.d.nz) * plane : nullptr, bytes, h->stream));
+                                      hi ? a + size_t(L.d.nz) * plane : nullptr, bytes, on ? on : h->stream));
         return MGPS_OK;
     }
     const int *n = L.nbandPlane;
@@ -448,7 +458,7 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL)
 // The band stage of a cut level in one exchange (SlabHalo): ghost plane + band closure of the next planes,
 // x and rhs, in one message per neighbour; then every rank runs the fused stage over its band and the band
 // cells of its ghost planes.  Leaves the ghost planes of x complete.
-int bandStageDeep(mgps_solver *h, int l, float *x, const float *b)
+int bandStageDeep(mgps_solver *h, int l, float *x, const float *b, hipStream_t on = nullptr)
 {
     DevLevel &L = h->lv[l];
     DevLevel::Halo &H = L.halo;
@@ -471,10 +481,17 @@ int bandStageDeep(mgps_solver *h, int l, float *x, const float *b)
         rHi = HaloSide{H.recvBuf[1], ptrdiff_t(size_t(L.d.nz) * plane), nullptr, H.nrecv[1], L.bandPlane[3], nbp[3], H.hx + H.nrecv[0],
                        H.hb + H.nrecv[0]};
     }
-    MGPS_LAUNCH(h, launchHaloPack(h->stream, sLo, sHi, x, b, plane));
+    // the message (pack, transfer, unpack) on `on` -- the solver's stream, or the transfer stream of an overlapped sweep: then
+    // the fused stage on the solver's stream waits for it
+    hipStream_t cs = on ? on : h->stream;
+    MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane));
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
-                                  hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], h->stream));
-    MGPS_LAUNCH(h, launchHaloUnpack(h->stream, rLo, rHi, x, bw, plane));
+                                  hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], cs));
+    MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane));
+    if (on) {
+        MGPS_HIP(h, hipEventRecord(h->evComm, on));
+        MGPS_HIP(h, hipStreamWaitEvent(h->stream, h->evComm, 0));
+    }
     MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb,
                                    H.frows, L.nband, H.nForeign));
     return MGPS_OK;
@@ -488,10 +505,11 @@ bool bandStageCompletesGhosts(const mgps_solver *h, int l)
 
 // `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
 // dot (single-device runs only): the scatters append their corrections to h->dotPartials (see mgps_solver::gatherDot)
-int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first, bool dot = false)
+// afterSplitSweep: the sweep before was launched edge first (sweepSplit): the stage's message goes on the transfer stream
+int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first, bool dot = false, bool afterSplitSweep = false)
 {
     DevLevel &L = h->lv[l];
-    if (bandStageCompletesGhosts(h, l)) return bandStageDeep(h, l, x, b);
+    if (bandStageCompletesGhosts(h, l)) return bandStageDeep(h, l, x, b, afterSplitSweep ? h->commStream : nullptr);
     auto sink = [&]() -> double * {
         if (!dot || L.nband <= 0) return nullptr;
         double *p = h->dotPartials + h->dotUsed;
@@ -574,6 +592,41 @@ int profMark(mgps_solver *h, bool begin)
     return MGPS_OK;
 }
 
+// Overlap of a cut level's exchanges with its sweeps (slab runs): can the sweep of level l be launched edge first?
+bool sweepSplittable(const mgps_solver *h, int l)
+{
+    if (!h->dist || !h->commStream) return false;
+    const DevLevel &L = h->lv[l];
+    if (!L.g.ghostLo && !L.g.ghostHi) return false;
+    const int kernel = stencilKernelOf(L.g);
+    if (kernel == 2) return L.g.planeBlocks && L.edgePlaneBlocks > 0 && L.edgePlaneBlocks <= L.g.nplaneBlocks;
+    return kernel == 1 && L.g.chunks && L.edgeChunks > 0 && L.edgeChunks <= L.g.nchunks;
+}
+// The sweep in two launches: the runs / blocks that touch the planes next to a cut, then the rest.  The transfer stream
+// is made to wait for the first part only -- whoever queues the exchange there next gets it started while the second part
+// still runs.  (The general BOUNDARY cells are patched after each part: the patch reads the sweep's input, so repeating it
+// is harmless, and the main kernel of the second part would otherwise overwrite the first patch.)
+int sweepSplit(mgps_solver *h, int l, StencilOp op, float *out, const float *x, const float *b, float omega)
+{
+    DevLevel &L = h->lv[l];
+    GridP ge = L.g, gi = L.g;
+    if (stencilKernelOf(L.g) == 2) {
+        ge.nplaneBlocks = L.edgePlaneBlocks;
+        gi.planeBlocks = L.g.planeBlocks + L.edgePlaneBlocks;
+        gi.nplaneBlocks = L.g.nplaneBlocks - L.edgePlaneBlocks;
+    } else {
+        ge.nchunks = L.edgeChunks;
+        gi.chunks = L.g.chunks + L.edgeChunks;
+        gi.nchunks = L.g.nchunks - L.edgeChunks;
+    }
+    MGPS_LAUNCH(h, launchStencil(h->stream, op, ge, out, x, b, omega, true));
+    MGPS_HIP(h, hipEventRecord(h->evEdge, h->stream));
+    MGPS_HIP(h, hipStreamWaitEvent(h->commStream, h->evEdge, 0));
+    MGPS_LAUNCH(h, launchStencil(h->stream, op, gi, out, x, b, omega, true));
+    ++h->overlappedExchanges;  // (every caller queues exactly one exchange on the transfer stream next)
+    return MGPS_OK;
+}
+
 int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL, bool dot = false,
                 bool timed = false)
 {
@@ -610,6 +663,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
     const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
+    bool split = false;  // the last sweep went edge first: the band stage after it overlaps its message with the sweep's interior
     for (int rep = 0; rep < reps; ++rep) {
         StageScope scope(h, ST_SMOOTH, l);
         const GhostMode before = rep == 0 ? afterBands : GHOST_FULL;  // a sweep rewrote everything
@@ -625,7 +679,10 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         } else {
             MGPS_TRY(exchangeGhosts(h, l, cur, before));
             if (timed) MGPS_TRY(profMark(h, true));
-            if (d) {
+            if (!d && rep == reps - 1 && bands && bandStageCompletesGhosts(h, l) && sweepSplittable(h, l)) {
+                MGPS_TRY(sweepSplit(h, l, OP_JACOBI, other, cur, b, h->opt.jacobi_weight));
+                split = true;
+            } else if (d) {
                 unsigned used = 0;
                 MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
                 h->dotUsed += used;
@@ -637,7 +694,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         if (timed) ++h->profSweeps;
     }
     StageScope scope(h, ST_BAND, l);
-    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot));  // the full-domain smoother rewrote everything
+    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot, split));  // the full-domain smoother rewrote everything
     return MGPS_OK;
 }
 
@@ -733,15 +790,23 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
             }
+            bool rExchanged = false;
             {
                 StageScope scope(h, ST_RESIDUAL, l);
                 MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
                                                       : h->opt.band_iterations > 0 ? GHOST_BAND
                                                                                    : GHOST_FULL));
-                MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
+                if (sweepSplittable(h, l)) {  // the residual's edge planes travel while its interior is computed
+                    MGPS_TRY(sweepSplit(h, l, OP_RESIDUAL, F.r, cur[l], rhs, 0.f));
+                    MGPS_TRY(exchangeGhosts(h, l, F.r, GHOST_FULL, h->commStream));
+                    MGPS_HIP(h, hipEventRecord(h->evComm, h->commStream));
+                    MGPS_HIP(h, hipStreamWaitEvent(h->stream, h->evComm, 0));
+                    rExchanged = true;
+                } else
+                    MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
             }
             StageScope scope(h, ST_RESTRICT, l);
-            MGPS_TRY(exchangeGhosts(h, l, F.r));
+            if (!rExchanged) MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
         }
         DevLevel &B = h->lv[nsmooth];
@@ -1374,6 +1439,8 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
                 h->opt.stencil_path};
     L.g.planeZc = planeZcFor(h->opt, HL.planeZc, HL.planeBlocks.size(), HL.chunks.size(), HL.chunkCells);
     if (!L.g.planeZc) L.g.planeBlocks = nullptr;
+    L.edgeChunks = HL.edgeChunks;
+    L.edgePlaneBlocks = HL.edgePlaneBlocks;
     return MGPS_OK;
 }
 
@@ -2403,6 +2470,20 @@ try {
     h->device = device;
     h->dist = true;
     h->comm = *comm;
+    {
+        static const bool overlap = [] {  // MGPS_OVERLAP=0: every exchange on the solver's stream (A/B, debugging)
+            const char *e = getenv("MGPS_OVERLAP");
+            return !(e && e[0] == '0');
+        }();
+        if (overlap && P > 1 &&
+            (hipStreamCreateWithFlags(&h->commStream, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&h->evEdge, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&h->evComm, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (h->commStream) (void)hipStreamDestroy(h->commStream);
+            h->commStream = nullptr;  // (no overlap then)
+        }
+    }
     h->splits.assign(splits, splits + P + 1);
     h->distLevels = D;
     h->totalLevels = hier->levels;
@@ -2627,6 +2708,7 @@ try {
 }
 MGPS_API_CATCH(h)
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
+int64_t mgps_overlapped_exchanges(const mgps_solver *h) { return h ? h->overlappedExchanges : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
 try {

@@ -266,6 +266,11 @@ class SlabSolver(GeometricMultigridPoissonSolver):
     def distributed_levels(self):
         return lib().mgps_distributed_levels(self.h)
 
+    @property
+    def overlapped_exchanges(self):
+        lib().mgps_overlapped_exchanges.restype = C.c_int64
+        return lib().mgps_overlapped_exchanges(self.h)
+
     def slab_range(self, level=0):
         z0, z1 = C.c_int(), C.c_int()
         check(lib().mgps_slab_range(self.h, level, C.byref(z0), C.byref(z1)), self.h)

@@ -97,6 +97,11 @@ def gpu_mode():
             assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
+            # exchanges queued on the transfer stream beside the interior part of the sweep that made their planes
+            if os.environ.get("MGPS_OVERLAP") == "0":
+                assert slab.overlapped_exchanges == 0
+            elif rank == 0:  # (a slab without liquid -- the top of the scene -- has nothing to launch edge first)
+                assert slab.overlapped_exchanges > 0, (kind, use_gs, deep)
             if deep == 1:  # the CG vectors in fp64 (options.pcg_fp64_vectors): their ghost planes travel as doubles
                 o64 = G.default_options()
                 o64.min_cells_per_rank, o64.pcg_fp64_vectors = 0, 1

@@ -28,12 +28,12 @@ def free_port():
     return port
 
 
-def run_workers(mode, nproc, timeout):
+def run_workers(mode, nproc, timeout, extra_env=None):
     cmd = [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), mode,
     ]
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=env)
     ok = [f"WORKER_OK {r}" in res.stdout for r in range(nproc)]
     assert res.returncode == 0 and all(ok), res.stdout[-4000:]
@@ -69,6 +69,15 @@ def test_slabs_balanced_by_active_cells(nproc):
     """mgps_slab_partition + mgps_create_slab_ranges: slabs of different sizes (equal active cells instead of equal planes),
     the collapse through gatherv / scatterv; Jacobi with the library's cuts, Gauss-Seidel with the caller's own."""
     out = run_workers("balanced", nproc, 420)
+    print(out[-800:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["gpu", "plane"])
+def test_slabs_without_overlap(mode):
+    """MGPS_OVERLAP=0: every exchange on the solver's own stream (the default launches a cut level's sweeps edge first and
+    runs the exchange that follows on a transfer stream beside the interior part) -- same bits either way."""
+    out = run_workers(mode, 2, 420, {"MGPS_OVERLAP": "0"})
     print(out[-800:])
 
 
