@@ -116,8 +116,8 @@ struct mgps_solver {
     // slab run
     bool dist = false;
     mgps_comm comm{};
-    // slab runs: the exchanges that follow a full-domain sweep run on their own stream while the sweep's interior part is
-    // still under way (edgeFirst in mgps_host.cpp); MGPS_OVERLAP=0 keeps everything on the solver's stream
+    // slab runs, MGPS_OVERLAP=1: the exchanges that follow a full-domain sweep run on their own stream while the sweep's interior
+    // part is still under way (edgeFirst in mgps_host.cpp); otherwise everything stays on the solver's stream
     hipStream_t commStream = nullptr;
     hipEvent_t evEdge = nullptr, evComm = nullptr;
     int64_t overlappedExchanges = 0;
@@ -598,6 +598,13 @@ bool sweepSplittable(const mgps_solver *h, int l)
     if (!h->dist || !h->commStream) return false;
     const DevLevel &L = h->lv[l];
     if (!L.g.ghostLo && !L.g.ghostHi) return false;
+    // the two event hops of an overlapped exchange cost about 15 us each (measured with a null transport: +0.15 ms per cycle
+    // over nine of them at 1024^3 / 8 ranks); a plane below 1 MiB crosses a link in less
+    static const size_t minPlaneBytes = [] {
+        const char *e = getenv("MGPS_OVERLAP_MIN_PLANE_KB");  // (tests use 0: every cut level)
+        return size_t(e ? std::max(0, atoi(e)) : 1024) << 10;
+    }();
+    if (size_t(L.d.nx) * L.d.ny * sizeof(float) < minPlaneBytes) return false;
     const int kernel = stencilKernelOf(L.g);
     if (kernel == 2) return L.g.planeBlocks && L.edgePlaneBlocks > 0 && L.edgePlaneBlocks <= L.g.nplaneBlocks;
     return kernel == 1 && L.g.chunks && L.edgeChunks > 0 && L.edgeChunks <= L.g.nchunks;
@@ -2471,9 +2478,13 @@ try {
     h->dist = true;
     h->comm = *comm;
     {
-        static const bool overlap = [] {  // MGPS_OVERLAP=0: every exchange on the solver's stream (A/B, debugging)
+        // MGPS_OVERLAP=1: exchanges beside the sweeps (see sweepSplit).  Off by default: on one GPU with a null transport the
+        // split launches and the two event hops cost the slowest rank 0.07 ms of a 1.75 ms cycle at 1024^3 / 8 ranks (rank 0:
+        // 0.23 ms, its two half-size launches no longer fill the chip; 0.15-0.27 ms at 2 and 4 ranks), and what the overlap
+        // returns -- an estimated 0.3-0.6 ms of plane transfers per cycle -- can only be measured on real links.
+        static const bool overlap = [] {
             const char *e = getenv("MGPS_OVERLAP");
-            return !(e && e[0] == '0');
+            return e && e[0] == '1';
         }();
         if (overlap && P > 1 &&
             (hipStreamCreateWithFlags(&h->commStream, hipStreamNonBlocking) != hipSuccess ||

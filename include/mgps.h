@@ -391,7 +391,7 @@ int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, co
 int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1);
 int mgps_distributed_levels(const mgps_solver *h);
 /* slab runs: how many ghost exchanges so far were queued on the transfer stream, beside the interior part of the sweep that
- * produced their planes (0 on single-device solvers and with MGPS_OVERLAP=0) */
+ * produced their planes (MGPS_OVERLAP=1; 0 otherwise and on single-device solvers) */
 int64_t mgps_overlapped_exchanges(const mgps_solver *h);
 /* raw copies between host memory and device memory of the solver's device (used by transports
  * that stage through the host) */
