@@ -1738,9 +1738,10 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     // filled and the thread-per-cell kernel wins (coarse 128^3: 19 us against 51 us)
     const int kc = 16;
     const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8, nbz = (coarse.nz + kc - 1) / kc;
-    // (the march walks every coarse column; the per-cell kernel walks the coarse level's activity runs at 1.2 x the cost per
-    // cell: it takes over where those runs hold a small part of the level)
-    const bool runsWin = coarse.chunks && double(coarse.nchunks) * coarse.chunkCells * 1.2 * runCostFactor(coarse.chunkCells) < double(n);
+    // (the march walks every coarse column; the per-cell kernel walks the coarse level's activity runs at 1.3 x the cost per
+    // cell -- 1.13 vs 0.88 ms at 1024^3 -> 512^3, 0.14 vs 0.118 ms one level down: it takes over where those runs hold a
+    // clearly smaller part of the level.  On the cube they hold 76 %: the march stays)
+    const bool runsWin = coarse.chunks && double(coarse.nchunks) * coarse.chunkCells * 1.3 * runCostFactor(coarse.chunkCells) < 0.8 * double(n);
     if (!perCell && !runsWin && coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
         restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         return int(hipGetLastError());
@@ -1788,7 +1789,7 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
     // The block kernel (one thread = 16 fine cells that share their coarse rows) walks the whole grid; the quad kernel walks the
     // level's activity runs at 1.7 x the cost per cell (0.272 vs 0.162 ms on the full 512^3 cube).  Where the liquid fills a small
     // part of the grid -- a 480^3 simulation in the 1024^3 power-of-two expansion: 62 M of 1074 M cells in runs -- the runs win.
-    const bool runsWin = fine.chunks && double(fine.nchunks) * fine.chunkCells * 1.7 * runCostFactor(fine.chunkCells) < double(n);
+    const bool runsWin = fine.chunks && double(fine.nchunks) * fine.chunkCells * 1.7 * runCostFactor(fine.chunkCells) < 0.8 * double(n);  // (a clear win only)
     if (!perCell && !runsWin && (fine.nx & 3) == 0 && fine.nx >= 8 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.ny >= 4 && fine.nz >= 2) {
         const int npj = fine.ny / 2 - 1;  // row pairs (1,2) .. (ny-3, ny-2)
         const int kp0 = fine.ghostLo ? -1 : 0, kp1 = fine.ghostHi ? fine.nz / 2 - 1 : fine.nz / 2 - 2;
