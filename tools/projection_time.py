@@ -14,6 +14,7 @@ base = int(sys.argv[1]) if len(sys.argv) > 1 else 480
 gs = (sys.argv[2] if len(sys.argv) > 2 else "gs") == "gs"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 stats = len(sys.argv) > 4 and sys.argv[4] == "stats"  # options.print_stats
+tight = "tight" in sys.argv[4:]  # mgps_expanded_layout(power_of_two = 0) instead of the reference's power-of-two solver grid
 pinned = "pinned" in sys.argv[4:]  # every host array in page-locked memory (mgps_host_alloc), as the Houdini shim stages them
 t = time.time()
 sc = D.projection_scene((base, base, base))
@@ -53,7 +54,7 @@ for r in range(reps):
     import geometricmultigridpressuresolver_amd as G
     opt = G.default_options()
     opt.print_stats = int(stats)
-    _, info = F.project_free_surface(sc["liquid_phi"], sc["solid_phi"], sc["cut_weights"], vel, p, use_old_pressure=False, use_gauss_seidel=gs, options=opt)
+    _, info = F.project_free_surface(sc["liquid_phi"], sc["solid_phi"], sc["cut_weights"], vel, p, use_old_pressure=False, use_gauss_seidel=gs, power_of_two=not tight, options=opt)
     wall = (time.time() - t) * 1e3
     out.append({k: info[k] for k in ("iterations", "setup_ms", "solve_ms", "total_ms", "mg_levels", "expanded", "liquid_cells", "divergence_max")})
     out[-1]["python_wall_ms"] = wall
