@@ -752,15 +752,12 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
     }
 }
 
-template <bool DOT = false>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
-__global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
-                                                         const int32_t *__restrict__ tiles, int forward,
-                                                         double *__restrict__ dotPartials = nullptr)
+// one pure tile by one workgroup; slot: where its <x, b> goes (DOT)
+template <bool DOT>
+__device__ __forceinline__ void gsPureTile(const GridP &g, float *__restrict__ x, const float *__restrict__ b, int tile, int forward,
+                                           double *__restrict__ dotPartials, unsigned slot, float *sx, float *sb)
 {
-    __shared__ float sx[kHalo3];
-    __shared__ float sb[kTile3];
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
-    const int tile = tiles[blockIdx.x];
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
     gsLoadTile<false>(g, x, b, i0, j0, k0, sx, sb, nullptr);
     __syncthreads();
@@ -789,25 +786,27 @@ __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restr
             for (int e = 0; e < 4; ++e) acc += double(src[e]) * double(bq[e]);
         }
     }
-    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
+    if (DOT) blockDotStore(acc, dotPartials, slot);
 }
-
-template <bool DOT = false>
-__global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
-                                                          const int32_t *__restrict__ tiles,
-                                                          const int32_t *__restrict__ tileBndStart, int forward,
-                                                          double *__restrict__ dotPartials = nullptr)
+template <bool DOT = false>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
+__global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                         const int32_t *__restrict__ tiles, int forward,
+                                                         double *__restrict__ dotPartials = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
-    __shared__ unsigned char sl[kHalo3];
-    __shared__ float srow[7 * kRowPool];
-    __shared__ unsigned short rowMask[kTile * kTile];   // bit i set: cell (i, j, k) of x-row (j,k) is BOUNDARY
-    __shared__ unsigned short rowStart[kTile * kTile];  // BOUNDARY cells of the tile before that x-row
-    __shared__ int scanTmp[4];
+    gsPureTile<DOT>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb);
+}
 
+// one mixed tile by one workgroup (rowMask: bit i set = cell (i, j, k) of x-row (j, k) is BOUNDARY; rowStart: BOUNDARY cells of
+// the tile before that x-row)
+template <bool DOT>
+__device__ __forceinline__ void gsMixedTile(const GridP &g, float *__restrict__ x, const float *__restrict__ b, int tile,
+                                            const int32_t *__restrict__ tileBndStart, int forward, double *__restrict__ dotPartials,
+                                            unsigned slot, float *sx, float *sb, unsigned char *sl, float *srow, unsigned short *rowMask,
+                                            unsigned short *rowStart, int *scanTmp)
+{
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
-    const int tile = tiles[blockIdx.x];
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
     const int bndBase = tileBndStart[tile], bndCount = tileBndStart[tile + 1] - bndBase;
     const size_t nb = size_t(g.nbnd);
@@ -892,7 +891,44 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
                 if (activeLabel(lq[e])) acc += double(src[e]) * double(bq[e]);
         }
     }
-    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
+    if (DOT) blockDotStore(acc, dotPartials, slot);
+}
+template <bool DOT = false>
+__global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                          const int32_t *__restrict__ tiles,
+                                                          const int32_t *__restrict__ tileBndStart, int forward,
+                                                          double *__restrict__ dotPartials = nullptr)
+{
+    __shared__ float sx[kHalo3];
+    __shared__ float sb[kTile3];
+    __shared__ unsigned char sl[kHalo3];
+    __shared__ float srow[7 * kRowPool];
+    __shared__ unsigned short rowMask[kTile * kTile];
+    __shared__ unsigned short rowStart[kTile * kTile];
+    __shared__ int scanTmp[4];
+    gsMixedTile<DOT>(g, x, b, tiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp);
+}
+// Both lists of a colour in one launch: workgroups [0, nmixed) take the mixed tiles, the rest the pure ones.  For the small
+// levels, where a launch is a handful of workgroups and each tile a chain of 46 barrier steps (~10 us): the two launches of
+// a colour pass then cost two such chains back to back, this one costs one.  (Every workgroup reserves the mixed tile's 53 KB
+// of LDS, so large levels -- where three instead of four pure tiles per CU would cost 7 % -- keep the two launches.)
+template <bool DOT = false>
+__global__ __launch_bounds__(256) void tiledGSBothKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+                                                         const int32_t *__restrict__ mixedTiles, int nmixed,
+                                                         const int32_t *__restrict__ pureTiles, const int32_t *__restrict__ tileBndStart,
+                                                         int forward, double *__restrict__ dotPartials = nullptr)
+{
+    __shared__ float sx[kHalo3];
+    __shared__ float sb[kTile3];
+    __shared__ unsigned char sl[kHalo3];
+    __shared__ float srow[7 * kRowPool];
+    __shared__ unsigned short rowMask[kTile * kTile];
+    __shared__ unsigned short rowStart[kTile * kTile];
+    __shared__ int scanTmp[4];
+    if (int(blockIdx.x) < nmixed)
+        gsMixedTile<DOT>(g, x, b, mixedTiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp);
+    else
+        gsPureTile<DOT>(g, x, b, pureTiles[int(blockIdx.x) - nmixed], forward, dotPartials, blockIdx.x, sx, sb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1701,7 +1737,13 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // same colour => no two tiles of either launch share a face: the two launches are independent
+    // same colour => no two tiles of either launch share a face: the two launches are independent.  Up to three workgroups
+    // per CU they go as one launch (tiledGSBothKernel)
+    if (nmixed > 0 && npure > 0 && nmixed + npure <= 768) {
+        if (dotPartials) tiledGSBothKernel<true><<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward, dotPartials);
+        else tiledGSBothKernel<<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward);
+        return int(hipGetLastError());
+    }
     if (dotPartials) {
         if (nmixed > 0) tiledGSMixedKernel<true><<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, dotPartials);
         if (npure > 0) tiledGSPureKernel<true><<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, dotPartials + nmixed);
