@@ -960,3 +960,28 @@ def test_config3_512_free_surface_pcg(oracle, torch_cuda):
         assert st["rel_residual"] < 1e-5
         assert rel_l2(x, x_ref) < 1e-5, (fp64, rel_l2(x, x_ref))
         assert st["rel_residual_recomputed"] < (1e-5 if fp64 else 1e-2), (fp64, st)
+
+
+@pytest.mark.parametrize("gs", [False, True])
+def test_extents_not_multiples_of_four(gs, oracle, torch_cuda):
+    """nx = 66: no 16-byte quads, so the sweeps take the scalar kernel while the vector ops walk the activity runs of the
+    flat array (runs straddle rows); two V-cycles and an MG-PCG against the oracle."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    bl, bw, dx = D.build_complex_domain((32, 36, 58), use_solid=True, dtype=np.float32)
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=2, solver_shape=(40, 44, 66))
+    s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)
+    assert s.stencil_kernel(0) == "scalar"
+    ref = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, gs)
+    b = _rand_active(lab, 3, dx * dx)
+    x_ref = np.zeros(lab.shape)
+    xd, bd = s.new_grid(), s.to_device(b)
+    b64 = bd.cpu().numpy().astype(np.float64)
+    for it in range(2):
+        ref.apply_vcycle(x_ref, b64, it > 0)
+        s.applyVCycle(xd, bd, it > 0)
+        assert rel_l2(xd.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1)
+    st = s.solveGeometricConjugateGradient(s.new_grid(), bd, 1e-6, 200, True)
+    assert st["outcome"] == "converged"
+    s.close()
