@@ -122,6 +122,23 @@ def test_errors_match_host_builder():
         assert "EXTERIOR" in str(e.value) or "divisible" in str(e.value), (host, str(e.value))
 
 
+def test_coarse_level_too_large_on_both_builders():
+    """two levels of a 96^3 box leave > 8192 unknowns on the coarsest level: the direct solver refuses, with the same text"""
+    lab, w, off, lev, dx = make_domain("simple", 64, levels=2)
+    msgs = []
+    for host in (1, 0):
+        o = G.default_options()
+        o.host_setup = host
+        with pytest.raises(G.MgpsError) as e:
+            G.GeometricMultigridPoissonSolver(lab, w, 2, False, options=o)
+        msgs.append(str(e.value))
+        assert "coarsest level has" in msgs[-1], msgs[-1]
+    assert msgs[0] == msgs[1]
+    # and nothing was left behind: the next solver builds
+    lab, w, off, lev, dx = make_domain("simple", 32)
+    G.GeometricMultigridPoissonSolver(lab, w, lev, False).close()
+
+
 def test_level_cap_quirk_on_device():
     """MG.cpp:241-246: the level count drops to l - 1 at the first level without a solvable cell -- same on both builders"""
     n = 64
