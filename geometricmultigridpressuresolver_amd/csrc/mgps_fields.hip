@@ -599,7 +599,9 @@ try {
     p->expanded[0] = ex;
     p->expanded[1] = ey;
     p->expanded[2] = ez;
-    // liquid cell count first: a domain without liquid has nothing to solve (Plug.cpp:270-282 returns there)
+    // liquid cell count first: a domain without liquid has nothing to solve.  (The reference has no such exit: it would run
+    // its solver on an empty system.  What it would publish -- the valid faces it computed and an all-zero pressure,
+    // Plug.cpp:286, 641 -- is published here as well; velocities stay as they came.)
     double div[3] = {0, 0, 0};
     {
         unsigned long long *count = pool.get<unsigned long long>(1), liquid = 0;
@@ -615,6 +617,12 @@ try {
     std::memset(&p->stats, 0, sizeof(p->stats));
     p->residual_inf = p->residual_l2 = p->divergence_sum = p->divergence_max = 0;
     if (div[2] == 0) {
+        if (copy.s && (he = hipStreamSynchronize(copy.s)) != hipSuccess) return failHip("upload", he);
+        if ((he = hipMemsetAsync(pressure, 0, cells * sizeof(float), s)) != hipSuccess) return failHip("pressure clear", he);
+        download(p->pressure, pressure, cells);
+        for (int a = 0; a < 3; ++a)
+            if (p->valid_faces[a] && he == hipSuccess) he = hipMemcpy(p->valid_faces[a], valid[a], faceCount(gx, gy, gz, a), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) return failHip("download", he);
         p->setup_ms = p->total_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
         p->solve_ms = 0;
         p->stats.outcome = MGPS_PCG_RHS_ZERO;
@@ -655,7 +663,10 @@ try {
     const int solveRc = rc;
     (void)hipDeviceSynchronize();
     const auto t2 = clock::now();
-    // Plug.cpp:644-707
+    // Plug.cpp:641-707: the pressure field is cleared before the solution is written into the liquid cells (`makeConstant(0)`,
+    // Plug.cpp:641) -- the warm start above has consumed the caller's old values; a cell that was liquid in the last sub-step and
+    // is air or solid now must not keep its old pressure (the gradient pass reads it across ghost-fluid faces)
+    if ((he = hipMemsetAsync(pressure, 0, cells * sizeof(float), s)) != hipSuccess) return failHip("pressure clear", he);
     PROJ_TRY(mgps_fields_solution_to_pressure(pressure, x, material, gx, gy, gz, ex, ey, ez, offset, s));
     for (int a = 0; a < 3; ++a) PROJ_TRY(mgps_fields_pressure_gradient(a, vel[a], phi, pressure, valid[a], material, gx, gy, gz, s));
     PROJ_TRY(mgps_fields_divergence(div, material, vel[0], vel[1], vel[2], svel[0], svel[1], svel[2], cw[0], cw[1], cw[2], gx, gy, gz, s));

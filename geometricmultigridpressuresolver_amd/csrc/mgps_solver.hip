@@ -200,17 +200,39 @@ int failH(mgps_solver *h, int code, const std::string &msg)
 // 1024^3 grid holds ~45 GiB in ~300 blocks, and a plugin that rebuilds it every sub-step (Plug.cpp:463) would pay more for
 // memory than for the solve.  Released blocks are therefore kept, per device, and handed to the next solver (sizes are
 // rounded up by at most 1/8 so that lists whose length moves with the liquid find their block again); the cap is
-// MGPS_DEVICE_CACHE_MB (default 98304 of the 288 GiB), mgps_trim_device_cache returns everything, and an allocation that
-// fails trims the cache and tries again.
+// MGPS_DEVICE_CACHE_MB (default: a quarter of the device's memory), the oldest blocks leave first once it is reached,
+// mgps_trim_device_cache returns everything, and an allocation that fails trims the cache and tries again.
 struct DeviceCache {
+    struct Block {
+        void *p;
+        uint64_t age;  // release order: the oldest cached block is the first to go when the cap is reached
+    };
     std::mutex guard;
-    std::multimap<std::pair<int, size_t>, void *> free;          // (device, bytes) -> block not in use
+    std::multimap<std::pair<int, size_t>, Block> free;           // (device, bytes) -> block not in use
+    std::map<uint64_t, std::multimap<std::pair<int, size_t>, Block>::iterator> byAge;
     std::unordered_map<void *, std::pair<int, size_t>> live;     // every block of the library, in use or cached
     size_t cached = 0;
-    size_t cap = [] {
-        const char *e = getenv("MGPS_DEVICE_CACHE_MB");
-        return size_t(e ? std::max(0, atoi(e)) : 98304) << 20;
-    }();
+    uint64_t clock = 0;
+    // cap: MGPS_DEVICE_CACHE_MB, else a quarter of the device's memory (72 of 288 GiB: a 1024^3 solver holds ~45 GiB, so the
+    // plugin's solver-per-sub-step pattern still finds all of its blocks again) -- the rest stays with whoever else
+    // allocates in the process (torch, RCCL, Houdini's own GPU users)
+    size_t cap = 0;
+    bool capKnown = false;
+    void findCap()
+    {
+        if (capKnown) return;
+        capKnown = true;
+        if (const char *e = getenv("MGPS_DEVICE_CACHE_MB")) {
+            cap = size_t(std::max(0, atoi(e))) << 20;
+            return;
+        }
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) cap = totalB / 4;
+        else {
+            (void)hipGetLastError();
+            cap = size_t(16) << 30;
+        }
+    }
 };
 DeviceCache &deviceCache()
 {
@@ -228,10 +250,11 @@ size_t deviceRounded(size_t bytes)
 void deviceTrimLocked(DeviceCache &c, std::vector<void *> &drop)
 {
     for (auto &b : c.free) {
-        drop.push_back(b.second);
-        c.live.erase(b.second);
+        drop.push_back(b.second.p);
+        c.live.erase(b.second.p);
     }
     c.free.clear();
+    c.byAge.clear();
     c.cached = 0;
 }
 }  // namespace
@@ -246,8 +269,9 @@ int deviceAlloc(void **p, size_t bytes)
         std::lock_guard<std::mutex> lock(c.guard);
         const auto it = c.free.find({dev, want});
         if (it != c.free.end()) {
-            *p = it->second;
+            *p = it->second.p;
             c.cached -= want;
+            c.byAge.erase(it->second.age);
             c.free.erase(it);
             return hipSuccess;
         }
@@ -269,23 +293,41 @@ int deviceAlloc(void **p, size_t bytes)
     return hipSuccess;
 }
 // (unlike hipFree this does not wait for the device: callers release only what no queued kernel touches any more)
+// A block larger than the cap goes straight back to the driver; otherwise it is kept and the OLDEST cached blocks are
+// returned until the cache fits its cap again (sizes nobody asks for any more age out instead of pinning the cache full).
 int deviceFree(void *p)
 {
     if (!p) return hipSuccess;
     DeviceCache &c = deviceCache();
+    std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lock(c.guard);
+        c.findCap();
         const auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            if (c.cached + it->second.second <= c.cap) {
-                c.free.emplace(it->second, p);
-                c.cached += it->second.second;
-                return hipSuccess;
-            }
+        if (it == c.live.end()) drop.push_back(p);  // (not ours: plain hipFree)
+        else if (it->second.second > c.cap) {
             c.live.erase(it);
+            drop.push_back(p);
+        } else {
+            const uint64_t age = c.clock++;
+            c.byAge[age] = c.free.emplace(it->second, DeviceCache::Block{p, age});
+            c.cached += it->second.second;
+            while (c.cached > c.cap && !c.byAge.empty()) {
+                const auto oldest = c.byAge.begin()->second;
+                drop.push_back(oldest->second.p);
+                c.cached -= oldest->first.second;
+                c.live.erase(oldest->second.p);
+                c.free.erase(oldest);
+                c.byAge.erase(c.byAge.begin());
+            }
         }
     }
-    return int(hipFree(p));
+    hipError_t e = hipSuccess;
+    for (void *b : drop) {
+        const hipError_t eb = hipFree(b);
+        if (eb != hipSuccess) e = eb;
+    }
+    return int(e);
 }
 void deviceTrim()
 {

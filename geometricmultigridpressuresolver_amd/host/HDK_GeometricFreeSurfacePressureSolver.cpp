@@ -259,12 +259,10 @@ bool HDK_GeometricFreeSurfacePressureSolver::solveGasSubclass(SIM_Engine &, SIM_
         addError(obj, SIM_MESSAGE, mgps_last_error(nullptr), rc == MGPS_ERR_INTERRUPTED ? UT_ERROR_WARNING : UT_ERROR_ABORT);
         return false;
     }
-    if (job.liquid_cells == 0) {
-        addError(obj, SIM_MESSAGE, "No liquid cells found", UT_ERROR_WARNING);
-        return false;
-    }
+    // (no liquid cells: nothing was solved; like the reference, the valid faces and an all-zero pressure are still published below)
+    if (job.liquid_cells == 0) addError(obj, SIM_MESSAGE, "No liquid cells found", UT_ERROR_WARNING);
     // the reference's printouts (CG.h:198-206, Plug.cpp:625-628, 704-706)
-    std::cout << "  MG levels: " << job.mg_levels << ", solver grid " << job.expanded[0] << " x " << job.expanded[1] << " x " << job.expanded[2]
+    else std::cout << "  MG levels: " << job.mg_levels << ", solver grid " << job.expanded[0] << " x " << job.expanded[1] << " x " << job.expanded[2]
               << "\n  Iterations: " << job.stats.iterations << "\n  Drifted relative L2 Error: " << job.stats.rel_residual
               << "\n  Recomputed relative L2 Error: " << job.stats.rel_residual_recomputed << "\n  L-infinity error: " << job.residual_inf
               << "\n  L-2 error: " << job.residual_l2 << "\n  Max divergence: " << job.divergence_max

@@ -225,7 +225,7 @@ void mgps_destroy(mgps_solver *h);
 void mgps_trim_host_cache(void);
 /* Device memory released by a solver (or by mgps_project_free_surface) is kept for the next one: once a process holds
  * tens of GiB, hipMalloc costs 60-130 ms per 4 GiB block and every hipFree 0.2 ms on this platform, more than the solve
- * (cap: MGPS_DEVICE_CACHE_MB, default 98304; an allocation that fails trims the cache and tries again).  This returns
+ * (cap: MGPS_DEVICE_CACHE_MB, default a quarter of the device memory, oldest blocks leave first; an allocation that fails trims the cache and tries again).  This returns
  * the cached blocks to the system, e.g. before another library needs the memory. */
 void mgps_trim_device_cache(void);
 /* Page-locked host memory for the caller's staging buffers (the flattened fields a Houdini shim uploads every

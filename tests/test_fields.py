@@ -321,3 +321,60 @@ def test_one_call_projection_matches_the_pass_by_pass_pipeline(dtype):
     _, info2 = F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel2, p_h.copy(),
                                       [h(a) for a in sc["solid_velocity"]], use_old_pressure=True, tolerance=1e-5, max_iterations=200)
     assert info2["iterations"] == 0 and info2["outcome"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_old", [False, True])
+def test_projection_clears_stale_pressure_outside_the_liquid(use_old):
+    """The reference clears the pressure field before it writes the solution into the liquid cells (`makeConstant(0)`,
+    Plug.cpp:641): a cell that was liquid in the last sub-step and is air or solid now must not keep its old value, which the
+    gradient pass would read across ghost-fluid faces.  Garbage outside the liquid in the incoming pressure changes nothing."""
+    import torch
+
+    from geometricmultigridpressuresolver_amd import fields as F
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=True)
+    h = lambda a: np.array(a, dtype=np.float32, order="C", copy=True)  # noqa: E731
+    material = F.buildMaterialCellLabels(_dev(sc["liquid_phi"], torch), _dev(sc["solid_phi"], torch), [_dev(a, torch) for a in sc["cut_weights"]]).cpu().numpy()
+    liquid = material == 1
+    assert liquid.any() and (~liquid).any()
+
+    def run(p0):
+        vel = [h(a) for a in sc["velocity"]]
+        p = p0.copy()
+        valid, info = F.project_free_surface(h(sc["liquid_phi"]), h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel, p,
+                                             [h(a) for a in sc["solid_velocity"]], use_old_pressure=use_old, tolerance=1e-6, max_iterations=200)
+        return vel, p, info
+
+    clean = np.zeros(SHAPE, dtype=np.float32)
+    if use_old:  # a warm start that means something inside the liquid
+        clean[liquid] = np.random.default_rng(5).standard_normal(int(liquid.sum())).astype(np.float32) * 1e-3
+    dirty = clean.copy()
+    dirty[~liquid] = np.random.default_rng(6).standard_normal(int((~liquid).sum())).astype(np.float32) * 1e3
+    vel_c, p_c, info_c = run(clean)
+    vel_d, p_d, info_d = run(dirty)
+    assert (p_d[~liquid] == 0).all() and (p_c[~liquid] == 0).all()
+    assert info_c["iterations"] == info_d["iterations"]
+    assert np.array_equal(p_c, p_d)
+    for a in range(3):
+        assert np.array_equal(vel_c[a], vel_d[a])
+
+
+@pytest.mark.gpu
+def test_projection_without_liquid_publishes_valid_faces_and_zero_pressure():
+    """No liquid cell: nothing to solve, but what the reference would publish is still published -- the valid faces it built
+    (Plug.cpp:286) and an all-zero pressure (Plug.cpp:641); velocities stay as they came."""
+    from geometricmultigridpressuresolver_amd import fields as F
+
+    sc = D.projection_scene(SHAPE, with_solid_velocity=False)
+    h = lambda a: np.array(a, dtype=np.float32, order="C", copy=True)  # noqa: E731
+    phi = np.full(SHAPE, 1.0, dtype=np.float32)  # air everywhere
+    vel = [h(a) for a in sc["velocity"]]
+    vel0 = [a.copy() for a in vel]
+    p = np.full(SHAPE, 7.0, dtype=np.float32)
+    valid, info = F.project_free_surface(phi, h(sc["solid_phi"]), [h(a) for a in sc["cut_weights"]], vel, p, None, use_old_pressure=True,
+                                         tolerance=1e-6, max_iterations=200)
+    assert info["liquid_cells"] == 0 and info["iterations"] == 0
+    assert (p == 0).all()
+    for a in range(3):
+        assert np.array_equal(vel[a], vel0[a]) and (valid[a] == 0).all()
