@@ -1088,6 +1088,244 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
     buildGroupsOverWindow(W, depth, out);
 }
 
+#define MGPS_TRY_RC(call)            \
+    do {                              \
+        const int rc_ = (call);       \
+        if (rc_ != MGPS_OK) return rc_; \
+    } while (0)
+
+// ---- fused band stage, box form (BandBoxes in mgps_internal.h): host builder ----------------------------------------
+// Per 16^3 tile (the tiles that can hold a closure cell: a band cell in the tile or in a face neighbour), a window of the
+// tile grown by depth + 2 cells holds per cell: active, band member, band entry.  A stack of sub-boxes of the tile is walked
+// left half first: O = bounding box of the sub-box's closure cells (band cells and active cells next to one); every cell of
+// O grown by depth + 1 is classified (see BandBoxes), R = bounding box of the classes != 0; a group whose R exceeds the
+// workgroup budget is halved along O's longest axis.  The device builder (bandBoxKernel, mgps_setup.hip) walks the same
+// recursion and fills the same arrays.
+namespace {
+
+struct BoxTileOut {
+    std::vector<int32_t> info, general;
+    std::vector<uint8_t> codes;
+};
+
+}  // namespace
+
+void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
+{
+    out = BandBoxes();
+    out.depth = depth;
+    if (depth < 1 || depth > kBandMaxDepth || L.band.empty()) return;
+    const Dims d = L.d;
+    const uint8_t *lab = L.ownedLabels ? L.ownedLabels : L.labels.data();
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
+    const int64_t nt = int64_t(tx) * ty * tz;
+    const int P = depth + 2, E = kTile + 2 * P, E2 = E * E, E3 = E2 * E, D = depth;
+    std::vector<BoxTileOut> tiles{size_t(nt)};
+    std::atomic<bool> broken{false};
+    const int32_t *tstart = L.bandTileStart.data();
+    parallelFor(nt, [&](int64_t t0, int64_t t1) {
+        std::vector<uint8_t> fl(static_cast<size_t>(E3), 0), cls(static_cast<size_t>(E3), 0);
+        std::vector<int32_t> ent(static_cast<size_t>(E3), 0);
+        for (int64_t t = t0; t < t1; ++t) {
+            const int ti = int(t % tx), tj = int((t / tx) % ty), tk = int(t / (int64_t(tx) * ty));
+            auto hasBand = [&](int a, int b, int c) {
+                if (a < 0 || b < 0 || c < 0 || a >= tx || b >= ty || c >= tz) return false;
+                const size_t q = (size_t(c) * ty + b) * tx + a;
+                return tstart[q + 1] > tstart[q];
+            };
+            if (!(hasBand(ti, tj, tk) || hasBand(ti - 1, tj, tk) || hasBand(ti + 1, tj, tk) || hasBand(ti, tj - 1, tk) || hasBand(ti, tj + 1, tk) ||
+                  hasBand(ti, tj, tk - 1) || hasBand(ti, tj, tk + 1)))
+                continue;
+            const int oi = ti * kTile - P, oj = tj * kTile - P, ok = tk * kTile - P;  // grid cell of window cell (0, 0, 0)
+            // window flags: bit 0 active, bit 1 band; ent = band entry (device order) of a band cell
+            for (int wk = 0; wk < E; ++wk)
+                for (int wj = 0; wj < E; ++wj) {
+                    const int gj = oj + wj, gk = ok + wk;
+                    const bool rowIn = gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz;
+                    for (int wi = 0; wi < E; ++wi) {
+                        const int gi = oi + wi;
+                        fl[size_t((wk * E + wj) * E + wi)] = (rowIn && gi >= 0 && gi < d.nx && isActive(lab[d.idx(gi, gj, gk)])) ? 1 : 0;
+                    }
+                }
+            for (int c = tk - 1; c <= tk + 1; ++c)
+                for (int b = tj - 1; b <= tj + 1; ++b)
+                    for (int a = ti - 1; a <= ti + 1; ++a) {
+                        if (a < 0 || b < 0 || c < 0 || a >= tx || b >= ty || c >= tz) continue;
+                        const size_t q = (size_t(c) * ty + b) * tx + a;
+                        for (int32_t s = tstart[q]; s < tstart[q + 1]; ++s) {
+                            const int32_t cell = L.band[size_t(s)];
+                            const int wi = cell % d.nx - oi, wj = (cell / d.nx) % d.ny - oj, wk = cell / (d.nx * d.ny) - ok;
+                            if (wi < 0 || wj < 0 || wk < 0 || wi >= E || wj >= E || wk >= E) continue;
+                            const size_t w = size_t((wk * E + wj) * E + wi);
+                            fl[w] |= 2;
+                            ent[w] = L.bandEntry[size_t(s)];
+                        }
+                    }
+            const int off[6] = {-1, 1, -E, E, -E2, E2};
+            auto closureCell = [&](int w) {  // band cell, or active cell with a band face neighbour (w not on the window's rim)
+                if (fl[size_t(w)] & 2) return true;
+                if (!(fl[size_t(w)] & 1)) return false;
+                for (int q = 0; q < 6; ++q)
+                    if (fl[size_t(w + off[q])] & 2) return true;
+                return false;
+            };
+            struct Box {
+                int lo[3], hi[3];
+            };
+            std::vector<Box> stack;
+            stack.push_back(Box{{0, 0, 0}, {kTile - 1, kTile - 1, kTile - 1}});
+            BoxTileOut &T = tiles[size_t(t)];
+            while (!stack.empty()) {
+                const Box B = stack.back();
+                stack.pop_back();
+                int lo[3] = {99, 99, 99}, hi[3] = {-1, -1, -1};
+                for (int lk = B.lo[2]; lk <= B.hi[2]; ++lk)
+                    for (int lj = B.lo[1]; lj <= B.hi[1]; ++lj)
+                        for (int li = B.lo[0]; li <= B.hi[0]; ++li) {
+                            if (!closureCell(((lk + P) * E + lj + P) * E + li + P)) continue;
+                            const int v[3] = {li, lj, lk};
+                            for (int a = 0; a < 3; ++a) {
+                                lo[a] = std::min(lo[a], v[a]);
+                                hi[a] = std::max(hi[a], v[a]);
+                            }
+                        }
+                if (hi[0] < 0) continue;
+                // window coordinates of O and of O grown by depth + 1
+                const int olo[3] = {lo[0] + P, lo[1] + P, lo[2] + P}, ohi[3] = {hi[0] + P, hi[1] + P, hi[2] + P};
+                const int mlo[3] = {olo[0] - (D + 1), olo[1] - (D + 1), olo[2] - (D + 1)}, mhi[3] = {ohi[0] + D + 1, ohi[1] + D + 1, ohi[2] + D + 1};
+                auto ringOf = [&](int wi, int wj, int wk) {
+                    const int v[3] = {wi, wj, wk};
+                    int r = 0;
+                    for (int a = 0; a < 3; ++a) r = std::max(r, std::max(olo[a] - v[a], v[a] - ohi[a]));
+                    return r;
+                };
+                const int dI[6] = {-1, 1, 0, 0, 0, 0}, dJ[6] = {0, 0, -1, 1, 0, 0}, dK[6] = {0, 0, 0, 0, -1, 1};
+                for (int wk = mlo[2]; wk <= mhi[2]; ++wk)
+                    for (int wj = mlo[1]; wj <= mhi[1]; ++wj)
+                        for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                            const int w = (wk * E + wj) * E + wi;
+                            const uint8_t f = fl[size_t(w)];
+                            uint8_t c = kBoxSkip;
+                            if (f & 2) c = kBoxGeneral;  // band cell (its code is looked up when the group is written)
+                            else {
+                                int best = 99;  // smallest ring among the band face neighbours
+                                for (int q = 0; q < 6; ++q)
+                                    if (fl[size_t(w + off[q])] & 2) best = std::min(best, ringOf(wi + dI[q], wj + dJ[q], wk + dK[q]));
+                                if (f & 1) {
+                                    if (best < 99 && ringOf(wi, wj, wk) == 0) c = kBoxFrozenOut;
+                                    else if (best <= D - 1) c = kBoxFrozen;
+                                    else if (best <= D) c = kBoxFrozenFar;
+                                } else if (best <= D)
+                                    c = kBoxZero;
+                            }
+                            cls[size_t(w)] = c;
+                        }
+                // active cells next to a closure-output cell: read by the closure pass
+                for (int wk = mlo[2]; wk <= mhi[2]; ++wk)
+                    for (int wj = mlo[1]; wj <= mhi[1]; ++wj)
+                        for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                            const int w = (wk * E + wj) * E + wi;
+                            if (cls[size_t(w)] != kBoxSkip || !(fl[size_t(w)] & 1)) continue;
+                            for (int q = 0; q < 6; ++q) {
+                                const int ni = wi + dI[q], nj = wj + dJ[q], nk = wk + dK[q];
+                                if (ni < mlo[0] || ni > mhi[0] || nj < mlo[1] || nj > mhi[1] || nk < mlo[2] || nk > mhi[2]) continue;
+                                if (cls[size_t(w + off[q])] == kBoxFrozenOut) {
+                                    cls[size_t(w)] = kBoxFrozenFar;  // (only class 11 seeds: no cascade inside this sweep)
+                                    break;
+                                }
+                            }
+                        }
+                int rlo[3] = {99, 99, 99}, rhi[3] = {-1, -1, -1}, gen = 0;
+                for (int wk = mlo[2]; wk <= mhi[2]; ++wk)
+                    for (int wj = mlo[1]; wj <= mhi[1]; ++wj)
+                        for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                            const size_t w = size_t((wk * E + wj) * E + wi);
+                            if (cls[w] == kBoxSkip) continue;
+                            const int v[3] = {wi, wj, wk};
+                            for (int a = 0; a < 3; ++a) {
+                                rlo[a] = std::min(rlo[a], v[a]);
+                                rhi[a] = std::max(rhi[a], v[a]);
+                            }
+                            if ((fl[w] & 2) && L.bandDiag[size_t(ent[w])] == 0 && ringOf(wi, wj, wk) <= D) ++gen;
+                        }
+                const int rx = rhi[0] - rlo[0] + 1, ry = rhi[1] - rlo[1] + 1, rz = rhi[2] - rlo[2] + 1, nodes = rx * ry * rz;
+                if (nodes > kBoxMaxNodes || gen > kBoxMaxGeneral) {
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a)
+                        if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                    if (hi[axis] == lo[axis]) {  // a single cell cannot exceed the budget
+                        broken = true;
+                        return;
+                    }
+                    const int mid = (lo[axis] + hi[axis] + 1) / 2;
+                    Box Lh, Rh;
+                    for (int a = 0; a < 3; ++a) {
+                        Lh.lo[a] = Rh.lo[a] = lo[a];
+                        Lh.hi[a] = Rh.hi[a] = hi[a];
+                    }
+                    Lh.hi[axis] = mid - 1;
+                    Rh.lo[axis] = mid;
+                    stack.push_back(Rh);  // the left half is walked first
+                    stack.push_back(Lh);
+                    continue;
+                }
+                const int32_t origin = int32_t(d.idx(oi + rlo[0], oj + rlo[1], ok + rlo[2]));
+                const int32_t inf[kBoxInfoInts] = {origin, rx | (ry << 8) | (rz << 16), int32_t(T.codes.size()), int32_t(T.general.size() / 2), gen,
+                                                   (olo[0] - rlo[0]) | ((olo[1] - rlo[1]) << 8) | ((olo[2] - rlo[2]) << 16),
+                                                   (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16), nodes};
+                T.info.insert(T.info.end(), inf, inf + kBoxInfoInts);
+                for (int wk = rlo[2]; wk <= rhi[2]; ++wk)
+                    for (int wj = rlo[1]; wj <= rhi[1]; ++wj)
+                        for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                            const size_t w = size_t((wk * E + wj) * E + wi);
+                            const bool in = wi >= mlo[0] && wi <= mhi[0] && wj >= mlo[1] && wj <= mhi[1] && wk >= mlo[2] && wk <= mhi[2];  // (always: R lies in O grown)
+                            uint8_t c = in ? cls[w] : uint8_t(kBoxSkip);
+                            const int ring = std::min(ringOf(wi, wj, wk), 7);
+                            if (c != kBoxSkip && (fl[w] & 2)) {
+                                const int dg = L.bandDiag[size_t(ent[w])];
+                                c = dg == 0 ? uint8_t(kBoxGeneral) : uint8_t(kBoxSimple + dg);
+                                if (dg == 0 && ring <= D) {
+                                    const int node = ((wk - rlo[2]) * ry + (wj - rlo[1])) * rx + (wi - rlo[0]);
+                                    T.general.push_back(node | (ring << 16));
+                                    T.general.push_back(ent[w]);
+                                }
+                            }
+                            T.codes.push_back(uint8_t(c | (ring << 4)));
+                        }
+                while (T.codes.size() & 3) T.codes.push_back(0);
+            }
+        }
+    }, 8);
+    if (broken) {
+        out = BandBoxes();
+        out.depth = depth;
+        return;
+    }
+    // concatenate in tile order; the per-tile offsets become global ones
+    std::vector<size_t> gAt(size_t(nt) + 1, 0), cAt(size_t(nt) + 1, 0), nAt(size_t(nt) + 1, 0);
+    for (int64_t t = 0; t < nt; ++t) {
+        gAt[size_t(t) + 1] = gAt[size_t(t)] + tiles[size_t(t)].info.size() / kBoxInfoInts;
+        cAt[size_t(t) + 1] = cAt[size_t(t)] + tiles[size_t(t)].codes.size();
+        nAt[size_t(t) + 1] = nAt[size_t(t)] + tiles[size_t(t)].general.size() / 2;
+    }
+    out.info.resize(gAt.back() * kBoxInfoInts);
+    out.codes.resize(cAt.back());
+    out.general.resize(nAt.back() * 2);
+    parallelFor(nt, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            const BoxTileOut &T = tiles[size_t(t)];
+            std::copy(T.codes.begin(), T.codes.end(), out.codes.begin() + ptrdiff_t(cAt[size_t(t)]));
+            std::copy(T.general.begin(), T.general.end(), out.general.begin() + ptrdiff_t(2 * nAt[size_t(t)]));
+            for (size_t g = 0; g < T.info.size() / kBoxInfoInts; ++g) {
+                int32_t *dst = out.info.data() + (gAt[size_t(t)] + g) * kBoxInfoInts;
+                std::copy(T.info.begin() + ptrdiff_t(g * kBoxInfoInts), T.info.begin() + ptrdiff_t((g + 1) * kBoxInfoInts), dst);
+                dst[2] += int32_t(cAt[size_t(t)]);
+                dst[3] += int32_t(nAt[size_t(t)]);
+            }
+        }
+    }, 64);
+}
+
 size_t bandCellsInPlane(const HostLevel &G, int p)
 {
     if (p < 0 || p >= G.d.nz) return 0;
@@ -2005,6 +2243,201 @@ try {
     }
     for (size_t t = 0; t < nband; ++t)
         if (fusedOut[t] != ref[size_t(L.bandDev[t])]) return fail(MGPS_ERR_HIERARCHY, "fused band replay differs from pass-by-pass replay");
+    return MGPS_OK;
+}
+MGPS_API_CATCH(nullptr)
+
+// Host check of the box form of the fused band stage (BandBoxes): builds the level's boxes, verifies their structure (every
+// closure cell -- band cell or active face neighbour of one -- in exactly one owned box, regions within the workgroup
+// budget, every neighbour a pass reads present in the region) and replays, on a seeded grid, what launchBandBox computes:
+//   plain mode    `depth` band passes group by group            == pass by pass over the whole band,
+//   closure mode  sweep(x) overwritten on the closure by the groups' depth passes + one Jacobi step
+//                                                                == band passes, then the Jacobi sweep,
+//   and the plain mode fed from the closure mode's snapshot (the stage after the sweep) == band passes on the sweep's result;
+// all bit for bit.  wx / wy / wz (optional, level 0 only): face weights, so that general BOUNDARY cells (operator rows) take
+// part; without them the operator has unit weights.
+int mgps_hierarchy_check_band_boxes(const mgps_hierarchy *hier, int level, int depth, const float *wx, const float *wy, const float *wz,
+                                    int64_t *out_groups, int64_t *out_region_cells, int64_t *out_general)
+try {
+    if (!hier || level < 0 || level >= hier->levels || depth < 1 || depth > kBandMaxDepth || ((wx || wy || wz) && (level != 0 || !wx || !wy || !wz)))
+        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_check_band_boxes: bad arguments");
+    HostLevel L;
+    buildSlabLevel(hier->lv[level], 0, hier->lv[level].d.nz, wx, wy, wz, L);
+    BandBoxes bx;
+    buildBandBoxes(L, depth, bx);
+    const Dims d = L.d;
+    const size_t n = d.cells(), nband = L.bandDev.size();
+    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
+    const ptrdiff_t goff[6] = {-1, 1, -sy, sy, -sz, sz};
+    if (out_groups) *out_groups = int64_t(bx.groups());
+    if (out_region_cells) *out_region_cells = 0;
+    if (out_general) *out_general = int64_t(bx.general.size() / 2);
+    if (nband == 0) return bx.groups() == 0 ? MGPS_OK : fail(MGPS_ERR_HIERARCHY, "band boxes without band cells");
+    if (bx.groups() == 0) return fail(MGPS_ERR_HIERARCHY, "band boxes: builder failed");
+    const uint8_t *lab = L.ownedLabels;
+    std::vector<int32_t> entryOfCell(n, -1);
+    for (size_t t = 0; t < nband; ++t) entryOfCell[size_t(L.bandDev[t])] = int32_t(t);
+    auto isBand = [&](ptrdiff_t c) { return entryOfCell[size_t(c)] >= 0; };
+    auto isClosure = [&](ptrdiff_t c) {
+        if (isBand(c)) return true;
+        if (!isActive(lab[c])) return false;
+        for (int q = 0; q < 6; ++q)
+            if (isBand(c + goff[q])) return true;
+        return false;
+    };
+    // seeded grids
+    std::vector<float> x(n, 0.f), b(n, 0.f);
+    uint32_t state = 777u + uint32_t(level) * 31u + uint32_t(depth);
+    auto rnd = [&] {
+        state = state * 1664525u + 1013904223u;
+        return float(state >> 8) * (1.f / 16777216.f);
+    };
+    for (size_t c = 0; c < n; ++c)
+        if (isActive(lab[c])) {
+            x[c] = rnd();
+            b[c] = rnd();
+        }
+    const float omega = 2.f / 3.f;
+    const size_t nb = size_t(L.numBoundary);
+    // one damped Jacobi update of cell c from grid v (entry t >= 0: a band cell, general when t < numBoundary; t < 0: INTERIOR)
+    auto updateCell = [&](const std::vector<float> &v, ptrdiff_t c, int32_t t) {
+        const float xc = v[size_t(c)];
+        if (t >= 0 && size_t(t) < nb) {
+            const float *r = L.rows.data() + t;
+            float acc = 0.f;
+            for (int q = 0; q < 6; ++q) acc -= r[size_t(q) * nb] * v[size_t(c + goff[q])];
+            const float diag = r[6 * nb], lap = acc + diag * xc;
+            return xc + omega * ((b[size_t(c)] - lap) / diag);
+        }
+        const float diag = t >= 0 ? float(L.bandDiag[size_t(t)]) : 6.f;
+        const float lap = diag * xc - (v[size_t(c - 1)] + v[size_t(c + 1)] + v[size_t(c - sy)] + v[size_t(c + sy)] + v[size_t(c - sz)] + v[size_t(c + sz)]);
+        return xc + omega * ((b[size_t(c)] - lap) * (1.f / diag));
+    };
+    auto bandPasses = [&](std::vector<float> &v) {
+        std::vector<float> tmp(nband);
+        for (int p = 0; p < depth; ++p) {
+            for (size_t t = 0; t < nband; ++t) tmp[t] = updateCell(v, L.bandDev[t], int32_t(t));
+            for (size_t t = 0; t < nband; ++t) v[size_t(L.bandDev[t])] = tmp[t];
+        }
+    };
+    // the full-domain sweep, out of place: simple cells in line (their diagonal from the labels' neighbours), general ones by row
+    auto sweep = [&](const std::vector<float> &v, std::vector<float> &o) {
+        o = v;
+        for (size_t c = 0; c < n; ++c) {
+            if (!isActive(lab[c])) continue;
+            int32_t t = entryOfCell[c];
+            if (t < 0 && lab[c] != MGPS_INTERIOR_CELL) return false;  // a BOUNDARY cell outside the band cannot be
+            o[c] = updateCell(v, ptrdiff_t(c), t);
+        }
+        return true;
+    };
+    // reference results
+    std::vector<float> refA = x;  // band passes
+    bandPasses(refA);
+    std::vector<float> refB;      // ... then the sweep
+    if (!sweep(refA, refB)) return fail(MGPS_ERR_HIERARCHY, "band boxes: BOUNDARY cell outside the band");
+    std::vector<float> refC = refB;  // ... then band passes again
+    bandPasses(refC);
+    // group replay, as the kernel does it
+    std::vector<uint8_t> owned(n, 0);
+    int64_t regionCells = 0;
+    auto runGroups = [&](bool closure, const std::vector<float> &src, std::vector<float> &dst, std::vector<float> *snap) -> int {
+        const int H = depth + (closure ? 1 : 0);
+        std::vector<float> v0, v1;
+        std::vector<int32_t> genOf;
+        for (size_t gI = 0; gI < bx.groups(); ++gI) {
+            const int32_t *gi = bx.info.data() + kBoxInfoInts * gI;
+            const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, rz = gi[1] >> 16, nodes = gi[7];
+            if (nodes != rx * ry * rz || nodes > kBoxMaxNodes || gi[4] > kBoxMaxGeneral) return fail(MGPS_ERR_HIERARCHY, "band box exceeds the workgroup budget");
+            const uint8_t *code = bx.codes.data() + gi[2];
+            const int loff[6] = {-1, 1, -rx, rx, -rx * ry, rx * ry};
+            auto cellOf = [&](int nd) { return ptrdiff_t(gi[0]) + (nd % rx) + ptrdiff_t((nd / rx) % ry) * sy + ptrdiff_t(nd / (rx * ry)) * sz; };
+            v0.assign(size_t(nodes), 0.f);
+            genOf.assign(size_t(nodes), -1);
+            for (int q = 0; q < gi[4]; ++q) {
+                const int32_t e0 = bx.general[2 * size_t(gi[3] + q)], row = bx.general[2 * size_t(gi[3] + q) + 1];
+                const int nd = e0 & 0xffff, ring = e0 >> 16;
+                if (nd >= nodes || (code[nd] & 15) != kBoxGeneral || (code[nd] >> 4) != ring || row < 0 || size_t(row) >= nb || L.bandDev[size_t(row)] != cellOf(nd))
+                    return fail(MGPS_ERR_HIERARCHY, "band box: general entry does not match its cell");
+                genOf[size_t(nd)] = row;
+            }
+            for (int nd = 0; nd < nodes; ++nd) {
+                const int cl = code[nd] & 15, ring = code[nd] >> 4;
+                const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
+                const ptrdiff_t c = cellOf(nd);
+                if (cl != kBoxSkip) {  // the byte must tell the truth about the cell
+                    if (c < 0 || size_t(c) >= n) return fail(MGPS_ERR_HIERARCHY, "band box: region cell outside the grid");
+                    const bool act = isActive(lab[c]);
+                    if (band != isBand(c) || (cl == kBoxZero) != !act) return fail(MGPS_ERR_HIERARCHY, "band box: cell class does not match the cell");
+                    if (band && cl != kBoxGeneral && cl - kBoxSimple != int(L.bandDiag[size_t(entryOfCell[size_t(c)])]))
+                        return fail(MGPS_ERR_HIERARCHY, "band box: diagonal mismatch");
+                    if (band && cl == kBoxGeneral && ring <= depth && genOf[size_t(nd)] < 0) return fail(MGPS_ERR_HIERARCHY, "band box: general cell without row");
+                }
+                const bool need = closure ? (cl != kBoxSkip && cl != kBoxZero) : (cl == kBoxFrozen || cl == kBoxFrozenOut || (band && ring <= depth));
+                if (need) v0[size_t(nd)] = src[size_t(c)];
+            }
+            v1 = v0;
+            auto nodeUpdate = [&](const std::vector<float> &v, int nd, int cl) -> float {
+                const int li = nd % rx, lj = (nd / rx) % ry, lk = nd / (rx * ry);
+                if (li == 0 || lj == 0 || lk == 0 || li == rx - 1 || lj == ry - 1 || lk == rz - 1) return NAN;  // an updated cell on the region's rim
+                const float xc = v[size_t(nd)], bc = b[size_t(cellOf(nd))];
+                if (cl == kBoxGeneral) {
+                    const int32_t t = genOf[size_t(nd)];
+                    const float *r = L.rows.data() + t;
+                    float acc = 0.f;
+                    for (int q = 0; q < 6; ++q) acc -= r[size_t(q) * nb] * v[size_t(nd + loff[q])];
+                    const float diag = r[6 * nb], lap = acc + diag * xc;
+                    return xc + omega * ((bc - lap) / diag);
+                }
+                const float diag = cl == kBoxFrozenOut ? 6.f : float(cl - kBoxSimple);
+                const float lap = diag * xc - (v[size_t(nd - 1)] + v[size_t(nd + 1)] + v[size_t(nd - rx)] + v[size_t(nd + rx)] + v[size_t(nd - rx * ry)] + v[size_t(nd + rx * ry)]);
+                return xc + omega * ((bc - lap) * (1.f / diag));
+            };
+            for (int p = 1; p <= H; ++p) {
+                const std::vector<float> &s = (p & 1) ? v0 : v1;
+                std::vector<float> &o = (p & 1) ? v1 : v0;
+                const bool last = closure && p == H;
+                for (int nd = 0; nd < nodes; ++nd) {
+                    const int cl = code[nd] & 15, ring = code[nd] >> 4;
+                    const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
+                    if (ring > H - p || !(band || (last && cl == kBoxFrozenOut))) continue;
+                    const float r = nodeUpdate(s, nd, cl);
+                    if (r != r) return fail(MGPS_ERR_HIERARCHY, "band box: a pass reads outside its region");
+                    o[size_t(nd)] = r;
+                }
+            }
+            const std::vector<float> &fin = (H & 1) ? v1 : v0;
+            for (int nd = 0; nd < nodes; ++nd) {
+                const int cl = code[nd] & 15, ring = code[nd] >> 4;
+                const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
+                if (ring != 0 || !(band || (closure && cl == kBoxFrozenOut))) continue;
+                const ptrdiff_t c = cellOf(nd);
+                dst[size_t(c)] = fin[size_t(nd)];
+                if (snap) (*snap)[size_t(c)] = fin[size_t(nd)];
+                if (closure) ++owned[size_t(c)];
+            }
+            if (closure) regionCells += nodes;
+        }
+        return MGPS_OK;
+    };
+    // plain mode, legacy form: out of place from x, band cells copied back
+    {
+        std::vector<float> scratch = x, got = x;
+        MGPS_TRY_RC(runGroups(false, x, scratch, nullptr));
+        for (size_t t = 0; t < nband; ++t) got[size_t(L.bandDev[t])] = scratch[size_t(L.bandDev[t])];
+        if (got != refA) return fail(MGPS_ERR_HIERARCHY, "band boxes: plain stage differs from pass-by-pass replay");
+    }
+    // closure mode: y = sweep(x) everywhere, then overwritten on the closure; snapshot = the closure values
+    std::vector<float> y, snapshot(n, NAN);
+    if (!sweep(x, y)) return fail(MGPS_ERR_HIERARCHY, "band boxes: BOUNDARY cell outside the band");
+    MGPS_TRY_RC(runGroups(true, x, y, &snapshot));
+    for (size_t c = 0; c < n; ++c)
+        if (owned[c] != (isClosure(ptrdiff_t(c)) ? 1 : 0)) return fail(MGPS_ERR_HIERARCHY, "band boxes: closure cell not owned exactly once");
+    if (y != refB) return fail(MGPS_ERR_HIERARCHY, "band boxes: closure stage differs from band passes + sweep");
+    // the stage after the sweep: reads the snapshot only, writes y in place
+    MGPS_TRY_RC(runGroups(false, snapshot, y, nullptr));
+    if (y != refC) return fail(MGPS_ERR_HIERARCHY, "band boxes: stage fed from the snapshot differs from pass-by-pass replay");
+    if (out_region_cells) *out_region_cells = regionCells;
     return MGPS_OK;
 }
 MGPS_API_CATCH(nullptr)

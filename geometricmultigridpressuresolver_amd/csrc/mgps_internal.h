@@ -152,6 +152,48 @@ struct BandGroups {
 };
 void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
 
+// Fused band stage, box form (whole-grid levels; round 3).  The graph form above spends 20 B of metadata per update node
+// and gathers every value by index (PMC: 131 B per band cell at 1024^3 against 16 algorithmic).  Here a group is a BOX of the
+// grid: the owned box O (a piece of a 16^3 tile: the bounding box of the tile's band-closure cells, halved until it fits)
+// and the region R around it that its passes touch (inside O dilated by depth + 1).  The workgroup loads R's needed cells
+// as row segments into a dense LDS block -- neighbours are index +-1, +-rx, +-rx*ry, no ids -- and one byte per region cell
+// says what the cell is (class) and how far outside O it lies (ring = Chebyshev distance, so that pass p recomputes the band
+// cells with ring <= H - p):
+//   class 0  not needed            1  frozen active cell read by the band passes     2  inactive neighbour (value 0)
+//         3  general band cell (row list)   4 + d  simple band cell, diagonal d (INTERIOR band cells: 10)
+//        11  frozen cell of O next to a band cell: gets the closure pass's Jacobi value (ring 0)
+//        12  frozen cell needed by the closure pass only
+// Two modes of the kernel (launchBandBox):
+//   plain    depth band passes (H = depth); the final values of O's band cells go to `dst`
+//   closure  depth band passes + ONE full-domain Jacobi step evaluated on the band closure of O (H = depth + 1): the
+//            stage "band passes, then sweep" becomes sweep(x -> y) over the whole grid followed by this kernel
+//            overwriting y on the closure (band cells and their active face neighbours) -- nothing is scattered back
+//            into x -- and the same values land in a snapshot grid from which the band stage AFTER the sweep reads
+//            (that one then writes y in place: no workgroup reads what another one writes).
+constexpr int kBoxMaxNodes = 4096;    // region cells of a group: two LDS copies of their values
+constexpr int kBoxThreads = 512;
+constexpr int kBoxSlots = kBoxMaxNodes / kBoxThreads;
+constexpr int kBoxMaxGeneral = 512;   // general band cells of a region (their rows sit in LDS)
+constexpr int kBoxInfoInts = 8;
+enum BoxNode : uint8_t { kBoxSkip = 0, kBoxFrozen = 1, kBoxZero = 2, kBoxGeneral = 3, kBoxSimple = 4, kBoxFrozenOut = 11, kBoxFrozenFar = 12 };
+struct BandBoxes {
+    int depth = 0;
+    // per group kBoxInfoInts ints: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first byte in
+    // `codes`, [3] first entry in `general`, [4] number of general entries, [5] origin of O inside the region (packed like
+    // [1]), [6] extents of O (packed), [7] rx * ry * rz
+    RawVec<int32_t> info;
+    RawVec<uint8_t> codes;     // per group rx*ry*rz bytes (k, j, i order; padded to a multiple of 4): class | ring << 4
+    RawVec<int32_t> general;   // per general band cell with ring <= depth two ints: region cell | ring << 16, row index
+    size_t groups() const { return info.size() / kBoxInfoInts; }
+};
+void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out);
+struct BandBoxesDev {
+    int depth = 0, ngroups = 0;
+    int32_t *info = nullptr, *general = nullptr;
+    uint8_t *codes = nullptr;
+    size_t codeBytes = 0, generalInts = 0;
+};
+
 // The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
 // besides its ghost plane a rank receives the *band closure* (band cells and their active face neighbours)
 // of the next `depth` planes of each neighbour, x and rhs, and recomputes the neighbour's band cells it
@@ -301,6 +343,16 @@ struct BandGroupsDev {
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                     float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr,
                     const float *frows = nullptr, int foreignBase = 0, int nForeign = 0, double *dotPartials = nullptr);
+// Box form of the fused band stage (BandBoxes).  src: where the region's values are read; dst: where the results go (the
+// band cells of every owned box; closure mode: every closure cell of it), snap (closure mode, optional): a second copy.
+// Grids are float, or binary16 when `half` is set (mixed precision: ms as in launchBandFusedMixed).
+// dotPartials (optional): one slot per group receives sum (new - old) * b over the group's output cells, `old` read from
+// dotOld (closure mode: the sweep's value in dst before it is overwritten; plain mode: the stage's input).
+int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap,
+                  float omega, bool half = false, const MixScale &ms = MixScale{}, double *dotPartials = nullptr, const void *dotOld = nullptr);
+// dst = src on the band cells of every owned box (the legacy form of the plain stage: out of place into a scratch grid,
+// then this copy -- used where no snapshot of the input exists)
+int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half = false);
 // one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
 // that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the
 // two lists into the halo arrays and the last part into the band cells of the ghost plane of b (the grids'
@@ -405,13 +457,15 @@ int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *
 int launchTileClassList(void *stream, const Dims &d, const int32_t *kind, int odd, int mixed, int32_t *flags, int32_t *rank, int32_t *list,
                         int32_t *scanScratch);
 int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
-// the group kernels run over the list of tiles that hold band cells; counts and offsets are indexed by list position
-int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
-                          const int32_t *bandTiles, int nBandTiles, int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken);
-int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *bandTiles, int nBandTiles, const int32_t *groupAt,
-                         const int32_t *updateAt, const int32_t *readAt, int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours,
-                         int32_t *readCell, int *broken);
+// the boxes of the fused band stage (BandBoxes), built over the list of tiles that can hold a band-closure cell; counts
+// and offsets are indexed by list position
+int launchBoxTileList(void *stream, const Dims &d, const int32_t *tileStart, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
+int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *nGroups, int32_t *nCodes,
+                         int32_t *nGeneral, int *broken);
+int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *groupAt,
+                        const int32_t *codeAt, const int32_t *generalAt, int32_t *info, uint8_t *codes, int32_t *general, int *broken);
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)

@@ -631,6 +631,174 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The fused band stage, box form (BandBoxes in mgps_internal.h; whole-grid levels).  A workgroup takes one group: the
+// region R (a box of the grid, <= kBoxMaxNodes cells) goes into a dense LDS block -- the six neighbours of node n are
+// n +- 1, n +- rx, n +- rx*ry, no ids -- filled from row segments of `src`; one byte per region cell (class | ring << 4)
+// says what the cell is and how far outside the owned box it lies.  Pass p recomputes the band cells with ring <= H - p
+// (redundant work near the rim instead of a round trip through HBM per pass), the arithmetic of bandComputeKernel:
+//   CLOSURE = false  H = depth band passes (Ops.h:524-619 x depth); the owned box's band cells go to `dst`.  Nothing else
+//                    may read `dst` cells in this launch: either src is another grid (a snapshot, or the stage runs out
+//                    of place into a scratch grid that bandBoxCopyKernel copies back), never src == dst;
+//   CLOSURE = true   the same passes and then ONE damped Jacobi step (Ops.h:262-367, same omega, same formula) on the
+//                    band cells of the owned box and their active face neighbours (class 11), H = depth + 1: what the
+//                    full-domain sweep would write there had the band passes gone before it.  The sweep itself runs
+//                    over the un-smoothed grid first; this launch overwrites its output on the band closure and leaves
+//                    the same values in `snap`, from which the stage after the sweep reads (then dst = the sweep's
+//                    output itself: written in place, no scatter anywhere).
+// General band cells (operator rows): at most kBoxMaxGeneral per group, rows and rhs staged in LDS, one thread each.
+// DOT: the workgroup leaves sum (new - old) * b over the cells it writes (old = dotOld at that cell).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int boxDiv(int n, int dv, float rcp)  // n / dv for 0 <= n < 2^20 (float estimate, fixed up)
+{
+    int q = int(float(n) * rcp);
+    q -= (q * dv > n) ? 1 : 0;
+    q += ((q + 1) * dv <= n) ? 1 : 0;
+    return q;
+}
+__device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
+
+template <class TX, bool CLOSURE, bool DOT>
+__global__ __launch_bounds__(kBoxThreads, 6) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+                                                              TX *__restrict__ snap, const int32_t *__restrict__ info,
+                                                              const uint8_t *__restrict__ codes, const int32_t *__restrict__ general, float omega,
+                                                              int depth, MixScale ms, double *__restrict__ dotPartials, const TX *__restrict__ dotOld)
+{
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
+    __shared__ float val[2][kBoxMaxNodes];
+    __shared__ float grow[7][kBoxMaxGeneral];
+    __shared__ float gbv[kBoxMaxGeneral];
+    __shared__ uint16_t gnode[kBoxMaxGeneral];  // region cell | ring << 12
+    const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
+    const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, nodes = gi[7], ngen = gi[4];
+    const int sxy = rx * ry;
+    const float rrx = 1.f / float(rx), rsxy = 1.f / float(sxy);
+    const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny, origin = gi[0];
+    const uint8_t *code = codes + gi[2];
+    const int H = depth + (CLOSURE ? 1 : 0);
+    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
+    const int tid = threadIdx.x;
+    auto cellOf = [&](int n) {
+        const int lk = boxDiv(n, sxy, rsxy), rem = n - lk * sxy, lj = boxDiv(rem, rx, rrx), li = rem - lj * rx;
+        return origin + li + lj * sy + lk * sz;
+    };
+    unsigned cd[kBoxSlots];
+    float bv[kBoxSlots];
+#pragma unroll
+    for (int m = 0; m < kBoxSlots; ++m) {
+        const int n = tid + m * kBoxThreads;
+        cd[m] = n < nodes ? code[n] : 0u;
+    }
+    {
+        float xv[kBoxSlots];
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const unsigned cls = cd[m] & 15u, ring = cd[m] >> 4;
+            const bool band = boxBand(cls);
+            const bool need = CLOSURE ? (cls != kBoxSkip && cls != kBoxZero) : (cls == kBoxFrozen || cls == kBoxFrozenOut || (band && int(ring) <= depth));
+            const bool bneed = (band && cls != kBoxGeneral && int(ring) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
+            xv[m] = 0.f;
+            bv[m] = 0.f;
+            if (need || bneed) {
+                const ptrdiff_t c = cellOf(tid + m * kBoxThreads);
+                if (need) xv[m] = Cell<TX>::load1(src + c);
+                if (bneed) bv[m] = kMixed ? bm * b[c] : b[c];
+            }
+        }
+        if (tid < ngen) {
+            const int32_t e0 = general[2 * size_t(gi[3] + tid)], row = general[2 * size_t(gi[3] + tid) + 1];
+            const int nd = e0 & 0xffff;
+            gnode[tid] = uint16_t(nd | ((e0 >> 16) << 12));
+            const size_t nb = size_t(g.nbnd);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) grow[q][tid] = g.rows[size_t(q) * nb + row];
+            const ptrdiff_t c = cellOf(nd);
+            gbv[tid] = kMixed ? bm * b[c] : b[c];
+        }
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const int n = tid + m * kBoxThreads;
+            if (n < nodes) {
+                val[0][n] = xv[m];
+                val[1][n] = xv[m];
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 1; p <= H; ++p) {
+        const float *from = val[(p - 1) & 1];
+        float *to = val[p & 1];
+        const int lim = H - p;
+        const bool last = CLOSURE && p == H;
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const unsigned cls = cd[m] & 15u;
+            const int n = tid + m * kBoxThreads;
+            const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
+            if (int(cd[m] >> 4) <= lim && (simple || (last && cls == kBoxFrozenOut))) {
+                const float xc = from[n];
+                const float diag = simple ? float(int(cls) - int(kBoxSimple)) : 6.f;
+                const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
+                to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
+            }
+        }
+        if (tid < ngen) {
+            const int nd = gnode[tid] & 0xfff;
+            if (int(gnode[tid] >> 12) <= lim) {
+                const float xc = from[nd];
+                float acc = 0.f;
+                acc -= grow[0][tid] * from[nd - 1];
+                acc -= grow[1][tid] * from[nd + 1];
+                acc -= grow[2][tid] * from[nd - rx];
+                acc -= grow[3][tid] * from[nd + rx];
+                acc -= grow[4][tid] * from[nd - sxy];
+                acc -= grow[5][tid] * from[nd + sxy];
+                const float diag = grow[6][tid];
+                const float lap = acc + diag * xc;
+                to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
+            }
+        }
+        __syncthreads();
+    }
+    const float *fin = val[H & 1];
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < kBoxSlots; ++m) {
+        const unsigned cls = cd[m] & 15u;
+        if ((cd[m] >> 4) == 0u && (boxBand(cls) || (CLOSURE && cls == kBoxFrozenOut))) {
+            const int n = tid + m * kBoxThreads;
+            const ptrdiff_t c = cellOf(n);
+            const float v = fin[n];
+            if (DOT) {
+                const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
+                acc += (double(stored) - double(Cell<TX>::load1(dotOld + c))) * double(b[c]);
+            }
+            Cell<TX>::store1(dst + c, v);
+            if (CLOSURE && snap) Cell<TX>::store1(snap + c, v);
+        }
+    }
+    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
+}
+
+// dst = src on the band cells of every owned box
+template <class TX>
+__global__ __launch_bounds__(kBoxThreads) void bandBoxCopyKernel(GridP g, const TX *__restrict__ src, TX *__restrict__ dst, const int32_t *__restrict__ info,
+                                                                const uint8_t *__restrict__ codes)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
+    const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, nodes = gi[7], sxy = rx * ry;
+    const float rrx = 1.f / float(rx), rsxy = 1.f / float(sxy);
+    const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny, origin = gi[0];
+    const uint8_t *code = codes + gi[2];
+    for (int n = threadIdx.x; n < nodes; n += kBoxThreads) {
+        const unsigned cdv = code[n];
+        if ((cdv >> 4) != 0u || !boxBand(cdv & 15u)) continue;
+        const int lk = boxDiv(n, sxy, rsxy), rem = n - lk * sxy, lj = boxDiv(rem, rx, rrx), li = rem - lj * rx;
+        const ptrdiff_t c = origin + li + lj * sy + lk * sz;
+        dst[c] = src[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tile-coloured Gauss-Seidel (Ops.h:369-520).  One 256-thread workgroup owns one 16^3 tile of the
 // requested colour: the 18^3 halo cube of x and the 16^3 rhs are staged in LDS, then the tile is
 // swept along anti-diagonal planes i+j+k = s.  For a 7-point stencil every cell of plane s depends
@@ -1634,6 +1802,46 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
     return int(hipGetLastError());
 }
 unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
+namespace {
+template <class TX>
+int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool closure, const TX *src, const float *b, TX *dst, TX *snap, float omega,
+                   const MixScale &ms, double *dotPartials, const TX *dotOld)
+{
+    const unsigned ng = unsigned(bx.ngroups);
+    const bool dot = dotPartials != nullptr;
+#define MGPS_BOX_LAUNCH(C, D) bandBoxKernel<TX, C, D><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.codes, bx.general, omega, bx.depth, ms, dotPartials, dotOld)
+    if (closure) {
+        if (dot) MGPS_BOX_LAUNCH(true, true);
+        else MGPS_BOX_LAUNCH(true, false);
+    } else {
+        if (dot) MGPS_BOX_LAUNCH(false, true);
+        else MGPS_BOX_LAUNCH(false, false);
+    }
+#undef MGPS_BOX_LAUNCH
+    return int(hipGetLastError());
+}
+}  // namespace
+int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap, float omega,
+                  bool half, const MixScale &ms, double *dotPartials, const void *dotOld)
+{
+    if (bx.ngroups <= 0) return 0;
+    if (src == dst || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (half)
+        return launchBandBoxT<__half>(s, g, bx, closure, static_cast<const __half *>(src), b, static_cast<__half *>(dst), static_cast<__half *>(snap), omega, ms,
+                                      dotPartials, static_cast<const __half *>(dotOld));
+    return launchBandBoxT<float>(s, g, bx, closure, static_cast<const float *>(src), b, static_cast<float *>(dst), static_cast<float *>(snap), omega, ms,
+                                 dotPartials, static_cast<const float *>(dotOld));
+}
+int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half)
+{
+    if (bx.ngroups <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (half) bandBoxCopyKernel<__half><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const __half *>(src), static_cast<__half *>(dst), bx.info, bx.codes);
+    else bandBoxCopyKernel<float><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const float *>(src), static_cast<float *>(dst), bx.info, bx.codes);
+    return int(hipGetLastError());
+}
+
 
 // ---- mixed precision (options.precision = 1): the fine level's iterate and residual live in binary16 ----------------
 // The launchers take the binary16 grids as void* (the solver layer does not see __half).  Solver-owned grids only:

@@ -620,49 +620,67 @@ __global__ void stripAdvanceKernel(int32_t *__restrict__ base, const int32_t *__
     if (threadIdx.x == 0) *base = b;
 }
 
-// ---- groups of the fused band stage (BandGroups in mgps_internal.h) --------------------------------------------------
+// ---- boxes of the fused band stage (BandBoxes in mgps_internal.h) -----------------------------------------------------
 
-// One workgroup per 16^3 tile walks the recursion of the host builder (buildGroupsOverWindow): the owned set starts as the
-// tile's band cells; the sub-graph of a set is found by dilating it depth-1 times through band-to-band stencil edges inside
-// the set's bounding box grown by depth (LDS), plus the active cells those nodes read; a set whose sub-graph exceeds one
-// workgroup of the band kernel is halved along the longest axis of its bounding box.  Nodes are numbered owned first, then
-// by distance, inside a distance (and the read-only nodes) by position in the box -- the host builder's canonical order.
-// FILL = false: per tile the number of groups, update nodes and read-only nodes; FILL = true: the arrays, at the tile's
-// scanned offsets.
-constexpr int kGroupThreads = 256;
-constexpr int kGroupMaxE = kTile + 2 * kBandMaxDepth;  // longest x-row of a box
-constexpr uint8_t kNodeNone = 255, kNodeRead = 200;
+// flags[t] = 1: tile t or one of its six face neighbours holds band cells (only such a tile can hold a band-closure cell)
+__global__ __launch_bounds__(256) void boxTileFlagKernel(const int32_t *__restrict__ tileStart, int tx, int ty, int tz, int32_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= tx * ty * tz) return;
+    const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    auto has = [&](int a, int b, int c) {
+        if (a < 0 || b < 0 || c < 0 || a >= tx || b >= ty || c >= tz) return false;
+        const int q = (c * ty + b) * tx + a;
+        return tileStart[q + 1] > tileStart[q];
+    };
+    flags[t] = (has(ti, tj, tk) || has(ti - 1, tj, tk) || has(ti + 1, tj, tk) || has(ti, tj - 1, tk) || has(ti, tj + 1, tk) || has(ti, tj, tk - 1) ||
+                has(ti, tj, tk + 1))
+                   ? 1
+                   : 0;
+}
+
+// One workgroup per listed 16^3 tile walks the recursion of the host builder (buildBandBoxes, mgps_host.cpp): a window of
+// the tile grown by depth + 2 cells holds per cell "active" and "band member" (labels, band masks); a stack of sub-boxes of
+// the tile is walked left half first: O = bounding box of the sub-box's closure cells (band cells and active cells next to
+// one), every cell of O grown by depth + 1 is classified (BoxNode), R = bounding box of the classes != 0; a group whose R
+// exceeds the band kernel's budget is halved along O's longest axis.  FILL = false: per tile the number of groups, code
+// bytes and general entries; FILL = true: the arrays, at the tile's scanned offsets.
+constexpr int kBoxBuildThreads = 256;
 
 struct Box {
     int8_t lo[3], hi[3];
 };
 
 template <bool FILL>
-__global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const uint8_t *__restrict__ lab, int tx, int ty, const uint32_t *__restrict__ mask,
-                                                                  const uint16_t *__restrict__ prefix, const int32_t *__restrict__ tileStart,
-                                                                  const int32_t *__restrict__ bandEntry, const uint8_t *__restrict__ bandDiag, int depth,
-                                                                  int32_t *__restrict__ nGroups, int32_t *__restrict__ nUpdate, int32_t *__restrict__ nReadOnly,
-                                                                  const int32_t *__restrict__ groupAt, const int32_t *__restrict__ updateAt,
-                                                                  const int32_t *__restrict__ readAt, int32_t *__restrict__ info,
-                                                                  int32_t *__restrict__ updateEntry, int32_t *__restrict__ updateCell,
-                                                                  uint16_t *__restrict__ neighbours, int32_t *__restrict__ readCell, int *__restrict__ broken,
-                                                                  const int32_t *__restrict__ bandTiles)
+__global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const uint8_t *__restrict__ lab, int tx, int ty, const uint32_t *__restrict__ mask,
+                                                                   const uint16_t *__restrict__ prefix, const int32_t *__restrict__ tileStart,
+                                                                   const int32_t *__restrict__ bandEntry, const uint8_t *__restrict__ bandDiag, int depth,
+                                                                   const int32_t *__restrict__ tiles, int32_t *__restrict__ nGroups,
+                                                                   int32_t *__restrict__ nCodes, int32_t *__restrict__ nGeneral,
+                                                                   const int32_t *__restrict__ groupAt, const int32_t *__restrict__ codeAt,
+                                                                   const int32_t *__restrict__ generalAt, int32_t *__restrict__ info,
+                                                                   uint8_t *__restrict__ codes, int32_t *__restrict__ general, int *__restrict__ broken)
 {
-    const int t = bandTiles[blockIdx.x];  // the tiles that hold band cells; counts and offsets are indexed by list position
     extern __shared__ uint8_t sm[];
-    const int EM = kTile + 2 * depth, EM3 = EM * EM * EM;
-    uint8_t *fl = sm;                                                  // bit 0 active, bit 1 band
-    uint8_t *node = sm + EM3;                                          // kNodeNone, distance 0 .. depth-1, kNodeRead
-    uint16_t *id = reinterpret_cast<uint16_t *>(sm + 2 * size_t(EM3) + (size_t(EM3) & 1));  // FILL: node numbers
-    __shared__ uint32_t tmask[128];
+    const int D = depth, P = depth + 2, E = kTile + 2 * P, E2 = E * E, E3 = E2 * E;
+    uint8_t *fl = sm;        // bit 0 active, bit 1 band
+    uint8_t *cls = sm + E3;  // BoxNode class of the cells of O grown by depth + 1
     __shared__ Box stack[48];
     __shared__ int sp;
-    __shared__ int bb[6];
-    __shared__ int waveTot[5][4];
+    __shared__ int bb[6], rb[6], sGen;
     __shared__ int scratch[4];
     const int tid = threadIdx.x;
-    const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
-    if (tid < 128) tmask[tid] = mask[size_t(t) * 128 + tid];
+    const int t = tiles[blockIdx.x], ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    const int oi = ti * kTile - P, oj = tj * kTile - P, ok = tk * kTile - P;  // grid cell of window cell (0, 0, 0)
+    // entry (sorted band position) of the band cell at grid (gi, gj, gk)
+    auto sortedOf = [&](int gi, int gj, int gk) {
+        const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
+        const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
+        const uint32_t w = mask[size_t(tile) * 128 + (b >> 5)];
+        return tileStart[tile] + int(prefix[size_t(tile) * 128 + (b >> 5)]) + __popc(w & ((1u << (b & 31)) - 1u));
+    };
+    // the window's labels: EXTERIOR everywhere, then the part inside the grid row by row as aligned 4-byte words
+    for (int q = tid; q < (E3 + 3) / 4; q += kBoxBuildThreads) reinterpret_cast<uint32_t *>(fl)[q] = 0x01010101u * MGPS_EXTERIOR_CELL;
     if (tid == 0) {
         sp = 1;
         for (int a = 0; a < 3; ++a) {
@@ -670,9 +688,52 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
             stack[0].hi[a] = kTile - 1;
         }
     }
-    int groups = 0, upd = 0, rd = 0;  // running totals of this tile (uniform across the workgroup)
-    const int gBase = FILL ? groupAt[blockIdx.x] : 0, uBase = FILL ? updateAt[blockIdx.x] : 0, rBase = FILL ? readAt[blockIdx.x] : 0;
     __syncthreads();
+    {
+        const int dshift = E + 7 <= 32 ? 3 : 4;  // words a row can touch
+        for (int w = tid; w < (E2 << dshift); w += kBoxBuildThreads) {
+            const int r = w >> dshift, q = w & ((1 << dshift) - 1);
+            const int lj = r % E, lk = r / E, gj = oj + lj, gk = ok + lk;
+            if (gj < 0 || gj >= d.ny || gk < 0 || gk >= d.nz) continue;
+            const ptrdiff_t rowBase = ptrdiff_t(cellIdx(d, 0, gj, gk));
+            const ptrdiff_t a0 = rowBase + max(oi, 0), a1 = rowBase + min(oi + E, d.nx);
+            const ptrdiff_t addr = (a0 & ~ptrdiff_t(3)) + 4 * q;
+            if (addr >= a1) continue;
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(lab + addr);  // (the allocation has a spare plane on each side)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const ptrdiff_t at = addr + b;
+                if (at >= a0 && at < a1) fl[r * E + int(at - rowBase) - oi] = uint8_t(word >> (8 * b));
+            }
+        }
+    }
+    __syncthreads();
+    // labels -> flags, band membership from the masks of the (up to three) tiles a row crosses
+    for (int r = tid; r < E2; r += kBoxBuildThreads) {
+        const int lj = r % E, lk = r / E, gj = oj + lj, gk = ok + lk;
+        const bool rowIn = gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz;
+        uint32_t w0 = 0, w1 = 0, w2 = 0;
+        const int tix0 = max(oi, 0) >> 4;
+        if (rowIn) {
+            const size_t trow = size_t((gk >> 4) * ty + (gj >> 4)) * tx;
+            const int word = (((gk & 15) << 4) | (gj & 15)) >> 1, sh = (gj & 1) << 4;
+            w0 = (mask[(trow + tix0) * 128 + word] >> sh) & 0xffffu;
+            if (tix0 + 1 < tx) w1 = (mask[(trow + tix0 + 1) * 128 + word] >> sh) & 0xffffu;
+            if (tix0 + 2 < tx) w2 = (mask[(trow + tix0 + 2) * 128 + word] >> sh) & 0xffffu;
+        }
+        for (int li = 0; li < E; ++li) {
+            const int gi = oi + li, q = (gi >> 4) - tix0;
+            uint8_t f = 0;
+            if (rowIn && gi >= 0 && gi < d.nx && activeCode(fl[r * E + li])) {
+                const uint32_t w = q == 0 ? w0 : (q == 1 ? w1 : w2);
+                f = ((w >> (gi & 15)) & 1u) ? 3 : 1;
+            }
+            fl[r * E + li] = f;
+        }
+    }
+    const int off[6] = {-1, 1, -E, E, -E2, E2};
+    int groups = 0, codeBytes = 0, gens = 0;  // running totals of this tile (uniform across the workgroup)
+    const int gBase = FILL ? groupAt[blockIdx.x] : 0, cBase = FILL ? codeAt[blockIdx.x] : 0, nBase = FILL ? generalAt[blockIdx.x] : 0;
     while (true) {
         __syncthreads();
         if (sp == 0) break;
@@ -682,201 +743,195 @@ __global__ __launch_bounds__(kGroupThreads) void bandGroupsKernel(Dims d, const 
             --sp;
             bb[0] = bb[1] = bb[2] = 99;
             bb[3] = bb[4] = bb[5] = -1;
+            rb[0] = rb[1] = rb[2] = 99;
+            rb[3] = rb[4] = rb[5] = -1;
+            sGen = 0;
         }
         __syncthreads();
-        // tight bounding box of the owned cells: the tile's band cells inside B (thread = one x-row of the tile)
-        int owned = 0;
-        {
+        {  // O: tight bounding box of the closure cells of the tile inside B (thread = one x-row of the tile)
             const int lk = tid >> 4, lj = tid & 15;
-            unsigned bits = 0;
             if (lk >= B.lo[2] && lk <= B.hi[2] && lj >= B.lo[1] && lj <= B.hi[1]) {
-                const uint32_t word = tmask[tid >> 1];
-                bits = (tid & 1) ? word >> 16 : word & 0xffffu;
-                bits &= (0xffffu >> (15 - B.hi[0])) & (0xffffu << B.lo[0]);
-            }
-            if (bits) {
-                atomicMin(&bb[0], __ffs(bits) - 1);
-                atomicMax(&bb[3], 31 - __clz(bits));
-                atomicMin(&bb[1], lj);
-                atomicMax(&bb[4], lj);
-                atomicMin(&bb[2], lk);
-                atomicMax(&bb[5], lk);
-            }
-            blockExclusiveScan(__popc(bits), &owned, scratch);
-        }
-        __syncthreads();
-        if (owned == 0) continue;
-        const int lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[3], bb[4], bb[5]};
-        const int ex = hi[0] - lo[0] + 1 + 2 * depth, ey = hi[1] - lo[1] + 1 + 2 * depth, ez = hi[2] - lo[2] + 1 + 2 * depth;
-        const int oi = ti * kTile + lo[0] - depth, oj = tj * kTile + lo[1] - depth, ok = tk * kTile + lo[2] - depth;  // grid cell of box cell (0,0,0)
-        // A thread owns a run of consecutive x-rows of the box (row r = lk * ey + lj): one division per row, the loads of a
-        // row issued together, and numbering by (thread, position) is the box order (k, j, i).
-        const int R = ey * ez, rp = (R + kGroupThreads - 1) / kGroupThreads, r0 = min(R, tid * rp), r1 = min(R, r0 + rp);
-        // flags of the box: activity from the labels, band membership from the masks of the (up to three) tiles a row crosses
-        for (int r = r0; r < r1; ++r) {
-            const int lj = r % ey, lk = r / ey, gj = oj + lj, gk = ok + lk;
-            const bool rowIn = gj >= 0 && gj < d.ny && gk >= 0 && gk < d.nz;
-            uint8_t v[kGroupMaxE];
-            uint32_t w0 = 0, w1 = 0, w2 = 0;
-            const int tix0 = max(oi, 0) >> 4;
-            if (rowIn) {
-                const uint8_t *src = lab + cellIdx(d, 0, gj, gk);
-#pragma unroll
-                for (int li = 0; li < kGroupMaxE; ++li) {
-                    const int gi = oi + li;
-                    v[li] = (li < ex && gi >= 0 && gi < d.nx) ? src[gi] : uint8_t(MGPS_EXTERIOR_CELL);
-                }
-                const size_t trow = size_t((gk >> 4) * ty + (gj >> 4)) * tx;
-                const int word = (((gk & 15) << 4) | (gj & 15)) >> 1, sh = (gj & 1) << 4;
-                w0 = (mask[(trow + tix0) * 128 + word] >> sh) & 0xffffu;
-                if (tix0 + 1 < tx) w1 = (mask[(trow + tix0 + 1) * 128 + word] >> sh) & 0xffffu;
-                if (tix0 + 2 < tx) w2 = (mask[(trow + tix0 + 2) * 128 + word] >> sh) & 0xffffu;
-            } else {
-#pragma unroll
-                for (int li = 0; li < kGroupMaxE; ++li) v[li] = MGPS_EXTERIOR_CELL;
-            }
-            const bool rowOwn = lj >= depth && lj < ey - depth && lk >= depth && lk < ez - depth;
-#pragma unroll
-            for (int li = 0; li < kGroupMaxE; ++li)
-                if (li < ex) {
-                    const int gi = oi + li, q = (gi >> 4) - tix0;
-                    uint8_t f = 0;
-                    if (activeCode(v[li])) {  // (a cell past the grid read EXTERIOR)
-                        const uint32_t w = q == 0 ? w0 : (q == 1 ? w1 : w2);
-                        f = ((w >> (gi & 15)) & 1u) ? 3 : 1;
+                int first = 99, lastI = -1;
+                for (int li = B.lo[0]; li <= B.hi[0]; ++li) {
+                    const int w = ((lk + P) * E + lj + P) * E + li + P;
+                    const unsigned f = fl[w];
+                    bool clo = (f & 2u) != 0;
+                    if (!clo && (f & 1u)) clo = ((fl[w - 1] | fl[w + 1] | fl[w - E] | fl[w + E] | fl[w - E2] | fl[w + E2]) & 2u) != 0;
+                    if (clo) {
+                        first = min(first, li);
+                        lastI = li;
                     }
-                    fl[r * ex + li] = f;
-                    // distance 0: the owned cells (band cells of this tile inside the tight box)
-                    node[r * ex + li] = (f == 3 && rowOwn && li >= depth && li < ex - depth) ? 0 : kNodeNone;
                 }
+                if (lastI >= 0) {
+                    atomicMin(&bb[0], first);
+                    atomicMax(&bb[3], lastI);
+                    atomicMin(&bb[1], lj);
+                    atomicMax(&bb[4], lj);
+                    atomicMin(&bb[2], lk);
+                    atomicMax(&bb[5], lk);
+                }
+            }
         }
         __syncthreads();
-        for (int ring = 1; ring <= depth; ++ring) {  // ring == depth: the read-only nodes (any active cell next to an update node)
-            const bool reads = ring == depth;
-            for (int r = r0; r < r1; ++r) {
-                const int lj = r % ey, lk = r / ey;
-                for (int li = 0; li < ex; ++li) {
-                    const int c = r * ex + li;
-                    if (node[c] != kNodeNone || (reads ? fl[c] == 0 : fl[c] != 3)) continue;
-                    auto hit = [&](bool in, int off) { return in && (reads ? node[c + off] < depth : node[c + off] == ring - 1); };
-                    if (hit(li > 0, -1) || hit(li + 1 < ex, 1) || hit(lj > 0, -ex) || hit(lj + 1 < ey, ex) || hit(lk > 0, -ex * ey) || hit(lk + 1 < ez, ex * ey))
-                        node[c] = reads ? kNodeRead : uint8_t(ring);
+        if (bb[3] < 0) continue;
+        const int lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[3], bb[4], bb[5]};
+        const int olo[3] = {lo[0] + P, lo[1] + P, lo[2] + P}, ohi[3] = {hi[0] + P, hi[1] + P, hi[2] + P};      // O in window coordinates
+        const int mlo[3] = {olo[0] - (D + 1), olo[1] - (D + 1), olo[2] - (D + 1)}, mhi[3] = {ohi[0] + D + 1, ohi[1] + D + 1, ohi[2] + D + 1};
+        const int mx = mhi[0] - mlo[0] + 1, my = mhi[1] - mlo[1] + 1, mz = mhi[2] - mlo[2] + 1, mrows = my * mz;
+        auto ringOf = [&](int wi, int wj, int wk) {
+            return max(max(max(olo[0] - wi, wi - ohi[0]), max(olo[1] - wj, wj - ohi[1])), max(max(olo[2] - wk, wk - ohi[2]), 0));
+        };
+        const int dI[6] = {-1, 1, 0, 0, 0, 0}, dJ[6] = {0, 0, -1, 1, 0, 0}, dK[6] = {0, 0, 0, 0, -1, 1};
+        for (int r = tid; r < mrows; r += kBoxBuildThreads) {
+            const int wj = mlo[1] + r % my, wk = mlo[2] + r / my;
+            for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                const int w = (wk * E + wj) * E + wi;
+                const unsigned f = fl[w];
+                uint8_t c = kBoxSkip;
+                if (f & 2u) c = kBoxGeneral;  // band cell (its code is looked up when the group is written)
+                else {
+                    int best = 99;  // smallest ring among the band face neighbours
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        if (fl[w + off[q]] & 2u) best = min(best, ringOf(wi + dI[q], wj + dJ[q], wk + dK[q]));
+                    if (f & 1u) {
+                        if (best < 99 && ringOf(wi, wj, wk) == 0) c = kBoxFrozenOut;
+                        else if (best <= D - 1) c = kBoxFrozen;
+                        else if (best <= D) c = kBoxFrozenFar;
+                    } else if (best <= D)
+                        c = kBoxZero;
                 }
-            }
-            __syncthreads();
-        }
-        // class counts of this thread's rows
-        const int c0 = r0 * ex, c1 = r1 * ex;
-        int cnt[5] = {0, 0, 0, 0, 0};
-        for (int c = c0; c < c1; ++c) {
-            const unsigned v = node[c];
-            if (v < kBandMaxDepth) ++cnt[v];
-            else if (v == kNodeRead) ++cnt[4];
-        }
-        int before[5], total[5];
-        {
-            int inc[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) inc[q] = waveInclusiveScan(cnt[q]);
-            if ((tid & 63) == 63)
-#pragma unroll
-                for (int q = 0; q < 5; ++q) waveTot[q][tid >> 6] = inc[q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                int b4 = 0, all = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int s = waveTot[q][w];
-                    b4 += w < (tid >> 6) ? s : 0;
-                    all += s;
-                }
-                before[q] = b4 + inc[q] - cnt[q];
-                total[q] = all;
+                cls[w] = c;
             }
         }
-        const int nUpd = total[0] + total[1] + total[2] + total[3], nRead = total[4];
-        if (nUpd > kBandMaxUpdate || nUpd + nRead + 1 > kBandMaxNodes) {
+        __syncthreads();
+        // active cells next to a closure-output cell: read by the closure pass (only class 11 seeds: no cascade)
+        for (int r = tid; r < mrows; r += kBoxBuildThreads) {
+            const int wj = mlo[1] + r % my, wk = mlo[2] + r / my;
+            for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                const int w = (wk * E + wj) * E + wi;
+                if (cls[w] != kBoxSkip || !(fl[w] & 1u)) continue;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int ni = wi + dI[q], nj = wj + dJ[q], nk = wk + dK[q];
+                    if (ni < mlo[0] || ni > mhi[0] || nj < mlo[1] || nj > mhi[1] || nk < mlo[2] || nk > mhi[2]) continue;
+                    if (cls[w + off[q]] == kBoxFrozenOut) {
+                        cls[w] = kBoxFrozenFar;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {  // R = bounding box of the classes != 0; general band cells with ring <= depth
+            int l0 = 99, l1 = 99, l2 = 99, h0 = -1, h1 = -1, h2 = -1, gen = 0;
+            for (int r = tid; r < mrows; r += kBoxBuildThreads) {
+                const int wj = mlo[1] + r % my, wk = mlo[2] + r / my;
+                for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
+                    const int w = (wk * E + wj) * E + wi;
+                    if (cls[w] == kBoxSkip) continue;
+                    l0 = min(l0, wi);
+                    h0 = max(h0, wi);
+                    l1 = min(l1, wj);
+                    h1 = max(h1, wj);
+                    l2 = min(l2, wk);
+                    h2 = max(h2, wk);
+                    if ((fl[w] & 2u) && ringOf(wi, wj, wk) <= D && bandDiag[bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)]] == 0) ++gen;
+                }
+            }
+            if (h0 >= 0) {
+                atomicMin(&rb[0], l0);
+                atomicMax(&rb[3], h0);
+                atomicMin(&rb[1], l1);
+                atomicMax(&rb[4], h1);
+                atomicMin(&rb[2], l2);
+                atomicMax(&rb[5], h2);
+                if (gen) atomicAdd(&sGen, gen);
+            }
+        }
+        __syncthreads();
+        const int rlo[3] = {rb[0], rb[1], rb[2]}, rhi[3] = {rb[3], rb[4], rb[5]}, gen = sGen;
+        const int rx = rhi[0] - rlo[0] + 1, ry = rhi[1] - rlo[1] + 1, rz = rhi[2] - rlo[2] + 1, nodes = rx * ry * rz;
+        (void)mx;
+        if (nodes > kBoxMaxNodes || gen > kBoxMaxGeneral) {
             __syncthreads();
             if (tid == 0) {
-                if (owned < 2 || sp + 2 > 48) *broken = 1;
+                int axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                if (hi[axis] == lo[axis] || sp + 2 > 48) *broken = 1;
                 else {
-                    int axis = 0;
-                    for (int a = 1; a < 3; ++a)
-                        if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
                     const int mid = (lo[axis] + hi[axis] + 1) / 2;
-                    Box L, R;
+                    Box Lh, Rh;
                     for (int a = 0; a < 3; ++a) {
-                        L.lo[a] = R.lo[a] = int8_t(lo[a]);
-                        L.hi[a] = R.hi[a] = int8_t(hi[a]);
+                        Lh.lo[a] = Rh.lo[a] = int8_t(lo[a]);
+                        Lh.hi[a] = Rh.hi[a] = int8_t(hi[a]);
                     }
-                    L.hi[axis] = int8_t(mid - 1);
-                    R.lo[axis] = int8_t(mid);
-                    stack[sp++] = R;  // the left half is walked first
-                    stack[sp++] = L;
+                    Lh.hi[axis] = int8_t(mid - 1);
+                    Rh.lo[axis] = int8_t(mid);
+                    stack[sp++] = Rh;  // the left half is walked first
+                    stack[sp++] = Lh;
                 }
             }
             continue;
         }
+        const int padded = (nodes + 3) & ~3;
         if (FILL) {
-            const int ringBase[4] = {0, total[0], total[0] + total[1], total[0] + total[1] + total[2]};
-            int run[5] = {before[0], before[1], before[2], before[3], before[4]};
-            for (int c = c0; c < c1; ++c) {
-                const unsigned v = node[c];
-                if (v < kBandMaxDepth) id[c] = uint16_t(ringBase[v] + run[v]++);
-                else if (v == kNodeRead) id[c] = uint16_t(nUpd + run[4]++);
-            }
-            __syncthreads();
-            const int uAt = uBase + upd, rAt = rBase + rd;
+            // a thread owns a run of consecutive x-rows of R: (thread, position) order is the region's (k, j, i) order
+            const int R = ry * rz, rp = (R + kBoxBuildThreads - 1) / kBoxBuildThreads, r0 = min(R, tid * rp), r1 = min(R, r0 + rp);
+            uint8_t *cdst = codes + size_t(cBase + codeBytes);
+            int myGen = 0;
             for (int r = r0; r < r1; ++r) {
-                const int lj = r % ey, lk = r / ey, gj = oj + lj, gk = ok + lk;
-                for (int li = 0; li < ex; ++li) {
-                    const int c = r * ex + li;
-                    const unsigned v = node[c];
-                    if (v == kNodeNone) continue;
-                    const int gi = oi + li;
-                    const int32_t cell = int32_t(cellIdx(d, gi, gj, gk));
-                    const int n = id[c];
-                    if (v == kNodeRead) {
-                        readCell[rAt + (n - nUpd)] = cell;
-                        continue;
-                    }
-                    updateCell[uAt + n] = cell;
-                    const int tile = ((gk >> 4) * ty + (gj >> 4)) * tx + (gi >> 4);
-                    const int b = (((gk & 15) << 4) | (gj & 15)) << 4 | (gi & 15);
-                    const uint32_t w = mask[size_t(tile) * 128 + (b >> 5)];
-                    const int sorted = tileStart[tile] + prefix[size_t(tile) * 128 + (b >> 5)] + __popc(w & ((1u << (b & 31)) - 1u));
-                    const int e = bandEntry[sorted];
-                    updateEntry[uAt + n] = e | (int32_t(bandDiag[e]) << kBandDiagShift);
-                    const int off[6] = {-1, 1, -ex, ex, -ex * ey, ex * ey};
-                    uint16_t q6[6];
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) q6[q] = fl[c + off[q]] ? id[c + off[q]] : uint16_t(nUpd + nRead);  // (an update node is never on the box's rim)
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(neighbours + 6 * size_t(uAt + n));
-                    dst[0] = uint32_t(q6[0]) | (uint32_t(q6[1]) << 16);
-                    dst[1] = uint32_t(q6[2]) | (uint32_t(q6[3]) << 16);
-                    dst[2] = uint32_t(q6[4]) | (uint32_t(q6[5]) << 16);
+                const int wj = rlo[1] + r % ry, wk = rlo[2] + r / ry;
+                for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                    const int w = (wk * E + wj) * E + wi;
+                    if ((fl[w] & 2u) && cls[w] != kBoxSkip && ringOf(wi, wj, wk) <= D && bandDiag[bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)]] == 0) ++myGen;
                 }
             }
+            int genBefore = 0, genTotal = 0;
+            genBefore = blockExclusiveScan(myGen, &genTotal, scratch);
+            int32_t *gdst = general + 2 * size_t(nBase + gens + genBefore);
+            for (int r = r0; r < r1; ++r) {
+                const int wj = rlo[1] + r % ry, wk = rlo[2] + r / ry;
+                for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                    const int w = (wk * E + wj) * E + wi;
+                    const int node = r * rx + (wi - rlo[0]);
+                    uint8_t c = cls[w];
+                    const int ring = min(ringOf(wi, wj, wk), 7);
+                    if (c != kBoxSkip && (fl[w] & 2u)) {
+                        const int e = bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)];
+                        const int dg = bandDiag[e];
+                        c = dg == 0 ? uint8_t(kBoxGeneral) : uint8_t(kBoxSimple + dg);
+                        if (dg == 0 && ring <= D) {
+                            gdst[0] = node | (ring << 16);
+                            gdst[1] = e;
+                            gdst += 2;
+                        }
+                    }
+                    cdst[node] = uint8_t(c | (ring << 4));
+                }
+            }
+            if (tid < padded - nodes) cdst[nodes + tid] = 0;
             if (tid == 0) {
-                int32_t *gi8 = info + 8 * size_t(gBase + groups);
-                const int c1n = total[0] + total[1], c2n = c1n + total[2], c3n = c2n + total[3];
-                const int cum[4] = {total[0], c1n, c2n, c3n};
-                gi8[0] = uAt;
-                gi8[1] = rAt;
-                gi8[2] = nRead;
-                for (int q = 0; q < kBandMaxDepth; ++q) gi8[3 + q] = cum[q < depth ? q : depth - 1];
-                gi8[7] = 0;
+                int32_t *g8 = info + kBoxInfoInts * size_t(gBase + groups);
+                g8[0] = int32_t(cellIdx(d, oi + rlo[0], oj + rlo[1], ok + rlo[2]));
+                g8[1] = rx | (ry << 8) | (rz << 16);
+                g8[2] = cBase + codeBytes;
+                g8[3] = nBase + gens;
+                g8[4] = gen;
+                g8[5] = (olo[0] - rlo[0]) | ((olo[1] - rlo[1]) << 8) | ((olo[2] - rlo[2]) << 16);
+                g8[6] = (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16);
+                g8[7] = nodes;
             }
         }
         ++groups;
-        upd += nUpd;
-        rd += nRead;
+        codeBytes += padded;
+        gens += gen;
     }
     if (!FILL && tid == 0) {
         nGroups[blockIdx.x] = groups;
-        nUpdate[blockIdx.x] = upd;
-        nReadOnly[blockIdx.x] = rd;
+        nCodes[blockIdx.x] = codeBytes;
+        nGeneral[blockIdx.x] = gens;
     }
 }
 
@@ -1009,11 +1064,6 @@ int launchRunList(void *stream, const Dims &d, const uint8_t *runFlags, size_t n
     return int(hipGetLastError());
 }
 
-static size_t groupLds(int depth, bool fill)
-{
-    const size_t EM = size_t(kTile + 2 * depth), EM3 = EM * EM * EM;
-    return 2 * EM3 + (EM3 & 1) + (fill ? 2 * EM3 : 0);  // flags + node classes (+ node numbers)
-}
 // flags / rank: nt and nt + 1 ints of scratch; list: room for nt entries; rank[nt] = the number of band tiles afterwards
 int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch)
 {
@@ -1044,26 +1094,41 @@ int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, in
     tileListKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(rank, n, list);
     return int(hipGetLastError());
 }
-int launchBandGroupsCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int depth,
-                          const int32_t *bandTiles, int nBandTiles, int32_t *nGroups, int32_t *nUpdate, int32_t *nReadOnly, int *broken)
+// list = the tiles that can hold a band-closure cell (a band cell in the tile or in a face neighbour); rank[nt] = their number
+int launchBoxTileList(void *stream, const Dims &d, const int32_t *tileStart, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch)
 {
-    if (nBandTiles <= 0) return 0;
-    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
-    bandGroupsKernel<false><<<unsigned(nBandTiles), kGroupThreads, groupLds(depth, false), S(stream)>>>(
-        d, lab, tx, ty, mask, prefix, tileStart, nullptr, nullptr, depth, nGroups, nUpdate, nReadOnly, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        nullptr, nullptr, broken, bandTiles);
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile, nt = tx * ty * tz;
+    boxTileFlagKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(tileStart, tx, ty, tz, flags);
+    const int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
+    if (e != 0) return e;
+    tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
     return int(hipGetLastError());
 }
-int launchBandGroupsFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *bandTiles, int nBandTiles, const int32_t *groupAt,
-                         const int32_t *updateAt, const int32_t *readAt, int32_t *info, int32_t *updateEntry, int32_t *updateCell, uint16_t *neighbours,
-                         int32_t *readCell, int *broken)
+static size_t boxBuildLds(int depth)
 {
-    if (nBandTiles <= 0) return 0;
+    const size_t E = size_t(kTile + 2 * (depth + 2));
+    return 2 * E * E * E + 8;
+}
+int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *nGroups, int32_t *nCodes,
+                         int32_t *nGeneral, int *broken)
+{
+    if (ntiles <= 0) return 0;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
-    bandGroupsKernel<true><<<unsigned(nBandTiles), kGroupThreads, groupLds(depth, true), S(stream)>>>(
-        d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, nullptr, nullptr, nullptr, groupAt, updateAt, readAt, info, updateEntry, updateCell,
-        neighbours, readCell, broken, bandTiles);
+    boxBuildKernel<false><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
+                                                                                                nGroups, nCodes, nGeneral, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                                                                nullptr, broken);
+    return int(hipGetLastError());
+}
+int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
+                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *groupAt,
+                        const int32_t *codeAt, const int32_t *generalAt, int32_t *info, uint8_t *codes, int32_t *general, int *broken)
+{
+    if (ntiles <= 0) return 0;
+    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
+    boxBuildKernel<true><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
+                                                                                               nullptr, nullptr, nullptr, groupAt, codeAt, generalAt, info, codes, general,
+                                                                                               broken);
     return int(hipGetLastError());
 }
 

@@ -58,7 +58,7 @@ struct DevLevel {
     float *packBuf[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
     int edgeChunks = 0, edgePlaneBlocks = 0;            // cut slab levels: the leading entries that touch the planes next to a cut
-    BandGroupsDev bandGroups;  // fused band passes (levels that are not cut into slabs)
+    BandBoxesDev bandBoxes;  // fused band stage, box form (levels that are not cut into slabs)
     // fused band stage of a cut level (SlabHalo): one exchange per stage
     struct Halo {
         int depth = 0;
@@ -417,11 +417,9 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.updateCell);
         (void)cacheFree(L.halo.groups.readCell);
         (void)cacheFree(L.halo.groups.neighbours);
-        (void)cacheFree(L.bandGroups.info);
-        (void)cacheFree(L.bandGroups.updateEntry);
-        (void)cacheFree(L.bandGroups.updateCell);
-        (void)cacheFree(L.bandGroups.readCell);
-        (void)cacheFree(L.bandGroups.neighbours);
+        (void)cacheFree(L.bandBoxes.info);
+        (void)cacheFree(L.bandBoxes.codes);
+        (void)cacheFree(L.bandBoxes.general);
     }
     for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
     (void)cacheFree(h->cinv);
@@ -545,6 +543,9 @@ bool bandStageCompletesGhosts(const mgps_solver *h, int l)
     return h->dist && h->lv[l].halo.depth > 0 && h->lv[l].halo.depth == h->opt.band_iterations;
 }
 
+// the level runs the box form of the fused band stage (BandBoxes: whole-grid levels, options.fuse_band_passes)
+bool levelHasBoxes(const mgps_solver *h, int l) { return h->lv[l].bandBoxes.ngroups > 0 && h->lv[l].bandBoxes.depth == h->opt.band_iterations; }
+
 // `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
 // dot (single-device runs only): the scatters append their corrections to h->dotPartials (see mgps_solver::gatherDot)
 // afterSplitSweep: the sweep before was launched edge first (sweepSplit): the stage's message goes on the transfer stream
@@ -558,9 +559,16 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first,
         h->dotUsed += bandScatterBlocks(L.nband);
         return p;
     };
-    if (L.bandGroups.ngroups > 0 && L.bandGroups.depth == h->opt.band_iterations) {  // level is not cut: no exchanges
-        MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, L.band, L.nband, L.bandTmp, h->opt.jacobi_weight, L.bandGroups, nullptr,
-                                       nullptr, nullptr, 0, 0, sink()));
+    if (levelHasBoxes(h, l)) {  // level is not cut: no exchanges.  No snapshot of x exists here: out of place into the level's
+                                // residual grid (free during a stroke), then the band cells copied back
+        double *s = nullptr;
+        if (dot) {
+            s = h->dotPartials + h->dotUsed;
+            h->dotUsed += unsigned(L.bandBoxes.ngroups);
+        }
+        if (x == L.r || b == L.r) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "band stage: the level's residual grid is its scratch");
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, x, b, L.r, nullptr, h->opt.jacobi_weight, false, MixScale{}, s, x));
+        MGPS_LAUNCH(h, launchBandBoxCopy(h->stream, L.g, L.bandBoxes, L.r, x));
         return MGPS_OK;
     }
     for (int it = 0; it < h->opt.band_iterations; ++it) {
@@ -704,6 +712,39 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
 {
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
+    if (bands && !h->useGS && (down ? h->opt.pre_sweeps : h->opt.post_sweeps) == 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r) {
+        // "band passes, sweep, band passes" in three launches, nothing scattered (launchBandBox): the sweep over the
+        // un-smoothed grid; the closure launch, which overwrites the sweep's output on the band closure with what the
+        // sweep would have written after the band passes and leaves a snapshot of it in the level's residual grid (free
+        // during a stroke); the second band stage, reading the snapshot and writing the sweep's output in place.
+        const bool timed = h->profiling && l == 0;
+        double *sinkA = nullptr, *sinkB = nullptr;
+        {
+            StageScope scope(h, ST_SMOOTH, l);
+            if (timed) MGPS_TRY(profMark(h, true));
+            if (dot) {
+                unsigned used = 0;
+                MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
+                h->dotUsed += used;
+                sinkA = h->dotPartials + h->dotUsed;
+                sinkB = sinkA + L.bandBoxes.ngroups;
+                h->dotUsed += 2u * unsigned(L.bandBoxes.ngroups);
+            } else {
+                GridP gs = L.g;
+                gs.nbnd = 0;  // every BOUNDARY cell lies in the band closure: the closure launch computes the general ones as well
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, cur, b, h->opt.jacobi_weight, true));
+            }
+            if (timed) {
+                MGPS_TRY(profMark(h, false));
+                ++h->profSweeps;
+            }
+        }
+        StageScope scope(h, ST_BAND, l);
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, cur, b, other, L.r, h->opt.jacobi_weight, false, MixScale{}, sinkA, other));
+        std::swap(cur, other);
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, L.r));
+        return MGPS_OK;
+    }
     {
         StageScope scope(h, ST_BAND, l);
         MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
@@ -964,27 +1005,51 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
     const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
     const bool gather = dotDev != nullptr && h->dotPartials != nullptr;
     h->dotUsed = 0;
+    // (the box form of the band stage, binary16 grids: see smoothStroke; the scratch / snapshot grid is the binary16 residual)
+    auto bandStage = [&](bool dot) -> int {  // no snapshot: out of place, band cells copied back
+        double *sink = nullptr;
+        if (dot && F.bandBoxes.ngroups > 0) {
+            sink = h->dotPartials + h->dotUsed;
+            h->dotUsed += unsigned(F.bandBoxes.ngroups);
+        }
+        MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, cur, b, h->mixR, nullptr, omega, true, smooth, sink, cur));
+        MGPS_LAUNCH(h, launchBandBoxCopy(h->stream, F.g, F.bandBoxes, h->mixR, cur, true));
+        return MGPS_OK;
+    };
+    auto sweep = [&](bool d, bool patchGeneral) -> int {
+        unsigned used = 0;
+        GridP gs = F.g;
+        if (!patchGeneral) gs.nbnd = 0;
+        if (h->profiling) MGPS_TRY(profMark(h, true));  // the measurement hook of smoothStroke: event pair around the fine sweep
+        MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, gs, other, cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
+        if (h->profiling) {
+            MGPS_TRY(profMark(h, false));
+            ++h->profSweeps;
+        }
+        h->dotUsed += used;
+        return MGPS_OK;
+    };
     auto stroke = [&](bool down, bool dot) -> int {
-        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth));
         const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
-        for (int rep = 0; rep < reps; ++rep) {
-            unsigned used = 0;
-            const bool d = dot && rep == reps - 1;
-            if (h->profiling) MGPS_TRY(profMark(h, true));  // the measurement hook of smoothStroke: event pair around the fine sweep
-            MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, F.g, other, cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
-            if (h->profiling) {
-                MGPS_TRY(profMark(h, false));
-                ++h->profSweeps;
+        if (reps == 1 && F.bandBoxes.ngroups > 0) {
+            MGPS_TRY(sweep(dot, dot));
+            double *sinkA = nullptr, *sinkB = nullptr;
+            if (dot) {
+                sinkA = h->dotPartials + h->dotUsed;
+                sinkB = sinkA + F.bandBoxes.ngroups;
+                h->dotUsed += 2u * unsigned(F.bandBoxes.ngroups);
             }
-            h->dotUsed += used;
+            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, cur, b, other, h->mixR, omega, true, smooth, sinkA, other));
+            std::swap(cur, other);
+            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, h->mixR, b, cur, nullptr, omega, true, smooth, sinkB, h->mixR));
+            return MGPS_OK;
+        }
+        MGPS_TRY(bandStage(false));
+        for (int rep = 0; rep < reps; ++rep) {
+            MGPS_TRY(sweep(dot && rep == reps - 1, true));
             std::swap(cur, other);
         }
-        double *sink = nullptr;
-        if (dot && F.nband > 0) {
-            sink = h->dotPartials + h->dotUsed;
-            h->dotUsed += bandScatterBlocks(F.nband);
-        }
-        MGPS_LAUNCH(h, launchBandFusedMixed(h->stream, F.g, cur, b, F.band, F.nband, F.bandTmp, omega, F.bandGroups, smooth, sink));
+        MGPS_TRY(bandStage(dot));
         return MGPS_OK;
     };
     MGPS_TRY(stroke(true, gather && nlv == 1));
@@ -1033,7 +1098,7 @@ int ensurePcgGrids(mgps_solver *h, bool needDiag)
     if (!h->dotPartials) {  // the fused A.p launch, or the last stroke of a V-cycle: sweep workgroups / tiles + band scatters
         const DevLevel &F = h->lv[0];
         const size_t tiles = size_t(F.npure[0]) + F.npure[1] + F.nmixed[0] + F.nmixed[1];
-        const size_t scatters = size_t(std::max(1, h->opt.band_iterations)) * bandScatterBlocks(F.nband);
+        const size_t scatters = size_t(std::max(1, h->opt.band_iterations)) * bandScatterBlocks(F.nband) + 2 * size_t(F.bandBoxes.ngroups);
         h->dotCapacity = applyDotPartialCount(F.g) + tiles + scatters + 64 + 2048;
         MGPS_TRY(devAlloc(h, &h->dotPartials, h->dotCapacity, true));
     }
@@ -1446,16 +1511,17 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     const bool cut = h->dist && (z0 > 0 || z1 < globalNz);
     if (!cut && h->opt.fuse_band_passes && h->opt.band_iterations >= 1 && h->opt.band_iterations <= kBandMaxDepth && !HL.bandDev.empty()) {
         StageClock gclock(h->opt.print_stats != 0);
-        BandGroups bg;
-        buildBandGroups(HL, h->opt.band_iterations, bg);
-        gclock.lap("  (band groups alone)");
-        L.bandGroups.depth = bg.depth;
-        L.bandGroups.ngroups = int(bg.groups());
-        MGPS_TRY(devUpload(h, &L.bandGroups.info, bg.info));
-        MGPS_TRY(devUpload(h, &L.bandGroups.updateEntry, bg.updateEntry));
-        MGPS_TRY(devUpload(h, &L.bandGroups.updateCell, bg.updateCell));
-        MGPS_TRY(devUpload(h, &L.bandGroups.readCell, bg.readCell));
-        MGPS_TRY(devUpload(h, &L.bandGroups.neighbours, bg.neighbours));
+        BandBoxes bx;
+        buildBandBoxes(HL, h->opt.band_iterations, bx);
+        gclock.lap("  (band boxes alone)");
+        if (bx.groups() == 0) return failH(h, MGPS_ERR_INTERNAL, "band boxes: the builder failed on level of " + std::to_string(L.d.nx) + " cells in x");
+        L.bandBoxes.depth = bx.depth;
+        L.bandBoxes.ngroups = int(bx.groups());
+        L.bandBoxes.codeBytes = bx.codes.size();
+        L.bandBoxes.generalInts = bx.general.size();
+        MGPS_TRY(devUpload(h, &L.bandBoxes.info, bx.info));
+        MGPS_TRY(devUpload(h, &L.bandBoxes.codes, bx.codes));
+        MGPS_TRY(devUpload(h, &L.bandBoxes.general, bx.general));
     }
     if (xbGrids) {
         MGPS_TRY(gridAlloc(h, &L.x, L.d));
@@ -1952,12 +2018,12 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         int32_t *sorted = nullptr, *general = nullptr, *genRank = nullptr, *bandEntry = nullptr;
         uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
         int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
-        int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr;
+        int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr, *boxTiles = nullptr;
         uint8_t *tileBits = nullptr;
         int *runCounts = nullptr;
         int32_t *listCounts = nullptr;  // pure even / odd, mixed even / odd tiles, plane blocks
         int runCells = 0, listLen = 0;
-        int nband = 0, nGen = 0, planeZc = 0, nBandTiles = 0;
+        int nband = 0, nGen = 0, planeZc = 0, nBandTiles = 0, nBoxTiles = 0;
         size_t nfine = 0, nplane = 0;
     };
     std::vector<LevelTmp> T{size_t(levels)};
@@ -2063,21 +2129,24 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         // (the groups below read the labels for activity only: patched or not makes no difference)
         ODS_LAUNCH(launchPatchSimpleCodes(nullptr, labOf(l), L.band, L.bandDiag, L.nbndGeneral, L.nband));
     }
-    // ---- groups of the fused band stage: counts
+    // ---- boxes of the fused band stage: counts
     const bool wantGroups = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
     std::vector<int> haveGroups(size_t(levels), 0);
     for (int l = 0; l < levels && wantGroups; ++l) {
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
-        if (t.nband == 0 || size_t(t.nband) > size_t(kBandEntryMask)) continue;
+        if (t.nband == 0) continue;
         haveGroups[size_t(l)] = 1;
+        ODS_TRY(tmp.get(h, &t.boxTiles, size_t(t.nt)));
+        ODS_LAUNCH(launchBoxTileList(nullptr, L.d, t.tileStart, t.tileFlags, t.tileRank, t.boxTiles, t.scan));
+        ODS_HIP(hipMemcpy(&t.nBoxTiles, t.tileRank + t.nt, sizeof(int), hipMemcpyDeviceToHost));
         for (int q = 0; q < 3; ++q) {
-            ODS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nBandTiles)));
-            ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nBandTiles) + 1));
+            ODS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nBoxTiles)));
+            ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nBoxTiles) + 1));
         }
-        ODS_LAUNCH(launchBandGroupsCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, o.band_iterations, t.bandTiles, t.nBandTiles, t.gcount[0],
-                                         t.gcount[1], t.gcount[2], flags + 2 * mgLevels + 2 + l));
-        for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nBandTiles), t.scan));
+        ODS_LAUNCH(launchBandBoxesCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.boxTiles, t.nBoxTiles,
+                                        t.gcount[0], t.gcount[1], t.gcount[2], flags + 2 * mgLevels + 2 + l));
+        for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nBoxTiles), t.scan));
     }
     // ---- host side of the lists: flags and kinds come back, lists go up
     for (int l = 0; l < levels; ++l) {
@@ -2150,29 +2219,27 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         fillGridP(h, L, l == 0, t.listLen, t.runCells, counts[4], t.planeZc);
     }
     clock.lap("device order, codes, activity + tile lists");
-    // ---- groups: totals to the host, arrays filled
+    // ---- boxes: totals to the host, arrays filled
     for (int l = 0; l < levels; ++l) {
         if (!haveGroups[size_t(l)]) continue;
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
         int tot[3] = {0, 0, 0}, brokenL = 0;
-        for (int q = 0; q < 3; ++q) ODS_HIP(hipMemcpy(&tot[q], t.gat[q] + t.nBandTiles, sizeof(int), hipMemcpyDeviceToHost));
+        for (int q = 0; q < 3; ++q) ODS_HIP(hipMemcpy(&tot[q], t.gat[q] + t.nBoxTiles, sizeof(int), hipMemcpyDeviceToHost));
         ODS_HIP(hipMemcpy(&brokenL, flags + 2 * mgLevels + 2 + l, sizeof(int), hipMemcpyDeviceToHost));
-        if (brokenL || tot[0] == 0) continue;  // (the level then runs its band passes one by one)
-        L.bandGroups.depth = o.band_iterations;
-        L.bandGroups.ngroups = tot[0];
-        ODS_TRY(devAlloc(h, &L.bandGroups.info, size_t(8) * size_t(tot[0]), false));
-        ODS_TRY(devAlloc(h, &L.bandGroups.updateEntry, size_t(tot[1]), false));
-        ODS_TRY(devAlloc(h, &L.bandGroups.updateCell, size_t(tot[1]), false));
-        ODS_TRY(devAlloc(h, &L.bandGroups.neighbours, size_t(6) * size_t(tot[1]), false));
-        ODS_TRY(devAlloc(h, &L.bandGroups.readCell, size_t(tot[2]), false));
-        ODS_LAUNCH(launchBandGroupsFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.bandTiles, t.nBandTiles,
-                                        t.gat[0], t.gat[1], t.gat[2],
-                                        L.bandGroups.info, L.bandGroups.updateEntry, L.bandGroups.updateCell, L.bandGroups.neighbours, L.bandGroups.readCell,
-                                        flags + 2 * mgLevels + 2 + l));
+        if (brokenL || tot[0] == 0) return bail(failH(h, MGPS_ERR_INTERNAL, "band boxes: the builder failed on level " + std::to_string(l)));
+        L.bandBoxes.depth = o.band_iterations;
+        L.bandBoxes.ngroups = tot[0];
+        L.bandBoxes.codeBytes = size_t(tot[1]);
+        L.bandBoxes.generalInts = 2 * size_t(tot[2]);
+        ODS_TRY(devAlloc(h, &L.bandBoxes.info, size_t(kBoxInfoInts) * size_t(tot[0]), false));
+        ODS_TRY(devAlloc(h, &L.bandBoxes.codes, size_t(tot[1]), false));
+        ODS_TRY(devAlloc(h, &L.bandBoxes.general, 2 * size_t(tot[2]), false));
+        ODS_LAUNCH(launchBandBoxesFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.boxTiles, t.nBoxTiles,
+                                       t.gat[0], t.gat[1], t.gat[2], L.bandBoxes.info, L.bandBoxes.codes, L.bandBoxes.general, flags + 2 * mgLevels + 2 + l));
     }
     ODS_HIP(hipDeviceSynchronize());
-    clock.lap("band groups");
+    clock.lap("band boxes");
     inverseJob.join();
     if (rcInverse != MGPS_OK) {
         h->lastError = lastGlobalError();
@@ -2735,21 +2802,9 @@ try {
     case 8: src = L.mixed[0], n = size_t(L.nmixed[0]); break;
     case 9: src = L.mixed[1], n = size_t(L.nmixed[1]); break;
     case 10: src = L.tileBndStart, n = size_t(nt) + 1; break;
-    case 11: src = L.bandGroups.info, n = size_t(8) * size_t(L.bandGroups.ngroups); break;
-    case 12:
-    case 13:
-    case 14:
-    case 15: {
-        if (L.bandGroups.ngroups == 0) break;
-        int32_t last[8];  // the last group's offsets + sizes give the totals
-        MGPS_HIP(h, hipMemcpy(last, L.bandGroups.info + 8 * size_t(L.bandGroups.ngroups - 1), sizeof(last), hipMemcpyDeviceToHost));
-        const size_t nUpd = size_t(last[0]) + size_t(last[3 + L.bandGroups.depth - 1]), nRead = size_t(last[1]) + size_t(last[2]);
-        if (which == 12) src = L.bandGroups.updateEntry, n = nUpd;
-        else if (which == 13) src = L.bandGroups.updateCell, n = nUpd;
-        else if (which == 14) src = L.bandGroups.neighbours, n = 6 * nUpd, elem = 2;
-        else src = L.bandGroups.readCell, n = nRead;
-        break;
-    }
+    case 11: src = L.bandBoxes.info, n = size_t(kBoxInfoInts) * size_t(L.bandBoxes.ngroups); break;
+    case 12: src = L.bandBoxes.codes, n = L.bandBoxes.codeBytes, elem = 1; break;
+    case 13: src = L.bandBoxes.general, n = L.bandBoxes.generalInts; break;
     default: return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: unknown array");
     }
     *count = int64_t(n);

@@ -160,6 +160,17 @@ class Hierarchy:
         check(lib().mgps_hierarchy_check_band_groups(self.h, int(level), int(depth), C.byref(g), C.byref(n)))
         return g.value, n.value
 
+    def check_band_boxes(self, level, depth=3, weights=None):
+        """host self-check of the box form of the fused band stage (level 0 with `weights` = [wx, wy, wz]: general BOUNDARY
+        cells take part); returns (groups, region cells, general entries)"""
+        g, n, q = C.c_int64(), C.c_int64(), C.c_int64()
+        w = [None, None, None]
+        if weights is not None:
+            w = [_np_f32(a) for a in weights]
+        check(lib().mgps_hierarchy_check_band_boxes(self.h, int(level), int(depth), *[(_p(a) if a is not None else None) for a in w],
+                                                    C.byref(g), C.byref(n), C.byref(q)))
+        return g.value, n.value, q.value
+
     @property
     def coarse_unknowns(self):
         return lib().mgps_hierarchy_coarse_unknowns(self.h)
@@ -233,8 +244,8 @@ class GeometricMultigridPoissonSolver:
 
     LEVEL_ARRAYS = {"codes": (0, np.uint8), "band": (1, np.int32), "band_diag": (2, np.uint8), "rows": (3, np.float32), "chunks": (4, np.int32),
                     "plane_blocks": (5, np.int32), "pure_even": (6, np.int32), "pure_odd": (7, np.int32), "mixed_even": (8, np.int32),
-                    "mixed_odd": (9, np.int32), "tile_bnd_start": (10, np.int32), "group_info": (11, np.int32), "group_update_entry": (12, np.int32),
-                    "group_update_cell": (13, np.int32), "group_neighbours": (14, np.uint16), "group_read_cell": (15, np.int32)}
+                    "mixed_odd": (9, np.int32), "tile_bnd_start": (10, np.int32), "box_info": (11, np.int32), "box_codes": (12, np.uint8),
+                    "box_general": (13, np.int32)}
 
     def level_array(self, level, name):
         """mgps_level_array: one of the set-up arrays of a level as it sits on the device (tests / tools)."""

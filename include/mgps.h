@@ -143,9 +143,9 @@ int mgps_device_count(int *count);
 /* Introspection for tests and tools: the set-up arrays of level `level` as they sit on the device.  `which`:
  * 0 cell codes (u8, nx*ny*nz), 1 band list in device order (i32), 2 band diagonals (u8), 3 operator rows of the general
  * BOUNDARY cells (f32, 7 x count SoA), 4 activity chunks (i32), 5 plane blocks (i32), 6 / 7 pure tiles even / odd (i32),
- * 8 / 9 mixed tiles even / odd (i32), 10 per-tile start of the general BOUNDARY cells (i32), 11..15 the groups of the fused
- * band stage: info (i32, 8 per group), update entries (i32), update cells (i32), neighbours (u16, 6 per update node),
- * read-only cells (i32).  *count = number of elements; out == NULL asks for the count only. */
+ * 8 / 9 mixed tiles even / odd (i32), 10 per-tile start of the general BOUNDARY cells (i32), 11..13 the boxes of the fused
+ * band stage: info (i32, 8 per group), region cell codes (u8), general entries (i32, 2 per entry).
+ * *count = number of elements; out == NULL asks for the count only. */
 int mgps_level_array(mgps_solver *h, int level, int which, void *out, int64_t *count);
 
 /* ---- domain expansion: host arrays --------------------------------------------------------
@@ -190,6 +190,14 @@ int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *ou
  * pass by pass on a seeded grid -- the two must agree bit for bit.  Returns the group and node counts. */
 int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
                                      int64_t *out_nodes);
+/* host self-check of the box form of the fused band stage (round 3; what single-device solvers run): builds the level's
+ * boxes for `depth` passes, verifies their structure and replays the three uses of launchBandBox group by group against
+ * pass-by-pass band smoothing and a full Jacobi sweep on a seeded grid, bit for bit: the plain stage, the closure stage
+ * (band passes + the sweep's values on the band closure) and the plain stage fed from the closure stage's snapshot.
+ * wx / wy / wz: optional face weights of level 0 (host arrays, the layout mgps_create takes) so that general BOUNDARY
+ * cells take part; NULL = unit weights.  Returns the group count, the sum of the region sizes and the general entries. */
+int mgps_hierarchy_check_band_boxes(const mgps_hierarchy *hier, int level, int depth, const float *wx, const float *wy, const float *wz,
+                                    int64_t *out_groups, int64_t *out_region_cells, int64_t *out_general);
 int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier);
 /* x = A_coarsest^{-1} b on the host, grids of the coarsest level's size (MG.cpp:669-692) */
 int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b);

@@ -114,6 +114,27 @@ def test_fused_band_groups_replay(kind, g, depth):
         assert (groups > 0) == (nband > 0) and nodes >= nband
 
 
+@pytest.mark.parametrize("kind,g", KINDS + [("solid", 40), ("solid", 72), ("simple", 100)])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_band_boxes_replay(kind, g, depth):
+    """Host side of the box form of the fused band stage (what single-device solvers run since round 3): every closure cell
+    owned by exactly one box, regions within the workgroup budget, and the group-by-group replay of all three uses of the
+    kernel -- plain stage, closure stage (band passes + the sweep's values on the band closure), plain stage fed from the
+    closure stage's snapshot -- bit-identical to pass-by-pass band smoothing and a full Jacobi sweep (Ops.h:524-619, 262-367).
+    Level 0 runs with the domain's face weights, so the general BOUNDARY cells (operator rows) take part."""
+    lab, w, off, lev, dx = make_domain(kind, g)
+    H = G.Hierarchy(lab, lev)
+    any_general = False
+    for l in range(H.levels):
+        nband = len(H.band_cells(l))
+        groups, cells, general = H.check_band_boxes(l, depth, w if l == 0 else None)
+        assert (groups > 0) == (nband > 0) and cells >= nband
+        any_general = any_general or general > 0
+        if l == 0:  # and with unit weights on the same labels
+            H.check_band_boxes(l, depth)
+    assert any_general == (kind != "simple")
+
+
 def test_hierarchy_non_cubic(oracle):
     bl = np.full((20, 12, 28), D.INTERIOR, dtype=np.uint8)
     bl[-4:] = D.DIRICHLET
