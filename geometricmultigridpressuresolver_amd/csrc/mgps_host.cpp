@@ -1105,7 +1105,7 @@ namespace {
 
 struct BoxTileOut {
     std::vector<int32_t> info, general;
-    std::vector<uint8_t> codes;
+    std::vector<uint32_t> list;
 };
 
 }  // namespace
@@ -1269,30 +1269,71 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
                     stack.push_back(Lh);
                     continue;
                 }
+                if (rx > 31 || ry > 31 || rz > 31) {  // (5 bits per coordinate; O grown by depth + 1 is at most 26 wide)
+                    broken = true;
+                    return;
+                }
+                // Lists in region order (k, j, i) per category: band cells by ring 0 .. depth, closure-output cells, what the
+                // plain mode reads besides, what only the closure mode reads
+                enum { kCatOut = kBandMaxDepth + 1, kCatReadPlain, kCatReadFar, kCats };
+                auto catOf = [&](int wi, int wj, int wk, bool &zero) {
+                    const size_t w = size_t((wk * E + wj) * E + wi);
+                    zero = false;
+                    const uint8_t c = cls[w];
+                    if (c == kBoxSkip) return -1;
+                    if (fl[w] & 2) {
+                        const int ring = ringOf(wi, wj, wk);
+                        return ring <= D ? ring : int(kCatReadFar);
+                    }
+                    if (c == kBoxFrozenOut) return int(kCatOut);
+                    if (c == kBoxFrozenFar) return int(kCatReadFar);
+                    zero = c == kBoxZero;
+                    return int(kCatReadPlain);
+                };
+                int count[kCats] = {0};
+                for (int wk = rlo[2]; wk <= rhi[2]; ++wk)
+                    for (int wj = rlo[1]; wj <= rhi[1]; ++wj)
+                        for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                            bool zero;
+                            const int c = catOf(wi, wj, wk, zero);
+                            if (c >= 0) ++count[c];
+                        }
+                const int listBase = int(T.list.size());
+                int cum[kBandMaxDepth + 1], total = 0;
+                {
+                    int run = 0;
+                    for (int r = 0; r <= kBandMaxDepth; ++r) {
+                        run += count[r];
+                        cum[r] = run;
+                    }
+                    for (int q = 0; q < kCats; ++q) total += count[q];
+                }
                 const int32_t origin = int32_t(d.idx(oi + rlo[0], oj + rlo[1], ok + rlo[2]));
-                const int32_t inf[kBoxInfoInts] = {origin, rx | (ry << 8) | (rz << 16), int32_t(T.codes.size()), int32_t(T.general.size() / 2), gen,
+                const int32_t inf[kBoxInfoInts] = {origin, rx | (ry << 8) | (rz << 16), listBase, 0, int32_t(T.general.size() / 2), gen, 0, total,
+                                                   cum[0], cum[1], cum[2], cum[3], cum[4], count[kCatOut],
                                                    (olo[0] - rlo[0]) | ((olo[1] - rlo[1]) << 8) | ((olo[2] - rlo[2]) << 16),
-                                                   (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16), nodes};
+                                                   (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16)};
                 T.info.insert(T.info.end(), inf, inf + kBoxInfoInts);
                 for (int wk = rlo[2]; wk <= rhi[2]; ++wk)
                     for (int wj = rlo[1]; wj <= rhi[1]; ++wj)
                         for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                            bool zero;
+                            const int c = catOf(wi, wj, wk, zero);
+                            if (c < 0) continue;
                             const size_t w = size_t((wk * E + wj) * E + wi);
-                            const bool in = wi >= mlo[0] && wi <= mhi[0] && wj >= mlo[1] && wj <= mhi[1] && wk >= mlo[2] && wk <= mhi[2];  // (always: R lies in O grown)
-                            uint8_t c = in ? cls[w] : uint8_t(kBoxSkip);
-                            const int ring = std::min(ringOf(wi, wj, wk), 7);
-                            if (c != kBoxSkip && (fl[w] & 2)) {
+                            const uint32_t coords = uint32_t(wi - rlo[0]) | (uint32_t(wj - rlo[1]) << 5) | (uint32_t(wk - rlo[2]) << 10);
+                            uint32_t code = c == kCatOut ? uint32_t(kBoxFrozenOut) : c == kCatReadFar ? uint32_t(kBoxFrozenFar) : zero ? uint32_t(kBoxZero) : uint32_t(kBoxFrozen);
+                            const uint32_t ring = uint32_t(std::min(ringOf(wi, wj, wk), 7));
+                            if (c <= kBandMaxDepth) {
                                 const int dg = L.bandDiag[size_t(ent[w])];
-                                c = dg == 0 ? uint8_t(kBoxGeneral) : uint8_t(kBoxSimple + dg);
-                                if (dg == 0 && ring <= D) {
-                                    const int node = ((wk - rlo[2]) * ry + (wj - rlo[1])) * rx + (wi - rlo[0]);
-                                    T.general.push_back(node | (ring << 16));
+                                code = dg == 0 ? uint32_t(kBoxGeneral) : uint32_t(kBoxSimple + dg);
+                                if (dg == 0) {
+                                    T.general.push_back(int32_t(T.list.size()) - listBase);
                                     T.general.push_back(ent[w]);
                                 }
                             }
-                            T.codes.push_back(uint8_t(c | (ring << 4)));
+                            T.list.push_back(coords | (code << 16) | (ring << 20));
                         }
-                while (T.codes.size() & 3) T.codes.push_back(0);
             }
         }
     }, 8);
@@ -1302,25 +1343,25 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
         return;
     }
     // concatenate in tile order; the per-tile offsets become global ones
-    std::vector<size_t> gAt(size_t(nt) + 1, 0), cAt(size_t(nt) + 1, 0), nAt(size_t(nt) + 1, 0);
+    std::vector<size_t> gAt(size_t(nt) + 1, 0), uAt(size_t(nt) + 1, 0), nAt(size_t(nt) + 1, 0);
     for (int64_t t = 0; t < nt; ++t) {
         gAt[size_t(t) + 1] = gAt[size_t(t)] + tiles[size_t(t)].info.size() / kBoxInfoInts;
-        cAt[size_t(t) + 1] = cAt[size_t(t)] + tiles[size_t(t)].codes.size();
+        uAt[size_t(t) + 1] = uAt[size_t(t)] + tiles[size_t(t)].list.size();
         nAt[size_t(t) + 1] = nAt[size_t(t)] + tiles[size_t(t)].general.size() / 2;
     }
     out.info.resize(gAt.back() * kBoxInfoInts);
-    out.codes.resize(cAt.back());
+    out.list.resize(uAt.back());
     out.general.resize(nAt.back() * 2);
     parallelFor(nt, [&](int64_t t0, int64_t t1) {
         for (int64_t t = t0; t < t1; ++t) {
             const BoxTileOut &T = tiles[size_t(t)];
-            std::copy(T.codes.begin(), T.codes.end(), out.codes.begin() + ptrdiff_t(cAt[size_t(t)]));
+            std::copy(T.list.begin(), T.list.end(), out.list.begin() + ptrdiff_t(uAt[size_t(t)]));
             std::copy(T.general.begin(), T.general.end(), out.general.begin() + ptrdiff_t(2 * nAt[size_t(t)]));
             for (size_t g = 0; g < T.info.size() / kBoxInfoInts; ++g) {
                 int32_t *dst = out.info.data() + (gAt[size_t(t)] + g) * kBoxInfoInts;
                 std::copy(T.info.begin() + ptrdiff_t(g * kBoxInfoInts), T.info.begin() + ptrdiff_t((g + 1) * kBoxInfoInts), dst);
-                dst[2] += int32_t(cAt[size_t(t)]);
-                dst[3] += int32_t(nAt[size_t(t)]);
+                dst[2] += int32_t(uAt[size_t(t)]);
+                dst[4] += int32_t(nAt[size_t(t)]);
             }
         }
     }, 64);
@@ -2344,52 +2385,68 @@ try {
     auto runGroups = [&](bool closure, const std::vector<float> &src, std::vector<float> &dst, std::vector<float> *snap) -> int {
         const int H = depth + (closure ? 1 : 0);
         std::vector<float> v0, v1;
-        std::vector<int32_t> genOf;
+        std::vector<uint8_t> present;
+        std::vector<int32_t> rowOf;
         for (size_t gI = 0; gI < bx.groups(); ++gI) {
             const int32_t *gi = bx.info.data() + kBoxInfoInts * gI;
-            const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, rz = gi[1] >> 16, nodes = gi[7];
-            if (nodes != rx * ry * rz || nodes > kBoxMaxNodes || gi[4] > kBoxMaxGeneral) return fail(MGPS_ERR_HIERARCHY, "band box exceeds the workgroup budget");
-            const uint8_t *code = bx.codes.data() + gi[2];
-            const int loff[6] = {-1, 1, -rx, rx, -rx * ry, rx * ry};
-            auto cellOf = [&](int nd) { return ptrdiff_t(gi[0]) + (nd % rx) + ptrdiff_t((nd / rx) % ry) * sy + ptrdiff_t(nd / (rx * ry)) * sz; };
-            v0.assign(size_t(nodes), 0.f);
-            genOf.assign(size_t(nodes), -1);
-            for (int q = 0; q < gi[4]; ++q) {
-                const int32_t e0 = bx.general[2 * size_t(gi[3] + q)], row = bx.general[2 * size_t(gi[3] + q) + 1];
-                const int nd = e0 & 0xffff, ring = e0 >> 16;
-                if (nd >= nodes || (code[nd] & 15) != kBoxGeneral || (code[nd] >> 4) != ring || row < 0 || size_t(row) >= nb || L.bandDev[size_t(row)] != cellOf(nd))
+            const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, rz = gi[1] >> 16, nodes = rx * ry * rz;
+            const int nList = gi[7], ngen = gi[5];
+            if (nodes > kBoxMaxNodes || ngen > kBoxMaxGeneral || rx > 31 || ry > 31 || rz > 31 || nList > kBoxMaxNodes)
+                return fail(MGPS_ERR_HIERARCHY, "band box exceeds the workgroup budget");
+            const uint32_t *U = bx.list.data() + gi[2];
+            auto nodeOf = [&](uint32_t e) { return int((((e >> 10) & 31u) * unsigned(ry) + ((e >> 5) & 31u)) * unsigned(rx) + (e & 31u)); };
+            auto cellOf = [&](uint32_t e) { return ptrdiff_t(gi[0]) + ptrdiff_t(e & 31u) + ptrdiff_t((e >> 5) & 31u) * sy + ptrdiff_t((e >> 10) & 31u) * sz; };
+            v0.assign(size_t(nodes), NAN);  // (a pass that reads a cell nobody staged propagates the NaN into the comparison)
+            present.assign(size_t(nodes), 0);
+            rowOf.assign(size_t(nList), -1);
+            for (int q = 0; q < ngen; ++q) {
+                const int32_t k = bx.general[2 * size_t(gi[4] + q)], row = bx.general[2 * size_t(gi[4] + q) + 1];
+                if (k < 0 || k >= nList || ((U[k] >> 16) & 15u) != kBoxGeneral || row < 0 || size_t(row) >= nb || L.bandDev[size_t(row)] != cellOf(U[k]))
                     return fail(MGPS_ERR_HIERARCHY, "band box: general entry does not match its cell");
-                genOf[size_t(nd)] = row;
+                rowOf[size_t(k)] = row;
             }
-            for (int nd = 0; nd < nodes; ++nd) {
-                const int cl = code[nd] & 15, ring = code[nd] >> 4;
-                const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
-                const ptrdiff_t c = cellOf(nd);
-                if (cl != kBoxSkip) {  // the byte must tell the truth about the cell
-                    if (c < 0 || size_t(c) >= n) return fail(MGPS_ERR_HIERARCHY, "band box: region cell outside the grid");
-                    const bool act = isActive(lab[c]);
-                    if (band != isBand(c) || (cl == kBoxZero) != !act) return fail(MGPS_ERR_HIERARCHY, "band box: cell class does not match the cell");
-                    if (band && cl != kBoxGeneral && cl - kBoxSimple != int(L.bandDiag[size_t(entryOfCell[size_t(c)])]))
-                        return fail(MGPS_ERR_HIERARCHY, "band box: diagonal mismatch");
-                    if (band && cl == kBoxGeneral && ring <= depth && genOf[size_t(nd)] < 0) return fail(MGPS_ERR_HIERARCHY, "band box: general cell without row");
-                }
-                const bool need = closure ? (cl != kBoxSkip && cl != kBoxZero) : (cl == kBoxFrozen || cl == kBoxFrozenOut || (band && ring <= depth));
+            int ringCount[kBandMaxDepth + 1] = {0}, nOut = 0, lastNode = -1;
+            for (int k = 0; k < nList; ++k) {
+                const uint32_t e = U[k], cl = (e >> 16) & 15u, ring = e >> 20;
+                const int nd = nodeOf(e);
+                const ptrdiff_t c = cellOf(e);
+                if ((e & 31u) >= unsigned(rx) || ((e >> 5) & 31u) >= unsigned(ry) || ((e >> 10) & 31u) >= unsigned(rz) || c < 0 || size_t(c) >= n || present[size_t(nd)]++ ||
+                    nd <= lastNode)
+                    return fail(MGPS_ERR_HIERARCHY, "band box: bad list entry");
+                lastNode = nd;
+                const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6, act = isActive(lab[c]);
+                if ((cl == kBoxZero) != !act || cl == kBoxSkip || (band && (!isBand(c) || int(ring) > depth)) || (!band && cl != kBoxFrozenFar && isBand(c)) ||
+                    (cl == kBoxFrozenOut && ring != 0))
+                    return fail(MGPS_ERR_HIERARCHY, "band box: cell class does not match the cell");
+                if (band && cl != kBoxGeneral && int(cl) - kBoxSimple != int(L.bandDiag[size_t(entryOfCell[size_t(c)])]))
+                    return fail(MGPS_ERR_HIERARCHY, "band box: diagonal mismatch");
+                if (band && cl == kBoxGeneral && rowOf[size_t(k)] < 0) return fail(MGPS_ERR_HIERARCHY, "band box: general cell without row");
+                if (band)
+                    for (int r = int(ring); r <= kBandMaxDepth; ++r) ++ringCount[r];
+                nOut += cl == kBoxFrozenOut;
+                const bool need = cl != kBoxZero && (closure || cl != kBoxFrozenFar);
                 if (need) v0[size_t(nd)] = src[size_t(c)];
+                else if (cl == kBoxZero) v0[size_t(nd)] = 0.f;
             }
+            for (int r = 0; r <= kBandMaxDepth; ++r)
+                if (gi[8 + r] != ringCount[r]) return fail(MGPS_ERR_HIERARCHY, "band box: ring counts");
+            if (gi[13] != nOut) return fail(MGPS_ERR_HIERARCHY, "band box: closure-output count");
             v1 = v0;
-            auto nodeUpdate = [&](const std::vector<float> &v, int nd, int cl) -> float {
-                const int li = nd % rx, lj = (nd / rx) % ry, lk = nd / (rx * ry);
-                if (li == 0 || lj == 0 || lk == 0 || li == rx - 1 || lj == ry - 1 || lk == rz - 1) return NAN;  // an updated cell on the region's rim
-                const float xc = v[size_t(nd)], bc = b[size_t(cellOf(nd))];
+            const int loff[6] = {-1, 1, -rx, rx, -rx * ry, rx * ry};
+            auto nodeUpdate = [&](const std::vector<float> &v, int k) -> float {
+                const uint32_t e = U[k], cl = (e >> 16) & 15u;
+                const int nd = nodeOf(e);
+                const unsigned li = e & 31u, lj = (e >> 5) & 31u, lk = (e >> 10) & 31u;
+                if (li == 0 || lj == 0 || lk == 0 || int(li) == rx - 1 || int(lj) == ry - 1 || int(lk) == rz - 1) return NAN;  // an updated cell on the region's rim
+                const float xc = v[size_t(nd)], bc = b[size_t(cellOf(e))];
                 if (cl == kBoxGeneral) {
-                    const int32_t t = genOf[size_t(nd)];
-                    const float *r = L.rows.data() + t;
+                    const float *r = L.rows.data() + rowOf[size_t(k)];
                     float acc = 0.f;
                     for (int q = 0; q < 6; ++q) acc -= r[size_t(q) * nb] * v[size_t(nd + loff[q])];
                     const float diag = r[6 * nb], lap = acc + diag * xc;
                     return xc + omega * ((bc - lap) / diag);
                 }
-                const float diag = cl == kBoxFrozenOut ? 6.f : float(cl - kBoxSimple);
+                const float diag = cl == kBoxFrozenOut ? 6.f : float(int(cl) - kBoxSimple);
                 const float lap = diag * xc - (v[size_t(nd - 1)] + v[size_t(nd + 1)] + v[size_t(nd - rx)] + v[size_t(nd + rx)] + v[size_t(nd - rx * ry)] + v[size_t(nd + rx * ry)]);
                 return xc + omega * ((bc - lap) * (1.f / diag));
             };
@@ -2397,26 +2454,26 @@ try {
                 const std::vector<float> &s = (p & 1) ? v0 : v1;
                 std::vector<float> &o = (p & 1) ? v1 : v0;
                 const bool last = closure && p == H;
-                for (int nd = 0; nd < nodes; ++nd) {
-                    const int cl = code[nd] & 15, ring = code[nd] >> 4;
+                for (int k = 0; k < nList; ++k) {
+                    const uint32_t cl = (U[k] >> 16) & 15u, ring = U[k] >> 20;
                     const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
-                    if (ring > H - p || !(band || (last && cl == kBoxFrozenOut))) continue;
-                    const float r = nodeUpdate(s, nd, cl);
-                    if (r != r) return fail(MGPS_ERR_HIERARCHY, "band box: a pass reads outside its region");
-                    o[size_t(nd)] = r;
+                    if (!((band && int(ring) <= H - p) || (last && cl == kBoxFrozenOut))) continue;
+                    const float r = nodeUpdate(s, k);
+                    if (r != r) return fail(MGPS_ERR_HIERARCHY, "band box: a pass reads a cell outside its list");
+                    o[size_t(nodeOf(U[k]))] = r;
                 }
             }
             const std::vector<float> &fin = (H & 1) ? v1 : v0;
-            for (int nd = 0; nd < nodes; ++nd) {
-                const int cl = code[nd] & 15, ring = code[nd] >> 4;
+            for (int k = 0; k < nList; ++k) {
+                const uint32_t cl = (U[k] >> 16) & 15u, ring = U[k] >> 20;
                 const bool band = cl >= kBoxGeneral && cl <= kBoxSimple + 6;
                 if (ring != 0 || !(band || (closure && cl == kBoxFrozenOut))) continue;
-                const ptrdiff_t c = cellOf(nd);
-                dst[size_t(c)] = fin[size_t(nd)];
-                if (snap) (*snap)[size_t(c)] = fin[size_t(nd)];
+                const ptrdiff_t c = cellOf(U[k]);
+                dst[size_t(c)] = fin[size_t(nodeOf(U[k]))];
+                if (snap) (*snap)[size_t(c)] = fin[size_t(nodeOf(U[k]))];
                 if (closure) ++owned[size_t(c)];
             }
-            if (closure) regionCells += nodes;
+            if (closure) regionCells += nList;
         }
         return MGPS_OK;
     };

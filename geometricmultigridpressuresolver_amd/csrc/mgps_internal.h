@@ -155,14 +155,24 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
 // Fused band stage, box form (whole-grid levels; round 3).  The graph form above spends 20 B of metadata per update node
 // and gathers every value by index (PMC: 131 B per band cell at 1024^3 against 16 algorithmic).  Here a group is a BOX of the
 // grid: the owned box O (a piece of a 16^3 tile: the bounding box of the tile's band-closure cells, halved until it fits)
-// and the region R around it that its passes touch (inside O dilated by depth + 1).  The workgroup loads R's needed cells
-// as row segments into a dense LDS block -- neighbours are index +-1, +-rx, +-rx*ry, no ids -- and one byte per region cell
-// says what the cell is (class) and how far outside O it lies (ring = Chebyshev distance, so that pass p recomputes the band
-// cells with ring <= H - p):
-//   class 0  not needed            1  frozen active cell read by the band passes     2  inactive neighbour (value 0)
-//         3  general band cell (row list)   4 + d  simple band cell, diagonal d (INTERIOR band cells: 10)
-//        11  frozen cell of O next to a band cell: gets the closure pass's Jacobi value (ring 0)
-//        12  frozen cell needed by the closure pass only
+// and the region R around it that its passes touch (inside O dilated by depth + 1, every extent < 32).  The values of R
+// live in a dense LDS block -- the neighbours of region cell n are n +- 1, n +- rx, n +- rx*ry, no ids -- and the
+// workgroup walks compact lists of the region cells that matter (4 B per update cell, 2 B per read-only cell):
+//   ONE list per group, 4 B per entry, in the region's own order (k, j, i) -- so that consecutive lanes stage consecutive
+//   cells of a row, like a dense block would, without the cells that need nothing:
+//       li | lj << 5 | lk << 10 | class << 16 | ring << 20        (ring = Chebyshev distance from O, at most 7)
+//   class 3      general band cell with ring <= depth (operator row: see `general`)
+//   class 4 + d  simple band cell with ring <= depth, diagonal d (INTERIOR band cells: 10); pass p recomputes the band
+//                cells with ring <= H - p
+//   class 11     closure-output cell: active cell of O next to a band cell; the closure mode's last pass gives it its Jacobi value
+//   class 1      frozen active cell next to a band cell of ring <= depth - 1: read by both modes
+//   class 2      inactive neighbour of a band cell: the value is 0, nothing is loaded
+//   class 12     read by the closure mode only: band cells of ring depth + 1, frozen cells next to a ring-depth band cell or
+//                to a closure-output cell
+//   A thread takes entries tid, tid + 1024, ...: all entries of a group are fetched in one batch of loads, all values in a
+//   second one (a kernel of this size lives on its chain of dependent memory round trips: rocprofv3 SQ_WAIT_ANY 66 %).
+//   (Tried: the same list sorted by ring, so that a pass walks a prefix -- the staging loads of a wave then hop between
+//   rows and the kernel ran 1.5 x slower, 470 vs 312 us per closure stage at 1024^3.)
 // Two modes of the kernel (launchBandBox):
 //   plain    depth band passes (H = depth); the final values of O's band cells go to `dst`
 //   closure  depth band passes + ONE full-domain Jacobi step evaluated on the band closure of O (H = depth + 1): the
@@ -171,27 +181,29 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
 //            into x -- and the same values land in a snapshot grid from which the band stage AFTER the sweep reads
 //            (that one then writes y in place: no workgroup reads what another one writes).
 constexpr int kBoxMaxNodes = 4096;    // region cells of a group: two LDS copies of their values
-constexpr int kBoxThreads = 512;
+constexpr int kBoxThreads = 1024;
 constexpr int kBoxSlots = kBoxMaxNodes / kBoxThreads;
 constexpr int kBoxMaxGeneral = 512;   // general band cells of a region (their rows sit in LDS)
-constexpr int kBoxInfoInts = 8;
+constexpr int kBoxInfoInts = 16;
 enum BoxNode : uint8_t { kBoxSkip = 0, kBoxFrozen = 1, kBoxZero = 2, kBoxGeneral = 3, kBoxSimple = 4, kBoxFrozenOut = 11, kBoxFrozenFar = 12 };
+// info: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first entry in `list`, [3] unused,
+// [4] first entry in `general`, [5] general entries, [6] unused, [7] list entries, [8 + r] band cells with ring <= r
+// (r = 0..4; r > depth repeats), [13] closure-output cells, [14] origin of O inside the region (packed like [1]),
+// [15] extents of O (packed)
 struct BandBoxes {
     int depth = 0;
-    // per group kBoxInfoInts ints: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first byte in
-    // `codes`, [3] first entry in `general`, [4] number of general entries, [5] origin of O inside the region (packed like
-    // [1]), [6] extents of O (packed), [7] rx * ry * rz
     RawVec<int32_t> info;
-    RawVec<uint8_t> codes;     // per group rx*ry*rz bytes (k, j, i order; padded to a multiple of 4): class | ring << 4
-    RawVec<int32_t> general;   // per general band cell with ring <= depth two ints: region cell | ring << 16, row index
+    RawVec<uint32_t> list;
+    RawVec<int32_t> general;   // per general band cell with ring <= depth two ints: its position in the group's list, row index
     size_t groups() const { return info.size() / kBoxInfoInts; }
 };
 void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out);
 struct BandBoxesDev {
     int depth = 0, ngroups = 0;
     int32_t *info = nullptr, *general = nullptr;
-    uint8_t *codes = nullptr;
-    size_t codeBytes = 0, generalInts = 0;
+    uint32_t *list = nullptr;
+    size_t listCount = 0, generalInts = 0;
+    bool anyGeneral = false;
 };
 
 // The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
@@ -460,12 +472,12 @@ int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, in
 // the boxes of the fused band stage (BandBoxes), built over the list of tiles that can hold a band-closure cell; counts
 // and offsets are indexed by list position
 int launchBoxTileList(void *stream, const Dims &d, const int32_t *tileStart, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
+// counts / at: three arrays each (groups, list entries, general entries)
 int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *nGroups, int32_t *nCodes,
-                         int32_t *nGeneral, int *broken);
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken);
 int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *groupAt,
-                        const int32_t *codeAt, const int32_t *generalAt, int32_t *info, uint8_t *codes, int32_t *general, int *broken);
+                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *const at[3],
+                        int32_t *info, uint32_t *list, int32_t *general, int *broken);
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)

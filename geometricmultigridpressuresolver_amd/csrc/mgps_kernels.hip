@@ -632,10 +632,10 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 
 // ---------------------------------------------------------------------------------------------
 // The fused band stage, box form (BandBoxes in mgps_internal.h; whole-grid levels).  A workgroup takes one group: the
-// region R (a box of the grid, <= kBoxMaxNodes cells) goes into a dense LDS block -- the six neighbours of node n are
-// n +- 1, n +- rx, n +- rx*ry, no ids -- filled from row segments of `src`; one byte per region cell (class | ring << 4)
-// says what the cell is and how far outside the owned box it lies.  Pass p recomputes the band cells with ring <= H - p
-// (redundant work near the rim instead of a round trip through HBM per pass), the arithmetic of bandComputeKernel:
+// values of its region R (a box of the grid, <= kBoxMaxNodes cells) sit in a dense LDS block -- the six neighbours of
+// region cell n are n +- 1, n +- rx, n +- rx*ry, no ids -- and the threads walk the group's list of the region cells that
+// matter (4 B each, region order).  Pass p recomputes the band cells with ring <= H - p (redundant work near the rim
+// instead of a round trip through HBM per pass), with the arithmetic of bandComputeKernel:
 //   CLOSURE = false  H = depth band passes (Ops.h:524-619 x depth); the owned box's band cells go to `dst`.  Nothing else
 //                    may read `dst` cells in this launch: either src is another grid (a snapshot, or the stage runs out
 //                    of place into a scratch grid that bandBoxCopyKernel copies back), never src == dst;
@@ -645,117 +645,137 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 //                    over the un-smoothed grid first; this launch overwrites its output on the band closure and leaves
 //                    the same values in `snap`, from which the stage after the sweep reads (then dst = the sweep's
 //                    output itself: written in place, no scatter anywhere).
-// General band cells (operator rows): at most kBoxMaxGeneral per group, rows and rhs staged in LDS, one thread each.
+// General band cells (operator rows): at most kBoxMaxGeneral per group, rows and rhs staged in LDS, one thread each
+// (GEN: the level has any; levels without them keep 18 KB of LDS free).
 // DOT: the workgroup leaves sum (new - old) * b over the cells it writes (old = dotOld at that cell).
+// What was tried on the way (1024^3, us per closure / plain stage): one code byte per region cell with every thread walking
+// the dense block 312 / 259; lists sorted by ring (a pass = a prefix) with separate read lists 684 / 386 (longer chain of
+// dependent loads), merged 812 / 688 at 512 threads x 8 entries (31 registers spilled), 470 / 337 at 1024 x 4 (the staging
+// loads of a wave hop between rows); this form 369 / 294 with a third of the first form's HBM traffic (rocprofv3 PMC at
+// 512^3: 79 / 65 B per band cell against 178 / 92) -- what bounds it is the chain info -> list -> values -> passes with two
+// workgroups per CU in flight, not bytes.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int boxDiv(int n, int dv, float rcp)  // n / dv for 0 <= n < 2^20 (float estimate, fixed up)
-{
-    int q = int(float(n) * rcp);
-    q -= (q * dv > n) ? 1 : 0;
-    q += ((q + 1) * dv <= n) ? 1 : 0;
-    return q;
-}
 __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
 
-template <class TX, bool CLOSURE, bool DOT>
-__global__ __launch_bounds__(kBoxThreads, 6) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
-                                                              TX *__restrict__ snap, const int32_t *__restrict__ info,
-                                                              const uint8_t *__restrict__ codes, const int32_t *__restrict__ general, float omega,
-                                                              int depth, MixScale ms, double *__restrict__ dotPartials, const TX *__restrict__ dotOld)
+template <class TX, bool CLOSURE, bool DOT, bool GEN>
+__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+                                                              TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                              const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
+                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
+    constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
     __shared__ float val[2][kBoxMaxNodes];
-    __shared__ float grow[7][kBoxMaxGeneral];
-    __shared__ float gbv[kBoxMaxGeneral];
-    __shared__ uint16_t gnode[kBoxMaxGeneral];  // region cell | ring << 12
-    const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
-    const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, nodes = gi[7], ngen = gi[4];
-    const int sxy = rx * ry;
-    const float rrx = 1.f / float(rx), rsxy = 1.f / float(sxy);
-    const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny, origin = gi[0];
-    const uint8_t *code = codes + gi[2];
+    __shared__ float grow[7][kGenRows];
+    __shared__ float gbv[kGenRows];
+    __shared__ uint16_t gnode[kGenRows], gring[kGenRows];  // region cell and ring
+    // the group's description is wave-uniform: scalar registers (addresses below: scalar base + one 32-bit vector offset)
+    const int32_t *gip = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
+    int gi[kBoxInfoInts];
+#pragma unroll
+    for (int q = 0; q < kBoxInfoInts; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
+    const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, sxy = rx * ry;
+    // a region cell's address = the region's origin + a 32-bit offset inside the region (it stays below 32 planes)
+    const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
+    const ptrdiff_t origin = gi[0];
+    src += origin;
+    b += origin;
+    dst += origin;
+    if (CLOSURE && snap) snap += origin;
+    if (DOT) dotOld += origin;
+    const uint32_t *U = list + gi[2];
+    const int ngen = GEN ? gi[5] : 0, nList = gi[7];
     const int H = depth + (CLOSURE ? 1 : 0);
     const float bm = kMixed ? mixRhsScale(ms) : 1.f;
     const int tid = threadIdx.x;
-    auto cellOf = [&](int n) {
-        const int lk = boxDiv(n, sxy, rsxy), rem = n - lk * sxy, lj = boxDiv(rem, rx, rrx), li = rem - lj * rx;
-        return origin + li + lj * sy + lk * sz;
-    };
-    unsigned cd[kBoxSlots];
+    auto nodeOf = [&](uint32_t e) { return int(((e >> 10) & 31u) * unsigned(sxy) + ((e >> 5) & 31u) * unsigned(rx) + (e & 31u)); };
+    auto cellOf = [&](uint32_t e) { return (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz; };
+    // element c of a grid whose base is the region's origin: scalar base + 32-bit BYTE offset (the form the global_load /
+    // global_store instructions take with one vector register)
+    auto rd = [&](const TX *base, unsigned c) { return Cell<TX>::load1(reinterpret_cast<const TX *>(reinterpret_cast<const char *>(base) + c * unsigned(sizeof(TX)))); };
+    auto rdf = [&](const float *base, unsigned c) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + c * 4u); };
+    auto wr = [&](TX *base, unsigned c, float v) { Cell<TX>::store1(reinterpret_cast<TX *>(reinterpret_cast<char *>(base) + c * unsigned(sizeof(TX))), v); };
+    uint32_t ue[kBoxSlots];
     float bv[kBoxSlots];
-#pragma unroll
-    for (int m = 0; m < kBoxSlots; ++m) {
-        const int n = tid + m * kBoxThreads;
-        cd[m] = n < nodes ? code[n] : 0u;
-    }
     {
+        // first batch of loads: every list entry of this thread (and its general entry); second batch: every value
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const int k = tid + m * kBoxThreads;
+            ue[m] = k < nList ? U[k] : (uint32_t(kBoxSkip) << 16);
+        }
+        int32_t gk = 0, grw = 0;
+        if (GEN && tid < ngen) {
+            gk = general[2 * size_t(gi[4] + tid)];
+            grw = general[2 * size_t(gi[4] + tid) + 1];
+        }
+        // (unconditional loads -- a cell that needs none reads the region's origin cell and drops the value -- so that all of
+        // them leave in one batch: a branch per slot made the compiler wait for each load on its own)
         float xv[kBoxSlots];
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const unsigned cls = cd[m] & 15u, ring = cd[m] >> 4;
-            const bool band = boxBand(cls);
-            const bool need = CLOSURE ? (cls != kBoxSkip && cls != kBoxZero) : (cls == kBoxFrozen || cls == kBoxFrozenOut || (band && int(ring) <= depth));
-            const bool bneed = (band && cls != kBoxGeneral && int(ring) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
-            xv[m] = 0.f;
-            bv[m] = 0.f;
-            if (need || bneed) {
-                const ptrdiff_t c = cellOf(tid + m * kBoxThreads);
-                if (need) xv[m] = Cell<TX>::load1(src + c);
-                if (bneed) bv[m] = kMixed ? bm * b[c] : b[c];
-            }
-        }
-        if (tid < ngen) {
-            const int32_t e0 = general[2 * size_t(gi[3] + tid)], row = general[2 * size_t(gi[3] + tid) + 1];
-            const int nd = e0 & 0xffff;
-            gnode[tid] = uint16_t(nd | ((e0 >> 16) << 12));
-            const size_t nb = size_t(g.nbnd);
-#pragma unroll
-            for (int q = 0; q < 7; ++q) grow[q][tid] = g.rows[size_t(q) * nb + row];
-            const ptrdiff_t c = cellOf(nd);
-            gbv[tid] = kMixed ? bm * b[c] : b[c];
+            const unsigned cls = (ue[m] >> 16) & 15u;
+            const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
+            const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
+            const unsigned c = cellOf(ue[m]);
+            xv[m] = rd(src, need ? c : 0u);
+            bv[m] = rdf(b, bneed ? c : 0u);
         }
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const int n = tid + m * kBoxThreads;
-            if (n < nodes) {
+            const unsigned cls = (ue[m] >> 16) & 15u;
+            if (cls == kBoxSkip || cls == kBoxZero) xv[m] = 0.f;  // (class 12 in the plain mode: whatever was loaded, nobody reads it)
+            if (kMixed) bv[m] *= bm;
+        }
+        if (GEN && tid < ngen) {
+            const uint32_t e = U[gk];
+            gring[tid] = uint16_t(e >> 20);
+            gnode[tid] = uint16_t(nodeOf(e));
+            const size_t nb = size_t(g.nbnd);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) grow[q][tid] = g.rows[size_t(q) * nb + grw];
+            const unsigned c = cellOf(e);
+            gbv[tid] = kMixed ? bm * rdf(b, c) : rdf(b, c);
+        }
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m)
+            if (tid + m * kBoxThreads < nList) {
+                const int n = nodeOf(ue[m]);
                 val[0][n] = xv[m];
                 val[1][n] = xv[m];
             }
-        }
     }
     __syncthreads();
     for (int p = 1; p <= H; ++p) {
         const float *from = val[(p - 1) & 1];
         float *to = val[p & 1];
-        const int lim = H - p;
+        const int lim = H - p;  // the band cells with ring <= H - p
         const bool last = CLOSURE && p == H;
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const unsigned cls = cd[m] & 15u;
-            const int n = tid + m * kBoxThreads;
+            const unsigned cls = (ue[m] >> 16) & 15u;
             const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
-            if (int(cd[m] >> 4) <= lim && (simple || (last && cls == kBoxFrozenOut))) {
+            if ((simple && int(ue[m] >> 20) <= lim) || (last && cls == kBoxFrozenOut)) {
+                const int n = nodeOf(ue[m]);
                 const float xc = from[n];
-                const float diag = simple ? float(int(cls) - int(kBoxSimple)) : 6.f;
+                const float diag = cls == kBoxFrozenOut ? 6.f : float(int(cls) - int(kBoxSimple));
                 const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
                 to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
             }
         }
-        if (tid < ngen) {
-            const int nd = gnode[tid] & 0xfff;
-            if (int(gnode[tid] >> 12) <= lim) {
-                const float xc = from[nd];
-                float acc = 0.f;
-                acc -= grow[0][tid] * from[nd - 1];
-                acc -= grow[1][tid] * from[nd + 1];
-                acc -= grow[2][tid] * from[nd - rx];
-                acc -= grow[3][tid] * from[nd + rx];
-                acc -= grow[4][tid] * from[nd - sxy];
-                acc -= grow[5][tid] * from[nd + sxy];
-                const float diag = grow[6][tid];
-                const float lap = acc + diag * xc;
-                to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
-            }
+        if (GEN && tid < ngen && int(gring[tid]) <= lim) {
+            const int nd = gnode[tid];
+            const float xc = from[nd];
+            float acc = 0.f;
+            acc -= grow[0][tid] * from[nd - 1];
+            acc -= grow[1][tid] * from[nd + 1];
+            acc -= grow[2][tid] * from[nd - rx];
+            acc -= grow[3][tid] * from[nd + rx];
+            acc -= grow[4][tid] * from[nd - sxy];
+            acc -= grow[5][tid] * from[nd + sxy];
+            const float diag = grow[6][tid];
+            const float lap = acc + diag * xc;
+            to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
         }
         __syncthreads();
     }
@@ -763,17 +783,16 @@ __global__ __launch_bounds__(kBoxThreads, 6) void bandBoxKernel(GridP g, const T
     double acc = 0.0;
 #pragma unroll
     for (int m = 0; m < kBoxSlots; ++m) {
-        const unsigned cls = cd[m] & 15u;
-        if ((cd[m] >> 4) == 0u && (boxBand(cls) || (CLOSURE && cls == kBoxFrozenOut))) {
-            const int n = tid + m * kBoxThreads;
-            const ptrdiff_t c = cellOf(n);
-            const float v = fin[n];
+        const unsigned cls = (ue[m] >> 16) & 15u;
+        if ((ue[m] >> 20) == 0u && (boxBand(cls) || (CLOSURE && cls == kBoxFrozenOut))) {
+            const unsigned c = cellOf(ue[m]);
+            const float v = fin[nodeOf(ue[m])];
             if (DOT) {
                 const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
-                acc += (double(stored) - double(Cell<TX>::load1(dotOld + c))) * double(b[c]);
+                acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
             }
-            Cell<TX>::store1(dst + c, v);
-            if (CLOSURE && snap) Cell<TX>::store1(snap + c, v);
+            wr(dst, c, v);
+            if (CLOSURE && snap) wr(snap, c, v);
         }
     }
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
@@ -782,18 +801,15 @@ __global__ __launch_bounds__(kBoxThreads, 6) void bandBoxKernel(GridP g, const T
 // dst = src on the band cells of every owned box
 template <class TX>
 __global__ __launch_bounds__(kBoxThreads) void bandBoxCopyKernel(GridP g, const TX *__restrict__ src, TX *__restrict__ dst, const int32_t *__restrict__ info,
-                                                                const uint8_t *__restrict__ codes)
+                                                                const uint32_t *__restrict__ list)
 {
     const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
-    const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, nodes = gi[7], sxy = rx * ry;
-    const float rrx = 1.f / float(rx), rsxy = 1.f / float(sxy);
     const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny, origin = gi[0];
-    const uint8_t *code = codes + gi[2];
-    for (int n = threadIdx.x; n < nodes; n += kBoxThreads) {
-        const unsigned cdv = code[n];
-        if ((cdv >> 4) != 0u || !boxBand(cdv & 15u)) continue;
-        const int lk = boxDiv(n, sxy, rsxy), rem = n - lk * sxy, lj = boxDiv(rem, rx, rrx), li = rem - lj * rx;
-        const ptrdiff_t c = origin + li + lj * sy + lk * sz;
+    const uint32_t *U = list + gi[2];
+    for (int k = threadIdx.x; k < gi[7]; k += kBoxThreads) {
+        const uint32_t e = U[k];
+        if ((e >> 20) != 0u || !boxBand((e >> 16) & 15u)) continue;
+        const ptrdiff_t c = origin + ptrdiff_t(e & 31u) + ptrdiff_t((e >> 5) & 31u) * sy + ptrdiff_t((e >> 10) & 31u) * sz;
         dst[c] = src[c];
     }
 }
@@ -1809,7 +1825,12 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
 {
     const unsigned ng = unsigned(bx.ngroups);
     const bool dot = dotPartials != nullptr;
-#define MGPS_BOX_LAUNCH(C, D) bandBoxKernel<TX, C, D><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.codes, bx.general, omega, bx.depth, ms, dotPartials, dotOld)
+#define MGPS_BOX_LAUNCH2(C, D, G) bandBoxKernel<TX, C, D, G><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld)
+#define MGPS_BOX_LAUNCH(C, D)                            \
+    do {                                                 \
+        if (bx.anyGeneral) MGPS_BOX_LAUNCH2(C, D, true); \
+        else MGPS_BOX_LAUNCH2(C, D, false);              \
+    } while (0)
     if (closure) {
         if (dot) MGPS_BOX_LAUNCH(true, true);
         else MGPS_BOX_LAUNCH(true, false);
@@ -1818,6 +1839,7 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
         else MGPS_BOX_LAUNCH(false, false);
     }
 #undef MGPS_BOX_LAUNCH
+#undef MGPS_BOX_LAUNCH2
     return int(hipGetLastError());
 }
 }  // namespace
@@ -1837,8 +1859,8 @@ int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, cons
 {
     if (bx.ngroups <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (half) bandBoxCopyKernel<__half><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const __half *>(src), static_cast<__half *>(dst), bx.info, bx.codes);
-    else bandBoxCopyKernel<float><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const float *>(src), static_cast<float *>(dst), bx.info, bx.codes);
+    if (half) bandBoxCopyKernel<__half><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const __half *>(src), static_cast<__half *>(dst), bx.info, bx.list);
+    else bandBoxCopyKernel<float><<<unsigned(bx.ngroups), kBoxThreads, 0, s>>>(g, static_cast<const float *>(src), static_cast<float *>(dst), bx.info, bx.list);
     return int(hipGetLastError());
 }
 

@@ -656,10 +656,10 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
                                                                    const uint16_t *__restrict__ prefix, const int32_t *__restrict__ tileStart,
                                                                    const int32_t *__restrict__ bandEntry, const uint8_t *__restrict__ bandDiag, int depth,
                                                                    const int32_t *__restrict__ tiles, int32_t *__restrict__ nGroups,
-                                                                   int32_t *__restrict__ nCodes, int32_t *__restrict__ nGeneral,
-                                                                   const int32_t *__restrict__ groupAt, const int32_t *__restrict__ codeAt,
+                                                                   int32_t *__restrict__ nList, int32_t *__restrict__ nGeneral,
+                                                                   const int32_t *__restrict__ groupAt, const int32_t *__restrict__ listAt,
                                                                    const int32_t *__restrict__ generalAt, int32_t *__restrict__ info,
-                                                                   uint8_t *__restrict__ codes, int32_t *__restrict__ general, int *__restrict__ broken)
+                                                                   uint32_t *__restrict__ list, int32_t *__restrict__ general, int *__restrict__ broken)
 {
     extern __shared__ uint8_t sm[];
     const int D = depth, P = depth + 2, E = kTile + 2 * P, E2 = E * E, E3 = E2 * E;
@@ -732,8 +732,8 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
         }
     }
     const int off[6] = {-1, 1, -E, E, -E2, E2};
-    int groups = 0, codeBytes = 0, gens = 0;  // running totals of this tile (uniform across the workgroup)
-    const int gBase = FILL ? groupAt[blockIdx.x] : 0, cBase = FILL ? codeAt[blockIdx.x] : 0, nBase = FILL ? generalAt[blockIdx.x] : 0;
+    int groups = 0, lists = 0, gens = 0;  // running totals of this tile (uniform across the workgroup)
+    const int gBase = FILL ? groupAt[blockIdx.x] : 0, uBase = FILL ? listAt[blockIdx.x] : 0, nBase = FILL ? generalAt[blockIdx.x] : 0;
     while (true) {
         __syncthreads();
         if (sp == 0) break;
@@ -875,62 +875,107 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
             }
             continue;
         }
-        const int padded = (nodes + 3) & ~3;
-        if (FILL) {
-            // a thread owns a run of consecutive x-rows of R: (thread, position) order is the region's (k, j, i) order
-            const int R = ry * rz, rp = (R + kBoxBuildThreads - 1) / kBoxBuildThreads, r0 = min(R, tid * rp), r1 = min(R, r0 + rp);
-            uint8_t *cdst = codes + size_t(cBase + codeBytes);
-            int myGen = 0;
-            for (int r = r0; r < r1; ++r) {
-                const int wj = rlo[1] + r % ry, wk = rlo[2] + r / ry;
-                for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
-                    const int w = (wk * E + wj) * E + wi;
-                    if ((fl[w] & 2u) && cls[w] != kBoxSkip && ringOf(wi, wj, wk) <= D && bandDiag[bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)]] == 0) ++myGen;
-                }
+        if (rx > 31 || ry > 31 || rz > 31) {  // (5 bits per coordinate; O grown by depth + 1 is at most 26 wide)
+            if (tid == 0) *broken = 1;
+            continue;
+        }
+        // Lists in region order (k, j, i) per category: band cells by ring 0 .. depth, closure-output cells, what the plain mode
+        // reads besides, what only the closure mode reads.  A thread owns a run of consecutive x-rows of R: (thread, position)
+        // order is the region's order.
+        constexpr int kCatOut = kBandMaxDepth + 1, kCatReadPlain = kCatOut + 1, kCatReadFar = kCatOut + 2, kCats = kCatOut + 3;
+        auto catOf = [&](int wi, int wj, int wk, bool &zero) {
+            const int w = (wk * E + wj) * E + wi;
+            zero = false;
+            const uint8_t c = cls[w];
+            if (c == kBoxSkip) return -1;
+            if (fl[w] & 2u) {
+                const int ring = ringOf(wi, wj, wk);
+                return ring <= D ? ring : kCatReadFar;
             }
-            int genBefore = 0, genTotal = 0;
-            genBefore = blockExclusiveScan(myGen, &genTotal, scratch);
+            if (c == kBoxFrozenOut) return kCatOut;
+            if (c == kBoxFrozenFar) return kCatReadFar;
+            zero = c == kBoxZero;
+            return kCatReadPlain;
+        };
+        const int R = ry * rz, rp = (R + kBoxBuildThreads - 1) / kBoxBuildThreads, r0 = min(R, tid * rp), r1 = min(R, r0 + rp);
+        int cnt[kCats], total[kCats], myGen = 0, myAll = 0;
+#pragma unroll
+        for (int q = 0; q < kCats; ++q) cnt[q] = 0;
+        for (int r = r0; r < r1; ++r) {
+            const int wj = rlo[1] + r % ry, wk = rlo[2] + r / ry;
+            for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
+                bool zero;
+                const int c = catOf(wi, wj, wk, zero);
+#pragma unroll
+                for (int q = 0; q < kCats; ++q) cnt[q] += c == q ? 1 : 0;
+                myAll += c >= 0 ? 1 : 0;
+                if (c >= 0 && c <= kBandMaxDepth && bandDiag[bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)]] == 0) ++myGen;
+            }
+        }
+        int nListGroup = 0, genTotal = 0;
+        const int allBefore = blockExclusiveScan(myAll, &nListGroup, scratch);
+        const int genBefore = blockExclusiveScan(myGen, &genTotal, scratch);
+        if (FILL) {
+            // the statistics of the group (ring counts): only the fill pass needs them
+            int dummy;
+#pragma unroll
+            for (int q = 0; q <= kCatOut; ++q) {
+                dummy = blockExclusiveScan(cnt[q], &total[q], scratch);
+                (void)dummy;
+            }
+            uint32_t *udst = list + size_t(uBase + lists);
             int32_t *gdst = general + 2 * size_t(nBase + gens + genBefore);
+            int pos = allBefore;
             for (int r = r0; r < r1; ++r) {
                 const int wj = rlo[1] + r % ry, wk = rlo[2] + r / ry;
                 for (int wi = rlo[0]; wi <= rhi[0]; ++wi) {
-                    const int w = (wk * E + wj) * E + wi;
-                    const int node = r * rx + (wi - rlo[0]);
-                    uint8_t c = cls[w];
-                    const int ring = min(ringOf(wi, wj, wk), 7);
-                    if (c != kBoxSkip && (fl[w] & 2u)) {
+                    bool zero;
+                    const int c = catOf(wi, wj, wk, zero);
+                    if (c < 0) continue;
+                    const uint32_t coords = uint32_t(wi - rlo[0]) | (uint32_t(wj - rlo[1]) << 5) | (uint32_t(wk - rlo[2]) << 10);
+                    uint32_t code = c == kCatOut ? uint32_t(kBoxFrozenOut) : c == kCatReadFar ? uint32_t(kBoxFrozenFar) : zero ? uint32_t(kBoxZero) : uint32_t(kBoxFrozen);
+                    const uint32_t ring = uint32_t(min(ringOf(wi, wj, wk), 7));
+                    if (c <= kBandMaxDepth) {
                         const int e = bandEntry[sortedOf(oi + wi, oj + wj, ok + wk)];
                         const int dg = bandDiag[e];
-                        c = dg == 0 ? uint8_t(kBoxGeneral) : uint8_t(kBoxSimple + dg);
-                        if (dg == 0 && ring <= D) {
-                            gdst[0] = node | (ring << 16);
+                        code = dg == 0 ? uint32_t(kBoxGeneral) : uint32_t(kBoxSimple + dg);
+                        if (dg == 0) {
+                            gdst[0] = pos;
                             gdst[1] = e;
                             gdst += 2;
                         }
                     }
-                    cdst[node] = uint8_t(c | (ring << 4));
+                    udst[pos++] = coords | (code << 16) | (ring << 20);
                 }
             }
-            if (tid < padded - nodes) cdst[nodes + tid] = 0;
             if (tid == 0) {
-                int32_t *g8 = info + kBoxInfoInts * size_t(gBase + groups);
-                g8[0] = int32_t(cellIdx(d, oi + rlo[0], oj + rlo[1], ok + rlo[2]));
-                g8[1] = rx | (ry << 8) | (rz << 16);
-                g8[2] = cBase + codeBytes;
-                g8[3] = nBase + gens;
-                g8[4] = gen;
-                g8[5] = (olo[0] - rlo[0]) | ((olo[1] - rlo[1]) << 8) | ((olo[2] - rlo[2]) << 16);
-                g8[6] = (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16);
-                g8[7] = nodes;
+                int32_t *g16 = info + kBoxInfoInts * size_t(gBase + groups);
+                g16[0] = int32_t(cellIdx(d, oi + rlo[0], oj + rlo[1], ok + rlo[2]));
+                g16[1] = rx | (ry << 8) | (rz << 16);
+                g16[2] = uBase + lists;
+                g16[3] = 0;
+                g16[4] = nBase + gens;
+                g16[5] = genTotal;
+                g16[6] = 0;
+                g16[7] = nListGroup;
+                int run = 0;
+#pragma unroll
+                for (int q = 0; q <= kBandMaxDepth; ++q) {
+                    run += total[q];
+                    g16[8 + q] = run;
+                }
+                g16[13] = total[kCatOut];
+                g16[14] = (olo[0] - rlo[0]) | ((olo[1] - rlo[1]) << 8) | ((olo[2] - rlo[2]) << 16);
+                g16[15] = (ohi[0] - olo[0] + 1) | ((ohi[1] - olo[1] + 1) << 8) | ((ohi[2] - olo[2] + 1) << 16);
             }
         }
         ++groups;
-        codeBytes += padded;
-        gens += gen;
+        lists += nListGroup;
+        gens += genTotal;
     }
     if (!FILL && tid == 0) {
         nGroups[blockIdx.x] = groups;
-        nCodes[blockIdx.x] = codeBytes;
+        nList[blockIdx.x] = lists;
         nGeneral[blockIdx.x] = gens;
     }
 }
@@ -1110,25 +1155,23 @@ static size_t boxBuildLds(int depth)
     return 2 * E * E * E + 8;
 }
 int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *nGroups, int32_t *nCodes,
-                         int32_t *nGeneral, int *broken)
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken)
 {
     if (ntiles <= 0) return 0;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
     boxBuildKernel<false><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
-                                                                                                nGroups, nCodes, nGeneral, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                                                                nullptr, broken);
+                                                                                                counts[0], counts[1], counts[2], nullptr, nullptr, nullptr, nullptr,
+                                                                                                nullptr, nullptr, broken);
     return int(hipGetLastError());
 }
 int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *groupAt,
-                        const int32_t *codeAt, const int32_t *generalAt, int32_t *info, uint8_t *codes, int32_t *general, int *broken)
+                        const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *const at[3],
+                        int32_t *info, uint32_t *list, int32_t *general, int *broken)
 {
     if (ntiles <= 0) return 0;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
     boxBuildKernel<true><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
-                                                                                               nullptr, nullptr, nullptr, groupAt, codeAt, generalAt, info, codes, general,
-                                                                                               broken);
+                                                                                               nullptr, nullptr, nullptr, at[0], at[1], at[2], info, list, general, broken);
     return int(hipGetLastError());
 }
 

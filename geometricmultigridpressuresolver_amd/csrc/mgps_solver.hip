@@ -418,7 +418,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.readCell);
         (void)cacheFree(L.halo.groups.neighbours);
         (void)cacheFree(L.bandBoxes.info);
-        (void)cacheFree(L.bandBoxes.codes);
+        (void)cacheFree(L.bandBoxes.list);
         (void)cacheFree(L.bandBoxes.general);
     }
     for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
@@ -1517,10 +1517,11 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
         if (bx.groups() == 0) return failH(h, MGPS_ERR_INTERNAL, "band boxes: the builder failed on level of " + std::to_string(L.d.nx) + " cells in x");
         L.bandBoxes.depth = bx.depth;
         L.bandBoxes.ngroups = int(bx.groups());
-        L.bandBoxes.codeBytes = bx.codes.size();
+        L.bandBoxes.listCount = bx.list.size();
         L.bandBoxes.generalInts = bx.general.size();
+        L.bandBoxes.anyGeneral = !bx.general.empty();
         MGPS_TRY(devUpload(h, &L.bandBoxes.info, bx.info));
-        MGPS_TRY(devUpload(h, &L.bandBoxes.codes, bx.codes));
+        MGPS_TRY(devUpload(h, &L.bandBoxes.list, bx.list));
         MGPS_TRY(devUpload(h, &L.bandBoxes.general, bx.general));
     }
     if (xbGrids) {
@@ -2017,7 +2018,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         int32_t *tileCount = nullptr, *tileKind = nullptr, *tileStart = nullptr, *scan = nullptr;
         int32_t *sorted = nullptr, *general = nullptr, *genRank = nullptr, *bandEntry = nullptr;
         uint8_t *diagS = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
-        int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
+        int32_t *gcount[4] = {nullptr, nullptr, nullptr, nullptr}, *gat[4] = {nullptr, nullptr, nullptr, nullptr};
         int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr, *boxTiles = nullptr;
         uint8_t *tileBits = nullptr;
         int *runCounts = nullptr;
@@ -2145,7 +2146,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
             ODS_TRY(tmp.get(h, &t.gat[q], size_t(t.nBoxTiles) + 1));
         }
         ODS_LAUNCH(launchBandBoxesCount(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.boxTiles, t.nBoxTiles,
-                                        t.gcount[0], t.gcount[1], t.gcount[2], flags + 2 * mgLevels + 2 + l));
+                                        t.gcount, flags + 2 * mgLevels + 2 + l));
         for (int q = 0; q < 3; ++q) ODS_LAUNCH(launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nBoxTiles), t.scan));
     }
     // ---- host side of the lists: flags and kinds come back, lists go up
@@ -2230,13 +2231,14 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         if (brokenL || tot[0] == 0) return bail(failH(h, MGPS_ERR_INTERNAL, "band boxes: the builder failed on level " + std::to_string(l)));
         L.bandBoxes.depth = o.band_iterations;
         L.bandBoxes.ngroups = tot[0];
-        L.bandBoxes.codeBytes = size_t(tot[1]);
+        L.bandBoxes.listCount = size_t(tot[1]);
         L.bandBoxes.generalInts = 2 * size_t(tot[2]);
+        L.bandBoxes.anyGeneral = tot[2] > 0;
         ODS_TRY(devAlloc(h, &L.bandBoxes.info, size_t(kBoxInfoInts) * size_t(tot[0]), false));
-        ODS_TRY(devAlloc(h, &L.bandBoxes.codes, size_t(tot[1]), false));
+        ODS_TRY(devAlloc(h, &L.bandBoxes.list, size_t(tot[1]), false));
         ODS_TRY(devAlloc(h, &L.bandBoxes.general, 2 * size_t(tot[2]), false));
         ODS_LAUNCH(launchBandBoxesFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.boxTiles, t.nBoxTiles,
-                                       t.gat[0], t.gat[1], t.gat[2], L.bandBoxes.info, L.bandBoxes.codes, L.bandBoxes.general, flags + 2 * mgLevels + 2 + l));
+                                       t.gat, L.bandBoxes.info, L.bandBoxes.list, L.bandBoxes.general, flags + 2 * mgLevels + 2 + l));
     }
     ODS_HIP(hipDeviceSynchronize());
     clock.lap("band boxes");
@@ -2803,7 +2805,7 @@ try {
     case 9: src = L.mixed[1], n = size_t(L.nmixed[1]); break;
     case 10: src = L.tileBndStart, n = size_t(nt) + 1; break;
     case 11: src = L.bandBoxes.info, n = size_t(kBoxInfoInts) * size_t(L.bandBoxes.ngroups); break;
-    case 12: src = L.bandBoxes.codes, n = L.bandBoxes.codeBytes, elem = 1; break;
+    case 12: src = L.bandBoxes.list, n = L.bandBoxes.listCount; break;
     case 13: src = L.bandBoxes.general, n = L.bandBoxes.generalInts; break;
     default: return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: unknown array");
     }
