@@ -399,6 +399,17 @@ int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigm
 int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev);
 int launchZeroActiveHalf(void *stream, const GridP &g, void *aH);
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse);
+// the up-stroke's prolongation folded into the sweep that follows it: out = Jacobi(x + 4 P coarse), x itself is not updated;
+// quads flagged in nearBand (launchMarkNearBand: every quad a box group stages; (cells / 4 + 31) / 32 words, zeroed first)
+// also leave x + 4 P coarse in `stage`
+bool prolongJacobiApplies(const GridP &fine);
+// blockFlags (optional): a byte per block of the plane-marching sweep (planeBlockCount; launchPlaneBlockFlags sets the listed ones):
+// tiles whose rows touch no active block return at once
+int launchProlongJacobi(void *stream, const GridP &fine, float *out, const float *x, const float *b, const float *coarse, float omega, const uint32_t *nearBand,
+                        float *stage, const uint8_t *blockFlags);
+size_t planeBlockCount(const GridP &g);
+int launchPlaneBlockFlags(void *stream, const GridP &g, uint8_t *flags);
+int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits);
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
                       float *gathered);
 int launchAxpy(void *stream, const GridP &g, float *dst, const float *src, const float *scaleDev, float scaleHost,

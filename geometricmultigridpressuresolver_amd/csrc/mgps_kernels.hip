@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
 // 14.8 B/cell (rocprofv3 FETCH_SIZE), 2.63 vs 2.87 ms at 1024^3.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the rows 16-byte aligned
+// lerp of Ops.h:841-871: (1 - f) a + f b, this exact form (HDK's SYSlerp breaks the R / P symmetry, Ops.h:837-839)
+__device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
 
 template <int OP, bool DOT = false>
 __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
@@ -384,6 +386,196 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     if (DOT) {
         __syncthreads();  // (the LDS planes are done with)
         blockDotStore(dotAcc, dotPartials, blockIdx.x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Prolongation folded into the sweep that follows it (up-stroke, MG.cpp:695-757 / 787-850): out = Jacobi(x + 4 P e)
+// in ONE pass over the fine grid -- 13.5 B per cell (x 4, coarse 0.5, rhs 4, code 1, out 4) instead of 9.5 + 13 for
+// prolongAddBlockKernel followed by stencilPlaneKernel<OP_JACOBI>.  The plane-marching sweep with every value of x
+// replaced, the moment it is loaded, by x' = x + 4 trilerp(e) on active cells (Ops.h:873-972; the same lerp order as
+// prolongAddBlockKernel, so x' has the bits the separate pass would have stored).  A thread keeps the 2 x 2 coarse rows
+// its quad interpolates from in registers (four values each); the pair of coarse planes advances every other fine plane,
+// the y-halo row of a tile's first / last thread row interpolates from the same coarse rows as its neighbour inside the
+// tile (tiles start at even j), the x-halo cells from the first / last coarse value of the thread's rows.
+// The iterate itself is never written back: the sweep's output replaces it (the grids swap).  What still needs x' after
+// this launch are the box groups of the band stage (launchBandBox, closure mode, reads the un-smoothed iterate on its
+// regions): quads flagged in `nearBand` (one bit per quad, set for every quad a group stages) also leave x' in `stage`.
+// ---------------------------------------------------------------------------------------------
+// Tiles: kFusedRows = 10 output rows per workgroup; its 12 thread rows stage rows j0 - 1 .. j0 + 10 (the first and the last
+// thread row only prolong and stage their row: the y-halo).  A thread row per halo row instead of a second quad per edge
+// thread, and 768 threads instead of 1024: the kernel needs 88 registers, which leaves two workgroups per CU only at
+// twelve waves each (with 16-row tiles and the halo rows staged by the edge rows it needed 108, one workgroup per CU, and
+// ran at 3.0 TB/s: 3.66 ms at 1024^3 against 1.27 + 1.92 ms for the two separate passes).  Measured in this form: 3.11 ms,
+// 3.9 TB/s of the 14.8 B per cell it really moves (y-halo rows 12 / 10, coarse rows re-read per tile) -- break-even with the two
+// passes, so the solver takes it only when asked to (MGPS_FUSE_PROLONG=1).  Keeping the x- / y-lerps of a coarse pair for the two
+// fine planes that share it: 3.28 ms (nine more registers spilled).
+constexpr int kFusedThreadRows = 12, kFusedRows = kFusedThreadRows - 2;
+constexpr int kCoarseRows = kFusedThreadRows / 2 + 2, kCoarsePitch = 132;  // coarse rows / values a tile (+ halo) interpolates from
+
+__global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
+                                                                              const float *__restrict__ b, const float *__restrict__ coarse,
+                                                                              float omega, unsigned nbx, unsigned nbyF, unsigned nby16, int zc,
+                                                                              const uint8_t *__restrict__ blockFlags, const uint32_t *__restrict__ nearBand,
+                                                                              float *__restrict__ stage)
+{
+    __shared__ float plane[2][kFusedThreadRows * kPlanePitch];
+    // three coarse planes in rotation (plane q in slot q % 3): the pair a fine plane interpolates from and the next one
+    // on its way; kCoarseRows rows of the 130 coarse values the tile's columns (+ the two x-halo cells) read
+    __shared__ float cpl[3][kCoarseRows * kCoarsePitch];
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nbyF, bz = bid / (nbx * nbyF);
+    const int j0 = int(by) * kFusedRows;  // first output row
+    if (blockFlags) {  // the 256 x 16 x zc blocks of the sweep's activity list that this tile's output rows touch
+        const unsigned ya = unsigned(j0) / kPlaneRows, yb = min(unsigned(j0 + kFusedRows - 1) / kPlaneRows, nby16 - 1);
+        if (!blockFlags[(size_t(bz) * nby16 + ya) * nbx + bx] && !blockFlags[(size_t(bz) * nby16 + yb) * nbx + bx]) return;
+    }
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = j0 - 1 + ty;
+    const bool outRow = ty >= 1 && ty <= kFusedRows;
+    const bool valid = outRow && i < g.nx && j < g.ny;
+    const int ic = min(i, g.nx - 4), jc = min(max(j, 0), g.ny - 1);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
+    const bool colL = lane == 0, colR = lane == kWave - 1;
+    const int cnx = g.nx >> 1, cny = g.ny >> 1, cnz = g.nz >> 1;
+    const int cb = (j0 - 2) >> 1;  // coarse row of local row 0: what fine row j0 - 1 reads first
+    // slot q % 3 <- coarse plane q: rows cb .., values 128 bx - 1 .. (clamped: the clamps only bite on the EXTERIOR shell)
+    auto fillCoarse = [&](int q) {
+        const int qc = min(max(q, 0), cnz - 1);
+        float *dst = cpl[(q + 3) % 3];
+        for (int t = threadIdx.x; t < kCoarseRows * kCoarsePitch; t += 64 * kFusedThreadRows) {
+            const int lr = t / kCoarsePitch, lx = t - lr * kCoarsePitch;
+            const int gy = min(max(cb + lr, 0), cny - 1), gx = min(max(128 * int(bx) - 1 + lx, 0), cnx - 1);
+            dst[t] = coarse[(size_t(qc) * cny + gy) * cnx + gx];
+        }
+    };
+    const int lr = ((jc - 1) >> 1) - cb;  // this thread's first coarse row (0 .. kCoarseRows - 2)
+    const float fy = (jc & 1) ? 0.25f : 0.75f;
+    // x' = x + 4 trilerp on the active cells of this thread's quad in fine plane k (Ops.h:841-871, 931-966; lerp order x, y, z as
+    // in prolongAddBlockKernel; the plane's coarse pair (k - 1) >> 1, + 1 must be in LDS)
+    auto prolongQuad = [&](int k, float4 v, uchar4 l) {
+        const int p = (k - 1) >> 1;
+        const float wz = (k & 1) ? 0.25f : 0.75f;
+        float vy[2][4];
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            const float *base = cpl[(p + zz + 3) % 3] + lr * kCoarsePitch + 2 * lane;
+            const float2 a01 = *reinterpret_cast<const float2 *>(base), a23 = *reinterpret_cast<const float2 *>(base + 2);
+            const float2 c01 = *reinterpret_cast<const float2 *>(base + kCoarsePitch), c23 = *reinterpret_cast<const float2 *>(base + kCoarsePitch + 2);
+            vy[zz][0] = lerpRef(lerpRef(a01.x, a01.y, 0.75f), lerpRef(c01.x, c01.y, 0.75f), fy);
+            vy[zz][1] = lerpRef(lerpRef(a01.y, a23.x, 0.25f), lerpRef(c01.y, c23.x, 0.25f), fy);
+            vy[zz][2] = lerpRef(lerpRef(a01.y, a23.x, 0.75f), lerpRef(c01.y, c23.x, 0.75f), fy);
+            vy[zz][3] = lerpRef(lerpRef(a23.x, a23.y, 0.25f), lerpRef(c23.x, c23.y, 0.25f), fy);
+        }
+        if (activeLabel(l.x)) v.x += 4.f * lerpRef(vy[0][0], vy[1][0], wz);
+        if (activeLabel(l.y)) v.y += 4.f * lerpRef(vy[0][1], vy[1][1], wz);
+        if (activeLabel(l.z)) v.z += 4.f * lerpRef(vy[0][2], vy[1][2], wz);
+        if (activeLabel(l.w)) v.w += 4.f * lerpRef(vy[0][3], vy[1][3], wz);
+        return v;
+    };
+    // the x-halo cells: fine i - 1 (odd: coarse 2m-1, 2m at 1/4) and i + 4 (even: coarse 2m+1, 2m+2 at 3/4), this thread's row
+    auto edgeAdd = [&](int k, bool right) {
+        const int p = (k - 1) >> 1;
+        const float wz = (k & 1) ? 0.25f : 0.75f, wx = right ? 0.75f : 0.25f;
+        float vy[2];
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            const float *base = cpl[(p + zz + 3) % 3] + lr * kCoarsePitch + 2 * lane + (right ? 2 : 0);
+            vy[zz] = lerpRef(lerpRef(base[0], base[1], wx), lerpRef(base[kCoarsePitch], base[kCoarsePitch + 1], wx), fy);
+        }
+        return 4.f * lerpRef(vy[0], vy[1], wz);
+    };
+    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
+    const int p0 = (k0 - 1) >> 1;  // k0 is even: planes k0 - 1 and k0 share the pair p0, p0 + 1; plane k0 + 1 needs p0 + 2
+    fillCoarse(p0);
+    fillCoarse(p0 + 1);
+    fillCoarse(p0 + 2);
+    float4 xc = *reinterpret_cast<const float4 *>(x + c);
+    uchar4 lc = streamLoad4(g.lab + c);
+    float hx = 0.f;
+    unsigned hl = MGPS_EXTERIOR_CELL;
+    if (colL && ic > 0) {
+        hx = x[c - 1];
+        hl = g.lab[c - 1];
+    }
+    if (colR && ic + 4 < g.nx) {
+        hx = x[c + 4];
+        hl = g.lab[c + 4];
+    }
+    float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 lm = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    if (k0 > 0 && outRow) {
+        xm = *reinterpret_cast<const float4 *>(x + c - sz);
+        lm = *reinterpret_cast<const uchar4 *>(g.lab + c - sz);
+    }
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (outRow) bc = streamLoad4(b + c);
+    __syncthreads();
+    if (k0 > 0 && outRow) xm = prolongQuad(k0 - 1, xm, lm);
+    xc = prolongQuad(k0, xc, lc);
+    if ((colL || colR) && activeLabel(hl)) hx += edgeAdd(k0, colR);
+    int buf = 0;
+    for (int k = k0; k < k1; ++k) {
+        float *me = plane[buf] + ty * kPlanePitch + 4 + lane * 4;
+        *reinterpret_cast<float4 *>(me) = xc;
+        if (colL) me[-1] = hx;
+        if (colR) me[4] = hx;
+        if (nearBand && valid) {  // the band stage's groups read x' here
+            const size_t q = c >> 2;
+            if ((nearBand[q >> 5] >> (q & 31)) & 1u) *reinterpret_cast<float4 *>(stage + c) = xc;
+        }
+        // next plane: its loads before this plane is computed; its prolongation needs the pair (k >> 1, + 1): in LDS since the
+        // barrier of the iteration before (filled below, two planes ahead)
+        const int kn = k + 1;
+        const size_t cn = kn < g.nz ? c + sz : c;
+        float4 xp = xc, bn = bc;
+        uchar4 ln = lc;
+        float hxn = hx;
+        unsigned hln = MGPS_EXTERIOR_CELL;
+        if (kn < g.nz) {
+            xp = *reinterpret_cast<const float4 *>(x + cn);
+            ln = streamLoad4(g.lab + cn);
+            if (outRow && kn < k1) bn = streamLoad4(b + cn);
+            if (colL && ic > 0) {
+                hxn = x[cn - 1];
+                hln = g.lab[cn - 1];
+            }
+            if (colR && ic + 4 < g.nx) {
+                hxn = x[cn + 4];
+                hln = g.lab[cn + 4];
+            }
+        }
+        if (k & 1) fillCoarse(((k + 1) >> 1) + 1);  // what fine plane k + 2 will add to its pair
+        if (kn < g.nz) {
+            xp = prolongQuad(kn, xp, ln);
+            if ((colL || colR) && activeLabel(hln)) hxn += edgeAdd(kn, colR);
+        }
+        __syncthreads();
+        if (outRow) {
+            const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
+            const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+            const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
+            const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+            const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+            const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+            const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
+            float res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float diag = simpleDiag(ls[e]);
+                const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+                res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_JACOBI>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_JACOBI>(xs[e + 1]);
+            }
+            if (valid) __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
+        }
+        xm = xc;
+        xc = xp;
+        bc = bn;
+        lc = ln;
+        hx = hxn;
+        c = cn;
+        buf ^= 1;
     }
 }
 
@@ -1220,8 +1412,6 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
 // (1-f) a + f b, x first, then y, then z (Ops.h:841-871).  One thread per fine cell.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
-
 __global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float *__restrict__ coarse)
 {
     const size_t n = size_t(fg.nx) * fg.ny * fg.nz;
@@ -2074,6 +2264,57 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
         if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
     } else
         prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
+    return int(hipGetLastError());
+}
+
+// out = Jacobi(x + 4 P coarse) in one pass (prolongJacobiPlaneKernel): levels that take the plane-marching sweep, fine and
+// coarse extents in the 2 : 1 ratio, whole grids (no slab ghosts), no general BOUNDARY patch (the caller's closure launch
+// computes those cells).  nearBand / stage: see the kernel.  false: the shape does not qualify
+bool prolongJacobiApplies(const GridP &fine) { return stencilKernelOf(fine) == 2 && !fine.ghostLo && !fine.ghostHi && (fine.nx & 3) == 0 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.nz >= 4; }
+int launchProlongJacobi(void *stream, const GridP &g, float *out, const float *x, const float *b, const float *coarse, float omega, const uint32_t *nearBand,
+                        float *stage, const uint8_t *blockFlags)
+{
+    const int zc = g.planeZc;
+    if (!prolongJacobiApplies(g) || zc <= 0 || (zc & 1)) return int(hipErrorInvalidValue);
+    const unsigned nbx = (g.nx + 255) / 256, nby16 = (g.ny + kPlaneRows - 1) / kPlaneRows, nbyF = (g.ny + kFusedRows - 1) / kFusedRows, nbz = (g.nz + zc - 1) / zc;
+    prolongJacobiPlaneKernel<<<nbx * nbyF * nbz, 64 * kFusedThreadRows, 0, static_cast<hipStream_t>(stream)>>>(g, out, x, b, coarse, omega, nbx, nbyF, nby16, zc, blockFlags,
+                                                                                                         nearBand, stage);
+    return int(hipGetLastError());
+}
+// flags[block] = 1 for the blocks of the plane-marching sweep's activity list (a byte per 256 x 16 x zc block, zeroed by the caller)
+__global__ __launch_bounds__(256) void planeBlockFlagsKernel(const int32_t *__restrict__ blocks, int n, uint8_t *__restrict__ flags)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) flags[blocks[t]] = 1;
+}
+size_t planeBlockCount(const GridP &g)
+{
+    const int zc = g.planeZc > 0 ? g.planeZc : 1;
+    return size_t((g.nx + 255) / 256) * size_t((g.ny + kPlaneRows - 1) / kPlaneRows) * size_t((g.nz + zc - 1) / zc);
+}
+int launchPlaneBlockFlags(void *stream, const GridP &g, uint8_t *flags)
+{
+    if (!g.planeBlocks || g.nplaneBlocks <= 0) return 0;
+    planeBlockFlagsKernel<<<blocksFor(size_t(g.nplaneBlocks), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(g.planeBlocks, g.nplaneBlocks, flags);
+    return int(hipGetLastError());
+}
+// nearBand bits (one per quad of the level's grid, zeroed by the caller) for every quad that holds a cell some group stages
+__global__ __launch_bounds__(256) void markNearBandKernel(GridP g, const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint32_t *__restrict__ bits)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, origin = size_t(gi[0]);
+    const uint32_t *U = list + gi[2];
+    for (int k = threadIdx.x; k < gi[7]; k += 256) {
+        const uint32_t e = U[k], cls = (e >> 16) & 15u;
+        if (cls == kBoxSkip || cls == kBoxZero) continue;
+        const size_t q = (origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz) >> 2;
+        atomicOr(bits + (q >> 5), 1u << (q & 31));
+    }
+}
+int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits)
+{
+    if (bx.ngroups <= 0) return 0;
+    markNearBandKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(g, bx.info, bx.list, bits);
     return int(hipGetLastError());
 }
 

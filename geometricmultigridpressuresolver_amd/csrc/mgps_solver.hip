@@ -59,6 +59,11 @@ struct DevLevel {
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
     int edgeChunks = 0, edgePlaneBlocks = 0;            // cut slab levels: the leading entries that touch the planes next to a cut
     BandBoxesDev bandBoxes;  // fused band stage, box form (levels that are not cut into slabs)
+    // up-stroke with the prolongation folded into the sweep (launchProlongJacobi; made on first use): one bit per quad that a
+    // box group stages, and the grid in which those quads receive x + 4 P e
+    uint32_t *nearBand = nullptr;
+    float *stage = nullptr;
+    uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
     // fused band stage of a cut level (SlabHalo): one exchange per stage
     struct Halo {
         int depth = 0;
@@ -419,6 +424,9 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.neighbours);
         (void)cacheFree(L.bandBoxes.info);
         (void)cacheFree(L.bandBoxes.list);
+        (void)cacheFree(L.nearBand);
+        (void)cacheFree(L.planeFlags);
+        gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
     for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
@@ -790,6 +798,33 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
 
 int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid = false, bool wantDot = false);
 
+// Up-stroke of level l as "Jacobi(x + 4 P e)" in one pass (launchProlongJacobi) + the two box launches: single-device levels that
+// take the plane-marching sweep and the box form of the band stage, the reference's one Jacobi sweep per stroke
+bool prolongFusable(const mgps_solver *h, int l, const float *cur, const float *other, const float *b)
+{
+    static const bool allowed = [] {  // MGPS_FUSE_PROLONG=1: on (off by default: measured break-even at 1024^3, see prolongJacobiPlaneKernel)
+        const char *e = getenv("MGPS_FUSE_PROLONG");
+        return e && e[0] == '1';
+    }();
+    const DevLevel &L = h->lv[l];
+    return allowed && !h->dist && !h->useGS && h->opt.post_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && prolongJacobiApplies(L.g) &&
+           cur != L.r && other != L.r && b != L.r;
+}
+int ensureProlongFusion(mgps_solver *h, int l)
+{
+    DevLevel &L = h->lv[l];
+    if (L.nearBand) return MGPS_OK;
+    const size_t words = (L.d.cells() / 4 + 31) / 32;
+    MGPS_TRY(devAlloc(h, &L.nearBand, words, true));
+    MGPS_TRY(gridAlloc(h, &L.stage, L.d));
+    MGPS_LAUNCH(h, launchMarkNearBand(h->stream, L.g, L.bandBoxes, L.nearBand));
+    if (L.g.planeBlocks) {
+        MGPS_TRY(devAlloc(h, &L.planeFlags, planeBlockCount(L.g), true));
+        MGPS_LAUNCH(h, launchPlaneBlockFlags(h->stream, L.g, L.planeFlags));
+    }
+    return MGPS_OK;
+}
+
 // levels distLevels .. totalLevels-1 of a slab run: gather the rhs of the collapse level to rank 0,
 // run the rest of the cycle there on the whole grid, scatter the correction back
 int collapsedTail(mgps_solver *h)
@@ -909,12 +944,29 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
         for (int l = nsmooth - 1; l >= 0; --l) {  // MG.cpp:695-784 (coarser), 787-880 (fine)
             DevLevel &F = h->lv[l];
             if (stopRequested()) return failH(h, MGPS_ERR_INTERRUPTED, "mgps_apply_vcycle: interrupted");
+            const float *rhsUp = l == 0 ? b : F.b;
+            if (!(h->gatherDot && l == 0) && prolongFusable(h, l, cur[l], other[l], rhsUp)) {
+                // prolongation + sweep in one pass over the level, then the two band stages as in smoothStroke: the closure launch
+                // reads x + 4 P e where the fused sweep left it for the quads near the band (F.stage)
+                MGPS_TRY(ensureProlongFusion(h, l));
+                {
+                    StageScope scope(h, ST_SMOOTH, l);
+                    GridP gs = F.g;
+                    gs.nbnd = 0;
+                    MGPS_LAUNCH(h, launchProlongJacobi(h->stream, gs, other[l], cur[l], rhsUp, cur[l + 1], h->opt.jacobi_weight, F.nearBand, F.stage, F.planeFlags));
+                }
+                StageScope scope(h, ST_BAND, l);
+                MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, F.stage, rhsUp, other[l], F.r, h->opt.jacobi_weight));
+                std::swap(cur[l], other[l]);
+                MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, F.r, rhsUp, cur[l], nullptr, h->opt.jacobi_weight));
+                continue;
+            }
             {
                 StageScope scope(h, ST_PROLONG, l);
                 MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
                 MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
             }
-            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], l == 0 ? b : F.b, false, false, h->gatherDot && l == 0));
+            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhsUp, false, false, h->gatherDot && l == 0));
         }
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
