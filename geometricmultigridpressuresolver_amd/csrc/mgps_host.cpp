@@ -1235,12 +1235,13 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
                                 }
                             }
                         }
-                int rlo[3] = {99, 99, 99}, rhi[3] = {-1, -1, -1}, gen = 0;
+                int rlo[3] = {99, 99, 99}, rhi[3] = {-1, -1, -1}, gen = 0, listed = 0;
                 for (int wk = mlo[2]; wk <= mhi[2]; ++wk)
                     for (int wj = mlo[1]; wj <= mhi[1]; ++wj)
                         for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
                             const size_t w = size_t((wk * E + wj) * E + wi);
                             if (cls[w] == kBoxSkip) continue;
+                            ++listed;
                             const int v[3] = {wi, wj, wk};
                             for (int a = 0; a < 3; ++a) {
                                 rlo[a] = std::min(rlo[a], v[a]);
@@ -1249,7 +1250,7 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
                             if ((fl[w] & 2) && L.bandDiag[size_t(ent[w])] == 0 && ringOf(wi, wj, wk) <= D) ++gen;
                         }
                 const int rx = rhi[0] - rlo[0] + 1, ry = rhi[1] - rlo[1] + 1, rz = rhi[2] - rlo[2] + 1, nodes = rx * ry * rz;
-                if (nodes > kBoxMaxNodes || gen > kBoxMaxGeneral) {
+                if (nodes > kBoxMaxNodes || listed > kBoxMaxList || gen > kBoxMaxGeneral) {
                     int axis = 0;
                     for (int a = 1; a < 3; ++a)
                         if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
@@ -1328,7 +1329,7 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
                                 const int dg = L.bandDiag[size_t(ent[w])];
                                 code = dg == 0 ? uint32_t(kBoxGeneral) : uint32_t(kBoxSimple + dg);
                                 if (dg == 0) {
-                                    T.general.push_back(int32_t(T.list.size()) - listBase);
+                                    T.general.push_back(int32_t(coords | (code << 16) | (ring << 20)));
                                     T.general.push_back(ent[w]);
                                 }
                             }
@@ -1604,6 +1605,12 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
         return fail(MGPS_ERR_COARSE_TOO_LARGE,
                     "coarsest level has " + std::to_string(cn) + " unknowns (cap " + std::to_string(maxUnknowns) +
                         "): raise mg_levels or options.max_coarse_unknowns");
+    H.coarseOnDevice = cn > kHostCoarseMax;
+    if (H.coarseOnDevice) {  // (BASELINE configs 3 / 5 as SURVEY 8(d) states them: 512^3 with 5 levels, coarsest 32^3)
+        H.coarseBW = 0;
+        H.coarseL.clear();
+        return MGPS_OK;
+    }
     const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
     int bw = 0;
     for (int r = 0; r < cn; ++r)
@@ -1648,6 +1655,7 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
 
 void mgps_hierarchy::bandedSolve(double *v) const
 {
+    if (coarseOnDevice) return;  // (no host factor: callers check)
     const int n = coarseN, bw = coarseBW, W = bw + 1;
     const double *Lm = coarseL.data();
     for (int r = 0; r < n; ++r) {
@@ -1667,7 +1675,7 @@ void mgps_hierarchy::bandedSolve(double *v) const
 // triangular sweeps by orders of magnitude.
 void mgps_hierarchy::buildDenseInverse()
 {
-    if (!coarseInverse.empty() || coarseN == 0) return;
+    if (!coarseInverse.empty() || coarseN == 0 || coarseOnDevice) return;
     const int n = coarseN, bw = coarseBW, W = bw + 1;
     coarseInverse.assign(size_t(n) * n, 0.f);
     // kCols unit vectors per sweep over the factor: the factor (n x W doubles, megabytes) is streamed once per
@@ -1731,7 +1739,7 @@ void mgps_default_options(mgps_options *opt)
     opt->jacobi_weight = 2.0f / 3.0f;  // Ops.h:291, 554
     opt->device = -1;
     opt->print_stats = 0;
-    opt->max_coarse_unknowns = 8192;
+    opt->max_coarse_unknowns = 32768;  // 32^3: above 8192 the solver factorises on the device
     opt->interrupt = nullptr;
     opt->interrupt_user = nullptr;
     opt->pre_sweeps = 1;   // MG.cpp:466-486
@@ -2112,7 +2120,7 @@ int mgps::hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int level
         {
             std::lock_guard<std::mutex> lock(guard);
             for (auto &k : kept)
-                if (k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->n <= o.max_coarse_unknowns &&
+                if (k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->n <= o.max_coarse_unknowns && k->n <= kHostCoarseMax &&
                     std::memcmp(k->labels.data(), coarsestLabels, C.d.cells()) == 0) {
                     hit = k;
                     break;
@@ -2132,7 +2140,7 @@ int mgps::hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int level
                 return rc;
             }
             H->buildDenseInverse();
-            if (size_t(H->coarseN) * H->coarseN * sizeof(float) <= (size_t(64) << 20)) {
+            if (!H->coarseOnDevice && size_t(H->coarseN) * H->coarseN * sizeof(float) <= (size_t(64) << 20)) {
                 auto k = std::make_shared<Kept>();
                 k->d = C.d;
                 k->labels.assign(coarsestLabels, coarsestLabels + C.d.cells());
@@ -2391,7 +2399,7 @@ try {
             const int32_t *gi = bx.info.data() + kBoxInfoInts * gI;
             const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, rz = gi[1] >> 16, nodes = rx * ry * rz;
             const int nList = gi[7], ngen = gi[5];
-            if (nodes > kBoxMaxNodes || ngen > kBoxMaxGeneral || rx > 31 || ry > 31 || rz > 31 || nList > kBoxMaxNodes)
+            if (nodes > kBoxMaxNodes || ngen > kBoxMaxGeneral || rx > 31 || ry > 31 || rz > 31 || nList > kBoxMaxList)
                 return fail(MGPS_ERR_HIERARCHY, "band box exceeds the workgroup budget");
             const uint32_t *U = bx.list.data() + gi[2];
             auto nodeOf = [&](uint32_t e) { return int((((e >> 10) & 31u) * unsigned(ry) + ((e >> 5) & 31u)) * unsigned(rx) + (e & 31u)); };
@@ -2400,8 +2408,12 @@ try {
             present.assign(size_t(nodes), 0);
             rowOf.assign(size_t(nList), -1);
             for (int q = 0; q < ngen; ++q) {
-                const int32_t k = bx.general[2 * size_t(gi[4] + q)], row = bx.general[2 * size_t(gi[4] + q) + 1];
-                if (k < 0 || k >= nList || ((U[k] >> 16) & 15u) != kBoxGeneral || row < 0 || size_t(row) >= nb || L.bandDev[size_t(row)] != cellOf(U[k]))
+                const uint32_t ge = uint32_t(bx.general[2 * size_t(gi[4] + q)]);
+                const int32_t row = bx.general[2 * size_t(gi[4] + q) + 1];
+                int k = -1;
+                for (int kk = 0; kk < nList && k < 0; ++kk)
+                    if (U[kk] == ge) k = kk;
+                if (k < 0 || ((ge >> 16) & 15u) != kBoxGeneral || row < 0 || size_t(row) >= nb || L.bandDev[size_t(row)] != cellOf(ge))
                     return fail(MGPS_ERR_HIERARCHY, "band box: general entry does not match its cell");
                 rowOf[size_t(k)] = row;
             }
@@ -2504,6 +2516,9 @@ int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier) { return hier ? h
 int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b)
 try {
     if (!hier || !x || !b) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_coarse_solve: bad arguments");
+    if (hier->coarseOnDevice)
+        return fail(MGPS_ERR_COARSE_TOO_LARGE, "mgps_hierarchy_coarse_solve: the host factor stops at " + std::to_string(kHostCoarseMax) +
+                                                   " unknowns (larger coarsest levels are factorised on the device: mgps_coarse_solve)");
     std::vector<double> v(hier->coarseN);
     for (int r = 0; r < hier->coarseN; ++r) v[r] = b[hier->coarseCell[r]];
     hier->bandedSolve(v.data());

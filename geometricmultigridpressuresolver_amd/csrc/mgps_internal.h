@@ -180,10 +180,11 @@ void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
 //            overwriting y on the closure (band cells and their active face neighbours) -- nothing is scattered back
 //            into x -- and the same values land in a snapshot grid from which the band stage AFTER the sweep reads
 //            (that one then writes y in place: no workgroup reads what another one writes).
-constexpr int kBoxMaxNodes = 4096;    // region cells of a group: two LDS copies of their values
+constexpr int kBoxMaxNodes = 8192;    // region cells of a group: two LDS copies of their values (64 KB: two workgroups per CU)
+constexpr int kBoxMaxList = 4096;     // ... of which at most this many matter (list entries: kBoxSlots per thread, in registers)
 constexpr int kBoxThreads = 1024;
-constexpr int kBoxSlots = kBoxMaxNodes / kBoxThreads;
-constexpr int kBoxMaxGeneral = 512;   // general band cells of a region (their rows sit in LDS)
+constexpr int kBoxSlots = kBoxMaxList / kBoxThreads;
+constexpr int kBoxMaxGeneral = 384;   // general band cells of a region (their rows sit in LDS: 13.5 KB)
 constexpr int kBoxInfoInts = 16;
 enum BoxNode : uint8_t { kBoxSkip = 0, kBoxFrozen = 1, kBoxZero = 2, kBoxGeneral = 3, kBoxSimple = 4, kBoxFrozenOut = 11, kBoxFrozenFar = 12 };
 // info: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first entry in `list`, [3] unused,
@@ -194,7 +195,7 @@ struct BandBoxes {
     int depth = 0;
     RawVec<int32_t> info;
     RawVec<uint32_t> list;
-    RawVec<int32_t> general;   // per general band cell with ring <= depth two ints: its position in the group's list, row index
+    RawVec<int32_t> general;   // per general band cell with ring <= depth two ints: its list entry (coordinates, class, ring), row index
     size_t groups() const { return info.size() / kBoxInfoInts; }
 };
 void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out);
@@ -410,6 +411,9 @@ int launchProlongJacobi(void *stream, const GridP &fine, float *out, const float
 size_t planeBlockCount(const GridP &g);
 int launchPlaneBlockFlags(void *stream, const GridP &g, uint8_t *flags);
 int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits);
+// dense coarsest matrix (n x n doubles, zeroed by the caller) from the level's labels; fp32 inverse from the triangle potri left
+int launchCoarseAssemble(void *stream, int n, int nx, int ny, const int32_t *cells, const int32_t *index, const uint8_t *lab, double *A);
+int launchCoarseNarrow(void *stream, int n, const double *A, float *inv);
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
                       float *gathered);
 int launchAxpy(void *stream, const GridP &g, float *dst, const float *src, const float *scaleDev, float scaleHost,
@@ -500,6 +504,10 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 
 }  // namespace mgps
 
+namespace mgps {
+constexpr int kHostCoarseMax = 8192;
+}
+
 // Host-only hierarchy (C-ABI opaque type).
 struct mgps_hierarchy {
     int levels = 0;
@@ -513,6 +521,9 @@ struct mgps_hierarchy {
     std::vector<int32_t> coarseIndex;   // linear cell -> unknown id or -1
     std::vector<double> coarseL;        // banded Cholesky factor, coarseN x (coarseBW+1)
     std::vector<float> coarseInverse;   // dense coarseN x coarseN inverse (built on demand for the GPU)
+    // more unknowns than kHostCoarseMax: no factor on the host (the reference's tile numbering gives the banded factor a width
+    // of thousands there); the solver factorises and inverts the dense matrix on the device (hipSOLVER potrf / potri in fp64)
+    bool coarseOnDevice = false;
     void bandedSolve(double *v) const;
     void buildDenseInverse();
 };

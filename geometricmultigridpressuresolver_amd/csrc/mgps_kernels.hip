@@ -896,9 +896,10 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
             const int k = tid + m * kBoxThreads;
             ue[m] = k < nList ? U[k] : (uint32_t(kBoxSkip) << 16);
         }
-        int32_t gk = 0, grw = 0;
+        uint32_t ge = 0;  // this thread's general cell: its list entry and its row, in the first batch like the rest
+        int32_t grw = 0;
         if (GEN && tid < ngen) {
-            gk = general[2 * size_t(gi[4] + tid)];
+            ge = uint32_t(general[2 * size_t(gi[4] + tid)]);
             grw = general[2 * size_t(gi[4] + tid) + 1];
         }
         // (unconditional loads -- a cell that needs none reads the region's origin cell and drops the value -- so that all of
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
             if (kMixed) bv[m] *= bm;
         }
         if (GEN && tid < ngen) {
-            const uint32_t e = U[gk];
+            const uint32_t e = ge;
             gring[tid] = uint16_t(e >> 20);
             gnode[tid] = uint16_t(nodeOf(e));
             const size_t nb = size_t(g.nbnd);
@@ -2318,6 +2319,47 @@ int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uin
     return int(hipGetLastError());
 }
 
+// Coarsest levels past kHostCoarseMax unknowns: the dense matrix of MG.cpp:359-382 assembled on the device in fp64 (row r =
+// unknown r: -1 per active neighbour, diagonal = active + DIRICHLET neighbours), factorised and inverted by hipSOLVER
+// (potrf / potri leave one triangle), then folded into the fp32 inverse that coarseMatVecKernel multiplies with.
+__global__ __launch_bounds__(256) void coarseAssembleKernel(int n, int nx, int ny, const int32_t *__restrict__ cells, const int32_t *__restrict__ index,
+                                                            const uint8_t *__restrict__ lab, double *__restrict__ A)
+{
+    const int r = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const ptrdiff_t c = cells[r], off[6] = {-1, 1, -ptrdiff_t(nx), ptrdiff_t(nx), -ptrdiff_t(nx) * ny, ptrdiff_t(nx) * ny};
+    double diag = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const unsigned l = lab[c + off[q]];
+        if (activeLabel(l)) {
+            A[size_t(r) * n + index[c + off[q]]] = -1.0;
+            diag += 1.0;
+        } else if (l == MGPS_DIRICHLET_CELL)
+            diag += 1.0;
+    }
+    A[size_t(r) * n + r] = diag;
+}
+// inv[r][c] = float(A[min(r,c)][max(r,c)]): the triangle potri(LOWER) fills in column-major storage is the upper one of the
+// row-major view
+__global__ __launch_bounds__(256) void coarseNarrowKernel(int n, const double *__restrict__ A, float *__restrict__ inv)
+{
+    const size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (t >= size_t(n) * n) return;
+    const size_t r = t / n, c = t - r * n;
+    inv[t] = float(r <= c ? A[t] : A[c * n + r]);
+}
+int launchCoarseAssemble(void *stream, int n, int nx, int ny, const int32_t *cells, const int32_t *index, const uint8_t *lab, double *A)
+{
+    coarseAssembleKernel<<<blocksFor(size_t(n), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, nx, ny, cells, index, lab, A);
+    return int(hipGetLastError());
+}
+int launchCoarseNarrow(void *stream, int n, const double *A, float *inv)
+{
+    coarseNarrowKernel<<<blocksFor(size_t(n) * n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, A, inv);
+    return int(hipGetLastError());
+}
+
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
                       float *gathered)
 {
@@ -2512,8 +2554,11 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
                 }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[c0 + e] = res[e];
+        {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            reinterpret_cast<d2 *>(out + c0)[0] = d2{res[0], res[1]};
+            reinterpret_cast<d2 *>(out + c0)[1] = d2{res[2], res[3]};
+        }
         if (MODE == 1) reinterpret_cast<float4 *>(out32)[q] = make_float4(float(res[0]), float(res[1]), float(res[2]), float(res[3]));
     }
     const double total = blockReduce<0>(acc);
@@ -2544,7 +2589,10 @@ __global__ __launch_bounds__(256) void boundary64Kernel(GridP g, double *__restr
     const double total = blockReduce<0>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
-// x += alpha p, r -= alpha t, r32 = float(r), shares of |r|^2 (CG.h:132-153)
+// x += alpha p, r -= alpha t, r32 = float(r), shares of |r|^2 (CG.h:132-153).  16-byte accesses: a thread's quad is two
+// double2 per fp64 array (round 2 moved every double on its own: 846 us per pass at the 512^3 pool, 0.37 of the HBM peak);
+// inactive cells keep their values (0 in r, whatever x holds)
+typedef double d2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void cgUpdate64Kernel(GridP g, double *__restrict__ x, const double *__restrict__ p,
                                                          double *__restrict__ r, const double *__restrict__ t, double alpha,
                                                          float *__restrict__ r32, double *__restrict__ partials)
@@ -2555,22 +2603,30 @@ __global__ __launch_bounds__(256) void cgUpdate64Kernel(GridP g, double *__restr
     for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
-        const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        if (!anyActive(l4)) continue;
+        const bool on[4] = {activeLabel(l4.x), activeLabel(l4.y), activeLabel(l4.z), activeLabel(l4.w)};
+        d2v *x2 = reinterpret_cast<d2v *>(x) + 2 * q, *r2 = reinterpret_cast<d2v *>(r) + 2 * q;
+        const d2v *p2 = reinterpret_cast<const d2v *>(p) + 2 * q, *t2 = reinterpret_cast<const d2v *>(t) + 2 * q;
+        const d2v xa = x2[0], xb = x2[1], pa = p2[0], pb = p2[1], ra = r2[0], rb = r2[1], ta = t2[0], tb = t2[1];
+        double xv[4] = {xa.x, xa.y, xb.x, xb.y}, rv[4] = {ra.x, ra.y, rb.x, rb.y};
+        const double pv[4] = {pa.x, pa.y, pb.x, pb.y}, tv[4] = {ta.x, ta.y, tb.x, tb.y};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const size_t c = (q << 2) + e;
-            if (!activeLabel(ls[e])) continue;
-            x[c] += alpha * p[c];
-            const double rv = r[c] - alpha * t[c];
-            r[c] = rv;
-            r32[c] = float(rv);
-            acc += rv * rv;
-        }
+        for (int e = 0; e < 4; ++e)
+            if (on[e]) {
+                xv[e] += alpha * pv[e];
+                rv[e] -= alpha * tv[e];
+                acc += rv[e] * rv[e];
+            }
+        x2[0] = d2v{xv[0], xv[1]};
+        x2[1] = d2v{xv[2], xv[3]};
+        r2[0] = d2v{rv[0], rv[1]};
+        r2[1] = d2v{rv[2], rv[3]};
+        reinterpret_cast<float4 *>(r32)[q] = make_float4(float(rv[0]), float(rv[1]), float(rv[2]), float(rv[3]));
     }
     const double total = blockReduce<0>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
-// p = z + beta p (CG.h:191); first: p = z
+// p = z + beta p (CG.h:189-191); first: p = z
 __global__ __launch_bounds__(256) void xpay64Kernel(GridP g, double *__restrict__ p, const float *__restrict__ z, double beta, int first)
 {
     const size_t nq = (size_t(g.nx) * g.ny * g.nz) >> 2;
@@ -2578,24 +2634,45 @@ __global__ __launch_bounds__(256) void xpay64Kernel(GridP g, double *__restrict_
     for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
-        const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const size_t c = (q << 2) + e;
-            if (activeLabel(ls[e])) p[c] = first ? double(z[c]) : double(z[c]) + beta * p[c];
+        if (!anyActive(l4)) continue;
+        const bool on[4] = {activeLabel(l4.x), activeLabel(l4.y), activeLabel(l4.z), activeLabel(l4.w)};
+        d2v *p2 = reinterpret_cast<d2v *>(p) + 2 * q;
+        const float4 zq = reinterpret_cast<const float4 *>(z)[q];
+        const float zv[4] = {zq.x, zq.y, zq.z, zq.w};
+        double pv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!first || !(on[0] && on[1] && on[2] && on[3])) {
+            const d2v pa = p2[0], pb = p2[1];
+            pv[0] = pa.x;
+            pv[1] = pa.y;
+            pv[2] = pb.x;
+            pv[3] = pb.y;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (on[e]) pv[e] = first ? double(zv[e]) : double(zv[e]) + beta * pv[e];
+        p2[0] = d2v{pv[0], pv[1]};
+        p2[1] = d2v{pv[2], pv[3]};
     }
 }
 // widen / narrow a whole grid (inactive cells hold 0 on both sides)
 __global__ __launch_bounds__(256) void widenKernel(double *__restrict__ dst, const float *__restrict__ src, size_t n)
 {
-    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c < n) dst[c] = double(src[c]);
+    const size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x;  // n is a multiple of 4 (grids with nx % 4 == 0) or handled by the tail
+    if (4 * q + 3 < n) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[q];
+        reinterpret_cast<d2v *>(dst)[2 * q] = d2v{double(v.x), double(v.y)};
+        reinterpret_cast<d2v *>(dst)[2 * q + 1] = d2v{double(v.z), double(v.w)};
+    } else
+        for (size_t c = 4 * q; c < n; ++c) dst[c] = double(src[c]);
 }
 __global__ __launch_bounds__(256) void narrowKernel(float *__restrict__ dst, const double *__restrict__ src, size_t n)
 {
-    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c < n) dst[c] = float(src[c]);
+    const size_t q = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (4 * q + 3 < n) {
+        const d2v a = reinterpret_cast<const d2v *>(src)[2 * q], b = reinterpret_cast<const d2v *>(src)[2 * q + 1];
+        reinterpret_cast<float4 *>(dst)[q] = make_float4(float(a.x), float(a.y), float(b.x), float(b.y));
+    } else
+        for (size_t c = 4 * q; c < n; ++c) dst[c] = float(src[c]);
 }
 
 // workgroups of an fp64 vector pass: one per 1024 cells of the active chunks, capped by the room for their partial sums
@@ -2638,12 +2715,12 @@ int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double
 }
 int launchWiden(void *stream, double *dst, const float *src, size_t n)
 {
-    widenKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
+    widenKernel<<<blocksFor((n + 3) / 4, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
     return int(hipGetLastError());
 }
 int launchNarrow(void *stream, float *dst, const double *src, size_t n)
 {
-    narrowKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
+    narrowKernel<<<blocksFor((n + 3) / 4, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, src, n);
     return int(hipGetLastError());
 }
 

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
     uint8_t *cls = sm + E3;  // BoxNode class of the cells of O grown by depth + 1
     __shared__ Box stack[48];
     __shared__ int sp;
-    __shared__ int bb[6], rb[6], sGen;
+    __shared__ int bb[6], rb[6], sGen, sListed;
     __shared__ int scratch[4];
     const int tid = threadIdx.x;
     const int t = tiles[blockIdx.x], ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
             rb[0] = rb[1] = rb[2] = 99;
             rb[3] = rb[4] = rb[5] = -1;
             sGen = 0;
+            sListed = 0;
         }
         __syncthreads();
         {  // O: tight bounding box of the closure cells of the tile inside B (thread = one x-row of the tile)
@@ -824,12 +825,13 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
         }
         __syncthreads();
         {  // R = bounding box of the classes != 0; general band cells with ring <= depth
-            int l0 = 99, l1 = 99, l2 = 99, h0 = -1, h1 = -1, h2 = -1, gen = 0;
+            int l0 = 99, l1 = 99, l2 = 99, h0 = -1, h1 = -1, h2 = -1, gen = 0, listed = 0;
             for (int r = tid; r < mrows; r += kBoxBuildThreads) {
                 const int wj = mlo[1] + r % my, wk = mlo[2] + r / my;
                 for (int wi = mlo[0]; wi <= mhi[0]; ++wi) {
                     const int w = (wk * E + wj) * E + wi;
                     if (cls[w] == kBoxSkip) continue;
+                    ++listed;
                     l0 = min(l0, wi);
                     h0 = max(h0, wi);
                     l1 = min(l1, wj);
@@ -847,13 +849,14 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
                 atomicMin(&rb[2], l2);
                 atomicMax(&rb[5], h2);
                 if (gen) atomicAdd(&sGen, gen);
+                atomicAdd(&sListed, listed);
             }
         }
         __syncthreads();
         const int rlo[3] = {rb[0], rb[1], rb[2]}, rhi[3] = {rb[3], rb[4], rb[5]}, gen = sGen;
         const int rx = rhi[0] - rlo[0] + 1, ry = rhi[1] - rlo[1] + 1, rz = rhi[2] - rlo[2] + 1, nodes = rx * ry * rz;
         (void)mx;
-        if (nodes > kBoxMaxNodes || gen > kBoxMaxGeneral) {
+        if (nodes > kBoxMaxNodes || sListed > kBoxMaxList || gen > kBoxMaxGeneral) {
             __syncthreads();
             if (tid == 0) {
                 int axis = 0;
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
                         const int dg = bandDiag[e];
                         code = dg == 0 ? uint32_t(kBoxGeneral) : uint32_t(kBoxSimple + dg);
                         if (dg == 0) {
-                            gdst[0] = pos;
+                            gdst[0] = int32_t(coords | (code << 16) | (ring << 20));
                             gdst[1] = e;
                             gdst += 2;
                         }

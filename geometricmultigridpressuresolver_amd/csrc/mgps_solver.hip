@@ -7,6 +7,8 @@
 // MGPS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -18,6 +20,7 @@
 #include <thread>
 #include <unordered_map>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "mgps_internal.h"
@@ -94,6 +97,7 @@ struct mgps_solver {
     // coarsest-level dense inverse
     int cn = 0;
     float *cinv = nullptr, *cvec = nullptr;
+    std::shared_ptr<void> cinvShared;  // set when cinv is the device-built inverse, shared with the cache of the last one (buildDeviceInverse)
     int32_t *ccells = nullptr;
     bool tailOfSlabRun = false;  // this solver is the collapsed tail owned by rank 0 of a slab run
     // reductions
@@ -430,7 +434,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.bandBoxes.general);
     }
     for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
-    (void)cacheFree(h->cinv);
+    if (!h->cinvShared) (void)cacheFree(h->cinv);  // (a device-built inverse belongs to its shared holder)
     (void)cacheFree(h->cvec);
     (void)cacheFree(h->ccells);
     (void)cacheFree(h->partials);
@@ -1612,13 +1616,135 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     return MGPS_OK;
 }
 
+// ---- coarsest level past kHostCoarseMax unknowns: factorised and inverted on the device ---------------------------------
+// hipSOLVER through dlopen (like librccl: the library links against nothing but the HIP runtime): potrf + potri in fp64 on the
+// dense matrix.  BASELINE configs 3 / 5 as SURVEY 8(d) states them have 5 levels at 512^3: a 32^3 coarsest level, ~27 000
+// unknowns, 5.8 GB of doubles for the factorisation, 2.9 GB for the fp32 inverse the solve multiplies with.  The last inverse
+// is kept by label pattern (a plugin that rebuilds its solver every sub-step, Plug.cpp:463, rarely changes the coarsest level).
+struct HipSolver {
+    void *lib = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*setStream)(void *, hipStream_t) = nullptr;
+    int (*potrfSize)(void *, int, int, double *, int, int *) = nullptr;
+    int (*potrf)(void *, int, int, double *, int, double *, int, int *) = nullptr;
+    int (*potriSize)(void *, int, int, double *, int, int *) = nullptr;
+    int (*potri)(void *, int, int, double *, int, double *, int, int *) = nullptr;
+    bool ok = false;
+    HipSolver()
+    {
+        for (const char *name : {"libhipsolver.so", "libhipsolver.so.1", "/opt/rocm/lib/libhipsolver.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        auto sym = [&](const char *n) { return dlsym(lib, n); };
+        create = reinterpret_cast<decltype(create)>(sym("hipsolverCreate"));
+        destroy = reinterpret_cast<decltype(destroy)>(sym("hipsolverDestroy"));
+        setStream = reinterpret_cast<decltype(setStream)>(sym("hipsolverSetStream"));
+        potrfSize = reinterpret_cast<decltype(potrfSize)>(sym("hipsolverDpotrf_bufferSize"));
+        potrf = reinterpret_cast<decltype(potrf)>(sym("hipsolverDpotrf"));
+        potriSize = reinterpret_cast<decltype(potriSize)>(sym("hipsolverDpotri_bufferSize"));
+        potri = reinterpret_cast<decltype(potri)>(sym("hipsolverDpotri"));
+        ok = create && destroy && setStream && potrfSize && potrf && potriSize && potri;
+    }
+};
+struct DeviceInverse {
+    float *p = nullptr;
+    int n = 0, device = 0;
+    Dims d;
+    std::vector<uint8_t> labels;
+    ~DeviceInverse() { (void)cacheFree(p); }
+};
+std::mutex gDevInverseGuard;
+std::shared_ptr<DeviceInverse> gDevInverseKept;  // the most recent one
+
+int buildDeviceInverse(mgps_solver *h)
+{
+    mgps_hierarchy *hier = h->hier;
+    const HostLevel &C = hier->lv[size_t(hier->levels - 1)];
+    const int n = hier->coarseN;
+    {
+        std::lock_guard<std::mutex> lock(gDevInverseGuard);
+        const auto &k = gDevInverseKept;
+        if (k && k->n == n && k->device == h->device && k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->labels.size() == C.labels.size() &&
+            std::memcmp(k->labels.data(), C.labels.data(), C.labels.size()) == 0) {
+            h->cinvShared = k;
+            h->cinv = k->p;
+            return MGPS_OK;
+        }
+    }
+    static HipSolver *solver = new HipSolver();  // (never unloaded: process tear-down order)
+    if (!solver->ok)
+        return failH(h, MGPS_ERR_COARSE_TOO_LARGE, "coarsest level has " + std::to_string(n) + " unknowns: above " + std::to_string(kHostCoarseMax) +
+                                                       " the direct solver needs libhipsolver.so, which could not be loaded (raise mg_levels)");
+    const int kLower = 122;  // HIPSOLVER_FILL_MODE_LOWER
+    double *A = nullptr, *work = nullptr;
+    int32_t *index = nullptr, *cells = nullptr;
+    uint8_t *lab = nullptr;
+    int *info = nullptr;
+    void *handle = nullptr;
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(h->stream);
+        (void)cacheFree(A);
+        (void)cacheFree(work);
+        (void)cacheFree(index);
+        (void)cacheFree(cells);
+        (void)cacheFree(lab);
+        (void)cacheFree(info);
+        if (handle) (void)solver->destroy(handle);
+    };
+    auto fail = [&](const std::string &what) {
+        cleanup();
+        return failH(h, MGPS_ERR_COARSE_FACTOR, "coarsest-level factorisation on the device: " + what);
+    };
+    const size_t plane = size_t(C.d.nx) * C.d.ny;
+    if (devAlloc(h, &A, size_t(n) * n, true) != MGPS_OK || devUpload(h, &index, hier->coarseIndex) != MGPS_OK || devUpload(h, &cells, hier->coarseCell) != MGPS_OK ||
+        devAlloc(h, &info, 1, true) != MGPS_OK || devAlloc(h, &lab, C.labels.size() + 2 * plane, false) != MGPS_OK)
+        return fail("allocation");
+    if (hipMemsetAsync(lab, MGPS_EXTERIOR_CELL, C.labels.size() + 2 * plane, h->stream) != hipSuccess ||
+        hipMemcpyAsync(lab + plane, C.labels.data(), C.labels.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        return fail("label upload");
+    if (launchCoarseAssemble(h->stream, n, C.d.nx, C.d.ny, cells, index, lab + plane, A) != 0) return fail("assembly launch");
+    if (solver->create(&handle) != 0 || solver->setStream(handle, h->stream) != 0) return fail("hipsolverCreate");
+    int lw1 = 0, lw2 = 0;
+    if (solver->potrfSize(handle, kLower, n, A, n, &lw1) != 0 || solver->potriSize(handle, kLower, n, A, n, &lw2) != 0) return fail("workspace query");
+    const int lwork = std::max(std::max(lw1, lw2), 1);
+    if (devAlloc(h, &work, size_t(lwork), false) != MGPS_OK) return fail("workspace allocation");
+    int hinfo = 0;
+    if (solver->potrf(handle, kLower, n, A, n, work, lwork, info) != 0) return fail("potrf");
+    if (hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hinfo != 0) {
+        cleanup();
+        return failH(h, MGPS_ERR_COARSE_FACTOR, "coarsest-level matrix is not positive definite");
+    }
+    if (solver->potri(handle, kLower, n, A, n, work, lwork, info) != 0) return fail("potri");
+    auto inv = std::make_shared<DeviceInverse>();
+    if (devAlloc(h, &inv->p, size_t(n) * n, false) != MGPS_OK) return fail("inverse allocation");
+    if (launchCoarseNarrow(h->stream, n, A, inv->p) != 0) return fail("narrow launch");
+    if (hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hinfo != 0)
+        return fail("potri reported " + std::to_string(hinfo));
+    cleanup();
+    inv->n = n;
+    inv->device = h->device;
+    inv->d = C.d;
+    inv->labels.assign(C.labels.begin(), C.labels.end());
+    h->cinvShared = inv;
+    h->cinv = inv->p;
+    std::lock_guard<std::mutex> lock(gDevInverseGuard);
+    gDevInverseKept = inv;
+    return MGPS_OK;
+}
+
 int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
 {
     mgps_hierarchy *hier = h->hier;
     if (needCoarseSolver) {
-        hier->buildDenseInverse();
         h->cn = hier->coarseN;
-        MGPS_TRY(devUpload(h, &h->cinv, hier->coarseInverse));
+        if (hier->coarseOnDevice) MGPS_TRY(buildDeviceInverse(h));
+        else {
+            hier->buildDenseInverse();
+            MGPS_TRY(devUpload(h, &h->cinv, hier->coarseInverse));
+        }
         MGPS_TRY(devUpload(h, &h->ccells, hier->coarseCell));
         MGPS_TRY(devAlloc(h, &h->cvec, size_t(h->cn), true));
     }

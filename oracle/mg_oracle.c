@@ -733,17 +733,23 @@ static int build_coarse_direct(mgo_solver *s)
     const size_t n = (size_t)d.nx * d.ny * d.nz;
     s->cindex = (int32_t *)malloc(n * sizeof(int32_t));
     int cnt = 0;
-    /* numbering: tile order, then in-tile x-fastest order (MG.cpp:296-324) */
+    /* numbering: tile order, then in-tile x-fastest order (MG.cpp:296-324) -- while the coarsest grid is a single tile,
+     * which is every hierarchy the reference's own level rule produces.  A larger coarsest level (BASELINE configs 3 / 5:
+     * 512^3 with 5 levels, 32^3 = 2 x 2 x 2 tiles) is numbered cell by cell instead: the numbering only decides the band
+     * width of this file's Cholesky factor (tile order: ~12 000, cell order: nx * ny <= 1024), not the solution of the
+     * system -- Eigen's SimplicialCholesky reorders by AMD anyway (MG.cpp:405-411). */
     const int tx = (d.nx + TILE - 1) / TILE, ty = (d.ny + TILE - 1) / TILE, tz = (d.nz + TILE - 1) / TILE;
     for (size_t c = 0; c < n; ++c) s->cindex[c] = -1;
-    for (int t = 0; t < tx * ty * tz; ++t) {
-        const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
-        for (int k = tk * TILE; k < (tk + 1) * TILE && k < d.nz; ++k)
-            for (int j = tj * TILE; j < (tj + 1) * TILE && j < d.ny; ++j)
-                for (int i = ti * TILE; i < (ti + 1) * TILE && i < d.nx; ++i) {
+    if (tx * ty * tz == 1) {
+        for (int k = 0; k < d.nz; ++k)
+            for (int j = 0; j < d.ny; ++j)
+                for (int i = 0; i < d.nx; ++i) {
                     const size_t c = cidx(&d, i, j, k);
                     if (is_active(lab[c])) s->cindex[c] = cnt++;
                 }
+    } else {
+        for (size_t c = 0; c < n; ++c)
+            if (is_active(lab[c])) s->cindex[c] = cnt++;
     }
     s->cn = cnt;
     const ptrdiff_t stride[3] = {1, d.nx, (ptrdiff_t)d.nx * d.ny};

@@ -123,12 +123,15 @@ def test_errors_match_host_builder():
 
 
 def test_coarse_level_too_large_on_both_builders():
-    """two levels of a 96^3 box leave > 8192 unknowns on the coarsest level: the direct solver refuses, with the same text"""
+    """two levels of a 96^3 box leave more unknowns on the coarsest level than options.max_coarse_unknowns allows (here 8192, the
+    default of rounds 1 and 2; the default is 32768 since the device factorisation of round 3): the direct solver refuses, with
+    the same text"""
     lab, w, off, lev, dx = make_domain("simple", 64, levels=2)
     msgs = []
     for host in (1, 0):
         o = G.default_options()
         o.host_setup = host
+        o.max_coarse_unknowns = 8192
         with pytest.raises(G.MgpsError) as e:
             G.GeometricMultigridPoissonSolver(lab, w, 2, False, options=o)
         msgs.append(str(e.value))

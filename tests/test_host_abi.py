@@ -34,7 +34,7 @@ def test_options_struct_matches_header():
     assert o.struct_size == C.sizeof(Options)
     assert (o.band_width, o.band_iterations) == (3, 3)  # MG.cpp:141-142
     assert o.jacobi_weight == pytest.approx(2.0 / 3.0)  # Ops.h:291
-    assert o.device == -1 and o.max_coarse_unknowns == 8192
+    assert o.device == -1 and o.max_coarse_unknowns == 32768
     assert (o.pre_sweeps, o.post_sweeps, o.stencil_path) == (1, 1, 0)  # MG.cpp:466-486, 740-757: one sweep per stroke
     assert lib().mgps_status_string(0) == b"ok" and lib().mgps_status_string(2) == b"no HIP device"
 
