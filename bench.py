@@ -302,6 +302,7 @@ def main():
         elapsed, smooth_ms = float(t[0]), float(t[1])
 
     cells = float(n) ** 3  # whole job; a rank holds cells / world of them
+    active_cells = float(((lab[z0:z1] == 0) | (lab[z0:z1] == 3)).sum())  # this rank's INTERIOR + BOUNDARY cells
     # the sweep skips chunks / blocks / tiles without active cells (as the reference skips constant tiles):
     # algorithmic bytes count the cells a launch actually visits on this rank, not the allocation
     swept = solver.swept_cells(0)[1 if use_gs else 0]
@@ -338,8 +339,12 @@ def main():
             "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
+        # the whole cycle against the HBM peak: SURVEY 8(d)'s 60.7 B per fine cell (band passes excluded) x the cells a sweep
+        # visits (active runs), per GPU
+        "vcycle_frac_visited": VCYCLE_BYTES_PER_FINE_CELL * swept * vps / 1e9 / HBM_PEAK_GBS,
         # device time per cycle by stage, all levels (the reference's stopwatch scopes, MG.cpp:436-878; rank 0's figures)
-        "stages_ms_per_cycle": {k: v / max(stages["cycles"], 1) for k, v in stages.items() if k != "cycles"},
+        "stages_ms_per_cycle": {k: v / max(stages["cycles"], 1) for k, v in stages.items() if k not in ("cycles", "fine")},
+        "stages_ms_per_cycle_fine_level": {k: v / max(stages["cycles"], 1) for k, v in stages.get("fine", {}).items()},
         "roofline": {
             "kernel": "fine-level tiled Gauss-Seidel sweep (tiledGSPureKernel + tiledGSMixedKernel, two colours)" if use_gs
             else "fine-level damped-Jacobi sweep (%s<OP_JACOBI>)" % ("stencilPlaneKernel" if n >= 256 and n * n * 4 > (2 << 20) else "stencilQuadKernel"),
@@ -354,12 +359,37 @@ def main():
             "cells_per_launch": swept,
             "cells_allocated": float(n) * n * (z1 - z0),
             "achieved_over_allocated_cells": sweep_bytes * (float(n) * n * (z1 - z0)) / t_sweep / 1e9,
+            # the same launch priced three ways: the cells it visits (frac), the active cells alone (the runs carry row-end
+            # padding), every allocated cell (SURVEY 8(d)'s "13 N^3")
+            "frac_active": sweep_bytes * active_cells / t_sweep / 1e9 / HBM_PEAK_GBS,
+            "frac_allocated": sweep_bytes * (float(n) * n * (z1 - z0)) / t_sweep / 1e9 / HBM_PEAK_GBS,
+            "cells_active": active_cells,
             "note": "per GPU; achieved = %g B x cells the launch visits (active runs only) / mean launch time (HIP events on the solver's stream)" % sweep_bytes,
         },
     }
+    # the band stage of the fine level (launchBandBox: closure + plain launch per stroke, two strokes per cycle): 16 B per band
+    # cell algorithmic (iterate in, rhs, iterate out + the closure's Jacobi value), device time from the stage marks
+    if not slab_run and not use_gs and args.sweeps == 1:
+        try:
+            nband = len(solver.level_array(0, "band"))
+            band_ms = stages["fine"]["boundary_smoother"] / max(stages["cycles"], 1) / 4.0  # four stages per cycle on level 0
+            out["band_stage"] = {
+                "kernel": "bandBoxKernel (closure / plain, mean of the four stage launches of the fine level)",
+                "bound": "hbm",
+                "cells": nband,
+                "ms_per_stage": band_ms,
+                "achieved": 16.0 * nband / (band_ms * 1e-3) / 1e9 if band_ms > 0 else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": 16.0 * nband / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if band_ms > 0 else None,
+                "note": "O(N^2) cells at a line-granular cost: an x-face band row is three cells of one 128-B line per array "
+                        "(profiles/r03_pmc_band_512.txt: 79 / 65 B per band cell fetched + written by the closure / plain launch)",
+            }
+        except Exception as e:
+            out["band_stage"] = {"error": str(e)}
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
     # (profiles/r01_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)
-    for pmc_file in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for pmc_file in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["fine_jacobi_sweep"]
             if str(n) in pmc and not use_gs and world == 1 and args.precision == "fp32":
@@ -380,15 +410,16 @@ def main():
             lab5, w5, h5 = D.interior_cube(512, default_levels(512))
             s5 = G.GeometricMultigridPoissonSolver(lab5, w5, default_levels(512), use_gs, device=local_rank, options=opt)
             b5, x5 = s5.to_device(D.random_rhs(lab5, h5)), s5.new_grid()
+            s5.applyVCycle(x5, b5, False)
             for _ in range(5):
-                s5.applyVCycle(x5, b5, True)
+                s5.applyVCycle(x5, b5, guess)
             s5.profile_enable(True)
             for _ in range(20):
-                s5.applyVCycle(x5, b5, True)
+                s5.applyVCycle(x5, b5, guess)
             ms5, groups5 = s5.profile_read()
             swept5 = s5.swept_cells(0)[1 if use_gs else 0]
             t5 = ms5 * 1e-3 / max(groups5, 1)
-            out["roofline"]["frac_512"] = SMOOTHER_BYTES_PER_CELL * swept5 / t5 / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["frac_512"] = sweep_bytes * swept5 / t5 / 1e9 / HBM_PEAK_GBS
             out["roofline"]["ms_per_launch_512"] = t5 * 1e3
             s5.close()
         except Exception as e:

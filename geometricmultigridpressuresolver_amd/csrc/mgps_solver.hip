@@ -150,6 +150,8 @@ struct mgps_solver {
     std::vector<StageMark> stageMarks;
     std::vector<hipEvent_t> stageEvents;  // 2 per mark
     double stageMs[6] = {0, 0, 0, 0, 0, 0};
+    double stageMsFine[6] = {0, 0, 0, 0, 0, 0};  // the same, level 0 only
+    double stageMsFineLast[6] = {0, 0, 0, 0, 0, 0};  // what the last mgps_stage_times call covered (mgps_stage_times_fine)
     int stageCycles = 0;
     std::string lastError = "";
 };
@@ -632,6 +634,7 @@ void stageFlush(mgps_solver *h)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->stageEvents[2 * q], h->stageEvents[2 * q + 1]) != hipSuccess) continue;
         h->stageMs[h->stageMarks[q].stage] += ms;
+        if (h->stageMarks[q].level == 0) h->stageMsFine[h->stageMarks[q].stage] += ms;
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("      level %d  %s: %.4f ms\n", h->stageMarks[q].level, kStageNames[h->stageMarks[q].stage], double(ms));
     }
@@ -3333,9 +3336,20 @@ try {
     for (int q = 0; q < 6; ++q) {
         out_ms[q] = h->stageMs[q];
         h->stageMs[q] = 0;
+        h->stageMsFineLast[q] = h->stageMsFine[q];
+        h->stageMsFine[q] = 0;
     }
     if (cycles) *cycles = h->stageCycles;
     h->stageCycles = 0;
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
+
+int mgps_stage_times_fine(mgps_solver *h, double out_ms[6])
+try {
+    MGPS_TRY(checkLevel(h, 0, "mgps_stage_times_fine"));
+    if (!out_ms) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_stage_times_fine: NULL pointer");
+    for (int q = 0; q < 6; ++q) out_ms[q] = h->stageMsFineLast[q];
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)

@@ -391,6 +391,9 @@ class GeometricMultigridPoissonSolver:
         names = ("boundary_smoother", "smoother", "residual", "downsample", "direct_solve", "upsample_add")
         out = {k: ms[i] for i, k in enumerate(names)}
         out["cycles"] = n.value
+        fine = (C.c_double * 6)()
+        check(lib().mgps_stage_times_fine(self.h, fine), self.h)
+        out["fine"] = {k: fine[i] for i, k in enumerate(names)}
         return out
 
     def swept_cells(self, level=0):

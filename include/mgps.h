@@ -422,6 +422,8 @@ int mgps_profile_enable(mgps_solver *h, int enable);  /* 0 off, 1 fine-smoother 
  * timed regions.  Synchronises the stream.  Each stage is bracketed by an event pair, so on small levels the
  * figures include the few microseconds between dependent launches. */
 int mgps_stage_times(mgps_solver *h, double out_ms[6], int *cycles);
+/* the level-0 share of what the last mgps_stage_times call returned (same six stages, same cycles) */
+int mgps_stage_times_fine(mgps_solver *h, double out_ms[6]);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
 /* Cells one full-domain sweep of `level` visits: the kernels skip 1024-cell chunks / 256x16xzc blocks /
  * 16^3 tiles without active cells (the reference skips constant tiles the same way, Ops.h:300-312);
