@@ -120,6 +120,14 @@ int rcclAllreduce(void *user, double *values, int count, int op)
     return 0;
 }
 
+// the same on device doubles, on the caller's stream: ordered with the kernels around it, no host hop
+int rcclAllreduceDevice(void *user, double *valuesDev, int count, int op, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    NCCL_TRY(gApi.AllReduce(valuesDev, valuesDev, size_t(count), ncclDouble, op == 0 ? ncclSum : ncclMax, s->comm, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int rcclGather(void *user, const void *send, void *recv, size_t bytes, int root, void *stream)
 {
     auto *s = static_cast<RcclState *>(user);
@@ -265,6 +273,7 @@ try {
     out->destroy = rcclDestroy;
     out->gatherv = rcclGatherv;
     out->scatterv = rcclScatterv;
+    out->allreduce_device = rcclAllreduceDevice;
     return MGPS_OK;
 }
 MGPS_API_CATCH(nullptr)

@@ -1399,12 +1399,19 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         const char *e = getenv("MGPS_CG_DEVICE_SCALARS");  // 0: the host computes alpha and beta (A/B timing)
         return !(e && e[0] == '0');
     }();
-    const bool devScal = !h->dist && deviceScalarsAllowed && !checkGathered;
+    // Slab runs do the same when the transport can all-reduce device doubles on the solver's stream (mgps_comm::
+    // allreduce_device: ncclAllReduce for the RCCL transport): every rank's reduction leaves its share on the device, the
+    // collective sums it there, the scalar kernel divides.
+    const bool devScal = (!h->dist || h->comm.allreduce_device != nullptr) && deviceScalarsAllowed && !checkGathered;
     double *scal = h->cgScal;
     float *betaDev = reinterpret_cast<float *>(h->cgScal + 4);
+    auto sumOverRanks = [&](double *dev) -> int {  // (slab runs: the value a reduction just left on the device, summed in place)
+        if (h->dist) MGPS_COMM(h, h->comm.allreduce_device(h->comm.user, dev, 1, 0, h->stream));
+        return MGPS_OK;
+    };
     auto dotToDevice = [&](const float *v) -> int {  // scal[3] = <v, r> right after precondition(v, r)
         if (!gathered) MGPS_LAUNCH(h, launchReduce(h->stream, 0, F.g, v, r, h->partials, scal + 3));
-        return MGPS_OK;
+        return sumOverRanks(scal + 3);
     };
     h->dotTarget = devScal ? scal + 3 : nullptr;
     MGPS_LAUNCH(h, launchZero(h->stream, p, F.d.cells()));  // CG.h:69
@@ -1430,6 +1437,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         // t = A p (CG.h:110) and <p, A p> (CG.h:121) in one pass over p
         MGPS_TRY(exchangeGhosts(h, 0, p));
         MGPS_LAUNCH(h, launchApplyDot(h->stream, F.g, t, p, h->dotPartials, devScal ? scal + 1 : h->resultDev));
+        if (devScal) MGPS_TRY(sumOverRanks(scal + 1));
         double alpha = 0;
         if (!devScal) {
             double pAp = 0;
@@ -1440,7 +1448,13 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         const bool mixed = useMG && h->opt.precision == 1;  // the pass also leaves max |r| for the cycle's normalisation
         MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr,
                                       mixed ? h->mixMax : nullptr));
-        MGPS_TRY(fetchReduction(h, 1, &res2));
+        if (devScal && h->dist) {  // |r|^2 summed on the device too: the fetch below is then the iteration's only host round trip
+            MGPS_TRY(sumOverRanks(h->resultDev));
+            MGPS_HIP(h, hipMemcpyAsync(h->resultHost, h->resultDev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            MGPS_HIP(h, hipStreamSynchronize(h->stream));
+            res2 = *h->resultHost;
+        } else
+            MGPS_TRY(fetchReduction(h, 1, &res2));
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161 -- the counter is not advanced on the exit pass

@@ -28,6 +28,7 @@ _GATH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c
 _DEST = C.CFUNCTYPE(None, C.c_void_p)
 _GATHV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
 _SCATV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+_ALLRD = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 
 class CommStruct(C.Structure):
@@ -45,6 +46,7 @@ class CommStruct(C.Structure):
         ("destroy", _DEST),
         ("gatherv", _GATHV),
         ("scatterv", _SCATV),
+        ("allreduce_device", _ALLRD),
     ]
 
 
@@ -94,8 +96,9 @@ class TorchDistComm:
         self.exchanges = 0
         self.bytes_sent = 0
         self._cb = (_EXCH(self._exchange), _ALLR(self._allreduce), _GATH(self._gather), _GATH(self._scatter))
-        self._cbv = (_GATHV(self._gatherv), _SCATV(self._scatterv))
+        self._cbv = (_GATHV(self._gatherv), _SCATV(self._scatterv), _ALLRD(self._allreduce_device))
         self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST(), *self._cbv)
+        self.device_allreduces = 0
 
     # -- staging helpers ---------------------------------------------------------------------------
     def _d2h(self, ptr, nbytes, stream):
@@ -143,6 +146,18 @@ class TorchDistComm:
             return 0
         except Exception as e:
             print("TorchDistComm.allreduce failed:", e, flush=True)
+            return 1
+
+    def _allreduce_device(self, user, values_dev, count, op, stream):
+        """device doubles, in place: staged through the host here (RCCL does it on the stream)"""
+        try:
+            self.device_allreduces += 1
+            t = self._d2h(values_dev, 8 * count, stream).view(torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=self.group)
+            self._h2d(values_dev, t.view(torch.uint8))
+            return 0
+        except Exception as e:
+            print("TorchDistComm.allreduce_device failed:", e, flush=True)
             return 1
 
     def _gather(self, user, send, recv, nbytes, root, stream):

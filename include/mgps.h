@@ -355,6 +355,11 @@ typedef struct mgps_comm {
                    int root, void *hip_stream);
     int (*scatterv)(void *user, const void *send_dev, const size_t *counts, const size_t *displs, void *recv_dev, size_t recv_bytes,
                     int root, void *hip_stream);
+    /* in-place all-reduce of `count` DEVICE doubles, ordered on hip_stream with the kernels around it (op as above).  With it
+     * the slab PCG keeps alpha and beta on the device like the single-device loop: the scalars <p, A p> and <z, r> never meet
+     * the host and |r|^2 -- the convergence test -- is the one host round trip of an iteration.  NULL is allowed: the loop then
+     * sums every scalar through `allreduce` (three round trips per iteration). */
+    int (*allreduce_device)(void *user, double *values_dev, int count, int op, void *hip_stream);
 } mgps_comm;
 
 /* RCCL transport.  Rank 0 calls mgps_rccl_unique_id and ships the 128 bytes to the other ranks by

@@ -95,6 +95,8 @@ def gpu_mode():
             sw = whole.solveGeometricConjugateGradient(xw, whole.to_device(bd), 1e-5, 200, True)
             ss = slab.solveGeometricConjugateGradient(xs, slab.to_device(bd[z0:z1]), 1e-5, 200, True)
             assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+            # alpha and beta stayed on the device: the CG scalars were summed through the transport's device all-reduce
+            assert comm.device_allreduces >= 3 * ss["iterations"], (comm.device_allreduces, ss)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
             # exchanges queued on the transfer stream beside the interior part of the sweep that made their planes

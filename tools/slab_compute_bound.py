@@ -12,7 +12,7 @@ import time
 import torch
 
 from geometricmultigridpressuresolver_amd import domains as D
-from geometricmultigridpressuresolver_amd.distributed import _ALLR, _DEST, _EXCH, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver, slab_partition
+from geometricmultigridpressuresolver_amd.distributed import _ALLR, _ALLRD, _DEST, _EXCH, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver, slab_partition
 
 
 class NullComm:
@@ -25,7 +25,7 @@ class NullComm:
             return 0
 
         self._cb = (_EXCH(exch), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
-        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0))
+        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0))
         self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
 
 
