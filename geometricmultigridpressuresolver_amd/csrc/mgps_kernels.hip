@@ -2220,7 +2220,10 @@ int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, con
     const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
     const int kc = 16;
     const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8, nbz = (coarse.nz + kc - 1) / kc;
-    if (coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
+    // (the same choice as launchRestrict: where the coarse level's activity runs hold a clearly smaller part of the level -- a
+    // free surface -- the list-driven kernel wins: round 2 always marched here, 124 against 84 us on the 512^3 pool)
+    const bool runsWin = coarse.chunks && double(coarse.nchunks) * coarse.chunkCells * 1.3 * runCostFactor(coarse.chunkCells) < 0.8 * double(n);
+    if (!runsWin && coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
         restrictMarchKernel<__half><<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby, fm);
         return int(hipGetLastError());
     }
