@@ -383,7 +383,7 @@ def main():
                 "unit": "GB/s",
                 "frac": 16.0 * nband / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if band_ms > 0 else None,
                 "note": "O(N^2) cells at a line-granular cost: an x-face band row is three cells of one 128-B line per array "
-                        "(profiles/r03_pmc_band_512.txt: 79 / 65 B per band cell fetched + written by the closure / plain launch)",
+                        "(profiles/r03_pmc_hbm_traffic.json, bandBoxKernel entries: 84 / 68 B per band cell fetched + written by the closure / plain launch at 1024^3)",
             }
         except Exception as e:
             out["band_stage"] = {"error": str(e)}

@@ -87,7 +87,8 @@ typedef struct mgps_options {
                                x and b stay fp32 at the boundary.  Same iteration counts either way (measured at 512^3
                                and 1024^3); with fp64 vectors the residual recomputed at the end (CG.h:203-206) is a
                                true one instead of flooring at eps * cond (3e-3 at 512^3, 2e-2 at 1024^3 on the
-                               free-surface case), for +17..36 % solve time.  Slab runs exchange the ghost planes of
+                               free-surface case), for +15..21 % solve time at 512^3 (round 3: 16-byte accesses in the fp64 passes; +31..40 % before),
+                               +30..36 % at 1024^3.  Slab runs exchange the ghost planes of
                                these vectors as doubles */
     int (*interrupt)(void *user); /* non-zero stops the call with MGPS_ERR_INTERRUPTED (UT_Interrupt::opInterrupt, which the
                                      reference polls in every operator loop, e.g. Ops.h:319).  Polled before every PCG
