@@ -208,7 +208,9 @@ __device__ __forceinline__ bool listQuad(const int32_t *__restrict__ chunks, int
 // lanes whose x-neighbour quad lives in another lane's registers: all but the ends of a run
 __device__ __forceinline__ int listRunMask(const int32_t *chunks, int chunkCells) { return (chunks && chunkCells < kWaveChunkCells) ? (chunkCells >> 2) - 1 : kWave - 1; }
 
-template <int OP, bool DOT = false, class TX = float>
+// XZERO: the iterate is known to be zero everywhere (the first sweep of a stroke that starts from the cleared grid, MG.cpp:439-440 /
+// 566): nothing of x is loaded and nobody had to clear it
+template <int OP, bool DOT = false, class TX = float, bool XZERO = false>
 __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
                                                           const float *__restrict__ b, float omega, unsigned nblocks,
                                                           const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr,
@@ -231,15 +233,16 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
     const size_t c = row * sy + i;
 
-    const float4 xc = Cell<TX>::load4(x + c);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 xc = XZERO ? zero4 : Cell<TX>::load4(x + c);
     // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
     // results are discarded, the loads only have to stay in bounds
     const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
     const size_t czm = (k > 0 || g.ghostLo) ? c - sz : c, czp = (k < g.nz - 1 || g.ghostHi) ? c + sz : c;
-    const float4 ym = Cell<TX>::load4(x + cym);
-    const float4 yp = Cell<TX>::load4(x + cyp);
-    const float4 zm = Cell<TX>::load4(x + czm);
-    const float4 zp = Cell<TX>::load4(x + czp);
+    const float4 ym = XZERO ? zero4 : Cell<TX>::load4(x + cym);
+    const float4 yp = XZERO ? zero4 : Cell<TX>::load4(x + cyp);
+    const float4 zm = XZERO ? zero4 : Cell<TX>::load4(x + czm);
+    const float4 zp = XZERO ? zero4 : Cell<TX>::load4(x + czp);
     const uchar4 lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
@@ -248,8 +251,10 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
-    if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
-    if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
+    if (!XZERO) {
+        if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
+        if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
+    }
 
     const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
     const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
@@ -849,7 +854,8 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
 
-template <class TX, bool CLOSURE, bool DOT, bool GEN>
+// XZERO (closure mode): src is zero everywhere (see stencilQuadKernel): no value of it is loaded
+template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
 __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                                               TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
                                                               const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
     // a region cell's address = the region's origin + a 32-bit offset inside the region (it stays below 32 planes)
     const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
     const ptrdiff_t origin = gi[0];
-    src += origin;
+    if (!XZERO) src += origin;
     b += origin;
     dst += origin;
     if (CLOSURE && snap) snap += origin;
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
             const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
             const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
             const unsigned c = cellOf(ue[m]);
-            xv[m] = rd(src, need ? c : 0u);
+            xv[m] = XZERO ? 0.f : rd(src, need ? c : 0u);
             bv[m] = rdf(b, bneed ? c : 0u);
         }
 #pragma unroll
@@ -1792,6 +1798,8 @@ size_t stencilSweptCells(const GridP &g)
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                   bool skipInactive)
 {
+    // x == nullptr: the iterate is zero everywhere (Jacobi on a level that takes the quad sweep and has no general cells to patch)
+    if (!x && (op != OP_JACOBI || stencilKernelOf(g) != 1 || g.nbnd > 0)) return int(hipErrorInvalidValue);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const int forced = forcedStencil(g);
@@ -1816,7 +1824,10 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
         const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
         const int32_t *chunks = list ? g.chunks : nullptr;
         if (nb > 0) switch (op) {
-                case OP_JACOBI: stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
+                case OP_JACOBI:
+                    if (x) stencilQuadKernel<OP_JACOBI><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks);
+                    else stencilQuadKernel<OP_JACOBI, false, float, true><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks);  // x == 0 everywhere
+                    break;
                 case OP_RESIDUAL: stencilQuadKernel<OP_RESIDUAL><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
                 default: stencilQuadKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, chunks); break;
             }
@@ -2022,7 +2033,11 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
         if (bx.anyGeneral) MGPS_BOX_LAUNCH2(C, D, true); \
         else MGPS_BOX_LAUNCH2(C, D, false);              \
     } while (0)
-    if (closure) {
+    if (closure && !src) {  // the iterate is zero everywhere
+        if (dot) return int(hipErrorInvalidValue);
+        if (bx.anyGeneral) bandBoxKernel<TX, true, false, true, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld);
+        else bandBoxKernel<TX, true, false, false, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld);
+    } else if (closure) {
         if (dot) MGPS_BOX_LAUNCH(true, true);
         else MGPS_BOX_LAUNCH(true, false);
     } else {
@@ -2038,7 +2053,7 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
                   bool half, const MixScale &ms, double *dotPartials, const void *dotOld)
 {
     if (bx.ngroups <= 0) return 0;
-    if (src == dst || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own)
+    if ((src == dst) || (!src && !closure) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: zero everywhere, closure mode)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (half)
         return launchBandBoxT<__half>(s, g, bx, closure, static_cast<const __half *>(src), b, static_cast<__half *>(dst), static_cast<__half *>(snap), omega, ms,

@@ -716,6 +716,20 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
     return MGPS_OK;
 }
 
+// A down-stroke that starts from the cleared iterate (MG.cpp:439-440, 566) can skip the clearing launch when it runs as "sweep,
+// closure launch, plain launch" on a level that takes the quad sweep: both readers of the iterate take it as zero, and the grid
+// itself becomes the stroke's spare.  Own grids only: their chunks without active cells hold 0 already.
+bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float *other, const float *b, bool dot)
+{
+    static const bool allowed = [] {  // MGPS_ZERO_START=0: clear and read the grid (A/B timing)
+        const char *e = getenv("MGPS_ZERO_START");
+        return !(e && e[0] == '0');
+    }();
+    const DevLevel &L = h->lv[l];
+    return allowed && !dot && !h->dist && !h->useGS && h->opt.pre_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && stencilKernelOf(L.g) == 1 &&
+           !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
+}
+
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // The smoother runs options.pre_sweeps (down) / post_sweeps (up) times; the reference's count is one.
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
@@ -723,7 +737,9 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
 // Ghost traffic of a stroke: whole planes after whatever rewrote the whole grid (the caller's
 // prolongation / initial guess, the full-domain smoother), packed band cells after band passes.
 // dot: see mgps_solver::gatherDot (the caller folds the partials afterwards)
-int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh, bool dot = false)
+// xZero: `cur` is known to be zero everywhere and was NOT cleared (strokeTakesZero said the stroke needs no copy of it): the sweep
+// and the closure launch take the iterate as zero
+int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh, bool dot = false, bool xZero = false)
 {
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
@@ -747,7 +763,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             } else {
                 GridP gs = L.g;
                 gs.nbnd = 0;  // every BOUNDARY cell lies in the band closure: the closure launch computes the general ones as well
-                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, cur, b, h->opt.jacobi_weight, true));
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, xZero ? nullptr : cur, b, h->opt.jacobi_weight, true));
             }
             if (timed) {
                 MGPS_TRY(profMark(h, false));
@@ -755,7 +771,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             }
         }
         StageScope scope(h, ST_BAND, l);
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, cur, b, other, L.r, h->opt.jacobi_weight, false, MixScale{}, sinkA, other));
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, xZero ? nullptr : cur, b, other, L.r, h->opt.jacobi_weight, false, MixScale{}, sinkA, other));
         std::swap(cur, other);
         MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, L.r));
         return MGPS_OK;
@@ -900,13 +916,15 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     std::vector<float *> cur(nlv, nullptr), other(nlv, nullptr);
     cur[0] = x;
     other[0] = h->lv[0].tmp;
-    bool fresh = false;
+    bool fresh = false, zero0 = false;
     if (!useInitialGuess) {  // MG.cpp:439-440
-        if (ownGrid) MGPS_TRY(zeroOwnGrid(h, 0, x, true));
+        zero0 = ownGrid && strokeTakesZero(h, 0, cur[0], other[0], b, h->gatherDot && !hasBottom);
+        if (zero0) {
+        } else if (ownGrid) MGPS_TRY(zeroOwnGrid(h, 0, x, true));
         else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
-    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom));
+    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom, zero0));
     if (hasBottom) {
         const float *rhs = b;
         // options.interrupt is also polled once per level and stroke of a single-device cycle (the reference polls inside
@@ -919,8 +937,9 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 cur[l] = F.x;
                 other[l] = F.tmp;
                 rhs = F.b;
-                MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
-                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true));
+                const bool zl = strokeTakesZero(h, l, cur[l], other[l], rhs, false);
+                if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
+                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
             }
             bool rExchanged = false;
             {
@@ -995,8 +1014,9 @@ int innerCycle(mgps_solver *h, int first, float **result)
         DevLevel &F = h->lv[l], &C = h->lv[l + 1];
         cur[l] = F.x;
         other[l] = F.tmp;
-        MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
-        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, true, true));
+        const bool zl = strokeTakesZero(h, l, cur[l], other[l], F.b, false);
+        if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
+        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, true, true, false, zl));
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], F.b, 0.f, true));
         MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
     }
