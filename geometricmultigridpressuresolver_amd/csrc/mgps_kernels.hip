@@ -298,7 +298,7 @@ constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the 
 // lerp of Ops.h:841-871: (1 - f) a + f b, this exact form (HDK's SYSlerp breaks the R / P symmetry, Ops.h:837-839)
 __device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
 
-template <int OP, bool DOT = false>
+template <int OP, bool DOT = false, bool XZERO = false>  // XZERO: see stencilQuadKernel
 __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ b, float omega,
@@ -323,17 +323,18 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     const ptrdiff_t dym = jc > 0 ? -ptrdiff_t(sy) : 0, dyp = jc < g.ny - 1 ? ptrdiff_t(sy) : 0;
     const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
 
-    float4 xm = *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c));
-    float4 xc = *reinterpret_cast<const float4 *>(x + c);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xm = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c));
+    float4 xc = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP != OP_APPLY) bc = streamLoad4(b + c);
     uchar4 lc = streamLoad4(g.lab + c);
     float4 hy = make_float4(0.f, 0.f, 0.f, 0.f);  // y-halo row this thread stages (top / bottom rows only)
-    if (rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
-    if (rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
+    if (!XZERO && rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
+    if (!XZERO && rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
     float hx = 0.f;  // x-halo cell this thread stages (first / last lane only)
-    if (colL) hx = ic > 0 ? x[c - 1] : 0.f;
-    if (colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
+    if (!XZERO && colL) hx = ic > 0 ? x[c - 1] : 0.f;
+    if (!XZERO && colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
 
     int buf = 0;
     for (int k = k0; k < k1; ++k) {
@@ -345,17 +346,17 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         if (colR) me[4] = hx;
         // next plane: issue its loads before this plane is computed
         const size_t cn = (k + 1 < g.nz || g.ghostHi) ? c + sz : c;
-        const float4 xp = *reinterpret_cast<const float4 *>(x + cn);
+        const float4 xp = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + cn);
         float4 bn = bc, hyn = hy;
         uchar4 ln = lc;
         float hxn = hx;
         if (k + 1 < k1) {
             if (OP != OP_APPLY) bn = streamLoad4(b + cn);
             ln = streamLoad4(g.lab + cn);
-            if (rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
-            if (rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
-            if (colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
-            if (colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
+            if (!XZERO && rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
+            if (!XZERO && rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
+            if (!XZERO && colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
+            if (!XZERO && colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
         }
         __syncthreads();
         const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
@@ -1798,8 +1799,8 @@ size_t stencilSweptCells(const GridP &g)
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                   bool skipInactive)
 {
-    // x == nullptr: the iterate is zero everywhere (Jacobi on a level that takes the quad sweep and has no general cells to patch)
-    if (!x && (op != OP_JACOBI || stencilKernelOf(g) != 1 || g.nbnd > 0)) return int(hipErrorInvalidValue);
+    // x == nullptr: the iterate is zero everywhere (Jacobi on a level that takes the quad or the plane sweep and has no general cells to patch)
+    if (!x && (op != OP_JACOBI || stencilKernelOf(g) == 3 || g.nbnd > 0)) return int(hipErrorInvalidValue);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const int forced = forcedStencil(g);
@@ -1815,7 +1816,10 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
         const unsigned nb = list ? unsigned(g.nplaneBlocks) : nbx * nby * nbz;
         const int32_t *blocks = list ? g.planeBlocks : nullptr;
         if (nb > 0) switch (op) {
-                case OP_JACOBI: stencilPlaneKernel<OP_JACOBI><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
+                case OP_JACOBI:
+                    if (x) stencilPlaneKernel<OP_JACOBI><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks);
+                    else stencilPlaneKernel<OP_JACOBI, false, true><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks);  // x == 0 everywhere
+                    break;
                 case OP_RESIDUAL: stencilPlaneKernel<OP_RESIDUAL><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
                 default: stencilPlaneKernel<OP_APPLY><<<nb, 64 * kPlaneRows, 0, s>>>(g, out, x, b, omega, nbx, nby, nbz, zc, blocks); break;
             }
@@ -2378,11 +2382,35 @@ int launchCoarseNarrow(void *stream, int n, const double *A, float *inv)
     return int(hipGetLastError());
 }
 
+// the same with the gather inside: every workgroup (four rows) stages the gathered rhs in LDS itself -- one launch instead of
+// two on the cycle's critical path (the rhs is a few KB: re-gathered from the L2 by each workgroup).  n <= kCoarseLdsMax
+constexpr int kCoarseLdsMax = 8192;
+__global__ __launch_bounds__(256) void coarseSolveFusedKernel(int n, const float *__restrict__ inv, const int32_t *__restrict__ cells,
+                                                              const float *__restrict__ b, float *__restrict__ x)
+{
+    __shared__ float v[kCoarseLdsMax];
+    for (int c = threadIdx.x; c < n; c += 256) v[c] = b[cells[c]];
+    __syncthreads();
+    const int row = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (row >= n) return;
+    const float *r = inv + size_t(row) * n;
+    double acc = 0.0;
+    for (int c = lane; c < n; c += kWave) acc += double(r[c]) * double(v[c]);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) x[cells[row]] = float(acc);
+}
+
 int launchCoarseSolve(void *stream, int n, const float *inverse, const int32_t *cells, float *x, const float *b,
                       float *gathered)
 {
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n <= kCoarseLdsMax && x != b) {
+        coarseSolveFusedKernel<<<blocksFor(size_t(n), 4), 256, 0, s>>>(n, inverse, cells, b, x);
+        return int(hipGetLastError());
+    }
     coarseGatherKernel<<<blocksFor(size_t(n), 256), 256, 0, s>>>(n, cells, b, gathered);
     coarseMatVecKernel<<<blocksFor(size_t(n), 4), 256, 0, s>>>(n, inverse, cells, gathered, x);
     return int(hipGetLastError());

@@ -717,7 +717,7 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
 }
 
 // A down-stroke that starts from the cleared iterate (MG.cpp:439-440, 566) can skip the clearing launch when it runs as "sweep,
-// closure launch, plain launch" on a level that takes the quad sweep: both readers of the iterate take it as zero, and the grid
+// closure launch, plain launch" on a level that takes the quad or the plane-marching sweep: both readers of the iterate take it as zero, and the grid
 // itself becomes the stroke's spare.  Own grids only: their chunks without active cells hold 0 already.
 bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float *other, const float *b, bool dot)
 {
@@ -726,7 +726,7 @@ bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float 
         return !(e && e[0] == '0');
     }();
     const DevLevel &L = h->lv[l];
-    return allowed && !dot && !h->dist && !h->useGS && h->opt.pre_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && stencilKernelOf(L.g) == 1 &&
+    return allowed && !dot && !h->dist && !h->useGS && h->opt.pre_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && stencilKernelOf(L.g) != 3 &&
            !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
 }
 
