@@ -250,7 +250,9 @@ static bool coarsenLabels(const HostLevel &fine, HostLevel &coarse)
 
 // Band list (Ops.cpp:165-469): BOUNDARY cells plus `width`-1 rings of INTERIOR cells grown
 // through face neighbours, ordered by (tile id, k, j, i).
-static void buildBand(HostLevel &L, int width)
+// tk0 / tk1 (slab runs): only the tiles of the z-rows [tk0, tk1] (the rank's window: its slab, the ghost planes and the planes
+// its one-exchange band stage reaches); the other tiles get no entries
+static void buildBand(HostLevel &L, int width, int tk0 = 0, int tk1 = -1)
 {
     // Tile by tile, which is the order of the list: a band cell of a 16^3 tile lies within width-1 steps of a
     // BOUNDARY cell, so the tile plus a halo of width-1 cells decides its part of the list.  Every tile is an
@@ -262,7 +264,11 @@ static void buildBand(HostLevel &L, int width)
     const int64_t ntiles = int64_t(tx) * ty * tz;
     L.bandTileStart.assign(size_t(ntiles) + 1, 0);
     int32_t *tileCount = L.bandTileStart.data() + 1;
-    parallelCollect<int32_t>(ntiles, 64, L.band, [&](int64_t b, int64_t e, std::vector<int32_t> &out) {
+    if (tk1 < 0 || tk1 >= tz) tk1 = tz - 1;
+    tk0 = std::max(0, std::min(tk0, tk1));
+    const int64_t tFirst = int64_t(tk0) * tx * ty, tCount = int64_t(tk1 - tk0 + 1) * tx * ty;
+    parallelCollect<int32_t>(tCount, 64, L.band, [&](int64_t b0, int64_t e0, std::vector<int32_t> &out) {
+        const int64_t b = b0 + tFirst, e = e0 + tFirst;
         // (the outermost layer of blk is never written: it stays EXTERIOR)
         std::vector<uint8_t> blk(size_t(F) * F * F, uint8_t(MGPS_EXTERIOR_CELL)), dist(size_t(F) * F * F);
         std::vector<int32_t> cur, nxt;
@@ -1985,8 +1991,11 @@ MGPS_API_CATCH(nullptr)
 
 // forceCoarseSolver: factorise the last level even in a one-level hierarchy (the collapsed tail of a
 // slab solver can consist of the direct solve alone).  requireShell: insist on the EXTERIOR shell.
+// window (slab runs; fine planes [window[0], window[1]) of the rank): band lists only for the tiles the rank's slab builders
+// read -- its slab and kSlabWindowMargin planes either side on every level; no coarsest-level factor (the tail builds its own).
+// Labels of all levels stay global (the collapse level needs them).  mgps_get_hierarchy completes such a hierarchy on demand.
 int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
-                          const mgps_options *opt, bool forceCoarseSolver, bool requireShell)
+                          const mgps_options *opt, bool forceCoarseSolver, bool requireShell, const int *window)
 {
     if (!out) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_create: out is NULL");
     *out = nullptr;
@@ -2048,7 +2057,18 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     }
     lap.lap("hierarchy: copy + shell check");
     // the fine level's band list (the largest single piece, MG.cpp:279-281) beside the coarsening chain
-    std::thread fineBand([H] { buildBand(H->lv[0], H->bandWidth); });
+    constexpr int kSlabWindowMargin = kBandMaxDepth + 3;  // ghost plane + the closure planes of the one-exchange band stage + one
+    auto tileRows = [&](int l, int &tk0, int &tk1) {
+        tk0 = 0;
+        tk1 = -1;
+        if (!window) return;
+        tk0 = std::max(0, ((window[0] >> l) - kSlabWindowMargin)) / kTile;
+        tk1 = ((window[1] >> l) + kSlabWindowMargin) / kTile;
+    };
+    H->windowed = window != nullptr;
+    int ftk0, ftk1;
+    tileRows(0, ftk0, ftk1);
+    std::thread fineBand([H, ftk0, ftk1] { buildBand(H->lv[0], H->bandWidth, ftk0, ftk1); });
     int levels = mg_levels;
     int shellLost = 0;
     for (int l = 1; l < levels; ++l) {  // MG.cpp:238-253
@@ -2076,12 +2096,14 @@ int mgps::hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const ui
     H->lv.resize(levels);
     lap.lap("hierarchy: coarsen labels + fine band list");
     for (int l = 1; l < levels; ++l) {
-        buildBand(H->lv[size_t(l)], H->bandWidth);  // MG.cpp:279-281
+        int tk0, tk1;
+        tileRows(l, tk0, tk1);
+        buildBand(H->lv[size_t(l)], H->bandWidth, tk0, tk1);  // MG.cpp:279-281
         lap.lap("hierarchy: band list");
     }
     // A one-level hierarchy never reaches the direct solve (applyVCycle returns at MG.cpp:516-517);
     // the reference still factorises the fine matrix there, which serves nothing, so it is skipped.
-    const int rc = (levels > 1 || forceCoarseSolver) ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
+    const int rc = ((levels > 1 || forceCoarseSolver) && !window) ? buildCoarseSolver(*H, o.max_coarse_unknowns) : MGPS_OK;
     lap.lap("hierarchy: coarse factor");
     if (rc != MGPS_OK) {
         delete H;

@@ -246,7 +246,7 @@ int launchBoundaryRows(void *stream, const Dims &d, const uint8_t *labels, const
 // the label-only half of unitTestBoundaryCells (Ops.h:1771-1870): every INTERIOR cell has six active neighbours
 void checkInteriorCells(const uint8_t *labels, int nx, int ny, int nz, int *pass);
 int hierarchyCreate(mgps_hierarchy **out, int nx, int ny, int nz, const uint8_t *labels, int mg_levels,
-                    const mgps_options *opt, bool forceCoarseSolver, bool requireShell);
+                    const mgps_options *opt, bool forceCoarseSolver, bool requireShell, const int *window = nullptr);
 // pieces of the host builder the device-side set-up shares: the activity list of a level from the flags of its
 // runs of 64 cells, and the Gauss-Seidel tile lists from the per-tile kinds ((active cells << 1) | all INTERIOR)
 void chunkListsFromFlags(HostLevel &L, const uint8_t *segAct, int64_t nseg);
@@ -513,6 +513,7 @@ struct mgps_hierarchy {
     int levels = 0;
     int bandWidth = 3;
     bool light = false;  // hierarchyLight: only the extents of the levels and the labels of the coarsest one
+    bool windowed = false;  // slab runs: band lists of the rank's z-window only, no coarsest-level factor
     std::vector<mgps::HostLevel> lv;
     // coarsest-level direct solver
     int coarseN = 0;

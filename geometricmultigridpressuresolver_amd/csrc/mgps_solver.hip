@@ -87,6 +87,7 @@ struct DevLevel {
 
 struct mgps_solver {
     mgps_hierarchy *hier = nullptr;  // global hierarchy (all levels, whole grid)
+    std::vector<mgps_hierarchy *> retiredHier;  // (mgps_get_hierarchy replaced a slab rank's windowed hierarchy: freed with the solver)
     mgps_options opt{};
     bool useGS = false;
     int device = 0;
@@ -462,6 +463,7 @@ void freeAll(mgps_solver *h)
     for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->stageEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
+    for (mgps_hierarchy *r : h->retiredHier) mgps_hierarchy_destroy(r);
     delete h;
 }
 
@@ -2787,7 +2789,14 @@ try {
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
     mgps_hierarchy *hier = nullptr;
-    MGPS_TRY(mgps_hierarchy_create(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o));
+    {  // the rank's window of the hierarchy: labels of every level, band lists around its slab only
+        static const bool windowedSetup = [] {  // MGPS_SLAB_WINDOW=0: band lists of the whole grid on every rank (rounds 1-2; A/B)
+            const char *e = getenv("MGPS_SLAB_WINDOW");
+            return !(e && e[0] == '0');
+        }();
+        const int window[2] = {splits[rank], splits[rank + 1]};
+        MGPS_TRY(hierarchyCreate(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o, false, true, (windowedSetup && P > 1) ? window : nullptr));
+    }
     // distributed levels (distributedLevelsFor); the last level is always collapsed
     const int D = distributedLevelsFor(splits, P, nx, ny, hier->levels, use_gauss_seidel != 0, o);
     if (D < 1) {
@@ -2977,6 +2986,18 @@ int mgps_levels(const mgps_solver *h) { return h ? h->totalLevels : 0; }
 const mgps_hierarchy *mgps_get_hierarchy(const mgps_solver *hc)
 try {
     auto *h = const_cast<mgps_solver *>(hc);
+    if (h && h->hier && h->hier->windowed) {  // a slab rank's window: complete it from the global labels it holds
+        mgps_hierarchy *full = nullptr;
+        const Dims d0 = h->hier->lv[0].d;
+        if (hierarchyCreate(&full, d0.nx, d0.ny, d0.nz, h->hier->lv[0].labels.data(), h->totalLevels, &h->opt, false, true) != MGPS_OK) {
+            failH(h, MGPS_ERR_HIERARCHY, std::string("mgps_get_hierarchy: ") + lastGlobalError());
+            return nullptr;
+        }
+        // (the device levels keep views into the old labels: the old hierarchy stays alive with the solver)
+        h->retiredHier.push_back(h->hier);
+        h->hier = full;
+        return full;
+    }
     if (!h || !h->hier || !h->hier->light) return h ? h->hier : nullptr;
     (void)hipSetDevice(h->device);
     const Dims d = h->lv[0].d;

@@ -1,0 +1,32 @@
+"""Set-up time of one rank of a P-rank slab run (null transport, one GPU): python tools/slab_setup_time.py N P RANK
+MGPS_SLAB_WINDOW=0 builds the band lists of the whole grid on the rank (rounds 1-2), the default only the rank's window."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import torch
+from geometricmultigridpressuresolver_amd import domains as D
+from geometricmultigridpressuresolver_amd.distributed import _ALLR, _ALLRD, _DEST, _EXCH, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver
+
+
+class NullComm:  # a transport that moves nothing (set-up has collectives: they see their own values)
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+        self._cb = (_EXCH(lambda *a: 0), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
+        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0))
+        self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
+
+
+n, P, rank = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+levels = 1
+while (n >> (levels - 1)) > 16:
+    levels += 1
+cuts = [n // P * r for r in range(P + 1)]
+z0, z1 = cuts[rank], cuts[rank + 1]
+lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
+for rep in range(3):
+    torch.cuda.synchronize()
+    t = time.time()
+    s = SlabSolver(lab, w, levels, False, NullComm(rank, P), device=0, splits=cuts)
+    torch.cuda.synchronize()
+    print("slab set-up N=%d P=%d rank=%d window=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), (time.time() - t) * 1e3), flush=True)
+    s.close()
