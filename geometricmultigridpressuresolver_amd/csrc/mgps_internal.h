@@ -298,7 +298,13 @@ struct GridP {
     int streaming;
     // which sweep kernel launchStencil takes (options.stencil_path): 0 = by size, 1 = quad, 2 = plane-marching where it applies
     int sweepPath;
+    // x extent of the active cells, quad-aligned: [xlo, xhi) holds every active cell of the level.  The reference's power-of-two
+    // expansion pads every row with 2^(L-1) EXTERIOR cells per side (an eighth of a 1024-cell row at L = 7): activity-skipping
+    // sweeps leave the quads outside the range alone -- nothing loaded, nothing stored, like the runs / blocks without active cells
+    int xlo, xhi;
 };
+// xlo / xhi of a level from its cell codes (range[0] = min x, range[1] = max x over the active cells; range preset to {nx, -1})
+int launchActiveXRange(void *stream, const uint8_t *lab, int nx, size_t cells, int *range);
 
 // Scales of the mixed-precision V-cycle (options.precision = 1).  The cycle works on the rhs normalised by a power of
 // two, sigma (device scalar: 2^-ceil(log2 max|b|), so that max |sigma b| is in (1/2, 1]); the fine-level iterate is stored
@@ -361,10 +367,19 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
 // Grids are float, or binary16 when `half` is set (mixed precision: ms as in launchBandFusedMixed).
 // dotPartials (optional): one slot per group receives sum (new - old) * b over the group's output cells, `old` read from
 // dotOld (closure mode: the sweep's value in dst before it is overwritten; plain mode: the stage's input).
+// Closure mode with dst == nullptr fills the snapshot only; the plain launch after the sweep, with outClosure, then writes the
+// closure-output cells from the snapshot as well as the band cells -- the closure launch needs nothing of the sweep's output and
+// can run beside the sweep (smoothStroke).
 int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap,
-                  float omega, bool half = false, const MixScale &ms = MixScale{}, double *dotPartials = nullptr, const void *dotOld = nullptr);
+                  float omega, bool half = false, const MixScale &ms = MixScale{}, double *dotPartials = nullptr, const void *dotOld = nullptr,
+                  bool outClosure = false);
 // dst = src on the band cells of every owned box (the legacy form of the plain stage: out of place into a scratch grid,
 // then this copy -- used where no snapshot of the input exists)
+// Down-stroke from the zero iterate, sweep and residual in one pass: xout = omega b / diag (the Jacobi sweep of x = 0), rout = b - A xout.
+// Right away from the band; after the plain box launch has put the band closure into xout, launchBoxResidual recomputes r on the
+// closure and on the cells next to it.  Levels that take the quad or the plane sweep (stencilKernelOf != 3)
+int launchZeroSweepResidual(void *stream, const GridP &g, float *xout, float *rout, const float *b, float omega);
+int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, const float *x, const float *b, float *r);
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half = false);
 // one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
 // that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the

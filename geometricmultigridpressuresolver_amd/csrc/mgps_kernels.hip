@@ -234,24 +234,29 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const size_t c = row * sy + i;
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 xc = XZERO ? zero4 : Cell<TX>::load4(x + c);
+    // quads outside the level's active x range (GridP::xlo): EXTERIOR padding, zero in every grid -- nothing loaded, nothing stored
+    const bool live = i >= g.xlo && i < g.xhi;
+    valid = valid && live;
+    const bool ld = live && !XZERO;
+    const float4 xc = ld ? Cell<TX>::load4(x + c) : zero4;
     // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
     // results are discarded, the loads only have to stay in bounds
     const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
     const size_t czm = (k > 0 || g.ghostLo) ? c - sz : c, czp = (k < g.nz - 1 || g.ghostHi) ? c + sz : c;
-    const float4 ym = XZERO ? zero4 : Cell<TX>::load4(x + cym);
-    const float4 yp = XZERO ? zero4 : Cell<TX>::load4(x + cyp);
-    const float4 zm = XZERO ? zero4 : Cell<TX>::load4(x + czm);
-    const float4 zp = XZERO ? zero4 : Cell<TX>::load4(x + czp);
-    const uchar4 lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
+    const float4 ym = ld ? Cell<TX>::load4(x + cym) : zero4;
+    const float4 yp = ld ? Cell<TX>::load4(x + cyp) : zero4;
+    const float4 zm = ld ? Cell<TX>::load4(x + czm) : zero4;
+    const float4 zp = ld ? Cell<TX>::load4(x + czp) : zero4;
+    uchar4 lab = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    if (live) lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
+    if (OP != OP_APPLY && live) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
 
     // x neighbours across the quad boundary
     const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
-    if (!XZERO) {
+    if (ld) {
         if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
         if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
     }
@@ -313,10 +318,13 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
     const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
     const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
-    const bool valid = i < g.nx && j < g.ny;
     // threads past the grid edge shadow the last quad / row: their loads stay in bounds, they take
     // part in the barriers, they do not store
     const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
+    // quad columns outside the level's active x range (GridP::xlo): zero in every grid, staged as zeros, nothing loaded or stored
+    const bool live = ic >= g.xlo && ic < g.xhi;
+    const bool valid = i < g.nx && j < g.ny && live;
+    const bool ld = live && !XZERO;
     const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
     const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
     size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
@@ -324,17 +332,18 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 xm = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c));
-    float4 xc = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + c);
+    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    float4 xm = ld ? *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c)) : zero4;
+    float4 xc = ld ? *reinterpret_cast<const float4 *>(x + c) : zero4;
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY) bc = streamLoad4(b + c);
-    uchar4 lc = streamLoad4(g.lab + c);
+    if (OP != OP_APPLY && live) bc = streamLoad4(b + c);
+    uchar4 lc = live ? streamLoad4(g.lab + c) : ext4;
     float4 hy = make_float4(0.f, 0.f, 0.f, 0.f);  // y-halo row this thread stages (top / bottom rows only)
-    if (!XZERO && rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
-    if (!XZERO && rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
+    if (ld && rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
+    if (ld && rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
     float hx = 0.f;  // x-halo cell this thread stages (first / last lane only)
-    if (!XZERO && colL) hx = ic > 0 ? x[c - 1] : 0.f;
-    if (!XZERO && colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
+    if (ld && colL) hx = ic > 0 ? x[c - 1] : 0.f;
+    if (ld && colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
 
     int buf = 0;
     for (int k = k0; k < k1; ++k) {
@@ -346,11 +355,11 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         if (colR) me[4] = hx;
         // next plane: issue its loads before this plane is computed
         const size_t cn = (k + 1 < g.nz || g.ghostHi) ? c + sz : c;
-        const float4 xp = XZERO ? zero4 : *reinterpret_cast<const float4 *>(x + cn);
+        const float4 xp = ld ? *reinterpret_cast<const float4 *>(x + cn) : zero4;
         float4 bn = bc, hyn = hy;
         uchar4 ln = lc;
         float hxn = hx;
-        if (k + 1 < k1) {
+        if (k + 1 < k1 && live) {
             if (OP != OP_APPLY) bn = streamLoad4(b + cn);
             ln = streamLoad4(g.lab + cn);
             if (!XZERO && rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
@@ -392,6 +401,211 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
     if (DOT) {
         __syncthreads();  // (the LDS planes are done with)
         blockDotStore(dotAcc, dotPartials, blockIdx.x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The down-stroke's sweep and residual in ONE pass when the stroke starts from the zero iterate (MG.cpp:439-440 / 566, then
+// 445-547 / 571-660): the Jacobi sweep of x = 0 is pointwise, x1 = omega b / diag (Ops.h:356-361 with x = 0), so the residual
+// r = b - A x1 (Ops.h:716-732) needs no iterate from memory at all -- every x1 it reads is rebuilt from the rhs and the code of
+// that cell.  13 B per cell (rhs 4, code 1, x1 4, r 4) instead of 9 (the zero-start sweep) + 13 (the residual).  The same
+// expressions in the same order as stencil...Kernel<OP_JACOBI, ..., XZERO> followed by <OP_RESIDUAL>: the same bits.
+// Right away from the band: the band stages change x on the band closure, so x1 there and r on the closure dilated by one
+// cell are overwritten after this launch (launchBandBox, plain mode; launchBoxResidual).  General BOUNDARY cells (all band
+// cells) are left to those launches entirely.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float zeroSweepCell(float b, unsigned l, float omega)
+{
+    // stencil...Kernel<OP_JACOBI, XZERO>: lap = diag * 0 - 0, res = 0 + omega * ((b - lap) * rcp(diag))
+    const float diag = simpleDiag(l);
+    const float lap = diag * 0.f - (0.f + 0.f + 0.f + 0.f + 0.f + 0.f);
+    return simpleCell(l) ? epilogueRcp<OP_JACOBI>(0.f, b, lap, simpleRcp(diag), omega) : inactiveValue<OP_JACOBI>(0.f);
+}
+__device__ __forceinline__ float4 zeroSweepQuad(float4 b, uchar4 l, float omega)
+{
+    return make_float4(zeroSweepCell(b.x, l.x, omega), zeroSweepCell(b.y, l.y, omega), zeroSweepCell(b.z, l.z, omega), zeroSweepCell(b.w, l.w, omega));
+}
+
+__global__ __launch_bounds__(256) void zeroSweepResidualQuadKernel(GridP g, float *__restrict__ xout, float *__restrict__ rout, const float *__restrict__ b,
+                                                                    float omega, unsigned nblocks, const int32_t *__restrict__ chunks)
+{
+    const unsigned nq = unsigned(g.nx) >> 2;
+    const size_t rows = size_t(g.ny) * g.nz;
+    const size_t totalQuads = size_t(nq) * rows;
+    const unsigned block = remapBlock(blockIdx.x, nblocks);
+    size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    bool valid = true;
+    if (chunks) valid = listQuad(chunks, g.chunkCells, block, t);
+    valid = valid && t < totalQuads;
+    const size_t tt = valid ? t : totalQuads - 1;
+    const unsigned q = unsigned(tt % nq);
+    const size_t row = tt / nq;
+    const int j = int(row % g.ny), k = int(row / g.ny);
+    const int i = int(q) << 2;
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const size_t c = row * sy + i;
+    const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
+    const size_t czm = k > 0 ? c - sz : c, czp = k < g.nz - 1 ? c + sz : c;
+    auto quadAt = [&](size_t p) { return zeroSweepQuad(*reinterpret_cast<const float4 *>(b + p), *reinterpret_cast<const uchar4 *>(g.lab + p), omega); };
+    const uchar4 lab = *reinterpret_cast<const uchar4 *>(g.lab + c);
+    const float4 bc = *reinterpret_cast<const float4 *>(b + c);
+    const float4 xc = zeroSweepQuad(bc, lab, omega);
+    const float4 ym = quadAt(cym), yp = quadAt(cyp), zm = quadAt(czm), zp = quadAt(czp);
+    const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
+    float left = __shfl_up(xc.w, 1);
+    float right = __shfl_down(xc.x, 1);
+    if (lane == 0 || q == 0) left = (i > 0) ? zeroSweepCell(b[c - 1], g.lab[c - 1], omega) : 0.f;
+    if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? zeroSweepCell(b[c + 4], g.lab[c + 4], omega) : 0.f;
+    const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
+    const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+    const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
+    const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+    const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
+    float res[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float diag = simpleDiag(ls[e]);
+        const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+        res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
+    }
+    if (valid) {
+        *reinterpret_cast<float4 *>(xout + c) = xc;
+        *reinterpret_cast<float4 *>(rout + c) = make_float4(res[0], res[1], res[2], res[3]);
+    }
+}
+
+// the plane-marching form (stencilPlaneKernel): x1 of planes z - 1 / z / z + 1 in registers, built from the rhs and code
+// planes as they arrive; the halo row / cell a thread stages likewise
+__global__ __launch_bounds__(64 * kPlaneRows) void zeroSweepResidualPlaneKernel(GridP g, float *__restrict__ xout, float *__restrict__ rout,
+                                                                                const float *__restrict__ b, float omega, unsigned nbx, unsigned nby,
+                                                                                unsigned nbz, int zc, const int32_t *__restrict__ blocks)
+{
+    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
+    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    if (blocks) bid = unsigned(blocks[bid]);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
+    const bool valid = i < g.nx && j < g.ny;
+    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
+    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
+    const ptrdiff_t dym = jc > 0 ? -ptrdiff_t(sy) : 0, dyp = jc < g.ny - 1 ? ptrdiff_t(sy) : 0;
+    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
+    const ptrdiff_t dh = rowTop ? dym : dyp;                 // the y-halo row of the first / last thread row
+    const bool edgeRow = rowTop || rowBot, edgeCol = colL || colR;
+    const ptrdiff_t dx = colL ? (ic > 0 ? -1 : 0) : (ic + 4 < g.nx ? 4 : 3);  // the x-halo cell of the first / last lane (clamped: a cell of the quad, result unused)
+    const bool xHaloReal = colL ? ic > 0 : ic + 4 < g.nx;
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t cm = k0 > 0 ? c - sz : c;
+    float4 xm = zeroSweepQuad(*reinterpret_cast<const float4 *>(b + cm), *reinterpret_cast<const uchar4 *>(g.lab + cm), omega);
+    float4 bc = streamLoad4(b + c);
+    uchar4 lc = streamLoad4(g.lab + c);
+    float4 xc = zeroSweepQuad(bc, lc, omega);
+    float4 hy = zero4;
+    if (edgeRow) hy = zeroSweepQuad(*reinterpret_cast<const float4 *>(b + c + dh), *reinterpret_cast<const uchar4 *>(g.lab + c + dh), omega);
+    float hx = 0.f;
+    if (edgeCol && xHaloReal) hx = zeroSweepCell(b[c + dx], g.lab[c + dx], omega);
+
+    int buf = 0;
+    for (int k = k0; k < k1; ++k) {
+        float *me = plane[buf] + (ty + 1) * kPlanePitch + 4 + lane * 4;
+        *reinterpret_cast<float4 *>(me) = xc;
+        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
+        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
+        if (colL) me[-1] = hx;
+        if (colR) me[4] = hx;
+        // next plane: rhs and codes (the plane after the block's last one: its x1 only, plain loads)
+        const size_t cn = k + 1 < g.nz ? c + sz : c;
+        float4 bn;
+        uchar4 ln;
+        if (k + 1 < k1) {
+            bn = streamLoad4(b + cn);
+            ln = streamLoad4(g.lab + cn);
+        } else {
+            bn = *reinterpret_cast<const float4 *>(b + cn);
+            ln = *reinterpret_cast<const uchar4 *>(g.lab + cn);
+        }
+        float4 hbn = zero4;
+        uchar4 hln = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+        float hxb = 0.f;
+        unsigned hxl = MGPS_EXTERIOR_CELL;
+        if (k + 1 < k1) {
+            if (edgeRow) {
+                hbn = *reinterpret_cast<const float4 *>(b + cn + dh);
+                hln = *reinterpret_cast<const uchar4 *>(g.lab + cn + dh);
+            }
+            if (edgeCol && xHaloReal) {
+                hxb = b[cn + dx];
+                hxl = g.lab[cn + dx];
+            }
+        }
+        __syncthreads();
+        const float4 xp = zeroSweepQuad(bn, ln, omega);
+        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
+        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
+        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float diag = simpleDiag(ls[e]);
+            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
+        }
+        if (valid) {
+            __builtin_nontemporal_store(v4f{xc.x, xc.y, xc.z, xc.w}, reinterpret_cast<v4f *>(xout + c));
+            __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(rout + c));
+        }
+        xm = xc;
+        xc = xp;
+        bc = bn;
+        lc = ln;
+        hy = zeroSweepQuad(hbn, hln, omega);
+        hx = zeroSweepCell(hxb, hxl, omega);
+        c = cn;
+        buf ^= 1;
+    }
+}
+
+// r = b - A x on the cells whose residual the one-pass kernel above could not know: the band closure (its x came from the box
+// launches) and the cells next to it (class "far": a neighbour's x did).  One thread per list entry, x from
+// the grid (every value final: this runs after the plain launch); the arithmetic of stencil...Kernel<OP_RESIDUAL> /
+// boundaryOpKernel<OP_RESIDUAL>, so the residual grid ends with the bits the separate residual pass leaves.
+__global__ __launch_bounds__(kBoxThreads) void boxResidualKernel(GridP g, const float *__restrict__ x, const float *__restrict__ b, float *__restrict__ r,
+                                                                 const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                                 const int32_t *__restrict__ general)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, origin = size_t(gi[0]);
+    const uint32_t *U = list + gi[2];
+    const int nList = gi[7], ngen = gi[5];
+    for (int k = threadIdx.x; k < nList; k += kBoxThreads) {
+        const uint32_t e = U[k];
+        const unsigned cls = (e >> 16) & 15u;
+        const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
+        // owned closure cells; "far" cells up to one cell outside the owned box -- an active cell next to a closure-output cell
+        // lies there and may be inside no group's owned box (two groups may write it: the same bits, r = b - A x of the final x)
+        if (!(((simple || cls == kBoxFrozenOut) && (e >> 20) == 0u) || (cls == kBoxFrozenFar && (e >> 20) <= 1u))) continue;  // (general cells: below)
+        const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
+        const float diag = simple ? float(int(cls) - int(kBoxSimple)) : 6.f;
+        const float xc = x[c];
+        const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+        r[c] = epilogueRcp<OP_RESIDUAL>(xc, b[c], lap, 0.f, 0.f);
+    }
+    for (int k = threadIdx.x; k < ngen; k += kBoxThreads) {
+        const uint32_t e = uint32_t(general[2 * size_t(gi[4] + k)]);
+        if ((e >> 20) != 0u) continue;
+        const int t = general[2 * size_t(gi[4] + k) + 1];
+        const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
+        float lap, diag;
+        boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
+        r[c] = epilogue<OP_RESIDUAL>(x[c], b[c], lap, diag, 0.f);
     }
 }
 
@@ -860,7 +1074,7 @@ template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
 __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                                               TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
                                                               const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
-                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld)
+                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
@@ -879,7 +1093,7 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
     const ptrdiff_t origin = gi[0];
     if (!XZERO) src += origin;
     b += origin;
-    dst += origin;
+    if (dst) dst += origin;
     if (CLOSURE && snap) snap += origin;
     if (DOT) dotOld += origin;
     const uint32_t *U = list + gi[2];
@@ -984,14 +1198,16 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
 #pragma unroll
     for (int m = 0; m < kBoxSlots; ++m) {
         const unsigned cls = (ue[m] >> 16) & 15u;
-        if ((ue[m] >> 20) == 0u && (boxBand(cls) || (CLOSURE && cls == kBoxFrozenOut))) {
+        // plain mode with outClosure: the closure-output cells too -- their staged value (what the closure launch left in the
+        // snapshot) goes to dst, which then needs nothing from the closure launch itself
+        if ((ue[m] >> 20) == 0u && (boxBand(cls) || ((CLOSURE || outClosure) && cls == kBoxFrozenOut))) {
             const unsigned c = cellOf(ue[m]);
             const float v = fin[nodeOf(ue[m])];
             if (DOT) {
                 const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
                 acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
             }
-            wr(dst, c, v);
+            if (dst) wr(dst, c, v);
             if (CLOSURE && snap) wr(snap, c, v);
         }
     }
@@ -1784,16 +2000,63 @@ static int forcedStencil(const GridP &g)
     return g.sweepPath ? g.sweepPath : forced;  // options.stencil_path wins over the environment
 }
 
-// Cells one activity-skipping full-domain sweep visits (the denominator of the measured bytes per cell).
+// Cells one activity-skipping full-domain sweep visits (the denominator of the measured bytes per cell): the cells of the listed
+// runs / blocks that lie inside the level's active x range (GridP::xlo) -- counted on the device from the list the sweep walks
+// (a diagnostic: one small launch and a synchronisation per call).
+namespace {
+__global__ __launch_bounds__(256) void sweptCountKernel(GridP g, int plane, unsigned nbx, const int32_t *__restrict__ list, size_t nentries,
+                                                        unsigned long long *__restrict__ total)
+{
+    unsigned long long acc = 0;
+    for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nentries; e += size_t(gridDim.x) * blockDim.x) {
+        if (plane) {  // a block: 256 cells of kPlaneRows rows of planeZc planes
+            const unsigned bid = list ? unsigned(list[e]) : unsigned(e);
+            const int x0 = int(bid % nbx) * 256;
+            const int w = max(0, min(min(x0 + 256, g.nx), g.xhi) - max(x0, g.xlo));
+            acc += (unsigned long long)(w) * kPlaneRows * g.planeZc;
+        } else {  // a run of chunkCells consecutive cells (-1: list padding), or the whole grid as one run per row
+            const int32_t ch = list ? list[e] : int32_t(e);
+            if (ch < 0) continue;
+            const size_t cells = list ? size_t(g.chunkCells) : size_t(g.nx);
+            size_t c = size_t(ch) * cells, end = c + cells;
+            while (c < end) {  // row by row
+                const int i = int(c % size_t(g.nx));
+                const size_t rowEnd = std::min(end, c + size_t(g.nx - i));
+                const int i1 = i + int(rowEnd - c);
+                acc += (unsigned long long)(max(0, min(i1, g.xhi) - max(i, g.xlo)));
+                c = rowEnd;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & (kWave - 1)) == 0 && acc) atomicAdd(total, acc);
+}
+}  // namespace
 size_t stencilSweptCells(const GridP &g)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz;
-    const int forced = forcedStencil(g);
-    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
-    if (g.planeZc && (forced == 2 || (forced == 0 && planeWins)))
-        return g.planeBlocks ? std::min(n, size_t(g.nplaneBlocks) * 256 * kPlaneRows * g.planeZc) : n;
-    if ((g.nx & 3) == 0 && g.chunks) return std::min(n, size_t(g.nchunks) * g.chunkCells);
-    return n;
+    const int kind = stencilKernelOf(g);
+    if (kind == 3) return n;
+    const bool plane = kind == 2;
+    const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = plane ? (g.nz + g.planeZc - 1) / g.planeZc : 0;
+    const int32_t *list = plane ? g.planeBlocks : g.chunks;
+    const size_t entries = plane ? (list ? size_t(g.nplaneBlocks) : size_t(nbx) * nby * nbz) : (list ? size_t(g.nchunks) : size_t(g.ny) * g.nz);
+    unsigned long long *dev = nullptr, host = 0;
+    if (entries == 0) return 0;
+    if (hipMalloc(reinterpret_cast<void **>(&dev), sizeof(host)) != hipSuccess || hipMemset(dev, 0, sizeof(host)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dev) (void)hipFree(dev);
+        return n;
+    }
+    sweptCountKernel<<<unsigned(std::min<size_t>((entries + 255) / 256, 4096)), 256>>>(g, plane ? 1 : 0, nbx, list, entries, dev);
+    const bool ok = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(dev);
+    if (!ok) {
+        (void)hipGetLastError();
+        return n;
+    }
+    return std::min(n, size_t(host));
 }
 
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
@@ -1801,6 +2064,12 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
 {
     // x == nullptr: the iterate is zero everywhere (Jacobi on a level that takes the quad or the plane sweep and has no general cells to patch)
     if (!x && (op != OP_JACOBI || stencilKernelOf(g) == 3 || g.nbnd > 0)) return int(hipErrorInvalidValue);
+    if (!skipInactive && (g.xlo > 0 || g.xhi < g.nx)) {  // every cell of the grid is written
+        GridP whole = g;
+        whole.xlo = 0;
+        whole.xhi = g.nx;
+        return launchStencil(stream, op, whole, out, x, b, omega, false);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const int forced = forcedStencil(g);
@@ -1851,6 +2120,63 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
             default: boundaryOpKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
         }
     }
+    return int(hipGetLastError());
+}
+
+// xout = the Jacobi sweep of the zero iterate, rout = b - A xout, one pass (zeroSweepResidual...Kernel; quad or plane form as
+// launchStencil chooses; the scalar form has no such kernel: invalid value)
+int launchZeroSweepResidual(void *stream, const GridP &g, float *xout, float *rout, const float *b, float omega)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int kind = stencilKernelOf(g);
+    if (kind == 3 || !xout || !rout || xout == rout) return int(hipErrorInvalidValue);
+    if (kind == 2) {
+        const int zc = g.planeZc;
+        const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;
+        const bool list = g.planeBlocks != nullptr;
+        const unsigned nb = list ? unsigned(g.nplaneBlocks) : nbx * nby * nbz;
+        if (nb > 0) zeroSweepResidualPlaneKernel<<<nb, 64 * kPlaneRows, 0, s>>>(g, xout, rout, b, omega, nbx, nby, nbz, zc, list ? g.planeBlocks : nullptr);
+    } else {
+        const size_t n = size_t(g.nx) * g.ny * g.nz;
+        const bool list = g.chunks != nullptr;
+        const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
+        if (nb > 0) zeroSweepResidualQuadKernel<<<nb, 256, 0, s>>>(g, xout, rout, b, omega, nb, list ? g.chunks : nullptr);
+    }
+    return int(hipGetLastError());
+}
+
+int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, const float *x, const float *b, float *r)
+{
+    if (bx.ngroups <= 0) return 0;
+    boxResidualKernel<<<unsigned(bx.ngroups), kBoxThreads, 0, static_cast<hipStream_t>(stream)>>>(g, x, b, r, bx.info, bx.list, bx.general);
+    return int(hipGetLastError());
+}
+
+// min / max x over the active cells of a level (GridP::xlo / xhi)
+__global__ __launch_bounds__(256) void activeXRangeKernel(const uint8_t *__restrict__ lab, int nx, size_t cells, int *__restrict__ range)
+{
+    int lo = nx, hi = -1;
+    for (size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x; c < cells; c += size_t(gridDim.x) * blockDim.x)
+        if (activeLabel(lab[c])) {
+            const int i = int(c % size_t(nx));
+            lo = min(lo, i);
+            hi = max(hi, i);
+        }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off));
+        hi = max(hi, __shfl_down(hi, off));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && hi >= 0) {
+        atomicMin(range, lo);
+        atomicMax(range + 1, hi);
+    }
+}
+int launchActiveXRange(void *stream, const uint8_t *lab, int nx, size_t cells, int *range)
+{
+    if (cells == 0) return 0;
+    const unsigned nb = unsigned(std::min<size_t>((cells + 255) / 256, 256 * 32));
+    activeXRangeKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(lab, nx, cells, range);
     return int(hipGetLastError());
 }
 
@@ -2027,11 +2353,11 @@ unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nban
 namespace {
 template <class TX>
 int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool closure, const TX *src, const float *b, TX *dst, TX *snap, float omega,
-                   const MixScale &ms, double *dotPartials, const TX *dotOld)
+                   const MixScale &ms, double *dotPartials, const TX *dotOld, int outClosure)
 {
     const unsigned ng = unsigned(bx.ngroups);
     const bool dot = dotPartials != nullptr;
-#define MGPS_BOX_LAUNCH2(C, D, G) bandBoxKernel<TX, C, D, G><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld)
+#define MGPS_BOX_LAUNCH2(C, D, G) bandBoxKernel<TX, C, D, G><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure)
 #define MGPS_BOX_LAUNCH(C, D)                            \
     do {                                                 \
         if (bx.anyGeneral) MGPS_BOX_LAUNCH2(C, D, true); \
@@ -2039,8 +2365,8 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
     } while (0)
     if (closure && !src) {  // the iterate is zero everywhere
         if (dot) return int(hipErrorInvalidValue);
-        if (bx.anyGeneral) bandBoxKernel<TX, true, false, true, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld);
-        else bandBoxKernel<TX, true, false, false, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld);
+        if (bx.anyGeneral) bandBoxKernel<TX, true, false, true, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);
+        else bandBoxKernel<TX, true, false, false, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);
     } else if (closure) {
         if (dot) MGPS_BOX_LAUNCH(true, true);
         else MGPS_BOX_LAUNCH(true, false);
@@ -2054,16 +2380,17 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
 }
 }  // namespace
 int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap, float omega,
-                  bool half, const MixScale &ms, double *dotPartials, const void *dotOld)
+                  bool half, const MixScale &ms, double *dotPartials, const void *dotOld, bool outClosure)
 {
     if (bx.ngroups <= 0) return 0;
-    if ((src == dst) || (!src && !closure) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: zero everywhere, closure mode)
+    if (!dst && !(closure && snap)) return int(hipErrorInvalidValue);  // (dst == nullptr: the closure launch fills the snapshot only)
+    if ((src && src == dst) || (!src && !closure) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: zero everywhere, closure mode)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (half)
         return launchBandBoxT<__half>(s, g, bx, closure, static_cast<const __half *>(src), b, static_cast<__half *>(dst), static_cast<__half *>(snap), omega, ms,
-                                      dotPartials, static_cast<const __half *>(dotOld));
+                                      dotPartials, static_cast<const __half *>(dotOld), outClosure ? 1 : 0);
     return launchBandBoxT<float>(s, g, bx, closure, static_cast<const float *>(src), b, static_cast<float *>(dst), static_cast<float *>(snap), omega, ms,
-                                 dotPartials, static_cast<const float *>(dotOld));
+                                 dotPartials, static_cast<const float *>(dotOld), outClosure ? 1 : 0);
 }
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half)
 {

@@ -732,6 +732,44 @@ bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float 
            !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
 }
 
+// A zero-start down-stroke that is followed by the residual (every level above the coarsest one): sweep and residual leave in one pass
+// over the level (launchZeroSweepResidual), 13 instead of 9 + 13 bytes per cell.  MGPS_FUSE_DOWN=0: the two passes (A/B timing)
+bool downStrokeFusesResidual(const mgps_solver *h, int l)
+{
+    static const bool allowed = [] {
+        const char *e = getenv("MGPS_FUSE_DOWN");
+        return !(e && e[0] == '0');
+    }();
+    static const size_t minCells = [] {  // (levels that live in the caches gain nothing from bytes not moved: see DESIGN.md section 3)
+        const char *e = getenv("MGPS_FUSE_DOWN_MIN_CELLS");
+        return e ? size_t(std::max(0ll, atoll(e))) : (size_t(1) << 24);
+    }();
+    return allowed && h->lv[l].d.cells() >= minCells;
+}
+// `cur` is the never-cleared iterate grid (see strokeTakesZero): free during the stroke, it takes the closure launch's snapshot
+// -- the level's residual grid, where smoothStroke keeps it, is being written by the one-pass kernel.  On return `cur` holds the
+// smoothed iterate and L.r the residual (MG.cpp:445-547 / 571-660)
+int zeroStrokeWithResidual(mgps_solver *h, int l, float *&cur, float *&other, const float *b)
+{
+    DevLevel &L = h->lv[l];
+    {
+        StageScope scope(h, ST_BAND, l);
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, nullptr, b, nullptr, cur, h->opt.jacobi_weight));
+    }
+    {
+        StageScope scope(h, ST_SMOOTH, l);
+        MGPS_LAUNCH(h, launchZeroSweepResidual(h->stream, L.g, other, L.r, b, h->opt.jacobi_weight));
+    }
+    std::swap(cur, other);
+    {
+        StageScope scope(h, ST_BAND, l);
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, other, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, nullptr, nullptr, true));
+    }
+    StageScope scope(h, ST_RESIDUAL, l);
+    MGPS_LAUNCH(h, launchBoxResidual(h->stream, L.g, L.bandBoxes, cur, b, L.r));
+    return MGPS_OK;
+}
+
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // The smoother runs options.pre_sweeps (down) / post_sweeps (up) times; the reference's count is one.
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
@@ -746,12 +784,21 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
     if (bands && !h->useGS && (down ? h->opt.pre_sweeps : h->opt.post_sweeps) == 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r) {
-        // "band passes, sweep, band passes" in three launches, nothing scattered (launchBandBox): the sweep over the
-        // un-smoothed grid; the closure launch, which overwrites the sweep's output on the band closure with what the
-        // sweep would have written after the band passes and leaves a snapshot of it in the level's residual grid (free
-        // during a stroke); the second band stage, reading the snapshot and writing the sweep's output in place.
+        // "band passes, sweep, band passes" in three launches, nothing scattered (launchBandBox): the closure launch, which
+        // computes on the band closure what the sweep would write there after the band passes and leaves it as a snapshot in
+        // the level's residual grid (free during a stroke); the sweep over the un-smoothed grid; the second band stage, which
+        // reads the snapshot and writes the band cells AND the closure-output cells into the sweep's output (4 bytes less per
+        // closure cell than a closure launch that patches the sweep's output itself: +1.5 % at 512^3, +0.7 % at 1024^3).  The two
+        // launches before the plain one are independent of each other; running the closure launch on a second stream beside the
+        // sweep was measured and lost -- 1024^3: sweep 1.72 -> 2.02 ms with the closure launch at 1.57 ms beside it, cycle 10.81 ->
+        // 10.91 ms; on small levels the two event hops cost ~17 us per stroke)
         const bool timed = h->profiling && l == 0;
-        double *sinkA = nullptr, *sinkB = nullptr;
+        double *sinkB = nullptr;
+        const float *src = xZero ? nullptr : cur;
+        {
+            StageScope scope(h, ST_BAND, l);
+            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, src, b, nullptr, L.r, h->opt.jacobi_weight));
+        }
         {
             StageScope scope(h, ST_SMOOTH, l);
             if (timed) MGPS_TRY(profMark(h, true));
@@ -759,13 +806,12 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
                 unsigned used = 0;
                 MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
                 h->dotUsed += used;
-                sinkA = h->dotPartials + h->dotUsed;
-                sinkB = sinkA + L.bandBoxes.ngroups;
-                h->dotUsed += 2u * unsigned(L.bandBoxes.ngroups);
+                sinkB = h->dotPartials + h->dotUsed;
+                h->dotUsed += unsigned(L.bandBoxes.ngroups);
             } else {
                 GridP gs = L.g;
-                gs.nbnd = 0;  // every BOUNDARY cell lies in the band closure: the closure launch computes the general ones as well
-                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, xZero ? nullptr : cur, b, h->opt.jacobi_weight, true));
+                gs.nbnd = 0;  // every BOUNDARY cell lies in the band closure: the box launches compute the general ones as well
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, src, b, h->opt.jacobi_weight, true));
             }
             if (timed) {
                 MGPS_TRY(profMark(h, false));
@@ -773,9 +819,9 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             }
         }
         StageScope scope(h, ST_BAND, l);
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, xZero ? nullptr : cur, b, other, L.r, h->opt.jacobi_weight, false, MixScale{}, sinkA, other));
         std::swap(cur, other);
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, L.r));
+        // (the gathered dot: the sweep left sum x' b with its own values everywhere; this launch adds (new - sweep's) b on every cell it writes)
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, cur, true));
         return MGPS_OK;
     }
     {
@@ -926,7 +972,9 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
         else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
-    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom, zero0));
+    bool haveResidual = zero0 && hasBottom && downStrokeFusesResidual(h, 0);  // (level 0's residual came with the stroke)
+    if (haveResidual) MGPS_TRY(zeroStrokeWithResidual(h, 0, cur[0], other[0], b));
+    else MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom, zero0));
     if (hasBottom) {
         const float *rhs = b;
         // options.interrupt is also polled once per level and stroke of a single-device cycle (the reference polls inside
@@ -941,10 +989,12 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 rhs = F.b;
                 const bool zl = strokeTakesZero(h, l, cur[l], other[l], rhs, false);
                 if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
-                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
+                haveResidual = zl && downStrokeFusesResidual(h, l);
+                if (haveResidual) MGPS_TRY(zeroStrokeWithResidual(h, l, cur[l], other[l], rhs));
+                else MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
             }
             bool rExchanged = false;
-            {
+            if (!haveResidual) {
                 StageScope scope(h, ST_RESIDUAL, l);
                 MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
                                                       : h->opt.band_iterations > 0 ? GHOST_BAND
@@ -1791,7 +1841,39 @@ int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
     MGPS_TRY(devAlloc(h, &h->resultDev, 1, true));
     if (hipHostMalloc(reinterpret_cast<void **>(&h->resultHost), sizeof(double)) != hipSuccess)
         return failH(h, MGPS_ERR_ALLOC, "pinned allocation failed");
+    // the active x range of every level (GridP::xlo): one pass over the codes, the answers come back with the set-up's last sync
+    static const bool rangeSkip = [] {  // MGPS_X_RANGE=0: sweeps visit the whole rows of their runs / blocks (A/B timing)
+        const char *e = getenv("MGPS_X_RANGE");
+        return !(e && e[0] == '0');
+    }();
+    const size_t nlv = h->lv.size();
+    std::vector<int> range(2 * nlv);
+    int *rangeDev = nullptr;
+    for (size_t l = 0; l < nlv; ++l) {
+        range[2 * l] = h->lv[l].g.nx;
+        range[2 * l + 1] = -1;
+        h->lv[l].g.xlo = 0;
+        h->lv[l].g.xhi = h->lv[l].g.nx;
+    }
+    if (rangeSkip && nlv > 0) {
+        MGPS_TRY(devAlloc(h, &rangeDev, 2 * nlv, false));
+        // (the null stream, like the set-up kernels that wrote the codes)
+        MGPS_HIP(h, hipMemcpyAsync(rangeDev, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice, nullptr));
+        for (size_t l = 0; l < nlv; ++l) {
+            const GridP &g = h->lv[l].g;
+            if (g.lab && (g.nx & 3) == 0) MGPS_LAUNCH(h, launchActiveXRange(nullptr, g.lab, g.nx, size_t(g.nx) * g.ny * g.nz, rangeDev + 2 * l));
+        }
+        MGPS_HIP(h, hipMemcpyAsync(range.data(), rangeDev, range.size() * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    }
     MGPS_HIP(h, hipDeviceSynchronize());
+    if (rangeDev) {
+        (void)cacheFree(rangeDev);
+        for (size_t l = 0; l < nlv; ++l)
+            if (range[2 * l + 1] >= range[2 * l]) {  // (a level without active cells keeps the whole row)
+                h->lv[l].g.xlo = range[2 * l] & ~3;
+                h->lv[l].g.xhi = (range[2 * l + 1] | 3) + 1;
+            }
+    }
     return MGPS_OK;
 }
 

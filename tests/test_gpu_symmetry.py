@@ -187,3 +187,60 @@ np.save(sys.argv[1], x.cpu().numpy())
             outs.append(np.load(path))
     ref = np.abs(outs[1]).max()
     assert ref > 0 and np.abs(outs[0] - outs[1]).max() < 2e-6 * ref
+
+
+@pytest.mark.parametrize("case", ["pool128", "plane"])
+def test_zero_start_down_stroke_with_its_residual_in_one_pass_is_bit_equal(torch_cuda, case):
+    """The down-stroke from the zero iterate with the residual in the same pass (launchZeroSweepResidual + launchBoxResidual,
+    the default) against MGPS_FUSE_DOWN=0 (zero-start sweep, band boxes, separate residual pass): the same expressions in
+    the same order, so two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve
+    leave the same bits.  pool128: free surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels);
+    plane: 1024 x 1024 x 96 box (plane-marching kernels on level 0)."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import geometricmultigridpressuresolver_amd as G
+from geometricmultigridpressuresolver_amd import domains as D
+case = sys.argv[2]
+if case == "pool128":
+    lab, w, dx = D.free_surface_pool(128, 4)
+    lev = 4
+else:
+    shape = (64, 992, 992)
+    bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
+    bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
+    bw = []
+    for axis in range(3):
+        wa = np.zeros(D.face_shape(*shape, axis), dtype=np.float32)
+        back, fwd = D._shift_pair(bl, axis)
+        wa[D._inner_faces(wa, axis)] = np.where((back == D.INTERIOR) | (fwd == D.INTERIOR), 1.0, 0.0)
+        bw.append(wa)
+    dx = 1.0 / 992
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
+s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
+if case == "plane":
+    assert s.stencil_kernel(0) == "plane"
+b = s.to_device(D.random_rhs(lab, dx))
+x = s.new_grid()
+s.applyVCycle(x, b, False)
+y = s.new_grid()
+y.copy_(x)
+s.applyVCycle(y, b, False)  # (again from zero: the same answer, and the grids have been through a swap)
+z = s.new_grid()
+st = s.solveGeometricConjugateGradient(z, b, 1e-5, 8)
+np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), it=st["iterations"])
+""" % ROOT
+    import tempfile
+
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for fuse in ("1", "0"):
+            path = os.path.join(tmp, f"x{fuse}.npz")
+            env = dict(os.environ, MGPS_FUSE_DOWN=fuse)
+            subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
+            outs.append(np.load(path))
+    assert np.abs(outs[0]["x"]).max() > 0
+    for key in ("x", "y", "z"):
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+    assert np.array_equal(outs[0]["x"], outs[0]["y"])
+    assert int(outs[0]["it"]) == int(outs[1]["it"])
