@@ -304,7 +304,8 @@ constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the 
 __device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
 
 template <int OP, bool DOT = false, bool XZERO = false>  // XZERO: see stencilQuadKernel
-__global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, float *__restrict__ out,
+__global__ __launch_bounds__(64 * kPlaneRows, 8) void stencilPlaneKernel(  // (8 waves per SIMD = two workgroups per CU: at most 64 registers)
+GridP g, float *__restrict__ out,
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ b, float omega,
                                                                       unsigned nbx, unsigned nby, unsigned nbz, int zc,
@@ -333,8 +334,15 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    // Two planes of a thread's own x quad are in flight at any time: plane k + 2 is requested while plane k is computed, so the
+    // plane k + 1 a step needs (its z + 1 neighbours) was requested a whole step earlier -- like the rhs, the codes and the halo,
+    // which are requested one plane ahead and used one step later (with one plane of look-ahead for x every step ended by
+    // waiting out a full memory round trip)
+    auto planeAt = [&](int k) { return (k < g.nz || g.ghostHi) ? (size_t(min(k, g.nz)) * g.ny + jc) * sy + ic : (size_t(g.nz - 1) * g.ny + jc) * sy + ic; };
     float4 xm = ld ? *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c)) : zero4;
     float4 xc = ld ? *reinterpret_cast<const float4 *>(x + c) : zero4;
+    const size_t c1 = planeAt(k0 + 1);
+    float4 xp = ld ? *reinterpret_cast<const float4 *>(x + c1) : zero4;
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (OP != OP_APPLY && live) bc = streamLoad4(b + c);
     uchar4 lc = live ? streamLoad4(g.lab + c) : ext4;
@@ -353,19 +361,22 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
         if (colL) me[-1] = hx;
         if (colR) me[4] = hx;
-        // next plane: issue its loads before this plane is computed
+        // the plane after the next one (own quad); the next plane's halo
         const size_t cn = (k + 1 < g.nz || g.ghostHi) ? c + sz : c;
-        const float4 xp = ld ? *reinterpret_cast<const float4 *>(x + cn) : zero4;
-        float4 bn = bc, hyn = hy;
+        const size_t cq = planeAt(k + 2);
+        float4 xq = zero4, bn = bc, hyn = hy;
         uchar4 ln = lc;
         float hxn = hx;
-        if (k + 1 < k1 && live) {
+        if (k + 1 < k1 && ld) xq = *reinterpret_cast<const float4 *>(x + cq);  // (the last step's z + 1 plane is already here: xp)
+        if (k + 1 < k1 && live) {  // (rhs and codes of the next plane: used a step from now as they are)
             if (OP != OP_APPLY) bn = streamLoad4(b + cn);
             ln = streamLoad4(g.lab + cn);
-            if (!XZERO && rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
-            if (!XZERO && rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
-            if (!XZERO && colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
-            if (!XZERO && colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
+        }
+        if (k + 1 < k1 && ld) {
+            if (rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
+            if (rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
+            if (colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
+            if (colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
         }
         __syncthreads();
         const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(64 * kPlaneRows) void stencilPlaneKernel(GridP g, f
         }
         xm = xc;
         xc = xp;
+        xp = xq;
         bc = bn;
         lc = ln;
         hy = hyn;

@@ -732,17 +732,19 @@ bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float 
            !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
 }
 
-// A zero-start down-stroke that is followed by the residual (every level above the coarsest one): sweep and residual leave in one pass
-// over the level (launchZeroSweepResidual), 13 instead of 9 + 13 bytes per cell.  MGPS_FUSE_DOWN=0: the two passes (A/B timing)
+// A zero-start down-stroke that is followed by the residual (every level above the coarsest one) can leave sweep and residual in one
+// pass over the level (launchZeroSweepResidual): 13 instead of 9 + 13 bytes per cell, bit-equal.  OPT-IN (MGPS_FUSE_DOWN=1, levels of
+// at least MGPS_FUSE_DOWN_MIN_CELLS cells): measured, it does not pay -- 512^3 pool MG-PCG 60.0 -> 61.5 ms, 1024^3 pool level 0:
+// 1.36 ms + 0.35 ms for the residual patch against 0.66 + 1.07 ms for the two passes
 bool downStrokeFusesResidual(const mgps_solver *h, int l)
 {
     static const bool allowed = [] {
         const char *e = getenv("MGPS_FUSE_DOWN");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
-    static const size_t minCells = [] {  // (levels that live in the caches gain nothing from bytes not moved: see DESIGN.md section 3)
+    static const size_t minCells = [] {
         const char *e = getenv("MGPS_FUSE_DOWN_MIN_CELLS");
-        return e ? size_t(std::max(0ll, atoll(e))) : (size_t(1) << 24);
+        return e ? size_t(std::max(0ll, atoll(e))) : size_t(0);
     }();
     return allowed && h->lv[l].d.cells() >= minCells;
 }
@@ -1841,7 +1843,10 @@ int commonDeviceState(mgps_solver *h, bool needCoarseSolver)
     MGPS_TRY(devAlloc(h, &h->resultDev, 1, true));
     if (hipHostMalloc(reinterpret_cast<void **>(&h->resultHost), sizeof(double)) != hipSuccess)
         return failH(h, MGPS_ERR_ALLOC, "pinned allocation failed");
-    // the active x range of every level (GridP::xlo): one pass over the codes, the answers come back with the set-up's last sync
+    // the active x range of every level (GridP::xlo): one pass over the codes, the answers come back with the set-up's last sync.
+    // (Tried on top of it and dropped: 128 x 32 tiles from the start of the range for the plane-marching sweep, so that no lane owns
+    // only padding -- 896 active cells are 7 such tiles against 3.5 of the 256 x 16 ones: 1.949 -> 1.919 ms per sweep at 1024^3,
+    // 94.0 -> 94.4 cycles/s.  The idle lanes of a partly active tile cost next to nothing; what the range saves is the bytes.)
     static const bool rangeSkip = [] {  // MGPS_X_RANGE=0: sweeps visit the whole rows of their runs / blocks (A/B timing)
         const char *e = getenv("MGPS_X_RANGE");
         return !(e && e[0] == '0');

@@ -189,13 +189,19 @@ np.save(sys.argv[1], x.cpu().numpy())
     assert ref > 0 and np.abs(outs[0] - outs[1]).max() < 2e-6 * ref
 
 
-@pytest.mark.parametrize("case", ["pool128", "plane"])
-def test_zero_start_down_stroke_with_its_residual_in_one_pass_is_bit_equal(torch_cuda, case):
-    """The down-stroke from the zero iterate with the residual in the same pass (launchZeroSweepResidual + launchBoxResidual,
-    the default) against MGPS_FUSE_DOWN=0 (zero-start sweep, band boxes, separate residual pass): the same expressions in
-    the same order, so two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve
-    leave the same bits.  pool128: free surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels);
-    plane: 1024 x 1024 x 96 box (plane-marching kernels on level 0)."""
+@pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
+                                         ("MGPS_X_RANGE", "plane880")])
+def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
+    """Two switches that must not change a single bit of the answer, each on (1) against off (0):
+    MGPS_FUSE_DOWN (opt-in) -- the down-stroke from the zero iterate with the residual in the same pass
+    (launchZeroSweepResidual + launchBoxResidual) against zero-start sweep, band boxes, separate residual pass: the same
+    expressions in the same order;
+    MGPS_X_RANGE (default on) -- sweeps leave the quads outside the level's active x range alone (GridP::xlo: the EXTERIOR
+    padding of the power-of-two expansion) against visiting whole runs / blocks;
+    (plane880: 880 active cells of a 1024-cell row; the sweep must visit fewer cells with the range on.)
+    Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
+    surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
+    box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -206,7 +212,7 @@ if case == "pool128":
     lab, w, dx = D.free_surface_pool(128, 4)
     lev = 4
 else:
-    shape = (64, 992, 992)
+    shape = (64, 992, int(case[5:]))
     bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
     bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
     bw = []
@@ -218,7 +224,7 @@ else:
     dx = 1.0 / 992
     lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
 s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
-if case == "plane":
+if case != "pool128":
     assert s.stencil_kernel(0) == "plane"
 b = s.to_device(D.random_rhs(lab, dx))
 x = s.new_grid()
@@ -228,7 +234,7 @@ y.copy_(x)
 s.applyVCycle(y, b, False)  # (again from zero: the same answer, and the grids have been through a swap)
 z = s.new_grid()
 st = s.solveGeometricConjugateGradient(z, b, 1e-5, 8)
-np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), it=st["iterations"])
+np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), it=st["iterations"], swept=s.swept_cells(0)[0])
 """ % ROOT
     import tempfile
 
@@ -236,7 +242,7 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
     with tempfile.TemporaryDirectory() as tmp:
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
-            env = dict(os.environ, MGPS_FUSE_DOWN=fuse)
+            env = dict(os.environ, **{switch: fuse})
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
@@ -244,3 +250,5 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
         assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
     assert int(outs[0]["it"]) == int(outs[1]["it"])
+    if switch != "MGPS_FUSE_DOWN" and case != "pool128":
+        assert int(outs[0]["swept"]) < int(outs[1]["swept"])  # (the switch was live: fewer cells visited with it on)
