@@ -2429,8 +2429,10 @@ int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, c
     const bool list = g.chunks != nullptr;
     const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
     const bool dot = dotPartials != nullptr && op == OP_JACOBI;
+    if (!x && (op != OP_JACOBI || dot || g.nbnd > 0)) return int(hipErrorInvalidValue);  // x == nullptr: the zero iterate (see launchStencil)
     if (nb > 0) {
-        if (dot) stencilQuadKernel<OP_JACOBI, true, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, dotPartials, ms);
+        if (!x) stencilQuadKernel<OP_JACOBI, false, __half, true><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
+        else if (dot) stencilQuadKernel<OP_JACOBI, true, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, dotPartials, ms);
         else if (op == OP_JACOBI) stencilQuadKernel<OP_JACOBI, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
         else stencilQuadKernel<OP_RESIDUAL, false, __half><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb, g.chunks, nullptr, ms);
     }

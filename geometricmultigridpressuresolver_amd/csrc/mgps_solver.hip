@@ -1134,7 +1134,10 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
     }
     MGPS_LAUNCH(h, launchMixSigma(h->stream, maxAbsDev, h->mixSigma));
     void *cur = h->mixX, *other = h->mixTmp;
-    MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));  // MG.cpp:439-440
+    // (the first stroke starts from zero, MG.cpp:439-440: like strokeTakesZero, it can take the iterate as zero instead of clearing and reading it)
+    const bool gatherDown = dotDev != nullptr && h->dotPartials != nullptr && nlv == 1;
+    const bool zeroStart = strokeTakesZero(h, 0, h->lv[0].x, h->lv[0].tmp, b, gatherDown) && (F.g.nx & 3) == 0;
+    if (!zeroStart) MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));
     const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
     const bool gather = dotDev != nullptr && h->dotPartials != nullptr;
     h->dotUsed = 0;
@@ -1149,12 +1152,12 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         MGPS_LAUNCH(h, launchBandBoxCopy(h->stream, F.g, F.bandBoxes, h->mixR, cur, true));
         return MGPS_OK;
     };
-    auto sweep = [&](bool d, bool patchGeneral) -> int {
+    auto sweep = [&](bool d, bool patchGeneral, bool xZero) -> int {
         unsigned used = 0;
         GridP gs = F.g;
         if (!patchGeneral) gs.nbnd = 0;
         if (h->profiling) MGPS_TRY(profMark(h, true));  // the measurement hook of smoothStroke: event pair around the fine sweep
-        MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, gs, other, cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
+        MGPS_LAUNCH(h, launchStencilMixed(h->stream, OP_JACOBI, gs, other, xZero ? nullptr : cur, b, omega, smooth, d ? h->dotPartials + h->dotUsed : nullptr, &used));
         if (h->profiling) {
             MGPS_TRY(profMark(h, false));
             ++h->profSweeps;
@@ -1162,30 +1165,29 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         h->dotUsed += used;
         return MGPS_OK;
     };
-    auto stroke = [&](bool down, bool dot) -> int {
+    auto stroke = [&](bool down, bool dot, bool xZero) -> int {
         const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
-        if (reps == 1 && F.bandBoxes.ngroups > 0) {
-            MGPS_TRY(sweep(dot, dot));
-            double *sinkA = nullptr, *sinkB = nullptr;
+        if (reps == 1 && F.bandBoxes.ngroups > 0) {  // closure launch (snapshot only), sweep, plain launch: see smoothStroke
+            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, xZero ? nullptr : cur, b, nullptr, h->mixR, omega, true, smooth));
+            MGPS_TRY(sweep(dot, dot, xZero));
+            double *sinkB = nullptr;
             if (dot) {
-                sinkA = h->dotPartials + h->dotUsed;
-                sinkB = sinkA + F.bandBoxes.ngroups;
-                h->dotUsed += 2u * unsigned(F.bandBoxes.ngroups);
+                sinkB = h->dotPartials + h->dotUsed;
+                h->dotUsed += unsigned(F.bandBoxes.ngroups);
             }
-            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, cur, b, other, h->mixR, omega, true, smooth, sinkA, other));
             std::swap(cur, other);
-            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, h->mixR, b, cur, nullptr, omega, true, smooth, sinkB, h->mixR));
+            MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, h->mixR, b, cur, nullptr, omega, true, smooth, sinkB, cur, true));
             return MGPS_OK;
         }
         MGPS_TRY(bandStage(false));
         for (int rep = 0; rep < reps; ++rep) {
-            MGPS_TRY(sweep(dot && rep == reps - 1, true));
+            MGPS_TRY(sweep(dot && rep == reps - 1, true, false));
             std::swap(cur, other);
         }
         MGPS_TRY(bandStage(dot));
         return MGPS_OK;
     };
-    MGPS_TRY(stroke(true, gather && nlv == 1));
+    MGPS_TRY(stroke(true, gather && nlv == 1, zeroStart));
     if (nlv > 1) {
         DevLevel &C = h->lv[1];
         // r~ = 256 r^ = 256 sigma b - 256 2^e (A x~); level 1 receives Restrict(r^) in fp32
@@ -1195,7 +1197,7 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         float *corr = nullptr;
         MGPS_TRY(innerCycle(h, 1, &corr));
         MGPS_LAUNCH(h, launchProlongAddMixed(h->stream, F.g, cur, corr, xs));
-        MGPS_TRY(stroke(false, gather));
+        MGPS_TRY(stroke(false, gather, false));
     }
     if (gather) {
         MGPS_LAUNCH(h, launchFoldDot(h->stream, h->dotPartials, h->dotUsed, dotDev));

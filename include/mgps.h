@@ -432,7 +432,9 @@ int mgps_stage_times(mgps_solver *h, double out_ms[6], int *cycles);
 int mgps_stage_times_fine(mgps_solver *h, double out_ms[6]);
 int mgps_profile_read(mgps_solver *h, double *fine_smoother_ms, int *fine_smoother_launches);
 /* Cells one full-domain sweep of `level` visits: the kernels skip 1024-cell chunks / 256x16xzc blocks /
- * 16^3 tiles without active cells (the reference skips constant tiles the same way, Ops.h:300-312);
+ * 16^3 tiles without active cells (the reference skips constant tiles the same way, Ops.h:300-312) and, inside the
+ * runs / blocks they do visit, the quads outside the level's active x range (the EXTERIOR padding at the row ends);
+ * counted on the device from the list the sweep walks (one small launch and a synchronisation per call);
  * stencil_cells is for the Jacobi / residual / apply sweep, gs_cells for the two tiled-GS half sweeps.
  * This is the cell count behind bench.py's algorithmic bytes per launch. */
 int mgps_swept_cells(const mgps_solver *h, int level, long long *stencil_cells, long long *gs_cells);

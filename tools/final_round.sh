@@ -16,6 +16,13 @@ for sz in 512 1024; do
   python bench.py --size $sz --zero-guess --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_fp32.json 2>/dev/null || exit 1
   python bench.py --size $sz --zero-guess --precision mixed --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_mixed.json 2>/dev/null || exit 1
 done
+# multi-GPU compute ceiling (null transport on one GPU) and slab set-up time
+python tools/slab_compute_bound.py 1024 > gpurun_out/${round}_slab_compute_bound_1024.json 2> gpurun_out/slab_cb.err || echo "slab_compute_bound failed"
+python tools/slab_setup_time.py 1024 8 3 > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
+for sz in 256 512; do
+  rocprofv3 --kernel-trace -d gpurun_out/tl_$sz --output-format csv -- python3 bench.py --size $sz --steps 6 --warmup 2 --no-cpu --no-frac512 > /dev/null 2>&1
+  python3 tools/cycle_timeline.py gpurun_out/tl_$sz > gpurun_out/${round}_cycle_timeline_$sz.txt; rm -rf gpurun_out/tl_$sz
+done
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("gpurun_out/${round}_bench*.json")):
