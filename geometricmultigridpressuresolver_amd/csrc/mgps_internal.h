@@ -399,6 +399,8 @@ int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
                   const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials = nullptr);
+int launchTiledGSMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *pureTiles, int npure, const int32_t *mixedTiles, int nmixed,
+                       const int32_t *tileBndStart, int forward, const MixScale &ms);
 // codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
 int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, const uint8_t *bandDiag, int nbnd, int nband);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);

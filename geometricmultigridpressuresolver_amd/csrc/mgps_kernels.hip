@@ -1264,10 +1264,13 @@ constexpr int kRowPool = 240;   // BOUNDARY rows of one tile kept in LDS (the re
 __device__ __forceinline__ int haloIdx(int li, int lj, int lk) { return ((lk + 1) * kHalo + (lj + 1)) * kHalo + (li + 1); }
 
 // stage the halo cube of x (and optionally the labels) and the rhs of tile (i0,j0,k0)
-template <bool LABELS>
-__device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restrict__ x, const float *__restrict__ b,
-                                           int i0, int j0, int k0, float *sx, float *sb, unsigned char *sl)
+// TX = __half (options.precision = 1): the iterate lives in binary16 and is staged / swept in fp32; bm scales the rhs into the
+// iterate's units (mixRhsScale; 1 for fp32 grids)
+template <bool LABELS, class TX = float>
+__device__ __forceinline__ void gsLoadTile(const GridP &g, const TX *__restrict__ x, const float *__restrict__ b,
+                                           int i0, int j0, int k0, float *sx, float *sb, unsigned char *sl, float bm = 1.f)
 {
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
     const bool full = i0 + kTile <= g.nx && j0 + kTile <= g.ny && k0 + kTile <= g.nz;
     if (full) {
         // 18 x 18 rows of the cube: the 16 interior floats of a row as 4 aligned float4, the two x-halo cells as
@@ -1289,7 +1292,7 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             xv[m] = make_float4(0.f, 0.f, 0.f, 0.f);
             lv[m] = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
             if (in) {
-                xv[m] = *reinterpret_cast<const float4 *>(x + rowOff);
+                xv[m] = Cell<TX>::load4(x + rowOff);
                 // labels of the tile's own rows only: the sweep never looks at a halo cell's label (a 16-byte label row is
                 // an eighth of a line: 68 halo rows would be 68 more lines per tile)
                 if (LABELS && lj >= 1 && lj <= kTile && lk >= 1 && lk <= kTile) lv[m] = *reinterpret_cast<const uchar4 *>(g.lab + rowOff);
@@ -1304,7 +1307,7 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             const ptrdiff_t c = (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi;
             hv[m] = 0.f;
             hl[m] = (unsigned char)MGPS_EXTERIOR_CELL;  // (x-halo labels are never read either)
-            if (in) hv[m] = x[c];
+            if (in) hv[m] = Cell<TX>::load1(x + c);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -1341,10 +1344,10 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float *dst = sb + (tid + m * 256) * 4;
-            dst[0] = bv[m].x;
-            dst[1] = bv[m].y;
-            dst[2] = bv[m].z;
-            dst[3] = bv[m].w;
+            dst[0] = kMixed ? bm * bv[m].x : bv[m].x;
+            dst[1] = kMixed ? bm * bv[m].y : bv[m].y;
+            dst[2] = kMixed ? bm * bv[m].z : bv[m].z;
+            dst[3] = kMixed ? bm * bv[m].w : bv[m].w;
         }
     } else {  // ragged tile at the end of a grid whose extent is not a multiple of 16
         for (int h = threadIdx.x; h < kHalo3; h += blockDim.x) {
@@ -1352,26 +1355,26 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const float *__restri
             const int gi = i0 + li - 1, gj = j0 + lj - 1, gk = k0 + lk - 1;
             const bool in = gi >= 0 && gj >= 0 && gk >= -g.ghostLo && gi < g.nx && gj < g.ny && gk < g.nz + g.ghostHi;
             const ptrdiff_t c = in ? (ptrdiff_t(gk) * g.ny + gj) * g.nx + gi : 0;
-            sx[h] = in ? x[c] : 0.f;
+            sx[h] = in ? Cell<TX>::load1(x + c) : 0.f;
             if (LABELS) sl[h] = in ? g.lab[c] : (unsigned char)MGPS_EXTERIOR_CELL;
         }
         for (int h = threadIdx.x; h < kTile3; h += blockDim.x) {
             const int li = h % kTile, lj = (h / kTile) % kTile, lk = h / (kTile * kTile);
             const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
             const bool in = gi < g.nx && gj < g.ny && gk < g.nz;
-            sb[h] = in ? b[(size_t(gk) * g.ny + gj) * g.nx + gi] : 0.f;
+            sb[h] = in ? (kMixed ? bm * b[(size_t(gk) * g.ny + gj) * g.nx + gi] : b[(size_t(gk) * g.ny + gj) * g.nx + gi]) : 0.f;
         }
     }
 }
 
 // one pure tile by one workgroup; slot: where its <x, b> goes (DOT)
-template <bool DOT>
-__device__ __forceinline__ void gsPureTile(const GridP &g, float *__restrict__ x, const float *__restrict__ b, int tile, int forward,
-                                           double *__restrict__ dotPartials, unsigned slot, float *sx, float *sb)
+template <bool DOT, class TX = float>
+__device__ __forceinline__ void gsPureTile(const GridP &g, TX *__restrict__ x, const float *__restrict__ b, int tile, int forward,
+                                           double *__restrict__ dotPartials, unsigned slot, float *sx, float *sb, float bm = 1.f)
 {
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
-    gsLoadTile<false>(g, x, b, i0, j0, k0, sx, sb, nullptr);
+    gsLoadTile<false, TX>(g, x, b, i0, j0, k0, sx, sb, nullptr, bm);
     __syncthreads();
     const int li = threadIdx.x % kTile, lj = threadIdx.x / kTile;  // this thread's (i, j) column
     for (int step = 0; step < kPlanes; ++step) {
@@ -1390,8 +1393,7 @@ __device__ __forceinline__ void gsPureTile(const GridP &g, float *__restrict__ x
     for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
         const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
         const float *src = sx + haloIdx(4 * q, cj, ck);
-        *reinterpret_cast<float4 *>(x + (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q) =
-            make_float4(src[0], src[1], src[2], src[3]);
+        Cell<TX>::store4(x + (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
         if (DOT) {
             const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
 #pragma unroll
@@ -1400,29 +1402,29 @@ __device__ __forceinline__ void gsPureTile(const GridP &g, float *__restrict__ x
     }
     if (DOT) blockDotStore(acc, dotPartials, slot);
 }
-template <bool DOT = false>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
-__global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+template <bool DOT = false, class TX = float>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
+__global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, TX *__restrict__ x, const float *__restrict__ b,
                                                          const int32_t *__restrict__ tiles, int forward,
-                                                         double *__restrict__ dotPartials = nullptr)
+                                                         double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{})
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
-    gsPureTile<DOT>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb);
+    gsPureTile<DOT, TX>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb, std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms));
 }
 
 // one mixed tile by one workgroup (rowMask: bit i set = cell (i, j, k) of x-row (j, k) is BOUNDARY; rowStart: BOUNDARY cells of
 // the tile before that x-row)
-template <bool DOT>
-__device__ __forceinline__ void gsMixedTile(const GridP &g, float *__restrict__ x, const float *__restrict__ b, int tile,
+template <bool DOT, class TX = float>
+__device__ __forceinline__ void gsMixedTile(const GridP &g, TX *__restrict__ x, const float *__restrict__ b, int tile,
                                             const int32_t *__restrict__ tileBndStart, int forward, double *__restrict__ dotPartials,
                                             unsigned slot, float *sx, float *sb, unsigned char *sl, float *srow, unsigned short *rowMask,
-                                            unsigned short *rowStart, int *scanTmp)
+                                            unsigned short *rowStart, int *scanTmp, float bm = 1.f)
 {
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
     const int bndBase = tileBndStart[tile], bndCount = tileBndStart[tile + 1] - bndBase;
     const size_t nb = size_t(g.nbnd);
-    gsLoadTile<true>(g, x, b, i0, j0, k0, sx, sb, sl);
+    gsLoadTile<true, TX>(g, x, b, i0, j0, k0, sx, sb, sl, bm);
     for (int r = threadIdx.x; r < 7 * min(bndCount, kRowPool); r += blockDim.x) {
         const int q = r / min(bndCount, kRowPool), t = r % min(bndCount, kRowPool);
         srow[q * kRowPool + t] = g.rows[q * nb + bndBase + t];
@@ -1492,10 +1494,10 @@ __device__ __forceinline__ void gsMixedTile(const GridP &g, float *__restrict__ 
         const int gi = i0 + 4 * q, gj = j0 + cj, gk = k0 + ck;
         if (gj >= g.ny || gk >= g.nz || gi >= g.nx) continue;
         const float *src = sx + haloIdx(4 * q, cj, ck);
-        float *dst = x + (size_t(gk) * g.ny + gj) * g.nx + gi;
-        if (gi + 3 < g.nx && (g.nx & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+        TX *dst = x + (size_t(gk) * g.ny + gj) * g.nx + gi;
+        if (gi + 3 < g.nx && (g.nx & 3) == 0) Cell<TX>::store4(dst, make_float4(src[0], src[1], src[2], src[3]));
         else
-            for (int e = 0; e < 4 && gi + e < g.nx; ++e) dst[e] = src[e];
+            for (int e = 0; e < 4 && gi + e < g.nx; ++e) Cell<TX>::store1(dst + e, src[e]);
         if (DOT) {
             const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
             const unsigned char *lq = sl + haloIdx(4 * q, cj, ck);
@@ -1505,11 +1507,11 @@ __device__ __forceinline__ void gsMixedTile(const GridP &g, float *__restrict__ 
     }
     if (DOT) blockDotStore(acc, dotPartials, slot);
 }
-template <bool DOT = false>
-__global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
+template <bool DOT = false, class TX = float>
+__global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, TX *__restrict__ x, const float *__restrict__ b,
                                                           const int32_t *__restrict__ tiles,
                                                           const int32_t *__restrict__ tileBndStart, int forward,
-                                                          double *__restrict__ dotPartials = nullptr)
+                                                          double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{})
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
@@ -1518,7 +1520,8 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, float *__rest
     __shared__ unsigned short rowMask[kTile * kTile];
     __shared__ unsigned short rowStart[kTile * kTile];
     __shared__ int scanTmp[4];
-    gsMixedTile<DOT>(g, x, b, tiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp);
+    gsMixedTile<DOT, TX>(g, x, b, tiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp,
+                         std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms));
 }
 // Both lists of a colour in one launch: workgroups [0, nmixed) take the mixed tiles, the rest the pure ones.  For the small
 // levels, where a launch is a handful of workgroups and each tile a chain of 46 barrier steps (~10 us): the two launches of
@@ -2532,6 +2535,18 @@ int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const 
     }
     if (nmixed > 0) tiledGSMixedKernel<<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward);
     if (npure > 0) tiledGSPureKernel<<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward);
+    return int(hipGetLastError());
+}
+
+// one colour's tiles of the binary16 iterate (options.precision = 1 with the Gauss-Seidel smoother): staged, swept and summed in
+// fp32 like the fp32 grids, rounded once when the tile is written back; the rhs in the iterate's units (ms)
+int launchTiledGSMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *pureTiles, int npure, const int32_t *mixedTiles, int nmixed,
+                       const int32_t *tileBndStart, int forward, const MixScale &ms)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    __half *x = static_cast<__half *>(xH);
+    if (nmixed > 0) tiledGSMixedKernel<false, __half><<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, nullptr, ms);
+    if (npure > 0) tiledGSPureKernel<false, __half><<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, nullptr, ms);
     return int(hipGetLastError());
 }
 

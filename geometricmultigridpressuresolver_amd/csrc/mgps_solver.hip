@@ -1139,7 +1139,7 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
     const bool zeroStart = strokeTakesZero(h, 0, h->lv[0].x, h->lv[0].tmp, b, gatherDown) && (F.g.nx & 3) == 0;
     if (!zeroStart) MGPS_LAUNCH(h, launchZeroActiveHalf(h->stream, F.g, cur));
     const MixScale smooth{h->mixSigma, xs, 1.f};  // the iterate's units: rhs sigma 2^-e b
-    const bool gather = dotDev != nullptr && h->dotPartials != nullptr;
+    const bool gather = dotDev != nullptr && h->dotPartials != nullptr && !h->useGS;  // (the binary16 tile kernels gather nothing: a separate pass below)
     h->dotUsed = 0;
     // (the box form of the band stage, binary16 grids: see smoothStroke; the scratch / snapshot grid is the binary16 residual)
     auto bandStage = [&](bool dot) -> int {  // no snapshot: out of place, band cells copied back
@@ -1167,7 +1167,7 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
     };
     auto stroke = [&](bool down, bool dot, bool xZero) -> int {
         const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
-        if (reps == 1 && F.bandBoxes.ngroups > 0) {  // closure launch (snapshot only), sweep, plain launch: see smoothStroke
+        if (reps == 1 && F.bandBoxes.ngroups > 0 && !h->useGS) {  // closure launch (snapshot only), sweep, plain launch: see smoothStroke
             MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, xZero ? nullptr : cur, b, nullptr, h->mixR, omega, true, smooth));
             MGPS_TRY(sweep(dot, dot, xZero));
             double *sinkB = nullptr;
@@ -1181,6 +1181,19 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         }
         MGPS_TRY(bandStage(false));
         for (int rep = 0; rep < reps; ++rep) {
+            if (h->useGS) {  // the colour passes of smoothStroke (MG.cpp:466-479 down, 740-751 up), in place on the binary16 iterate
+                const int first = down ? 1 : 0, forward = down ? 1 : 0;
+                if (h->profiling) MGPS_TRY(profMark(h, true));
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int odd = pass == 0 ? first : 1 - first;
+                    MGPS_LAUNCH(h, launchTiledGSMixed(h->stream, F.g, cur, b, F.pure[odd], F.npure[odd], F.mixed[odd], F.nmixed[odd], F.tileBndStart, forward, smooth));
+                }
+                if (h->profiling) {
+                    MGPS_TRY(profMark(h, false));
+                    ++h->profSweeps;
+                }
+                continue;
+            }
             MGPS_TRY(sweep(dot && rep == reps - 1, true, false));
             std::swap(cur, other);
         }
@@ -1204,6 +1217,7 @@ int vcycleMixed(mgps_solver *h, float *x, const float *b, bool useInitialGuess, 
         MGPS_LAUNCH(h, launchScaleResult(h->stream, dotDev, h->mixSigma, xsInv));
     }
     h->mixResult = cur;
+    if (dotDev && !gather) MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, cur, b, h->mixSigma, xsInv, h->partials, dotDev));
     if (x) MGPS_LAUNCH(h, launchFromHalf(h->stream, x, cur, h->mixSigma, xsInv, n));
     return MGPS_OK;
 }
@@ -2019,9 +2033,9 @@ int createWhole(mgps_solver **out, mgps_hierarchy *hier, const float *wx, const 
     if (tailOfSlabRun) h->opt.precision = 0;
     if (h->opt.precision == 1) {
         const bool fused = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
-        if (useGS || !fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
+        if (!fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
             return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT,
-                              "options.precision = 1 (mixed precision) needs the Jacobi smoother (use_gauss_seidel = 0), the fused band stage "
+                              "options.precision = 1 (mixed precision) needs the fused band stage "
                               "(fuse_band_passes, 1 <= band_iterations <= 4) and a fine grid with nx % 4 == 0 and even ny, nz"));
     }
     StageClock clock(h->opt.print_stats != 0);
@@ -2214,9 +2228,9 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     const Dims d0{nx, ny, nz};
     if (h->opt.precision == 1) {
         const bool fused = o.fuse_band_passes && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
-        if (useGS || !fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
+        if (!fused || !mixedPrecisionShapeOk(d0.nx, d0.ny, d0.nz))
             return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT,
-                              "options.precision = 1 (mixed precision) needs the Jacobi smoother (use_gauss_seidel = 0), the fused band stage "
+                              "options.precision = 1 (mixed precision) needs the fused band stage "
                               "(fuse_band_passes, 1 <= band_iterations <= 4) and a fine grid with nx % 4 == 0 and even ny, nz"));
     }
     StageClock clock(h->opt.print_stats != 0);

@@ -113,7 +113,8 @@ typedef struct mgps_options {
        arithmetic is fp32.  The cycle runs on the rhs normalised by a power of two (max |b| in (1/2, 1]) with fixed
        per-grid scales, so that binary16's range is used where the values are; results are returned in the caller's
        units.  A cycle from an initial guess runs as x + M (b - A x) with the residual in fp32 (iterative refinement:
-       only corrections pass through binary16).  Single-device solvers with the Jacobi smoother (use_gauss_seidel = 0) whose fine nx is a multiple of 4.
+       only corrections pass through binary16).  Single-device solvers whose fine nx is a multiple of 4; either smoother (the tiled
+       Gauss-Seidel passes stage and sweep a tile in fp32 and round it once when it is written back).
        mgps_solve_pcg then preconditions with this cycle: tolerance and iteration counts against fp32 in DESIGN.md */
     int precision;
     /* 0 (default): single-device solvers build the hierarchy (coarse labels MG.cpp:238-253, band lists MG.cpp:279-281) and

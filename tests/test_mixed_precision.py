@@ -1,5 +1,5 @@
 """BASELINE config 5: mixed precision (options.precision = 1) -- the fine level of the V-cycle keeps its iterate and its
-residual in binary16 (damped-Jacobi smoother, restriction input, prolongation target), the rhs, every coarser level,
+residual in binary16 (smoother -- damped Jacobi or the plugin's tiled Gauss-Seidel --, restriction input, prolongation target), the rhs, every coarser level,
 the CG vectors, A.p and all reductions stay fp32; arithmetic is fp32 throughout.  The reference has no such mode (it
 is its README TO-DO, README.md:34-35), so the yardsticks are the fp64 oracle and this library's own fp32 path.
 
@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 MIXED_VCYCLE_TOL = 2e-3
 
 
-def _solvers(lab, w, lev, **kw):
+def _solvers(lab, w, lev, use_gs=False, **kw):
     import geometricmultigridpressuresolver_amd as G
 
     out = []
@@ -29,19 +29,22 @@ def _solvers(lab, w, lev, **kw):
         opt.precision = prec
         for k, v in kw.items():
             setattr(opt, k, v)
-        out.append(G.GeometricMultigridPoissonSolver(lab, w, lev, False, options=opt))
+        out.append(G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, options=opt))
     return out
 
 
-@pytest.mark.parametrize("kind,g,sweeps", [("simple", 32, 1), ("solid", 64, 1), ("complex", 64, 2), ("wide512", 40, 1)])
-def test_mixed_vcycle_matches_oracle(kind, g, sweeps, domain_factory, oracle):
+@pytest.mark.parametrize("kind,g,sweeps,use_gs", [("simple", 32, 1, False), ("solid", 64, 1, False), ("complex", 64, 2, False), ("wide512", 40, 1, False),
+                                                  ("simple", 32, 1, True), ("complex", 64, 1, True), ("solid", 64, 2, True)])
+def test_mixed_vcycle_matches_oracle(kind, g, sweeps, use_gs, domain_factory, oracle):
+    """use_gs: the plugin's smoother (tiled Gauss-Seidel, HDK_GeometricFreeSurfacePressureSolver.cpp:466) on the binary16 iterate:
+    tiles staged and swept in fp32, rounded when written back (launchTiledGSMixed)."""
     from geometricmultigridpressuresolver_amd import domains as D
     from test_gpu_parity import _wide_args
 
     levels, shape = _wide_args(kind)
     lab, w, off, lev, dx = domain_factory(kind, g, levels, shape)
-    f32, mix = _solvers(lab, w, lev, pre_sweeps=sweeps, post_sweeps=sweeps)
-    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, False, pre_sweeps=sweeps, post_sweeps=sweeps)
+    f32, mix = _solvers(lab, w, lev, use_gs, pre_sweeps=sweeps, post_sweeps=sweeps)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, use_gs, pre_sweeps=sweeps, post_sweeps=sweeps)
     b = D.random_rhs(lab, dx, seed=5).astype(np.float32) * 37.0  # any magnitude: the cycle normalises by a power of two
     bd = mix.to_device(b)
     x_ref = np.zeros(lab.shape)
@@ -65,16 +68,16 @@ def test_mixed_vcycle_matches_oracle(kind, g, sweeps, domain_factory, oracle):
     f32.close()
 
 
-@pytest.mark.parametrize("kind,g", [("solid", 64), ("complex", 64)])
-def test_mixed_pcg_matches_oracle(kind, g, domain_factory, oracle):
+@pytest.mark.parametrize("kind,g,use_gs", [("solid", 64, False), ("complex", 64, False), ("complex", 64, True)])
+def test_mixed_pcg_matches_oracle(kind, g, use_gs, domain_factory, oracle):
     from geometricmultigridpressuresolver_amd import domains as D
 
     lab, w, off, lev, dx = domain_factory(kind, g)
     b = (D.delta_rhs(lab, g, off, dx) + D.random_rhs(lab, dx)).astype(np.float32)
-    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, False)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], lev, use_gs)
     x_ref = np.zeros(lab.shape)
     ref = orc.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 500, True)
-    f32, mix = _solvers(lab, w, lev)
+    f32, mix = _solvers(lab, w, lev, use_gs)
     xf, xm = f32.new_grid(), mix.new_grid()
     sf = f32.solveGeometricConjugateGradient(xf, f32.to_device(b), 1e-5, 500, True)
     sm = mix.solveGeometricConjugateGradient(xm, mix.to_device(b), 1e-5, 500, True)
@@ -86,7 +89,7 @@ def test_mixed_pcg_matches_oracle(kind, g, domain_factory, oracle):
 
     opt = G.default_options()
     opt.precision, opt.pcg_fp64_vectors = 1, 1
-    s64 = G.GeometricMultigridPoissonSolver(lab, w, lev, False, options=opt)
+    s64 = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, options=opt)
     x64 = s64.new_grid()
     st = s64.solveGeometricConjugateGradient(x64, s64.to_device(b), 1e-5, 500, True)
     assert st["outcome"] == "converged" and st["rel_residual_recomputed"] < 1e-5 and st["iterations"] <= 1.5 * sf["iterations"]
@@ -100,9 +103,11 @@ def test_mixed_precision_refuses_what_it_does_not_cover(domain_factory):
     lab, w, off, lev, dx = domain_factory("simple", 32)
     opt = G.default_options()
     opt.precision = 1
+    opt.fuse_band_passes = 0
     with pytest.raises(G.MgpsError) as e:
-        G.GeometricMultigridPoissonSolver(lab, w, lev, True, options=opt)  # Gauss-Seidel: not in binary16
-    assert e.value.status == 1 and "Jacobi" in str(e.value)
+        G.GeometricMultigridPoissonSolver(lab, w, lev, False, options=opt)  # the pass-by-pass band stage: not in binary16
+    assert e.value.status == 1 and "fused band stage" in str(e.value)
+    opt.fuse_band_passes = 1
     opt.precision = 2
     with pytest.raises(G.MgpsError):
         G.GeometricMultigridPoissonSolver(lab, w, lev, False, options=opt)

@@ -16,6 +16,9 @@ for sz in 512 1024; do
   python bench.py --size $sz --zero-guess --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_fp32.json 2>/dev/null || exit 1
   python bench.py --size $sz --zero-guess --precision mixed --no-cpu --no-frac512 --steps 20 --warmup 5 > gpurun_out/${round}_bench${sz}_zeroguess_mixed.json 2>/dev/null || exit 1
 done
+# config 5 with the plugin's smoother: 512^3 pool MG-PCG, tiled Gauss-Seidel, fp32 against mixed precision
+python tools/prof_pcg.py 512 0 1 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_gs_fp32_vs_mixed.txt
+python tools/prof_pcg.py 512 1 1 2>/dev/null | tail -n 1 >> gpurun_out/${round}_pcg512_gs_fp32_vs_mixed.txt
 # multi-GPU compute ceiling (null transport on one GPU) and slab set-up time
 python tools/slab_compute_bound.py 1024 > gpurun_out/${round}_slab_compute_bound_1024.json 2> gpurun_out/slab_cb.err || echo "slab_compute_bound failed"
 python tools/slab_setup_time.py 1024 8 3 > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
