@@ -1597,6 +1597,9 @@ __global__ void restrictKernel(GridP cg, float *__restrict__ coarse, const TF *_
 // in-plane 4 x 4 weighted sums of the last fine planes in registers -- every fine plane's sum is formed once and
 // feeds the two coarse planes it belongs to, where the per-cell kernel above forms it twice (and its z-overlap
 // reads miss the L2 on large planes: 1.6x the algorithmic HBM traffic).  x, then y, then z summation.
+// (Round 3, tried and dropped: one 8-byte load per row and lane -- the fine pair (2 I, 2 I + 1) -- with 2 I - 1 / 2 I + 2 taken
+// from the neighbour lanes instead of four 4-byte loads at an 8-byte lane stride: 78 registers and twelve ds_bpermute per fine
+// plane; 1024^3 cycle 10.44 -> 11.25 ms, 512^3 1.65 -> 1.77 ms.)
 template <class TF = float>
 __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__restrict__ coarse, const TF *__restrict__ fine,
                                                            int kc, unsigned nbx, unsigned nby, float fm = 1.f)
