@@ -234,23 +234,28 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const size_t c = row * sy + i;
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // quads outside the level's active x range (GridP::xlo): EXTERIOR padding, zero in every grid -- nothing loaded, nothing stored
+    // quads outside the level's active x range (GridP::xlo): EXTERIOR padding, zero in every grid -- nothing of theirs is loaded or
+    // stored.  Their lanes issue the same (unconditional) loads as everybody, aimed at the nearest quad of the range in their row --
+    // lines the wave fetches anyway -- and drop what arrives: a branch or a select per load put every binary16 load + conversion
+    // behind its own wait (mixed-precision sweep 0.19 -> 0.26 ms at 512^3)
     const bool live = i >= g.xlo && i < g.xhi;
     valid = valid && live;
-    const bool ld = live && !XZERO;
-    const float4 xc = ld ? Cell<TX>::load4(x + c) : zero4;
+    const size_t cl = live ? c : c - size_t(i) + size_t(min(max(i, g.xlo), max(g.xhi - 4, 0)));
     // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
     // results are discarded, the loads only have to stay in bounds
-    const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
-    const size_t czm = (k > 0 || g.ghostLo) ? c - sz : c, czp = (k < g.nz - 1 || g.ghostHi) ? c + sz : c;
-    const float4 ym = ld ? Cell<TX>::load4(x + cym) : zero4;
-    const float4 yp = ld ? Cell<TX>::load4(x + cyp) : zero4;
-    const float4 zm = ld ? Cell<TX>::load4(x + czm) : zero4;
-    const float4 zp = ld ? Cell<TX>::load4(x + czp) : zero4;
-    uchar4 lab = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-    if (live) lab = g.streaming ? streamLoad4(g.lab + c) : *reinterpret_cast<const uchar4 *>(g.lab + c);
+    const size_t cym = j > 0 ? cl - sy : cl, cyp = j < g.ny - 1 ? cl + sy : cl;
+    const size_t czm = (k > 0 || g.ghostLo) ? cl - sz : cl, czp = (k < g.nz - 1 || g.ghostHi) ? cl + sz : cl;
+    float4 xc = XZERO ? zero4 : Cell<TX>::load4(x + cl);
+    const float4 ym = XZERO ? zero4 : Cell<TX>::load4(x + cym);
+    const float4 yp = XZERO ? zero4 : Cell<TX>::load4(x + cyp);
+    const float4 zm = XZERO ? zero4 : Cell<TX>::load4(x + czm);
+    const float4 zp = XZERO ? zero4 : Cell<TX>::load4(x + czp);
+    // (the four codes as one word, taken apart only where they are used: unpacking them here made the load's wait precede the rhs load)
+    const unsigned labw = g.streaming ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(g.lab + cl)) : *reinterpret_cast<const unsigned *>(g.lab + cl);
     float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY && live) bc = g.streaming ? streamLoad4(b + c) : *reinterpret_cast<const float4 *>(b + c);
+    if (OP != OP_APPLY) bc = g.streaming ? streamLoad4(b + cl) : *reinterpret_cast<const float4 *>(b + cl);
+    if (!live) xc = zero4;  // (what the neighbour lanes see of this quad; its own results are never stored, `valid`)
+    const bool ld = live && !XZERO;
 
     // x neighbours across the quad boundary
     const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
     const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
     const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
-    const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
+    const unsigned ls[4] = {labw & 255u, (labw >> 8) & 255u, (labw >> 16) & 255u, labw >> 24};
     const float bm = kMixed ? mixRhsScale(ms) : 1.f;
     float res[4];
     // INTERIOR and simple BOUNDARY cells; general BOUNDARY cells are patched by boundaryOpKernel
