@@ -342,7 +342,12 @@ GridP g, float *__restrict__ out,
     // Two planes of a thread's own x quad are in flight at any time: plane k + 2 is requested while plane k is computed, so the
     // plane k + 1 a step needs (its z + 1 neighbours) was requested a whole step earlier -- like the rhs, the codes and the halo,
     // which are requested one plane ahead and used one step later (with one plane of look-ahead for x every step ended by
-    // waiting out a full memory round trip)
+    // waiting out a full memory round trip).
+    // (Tried on top and dropped: the four planes in a ring of named registers with the march unrolled four times -- the rolled loop's
+    // end-of-step copies xc = xp = xq are waits for those loads --, every load unconditional (dead lanes aim at the range's nearest
+    // quad, every thread loads a halo row / cell) and ordered by first use: the waits became partial (vmcnt(4-5) instead of 0), but
+    // the halo row then has to be parked in a register that is free only after a wait, and every thread pays a fifth load per plane:
+    // 1024^3 cycle 10.32 -> 12.22 ms.)
     auto planeAt = [&](int k) { return (k < g.nz || g.ghostHi) ? (size_t(min(k, g.nz)) * g.ny + jc) * sy + ic : (size_t(g.nz - 1) * g.ny + jc) * sy + ic; };
     float4 xm = ld ? *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c)) : zero4;
     float4 xc = ld ? *reinterpret_cast<const float4 *>(x + c) : zero4;
