@@ -383,8 +383,18 @@ def main():
                 "unit": "GB/s",
                 "frac": 16.0 * nband / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if band_ms > 0 else None,
                 "note": "O(N^2) cells at a line-granular cost: an x-face band row is three cells of one 128-B line per array "
-                        "(profiles/r03_pmc_hbm_traffic.json, bandBoxKernel entries: 84 / 68 B per band cell fetched + written by the closure / plain launch at 1024^3)",
+                        "(traffic: profiles/r03_pmc_hbm_traffic.json, bandBoxKernel entries of the fine level, fetched + written per band cell)",
             }
+            try:  # measured bytes per band cell of the closure / plain launch at this size, from the committed PMC passes
+                kern = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["kernels"]
+                fine = {k: v for k, v in kern.items() if k.startswith("bandBoxKernel<float, ") and f"@{n}^3" in k}
+                top = max(int(k.split("grid=")[1]) for k in fine) if fine else 0
+                for k, v in fine.items():
+                    if int(k.split("grid=")[1]) == top and ", false, false, false>" in k:
+                        which = "closure" if k.startswith("bandBoxKernel<float, true") else "plain"
+                        out["band_stage"][f"traffic_bytes_per_band_cell_{which}"] = v["traffic_bytes"] / nband
+            except Exception:
+                pass
         except Exception as e:
             out["band_stage"] = {"error": str(e)}
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes

@@ -2180,16 +2180,35 @@ int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, cons
     return int(hipGetLastError());
 }
 
-// min / max x over the active cells of a level (GridP::xlo / xhi)
+// min / max x over the active cells of a level (GridP::xlo / xhi); nx % 4 == 0: a thread takes 16 codes (four words) at a time
 __global__ __launch_bounds__(256) void activeXRangeKernel(const uint8_t *__restrict__ lab, int nx, size_t cells, int *__restrict__ range)
 {
     int lo = nx, hi = -1;
-    for (size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x; c < cells; c += size_t(gridDim.x) * blockDim.x)
-        if (activeLabel(lab[c])) {
-            const int i = int(c % size_t(nx));
-            lo = min(lo, i);
-            hi = max(hi, i);
+    const unsigned nq = unsigned(nx) >> 2;  // quads per row
+    const size_t quads = cells >> 2;
+    const unsigned *w = reinterpret_cast<const unsigned *>(lab);
+    for (size_t q0 = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4; q0 < quads; q0 += size_t(gridDim.x) * blockDim.x * 4) {
+        unsigned v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = q0 + m < quads ? w[q0 + m] : 0x01010101u;  // (EXTERIOR)
+        const unsigned iq = unsigned(q0 % nq);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (v[m] == 0x01010101u) continue;  // (four EXTERIOR cells: most of what lies outside the range)
+            unsigned any = 0xFu;                // (four INTERIOR cells: most of what lies inside)
+            if (v[m] != 0u) {
+                any = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) any |= activeLabel((v[m] >> (8 * e)) & 255u) ? (1u << e) : 0u;
+            }
+            if (any) {
+                unsigned qi = iq + m;
+                if (qi >= nq) qi -= nq;  // (at most one row wrap in four quads: nq >= 4 where this kernel runs)
+                lo = min(lo, int(4 * qi) + __ffs(any) - 1);
+                hi = max(hi, int(4 * qi) + 31 - __clz(any));
+            }
         }
+    }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
         lo = min(lo, __shfl_down(lo, off));
@@ -2202,9 +2221,9 @@ __global__ __launch_bounds__(256) void activeXRangeKernel(const uint8_t *__restr
 }
 int launchActiveXRange(void *stream, const uint8_t *lab, int nx, size_t cells, int *range)
 {
-    if (cells == 0) return 0;
-    const unsigned nb = unsigned(std::min<size_t>((cells + 255) / 256, 256 * 32));
-    activeXRangeKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(lab, nx, cells, range);
+    if (cells == 0 || (nx & 3) != 0 || nx < 16) return 0;
+    const unsigned nb = unsigned(std::min<size_t>((cells / 16 + 255) / 256, 256 * 32));
+    activeXRangeKernel<<<std::max(nb, 1u), 256, 0, static_cast<hipStream_t>(stream)>>>(lab, nx, cells, range);
     return int(hipGetLastError());
 }
 

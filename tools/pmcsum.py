@@ -54,7 +54,7 @@ def main(out, specs):
                 "dispatches": cnt[k],
             }
             res["kernels"][f"{k[0]}@{size}^3 grid={k[1]}"] = e
-            if re.match(r"stencil(Quad|Plane)Kernel<0(, *false)?(, *float)?>", k[0]) and (best is None or k[1] > best[0][1] or
+            if re.match(r"stencil(Quad|Plane)Kernel<0(, *false)?(, *float)?(, *false)?>", k[0]) and (best is None or k[1] > best[0][1] or
                                                                      (k[1] == best[0][1] and False)):
                 if best is None or e["traffic_bytes"] > best[1]["traffic_bytes"]:
                     best = (k, e)
