@@ -380,6 +380,11 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
 // closure and on the cells next to it.  Levels that take the quad or the plane sweep (stencilKernelOf != 3)
 int launchZeroSweepResidual(void *stream, const GridP &g, float *xout, float *rout, const float *b, float omega);
 int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, const float *x, const float *b, float *r);
+// The closure launch and the sweep of a stroke as one launch (levels that take the quad sweep; x == nullptr: the zero iterate): the
+// sweep leaves the cells whose bit is set in `keep` alone (launchMarkClosure: the owned band / closure-output cells of the boxes, one
+// bit per cell, cells / 32 words zeroed by the caller), which the plain launch writes afterwards
+int launchStrokeFront(void *stream, const GridP &g, const BandBoxesDev &bx, float *out, const float *x, const float *b, float *snap, float omega, const uint32_t *keep);
+int launchMarkClosure(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits);
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half = false);
 // one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
 // that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the

@@ -188,42 +188,46 @@ __device__ __forceinline__ unsigned remapBlock(unsigned bid, unsigned nblocks)
 // The quad (4 cells) this thread owns in share `block` of a level's activity list -- the list entries are runs of
 // chunkCells consecutive cells that hold an active cell: 1024 = one entry per workgroup, 256 = one per wavefront, 64 / 32 =
 // one per 16 / 8 lanes (free surfaces that cut the x-rows: most of a 256-cell run would be air).  false: list padding (-1).
-__device__ __forceinline__ bool listQuad(const int32_t *__restrict__ chunks, int chunkCells, size_t block, size_t &t)
+// (tid: the thread's index in its 256-thread share -- threadIdx.x, except in kernels whose workgroups take several shares)
+__device__ __forceinline__ bool listQuad(const int32_t *__restrict__ chunks, int chunkCells, size_t block, size_t &t, unsigned tid)
 {
     if (chunkCells == kChunkCells) {
-        t = size_t(chunks[block]) * 256 + threadIdx.x;
+        t = size_t(chunks[block]) * 256 + tid;
         return true;
     }
     int ch;
     if (chunkCells == kWaveChunkCells) {  // wave-uniform index: a scalar load
-        ch = chunks[block * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-        t = size_t(max(ch, 0)) * kWave + (threadIdx.x & (kWave - 1));
+        ch = chunks[block * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)];
+        t = size_t(max(ch, 0)) * kWave + (tid & (kWave - 1));
     } else {
         const int lanes = chunkCells >> 2, shift = __ffs(lanes) - 1;  // 16 or 8 lanes per run
-        ch = chunks[(block << (8 - shift)) + (threadIdx.x >> shift)];
-        t = (size_t(max(ch, 0)) << shift) + (threadIdx.x & (lanes - 1));
+        ch = chunks[(block << (8 - shift)) + (tid >> shift)];
+        t = (size_t(max(ch, 0)) << shift) + (tid & (lanes - 1));
     }
     return ch >= 0;
 }
+__device__ __forceinline__ bool listQuad(const int32_t *__restrict__ chunks, int chunkCells, size_t block, size_t &t) { return listQuad(chunks, chunkCells, block, t, threadIdx.x); }
 // lanes whose x-neighbour quad lives in another lane's registers: all but the ends of a run
 __device__ __forceinline__ int listRunMask(const int32_t *chunks, int chunkCells) { return (chunks && chunkCells < kWaveChunkCells) ? (chunkCells >> 2) - 1 : kWave - 1; }
 
 // XZERO: the iterate is known to be zero everywhere (the first sweep of a stroke that starts from the cleared grid, MG.cpp:439-440 /
 // 566): nothing of x is loaded and nobody had to clear it
-template <int OP, bool DOT = false, class TX = float, bool XZERO = false>
-__global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
-                                                          const float *__restrict__ b, float omega, unsigned nblocks,
-                                                          const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr,
-                                                          MixScale ms = MixScale{})
+// The body serves two kernels: stencilQuadKernel (a 256-thread workgroup = one share `vblock` of the launch) and strokeFrontKernel
+// (1024-thread workgroups, four shares each).  KEEP: `keep` holds one bit per cell, set = this launch must not write the cell
+// (strokeFrontKernel: the band closure, which the band boxes own)
+template <int OP, bool DOT, class TX, bool XZERO, bool KEEP>
+__device__ __forceinline__ void stencilQuadBody(const GridP &g, TX *__restrict__ out, const TX *__restrict__ x, const float *__restrict__ b, float omega,
+                                                unsigned nblocks, const int32_t *__restrict__ chunks, double *__restrict__ dotPartials, const MixScale &ms,
+                                                unsigned vblock, unsigned tid, const uint32_t *__restrict__ keep)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     const unsigned nq = unsigned(g.nx) >> 2;  // quads per row
     const size_t rows = size_t(g.ny) * g.nz;
     const size_t totalQuads = size_t(nq) * rows;
-    const unsigned block = remapBlock(blockIdx.x, nblocks);
-    size_t t = size_t(block) * blockDim.x + threadIdx.x;
+    const unsigned block = remapBlock(vblock, nblocks);
+    size_t t = size_t(block) * 256 + tid;
     bool valid = true;
-    if (chunks) valid = listQuad(chunks, g.chunkCells, block, t);  // only the runs that hold active cells
+    if (chunks) valid = listQuad(chunks, g.chunkCells, block, t, tid);  // only the runs that hold active cells
     valid = valid && t < totalQuads;
     const size_t tt = valid ? t : totalQuads - 1;
     const unsigned q = unsigned(tt % nq);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
     const bool ld = live && !XZERO;
 
     // x neighbours across the quad boundary
-    const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
+    const int runMask = listRunMask(chunks, g.chunkCells), lane = tid & runMask;
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
     if (ld) {
@@ -282,17 +286,31 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
         if (kMixed) res[e] = simpleCell(ls[e]) ? epilogueMix<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega, bm, ms.c2) : inactiveValue<OP>(xs[e + 1]);
         else res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
     }
-    if (valid) {
+    unsigned skip = 0;  // cells of this quad the launch leaves alone
+    if (KEEP && valid) skip = (keep[c >> 5] >> (c & 31)) & 15u;
+    if (valid && !skip) {
         if (g.streaming) Cell<TX>::store4nt(out + c, make_float4(res[0], res[1], res[2], res[3]));
         else Cell<TX>::store4(out + c, make_float4(res[0], res[1], res[2], res[3]));
+    } else if (KEEP && valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(skip & (1u << e))) Cell<TX>::store1(out + c + e, res[e]);
     }
     if (DOT) {  // general BOUNDARY cells add theirs in boundaryOpKernel
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (valid && simpleCell(ls[e])) acc += dotTerm<OP>(xs[e + 1], bs[e], kMixed ? __half2float(toHalfSat(res[e])) : res[e]);  // (the value as stored)
-        blockDotStore(acc, dotPartials, blockIdx.x);
+        blockDotStore(acc, dotPartials, vblock);
     }
+}
+template <int OP, bool DOT = false, class TX = float, bool XZERO = false>
+__global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict__ out, const TX *__restrict__ x,
+                                                          const float *__restrict__ b, float omega, unsigned nblocks,
+                                                          const int32_t *__restrict__ chunks, double *__restrict__ dotPartials = nullptr,
+                                                          MixScale ms = MixScale{})
+{
+    stencilQuadBody<OP, DOT, TX, XZERO, false>(g, out, x, b, omega, nblocks, chunks, dotPartials, ms, blockIdx.x, threadIdx.x, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1092,11 +1110,12 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
 
 // XZERO (closure mode): src is zero everywhere (see stencilQuadKernel): no value of it is loaded
-template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
-__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
-                                                              TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                                              const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
-                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
+// (the body: bandBoxKernel runs group remapBlock(blockIdx.x), strokeFrontKernel its first workgroups)
+template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO>
+__device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+                                            TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                            const int32_t *__restrict__ general, float omega, int depth, const MixScale &ms,
+                                            double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned group, unsigned slot)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
@@ -1105,7 +1124,7 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
     __shared__ float gbv[kGenRows];
     __shared__ uint16_t gnode[kGenRows], gring[kGenRows];  // region cell and ring
     // the group's description is wave-uniform: scalar registers (addresses below: scalar base + one 32-bit vector offset)
-    const int32_t *gip = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
+    const int32_t *gip = info + kBoxInfoInts * size_t(group);
     int gi[kBoxInfoInts];
 #pragma unroll
     for (int q = 0; q < kBoxInfoInts; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
@@ -1233,7 +1252,51 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
             if (CLOSURE && snap) wr(snap, c, v);
         }
     }
-    if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
+    if (DOT) blockDotStore(acc, dotPartials, slot);
+}
+template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
+__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+                                                              TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                              const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
+                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
+{
+    bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, general, omega, depth, ms, dotPartials, dotOld, outClosure,
+                                              remapBlock(blockIdx.x, gridDim.x), blockIdx.x);
+}
+
+// The front of a smoothing stroke in ONE launch: the closure launch of the band boxes (workgroups [0, ngroups)) and the sweep
+// (the rest; a workgroup = four 256-thread shares of stencilQuadKernel).  The two are independent once the sweep leaves the band
+// closure alone -- the closure launch writes only the snapshot, and the plain launch that follows writes band and closure cells
+// of the sweep's output whatever the sweep put there: `keep` (one bit per cell: owned band / closure-output cell of some box)
+// masks the sweep's stores, so the plain launch no longer has to come after the sweep's stores to those cells.  For levels
+// whose launches are latency chains (a closure launch of a 64^3 level is ~6 us whatever it does): one chain instead of two.
+template <bool GEN, bool XZERO>
+__global__ __launch_bounds__(kBoxThreads, 8) void strokeFrontKernel(GridP g, float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ b,
+                                                                  float *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                                  const int32_t *__restrict__ general, float omega, int depth, unsigned ngroups,
+                                                                  unsigned nshares, const int32_t *__restrict__ chunks, const uint32_t *__restrict__ keep)
+{
+    if (blockIdx.x < ngroups) {
+        bandBoxBody<float, true, false, GEN, XZERO>(g, x, b, nullptr, snap, info, list, general, omega, depth, MixScale{}, nullptr, nullptr, 0,
+                                                    remapBlock(blockIdx.x, ngroups), 0u);
+        return;
+    }
+    const unsigned share = (blockIdx.x - ngroups) * (kBoxThreads / 256) + (threadIdx.x >> 8);
+    if (share < nshares) stencilQuadBody<OP_JACOBI, false, float, XZERO, true>(g, out, x, b, omega, nshares, chunks, nullptr, MixScale{}, share, threadIdx.x & 255u, keep);
+}
+// keep bits of a level: the owned band and closure-output cells of its boxes
+__global__ __launch_bounds__(256) void markClosureKernel(GridP g, const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint32_t *__restrict__ bits)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, origin = size_t(gi[0]);
+    const uint32_t *U = list + gi[2];
+    for (int k = threadIdx.x; k < gi[7]; k += 256) {
+        const uint32_t e = U[k];
+        const unsigned cls = (e >> 16) & 15u;
+        if ((e >> 20) != 0u || !(boxBand(cls) || cls == kBoxFrozenOut)) continue;
+        const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
+        atomicOr(bits + (c >> 5), 1u << (c & 31));
+    }
 }
 
 // dst = src on the band cells of every owned box
@@ -2438,6 +2501,34 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
                                       dotPartials, static_cast<const __half *>(dotOld), outClosure ? 1 : 0);
     return launchBandBoxT<float>(s, g, bx, closure, static_cast<const float *>(src), b, static_cast<float *>(dst), static_cast<float *>(snap), omega, ms,
                                  dotPartials, static_cast<const float *>(dotOld), outClosure ? 1 : 0);
+}
+// closure launch + sweep of a stroke in one launch (strokeFrontKernel): levels that take the quad sweep, fp32, no gathered dot.
+// x == nullptr: the zero iterate.  keep: launchMarkClosure's bits
+int launchStrokeFront(void *stream, const GridP &g, const BandBoxesDev &bx, float *out, const float *x, const float *b, float *snap, float omega, const uint32_t *keep)
+{
+    if (bx.ngroups <= 0 || stencilKernelOf(g) != 1 || !keep || !snap || !out || out == snap) return int(hipErrorInvalidValue);  // (g with its general rows: the boxes read them; the sweep's general cells are band cells, left to the boxes)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    const bool list = g.chunks != nullptr;
+    const unsigned nshares = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
+    const unsigned ng = unsigned(bx.ngroups), nb = ng + (nshares + kBoxThreads / 256 - 1) / (kBoxThreads / 256);
+    const int32_t *chunks = list ? g.chunks : nullptr;
+#define MGPS_FRONT(G, Z) strokeFrontKernel<G, Z><<<nb, kBoxThreads, 0, s>>>(g, out, x, b, snap, bx.info, bx.list, bx.general, omega, bx.depth, ng, nshares, chunks, keep)
+    if (bx.anyGeneral) {
+        if (x) MGPS_FRONT(true, false);
+        else MGPS_FRONT(true, true);
+    } else {
+        if (x) MGPS_FRONT(false, false);
+        else MGPS_FRONT(false, true);
+    }
+#undef MGPS_FRONT
+    return int(hipGetLastError());
+}
+int launchMarkClosure(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits)
+{
+    if (bx.ngroups <= 0) return 0;
+    markClosureKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(g, bx.info, bx.list, bits);
+    return int(hipGetLastError());
 }
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half)
 {

@@ -67,6 +67,7 @@ struct DevLevel {
     uint32_t *nearBand = nullptr;
     float *stage = nullptr;
     uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
+    uint32_t *keepBits = nullptr;   // launchStrokeFront: one bit per cell, the owned band / closure-output cells of the boxes (made on first use)
     // fused band stage of a cut level (SlabHalo): one exchange per stage
     struct Halo {
         int depth = 0;
@@ -433,6 +434,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.bandBoxes.list);
         (void)cacheFree(L.nearBand);
         (void)cacheFree(L.planeFlags);
+        (void)cacheFree(L.keepBits);
         gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
@@ -772,6 +774,26 @@ int zeroStrokeWithResidual(mgps_solver *h, int l, float *&cur, float *&other, co
     return MGPS_OK;
 }
 
+// The closure launch and the sweep of a stroke in one launch (launchStrokeFront): whole-grid levels that take the quad sweep, up to
+// MGPS_FRONT_MAX_CELLS cells (default 2^24 = a 256^3 level; 0 = off) -- where a launch is a latency chain, one chain instead of two
+bool strokeFrontMerges(const mgps_solver *h, int l)
+{
+    static const size_t maxCells = [] {
+        const char *e = getenv("MGPS_FRONT_MAX_CELLS");
+        return e ? size_t(std::max(0ll, atoll(e))) : (size_t(1) << 24);
+    }();
+    const DevLevel &L = h->lv[l];
+    return !h->dist && L.d.cells() <= maxCells && stencilKernelOf(L.g) == 1 && (L.d.cells() & 31) == 0;  // (512^3 level: 618-629 -> 565-593 cycles/s merged)
+}
+int ensureKeepBits(mgps_solver *h, int l)
+{
+    DevLevel &L = h->lv[l];
+    if (L.keepBits) return MGPS_OK;
+    MGPS_TRY(devAlloc(h, &L.keepBits, L.d.cells() / 32, true));
+    MGPS_LAUNCH(h, launchMarkClosure(h->stream, L.g, L.bandBoxes, L.keepBits));
+    return MGPS_OK;
+}
+
 // 3 x band Jacobi -> full-domain smoother -> 3 x band Jacobi (MG.cpp:445-513 down, 806-879 up).
 // The smoother runs options.pre_sweeps (down) / post_sweeps (up) times; the reference's count is one.
 // Jacobi runs out of place: `cur` holds the current iterate, `other` the spare grid; they swap.
@@ -797,6 +819,13 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         const bool timed = h->profiling && l == 0;
         double *sinkB = nullptr;
         const float *src = xZero ? nullptr : cur;
+        if (!dot && !timed && !stageTimingOn(h) && strokeFrontMerges(h, l)) {  // (stage timers and the sweep timer want the launches apart)
+            MGPS_TRY(ensureKeepBits(h, l));
+            MGPS_LAUNCH(h, launchStrokeFront(h->stream, L.g, L.bandBoxes, other, src, b, L.r, h->opt.jacobi_weight, L.keepBits));
+            std::swap(cur, other);
+            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, nullptr, nullptr, true));
+            return MGPS_OK;
+        }
         {
             StageScope scope(h, ST_BAND, l);
             MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, src, b, nullptr, L.r, h->opt.jacobi_weight));

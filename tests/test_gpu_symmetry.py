@@ -190,15 +190,17 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880")])
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
-    """Two switches that must not change a single bit of the answer, each on (1) against off (0):
+    """Switches that must not change a single bit of the answer, each on against off:
     MGPS_FUSE_DOWN (opt-in) -- the down-stroke from the zero iterate with the residual in the same pass
     (launchZeroSweepResidual + launchBoxResidual) against zero-start sweep, band boxes, separate residual pass: the same
     expressions in the same order;
     MGPS_X_RANGE (default on) -- sweeps leave the quads outside the level's active x range alone (GridP::xlo: the EXTERIOR
     padding of the power-of-two expansion) against visiting whole runs / blocks;
     (plane880: 880 active cells of a 1024-cell row; the sweep must visit fewer cells with the range on.)
+    MGPS_FRONT_MAX_CELLS (default 2^24) -- the closure launch of the band boxes and the sweep of a stroke as ONE launch
+    (launchStrokeFront: the sweep's stores masked on the band closure) on every level against three launches per stroke.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
@@ -242,7 +244,7 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
     with tempfile.TemporaryDirectory() as tmp:
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
-            env = dict(os.environ, **{switch: fuse})
+            env = dict(os.environ, **{switch: {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else fuse})
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
