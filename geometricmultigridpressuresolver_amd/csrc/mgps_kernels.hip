@@ -2254,7 +2254,7 @@ __global__ __launch_bounds__(256) void activeXRangeKernel(const uint8_t *__restr
         unsigned v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = q0 + m < quads ? w[q0 + m] : 0x01010101u;  // (EXTERIOR)
-        const unsigned iq = unsigned(q0 % nq);
+        const unsigned iq = quads <= 0xffffffffull ? unsigned(q0) % nq : unsigned(q0 % nq);  // (a 64-bit remainder costs a hundred instructions)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (v[m] == 0x01010101u) continue;  // (four EXTERIOR cells: most of what lies outside the range)
