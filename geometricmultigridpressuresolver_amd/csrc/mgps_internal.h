@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstddef>
 #include <memory>
 #include <string>
@@ -322,7 +323,12 @@ inline int planeSweepZc(int nx, int ny, int nz)
 {
     if ((nx & 3) != 0 || nx < 256 || ny < kPlaneRows) return 0;
     const size_t nbx = (nx + 255) / 256, nby = (ny + kPlaneRows - 1) / kPlaneRows;
-    int zc = 32;  // fewer planes per workgroup on small grids so that the launch still fills 256 CUs
+    static const int zcTop = [] {  // MGPS_PLANE_ZC=N: planes per block on large levels (tuning runs)
+        const char *e = getenv("MGPS_PLANE_ZC");
+        const int v = e ? atoi(e) : 0;
+        return v >= 4 && v <= 256 ? v : 32;
+    }();
+    int zc = zcTop;  // fewer planes per workgroup on small grids so that the launch still fills 256 CUs
     while (zc > 4 && nbx * nby * size_t((nz + zc - 1) / zc) < 1024) zc >>= 1;
     return zc;
 }
