@@ -616,6 +616,7 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
                 r.simple &= (w[q] == 1.f);
             }
         }
+        r.simple = r.simple && r.diag >= 1.f;  // (no open face: a general row, see evalRow in mgps_setup.hip)
         return r;
     };
     // band of the slab in reference order, then split: general BOUNDARY cells first, the rest after.  Ranges of the

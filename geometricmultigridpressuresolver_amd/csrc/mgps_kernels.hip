@@ -2983,7 +2983,7 @@ __global__ void boundaryRowsKernel(Dims d, const uint8_t *__restrict__ lab, cons
 #pragma unroll
     for (int q = 0; q < 6; ++q) o[q] = r[q];
     o[6] = diag;
-    o[7] = simple ? 1.f : 0.f;
+    o[7] = (simple && diag >= 1.f) ? 1.f : 0.f;  // (no open face: a general row, see evalRow in mgps_setup.hip)
     if (!ruleOk) atomicAdd(violations, 1);
 }
 

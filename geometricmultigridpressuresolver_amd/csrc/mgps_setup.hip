@@ -449,6 +449,9 @@ __device__ __forceinline__ RowEval evalRow(const Dims &d, const uint8_t *__restr
         } else
             r.ruleOk = true;
     }
+    // a liquid cell without an open face (diagonal 0; the reference asserts diagonal > 0, Ops.h:354) is no simple cell: "simple with
+    // diagonal 0" would read as "general" in the band diagonals.  As a general row it divides by zero like the reference's release build
+    r.simple = r.simple && r.diag >= 1.f;
     return r;
 }
 
