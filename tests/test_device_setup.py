@@ -284,7 +284,7 @@ def random_domain(shape, levels, seed, closed_faces=True):
     return lab, w
 
 
-@pytest.mark.parametrize("shape,levels", [((24, 40, 56), 2), ((48, 64, 32), 3), ((64, 64, 96), 3)])
+@pytest.mark.parametrize("shape,levels", [((24, 40, 56), 2), ((48, 64, 32), 3), ((64, 64, 96), 3), ((32, 96, 200), 3)])
 @pytest.mark.parametrize("seed", [3, 4] + list(range(100, 100 + int(__import__("os").environ.get("MGPS_FUZZ_SEEDS", "0")))))
 def test_random_domain_cycles_match_oracle(shape, levels, seed, oracle):
     """The same random domains through the solve: a V-cycle from zero, one from that guess, and a short MG-PCG (whose
