@@ -49,14 +49,19 @@ def gpu_mode():
     torch.cuda.set_device(0)
     # liquid must straddle every slab cut, otherwise the exchanges carry nothing
     for kind, g, levels, shape in (("solid", 96, 5, (128, 128, 128)), ("simple", 40 if size == 2 else 48, 4, (64, 64, 64)),
-                                   ("scene", 48, 4, (64, 64, 64))):
+                                   ("scene", 48, 4, (64, 64, 64)), ("random", 0, 3, (64, 64, 96))):
         if kind == "scene":  # a seeded projection scene (wavy free surface, cut-cell box): general cells near the cuts
             lab, w, off, lev, dx = scene_domain(g, levels, shape)
+        elif kind == "random":  # blobs of every label, fractional weights everywhere (tests/test_device_setup.py): general cells in every group across the cuts
+            from test_device_setup import random_domain
+
+            lab, w = random_domain(shape, levels, 4, closed_faces=False)
+            off, lev, dx = 0, levels, 1.0 / shape[2]
         else:
             lab, w, off, lev, dx = make_domain(kind, g, levels, shape)
         nz = lab.shape[0]
         cuts = [D.active_mask(lab[c - 1 : c + 1]).any() for c in range(nz // size, nz, nz // size)]
-        assert all(cuts) or (kind == "scene" and any(cuts))
+        assert all(cuts) or (kind in ("scene", "random") and any(cuts))
         nzl = nz // size
         z0, z1 = rank * nzl, (rank + 1) * nzl
         slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
@@ -90,7 +95,7 @@ def gpu_mode():
                 err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
                 assert err < 1e-6, (kind, use_gs, it, err)
             # MG-PCG
-            bd = D.delta_rhs(lab, g, off, dx) if kind != "scene" else D.random_rhs(lab, dx, seed=9)
+            bd = D.delta_rhs(lab, g, off, dx) if kind not in ("scene", "random") else D.random_rhs(lab, dx, seed=9)
             xw, xs = whole.new_grid(), slab.new_grid()
             sw = whole.solveGeometricConjugateGradient(xw, whole.to_device(bd), 1e-5, 200, True)
             ss = slab.solveGeometricConjugateGradient(xs, slab.to_device(bd[z0:z1]), 1e-5, 200, True)
