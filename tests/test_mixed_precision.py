@@ -158,3 +158,30 @@ def test_config5_512_free_surface_mixed(record_property):
         record_property(k, v)
     print("config 5:", report)
     assert sm["solve_ms"] < 1.15 * sf["solve_ms"]  # no slower than fp32 beyond box noise; the gain is reported, not assumed
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_mixed_vcycle_on_a_random_domain(seed, oracle):
+    """Blobs of every label and fractional face weights everywhere (tests/test_device_setup.py: random_domain): general BOUNDARY
+    rows in every band box, liquid ending anywhere in a row; one mixed-precision cycle against the fp64 oracle at the stated
+    tolerance, both smoothers (by seed)."""
+    from geometricmultigridpressuresolver_amd import domains as D
+    from test_device_setup import random_domain
+
+    shape, levels = (64, 64, 96), 3
+    lab, w = random_domain(shape, levels, seed, closed_faces=False)
+    use_gs = bool(seed & 1)
+    f32, mix = _solvers(lab, w, levels, use_gs)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, use_gs)
+    b = D.random_rhs(lab, 1.0 / shape[2], seed=seed).astype(np.float32)
+    x_ref = np.zeros(lab.shape)
+    orc.apply_vcycle(x_ref, b.astype(np.float64), False)
+    xm = mix.new_grid()
+    mix.applyVCycle(xm, mix.to_device(b), False)
+    x = xm.cpu().numpy()
+    assert np.isfinite(x).all() and rel_l2(x, x_ref) < MIXED_VCYCLE_TOL
+    zm = mix.new_grid()
+    st = mix.solveGeometricConjugateGradient(zm, mix.to_device(b), 1e-5, 200, True)
+    assert st["outcome"] == "converged"
+    mix.close()
+    f32.close()
