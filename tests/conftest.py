@@ -41,6 +41,12 @@ def make_domain(kind, g, levels=None, solver_shape=None, dtype=np.float32):
     """kind in {'simple', 'complex', 'solid'} -> (labels uint8, weights[3], offset, levels, dx)."""
     from geometricmultigridpressuresolver_amd import domains as D
 
+    if kind == "random":  # blobs of every label, fractional weights everywhere (g = the seed): general rows in every band box, ragged rows
+        from test_device_setup import random_domain
+
+        shape, lev = (64, 64, 96), 3
+        lab, w = random_domain(shape, lev, g, closed_faces=False)
+        return lab, [a.astype(dtype) for a in w], 0, lev, 1.0 / shape[2]
     if kind == "wide":  # non-cubic free-surface box, 256 cells along x (one wavefront per row; with options.stencil_path = 2: the plane-marching sweep)
         bl, bw, dx = D.build_complex_domain((g, g, 248), dtype=dtype)
     elif kind == "widesolid":  # free surface + cut-cell solid box, 264 x 40 x 32 solver grid: ragged in x (256 + 8) and y (2 x 16 + 8)

@@ -49,7 +49,7 @@ def _rand_active(lab, seed, scale=1.0):
     return v
 
 
-DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24), ("odd", 36)]
+DOMAINS = [("simple", 32), ("complex", 32), ("solid", 48), ("wide", 24), ("odd", 36), ("random", 4)]
 
 
 def _wide_args(kind):
