@@ -350,3 +350,38 @@ def test_liquid_cell_without_an_open_face_is_a_general_row(domain_factory):
     finally:
         for s in solvers:
             s.close()
+
+
+@pytest.mark.parametrize("seed", [3, 4] + list(range(100, 100 + int(__import__("os").environ.get("MGPS_FUZZ_SEEDS", "0")))))
+def test_random_domain_through_the_plane_marching_sweep(seed, oracle):
+    """The random domains with the plane-marching sweep forced (options.stencil_path = 2; by size it only takes levels whose
+    x-y planes exceed 2 MiB): rows that are part liquid, part air, part solid inside its 256 x 16 tiles, the active x range,
+    two planes of look-ahead -- V-cycles and a short MG-PCG against the fp64 oracle."""
+    from conftest import rel_l2
+
+    shape, levels = (32, 64, 256), 3
+    lab, w = random_domain(shape, levels, seed, closed_faces=False)
+    o = G.default_options()
+    o.stencil_path = 2
+    try:
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, False, options=o)
+    except G.MgpsError:
+        pytest.skip("the random labels gave no valid hierarchy")
+    try:
+        assert gpu.stencil_kernel(0) == "plane"
+        orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, False)
+        b = D.random_rhs(lab, 1.0 / shape[2], seed=seed)
+        bd = gpu.to_device(b)
+        x, x_ref = gpu.new_grid(), np.zeros(lab.shape)
+        for it in range(2):
+            gpu.applyVCycle(x, bd, it > 0)
+            orc.apply_vcycle(x_ref, b.astype(np.float64), it > 0)
+            if not np.isfinite(x_ref).all() or not np.abs(x_ref).max() > 0:
+                pytest.skip("the oracle itself has no finite answer on this random domain")
+            assert rel_l2(x.cpu().numpy(), x_ref) < 2e-5, it
+        z, z_ref = gpu.new_grid(), np.zeros(lab.shape)
+        st = gpu.solveGeometricConjugateGradient(z, bd, 1e-5, 6, True)
+        so = orc.solve_pcg(z_ref, b.astype(np.float64), 1e-5, 6, True)
+        assert st["iterations"] == so["iterations"] and rel_l2(z.cpu().numpy(), z_ref) < 1e-4
+    finally:
+        gpu.close()
