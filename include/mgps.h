@@ -212,7 +212,10 @@ int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const floa
  * asserts unitTestExteriorCells per level, MG.cpp:235, 252), i.e. the solver grid needs at least 2^(mg_levels-1)
  * EXTERIOR cells on every side -- what buildExpandedCellLabels / mgps_expanded_layout pad (Ops.h:1347-1351); labels
  * that break it are refused with MGPS_ERR_HIERARCHY.  use_gauss_seidel selects the tile-coloured Gauss-Seidel smoother (the plugin
- * hard-wires it on, Plug.cpp:466); 0 selects damped Jacobi. */
+ * hard-wires it on, Plug.cpp:466); 0 selects damped Jacobi.
+ * Weights contract: every liquid cell needs an open face (a diagonal > 0; the reference asserts it, Ops.h:354).  A cell without one
+ * is accepted -- it becomes an operator row with diagonal 0 and divides by zero in every smoother, as in the reference's release
+ * build -- and poisons the result with inf / NaN; nothing else depends on it (no index, no list). */
 int mgps_create(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels_host,
                 const float *wx_host, const float *wy_host, const float *wz_host, int mg_levels,
                 int use_gauss_seidel, const mgps_options *opt);
