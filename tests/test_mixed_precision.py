@@ -157,7 +157,7 @@ def test_config5_512_free_surface_mixed(record_property):
     for k, v in report.items():
         record_property(k, v)
     print("config 5:", report)
-    assert sm["solve_ms"] < 1.15 * sf["solve_ms"]  # no slower than fp32 beyond box noise; the gain is reported, not assumed
+    assert sm["solve_ms"] < 1.25 * sf["solve_ms"]  # measured 1.10 x fp32 (it does not pay); a bound against regressions, with room for box noise
 
 
 @pytest.mark.parametrize("seed", [3, 4])
