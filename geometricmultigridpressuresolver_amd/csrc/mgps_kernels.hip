@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
     const int I = int(bx) * 64 + int(threadIdx.x & 63), J = 2 * (int(by) * 4 + int(threadIdx.x >> 6));
     const int K0 = int(bz) * kc, K1 = min(K0 + kc, cg.nz);
-    if (I >= cg.nx || J >= cg.ny) return;
+    if (I >= cg.nx || J >= cg.ny || I < cg.xlo || I >= cg.xhi) return;  // (columns outside the coarse level's active x range hold no active cell)
     const bool second = J + 1 < cg.ny;
     const size_t cplane = size_t(cg.nx) * cg.ny, col = size_t(J) * cg.nx + I;
     bool any = false;
@@ -1812,6 +1812,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, TX *__res
     const size_t t = size_t(remapBlock(blockIdx.x, nblocks)) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const unsigned m = unsigned(t % nq);
+    if (int(4 * m) < fg.xlo || int(4 * m) >= fg.xhi) return;  // (outside the level's active x range: nothing to add to, not even codes to read)
     const size_t rest = t / nq;
     const int jp = int(rest % unsigned(npj)), kp = kp0 + int(rest / unsigned(npj));
     const int js[2] = {2 * jp + 1, 2 * jp + 2}, ks[2] = {2 * kp + 1, 2 * kp + 2};
