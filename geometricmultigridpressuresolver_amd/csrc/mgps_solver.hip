@@ -855,16 +855,31 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, cur, true));
         return MGPS_OK;
     }
-    {
+    const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
+    // Several Jacobi sweeps per stroke (options.pre_sweeps / post_sweeps > 1, BASELINE config 1's "2 + 2") on a level with boxes: the
+    // first band stage and the first sweep as above -- sweep over the un-smoothed grid, then the closure launch writes what the
+    // sweep should hold on the band closure straight into its output (no snapshot: the next sweep reads the grid) -- two launches
+    // instead of three (band stage out of place, copy, sweep); the remaining sweeps and the last band stage as below
+    const bool firstFused = bands && !h->useGS && reps > 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r && !(h->profiling && l == 0);
+    if (firstFused) {
+        {
+            StageScope scope(h, ST_SMOOTH, l);
+            GridP gs = L.g;
+            gs.nbnd = 0;
+            MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, cur, b, h->opt.jacobi_weight, true));
+        }
+        StageScope scope(h, ST_BAND, l);
+        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, cur, b, other, nullptr, h->opt.jacobi_weight));
+        std::swap(cur, other);
+    } else {
         StageScope scope(h, ST_BAND, l);
         MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
     }
     // after the band passes only band cells are stale across the cut -- unless there were none
     const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
-    const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
     bool split = false;  // the last sweep went edge first: the band stage after it overlaps its message with the sweep's interior
-    for (int rep = 0; rep < reps; ++rep) {
+    for (int rep = firstFused ? 1 : 0; rep < reps; ++rep) {
         StageScope scope(h, ST_SMOOTH, l);
         const GhostMode before = rep == 0 ? afterBands : GHOST_FULL;  // a sweep rewrote everything
         const bool d = dot && rep == reps - 1;  // <x, b> of the stroke's result: the last sweep's values
