@@ -860,13 +860,19 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     // first band stage and the first sweep as above -- sweep over the un-smoothed grid, then the closure launch writes what the
     // sweep should hold on the band closure straight into its output (no snapshot: the next sweep reads the grid) -- two launches
     // instead of three (band stage out of place, copy, sweep); the remaining sweeps and the last band stage as below
-    const bool firstFused = bands && !h->useGS && reps > 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r && !(h->profiling && l == 0);
+    const bool firstFused = bands && !h->useGS && reps > 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r;
     if (firstFused) {
         {
             StageScope scope(h, ST_SMOOTH, l);
             GridP gs = L.g;
             gs.nbnd = 0;
+            const bool timedFirst = h->profiling && l == 0;  // (the sweep is a launch of its own here: the sweep timer takes it)
+            if (timedFirst) MGPS_TRY(profMark(h, true));
             MGPS_LAUNCH(h, launchStencil(h->stream, OP_JACOBI, gs, other, cur, b, h->opt.jacobi_weight, true));
+            if (timedFirst) {
+                MGPS_TRY(profMark(h, false));
+                ++h->profSweeps;
+            }
         }
         StageScope scope(h, ST_BAND, l);
         MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, cur, b, other, nullptr, h->opt.jacobi_weight));
