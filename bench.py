@@ -364,7 +364,9 @@ def main():
             "frac_active": sweep_bytes * active_cells / t_sweep / 1e9 / HBM_PEAK_GBS,
             "frac_allocated": sweep_bytes * (float(n) * n * (z1 - z0)) / t_sweep / 1e9 / HBM_PEAK_GBS,
             "cells_active": active_cells,
-            "note": "per GPU; achieved = %g B x cells the launch visits (active runs only) / mean launch time (HIP events on the solver's stream)" % sweep_bytes,
+            "note": "per GPU; achieved = %g B x cells the launch visits (listed runs / blocks, inside the level's active x range: since round 3 the sweeps "
+                    "leave the EXTERIOR padding at the row ends alone, an eighth of every row on the BASELINE cubes, so the cell count is 12.5 %% below "
+                    "round 2's for the same grid) / mean launch time (HIP events on the solver's stream)" % sweep_bytes,
         },
     }
     # the band stage of the fine level (launchBandBox: closure + plain launch per stroke, two strokes per cycle): 16 B per band
