@@ -317,6 +317,7 @@ struct MixScale {
 };
 
 constexpr int kPlaneRows = 16;  // y extent of a plane-marching block (x extent 256)
+constexpr size_t kPlaneSweepMinPlaneBytes = size_t(4) << 20;  // levels whose x-y planes are larger take the plane-marching sweep by size (launchStencil)
 constexpr int kSlabEdgePlanes = kBandMaxDepth + 1;  // planes at either end of a slab whose sweep goes first: the band closure a stage message carries reaches band_iterations planes in, its face neighbours one more
 // does the plane-marching sweep apply to a level of this shape, and with how many planes per block
 inline int planeSweepZc(int nx, int ny, int nz)

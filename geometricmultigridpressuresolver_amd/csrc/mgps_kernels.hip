@@ -2166,10 +2166,14 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const int forced = forcedStencil(g);
     const int zc = g.planeZc;  // 0: the plane-marching sweep does not apply to this shape
-    // measured on MI355X (fine Jacobi sweep, plane vs quad kernel): 256^3 42.8 vs 40.8 us, 512^3 367 vs
+    // measured on MI355X (fine Jacobi sweep, plane vs quad kernel), round 1: 256^3 42.8 vs 40.8 us, 512^3 367 vs
     // 345 us, 1024^3 2.68 vs 2.95 ms -- the cache-only kernel wins while three x-y planes of x stay in an
-    // XCD's L2 share, the register/LDS-marching one beyond that (x-y plane > 2 MiB)
-    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
+    // XCD's L2 share, the register/LDS-marching one beyond that.  Round 3, after the quad kernel's loads were regrouped
+    // and both kernels leave the row-end padding alone: 1024^3 1.854 (plane) vs 1.823 ms (quad), cycle 95.9 vs 98.1
+    // per second -- the 256 MiB Infinity Cache holds the z neighbours of a 4 MiB plane.  The plane kernel keeps the
+    // levels whose x-y planes are LARGER than 4 MiB (kPlaneSweepMinPlaneBytes), and whatever options.stencil_path = 2 /
+    // MGPS_STENCIL=plane send to it
+    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > kPlaneSweepMinPlaneBytes;
     if (zc && (forced == 2 || (forced == 0 && planeWins))) {
         const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows;
         const unsigned nbz = (g.nz + zc - 1) / zc;
@@ -2297,7 +2301,7 @@ static unsigned sweepBlocks(const GridP &g, bool skipInactive, int *path)
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const int forced = forcedStencil(g);
     const int zc = g.planeZc;
-    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > (size_t(2) << 20);
+    const bool planeWins = size_t(g.nx) * g.ny * sizeof(float) > kPlaneSweepMinPlaneBytes;
     if (zc && (forced == 2 || (forced == 0 && planeWins))) {
         *path = 0;
         const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;

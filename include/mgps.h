@@ -102,7 +102,7 @@ typedef struct mgps_options {
        BASELINE config 1's "2+2 damped-Jacobi sweeps" is pre_sweeps = post_sweeps = 2 */
     int pre_sweeps, post_sweeps;
     /* which full-domain sweep kernel the Jacobi / residual / A.x passes use: 0 (default) = by size (the
-       plane-marching kernel where an x-y plane exceeds 2 MiB, i.e. 1024^2; the cache-served quad kernel below),
+       plane-marching kernel where an x-y plane exceeds 4 MiB, i.e. beyond 1024^2; the cache-served quad kernel up to there),
        1 = the quad kernel, 2 = the plane-marching kernel wherever its shape rule allows (nx >= 256, nx % 4 == 0,
        ny >= 16).  Same arithmetic per cell either way; for tuning and for parity tests of both kernels at small sizes */
     int stencil_path;

@@ -182,7 +182,7 @@ np.save(sys.argv[1], x.cpu().numpy())
     with tempfile.TemporaryDirectory() as tmp:
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npy")
-            env = dict(os.environ, MGPS_FUSE_PROLONG=fuse)
+            env = dict(os.environ, MGPS_FUSE_PROLONG=fuse, MGPS_STENCIL="plane")  # (a 4 MiB plane goes to the quad kernel by size since round 3)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     ref = np.abs(outs[1]).max()
@@ -245,6 +245,8 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
             env = dict(os.environ, **{switch: {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else fuse})
+            if case != "pool128":
+                env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
