@@ -347,7 +347,7 @@ def main():
         "stages_ms_per_cycle_fine_level": {k: v / max(stages["cycles"], 1) for k, v in stages.get("fine", {}).items()},
         "roofline": {
             "kernel": "fine-level tiled Gauss-Seidel sweep (tiledGSPureKernel + tiledGSMixedKernel, two colours)" if use_gs
-            else "fine-level damped-Jacobi sweep (%s<OP_JACOBI>)" % ("stencilPlaneKernel" if n >= 256 and n * n * 4 > (2 << 20) else "stencilQuadKernel"),
+            else "fine-level damped-Jacobi sweep (%s<OP_JACOBI>)" % ("stencilPlaneKernel" if solver.stencil_kernel(0) == "plane" else "stencilQuadKernel"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
