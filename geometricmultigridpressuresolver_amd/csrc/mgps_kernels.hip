@@ -1264,6 +1264,201 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const T
                                               remapBlock(blockIdx.x, gridDim.x), blockIdx.x);
 }
 
+// The same stage by PERSISTENT workgroups (round 4; two per CU, each walking the groups v = blockIdx.x, blockIdx.x + gridDim.x, ...)
+// with the loads of the next group in flight while the current one runs its passes.  A group is a chain of dependent round trips --
+// info -> list -> values -> H LDS passes -> stores -- and with 64 KB of LDS per group only two chains per CU are in flight
+// (rocprofv3, round 3: SQ_WAIT_ANY 66 %, 3.3 TB/s of a traffic that is 4.7 x the algorithmic bytes).  Here a workgroup holds, while
+// group i computes: the info of groups i + 1 and i + 2 (scalar registers), the list entries of group i + 1 (requested before
+// pass 1) and its values (requested after pass 1, once the entries are there) -- the memory side of group i + 1 hides behind
+// the LDS side of group i.  Same arithmetic, same order per cell: bit-equal to bandBoxKernel (MGPS_BOX_PIPE=0 is the A/B).
+struct BoxInfo {
+    int origin, rxy, listStart, genStart, ngen, nList;
+};
+__device__ __forceinline__ BoxInfo boxInfoLoad(const int32_t *__restrict__ info, unsigned v, unsigned ngroups)
+{
+    const bool valid = v < ngroups;
+    const int32_t *gip = info + kBoxInfoInts * size_t(remapBlock(valid ? v : ngroups - 1, ngroups));
+    BoxInfo I;
+    I.origin = __builtin_amdgcn_readfirstlane(gip[0]);
+    I.rxy = __builtin_amdgcn_readfirstlane(gip[1]);
+    I.listStart = __builtin_amdgcn_readfirstlane(gip[2]);
+    I.genStart = __builtin_amdgcn_readfirstlane(gip[4]);
+    I.ngen = valid ? __builtin_amdgcn_readfirstlane(gip[5]) : 0;
+    I.nList = valid ? __builtin_amdgcn_readfirstlane(gip[7]) : 0;  // (past the end: a group without entries -- its loads read the last group's origin cell and drop it)
+    return I;
+}
+template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
+__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxPipeKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+                                                                  TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                                  const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
+                                                                  double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned ngroups)
+{
+    constexpr bool kMixed = !std::is_same<TX, float>::value;
+    constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
+    __shared__ float val[2][kBoxMaxNodes];
+    __shared__ float grow[7][kGenRows];
+    __shared__ float gbv[kGenRows];
+    __shared__ uint16_t gnode[kGenRows], gring[kGenRows];
+    const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
+    const int H = depth + (CLOSURE ? 1 : 0);
+    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
+    const int tid = threadIdx.x;
+    const size_t nb = size_t(g.nbnd);
+    auto cellOf = [&](uint32_t e) { return (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz; };
+    auto rd = [&](const TX *base, unsigned c) { return Cell<TX>::load1(reinterpret_cast<const TX *>(reinterpret_cast<const char *>(base) + c * unsigned(sizeof(TX)))); };
+    auto rdf = [&](const float *base, unsigned c) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + c * 4u); };
+    auto wr = [&](TX *base, unsigned c, float v) { Cell<TX>::store1(reinterpret_cast<TX *>(reinterpret_cast<char *>(base) + c * unsigned(sizeof(TX))), v); };
+    // first batch of a group: its list entries (and this thread's general cell: list entry + row number)
+    auto loadList = [&](const BoxInfo &I, uint32_t (&ue)[kBoxSlots], uint32_t &ge, int32_t &grw) {
+        const uint32_t *U = list + I.listStart;
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const int k = tid + m * kBoxThreads;
+            ue[m] = k < I.nList ? U[k] : (uint32_t(kBoxSkip) << 16);
+        }
+        ge = 0;
+        grw = 0;
+        if (GEN && tid < I.ngen) {
+            ge = uint32_t(general[2 * size_t(I.genStart + tid)]);
+            grw = general[2 * size_t(I.genStart + tid) + 1];
+        }
+    };
+    // second batch: every value (unconditional loads: a cell that needs none reads the region's origin cell and drops it)
+    auto loadValues = [&](const BoxInfo &I, const uint32_t (&ue)[kBoxSlots], uint32_t ge, int32_t grw, float (&xv)[kBoxSlots], float (&bv)[kBoxSlots],
+                          float (&rw)[7], float &gb) {
+        const TX *s = XZERO ? nullptr : src + ptrdiff_t(I.origin);
+        const float *bb = b + ptrdiff_t(I.origin);
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const unsigned cls = (ue[m] >> 16) & 15u;
+            const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
+            const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
+            const unsigned c = cellOf(ue[m]);
+            xv[m] = XZERO ? 0.f : rd(s, need ? c : 0u);
+            bv[m] = rdf(bb, bneed ? c : 0u);
+        }
+        if (GEN) {
+            const bool mine = tid < I.ngen;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) rw[q] = g.rows[size_t(q) * nb + (mine ? grw : 0)];
+            gb = rdf(bb, mine ? cellOf(ge) : 0u);
+        }
+    };
+    const unsigned P = gridDim.x;
+    unsigned v = blockIdx.x;
+    BoxInfo cur = boxInfoLoad(info, v, ngroups), nxt = boxInfoLoad(info, v + P, ngroups);
+    uint32_t ue[kBoxSlots], ge;
+    int32_t grw;
+    float xv[kBoxSlots], bv[kBoxSlots], rw[7], gb = 0.f;
+    loadList(cur, ue, ge, grw);
+    loadValues(cur, ue, ge, grw, xv, bv, rw, gb);
+    for (; v < ngroups; v += P) {
+        const int rx = cur.rxy & 255, ry = (cur.rxy >> 8) & 255, sxy = rx * ry;
+        auto nodeOf = [&](uint32_t e) { return int(((e >> 10) & 31u) * unsigned(sxy) + ((e >> 5) & 31u) * unsigned(rx) + (e & 31u)); };
+        const int ngen = GEN ? cur.ngen : 0, nList = cur.nList;
+        // stage the current group's values
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            const unsigned cls = (ue[m] >> 16) & 15u;
+            if (cls == kBoxSkip || cls == kBoxZero) xv[m] = 0.f;
+            if (kMixed) bv[m] *= bm;
+            if (tid + m * kBoxThreads < nList) {
+                const int n = nodeOf(ue[m]);
+                val[0][n] = xv[m];
+                val[1][n] = xv[m];
+            }
+        }
+        if (GEN && tid < ngen) {
+            gring[tid] = uint16_t(ge >> 20);
+            gnode[tid] = uint16_t(nodeOf(ge));
+#pragma unroll
+            for (int q = 0; q < 7; ++q) grow[q][tid] = rw[q];
+            gbv[tid] = kMixed ? bm * gb : gb;
+        }
+        // the next group's entries leave now, the info of the one after it as well
+        uint32_t ueN[kBoxSlots], geN;
+        int32_t grwN;
+        loadList(nxt, ueN, geN, grwN);
+        const BoxInfo nn = boxInfoLoad(info, v + 2 * P, ngroups);
+        float xvN[kBoxSlots], bvN[kBoxSlots], rwN[7], gbN = 0.f;
+        __syncthreads();
+        auto pass = [&](int p) {
+            const float *from = val[(p - 1) & 1];
+            float *to = val[p & 1];
+            const int lim = H - p;
+            const bool last = CLOSURE && p == H;
+#pragma unroll
+            for (int m = 0; m < kBoxSlots; ++m) {
+                const unsigned cls = (ue[m] >> 16) & 15u;
+                const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
+                if ((simple && int(ue[m] >> 20) <= lim) || (last && cls == kBoxFrozenOut)) {
+                    const int n = nodeOf(ue[m]);
+                    const float xc = from[n];
+                    const float diag = cls == kBoxFrozenOut ? 6.f : float(int(cls) - int(kBoxSimple));
+                    const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
+                    to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
+                }
+            }
+            if (GEN && tid < ngen && int(gring[tid]) <= lim) {
+                const int nd = gnode[tid];
+                const float xc = from[nd];
+                float acc = 0.f;
+                acc -= grow[0][tid] * from[nd - 1];
+                acc -= grow[1][tid] * from[nd + 1];
+                acc -= grow[2][tid] * from[nd - rx];
+                acc -= grow[3][tid] * from[nd + rx];
+                acc -= grow[4][tid] * from[nd - sxy];
+                acc -= grow[5][tid] * from[nd + sxy];
+                const float diag = grow[6][tid];
+                const float lap = acc + diag * xc;
+                to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
+            }
+        };
+        pass(1);
+        loadValues(nxt, ueN, geN, grwN, xvN, bvN, rwN, gbN);  // (the entries were requested a pass ago)
+        __syncthreads();
+        for (int p = 2; p <= H; ++p) {
+            pass(p);
+            __syncthreads();
+        }
+        const float *fin = val[H & 1];
+        double acc = 0.0;
+        {
+            TX *d = dst ? dst + ptrdiff_t(cur.origin) : nullptr;
+            TX *sn = (CLOSURE && snap) ? snap + ptrdiff_t(cur.origin) : nullptr;
+#pragma unroll
+            for (int m = 0; m < kBoxSlots; ++m) {
+                const unsigned cls = (ue[m] >> 16) & 15u;
+                if ((ue[m] >> 20) == 0u && (boxBand(cls) || ((CLOSURE || outClosure) && cls == kBoxFrozenOut))) {
+                    const unsigned c = cellOf(ue[m]);
+                    const float r = fin[nodeOf(ue[m])];
+                    if (DOT) {
+                        const float stored = kMixed ? __half2float(toHalfSat(r)) : r;
+                        acc += (double(stored) - double(rd(dotOld + ptrdiff_t(cur.origin), c))) * double(rdf(b + ptrdiff_t(cur.origin), c));
+                    }
+                    if (d) wr(d, c, r);
+                    if (sn) wr(sn, c, r);
+                }
+            }
+        }
+        if (DOT) blockDotStore(acc, dotPartials, remapBlock(v, ngroups));
+        __syncthreads();  // (the next group's staging overwrites both copies)
+        cur = nxt;
+        nxt = nn;
+        ge = geN;
+        grw = grwN;
+        gb = gbN;
+#pragma unroll
+        for (int m = 0; m < kBoxSlots; ++m) {
+            ue[m] = ueN[m];
+            xv[m] = xvN[m];
+            bv[m] = bvN[m];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) rw[q] = rwN[q];
+    }
+}
+
 // The front of a smoothing stroke in ONE launch: the closure launch of the band boxes (workgroups [0, ngroups)) and the sweep
 // (the rest; a workgroup = four 256-thread shares of stencilQuadKernel).  The two are independent once the sweep leaves the band
 // closure alone -- the closure launch writes only the snapshot, and the plain launch that follows writes band and closure cells
@@ -2466,31 +2661,57 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
 }
 unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
 namespace {
+// persistent workgroups of the pipelined box kernel: two per CU (64 KB of LDS each)
+unsigned boxPipeGrid(unsigned ngroups)
+{
+    static const unsigned perDevice = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char *e = getenv("MGPS_BOX_PIPE_WG");  // (tuning runs: workgroups per launch)
+        const int v = e ? atoi(e) : 0;
+        return unsigned(v > 0 ? v : 2 * std::max(cus, 8)) & ~7u;  // a multiple of the XCD count: a workgroup stays in one chiplet's run of groups (remapBlock)
+    }();
+    return std::min(ngroups, perDevice);
+}
+bool boxPipeOn()
+{
+    static const bool on = [] {  // MGPS_BOX_PIPE=0: one workgroup per group (bandBoxKernel), the A/B
+        const char *e = getenv("MGPS_BOX_PIPE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 template <class TX>
 int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool closure, const TX *src, const float *b, TX *dst, TX *snap, float omega,
                    const MixScale &ms, double *dotPartials, const TX *dotOld, int outClosure)
 {
     const unsigned ng = unsigned(bx.ngroups);
     const bool dot = dotPartials != nullptr;
-#define MGPS_BOX_LAUNCH2(C, D, G) bandBoxKernel<TX, C, D, G><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure)
-#define MGPS_BOX_LAUNCH(C, D)                            \
-    do {                                                 \
-        if (bx.anyGeneral) MGPS_BOX_LAUNCH2(C, D, true); \
-        else MGPS_BOX_LAUNCH2(C, D, false);              \
+    const bool pipe = boxPipeOn() && ng > boxPipeGrid(ng);  // (a level with fewer groups than resident workgroups has nothing to pipeline)
+    const unsigned np = boxPipeGrid(ng);
+#define MGPS_BOX_LAUNCH3(C, D, G, Z)                                                                                                                                  \
+    do {                                                                                                                                                               \
+        if (pipe) bandBoxPipeKernel<TX, C, D, G, Z><<<np, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure, ng); \
+        else bandBoxKernel<TX, C, D, G, Z><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);          \
     } while (0)
-    if (closure && !src) {  // the iterate is zero everywhere
+#define MGPS_BOX_LAUNCH(C, D, Z)                               \
+    do {                                                       \
+        if (bx.anyGeneral) MGPS_BOX_LAUNCH3(C, D, true, Z);    \
+        else MGPS_BOX_LAUNCH3(C, D, false, Z);                 \
+    } while (0)
+    if (!src) {  // the iterate is zero everywhere
         if (dot) return int(hipErrorInvalidValue);
-        if (bx.anyGeneral) bandBoxKernel<TX, true, false, true, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);
-        else bandBoxKernel<TX, true, false, false, true><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);
+        if (closure) MGPS_BOX_LAUNCH(true, false, true);
+        else MGPS_BOX_LAUNCH(false, false, true);
     } else if (closure) {
-        if (dot) MGPS_BOX_LAUNCH(true, true);
-        else MGPS_BOX_LAUNCH(true, false);
+        if (dot) MGPS_BOX_LAUNCH(true, true, false);
+        else MGPS_BOX_LAUNCH(true, false, false);
     } else {
-        if (dot) MGPS_BOX_LAUNCH(false, true);
-        else MGPS_BOX_LAUNCH(false, false);
+        if (dot) MGPS_BOX_LAUNCH(false, true, false);
+        else MGPS_BOX_LAUNCH(false, false, false);
     }
 #undef MGPS_BOX_LAUNCH
-#undef MGPS_BOX_LAUNCH2
+#undef MGPS_BOX_LAUNCH3
     return int(hipGetLastError());
 }
 }  // namespace
@@ -2499,7 +2720,7 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
 {
     if (bx.ngroups <= 0) return 0;
     if (!dst && !(closure && snap)) return int(hipErrorInvalidValue);  // (dst == nullptr: the closure launch fills the snapshot only)
-    if ((src && src == dst) || (!src && !closure) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: zero everywhere, closure mode)
+    if ((src && src == dst) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: the iterate is zero everywhere, nothing is read and dst may be the iterate itself)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (half)
         return launchBandBoxT<__half>(s, g, bx, closure, static_cast<const __half *>(src), b, static_cast<__half *>(dst), static_cast<__half *>(snap), omega, ms,

@@ -190,7 +190,8 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128")])
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_BOX_PIPE", "pool128"),
+                                         ("MGPS_BOX_PIPE", "plane992")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
     MGPS_FUSE_DOWN (opt-in) -- the down-stroke from the zero iterate with the residual in the same pass
@@ -201,6 +202,8 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     (plane880: 880 active cells of a 1024-cell row; the sweep must visit fewer cells with the range on.)
     MGPS_FRONT_MAX_CELLS (default 2^24) -- the closure launch of the band boxes and the sweep of a stroke as ONE launch
     (launchStrokeFront: the sweep's stores masked on the band closure) on every level against three launches per stroke.
+    MGPS_BOX_PIPE (default on) -- the band boxes walked by persistent workgroups with the next group's loads in flight
+    (bandBoxPipeKernel; here with 8 workgroups, so that every one of them walks many groups) against one workgroup per group.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
@@ -247,6 +250,9 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
             env = dict(os.environ, **{switch: {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else fuse})
             if case != "pool128":
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
+            if switch == "MGPS_BOX_PIPE":
+                env["MGPS_BOX_PIPE_WG"] = "8"
+                env["MGPS_FRONT_MAX_CELLS"] = "0"  # (the merged front launch keeps the one-workgroup-per-group body)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
@@ -254,5 +260,5 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
         assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
     assert int(outs[0]["it"]) == int(outs[1]["it"])
-    if switch != "MGPS_FUSE_DOWN" and case != "pool128":
+    if switch == "MGPS_X_RANGE" and case != "pool128":
         assert int(outs[0]["swept"]) < int(outs[1]["swept"])  # (the switch was live: fewer cells visited with it on)
