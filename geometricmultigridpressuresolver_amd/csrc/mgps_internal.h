@@ -187,6 +187,7 @@ constexpr int kBoxThreads = 1024;
 constexpr int kBoxSlots = kBoxMaxList / kBoxThreads;
 constexpr int kBoxMaxGeneral = 384;   // general band cells of a region (their rows sit in LDS: 13.5 KB)
 constexpr int kBoxInfoInts = 16;
+constexpr int kBoxUInfoInts = 8;      // per group, made on the device from the list (launchBandBoxUpdates): simple band cells with ring <= r (r = 0..4), closure-output cells
 enum BoxNode : uint8_t { kBoxSkip = 0, kBoxFrozen = 1, kBoxZero = 2, kBoxGeneral = 3, kBoxSimple = 4, kBoxFrozenOut = 11, kBoxFrozenFar = 12 };
 // info: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first entry in `list`, [3] unused,
 // [4] first entry in `general`, [5] general entries, [6] unused, [7] list entries, [8 + r] band cells with ring <= r
@@ -206,7 +207,19 @@ struct BandBoxesDev {
     uint32_t *list = nullptr;
     size_t listCount = 0, generalInts = 0;
     bool anyGeneral = false;
+    // the update list of every group (round 4): the entries of `list` that are ever updated, at the group's offset in `list` --
+    // simple band cells sorted by ring, then the closure-output cells -- and their counts (kBoxUInfoInts per group).  Made on
+    // the device from info + list (launchBandBoxUpdates) whoever built those
+    uint32_t *ulist = nullptr;
+    int32_t *uinfo = nullptr;
 };
+int launchBandBoxUpdates(void *stream, const BandBoxesDev &bx);
+// the box kernels address a region cell by a 32-bit byte offset from the region's origin (31 planes at most) formed with 24-bit
+// multiplies: a level whose x-y planes hold 2^24 cells or more (4096 x 4096) keeps the pass-by-pass band smoother
+inline bool boxPlaneFits(const Dims &d) { return size_t(d.nx) * size_t(d.ny) < (size_t(1) << 24); }
+// the groups in the Morton order of their tiles (launch order = L2 locality of the overlapping regions): info / uinfo permuted
+// into infoOut / uinfoOut; synchronises the stream
+int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, const int32_t *uinfo, int ngroups, int32_t *infoOut, int32_t *uinfoOut);
 
 // The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
 // besides its ghost plane a rank receives the *band closure* (band cells and their active face neighbours)
@@ -409,8 +422,12 @@ struct HaloSide {
 int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane);
 int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
+// snap / snapTile (optional): the tiles flagged in snapTile (launchMarkSnapTiles) leave a second copy of their result in `snap`
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
-                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials = nullptr);
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials = nullptr,
+                  float *snap = nullptr, const uint8_t *snapTile = nullptr);
+// a byte per 16^3 tile (zeroed by the caller): set where some box group of the fused band stage reads a cell of the tile
+int launchMarkSnapTiles(void *stream, const GridP &g, const BandBoxesDev &bx, uint8_t *tiles);
 int launchTiledGSMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *pureTiles, int npure, const int32_t *mixedTiles, int nmixed,
                        const int32_t *tileBndStart, int forward, const MixScale &ms);
 // codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
@@ -428,7 +445,7 @@ int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const fl
 int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigmaDev, float mul, size_t cells);
 int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev);
 int launchZeroActiveHalf(void *stream, const GridP &g, void *aH);
-int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse);
+int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse, float *snap = nullptr, const uint8_t *snapTile = nullptr);
 // the up-stroke's prolongation folded into the sweep that follows it: out = Jacobi(x + 4 P coarse), x itself is not updated;
 // quads flagged in nearBand (launchMarkNearBand: every quad a box group stages; (cells / 4 + 31) / 32 words, zeroed first)
 // also leave x + 4 P coarse in `stage`

@@ -1109,11 +1109,23 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
 
-// XZERO (closure mode): src is zero everywhere (see stencilQuadKernel): no value of it is loaded
+// Round 4: TWO lists per group.  The region list above (`list`: every region cell that matters, region order) stages the
+// values: consecutive lanes take consecutive cells of a row.  The passes walk `ulist`, the cells that are ever UPDATED -- the
+// simple band cells sorted by ring (stable: region order inside a ring), then the closure-output cells -- so that pass p is the
+// prefix ucount[H - p] of it with every lane busy: in the region list only one entry in four is a band cell (3.9 entries per
+// band cell on the cube, 4.9 on the pool), and a pass that walks it runs its 7 LDS reads per slot at a quarter of the lanes
+// (rocprofv3 SQ counters, round 3: 7 LDS instructions per vector-memory read, SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY 3.3 at 8 waves per
+// SIMD -- the LDS pipe, not the load chain: walking the groups by persistent workgroups with the next group's loads in flight
+// changed nothing, 1024^3 97.0 -> 97.0 cycles/s).  The rhs is loaded for the update list only, a thread keeps the value of its
+// cell in a register from pass to pass (6 LDS reads per update instead of 7) and writes its outputs from that register: no LDS
+// read and no barrier after the last pass.  Same expressions in the same order per cell.
+// uinfo (kBoxUInfoInts per group): [r] = simple band cells with ring <= r (r = 0..4), [5] = closure-output cells.
+// XZERO: src is zero everywhere (see stencilQuadKernel): no value of it is loaded
 // (the body: bandBoxKernel runs group remapBlock(blockIdx.x), strokeFrontKernel its first workgroups)
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO>
 __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                             TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                            const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                             const int32_t *__restrict__ general, float omega, int depth, const MixScale &ms,
                                             double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned group, unsigned slot)
 {
@@ -1125,9 +1137,12 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
     __shared__ uint16_t gnode[kGenRows], gring[kGenRows];  // region cell and ring
     // the group's description is wave-uniform: scalar registers (addresses below: scalar base + one 32-bit vector offset)
     const int32_t *gip = info + kBoxInfoInts * size_t(group);
-    int gi[kBoxInfoInts];
+    const int32_t *uip = uinfo + kBoxUInfoInts * size_t(group);
+    int gi[8], cnt[6];
 #pragma unroll
-    for (int q = 0; q < kBoxInfoInts; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
+    for (int q = 0; q < 8; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) cnt[q] = __builtin_amdgcn_readfirstlane(uip[q]);
     const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, sxy = rx * ry;
     // a region cell's address = the region's origin + a 32-bit offset inside the region (it stays below 32 planes)
     const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
@@ -1137,28 +1152,36 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
     if (dst) dst += origin;
     if (CLOSURE && snap) snap += origin;
     if (DOT) dotOld += origin;
-    const uint32_t *U = list + gi[2];
+    const uint32_t *U = list + gi[2], *UB = ulist + gi[2];
     const int ngen = GEN ? gi[5] : 0, nList = gi[7];
+    const int nSimple = cnt[4], nUpd = cnt[4] + cnt[5];  // update list: [0, nSimple) band cells by ring, [nSimple, nUpd) closure-output cells
     const int H = depth + (CLOSURE ? 1 : 0);
     const float bm = kMixed ? mixRhsScale(ms) : 1.f;
     const int tid = threadIdx.x;
-    auto nodeOf = [&](uint32_t e) { return int(((e >> 10) & 31u) * unsigned(sxy) + ((e >> 5) & 31u) * unsigned(rx) + (e & 31u)); };
-    auto cellOf = [&](uint32_t e) { return (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz; };
+    // (24-bit multiplies: v_mul_u32_u24 / v_mad_u32_u24 run at the full rate, the 32-bit v_mul_lo_u32 / v_mad_u64_u32 at a quarter
+    // of it -- two of them per address, twice per entry, were a third of the kernel's vector ALU time.  launchBandBox refuses
+    // levels whose planes do not fit 24 bits)
+    auto nodeOf = [&](uint32_t e) { return int(__umul24((e >> 10) & 31u, unsigned(sxy)) + __umul24((e >> 5) & 31u, unsigned(rx)) + (e & 31u)); };
+    auto cellOf = [&](uint32_t e) { return (e & 31u) + __umul24((e >> 5) & 31u, sy) + __umul24((e >> 10) & 31u, sz); };
     // element c of a grid whose base is the region's origin: scalar base + 32-bit BYTE offset (the form the global_load /
     // global_store instructions take with one vector register)
     auto rd = [&](const TX *base, unsigned c) { return Cell<TX>::load1(reinterpret_cast<const TX *>(reinterpret_cast<const char *>(base) + c * unsigned(sizeof(TX)))); };
     auto rdf = [&](const float *base, unsigned c) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + c * 4u); };
     auto wr = [&](TX *base, unsigned c, float v) { Cell<TX>::store1(reinterpret_cast<TX *>(reinterpret_cast<char *>(base) + c * unsigned(sizeof(TX))), v); };
-    uint32_t ue[kBoxSlots];
-    float bv[kBoxSlots];
+    uint32_t ub[kBoxSlots];  // this thread's update entries
+    unsigned cb[kBoxSlots];  // ... and their cells (offsets from the region's origin)
+    float bv[kBoxSlots], xcur[kBoxSlots];
+    uint32_t ge = 0;  // this thread's general cell: its list entry and its row, in the first batch like the rest
+    const int nRhs = CLOSURE ? nSimple : cnt[min(H - 1, 4)];  // the band cells that are updated at all: ring <= H - 1 (closure mode: every listed one)
     {
         // first batch of loads: every list entry of this thread (and its general entry); second batch: every value
+        uint32_t ue[kBoxSlots];
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
             const int k = tid + m * kBoxThreads;
             ue[m] = k < nList ? U[k] : (uint32_t(kBoxSkip) << 16);
+            ub[m] = k < nUpd ? UB[k] : 0u;
         }
-        uint32_t ge = 0;  // this thread's general cell: its list entry and its row, in the first batch like the rest
         int32_t grw = 0;
         if (GEN && tid < ngen) {
             ge = uint32_t(general[2 * size_t(gi[4] + tid)]);
@@ -1169,12 +1192,13 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
         float xv[kBoxSlots];
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
+            const int k = tid + m * kBoxThreads;
             const unsigned cls = (ue[m] >> 16) & 15u;
             const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
-            const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
-            const unsigned c = cellOf(ue[m]);
-            xv[m] = XZERO ? 0.f : rd(src, need ? c : 0u);
-            bv[m] = rdf(b, bneed ? c : 0u);
+            const bool bneed = k < nRhs || (CLOSURE && k >= nSimple && k < nUpd);
+            xv[m] = XZERO ? 0.f : rd(src, need ? cellOf(ue[m]) : 0u);
+            cb[m] = cellOf(ub[m]);
+            bv[m] = rdf(b, bneed ? cb[m] : 0u);
         }
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
@@ -1200,262 +1224,140 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
                 val[1][n] = xv[m];
             }
     }
+    int nd[kBoxSlots];
+#pragma unroll
+    for (int m = 0; m < kBoxSlots; ++m) {
+        nd[m] = nodeOf(ub[m]);
+        xcur[m] = 0.f;
+    }
+    float gcur = 0.f;
     __syncthreads();
     for (int p = 1; p <= H; ++p) {
         const float *from = val[(p - 1) & 1];
         float *to = val[p & 1];
-        const int lim = H - p;  // the band cells with ring <= H - p
+        const int lim = H - p;  // the band cells with ring <= H - p: a prefix of the update list
+        const int nAct = cnt[min(lim, 4)];
         const bool last = CLOSURE && p == H;
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const unsigned cls = (ue[m] >> 16) & 15u;
-            const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
-            if ((simple && int(ue[m] >> 20) <= lim) || (last && cls == kBoxFrozenOut)) {
-                const int n = nodeOf(ue[m]);
-                const float xc = from[n];
-                const float diag = cls == kBoxFrozenOut ? 6.f : float(int(cls) - int(kBoxSimple));
+            const int k = tid + m * kBoxThreads;
+            if (m * kBoxThreads >= (last ? nUpd : nAct)) break;  // (wave-uniform)
+            const bool out = last && k >= nSimple && k < nUpd;
+            if (k < nAct || out) {
+                const int n = nd[m];
+                const float xc = (p == 1 || out) ? from[n] : xcur[m];  // (a cell of the prefix was in every earlier pass: its value is what this thread wrote)
+                const float diag = out ? 6.f : float(int((ub[m] >> 16) & 15u) - int(kBoxSimple));
                 const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
-                to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
+                const float v = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
+                to[n] = v;
+                xcur[m] = v;
             }
         }
         if (GEN && tid < ngen && int(gring[tid]) <= lim) {
-            const int nd = gnode[tid];
-            const float xc = from[nd];
+            const int n = gnode[tid];
+            const float xc = from[n];
             float acc = 0.f;
-            acc -= grow[0][tid] * from[nd - 1];
-            acc -= grow[1][tid] * from[nd + 1];
-            acc -= grow[2][tid] * from[nd - rx];
-            acc -= grow[3][tid] * from[nd + rx];
-            acc -= grow[4][tid] * from[nd - sxy];
-            acc -= grow[5][tid] * from[nd + sxy];
+            acc -= grow[0][tid] * from[n - 1];
+            acc -= grow[1][tid] * from[n + 1];
+            acc -= grow[2][tid] * from[n - rx];
+            acc -= grow[3][tid] * from[n + rx];
+            acc -= grow[4][tid] * from[n - sxy];
+            acc -= grow[5][tid] * from[n + sxy];
             const float diag = grow[6][tid];
             const float lap = acc + diag * xc;
-            to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
+            gcur = xc + omega * ((gbv[tid] - lap) / diag);
+            to[n] = gcur;
         }
-        __syncthreads();
+        if (p < H) __syncthreads();
     }
-    const float *fin = val[H & 1];
+    // the owned box's band cells (ring 0: in every pass, so the register holds the final value) and, in the closure mode, its
+    // closure-output cells (computed by the last pass); the plain mode with outClosure passes their staged value on -- what the
+    // closure launch left in the snapshot goes to dst, which then needs nothing from the closure launch itself
     double acc = 0.0;
+    auto emit = [&](unsigned c, float v) {
+        if (DOT) {
+            const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
+            acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
+        }
+        if (dst) wr(dst, c, v);
+        if (CLOSURE && snap) wr(snap, c, v);
+    };
 #pragma unroll
     for (int m = 0; m < kBoxSlots; ++m) {
-        const unsigned cls = (ue[m] >> 16) & 15u;
-        // plain mode with outClosure: the closure-output cells too -- their staged value (what the closure launch left in the
-        // snapshot) goes to dst, which then needs nothing from the closure launch itself
-        if ((ue[m] >> 20) == 0u && (boxBand(cls) || ((CLOSURE || outClosure) && cls == kBoxFrozenOut))) {
-            const unsigned c = cellOf(ue[m]);
-            const float v = fin[nodeOf(ue[m])];
-            if (DOT) {
-                const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
-                acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
-            }
-            if (dst) wr(dst, c, v);
-            if (CLOSURE && snap) wr(snap, c, v);
-        }
+        const int k = tid + m * kBoxThreads;
+        if (k < cnt[0]) emit(cb[m], xcur[m]);
+        else if ((CLOSURE || outClosure) && k >= nSimple && k < nUpd) emit(cb[m], CLOSURE ? xcur[m] : val[0][nd[m]]);
     }
+    if (GEN && tid < ngen && (ge >> 20) == 0u) emit(cellOf(ge), gcur);
     if (DOT) blockDotStore(acc, dotPartials, slot);
 }
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
 __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                                               TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                              const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                                               const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
                                                               double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
 {
-    bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, general, omega, depth, ms, dotPartials, dotOld, outClosure,
+    bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, ulist, uinfo, general, omega, depth, ms, dotPartials, dotOld, outClosure,
                                               remapBlock(blockIdx.x, gridDim.x), blockIdx.x);
 }
 
-// The same stage by PERSISTENT workgroups (round 4; two per CU, each walking the groups v = blockIdx.x, blockIdx.x + gridDim.x, ...)
-// with the loads of the next group in flight while the current one runs its passes.  A group is a chain of dependent round trips --
-// info -> list -> values -> H LDS passes -> stores -- and with 64 KB of LDS per group only two chains per CU are in flight
-// (rocprofv3, round 3: SQ_WAIT_ANY 66 %, 3.3 TB/s of a traffic that is 4.7 x the algorithmic bytes).  Here a workgroup holds, while
-// group i computes: the info of groups i + 1 and i + 2 (scalar registers), the list entries of group i + 1 (requested before
-// pass 1) and its values (requested after pass 1, once the entries are there) -- the memory side of group i + 1 hides behind
-// the LDS side of group i.  Same arithmetic, same order per cell: bit-equal to bandBoxKernel (MGPS_BOX_PIPE=0 is the A/B).
-struct BoxInfo {
-    int origin, rxy, listStart, genStart, ngen, nList;
-};
-__device__ __forceinline__ BoxInfo boxInfoLoad(const int32_t *__restrict__ info, unsigned v, unsigned ngroups)
+// The update list of every group (see bandBoxBody) from its region list: a stable counting sort by (ring of a simple band cell,
+// then closure-output cells); one workgroup per group, a thread = 16 consecutive entries.  Set-up only.
+__global__ __launch_bounds__(256) void boxUpdateListKernel(const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint32_t *__restrict__ ulist,
+                                                         int32_t *__restrict__ uinfo)
 {
-    const bool valid = v < ngroups;
-    const int32_t *gip = info + kBoxInfoInts * size_t(remapBlock(valid ? v : ngroups - 1, ngroups));
-    BoxInfo I;
-    I.origin = __builtin_amdgcn_readfirstlane(gip[0]);
-    I.rxy = __builtin_amdgcn_readfirstlane(gip[1]);
-    I.listStart = __builtin_amdgcn_readfirstlane(gip[2]);
-    I.genStart = __builtin_amdgcn_readfirstlane(gip[4]);
-    I.ngen = valid ? __builtin_amdgcn_readfirstlane(gip[5]) : 0;
-    I.nList = valid ? __builtin_amdgcn_readfirstlane(gip[7]) : 0;  // (past the end: a group without entries -- its loads read the last group's origin cell and drop it)
-    return I;
-}
-template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
-__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxPipeKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
-                                                                  TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                                                  const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
-                                                                  double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned ngroups)
-{
-    constexpr bool kMixed = !std::is_same<TX, float>::value;
-    constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
-    __shared__ float val[2][kBoxMaxNodes];
-    __shared__ float grow[7][kGenRows];
-    __shared__ float gbv[kGenRows];
-    __shared__ uint16_t gnode[kGenRows], gring[kGenRows];
-    const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
-    const int H = depth + (CLOSURE ? 1 : 0);
-    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
-    const int tid = threadIdx.x;
-    const size_t nb = size_t(g.nbnd);
-    auto cellOf = [&](uint32_t e) { return (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz; };
-    auto rd = [&](const TX *base, unsigned c) { return Cell<TX>::load1(reinterpret_cast<const TX *>(reinterpret_cast<const char *>(base) + c * unsigned(sizeof(TX)))); };
-    auto rdf = [&](const float *base, unsigned c) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + c * 4u); };
-    auto wr = [&](TX *base, unsigned c, float v) { Cell<TX>::store1(reinterpret_cast<TX *>(reinterpret_cast<char *>(base) + c * unsigned(sizeof(TX))), v); };
-    // first batch of a group: its list entries (and this thread's general cell: list entry + row number)
-    auto loadList = [&](const BoxInfo &I, uint32_t (&ue)[kBoxSlots], uint32_t &ge, int32_t &grw) {
-        const uint32_t *U = list + I.listStart;
-#pragma unroll
-        for (int m = 0; m < kBoxSlots; ++m) {
-            const int k = tid + m * kBoxThreads;
-            ue[m] = k < I.nList ? U[k] : (uint32_t(kBoxSkip) << 16);
-        }
-        ge = 0;
-        grw = 0;
-        if (GEN && tid < I.ngen) {
-            ge = uint32_t(general[2 * size_t(I.genStart + tid)]);
-            grw = general[2 * size_t(I.genStart + tid) + 1];
-        }
+    constexpr int kKeys = 6, kPer = kBoxMaxList / 256;
+    __shared__ int counts[kKeys][256];
+    __shared__ int keyBase[kKeys + 1];
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const uint32_t *U = list + gi[2];
+    uint32_t *UB = ulist + gi[2];
+    const int nList = gi[7], tid = threadIdx.x, k0 = tid * kPer;
+    auto keyOf = [](uint32_t e) {
+        const unsigned cls = (e >> 16) & 15u, ring = e >> 20;
+        if (cls > kBoxSimple && cls <= kBoxSimple + 6) return int(min(ring, 4u));
+        return (cls == kBoxFrozenOut && ring == 0u) ? 5 : -1;
     };
-    // second batch: every value (unconditional loads: a cell that needs none reads the region's origin cell and drops it)
-    auto loadValues = [&](const BoxInfo &I, const uint32_t (&ue)[kBoxSlots], uint32_t ge, int32_t grw, float (&xv)[kBoxSlots], float (&bv)[kBoxSlots],
-                          float (&rw)[7], float &gb) {
-        const TX *s = XZERO ? nullptr : src + ptrdiff_t(I.origin);
-        const float *bb = b + ptrdiff_t(I.origin);
+    int mine[kKeys] = {0, 0, 0, 0, 0, 0};
+    uint32_t e[kPer];
 #pragma unroll
-        for (int m = 0; m < kBoxSlots; ++m) {
-            const unsigned cls = (ue[m] >> 16) & 15u;
-            const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
-            const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
-            const unsigned c = cellOf(ue[m]);
-            xv[m] = XZERO ? 0.f : rd(s, need ? c : 0u);
-            bv[m] = rdf(bb, bneed ? c : 0u);
-        }
-        if (GEN) {
-            const bool mine = tid < I.ngen;
+    for (int q = 0; q < kPer; ++q) {
+        e[q] = k0 + q < nList ? U[k0 + q] : 0u;
+        const int key = k0 + q < nList ? keyOf(e[q]) : -1;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) rw[q] = g.rows[size_t(q) * nb + (mine ? grw : 0)];
-            gb = rdf(bb, mine ? cellOf(ge) : 0u);
-        }
-    };
-    const unsigned P = gridDim.x;
-    unsigned v = blockIdx.x;
-    BoxInfo cur = boxInfoLoad(info, v, ngroups), nxt = boxInfoLoad(info, v + P, ngroups);
-    uint32_t ue[kBoxSlots], ge;
-    int32_t grw;
-    float xv[kBoxSlots], bv[kBoxSlots], rw[7], gb = 0.f;
-    loadList(cur, ue, ge, grw);
-    loadValues(cur, ue, ge, grw, xv, bv, rw, gb);
-    for (; v < ngroups; v += P) {
-        const int rx = cur.rxy & 255, ry = (cur.rxy >> 8) & 255, sxy = rx * ry;
-        auto nodeOf = [&](uint32_t e) { return int(((e >> 10) & 31u) * unsigned(sxy) + ((e >> 5) & 31u) * unsigned(rx) + (e & 31u)); };
-        const int ngen = GEN ? cur.ngen : 0, nList = cur.nList;
-        // stage the current group's values
+        for (int c = 0; c < kKeys; ++c) mine[c] += key == c ? 1 : 0;
+    }
 #pragma unroll
-        for (int m = 0; m < kBoxSlots; ++m) {
-            const unsigned cls = (ue[m] >> 16) & 15u;
-            if (cls == kBoxSkip || cls == kBoxZero) xv[m] = 0.f;
-            if (kMixed) bv[m] *= bm;
-            if (tid + m * kBoxThreads < nList) {
-                const int n = nodeOf(ue[m]);
-                val[0][n] = xv[m];
-                val[1][n] = xv[m];
+    for (int c = 0; c < kKeys; ++c) counts[c][tid] = mine[c];
+    __syncthreads();
+    if (tid == 0) {  // (1536 additions once per group at set-up)
+        int run = 0;
+        for (int c = 0; c < kKeys; ++c) {
+            keyBase[c] = run;
+            for (int t = 0; t < 256; ++t) {
+                const int v = counts[c][t];
+                counts[c][t] = run;
+                run += v;
             }
         }
-        if (GEN && tid < ngen) {
-            gring[tid] = uint16_t(ge >> 20);
-            gnode[tid] = uint16_t(nodeOf(ge));
+        keyBase[kKeys] = run;
+        int32_t *ui = uinfo + kBoxUInfoInts * size_t(blockIdx.x);
+        for (int c = 0; c < 5; ++c) ui[c] = keyBase[c + 1];  // simple band cells with ring <= c
+        ui[5] = keyBase[6] - keyBase[5];
+        ui[6] = 0;
+        ui[7] = 0;
+    }
+    __syncthreads();
+    int at[kKeys];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) grow[q][tid] = rw[q];
-            gbv[tid] = kMixed ? bm * gb : gb;
-        }
-        // the next group's entries leave now, the info of the one after it as well
-        uint32_t ueN[kBoxSlots], geN;
-        int32_t grwN;
-        loadList(nxt, ueN, geN, grwN);
-        const BoxInfo nn = boxInfoLoad(info, v + 2 * P, ngroups);
-        float xvN[kBoxSlots], bvN[kBoxSlots], rwN[7], gbN = 0.f;
-        __syncthreads();
-        auto pass = [&](int p) {
-            const float *from = val[(p - 1) & 1];
-            float *to = val[p & 1];
-            const int lim = H - p;
-            const bool last = CLOSURE && p == H;
+    for (int c = 0; c < kKeys; ++c) at[c] = counts[c][tid];
 #pragma unroll
-            for (int m = 0; m < kBoxSlots; ++m) {
-                const unsigned cls = (ue[m] >> 16) & 15u;
-                const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
-                if ((simple && int(ue[m] >> 20) <= lim) || (last && cls == kBoxFrozenOut)) {
-                    const int n = nodeOf(ue[m]);
-                    const float xc = from[n];
-                    const float diag = cls == kBoxFrozenOut ? 6.f : float(int(cls) - int(kBoxSimple));
-                    const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
-                    to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
-                }
-            }
-            if (GEN && tid < ngen && int(gring[tid]) <= lim) {
-                const int nd = gnode[tid];
-                const float xc = from[nd];
-                float acc = 0.f;
-                acc -= grow[0][tid] * from[nd - 1];
-                acc -= grow[1][tid] * from[nd + 1];
-                acc -= grow[2][tid] * from[nd - rx];
-                acc -= grow[3][tid] * from[nd + rx];
-                acc -= grow[4][tid] * from[nd - sxy];
-                acc -= grow[5][tid] * from[nd + sxy];
-                const float diag = grow[6][tid];
-                const float lap = acc + diag * xc;
-                to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
-            }
-        };
-        pass(1);
-        loadValues(nxt, ueN, geN, grwN, xvN, bvN, rwN, gbN);  // (the entries were requested a pass ago)
-        __syncthreads();
-        for (int p = 2; p <= H; ++p) {
-            pass(p);
-            __syncthreads();
-        }
-        const float *fin = val[H & 1];
-        double acc = 0.0;
-        {
-            TX *d = dst ? dst + ptrdiff_t(cur.origin) : nullptr;
-            TX *sn = (CLOSURE && snap) ? snap + ptrdiff_t(cur.origin) : nullptr;
+    for (int q = 0; q < kPer; ++q) {
+        const int key = k0 + q < nList ? keyOf(e[q]) : -1;
 #pragma unroll
-            for (int m = 0; m < kBoxSlots; ++m) {
-                const unsigned cls = (ue[m] >> 16) & 15u;
-                if ((ue[m] >> 20) == 0u && (boxBand(cls) || ((CLOSURE || outClosure) && cls == kBoxFrozenOut))) {
-                    const unsigned c = cellOf(ue[m]);
-                    const float r = fin[nodeOf(ue[m])];
-                    if (DOT) {
-                        const float stored = kMixed ? __half2float(toHalfSat(r)) : r;
-                        acc += (double(stored) - double(rd(dotOld + ptrdiff_t(cur.origin), c))) * double(rdf(b + ptrdiff_t(cur.origin), c));
-                    }
-                    if (d) wr(d, c, r);
-                    if (sn) wr(sn, c, r);
-                }
-            }
-        }
-        if (DOT) blockDotStore(acc, dotPartials, remapBlock(v, ngroups));
-        __syncthreads();  // (the next group's staging overwrites both copies)
-        cur = nxt;
-        nxt = nn;
-        ge = geN;
-        grw = grwN;
-        gb = gbN;
-#pragma unroll
-        for (int m = 0; m < kBoxSlots; ++m) {
-            ue[m] = ueN[m];
-            xv[m] = xvN[m];
-            bv[m] = bvN[m];
-        }
-#pragma unroll
-        for (int q = 0; q < 7; ++q) rw[q] = rwN[q];
+        for (int c = 0; c < kKeys; ++c)
+            if (key == c) UB[at[c]++] = e[q];
     }
 }
 
@@ -1468,11 +1370,12 @@ __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxPipeKernel(GridP g, con
 template <bool GEN, bool XZERO>
 __global__ __launch_bounds__(kBoxThreads, 8) void strokeFrontKernel(GridP g, float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ b,
                                                                   float *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                                  const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                                                   const int32_t *__restrict__ general, float omega, int depth, unsigned ngroups,
                                                                   unsigned nshares, const int32_t *__restrict__ chunks, const uint32_t *__restrict__ keep)
 {
     if (blockIdx.x < ngroups) {
-        bandBoxBody<float, true, false, GEN, XZERO>(g, x, b, nullptr, snap, info, list, general, omega, depth, MixScale{}, nullptr, nullptr, 0,
+        bandBoxBody<float, true, false, GEN, XZERO>(g, x, b, nullptr, snap, info, list, ulist, uinfo, general, omega, depth, MixScale{}, nullptr, nullptr, 0,
                                                     remapBlock(blockIdx.x, ngroups), 0u);
         return;
     }
@@ -1491,6 +1394,23 @@ __global__ __launch_bounds__(256) void markClosureKernel(GridP g, const int32_t 
         if ((e >> 20) != 0u || !(boxBand(cls) || cls == kBoxFrozenOut)) continue;
         const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
         atomicOr(bits + (c >> 5), 1u << (c & 31));
+    }
+}
+
+// snapshot tiles of a level: the 16^3 tiles that hold a cell some group reads in the plain mode (launchMarkSnapTiles)
+__global__ __launch_bounds__(256) void markSnapTilesKernel(GridP g, const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint8_t *__restrict__ tiles)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const int tx = (g.nx + kTile - 1) / kTile, ty = (g.ny + kTile - 1) / kTile;
+    const size_t origin = size_t(gi[0]);
+    const int ox = int(origin % size_t(g.nx)), oy = int((origin / size_t(g.nx)) % size_t(g.ny)), oz = int(origin / (size_t(g.nx) * g.ny));
+    const uint32_t *U = list + gi[2];
+    for (int k = threadIdx.x; k < gi[7]; k += 256) {
+        const uint32_t e = U[k];
+        const unsigned cls = (e >> 16) & 15u;
+        if (cls == kBoxSkip || cls == kBoxZero) continue;  // (class 12 cells are not read by the plain mode; their tiles may be marked for nothing)
+        const int i = ox + int(e & 31u), j = oy + int((e >> 5) & 31u), k3 = oz + int((e >> 10) & 31u);
+        tiles[(size_t(k3 / kTile) * ty + j / kTile) * tx + i / kTile] = 1;
     }
 }
 
@@ -1636,9 +1556,13 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const TX *__restrict_
 }
 
 // one pure tile by one workgroup; slot: where its <x, b> goes (DOT)
+// snap / snapTile (optional, here and in the mixed tile): a tile whose byte is set in snapTile (launchMarkSnapTiles: some box group
+// of the fused band stage reads a cell of it) leaves a second copy of its result in `snap` -- the snapshot from which the band
+// stage after the sweep reads while it writes x in place (smoothStroke, Gauss-Seidel strokes)
 template <bool DOT, class TX = float>
 __device__ __forceinline__ void gsPureTile(const GridP &g, TX *__restrict__ x, const float *__restrict__ b, int tile, int forward,
-                                           double *__restrict__ dotPartials, unsigned slot, float *sx, float *sb, float bm = 1.f)
+                                           double *__restrict__ dotPartials, unsigned slot, float *sx, float *sb, float bm = 1.f,
+                                           TX *__restrict__ snap = nullptr, const uint8_t *__restrict__ snapTile = nullptr)
 {
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
@@ -1658,10 +1582,13 @@ __device__ __forceinline__ void gsPureTile(const GridP &g, TX *__restrict__ x, c
         __syncthreads();
     }
     double acc = 0.0;
+    const bool snapOn = snap && snapTile[tile];
     for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
         const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
         const float *src = sx + haloIdx(4 * q, cj, ck);
-        Cell<TX>::store4(x + (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
+        const size_t at = (size_t(k0 + ck) * g.ny + j0 + cj) * g.nx + i0 + 4 * q;
+        Cell<TX>::store4(x + at, make_float4(src[0], src[1], src[2], src[3]));
+        if (snapOn) Cell<TX>::store4(snap + at, make_float4(src[0], src[1], src[2], src[3]));
         if (DOT) {
             const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
 #pragma unroll
@@ -1673,11 +1600,12 @@ __device__ __forceinline__ void gsPureTile(const GridP &g, TX *__restrict__ x, c
 template <bool DOT = false, class TX = float>  // DOT: the workgroup also leaves <x, b> over its tile (see dotTerm)
 __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, TX *__restrict__ x, const float *__restrict__ b,
                                                          const int32_t *__restrict__ tiles, int forward,
-                                                         double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{})
+                                                         double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{},
+                                                         TX *__restrict__ snap = nullptr, const uint8_t *__restrict__ snapTile = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
-    gsPureTile<DOT, TX>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb, std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms));
+    gsPureTile<DOT, TX>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb, std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms), snap, snapTile);
 }
 
 // one mixed tile by one workgroup (rowMask: bit i set = cell (i, j, k) of x-row (j, k) is BOUNDARY; rowStart: BOUNDARY cells of
@@ -1686,7 +1614,8 @@ template <bool DOT, class TX = float>
 __device__ __forceinline__ void gsMixedTile(const GridP &g, TX *__restrict__ x, const float *__restrict__ b, int tile,
                                             const int32_t *__restrict__ tileBndStart, int forward, double *__restrict__ dotPartials,
                                             unsigned slot, float *sx, float *sb, unsigned char *sl, float *srow, unsigned short *rowMask,
-                                            unsigned short *rowStart, int *scanTmp, float bm = 1.f)
+                                            unsigned short *rowStart, int *scanTmp, float bm = 1.f, TX *__restrict__ snap = nullptr,
+                                            const uint8_t *__restrict__ snapTile = nullptr)
 {
     const int tilesX = (g.nx + kTile - 1) / kTile, tilesY = (g.ny + kTile - 1) / kTile;
     const int i0 = (tile % tilesX) * kTile, j0 = ((tile / tilesX) % tilesY) * kTile, k0 = (tile / (tilesX * tilesY)) * kTile;
@@ -1757,15 +1686,22 @@ __device__ __forceinline__ void gsMixedTile(const GridP &g, TX *__restrict__ x, 
     }
     // whole quads where the grid has them (inactive cells still hold the value they were loaded with: exactly 0)
     double acc = 0.0;
+    const bool snapOn = snap && snapTile[tile];
     for (int r = threadIdx.x; r < kTile * kTile * 4; r += blockDim.x) {
         const int q = r & 3, cj = (r >> 2) % kTile, ck = (r >> 2) / kTile;
         const int gi = i0 + 4 * q, gj = j0 + cj, gk = k0 + ck;
         if (gj >= g.ny || gk >= g.nz || gi >= g.nx) continue;
         const float *src = sx + haloIdx(4 * q, cj, ck);
-        TX *dst = x + (size_t(gk) * g.ny + gj) * g.nx + gi;
-        if (gi + 3 < g.nx && (g.nx & 3) == 0) Cell<TX>::store4(dst, make_float4(src[0], src[1], src[2], src[3]));
-        else
-            for (int e = 0; e < 4 && gi + e < g.nx; ++e) Cell<TX>::store1(dst + e, src[e]);
+        const size_t at = (size_t(gk) * g.ny + gj) * g.nx + gi;
+        TX *dst = x + at;
+        if (gi + 3 < g.nx && (g.nx & 3) == 0) {
+            Cell<TX>::store4(dst, make_float4(src[0], src[1], src[2], src[3]));
+            if (snapOn) Cell<TX>::store4(snap + at, make_float4(src[0], src[1], src[2], src[3]));
+        } else
+            for (int e = 0; e < 4 && gi + e < g.nx; ++e) {
+                Cell<TX>::store1(dst + e, src[e]);
+                if (snapOn) Cell<TX>::store1(snap + at + e, src[e]);
+            }
         if (DOT) {
             const float *bq = sb + (ck * kTile + cj) * kTile + 4 * q;
             const unsigned char *lq = sl + haloIdx(4 * q, cj, ck);
@@ -1779,7 +1715,8 @@ template <bool DOT = false, class TX = float>
 __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, TX *__restrict__ x, const float *__restrict__ b,
                                                           const int32_t *__restrict__ tiles,
                                                           const int32_t *__restrict__ tileBndStart, int forward,
-                                                          double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{})
+                                                          double *__restrict__ dotPartials = nullptr, MixScale ms = MixScale{},
+                                                          TX *__restrict__ snap = nullptr, const uint8_t *__restrict__ snapTile = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
@@ -1789,7 +1726,7 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, TX *__restric
     __shared__ unsigned short rowStart[kTile * kTile];
     __shared__ int scanTmp[4];
     gsMixedTile<DOT, TX>(g, x, b, tiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp,
-                         std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms));
+                         std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms), snap, snapTile);
 }
 // Both lists of a colour in one launch: workgroups [0, nmixed) take the mixed tiles, the rest the pure ones.  For the small
 // levels, where a launch is a handful of workgroups and each tile a chain of 46 barrier steps (~10 us): the two launches of
@@ -1799,7 +1736,8 @@ template <bool DOT = false>
 __global__ __launch_bounds__(256) void tiledGSBothKernel(GridP g, float *__restrict__ x, const float *__restrict__ b,
                                                          const int32_t *__restrict__ mixedTiles, int nmixed,
                                                          const int32_t *__restrict__ pureTiles, const int32_t *__restrict__ tileBndStart,
-                                                         int forward, double *__restrict__ dotPartials = nullptr)
+                                                         int forward, double *__restrict__ dotPartials = nullptr, float *__restrict__ snap = nullptr,
+                                                         const uint8_t *__restrict__ snapTile = nullptr)
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
@@ -1809,9 +1747,9 @@ __global__ __launch_bounds__(256) void tiledGSBothKernel(GridP g, float *__restr
     __shared__ unsigned short rowStart[kTile * kTile];
     __shared__ int scanTmp[4];
     if (int(blockIdx.x) < nmixed)
-        gsMixedTile<DOT>(g, x, b, mixedTiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp);
+        gsMixedTile<DOT>(g, x, b, mixedTiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp, 1.f, snap, snapTile);
     else
-        gsPureTile<DOT>(g, x, b, pureTiles[int(blockIdx.x) - nmixed], forward, dotPartials, blockIdx.x, sx, sb);
+        gsPureTile<DOT>(g, x, b, pureTiles[int(blockIdx.x) - nmixed], forward, dotPartials, blockIdx.x, sx, sb, 1.f, snap, snapTile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1922,7 +1860,16 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
 // (1-f) a + f b, x first, then y, then z (Ops.h:841-871).  One thread per fine cell.
 // ---------------------------------------------------------------------------------------------
-__global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float *__restrict__ coarse)
+// snap / snapTile (optional, all three prolongation kernels): cells of the tiles flagged in snapTile (launchMarkSnapTiles) also
+// leave their new value in `snap` -- the snapshot from which the band stage in front of a Gauss-Seidel sweep reads while it
+// writes the iterate in place (smoothStroke)
+__device__ __forceinline__ bool snapTileOf(const GridP &g, const uint8_t *__restrict__ snapTile, int i, int j, int k)
+{
+    const int tx = (g.nx + kTile - 1) / kTile, ty = (g.ny + kTile - 1) / kTile;
+    return snapTile[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile] != 0;
+}
+__global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float *__restrict__ coarse, float *__restrict__ snap = nullptr,
+                                 const uint8_t *__restrict__ snapTile = nullptr)
 {
     const size_t n = size_t(fg.nx) * fg.ny * fg.nz;
     const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1937,7 +1884,9 @@ __global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float
     const float v00 = lerpRef(p[0], p[1], fx), v10 = lerpRef(p[sy], p[sy + 1], fx);
     const float v01 = lerpRef(p[sz], p[sz + 1], fx), v11 = lerpRef(p[sz + sy], p[sz + sy + 1], fx);
     const float t = lerpRef(lerpRef(v00, v10, fy), lerpRef(v01, v11, fy), fz);
-    fine[c] += 4.f * t;  // Ops.h:964
+    const float v = fine[c] + 4.f * t;  // Ops.h:964
+    fine[c] = v;
+    if (snap && snapTileOf(fg, snapTile, i, j, k)) snap[c] = v;
 }
 
 // Same operator, one thread per 4 consecutive fine cells (16-byte read-modify-write of the fine
@@ -1945,7 +1894,8 @@ __global__ void prolongAddKernel(GridP fg, float *__restrict__ fine, const float
 //   4m: (2m-1, 2m; f=3/4)   4m+1: (2m, 2m+1; 1/4)   4m+2: (2m, 2m+1; 3/4)   4m+3: (2m+1, 2m+2; 1/4)
 // Requires fine nx % 4 == 0.
 __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__restrict__ fine,
-                                                            const float *__restrict__ coarse, unsigned nblocks)
+                                                            const float *__restrict__ coarse, unsigned nblocks, float *__restrict__ snap = nullptr,
+                                                            const uint8_t *__restrict__ snapTile = nullptr)
 {
     const unsigned nq = unsigned(fg.nx) >> 2;
     const size_t total = size_t(nq) * fg.ny * fg.nz;
@@ -1990,6 +1940,7 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
     if (a2) f.z += add[2];
     if (a3) f.w += add[3];
     *reinterpret_cast<float4 *>(fine + c) = f;
+    if (snap && snapTileOf(fg, snapTile, int(m) << 2, j, k)) *reinterpret_cast<float4 *>(snap + c) = f;
 }
 
 // The same operator with the coarse reads shared: one thread owns the fine quad 4m..4m+3 of the two rows
@@ -2000,7 +1951,8 @@ __global__ __launch_bounds__(256) void prolongAddQuadKernel(GridP fg, float *__r
 template <class TX = float>
 __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, TX *__restrict__ fine,
                                                              const float *__restrict__ coarse, unsigned nblocks,
-                                                             int npj, int kp0, size_t total, float pm = 1.f)
+                                                             int npj, int kp0, size_t total, float pm = 1.f, TX *__restrict__ snap = nullptr,
+                                                             const uint8_t *__restrict__ snapTile = nullptr)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     const unsigned nq = unsigned(fg.nx) >> 2;
@@ -2062,6 +2014,7 @@ __global__ __launch_bounds__(256) void prolongAddBlockKernel(GridP fg, TX *__res
             if (a3) f.w += add[3];
             if (fg.streaming) Cell<TX>::store4nt(fine + c[zz][yy], f);
             else Cell<TX>::store4(fine + c[zz][yy], f);
+            if (snap && snapTileOf(fg, snapTile, int(m) << 2, js[yy], ks[zz])) Cell<TX>::store4(snap + c[zz][yy], f);
         }
 }
 
@@ -2661,39 +2614,14 @@ int launchBandFused(void *stream, const GridP &g, float *x, const float *b, cons
 }
 unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
 namespace {
-// persistent workgroups of the pipelined box kernel: two per CU (64 KB of LDS each)
-unsigned boxPipeGrid(unsigned ngroups)
-{
-    static const unsigned perDevice = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const char *e = getenv("MGPS_BOX_PIPE_WG");  // (tuning runs: workgroups per launch)
-        const int v = e ? atoi(e) : 0;
-        return unsigned(v > 0 ? v : 2 * std::max(cus, 8)) & ~7u;  // a multiple of the XCD count: a workgroup stays in one chiplet's run of groups (remapBlock)
-    }();
-    return std::min(ngroups, perDevice);
-}
-bool boxPipeOn()
-{
-    static const bool on = [] {  // MGPS_BOX_PIPE=0: one workgroup per group (bandBoxKernel), the A/B
-        const char *e = getenv("MGPS_BOX_PIPE");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
 template <class TX>
 int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool closure, const TX *src, const float *b, TX *dst, TX *snap, float omega,
                    const MixScale &ms, double *dotPartials, const TX *dotOld, int outClosure)
 {
     const unsigned ng = unsigned(bx.ngroups);
     const bool dot = dotPartials != nullptr;
-    const bool pipe = boxPipeOn() && ng > boxPipeGrid(ng);  // (a level with fewer groups than resident workgroups has nothing to pipeline)
-    const unsigned np = boxPipeGrid(ng);
-#define MGPS_BOX_LAUNCH3(C, D, G, Z)                                                                                                                                  \
-    do {                                                                                                                                                               \
-        if (pipe) bandBoxPipeKernel<TX, C, D, G, Z><<<np, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure, ng); \
-        else bandBoxKernel<TX, C, D, G, Z><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure);          \
-    } while (0)
+#define MGPS_BOX_LAUNCH3(C, D, G, Z) \
+    bandBoxKernel<TX, C, D, G, Z><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.ulist, bx.uinfo, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure)
 #define MGPS_BOX_LAUNCH(C, D, Z)                               \
     do {                                                       \
         if (bx.anyGeneral) MGPS_BOX_LAUNCH3(C, D, true, Z);    \
@@ -2715,10 +2643,18 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
     return int(hipGetLastError());
 }
 }  // namespace
+int launchBandBoxUpdates(void *stream, const BandBoxesDev &bx)
+{
+    if (bx.ngroups <= 0) return 0;
+    if (!bx.ulist || !bx.uinfo) return int(hipErrorInvalidValue);
+    boxUpdateListKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(bx.info, bx.list, bx.ulist, bx.uinfo);
+    return int(hipGetLastError());
+}
 int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap, float omega,
                   bool half, const MixScale &ms, double *dotPartials, const void *dotOld, bool outClosure)
 {
     if (bx.ngroups <= 0) return 0;
+    if (!bx.ulist || !bx.uinfo || size_t(g.nx) * size_t(g.ny) >= (size_t(1) << 24)) return int(hipErrorInvalidValue);  // (24-bit plane stride: boxPlaneFits)
     if (!dst && !(closure && snap)) return int(hipErrorInvalidValue);  // (dst == nullptr: the closure launch fills the snapshot only)
     if ((src && src == dst) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: the iterate is zero everywhere, nothing is read and dst may be the iterate itself)
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2739,7 +2675,7 @@ int launchStrokeFront(void *stream, const GridP &g, const BandBoxesDev &bx, floa
     const unsigned nshares = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
     const unsigned ng = unsigned(bx.ngroups), nb = ng + (nshares + kBoxThreads / 256 - 1) / (kBoxThreads / 256);
     const int32_t *chunks = list ? g.chunks : nullptr;
-#define MGPS_FRONT(G, Z) strokeFrontKernel<G, Z><<<nb, kBoxThreads, 0, s>>>(g, out, x, b, snap, bx.info, bx.list, bx.general, omega, bx.depth, ng, nshares, chunks, keep)
+#define MGPS_FRONT(G, Z) strokeFrontKernel<G, Z><<<nb, kBoxThreads, 0, s>>>(g, out, x, b, snap, bx.info, bx.list, bx.ulist, bx.uinfo, bx.general, omega, bx.depth, ng, nshares, chunks, keep)
     if (bx.anyGeneral) {
         if (x) MGPS_FRONT(true, false);
         else MGPS_FRONT(true, true);
@@ -2754,6 +2690,12 @@ int launchMarkClosure(void *stream, const GridP &g, const BandBoxesDev &bx, uint
 {
     if (bx.ngroups <= 0) return 0;
     markClosureKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(g, bx.info, bx.list, bits);
+    return int(hipGetLastError());
+}
+int launchMarkSnapTiles(void *stream, const GridP &g, const BandBoxesDev &bx, uint8_t *tiles)
+{
+    if (bx.ngroups <= 0) return 0;
+    markSnapTilesKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(g, bx.info, bx.list, tiles);
     return int(hipGetLastError());
 }
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half)
@@ -2867,23 +2809,24 @@ int launchZeroActiveHalf(void *stream, const GridP &g, void *aH)
 
 // dotPartials (optional): nmixed + npure slots, one per tile, mixed tiles first
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
-                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials)
+                  const int32_t *mixedTiles, int nmixed, const int32_t *tileBndStart, int forward, double *dotPartials, float *snap, const uint8_t *snapTile)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (snap && !snapTile) return int(hipErrorInvalidValue);
     // same colour => no two tiles of either launch share a face: the two launches are independent.  Up to three workgroups
     // per CU they go as one launch (tiledGSBothKernel)
     if (nmixed > 0 && npure > 0 && nmixed + npure <= 768) {
-        if (dotPartials) tiledGSBothKernel<true><<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward, dotPartials);
-        else tiledGSBothKernel<<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward);
+        if (dotPartials) tiledGSBothKernel<true><<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward, dotPartials, snap, snapTile);
+        else tiledGSBothKernel<<<unsigned(nmixed + npure), 256, 0, s>>>(g, x, b, mixedTiles, nmixed, pureTiles, tileBndStart, forward, nullptr, snap, snapTile);
         return int(hipGetLastError());
     }
     if (dotPartials) {
-        if (nmixed > 0) tiledGSMixedKernel<true><<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, dotPartials);
-        if (npure > 0) tiledGSPureKernel<true><<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, dotPartials + nmixed);
+        if (nmixed > 0) tiledGSMixedKernel<true><<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, dotPartials, MixScale{}, snap, snapTile);
+        if (npure > 0) tiledGSPureKernel<true><<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, dotPartials + nmixed, MixScale{}, snap, snapTile);
         return int(hipGetLastError());
     }
-    if (nmixed > 0) tiledGSMixedKernel<<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward);
-    if (npure > 0) tiledGSPureKernel<<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward);
+    if (nmixed > 0) tiledGSMixedKernel<<<unsigned(nmixed), 256, 0, s>>>(g, x, b, mixedTiles, tileBndStart, forward, nullptr, MixScale{}, snap, snapTile);
+    if (npure > 0) tiledGSPureKernel<<<unsigned(npure), 256, 0, s>>>(g, x, b, pureTiles, forward, nullptr, MixScale{}, snap, snapTile);
     return int(hipGetLastError());
 }
 
@@ -2969,8 +2912,9 @@ int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const fl
 }
 bool mixedPrecisionShapeOk(int nx, int ny, int nz) { return (nx & 3) == 0 && nx >= 8 && (ny & 1) == 0 && (nz & 1) == 0 && ny >= 4 && nz >= 2; }
 
-int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse)
+int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse, float *snap, const uint8_t *snapTile)
 {
+    if (snap && !snapTile) return int(hipErrorInvalidValue);
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
     static const bool perCell = [] {  // MGPS_PROLONG=quad: A/B switch for tuning runs
         const char *e = getenv("MGPS_PROLONG");
@@ -2986,12 +2930,12 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
         const size_t total = size_t(fine.nx >> 2) * npj * size_t(std::max(kp1 - kp0 + 1, 0));
         const unsigned nb = blocksFor(total, 256);
         if (nb > 0)
-            prolongAddBlockKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb, npj, kp0, total);
+            prolongAddBlockKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb, npj, kp0, total, 1.f, snap, snapTile);
     } else if ((fine.nx & 3) == 0 && fine.nx >= 8) {
         const unsigned nb = fine.chunks ? unsigned(fine.nchunks) / unsigned(kChunkCells / fine.chunkCells) : blocksFor(n >> 2, 256);
-        if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb);
+        if (nb > 0) prolongAddQuadKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, nb, snap, snapTile);
     } else
-        prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse);
+        prolongAddKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(fine, fineInOut, coarse, snap, snapTile);
     return int(hipGetLastError());
 }
 

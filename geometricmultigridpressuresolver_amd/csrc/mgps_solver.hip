@@ -67,6 +67,7 @@ struct DevLevel {
     uint32_t *nearBand = nullptr;
     float *stage = nullptr;
     uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
+    uint8_t *snapTile = nullptr;    // Gauss-Seidel strokes: a byte per 16^3 tile, set where a box group reads (launchMarkSnapTiles; made on first use)
     uint32_t *keepBits = nullptr;   // launchStrokeFront: one bit per cell, the owned band / closure-output cells of the boxes (made on first use)
     // fused band stage of a cut level (SlabHalo): one exchange per stage
     struct Halo {
@@ -432,9 +433,12 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.neighbours);
         (void)cacheFree(L.bandBoxes.info);
         (void)cacheFree(L.bandBoxes.list);
+        (void)cacheFree(L.bandBoxes.ulist);
+        (void)cacheFree(L.bandBoxes.uinfo);
         (void)cacheFree(L.nearBand);
         (void)cacheFree(L.planeFlags);
         (void)cacheFree(L.keepBits);
+        (void)cacheFree(L.snapTile);
         gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
@@ -703,8 +707,9 @@ int sweepSplit(mgps_solver *h, int l, StencilOp op, float *out, const float *x, 
     return MGPS_OK;
 }
 
+// snap: the tiles the band boxes read also leave their result in the level's residual grid (see gsStrokeSnapshots)
 int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int forward, GhostMode ghosts = GHOST_FULL, bool dot = false,
-                bool timed = false)
+                bool timed = false, bool snap = false)
 {
     DevLevel &L = h->lv[l];
     MGPS_TRY(exchangeGhosts(h, l, x, ghosts));  // the other colour's tiles across the cut changed in the previous pass
@@ -715,8 +720,34 @@ int gsHalfSweep(mgps_solver *h, int l, float *x, const float *b, int odd, int fo
     }
     if (timed) MGPS_TRY(profMark(h, true));
     MGPS_LAUNCH(h, launchTiledGS(h->stream, L.g, x, b, L.pure[odd], L.npure[odd], L.mixed[odd], L.nmixed[odd],
-                                 L.tileBndStart, forward, sink));
+                                 L.tileBndStart, forward, sink, snap ? L.r : nullptr, snap ? L.snapTile : nullptr));
     if (timed) MGPS_TRY(profMark(h, false));
+    return MGPS_OK;
+}
+
+// Gauss-Seidel strokes on a level with band boxes (round 4).  The sweep runs in place, so no closure launch can compute "what the
+// sweep will hold"; but the box launch only must not read what another group writes.  Whoever writes the iterate last before a
+// band stage therefore leaves a copy of the cells the boxes read in the level's residual grid (free during a stroke) -- the
+// Gauss-Seidel tile kernels after their colour pass, the prolongation in front of an up-stroke; only tiles flagged in
+// L.snapTile, a fifth of the tiles on the cube -- and the stage reads that snapshot and writes the iterate IN PLACE: one launch
+// per stage instead of "out of place + copy" (round 3: bandBoxCopyKernel 39 us per stage at 512^3, and the plugin's own
+// smoother 10 % slower than in round 2).  A stroke that starts from the cleared iterate needs no snapshot: nothing is read.
+// MGPS_GS_SNAPSHOT=0: the round-3 form (A/B).
+bool gsStrokeSnapshots(const mgps_solver *h, int l, const float *cur, const float *b)
+{
+    static const bool allowed = [] {
+        const char *e = getenv("MGPS_GS_SNAPSHOT");
+        return !(e && e[0] == '0');
+    }();
+    return allowed && h->useGS && !h->dist && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && cur != h->lv[l].r && b != h->lv[l].r;
+}
+int ensureSnapTiles(mgps_solver *h, int l)
+{
+    DevLevel &L = h->lv[l];
+    if (L.snapTile) return MGPS_OK;
+    const size_t nt = size_t((L.d.nx + kTile - 1) / kTile) * size_t((L.d.ny + kTile - 1) / kTile) * size_t((L.d.nz + kTile - 1) / kTile);
+    MGPS_TRY(devAlloc(h, &L.snapTile, nt, true));
+    MGPS_LAUNCH(h, launchMarkSnapTiles(h->stream, L.g, L.bandBoxes, L.snapTile));
     return MGPS_OK;
 }
 
@@ -803,10 +834,49 @@ int ensureKeepBits(mgps_solver *h, int l)
 // dot: see mgps_solver::gatherDot (the caller folds the partials afterwards)
 // xZero: `cur` is known to be zero everywhere and was NOT cleared (strokeTakesZero said the stroke needs no copy of it): the sweep
 // and the closure launch take the iterate as zero
-int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh, bool dot = false, bool xZero = false)
+// preSnap (Gauss-Seidel up-strokes): the prolongation left the band boxes' input in L.r (gsStrokeSnapshots)
+int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float *b, bool down, bool ghostsFresh, bool dot = false, bool xZero = false,
+                 bool preSnap = false)
 {
     DevLevel &L = h->lv[l];
     const bool bands = h->opt.band_iterations > 0;
+    if (gsStrokeSnapshots(h, l, cur, b)) {
+        MGPS_TRY(ensureSnapTiles(h, l));
+        const bool timed = h->profiling && l == 0;
+        {
+            StageScope scope(h, ST_BAND, l);
+            if (down && ghostsFresh)  // the iterate was cleared (MG.cpp:439-440, 566): nothing is read, the stage writes it in place
+                MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, nullptr, b, cur, nullptr, h->opt.jacobi_weight));
+            else if (preSnap)
+                MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight));
+            else
+                MGPS_TRY(bandPasses(h, l, cur, b, GHOST_NONE));
+        }
+        const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
+        for (int rep = 0; rep < reps; ++rep) {
+            StageScope scope(h, ST_SMOOTH, l);
+            const bool d = dot && rep == reps - 1, sn = rep == reps - 1;  // (the last sweep's values are the stage's input)
+            if (down) {  // odd tiles forward, then even tiles forward (MG.cpp:466-479)
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 1, GHOST_NONE, d, timed, sn));
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 1, GHOST_NONE, d, timed, sn));
+            } else {  // even tiles backward, then odd tiles backward (MG.cpp:740-751)
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 0, 0, GHOST_NONE, d, timed, sn));
+                MGPS_TRY(gsHalfSweep(h, l, cur, b, 1, 0, GHOST_NONE, d, timed, sn));
+            }
+            if (timed) ++h->profSweeps;
+        }
+        StageScope scope(h, ST_BAND, l);
+        double *sink = nullptr;
+        if (dot) {
+            sink = h->dotPartials + h->dotUsed;
+            h->dotUsed += unsigned(L.bandBoxes.ngroups);
+        }
+        if (reps > 0)
+            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sink, cur));
+        else
+            MGPS_TRY(bandPasses(h, l, cur, b, GHOST_NONE, dot));
+        return MGPS_OK;
+    }
     if (bands && !h->useGS && (down ? h->opt.pre_sweeps : h->opt.post_sweeps) == 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r) {
         // "band passes, sweep, band passes" in three launches, nothing scattered (launchBandBox): the closure launch, which
         // computes on the band closure what the sweep would write there after the band passes and leaves it as a snapshot in
@@ -1075,6 +1145,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
             DevLevel &F = h->lv[l];
             if (stopRequested()) return failH(h, MGPS_ERR_INTERRUPTED, "mgps_apply_vcycle: interrupted");
             const float *rhsUp = l == 0 ? b : F.b;
+            bool upSnap = false;
             if (!(h->gatherDot && l == 0) && prolongFusable(h, l, cur[l], other[l], rhsUp)) {
                 // prolongation + sweep in one pass over the level, then the two band stages as in smoothStroke: the closure launch
                 // reads x + 4 P e where the fused sweep left it for the quads near the band (F.stage)
@@ -1094,9 +1165,12 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
             {
                 StageScope scope(h, ST_PROLONG, l);
                 MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
-                MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
+                const bool snap = gsStrokeSnapshots(h, l, cur[l], rhsUp);
+                if (snap) MGPS_TRY(ensureSnapTiles(h, l));
+                MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1], snap ? F.r : nullptr, snap ? F.snapTile : nullptr));
+                upSnap = snap;
             }
-            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhsUp, false, false, h->gatherDot && l == 0));
+            MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhsUp, false, false, h->gatherDot && l == 0, false, upSnap));
         }
     }
     if (cur[0] != x)  // single-level Jacobi cycle: the iterate ended in the spare grid
@@ -1129,8 +1203,10 @@ int innerCycle(mgps_solver *h, int first, float **result)
     cur[nsmooth] = B.x;
     for (int l = nsmooth - 1; l >= first; --l) {
         DevLevel &F = h->lv[l];
-        MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1]));
-        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, false, false));
+        const bool snap = gsStrokeSnapshots(h, l, cur[l], F.b);
+        if (snap) MGPS_TRY(ensureSnapTiles(h, l));
+        MGPS_LAUNCH(h, launchProlongAdd(h->stream, F.g, cur[l], cur[l + 1], snap ? F.r : nullptr, snap ? F.snapTile : nullptr));
+        MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, false, false, false, false, snap));
     }
     *result = cur[first];
     return MGPS_OK;
@@ -1680,6 +1756,35 @@ struct StageClock {
 };
 
 // codesPreloaded: the caller allocated L.codes, copies the labels into it itself and patches the simple cells afterwards
+// The boxes of a level once info / list / general are on the device, whoever built them: the update lists (launchBandBoxUpdates)
+// and the launch order of the groups (orderBandBoxes; MGPS_BOX_ORDER=0 keeps the builders' tile order: A/B)
+int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
+{
+    BandBoxesDev &bx = L.bandBoxes;
+    MGPS_TRY(devAlloc(h, &bx.ulist, bx.listCount, true));  // (zeroed: the slots past a group's update count are never written, and tests compare the array)
+    MGPS_TRY(devAlloc(h, &bx.uinfo, size_t(kBoxUInfoInts) * size_t(bx.ngroups), false));
+    MGPS_LAUNCH(h, launchBandBoxUpdates(s, bx));
+    static const bool ordered = [] {
+        const char *e = getenv("MGPS_BOX_ORDER");
+        return !(e && e[0] == '0');
+    }();
+    if (!ordered || bx.ngroups < 64) return MGPS_OK;  // (fewer groups than a chiplet has in flight)
+    int32_t *info2 = nullptr, *uinfo2 = nullptr;
+    MGPS_TRY(devAlloc(h, &info2, size_t(kBoxInfoInts) * size_t(bx.ngroups), false));
+    MGPS_TRY(devAlloc(h, &uinfo2, size_t(kBoxUInfoInts) * size_t(bx.ngroups), false));
+    const int e = orderBandBoxes(s, L.d, bx.info, bx.uinfo, bx.ngroups, info2, uinfo2);
+    if (e != 0) {
+        (void)cacheFree(info2);
+        (void)cacheFree(uinfo2);
+        return failH(h, MGPS_ERR_HIP, std::string("orderBandBoxes: ") + hipGetErrorString(hipError_t(e)));
+    }
+    (void)cacheFree(bx.info);
+    (void)cacheFree(bx.uinfo);
+    bx.info = info2;
+    bx.uinfo = uinfo2;
+    return MGPS_OK;
+}
+
 int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1, int globalNz, bool withWeights,
                 bool workGrids, bool xbGrids, bool codesPreloaded = false)
 {
@@ -1722,7 +1827,7 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     MGPS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
     // band passes fuse only where no ghost exchange has to happen between them
     const bool cut = h->dist && (z0 > 0 || z1 < globalNz);
-    if (!cut && h->opt.fuse_band_passes && h->opt.band_iterations >= 1 && h->opt.band_iterations <= kBandMaxDepth && !HL.bandDev.empty()) {
+    if (!cut && h->opt.fuse_band_passes && h->opt.band_iterations >= 1 && h->opt.band_iterations <= kBandMaxDepth && !HL.bandDev.empty() && boxPlaneFits(L.d)) {
         StageClock gclock(h->opt.print_stats != 0);
         BandBoxes bx;
         buildBandBoxes(HL, h->opt.band_iterations, bx);
@@ -1736,6 +1841,7 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
         MGPS_TRY(devUpload(h, &L.bandBoxes.info, bx.info));
         MGPS_TRY(devUpload(h, &L.bandBoxes.list, bx.list));
         MGPS_TRY(devUpload(h, &L.bandBoxes.general, bx.general));
+        MGPS_TRY(finishBandBoxes(h, L, h->stream));
     }
     if (xbGrids) {
         MGPS_TRY(gridAlloc(h, &L.x, L.d));
@@ -2506,7 +2612,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     for (int l = 0; l < levels && wantGroups; ++l) {
         DevLevel &L = h->lv[size_t(l)];
         LevelTmp &t = T[size_t(l)];
-        if (t.nband == 0) continue;
+        if (t.nband == 0 || !boxPlaneFits(L.d)) continue;
         haveGroups[size_t(l)] = 1;
         ODS_TRY(tmp.get(h, &t.boxTiles, size_t(t.nt)));
         ODS_LAUNCH(launchBoxTileList(nullptr, L.d, t.tileStart, t.tileFlags, t.tileRank, t.boxTiles, t.scan));
@@ -2609,6 +2715,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         ODS_TRY(devAlloc(h, &L.bandBoxes.general, 2 * size_t(tot[2]), false));
         ODS_LAUNCH(launchBandBoxesFill(nullptr, L.d, labOf(l), t.mask, t.prefix, t.tileStart, t.bandEntry, L.bandDiag, o.band_iterations, t.boxTiles, t.nBoxTiles,
                                        t.gat, L.bandBoxes.info, L.bandBoxes.list, L.bandBoxes.general, flags + 2 * mgLevels + 2 + l));
+        ODS_TRY(finishBandBoxes(h, L, nullptr));
     }
     ODS_HIP(hipDeviceSynchronize());
     clock.lap("band boxes");
@@ -3196,6 +3303,8 @@ try {
     case 11: src = L.bandBoxes.info, n = size_t(kBoxInfoInts) * size_t(L.bandBoxes.ngroups); break;
     case 12: src = L.bandBoxes.list, n = L.bandBoxes.listCount; break;
     case 13: src = L.bandBoxes.general, n = L.bandBoxes.generalInts; break;
+    case 14: src = L.bandBoxes.ulist, n = L.bandBoxes.listCount; break;
+    case 15: src = L.bandBoxes.uinfo, n = size_t(kBoxUInfoInts) * size_t(L.bandBoxes.ngroups); break;
     default: return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: unknown array");
     }
     *count = int64_t(n);

@@ -190,8 +190,8 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_BOX_PIPE", "pool128"),
-                                         ("MGPS_BOX_PIPE", "plane992")])
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"),
+                                         ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
     MGPS_FUSE_DOWN (opt-in) -- the down-stroke from the zero iterate with the residual in the same pass
@@ -202,8 +202,9 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     (plane880: 880 active cells of a 1024-cell row; the sweep must visit fewer cells with the range on.)
     MGPS_FRONT_MAX_CELLS (default 2^24) -- the closure launch of the band boxes and the sweep of a stroke as ONE launch
     (launchStrokeFront: the sweep's stores masked on the band closure) on every level against three launches per stroke.
-    MGPS_BOX_PIPE (default on) -- the band boxes walked by persistent workgroups with the next group's loads in flight
-    (bandBoxPipeKernel; here with 8 workgroups, so that every one of them walks many groups) against one workgroup per group.
+    MGPS_GS_SNAPSHOT (default on; cases ending in "gs" run the tiled Gauss-Seidel smoother) -- the band stages of a Gauss-Seidel
+    stroke read a snapshot that the tile kernels / the prolongation left and write the iterate in place (or start from the
+    cleared iterate and read nothing) against "out of place, then copy".
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
@@ -213,6 +214,9 @@ sys.path.insert(0, %r)
 import geometricmultigridpressuresolver_amd as G
 from geometricmultigridpressuresolver_amd import domains as D
 case = sys.argv[2]
+gs = case.endswith("gs")
+if gs:
+    case = case[:-2]
 if case == "pool128":
     lab, w, dx = D.free_surface_pool(128, 4)
     lev = 4
@@ -228,7 +232,7 @@ else:
         bw.append(wa)
     dx = 1.0 / 992
     lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
-s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
+s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)
 if case != "pool128":
     assert s.stencil_kernel(0) == "plane"
 b = s.to_device(D.random_rhs(lab, dx))
@@ -237,9 +241,14 @@ s.applyVCycle(x, b, False)
 y = s.new_grid()
 y.copy_(x)
 s.applyVCycle(y, b, False)  # (again from zero: the same answer, and the grids have been through a swap)
+if gs:
+    u = s.new_grid()
+    u.copy_(x)
+    s.applyVCycle(u, b, True)  # (from an initial guess: the fine level's first band stage has no snapshot)
 z = s.new_grid()
 st = s.solveGeometricConjugateGradient(z, b, 1e-5, 8)
-np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), it=st["iterations"], swept=s.swept_cells(0)[0])
+np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), it=st["iterations"], swept=s.swept_cells(0)[0],
+         **({"u": u.cpu().numpy()} if gs else {}))
 """ % ROOT
     import tempfile
 
@@ -248,15 +257,12 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
             env = dict(os.environ, **{switch: {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else fuse})
-            if case != "pool128":
+            if not case.startswith("pool128"):
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
-            if switch == "MGPS_BOX_PIPE":
-                env["MGPS_BOX_PIPE_WG"] = "8"
-                env["MGPS_FRONT_MAX_CELLS"] = "0"  # (the merged front launch keeps the one-workgroup-per-group body)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
-    for key in ("x", "y", "z"):
+    for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
         assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
     assert int(outs[0]["it"]) == int(outs[1]["it"])
