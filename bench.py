@@ -145,7 +145,8 @@ def free_surface_pcg(args):
     out = {"metric": "MG-PCG solve", "grid": n, "levels": levels, "tolerance": 1e-5,
            "active_cells": int(D.active_mask(lab).sum()), "general_boundary_note": "ghost-fluid + cut-cell rows"}
     # the two smoothers with fp32 CG vectors, then the same with the CG vectors in fp64 (options.pcg_fp64_vectors)
-    for use_gs, fp64 in ((True, False), (False, False), (True, True), (False, True)):
+    # (... and with the iterate alone in fp64, options.pcg_fp64_vectors = 2)
+    for use_gs, fp64 in ((True, 0), (False, 0), (True, 2), (False, 2), (True, 1), (False, 1)):
         opt = G.default_options()
         opt.pcg_fp64_vectors = int(fp64)
         solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=0, options=opt)
@@ -156,7 +157,7 @@ def free_surface_pcg(args):
             st = solver.solveGeometricConjugateGradient(x, bd, 1e-5, 2500, True)
             if best is None or st["solve_ms"] < best["solve_ms"]:
                 best = st
-        key = ("tiled_gs" if use_gs else "jacobi") + ("_fp64_vectors" if fp64 else "")
+        key = ("tiled_gs" if use_gs else "jacobi") + {0: "", 1: "_fp64_vectors", 2: "_fp64_iterate"}[fp64]
         out[key] = {k: best[k] for k in ("outcome", "iterations", "rel_residual", "rel_residual_recomputed", "solve_ms")}
         if not fp64:
             # roofline of the whole iteration, Jacobi form: 132 algorithmic B per ACTIVE cell and iteration (DESIGN.md section 11:

@@ -477,8 +477,9 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
 // x += alpha p, r -= alpha t, *resultDev = sum of the new r^2 over active cells (one pass, CG.h:132-153)
 // alphaDev (optional): alpha = float(alphaDev[0] / alphaDev[1]) read on the device instead of the host's value
 // maxAbsDev (optional; `partials` then holds 2 x kReducePartials doubles): *maxAbsDev = max |r| of the new residual
+// xWide (optional): the iterate in fp64 (options.pcg_fp64_vectors = 2) -- updated instead of x, with alpha in double
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev = nullptr, double *maxAbsDev = nullptr);
+                   double *resultDev, const double *alphaDev = nullptr, double *maxAbsDev = nullptr, double *xWide = nullptr);
 // CG steps that read the mixed-precision V-cycle's binary16 result in place, z = (mul / *sigma) x~ (level g = the fine level;
 // the grid's dimensions need n % 4 == 0): *resultDev = <z, r>; p = z + beta p
 int launchHalfDot(void *stream, const GridP &g, const void *xH, const float *r, const float *sigmaDev, float mul, double *partials, double *resultDev);

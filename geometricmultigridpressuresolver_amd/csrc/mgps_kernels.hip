@@ -3249,7 +3249,7 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
                 }
             }
         }
-        {
+        if (out) {  // (out == nullptr: only float(out) is wanted -- the residual replacement of the fp64-iterate CG loop)
             typedef double d2 __attribute__((ext_vector_type(2)));
             reinterpret_cast<d2 *>(out + c0)[0] = d2{res[0], res[1]};
             reinterpret_cast<d2 *>(out + c0)[1] = d2{res[2], res[3]};
@@ -3277,7 +3277,7 @@ __global__ __launch_bounds__(256) void boundary64Kernel(GridP g, double *__restr
         lap -= double(r[4 * nb]) * x[c - sz];
         lap -= double(r[5 * nb]) * x[c + sz];
         const double res = MODE == 0 ? lap : double(b[c]) - lap;
-        out[c] = res;
+        if (out) out[c] = res;
         if (MODE == 1) out32[c] = float(res);
         acc += MODE == 0 ? x[c] * res : res * res;
     }
@@ -3467,13 +3467,22 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 
 // One pass for the two vector updates of a CG iteration and the norm that follows them (CG.h:132-153):
 // x += alpha p, r -= alpha t on active cells, partial sums of the new r^2 -- 25 B per cell instead of 13 + 13 + 5.
-__global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ x,
+// XT = double (options.pcg_fp64_vectors = 2): the ITERATE alone lives in fp64 -- x += alpha p with p widened, 33 B per cell; r, p
+// and A p stay fp32.  fp32 storage of x is what limits the recomputed residual b - A x (A fl(x) differs from A x by eps |A| |x|,
+// ghost-fluid weights up to 100), not the recurrence: see mgps_options::pcg_fp64_vectors
+template <class XT>
+__global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *__restrict__ lab, XT *__restrict__ x,
                                                       const float *__restrict__ p, float *__restrict__ r,
                                                       const float *__restrict__ t, float alpha, double *__restrict__ partials,
                                                       const int32_t *__restrict__ chunks, int nchunks, int chunkCells,
                                                       const double *__restrict__ alphaDev, double *__restrict__ maxPartials)
 {
-    if (alphaDev) alpha = float(alphaDev[0] / alphaDev[1]);  // <z, r> / <p, A p> left on the device by the reductions (CG.h:121)
+    constexpr bool kWide = std::is_same<XT, double>::value;
+    double alphaD = double(alpha);
+    if (alphaDev) {  // <z, r> / <p, A p> left on the device by the reductions (CG.h:121)
+        alphaD = alphaDev[0] / alphaDev[1];
+        alpha = float(alphaD);
+    }
     double acc = 0.0;
     float big = 0.f;  // max |r| of the new residual: the mixed-precision V-cycle normalises its rhs by it
     const size_t nq = n >> 2;
@@ -3481,19 +3490,35 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
     for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
-        float4 xv = reinterpret_cast<const float4 *>(x)[q], rv = reinterpret_cast<const float4 *>(r)[q];
+        float4 rv = reinterpret_cast<const float4 *>(r)[q];
         const float4 pv = reinterpret_cast<const float4 *>(p)[q], tv = reinterpret_cast<const float4 *>(t)[q];
-        if (activeLabel(l.x)) { xv.x = xv.x + alpha * pv.x; rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); big = fmaxf(big, fabsf(rv.x)); }
-        if (activeLabel(l.y)) { xv.y = xv.y + alpha * pv.y; rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); big = fmaxf(big, fabsf(rv.y)); }
-        if (activeLabel(l.z)) { xv.z = xv.z + alpha * pv.z; rv.z = rv.z + (-alpha) * tv.z; acc += double(rv.z) * double(rv.z); big = fmaxf(big, fabsf(rv.z)); }
-        if (activeLabel(l.w)) { xv.w = xv.w + alpha * pv.w; rv.w = rv.w + (-alpha) * tv.w; acc += double(rv.w) * double(rv.w); big = fmaxf(big, fabsf(rv.w)); }
-        reinterpret_cast<float4 *>(x)[q] = xv;
+        if (kWide) {
+            double2 *xq = reinterpret_cast<double2 *>(x) + 2 * q;
+            double2 xa = xq[0], xb = xq[1];
+            if (activeLabel(l.x)) xa.x += alphaD * double(pv.x);
+            if (activeLabel(l.y)) xa.y += alphaD * double(pv.y);
+            if (activeLabel(l.z)) xb.x += alphaD * double(pv.z);
+            if (activeLabel(l.w)) xb.y += alphaD * double(pv.w);
+            xq[0] = xa;
+            xq[1] = xb;
+        } else {
+            float4 xv = reinterpret_cast<const float4 *>(x)[q];
+            if (activeLabel(l.x)) xv.x = xv.x + alpha * pv.x;
+            if (activeLabel(l.y)) xv.y = xv.y + alpha * pv.y;
+            if (activeLabel(l.z)) xv.z = xv.z + alpha * pv.z;
+            if (activeLabel(l.w)) xv.w = xv.w + alpha * pv.w;
+            reinterpret_cast<float4 *>(x)[q] = xv;
+        }
+        if (activeLabel(l.x)) { rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); big = fmaxf(big, fabsf(rv.x)); }
+        if (activeLabel(l.y)) { rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); big = fmaxf(big, fabsf(rv.y)); }
+        if (activeLabel(l.z)) { rv.z = rv.z + (-alpha) * tv.z; acc += double(rv.z) * double(rv.z); big = fmaxf(big, fabsf(rv.z)); }
+        if (activeLabel(l.w)) { rv.w = rv.w + (-alpha) * tv.w; acc += double(rv.w) * double(rv.w); big = fmaxf(big, fabsf(rv.w)); }
         reinterpret_cast<float4 *>(r)[q] = rv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t c = (nq << 2) + threadIdx.x;
         if (activeLabel(lab[c])) {
-            x[c] = x[c] + alpha * p[c];
+            x[c] = kWide ? XT(double(x[c]) + alphaD * double(p[c])) : XT(float(x[c]) + alpha * p[c]);
             r[c] = r[c] + (-alpha) * t[c];
             acc += double(r[c]) * double(r[c]);
             big = fmaxf(big, fabsf(r[c]));
@@ -3509,13 +3534,14 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
 }
 
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev, double *maxAbsDev)
+                   double *resultDev, const double *alphaDev, double *maxAbsDev, double *xWide)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
     double *maxPartials = maxAbsDev ? partials + kReducePartials : nullptr;  // (`partials` holds 2 x kReducePartials doubles)
-    cgUpdateKernel<<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
+    if (xWide) cgUpdateKernel<double><<<nb, 256, 0, s>>>(n, g.lab, xWide, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
+    else cgUpdateKernel<float><<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
     reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
     if (maxAbsDev) reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), maxPartials, maxAbsDev);
     return int(hipGetLastError());

@@ -221,37 +221,35 @@ struct DeviceCache {
         void *p;
         uint64_t age;  // release order: the oldest cached block is the first to go when the cap is reached
     };
+    using FreeMap = std::multimap<std::pair<int, size_t>, Block>;
     std::mutex guard;
-    std::multimap<std::pair<int, size_t>, Block> free;           // (device, bytes) -> block not in use
-    std::map<uint64_t, std::multimap<std::pair<int, size_t>, Block>::iterator> byAge;
+    FreeMap free;                                                 // (device, bytes) -> block not in use
     std::unordered_map<void *, std::pair<int, size_t>> live;     // every block of the library, in use or cached
-    size_t cached = 0;
     uint64_t clock = 0;
-    // cap: MGPS_DEVICE_CACHE_MB, else a quarter of the device's memory (72 of 288 GiB: a 1024^3 solver holds ~45 GiB, so the
-    // plugin's solver-per-sub-step pattern still finds all of its blocks again) -- the rest stays with whoever else
-    // allocates in the process (torch, RCCL, Houdini's own GPU users)
-    size_t cap = 0;
-    bool capKnown = false;
-    void findCap()
-    {
-        if (capKnown) return;
-        capKnown = true;
-        if (const char *e = getenv("MGPS_DEVICE_CACHE_MB")) {
-            cap = size_t(std::max(0, atoi(e))) << 20;
-            return;
-        }
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) cap = totalB / 4;
-        else {
-            (void)hipGetLastError();
-            cap = size_t(16) << 30;
-        }
-    }
+    // cached bytes, age list and cap PER DEVICE (a process that drives several GPUs: one device's releases never evict
+    // another device's blocks, and every device gets the whole cap).  cap: MGPS_DEVICE_CACHE_MB, else a quarter of that
+    // device's memory (72 of 288 GiB: a 1024^3 solver holds ~45 GiB, so the plugin's solver-per-sub-step pattern still finds
+    // all of its blocks again) -- the rest stays with whoever else allocates in the process (torch, RCCL, Houdini's own GPU
+    // users).  It is read on the device's first allocation, with that device current and outside the lock.
+    struct PerDevice {
+        size_t cached = 0, cap = 0;
+        bool capKnown = false;
+        std::map<uint64_t, FreeMap::iterator> byAge;
+    };
+    std::map<int, PerDevice> dev;
 };
 DeviceCache &deviceCache()
 {
     static DeviceCache *c = new DeviceCache();  // never destroyed (process tear-down order)
     return *c;
+}
+size_t deviceCapOfCurrent()
+{
+    if (const char *e = getenv("MGPS_DEVICE_CACHE_MB")) return size_t(std::max(0, atoi(e))) << 20;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) return totalB / 4;
+    (void)hipGetLastError();
+    return size_t(16) << 30;
 }
 size_t deviceRounded(size_t bytes)
 {
@@ -268,8 +266,10 @@ void deviceTrimLocked(DeviceCache &c, std::vector<void *> &drop)
         c.live.erase(b.second.p);
     }
     c.free.clear();
-    c.byAge.clear();
-    c.cached = 0;
+    for (auto &d : c.dev) {
+        d.second.byAge.clear();
+        d.second.cached = 0;
+    }
 }
 }  // namespace
 namespace mgps {
@@ -279,15 +279,27 @@ int deviceAlloc(void **p, size_t bytes)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t want = deviceRounded(bytes);
+    bool needCap = false;
     {
         std::lock_guard<std::mutex> lock(c.guard);
+        DeviceCache::PerDevice &D = c.dev[dev];
+        needCap = !D.capKnown;
         const auto it = c.free.find({dev, want});
         if (it != c.free.end()) {
             *p = it->second.p;
-            c.cached -= want;
-            c.byAge.erase(it->second.age);
+            D.cached -= want;
+            D.byAge.erase(it->second.age);
             c.free.erase(it);
             return hipSuccess;
+        }
+    }
+    if (needCap) {
+        const size_t cap = deviceCapOfCurrent();
+        std::lock_guard<std::mutex> lock(c.guard);
+        DeviceCache::PerDevice &D = c.dev[dev];
+        if (!D.capKnown) {
+            D.cap = cap;
+            D.capKnown = true;
         }
     }
     hipError_t e = hipMalloc(p, want);
@@ -307,8 +319,9 @@ int deviceAlloc(void **p, size_t bytes)
     return hipSuccess;
 }
 // (unlike hipFree this does not wait for the device: callers release only what no queued kernel touches any more)
-// A block larger than the cap goes straight back to the driver; otherwise it is kept and the OLDEST cached blocks are
-// returned until the cache fits its cap again (sizes nobody asks for any more age out instead of pinning the cache full).
+// A block larger than the cap goes straight back to the driver; otherwise it is kept and the OLDEST cached blocks of ITS device
+// are returned until that device's cache fits its cap again (sizes nobody asks for any more age out instead of pinning the
+// cache full).
 int deviceFree(void *p)
 {
     if (!p) return hipSuccess;
@@ -316,23 +329,25 @@ int deviceFree(void *p)
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lock(c.guard);
-        c.findCap();
         const auto it = c.live.find(p);
         if (it == c.live.end()) drop.push_back(p);  // (not ours: plain hipFree)
-        else if (it->second.second > c.cap) {
-            c.live.erase(it);
-            drop.push_back(p);
-        } else {
-            const uint64_t age = c.clock++;
-            c.byAge[age] = c.free.emplace(it->second, DeviceCache::Block{p, age});
-            c.cached += it->second.second;
-            while (c.cached > c.cap && !c.byAge.empty()) {
-                const auto oldest = c.byAge.begin()->second;
-                drop.push_back(oldest->second.p);
-                c.cached -= oldest->first.second;
-                c.live.erase(oldest->second.p);
-                c.free.erase(oldest);
-                c.byAge.erase(c.byAge.begin());
+        else {
+            DeviceCache::PerDevice &D = c.dev[it->second.first];  // (its cap was read when the block was allocated)
+            if (it->second.second > D.cap) {
+                c.live.erase(it);
+                drop.push_back(p);
+            } else {
+                const uint64_t age = c.clock++;
+                D.byAge[age] = c.free.emplace(it->second, DeviceCache::Block{p, age});
+                D.cached += it->second.second;
+                while (D.cached > D.cap && !D.byAge.empty()) {
+                    const auto oldest = D.byAge.begin()->second;
+                    drop.push_back(oldest->second.p);
+                    D.cached -= oldest->first.second;
+                    c.live.erase(oldest->second.p);
+                    c.free.erase(oldest);
+                    D.byAge.erase(D.byAge.begin());
+                }
             }
         }
     }
@@ -1549,7 +1564,7 @@ int interruptRequested(mgps_solver *h, bool *stop)
 int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool useMG, mgps_pcg_stats *st)
 {
     DevLevel &F = h->lv[0];
-    if (h->opt.pcg_fp64_vectors) {
+    if (h->opt.pcg_fp64_vectors == 1) {
         mgps_pcg_stats local64{};
         if (!st) st = &local64;
         std::memset(st, 0, sizeof(*st));
@@ -1560,12 +1575,34 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     std::memset(st, 0, sizeof(*st));
     MGPS_TRY(ensurePcgGrids(h, !useMG));
     float *r = h->pcg[0], *p = h->pcg[1], *z = h->pcg[2], *t = h->pcg[3];
+    // options.pcg_fp64_vectors = 2: the iterate alone in fp64 (round 4).  What keeps the recomputed residual b - A x of the fp32
+    // loop at eps * cond (2.8e-3 at 512^3, 2e-2 at 1024^3 on the free-surface pool, while the pressure is 4e-7 from the oracle's)
+    // is the fp32 STORAGE of x: the loop then carries x in fp64 (x += alpha p, 8 B more per cell and iteration), takes the
+    // residuals of CG.h:50-51 and 203-205 in fp64 from it and hands back the rounded x; r, p, A p and the V-cycle stay fp32
+    const bool wideX = h->opt.pcg_fp64_vectors == 2 && !(useMG && h->opt.precision == 1);
+    double *x64 = nullptr;
+    if (wideX) {
+        const size_t plane = size_t(F.d.nx) * F.d.ny;
+        if (!h->cg64[0]) {
+            double *base = nullptr;
+            MGPS_TRY(devAlloc(h, &base, F.d.cells() + 2 * plane, true));
+            h->cg64[0] = base + plane;
+        }
+        x64 = h->cg64[0];
+    }
     SolveClock clock(h);  // (destroys its events and resets h->dotTarget on every way out)
     if (!clock.ok) return failH(h, MGPS_ERR_HIP, "hipEventCreate failed");
     auto finish = [&](int outcome) {
+        if (wideX && outcome != MGPS_PCG_RHS_ZERO) (void)launchNarrow(h->stream, x, x64, F.d.cells());  // (what the iterations reached, rounded once)
         st->outcome = outcome;
         st->solve_ms = clock.stop();
         return MGPS_OK;
+    };
+    // r = b - A x from the wide iterate: the fp64 stencil pass of the fp64-vector loop (it leaves float(r) in r32 and |r|^2 on the device)
+    auto wideResidual = [&](double *res2) -> int {
+        MGPS_TRY(exchangeGhosts64(h, x64));
+        MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, nullptr, x64, b, r, h->dotPartials, h->dotCapacity, h->resultDev));
+        return fetchReduction(h, 1, res2);
     };
     // dst = M src; gathered: <dst, src> is already in h->resultDev (a by-product of the V-cycle's last stroke)
     bool gathered = false;
@@ -1600,9 +1637,14 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_TRY(reduceToHost(h, 1, 0, b, nullptr, &rhs2));  // CG.h:35
     st->rhs_norm2 = rhs2;
     if (rhs2 == 0) return finish(MGPS_PCG_RHS_ZERO);  // CG.h:36-40
-    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:50-51
     double res2 = 0;
-    MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));  // CG.h:57
+    if (wideX) {
+        MGPS_LAUNCH(h, launchWiden(h->stream, x64, x, F.d.cells()));
+        MGPS_TRY(wideResidual(&res2));  // CG.h:50-57 (r = float of the fp64 residual)
+    } else {
+        MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:50-51
+        MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &res2));  // CG.h:57
+    }
     const double threshold = tol * tol * rhs2;           // CG.h:58
     if (res2 < threshold) {                              // CG.h:60-64
         st->rel_residual = st->rel_residual_recomputed = std::sqrt(res2 / rhs2);
@@ -1641,7 +1683,12 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_LAUNCH(h, launchZero(h->stream, z, F.d.cells()));
     MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
-    bool converged = false;
+    bool converged = false, rFresh = false;
+    static const int wideReplaceEvery = [] {  // MGPS_WIDE_REPLACE=N (tuning runs): iterations between two residual replacements
+        const char *e = getenv("MGPS_WIDE_REPLACE");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 8;
+    }();
     for (; it < maxIt; ++it) {
         bool stop = false;
         MGPS_TRY(interruptRequested(h, &stop));
@@ -1663,7 +1710,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
         const bool mixed = useMG && h->opt.precision == 1;  // the pass also leaves max |r| for the cycle's normalisation
         MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr,
-                                      mixed ? h->mixMax : nullptr));
+                                      mixed ? h->mixMax : nullptr, x64));
         if (devScal && h->dist) {  // |r|^2 summed on the device too: the fetch below is then the iteration's only host round trip
             MGPS_TRY(sumOverRanks(h->resultDev));
             MGPS_HIP(h, hipMemcpyAsync(h->resultHost, h->resultDev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1671,6 +1718,16 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
             res2 = *h->resultHost;
         } else
             MGPS_TRY(fetchReduction(h, 1, &res2));
+        // fp64 iterate: the recurrence r -= alpha A p drifts from b - A x by the rounding of the fp32 products it sums (5e-4 of |b|
+        // after 23 iterations on the 512^3 pool).  Every few iterations, and whenever the recurrence claims convergence, r is
+        // REPLACED by the true residual float(b - A x) taken in fp64 from the wide iterate (residual replacement, van der Vorst
+        // & Ye 2000): the drift a solve ends with is what the last few -- by then tiny -- updates added, and "converged" is
+        // only ever said of a true residual.  One fp64 stencil pass per replacement.
+        rFresh = false;
+        if (wideX && (res2 < threshold || (it + 1) % wideReplaceEvery == 0)) {
+            MGPS_TRY(wideResidual(&res2));
+            rFresh = true;
+        }
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
         if (res2 < threshold) {  // CG.h:161 -- the counter is not advanced on the exit pass
@@ -1712,9 +1769,13 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     h->dotTarget = nullptr;
     st->iterations = it;
     st->rel_residual = std::sqrt(res2 / rhs2);      // CG.h:199
-    MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:203-204
     double rec2 = 0;
-    MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &rec2));
+    if (wideX && rFresh) rec2 = res2;  // (the loop's last test was on the true residual of this iterate)
+    else if (wideX) MGPS_TRY(wideResidual(&rec2));  // CG.h:203-205 on the iterate the loop carried
+    else {
+        MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:203-204
+        MGPS_TRY(reduceToHost(h, 1, 0, r, nullptr, &rec2));
+    }
     st->rel_residual_recomputed = std::sqrt(rec2 / rhs2);  // CG.h:205
     return finish(converged ? MGPS_PCG_CONVERGED : MGPS_PCG_MAX_ITERATIONS);
 }
@@ -1919,8 +1980,22 @@ struct DeviceInverse {
     std::vector<uint8_t> labels;
     ~DeviceInverse() { (void)cacheFree(p); }
 };
+// The device-built inverses are kept past their solvers (the plugin makes a solver per sub-step, and a 32^3 coarsest level costs a
+// potrf + potri): the most recent kDevInverseKeptPerDevice label patterns of every device, most recent first.  They are
+// outside the block cache while kept (n * n floats: 0.7 GB for config 5, up to 4.3 GB at the 32768-unknown cap), so
+// mgps_trim_device_cache drops them too -- a solver that still uses one keeps it alive through its shared_ptr -- and an entry
+// pushed out of the list goes back to the block cache, where the LRU eviction and the cap see it.
+constexpr size_t kDevInverseKeptPerDevice = 2;
 std::mutex gDevInverseGuard;
-std::shared_ptr<DeviceInverse> gDevInverseKept;  // the most recent one
+std::vector<std::shared_ptr<DeviceInverse>> gDevInverseKept;
+void dropKeptInverses()
+{
+    std::vector<std::shared_ptr<DeviceInverse>> drop;
+    {
+        std::lock_guard<std::mutex> lock(gDevInverseGuard);
+        drop.swap(gDevInverseKept);
+    }
+}  // (the destructors run here, outside the lock: cacheFree takes the block cache's own)
 
 int buildDeviceInverse(mgps_solver *h)
 {
@@ -1929,12 +2004,15 @@ int buildDeviceInverse(mgps_solver *h)
     const int n = hier->coarseN;
     {
         std::lock_guard<std::mutex> lock(gDevInverseGuard);
-        const auto &k = gDevInverseKept;
-        if (k && k->n == n && k->device == h->device && k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->labels.size() == C.labels.size() &&
-            std::memcmp(k->labels.data(), C.labels.data(), C.labels.size()) == 0) {
-            h->cinvShared = k;
-            h->cinv = k->p;
-            return MGPS_OK;
+        for (size_t q = 0; q < gDevInverseKept.size(); ++q) {
+            const std::shared_ptr<DeviceInverse> k = gDevInverseKept[q];
+            if (k->n == n && k->device == h->device && k->d.nx == C.d.nx && k->d.ny == C.d.ny && k->d.nz == C.d.nz && k->labels.size() == C.labels.size() &&
+                std::memcmp(k->labels.data(), C.labels.data(), C.labels.size()) == 0) {
+                std::rotate(gDevInverseKept.begin(), gDevInverseKept.begin() + ptrdiff_t(q), gDevInverseKept.begin() + ptrdiff_t(q) + 1);  // most recent first
+                h->cinvShared = k;
+                h->cinv = k->p;
+                return MGPS_OK;
+            }
         }
     }
     static HipSolver *solver = new HipSolver();  // (never unloaded: process tear-down order)
@@ -1993,8 +2071,19 @@ int buildDeviceInverse(mgps_solver *h)
     inv->labels.assign(C.labels.begin(), C.labels.end());
     h->cinvShared = inv;
     h->cinv = inv->p;
-    std::lock_guard<std::mutex> lock(gDevInverseGuard);
-    gDevInverseKept = inv;
+    std::vector<std::shared_ptr<DeviceInverse>> pushedOut;  // (released after the lock)
+    {
+        std::lock_guard<std::mutex> lock(gDevInverseGuard);
+        gDevInverseKept.insert(gDevInverseKept.begin(), inv);
+        size_t sameDevice = 0;
+        for (size_t q = 0; q < gDevInverseKept.size();) {
+            if (gDevInverseKept[q]->device == h->device && ++sameDevice > kDevInverseKeptPerDevice) {
+                pushedOut.push_back(gDevInverseKept[q]);
+                gDevInverseKept.erase(gDevInverseKept.begin() + ptrdiff_t(q));
+            } else
+                ++q;
+        }
+    }
     return MGPS_OK;
 }
 
@@ -2745,6 +2834,7 @@ void mgps_trim_host_cache(void) { pinnedTrim(); }
 void mgps_trim_device_cache(void)
 {
     (void)hipDeviceSynchronize();
+    dropKeptInverses();  // (their blocks land in the cache that is emptied next)
     deviceTrim();
 }
 
@@ -3031,8 +3121,9 @@ try {
     *out = nullptr;
     if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm || !splits)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: labels, the slab weights, a comm and the cuts are required");
-    if (comm->struct_size != int(sizeof(mgps_comm)) || !comm->exchange || !comm->allreduce || !comm->gather || !comm->scatter ||
-        comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
+    // (a transport built against the header before `allreduce_device` was appended is accepted: the missing tail reads as NULL)
+    if (comm->struct_size < int(offsetof(mgps_comm, allreduce_device)) || comm->struct_size > int(sizeof(mgps_comm)) || !comm->exchange || !comm->allreduce ||
+        !comm->gather || !comm->scatter || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
         return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: incomplete mgps_comm");
     const int P = comm->size, rank = comm->rank;
     bool cutsOk = splits[0] == 0 && splits[P] == nz_global, even = true;
@@ -3071,7 +3162,9 @@ try {
     h->useGS = use_gauss_seidel != 0;
     h->device = device;
     h->dist = true;
-    h->comm = *comm;
+    h->comm = mgps_comm{};
+    std::memcpy(&h->comm, comm, size_t(comm->struct_size));  // (struct_size bytes are the caller's; the rest stays NULL)
+    h->comm.struct_size = int(sizeof(mgps_comm));
     {
         // MGPS_OVERLAP=1: exchanges beside the sweeps (see sweepSplit).  Off by default: on one GPU with a null transport the
         // split launches and the two event hops cost the slowest rank 0.07 ms of a 1.75 ms cycle at 1024^3 / 8 ranks (rank 0:

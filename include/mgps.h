@@ -89,7 +89,10 @@ typedef struct mgps_options {
                                true one instead of flooring at eps * cond (3e-3 at 512^3, 2e-2 at 1024^3 on the
                                free-surface case), for +15..21 % solve time at 512^3 (round 3: 16-byte accesses in the fp64 passes; +31..40 % before),
                                +30..36 % at 1024^3.  Slab runs exchange the ghost planes of
-                               these vectors as doubles */
+                               these vectors as doubles.  2 (round 4): the ITERATE alone in fp64 -- x += alpha p with p
+                               widened, the residuals of CG.h:50-51 and 203-205 taken in fp64 from it, r, p, A p fp32 as in
+                               mode 0: what holds the recomputed residual of mode 0 at eps * cond is the fp32 storage of x
+                               (A fl(x) is eps |A| |x| away from A x whatever multiplies it), not the recurrence */
     int (*interrupt)(void *user); /* non-zero stops the call with MGPS_ERR_INTERRUPTED (UT_Interrupt::opInterrupt, which the
                                      reference polls in every operator loop, e.g. Ops.h:319).  Polled before every PCG
                                      iteration and, on single-device solvers, before every level of both strokes of a
@@ -241,7 +244,9 @@ void mgps_trim_host_cache(void);
 /* Device memory released by a solver (or by mgps_project_free_surface) is kept for the next one: once a process holds
  * tens of GiB, hipMalloc costs 60-130 ms per 4 GiB block and every hipFree 0.2 ms on this platform, more than the solve
  * (cap: MGPS_DEVICE_CACHE_MB, default a quarter of the device memory, oldest blocks leave first; an allocation that fails trims the cache and tries again).  This returns
- * the cached blocks to the system, e.g. before another library needs the memory. */
+ * the cached blocks to the system, e.g. before another library needs the memory -- including the dense inverses of large
+ * coarsest levels that the library keeps past their solvers (the two most recent label patterns per device; a live solver
+ * keeps its own). */
 void mgps_trim_device_cache(void);
 /* Page-locked host memory for the caller's staging buffers (the flattened fields a Houdini shim uploads every
  * sub-step).  On this platform a hipMemcpy out of a fresh pageable array runs at about 3 GB/s, out of a page-locked one
@@ -337,7 +342,7 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
  * All pointers handed to exchange / gather / scatter are device pointers; `hip_stream` is the
  * solver's stream: an implementation either enqueues on it or synchronises it and blocks. */
 typedef struct mgps_comm {
-    int struct_size; /* sizeof(mgps_comm) */
+    int struct_size; /* sizeof(mgps_comm) as the caller was compiled: members appended later (allreduce_device) may be missing and read as NULL */
     int rank, size;
     void *user;
     /* send `send_lo` (send_lo_bytes) to rank-1 and receive recv_lo_bytes from it into `recv_lo`; the

@@ -1,0 +1,2 @@
+#pragma once
+#include "SIM_Mock.h"

@@ -94,3 +94,26 @@ def test_flatten_roundtrip_and_cmake_configures_without_houdini(tmp_path):
                   '"validFaces"', "SIM_NAME_TOLERANCE", '"maxIterations"', '"useMGPreconditioner"', "initializeSIM", "mgps_project_free_surface"):
         assert token in shim, token
     assert "DECLARE_DATAFACTORY(HDK_GeometricFreeSurfacePressureSolver, GAS_SubSolver" in header and "solveGasSubclass" in header
+
+
+def test_dop_shim_compiles_against_hdk_mock(tmp_path):
+    """The DOP shim (host/HDK_GeometricFreeSurfacePressureSolver.{h,cpp}: the reference's node surface,
+    /root/reference/Source/HDK_GeometricFreeSurfacePressureSolver.h:14-55, around ONE mgps_project_free_surface call) goes
+    through the compiler front end against tests/hdk_mock/ -- declarations of the slice of the HDK it calls, test
+    infrastructure only -- so that a drift of include/mgps_fields.h (mgps_projection's members) or include/mgps.h under the
+    shim breaks a test on a machine without Houdini.  The check must bite: the same compile with one member of
+    mgps_projection renamed in a copy of the header fails."""
+    import shutil
+
+    host = os.path.join(ROOT, "geometricmultigridpressuresolver_amd", "host")
+    shim = os.path.join(host, "HDK_GeometricFreeSurfacePressureSolver.cpp")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "hdk_mock"), "-I" + host]
+    ok = subprocess.run(base + ["-I" + os.path.join(ROOT, "include"), shim], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stdout[-4000:]
+    drift = tmp_path / "include"
+    shutil.copytree(os.path.join(ROOT, "include"), drift)
+    text = (drift / "mgps_fields.h").read_text()
+    assert "use_gauss_seidel" in text
+    (drift / "mgps_fields.h").write_text(text.replace("use_gauss_seidel", "use_gauss_seidel_renamed"))
+    bad = subprocess.run(base + ["-I" + str(drift), shim], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert bad.returncode != 0 and "use_gauss_seidel" in bad.stdout

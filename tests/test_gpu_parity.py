@@ -837,6 +837,49 @@ def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
     gpu.close()
 
 
+def test_plane_sweep_by_size_matches_oracle(oracle, torch_cuda):
+    """The plane-marching sweep reached by the SIZE rule (no option, no environment): x-y planes of 1280 x 1024 cells
+    = 5 MiB > kPlaneSweepMinPlaneBytes -- the production path of every level with planes larger than 1024^2, with its two
+    planes of look-ahead, the zero-start variant and the active x range (1248 active cells of a 1280-cell row).  Against the
+    oracle on the same 63 M cells: residual, one Jacobi sweep and two V-cycles, the second from the first one's result."""
+    import geometricmultigridpressuresolver_amd as G
+    from geometricmultigridpressuresolver_amd import domains as D
+
+    shape = (16, 992, 1248)
+    z, y, x = np.meshgrid(np.arange(16) / 16, np.arange(992) / 992, np.arange(1248) / 1248, indexing="ij")
+    phi = y - 0.5 + 0.02 * np.sin(4.0 * np.pi * z) + 0.0 * x
+    del z, y, x
+    bl, bw, dx = D._complex_from_phi(phi, shape, True, (0.4, 0.6), np.float32, 1.0 / 992)
+    del phi
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(48, 1024, 1280))
+    gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
+    assert gpu.stencil_kernel(0) == "plane" and gpu.stencil_kernel(1) == "quad"
+    lab32 = lab.astype(np.int32)
+    w64 = [a.astype(np.float64) for a in w]
+    x0 = _rand_active(lab, 1)
+    b0 = _rand_active(lab, 2, dx * dx)
+    xd, bd = gpu.to_device(x0), gpu.to_device(b0)
+    ref = np.zeros_like(x0)
+    oracle.residual(ref, x0, b0, lab32, w64)
+    rd = gpu.new_grid()
+    gpu.computePoissonResidual(rd, xd, bd)
+    assert rel_err(rd.cpu().numpy(), ref) < OP_TOL
+    xj = x0.copy()
+    oracle.jacobi(xj, b0, lab32, w64)
+    gpu.jacobiPoissonSmoother(xd, bd)
+    assert rel_err(xd.cpu().numpy(), xj) < OP_TOL
+    del ref, xj, rd
+    orc = oracle.solver(lab32, w64, lev, False)
+    x_ref = np.zeros(lab.shape)
+    b_as_f32 = bd.cpu().numpy().astype(np.float64)
+    xs = gpu.new_grid()
+    for it in range(2):
+        orc.apply_vcycle(x_ref, b_as_f32, it > 0)
+        gpu.applyVCycle(xs, bd, it > 0)
+        assert rel_l2(xs.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
+    gpu.close()
+
+
 # ---- BASELINE configs 1 and 3 as stated -----------------------------------------------------------------------------
 def test_config1_128_L4_2plus2(oracle, torch_cuda):
     """BASELINE config 1: 128^3 interior-liquid cube, 4-level V-cycle, 2+2 damped-Jacobi sweeps (options.pre_sweeps =

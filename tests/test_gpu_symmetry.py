@@ -190,7 +190,7 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"),
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -205,6 +205,9 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     MGPS_GS_SNAPSHOT (default on; cases ending in "gs" run the tiled Gauss-Seidel smoother) -- the band stages of a Gauss-Seidel
     stroke read a snapshot that the tile kernels / the prolongation left and write the iterate in place (or start from the
     cleared iterate and read nothing) against "out of place, then copy".
+    MGPS_ZERO_START (default on) -- down-strokes that start from the zero iterate take it as zero instead of clearing and
+    reading the grid: the never-cleared grids then hold the previous cycle's values (the second cycle and the PCG run on such
+    stale grids), which must not reach the result -- the invariant behind the shortcut.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""

@@ -24,7 +24,8 @@ python tools/slab_compute_bound.py 1024 > gpurun_out/${round}_slab_compute_bound
 python tools/slab_setup_time.py 1024 8 3 > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
 for sz in 256 512; do
   rocprofv3 --kernel-trace -d gpurun_out/tl_$sz --output-format csv -- python3 bench.py --size $sz --steps 6 --warmup 2 --no-cpu --no-frac512 > /dev/null 2>&1
-  python3 tools/cycle_timeline.py gpurun_out/tl_$sz 7 > gpurun_out/${round}_cycle_timeline_$sz.txt  # (a cycle of the timed region: the last five carry the stage timers); rm -rf gpurun_out/tl_$sz
+  python3 tools/cycle_timeline.py gpurun_out/tl_$sz 7 > gpurun_out/${round}_cycle_timeline_$sz.txt  # (a cycle of the timed region: the last five carry the stage timers)
+  rm -rf gpurun_out/tl_$sz
 done
 python - <<PY
 import json, glob
