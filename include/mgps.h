@@ -82,7 +82,7 @@ typedef struct mgps_options {
     int min_cells_per_rank; /* slab runs: a level below the finest stays distributed only while every rank owns at least
                                this many cells of it (default 2097152 = 128^3); smaller levels are gathered to rank 0,
                                where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
-    int pcg_fp64_vectors;   /* 0 (default): the CG vectors x, r, p, A p are fp32 like every grid.  1: mgps_solve_pcg keeps
+    int pcg_fp64_vectors;   /* 0: the CG vectors x, r, p, A p are fp32 like every grid (the default of rounds 1-3).  1: mgps_solve_pcg keeps
                                them in fp64 (the reference's precision, MG.h:14-15) around the unchanged fp32 V-cycle;
                                x and b stay fp32 at the boundary.  Same iteration counts either way (measured at 512^3
                                and 1024^3); with fp64 vectors the residual recomputed at the end (CG.h:203-206) is a
@@ -92,7 +92,12 @@ typedef struct mgps_options {
                                these vectors as doubles.  2 (round 4): the ITERATE alone in fp64 -- x += alpha p with p
                                widened, the residuals of CG.h:50-51 and 203-205 taken in fp64 from it, r, p, A p fp32 as in
                                mode 0: what holds the recomputed residual of mode 0 at eps * cond is the fp32 storage of x
-                               (A fl(x) is eps |A| |x| away from A x whatever multiplies it), not the recurrence */
+                               (A fl(x) is eps |A| |x| away from A x whatever multiplies it) and, behind it, the drift of the
+                               fp32 recurrence (5e-4 on the 512^3 pool), which the loop removes by REPLACING r with
+                               float(b - A x) every 8 iterations and whenever the recurrence claims convergence
+                               (residual replacement).  DEFAULT since round 4: same iteration counts (+-1), "Recomputed
+                               relative L2 Error" (CG.h:203-206) equal to the recurrence's, +3..5 % solve time at 512^3,
+                               +8..9 % at 1024^3, 8 B per fine cell of memory.  Not with precision = 1 (falls back to 0) */
     int (*interrupt)(void *user); /* non-zero stops the call with MGPS_ERR_INTERRUPTED (UT_Interrupt::opInterrupt, which the
                                      reference polls in every operator loop, e.g. Ops.h:319).  Polled before every PCG
                                      iteration and, on single-device solvers, before every level of both strokes of a

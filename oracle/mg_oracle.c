@@ -723,7 +723,9 @@ typedef struct {
     int cn, cbw;
     int32_t *cindex; /* coarsest grid -> unknown id, -1 inactive */
     double *cL;      /* cn x (cbw+1), row-major, cL[r*(cbw+1)+ (cbw-(r-c))] = L(r,c) */
+    void *fast;      /* state of the optimised comparator (mgo_solver_apply_vcycle_fast), made on first use */
 } mgo_solver;
+static void fast_free(mgo_solver *s);
 
 static int build_coarse_direct(mgo_solver *s)
 {
@@ -829,6 +831,7 @@ static void coarse_solve(const mgo_solver *s, double *v) /* in place, v[cn] */
 void mgo_solver_destroy(mgo_solver *s)
 {
     if (!s) return;
+    fast_free(s);
     for (int l = 0; l < s->alloc_levels; ++l) {
         if (s->lab) free(s->lab[l]);
         if (s->x) free(s->x[l]);
@@ -1016,6 +1019,255 @@ void mgo_solver_apply_vcycle(mgo_solver *s, real *x, const real *b, int use_init
     }
     mgo_upsample_add(x, s->x[1], s->lab[0], d0.nx, d0.ny, d0.nz); /* MG.cpp:787-880 */
     smooth_stroke(s, 0, x, b, 0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The OPTIMISED CPU comparator ("an optimised CPU variant is reported separately so the speed-up is not
+ * inflated").  Same V-cycle and the same operators as mgo_solver_apply_vcycle with the Jacobi smoother and one sweep per
+ * stroke (the six neighbours of an INTERIOR cell are summed before they are subtracted: results agree to round-off, not bit
+ * for bit); what changes is what the reference's structure costs and a CPU does not need:
+ *   - no whole-grid copy per Jacobi sweep (Ops.h:289): the two sweeps of a level ping-pong between the iterate and one
+ *     spare grid -- down x -> t, up t -> x -- so the result lands where the caller expects it with no copy at all;
+ *   - the residual in ONE pass (the reference clears, applies A, adds: Ops.h:728-731);
+ *   - one-byte labels for the streaming passes (the reference's are 4-byte ints); BOUNDARY cells, a few percent, still go
+ *     through computeLaplacian with the int labels and the face weights;
+ *   - INTERIOR runs of a row in a branch-free inner loop the compiler vectorises; OpenMP over x-rows.
+ * Timed by bench.py's cpu_baseline as "optimised_variant" (build with -DMGO_REAL=float for fp32 storage).  Checked against
+ * the faithful cycle in tests/test_oracle_properties.py.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t **lab8;
+    real **spare; /* one spare grid per smoothed level */
+    /* band passes without look-ups: per band cell its linear index and its operator row (computeLaplacian, Ops.h:177-260,
+     * evaluated once: six off-diagonal weights in the reference's visiting order -x +x -y +y -z +z, 0 for a neighbour that
+     * contributes nothing, then the diagonal), SoA */
+    int64_t **bcell;
+    real **brow; /* 7 x band_n */
+    real **btmp;
+} mgo_fast;
+static mgo_fast *fast_of(mgo_solver *s)
+{
+    if (s->fast) return (mgo_fast *)s->fast;
+    mgo_fast *f = (mgo_fast *)calloc(1, sizeof(mgo_fast));
+    f->lab8 = (uint8_t **)calloc((size_t)s->levels, sizeof(uint8_t *));
+    f->spare = (real **)calloc((size_t)s->levels, sizeof(real *));
+    f->bcell = (int64_t **)calloc((size_t)s->levels, sizeof(int64_t *));
+    f->brow = (real **)calloc((size_t)s->levels, sizeof(real *));
+    f->btmp = (real **)calloc((size_t)s->levels, sizeof(real *));
+    for (int l = 0; l < s->levels; ++l) {
+        const dims_t d = s->dims[l];
+        const size_t n = (size_t)d.nx * d.ny * d.nz;
+        f->lab8[l] = (uint8_t *)malloc(n);
+        if (l < s->levels - 1) f->spare[l] = (real *)calloc(n, sizeof(real));
+        const int32_t *lab = s->lab[l];
+        uint8_t *l8 = f->lab8[l];
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < (int64_t)n; ++c) l8[c] = (uint8_t)lab[c];
+        if (l == s->levels - 1) continue;
+        const int64_t nb = s->band_n[l];
+        f->bcell[l] = (int64_t *)malloc((size_t)(nb > 0 ? nb : 1) * sizeof(int64_t));
+        f->brow[l] = (real *)malloc((size_t)(nb > 0 ? nb : 1) * 7 * sizeof(real));
+        f->btmp[l] = (real *)malloc((size_t)(nb > 0 ? nb : 1) * sizeof(real));
+        const real *w[3] = {s->w[0], s->w[1], s->w[2]};
+        const int weighted = l == 0;
+        const ptrdiff_t stride[3] = {1, d.nx, (ptrdiff_t)d.nx * d.ny};
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < nb; ++t) {
+            const int i = s->band[l][3 * t], j = s->band[l][3 * t + 1], k = s->band[l][3 * t + 2];
+            const size_t c = cidx(&d, i, j, k);
+            f->bcell[l][t] = (int64_t)c;
+            real diag = 0;
+            for (int axis = 0; axis < 3; ++axis)
+                for (int dir = 0; dir < 2; ++dir) { /* Ops.h:191-256 */
+                    const int nl = lab[c + (dir ? stride[axis] : -stride[axis])];
+                    real wt = 0, dg = 0;
+                    if (lab[c] == MGO_INTERIOR) wt = 1, dg = 1;
+                    else if (nl == MGO_INTERIOR) wt = 1, dg = 1;
+                    else if (nl == MGO_BOUNDARY) wt = dg = weighted ? w[axis][fidx(&d, axis, i, j, k, dir)] : (real)1;
+                    else if (nl == MGO_DIRICHLET) dg = weighted ? w[axis][fidx(&d, axis, i, j, k, dir)] : (real)1;
+                    f->brow[l][(size_t)(2 * axis + dir) * nb + t] = wt;
+                    diag += dg;
+                }
+            f->brow[l][(size_t)6 * nb + t] = diag;
+        }
+    }
+    s->fast = f;
+    return f;
+}
+static void fast_free(mgo_solver *s)
+{
+    mgo_fast *f = (mgo_fast *)s->fast;
+    if (!f) return;
+    for (int l = 0; l < s->levels; ++l) {
+        free(f->lab8[l]);
+        free(f->spare[l]);
+        free(f->bcell[l]);
+        free(f->brow[l]);
+        free(f->btmp[l]);
+    }
+    free(f->lab8);
+    free(f->spare);
+    free(f->bcell);
+    free(f->brow);
+    free(f->btmp);
+    free(f);
+    s->fast = NULL;
+}
+/* one full-domain pass over level l: mode 0 out = Jacobi(x) (inactive cells: out = x), mode 1 out = b - A x (inactive: 0) */
+static void fast_pass(mgo_solver *s, int l, int mode, real *out, const real *x, const real *b)
+{
+    const mgo_fast *f = (const mgo_fast *)s->fast;
+    const dims_t d = s->dims[l];
+    const uint8_t *l8 = f->lab8[l];
+    const int32_t *lab = s->lab[l];
+    const real *w[3] = {s->w[0], s->w[1], s->w[2]};
+    const real *const *wp = l == 0 ? w : NULL;
+    const ptrdiff_t sy = d.nx, sz = (ptrdiff_t)d.nx * d.ny;
+    const real damped = 2. / 3., sixth = (real)6;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < d.nz; ++k)
+        for (int j = 0; j < d.ny; ++j) {
+            const size_t row = cidx(&d, 0, j, k);
+            int i = 0;
+            while (i < d.nx) {
+                int e = i;
+                while (e < d.nx && l8[row + e] == MGO_INTERIOR) ++e; /* a run of INTERIOR cells: Ops.h:191-207, no look-ups */
+                const real *xc = x + row, *bc = b + row;
+                real *oc = out + row;
+#pragma omp simd
+                for (int q = i; q < e; ++q) {
+                    const real lap = sixth * xc[q] - (xc[q - 1] + xc[q + 1] + xc[q - sy] + xc[q + sy] + xc[q - sz] + xc[q + sz]);
+                    const real res = bc[q] - lap;
+                    oc[q] = mode == 0 ? xc[q] + damped * (res / sixth) : res;
+                }
+                if (e < d.nx) {
+                    const size_t c = row + e;
+                    if (l8[c] == MGO_BOUNDARY) {
+                        real lap, diag;
+                        laplacian(&d, x, lab, wp, e, j, k, &lap, &diag);
+                        const real res = b[c] - lap;
+                        out[c] = mode == 0 ? x[c] + damped * (res / diag) : res;
+                    } else
+                        out[c] = mode == 0 ? x[c] : (real)0;
+                    ++e;
+                }
+                i = e;
+            }
+        }
+}
+/* boundaryJacobiPoissonSmoother x band_iters (Ops.h:524-619) over the precomputed rows: compute into a list, then scatter */
+static void fast_band(mgo_solver *s, int l, real *x, const real *b)
+{
+    const mgo_fast *f = (const mgo_fast *)s->fast;
+    const dims_t d = s->dims[l];
+    const int64_t nb = s->band_n[l];
+    const int64_t *cell = f->bcell[l];
+    const real *row = f->brow[l];
+    real *tmp = f->btmp[l];
+    const ptrdiff_t sy = d.nx, sz = (ptrdiff_t)d.nx * d.ny;
+    const real damped = 2. / 3.;
+    for (int it = 0; it < s->band_iters; ++it) {
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < nb; ++t) {
+            const real *xc = x + cell[t];
+            real lap = 0;
+            lap -= row[t] * xc[-1];
+            lap -= row[nb + t] * xc[1];
+            lap -= row[2 * nb + t] * xc[-sy];
+            lap -= row[3 * nb + t] * xc[sy];
+            lap -= row[4 * nb + t] * xc[-sz];
+            lap -= row[5 * nb + t] * xc[sz];
+            const real diag = row[6 * nb + t];
+            lap += diag * xc[0];
+            real res = b[cell[t]] - lap;
+            res /= diag;
+            tmp[t] = xc[0] + damped * res;
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < nb; ++t) x[cell[t]] = tmp[t];
+    }
+}
+static void fast_downsample(real *coarse, const real *fine, const uint8_t *cl8, dims_t cd)
+{
+    static const real rw[4] = {1. / 8., 3. / 8., 3. / 8., 1. / 8.};
+    const dims_t fd = {2 * cd.nx, 2 * cd.ny, 2 * cd.nz};
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < cd.nz; ++k)
+        for (int j = 0; j < cd.ny; ++j)
+            for (int i = 0; i < cd.nx; ++i) {
+                const size_t c = cidx(&cd, i, j, k);
+                if (!is_active(cl8[c])) {
+                    coarse[c] = 0;
+                    continue;
+                }
+                real sum = 0;
+                const real *p0 = fine + cidx(&fd, 2 * i - 1, 2 * j - 1, 2 * k - 1);
+                for (int zo = 0; zo < 4; ++zo)
+                    for (int yo = 0; yo < 4; ++yo) {
+                        const real *p = p0 + ((size_t)zo * fd.ny + yo) * fd.nx;
+                        const real wyz = rw[yo] * rw[zo];
+                        sum += rw[0] * wyz * p[0];
+                        sum += rw[1] * wyz * p[1];
+                        sum += rw[2] * wyz * p[2];
+                        sum += rw[3] * wyz * p[3];
+                    }
+                coarse[c] = sum;
+            }
+}
+static void fast_upsample_add(real *fine, const real *coarse, const uint8_t *fl8, dims_t fd)
+{
+    const dims_t cd = {fd.nx / 2, fd.ny / 2, fd.nz / 2};
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k < fd.nz - 1; ++k)
+        for (int j = 1; j < fd.ny - 1; ++j) {
+            const int bj = (j - 1) >> 1, bk = (k - 1) >> 1;
+            const real fy = (j & 1) ? .25 : .75, fz = (k & 1) ? .25 : .75;
+            const real *r00 = coarse + cidx(&cd, 0, bj, bk), *r10 = r00 + cd.nx, *r01 = r00 + (size_t)cd.nx * cd.ny, *r11 = r01 + cd.nx;
+            const size_t row = cidx(&fd, 0, j, k);
+            for (int i = 1; i < fd.nx - 1; ++i) {
+                if (!is_active(fl8[row + i])) continue;
+                const int bi = (i - 1) >> 1;
+                const real fx = (i & 1) ? .25 : .75;
+                const real t = lerp(lerp(lerp(r00[bi], r00[bi + 1], fx), lerp(r10[bi], r10[bi + 1], fx), fy),
+                                    lerp(lerp(r01[bi], r01[bi + 1], fx), lerp(r11[bi], r11[bi + 1], fx), fy), fz);
+                fine[row + i] = fine[row + i] + 4. * t;
+            }
+        }
+}
+/* applyVCycle (MG.cpp:420-881), Jacobi smoother, one sweep per stroke.  Returns -1 where the faithful cycle must be used. */
+int mgo_solver_apply_vcycle_fast(mgo_solver *s, real *x, const real *b, int use_initial_guess)
+{
+    if (s->use_gs || s->pre_sweeps != 1 || s->post_sweeps != 1 || s->levels < 2) return -1;
+    const mgo_fast *f = fast_of(s);
+    const int L = s->levels;
+    real *cur[64];
+    for (int l = 0; l < L - 1; ++l) {
+        const dims_t d = s->dims[l];
+        const size_t n = (size_t)d.nx * d.ny * d.nz;
+        real *xl = l == 0 ? x : s->x[l];
+        const real *bl = l == 0 ? b : s->b[l];
+        if (l > 0 || !use_initial_guess) {
+#pragma omp parallel for schedule(static)
+            for (int k = 0; k < d.nz; ++k) memset(xl + (size_t)k * d.nx * d.ny, 0, (size_t)d.nx * d.ny * sizeof(real));
+        }
+        (void)n;
+        fast_band(s, l, xl, bl);
+        fast_pass(s, l, 0, f->spare[l], xl, bl); /* down: x -> spare */
+        cur[l] = f->spare[l];
+        fast_band(s, l, cur[l], bl);
+        fast_pass(s, l, 1, s->r[l], cur[l], bl);
+        fast_downsample(s->b[l + 1], s->r[l], f->lab8[l + 1], s->dims[l + 1]);
+    }
+    mgo_solver_coarse_solve(s, s->x[L - 1], s->b[L - 1]);
+    for (int l = L - 2; l >= 0; --l) {
+        real *xl = l == 0 ? x : s->x[l];
+        const real *bl = l == 0 ? b : s->b[l];
+        fast_upsample_add(cur[l], s->x[l + 1], f->lab8[l], s->dims[l]);
+        fast_band(s, l, cur[l], bl);
+        fast_pass(s, l, 0, xl, cur[l], bl); /* up: spare -> x */
+        fast_band(s, l, xl, bl);
+    }
+    return 0;
 }
 
 /* solveGeometricConjugateGradient (CG.h:18-207) with A = applyPoissonMatrix and

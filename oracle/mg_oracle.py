@@ -293,6 +293,14 @@ class OracleSolver:
         assert x.dtype == self.o.real and b.dtype == self.o.real and x.flags.c_contiguous
         self.o.lib.mgo_solver_apply_vcycle(self.h, _ptr(x), _ptr(b), int(bool(use_initial_guess)))
 
+    def apply_vcycle_fast(self, x, b, use_initial_guess=False):
+        """The optimised CPU comparator (mgo_solver_apply_vcycle_fast): Jacobi smoother, one sweep per stroke only."""
+        assert x.dtype == self.o.real and b.dtype == self.o.real and x.flags.c_contiguous
+        self.o.lib.mgo_solver_apply_vcycle_fast.restype = C.c_int
+        rc = self.o.lib.mgo_solver_apply_vcycle_fast(self.h, _ptr(x), _ptr(b), int(bool(use_initial_guess)))
+        if rc != 0:
+            raise ValueError("the optimised cycle covers the Jacobi smoother with one sweep per stroke on >= 2 levels")
+
     def solve_pcg(self, x, b, tol=1e-5, max_iter=2500, use_mg=True):
         stats = (C.c_double * 3)()
         hist = np.zeros(max_iter + 1, dtype=np.float64)
