@@ -1855,6 +1855,119 @@ __global__ __launch_bounds__(256) void restrictMarchKernel(GridP cg, float *__re
     }
 }
 
+// The marching restriction with every fine row staged ONCE per workgroup (round 4).  rocprofv3 on the kernel above, 1024^3 -> 512^3:
+// 5.2e7 L1 -> L2 line requests and 3.5e7 L2 -> fabric requests for 2.25e7 lines of data (FETCH 4.4 GB = 1.5 x) -- a wave's four
+// 4-byte loads at an 8-byte lane stride touch six lines for four lines of data (2 I - 1 and 2 I + 2 sit in the neighbours' lines),
+// the four waves of a workgroup re-request the two rows they share, and the L2 catches a third of it.  Here a workgroup of
+// 64 x 4 threads (coarse I x coarse row pairs, as above) loads the 18 fine rows x 136 columns of a fine plane as aligned 16-byte
+// quads (three per thread), leaves them in LDS, and every thread forms its two in-plane 4 x 4 sums from there; the next plane's
+// quads are in flight while the current plane is summed (two LDS buffers, one barrier per fine plane).  Same summation order
+// as above: x, then y, then z.  Coarse nx even (fine nx % 4 == 0).
+constexpr int kRtI = 64, kRtJ = 8;                       // coarse tile
+constexpr int kRtRows = 2 * kRtJ + 2, kRtQuads = 2 * kRtI / 4 + 2;  // 18 fine rows, 34 quads: fine x from 2 I0 - 4 to 2 I0 + 131
+constexpr int kRtStride = 4 * kRtQuads;
+constexpr int kRtLoads = (kRtRows * kRtQuads + 255) / 256;  // 3
+template <class TF = float>
+__global__ __launch_bounds__(256) void restrictTileKernel(GridP cg, float *__restrict__ coarse, const TF *__restrict__ fine,
+                                                          int kc, unsigned nbx, unsigned nby, float fm = 1.f)
+{
+    constexpr bool kMixed = !std::is_same<TF, float>::value;
+    __shared__ float tile[2][kRtRows * kRtStride];
+    __shared__ int anyActiveCol;
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int I0 = int(bx) * kRtI, J0 = int(by) * kRtJ;
+    const int li = int(threadIdx.x & 63), lp = int(threadIdx.x >> 6);
+    const int I = I0 + li, J = J0 + 2 * lp;
+    const int K0 = int(bz) * kc, K1 = min(K0 + kc, cg.nz);
+    const size_t cplane = size_t(cg.nx) * cg.ny, col = size_t(J) * cg.nx + I;
+    const bool inGrid = I < cg.nx && J < cg.ny && I >= cg.xlo && I < cg.xhi;
+    const bool second = J + 1 < cg.ny;
+    bool any = false;
+    if (inGrid)
+        for (int K = K0; K < K1; ++K) {
+            any = any || activeLabel(cg.lab[size_t(K) * cplane + col]);
+            if (second) any = any || activeLabel(cg.lab[size_t(K) * cplane + col + cg.nx]);
+        }
+    if (threadIdx.x == 0) anyActiveCol = 0;
+    __syncthreads();
+    if (any) anyActiveCol = 1;
+    __syncthreads();
+    if (!anyActiveCol) return;  // (a tile of EXTERIOR / DIRICHLET columns: the destination holds 0 there already)
+    const int fnx = 2 * cg.nx, fny = 2 * cg.ny;
+    const int kLo = cg.ghostLo ? -1 : 0, kHi = cg.ghostHi ? 2 * cg.nz : 2 * cg.nz - 1;
+    // the quads this thread stages of every fine plane: (row r, quad q) of the tile, fine x = 2 I0 - 4 + 4 q, fine y = 2 J0 - 1 + r.
+    // Quads outside the grid or outside the fine image of the active x range are not loaded (they feed EXTERIOR cells only)
+    const int fxlo = max(2 * cg.xlo - 4, 0), fxhi = min(2 * cg.xhi + 4, fnx);
+    ptrdiff_t off[kRtLoads];
+    bool ok[kRtLoads];
+#pragma unroll
+    for (int m = 0; m < kRtLoads; ++m) {
+        const int t = int(threadIdx.x) + m * 256;
+        const int r = t / kRtQuads, q = t % kRtQuads;
+        const int fx = 2 * I0 - 4 + 4 * q, fy = min(max(2 * J0 - 1 + r, 0), fny - 1);  // (rows clamped: results masked)
+        ok[m] = t < kRtRows * kRtQuads && fx >= fxlo && fx + 3 < fxhi;
+        off[m] = ptrdiff_t(fy) * fnx + fx;
+    }
+    auto loadPlane = [&](int fk, float4 (&v)[kRtLoads]) {
+        const TF *p = fine + ptrdiff_t(min(max(fk, kLo), kHi)) * fny * fnx;
+#pragma unroll
+        for (int m = 0; m < kRtLoads; ++m) v[m] = ok[m] ? Cell<TF>::load4(p + off[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto storePlane = [&](float *buf, const float4 (&v)[kRtLoads]) {
+#pragma unroll
+        for (int m = 0; m < kRtLoads; ++m) {
+            const int t = int(threadIdx.x) + m * 256;
+            if (t < kRtRows * kRtQuads) *reinterpret_cast<float4 *>(buf + (t / kRtQuads) * kRtStride + 4 * (t % kRtQuads)) = v[m];
+        }
+    };
+    const float w[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    struct Pair {
+        float a, b;
+    };
+    // in-plane sums of this thread's two coarse columns from the staged plane: fine x 2 I - 1 .. 2 I + 2 = tile column 2 li + 3 ..
+    auto planeSums = [&](const float *buf) {
+        const float *p = buf + (4 * lp) * kRtStride + 2 * li + 3;
+        float rs[6];
+#pragma unroll
+        for (int yo = 0; yo < 6; ++yo) {
+            const float *r = p + yo * kRtStride;
+            const float2 mid = *reinterpret_cast<const float2 *>(r + 1);  // (column 2 li + 4: 8-byte aligned)
+            rs[yo] = w[0] * r[0] + w[1] * mid.x + w[2] * mid.y + w[3] * r[3];
+        }
+        return Pair{w[0] * rs[0] + w[1] * rs[1] + w[2] * rs[2] + w[3] * rs[3], w[0] * rs[2] + w[1] * rs[3] + w[2] * rs[4] + w[3] * rs[5]};
+    };
+    // fine planes 2 K0 - 1 .. 2 K1: plane f sits in buffer f & 1 while it is summed, plane f + 1 is in flight meanwhile
+    float4 nextv[kRtLoads];
+    const int f0 = 2 * K0 - 1, f1 = 2 * (K1 - 1) + 2;
+    loadPlane(f0, nextv);
+    storePlane(tile[f0 & 1], nextv);
+    loadPlane(f0 + 1, nextv);
+    __syncthreads();
+    Pair p0 = planeSums(tile[f0 & 1]), p1{0.f, 0.f}, p2{0.f, 0.f};
+    int have = 1;  // sums held: p0 (and p1, p2 as they come)
+    for (int f = f0 + 1; f <= f1; ++f) {
+        storePlane(tile[f & 1], nextv);  // (the buffer of plane f - 2: everybody finished with it before the last barrier)
+        if (f < f1) loadPlane(f + 1, nextv);
+        __syncthreads();
+        const Pair s = planeSums(tile[f & 1]);
+        if (have == 1) p1 = s, have = 2;
+        else if (have == 2) p2 = s, have = 3;
+        else {  // s is the fourth plane of coarse plane K = (f - 2) / 2
+            const int K = (f - 2) >> 1;
+            if (inGrid && any) {
+                const size_t c = size_t(K) * cplane + col;
+                const float va = w[0] * p0.a + w[1] * p1.a + w[2] * p2.a + w[3] * s.a, vb = w[0] * p0.b + w[1] * p1.b + w[2] * p2.b + w[3] * s.b;
+                coarse[c] = activeLabel(cg.lab[c]) ? (kMixed ? fm * va : va) : 0.f;
+                if (second) coarse[c + cg.nx] = activeLabel(cg.lab[c + cg.nx]) ? (kMixed ? fm * vb : vb) : 0.f;
+            }
+            p0 = p2;
+            p1 = s;
+            have = 2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Prolongation + add (Ops.h:873-972): fine c += 4 * trilerp(coarse) at sample point c/2 - 1/4:
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
@@ -2872,8 +2985,13 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     // cell -- 1.13 vs 0.88 ms at 1024^3 -> 512^3, 0.14 vs 0.118 ms one level down: it takes over where those runs hold a
     // clearly smaller part of the level.  On the cube they hold 76 %: the march stays)
     const bool runsWin = coarse.chunks && double(coarse.nchunks) * coarse.chunkCells * 1.3 * runCostFactor(coarse.chunkCells) < 0.8 * double(n);
+    static const bool tiled = [] {  // MGPS_RESTRICT=march: the register-only march (A/B)
+        const char *e = getenv("MGPS_RESTRICT");
+        return !(e && e[0] == 'm');
+    }();
     if (!perCell && !runsWin && coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
-        restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
+        if (tiled && (coarse.nx & 1) == 0) restrictTileKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
+        else restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         return int(hipGetLastError());
     }
     const unsigned nb = coarse.chunks ? unsigned(size_t(coarse.nchunks) * size_t(coarse.chunkCells) / 256) : blocksFor(n, 256);

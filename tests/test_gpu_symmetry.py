@@ -190,7 +190,7 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"),
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_RESTRICT", "cube512"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -208,6 +208,8 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     MGPS_ZERO_START (default on) -- down-strokes that start from the zero iterate take it as zero instead of clearing and
     reading the grid: the never-cleared grids then hold the previous cycle's values (the second cycle and the PCG run on such
     stale grids), which must not reach the result -- the invariant behind the shortcut.
+    MGPS_RESTRICT (default: the LDS-tiled march, restrictTileKernel; "march": the register-only march it replaced) -- the same
+    sums in the same order, compared to round-off (not bit for bit: two kernels, two FMA contractions); cube512: the 512^3 cube, whose 256^3 coarse level is large enough to take either.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
@@ -223,6 +225,9 @@ if gs:
 if case == "pool128":
     lab, w, dx = D.free_surface_pool(128, 4)
     lev = 4
+elif case == "cube512":
+    lab, w, dx = D.interior_cube(512, 6)
+    lev = 6
 else:
     shape = (64, 992, int(case[5:]))
     bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
@@ -236,7 +241,7 @@ else:
     dx = 1.0 / 992
     lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
 s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)
-if case != "pool128":
+if case not in ("pool128", "cube512"):
     assert s.stencil_kernel(0) == "plane"
 b = s.to_device(D.random_rhs(lab, dx))
 x = s.new_grid()
@@ -259,14 +264,18 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
     with tempfile.TemporaryDirectory() as tmp:
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
-            env = dict(os.environ, **{switch: {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else fuse})
-            if not case.startswith("pool128"):
+            value = {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else {"1": "tile", "0": "march"}[fuse] if switch == "MGPS_RESTRICT" else fuse
+            env = dict(os.environ, **{switch: value})
+            if not case.startswith("pool128") and case != "cube512":
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0
     for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
-        assert np.array_equal(outs[0][key], outs[1][key]), key
+        if switch == "MGPS_RESTRICT":  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
+            assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-6 * np.abs(outs[1][key]).max(), key
+        else:
+            assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
     assert int(outs[0]["it"]) == int(outs[1]["it"])
     if switch == "MGPS_X_RANGE" and case != "pool128":
