@@ -300,7 +300,11 @@ def main():
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
         comm = TorchDistComm() if args.rehearse_gloo else RcclComm(device=local_rank)
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter()
         solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt, splits=cuts)
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t_setup) * 1e3
     else:
         solver = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, device=local_rank, options=opt)
     del w
@@ -319,21 +323,35 @@ def main():
         solver.applyVCycle(x, b, guess)
     solver.profile_enable(True)
     barrier()
+    exchanges0 = solver.exchange_count if slab_run else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.applyVCycle(x, b, guess)
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's own clock: its queue drained, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
+    exchanges_per_cycle = ((solver.exchange_count - exchanges0) / args.steps) if slab_run else 0
     smooth_ms, smooth_groups = solver.profile_read()
     solver.profile_enable(2)  # stage breakdown: a few extra cycles outside the timed region (its event records cost a few %)
     for _ in range(min(args.steps, 5)):
         solver.applyVCycle(x, b, guess)
     stages = solver.stage_times()
     solver.profile_enable(False)
+    slab_diag = None
     if slab_run:  # the job is as slow as its slowest rank
-        t = torch.tensor([elapsed, smooth_ms], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
+        dev = "cpu" if args.rehearse_gloo else "cuda"
+        t = torch.tensor([elapsed, smooth_ms, own_elapsed, setup_ms, float(exchanges_per_cycle)], dtype=torch.float64, device=dev)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed, smooth_ms = float(t[0]), float(t[1])
+        # what a first hardware run needs to be read: how uneven the ranks are (a rank's own cycle time: its queue drained, before
+        # the barrier), what the set-up cost and how many exchanges a cycle issues (middle ranks: two neighbours each)
+        slab_diag = {"rank_cycle_ms_max": float(t[2]) / args.steps * 1e3, "rank_cycle_ms_min": float(tmin[2]) / args.steps * 1e3,
+                     "setup_ms_max": float(t[3]), "setup_ms_min": float(tmin[3]), "exchanges_per_cycle_max": float(t[4]),
+                     "exchanges_per_cycle_min": float(tmin[4]), "overlapped_exchanges_rank0": int(solver.overlapped_exchanges),
+                     "distributed_levels": solver.distributed_levels}
 
     cells = float(n) ** 3  # whole job; a rank holds cells / world of them
     active_cells = float(((lab[z0:z1] == 0) | (lab[z0:z1] == 3)).sum())  # this rank's INTERIOR + BOUNDARY cells
@@ -372,6 +390,7 @@ def main():
             "slab_cuts": cuts,
             "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
+        **({"slab": slab_diag} if slab_diag else {}),
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
         # the whole cycle against the HBM peak: SURVEY 8(d)'s 60.7 B per fine cell (band passes excluded) x the cells a sweep
         # visits (active runs), per GPU

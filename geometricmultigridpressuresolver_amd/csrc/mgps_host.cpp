@@ -768,12 +768,15 @@ struct GroupBuild {
 struct BandWindow {
     Dims wd;
     const uint8_t *labels = nullptr;     // reference labels or device codes of the window (active: 0 or >= 3)
-    std::unique_ptr<int32_t[]> entryOf;  // window cell -> output entry (>= 0), kDeepBand, or kNoBand
+    // window cell -> output entry (>= 0), kDeepBand, or kNoBand.  A big block of the library (hostBigAlloc: page-locked and kept
+    // for the next solver -- in a process that holds GPU mappings 0.6 GB of FRESH pages cost ~100 ms, a third of a slab
+    // rank's set-up at 1024^3 / 8)
+    RawVec<int32_t> entryOf;
     void allocEntryOf()                  // filled with kNoBand by all host threads (0.5 GB at 512^3)
     {
         const size_t n = wd.cells();
-        entryOf.reset(new int32_t[n]);
-        int32_t *p = entryOf.get();
+        entryOf.resize(n);
+        int32_t *p = entryOf.data();
         parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); }, 1 << 20);
     }
     // whole-grid windows skip the dense map: the reference band order is (tile, k, j, i), so a cell is found by a
@@ -785,7 +788,7 @@ struct BandWindow {
     int tilesX = 0, tilesY = 0;
     int32_t entryAt(size_t wc) const
     {
-        if (entryOf) return entryOf[wc];
+        if (!entryOf.empty()) return entryOf[wc];
         const int i = int(wc % wd.nx), j = int((wc / wd.nx) % wd.ny), k = int(wc / (size_t(wd.nx) * wd.ny));
         const size_t tile = (size_t(k / kTile) * tilesY + j / kTile) * tilesX + i / kTile;
         const int32_t *lo = sortedBand + tileStart[tile], *hi = sortedBand + tileStart[tile + 1];
@@ -1424,10 +1427,19 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     W.wd = Dims{gd.nx, gd.ny, wz1 - wz0};
     W.labels = G.labels.data() + size_t(wz0) * plane;
     const size_t wcells = W.wd.cells(), wlo = size_t(wz0) * plane, whi = size_t(wz1) * plane;
-    std::vector<uint8_t> band(wcells, 0);
-    for (int32_t gcI : G.band) {
-        const size_t gc = size_t(gcI);
-        if (gc >= wlo && gc < whi) band[gc - wlo] = 1;
+    // (round 4: every pass over the window -- 145 M cells for a 128-plane slab of 1024^3 -- runs on all host threads; done one
+    // thread at a time, the flag array, the dense entry map and the closure scans were 240 of the 470 ms a rank's set-up took)
+    RawVec<uint8_t> band(wcells);
+    {
+        uint8_t *bp = band.data();
+        parallelFor(int64_t(wcells), [bp](int64_t b, int64_t e) { std::memset(bp + b, 0, size_t(e - b)); }, 1 << 22);
+        const int32_t *gb = G.band.data();
+        parallelFor(int64_t(G.band.size()), [bp, gb, wlo, whi](int64_t b, int64_t e) {
+            for (int64_t q = b; q < e; ++q) {
+                const size_t gc = size_t(gb[q]);
+                if (gc >= wlo && gc < whi) bp[gc - wlo] = 1;
+            }
+        }, 1 << 16);
     }
     const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
     const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
@@ -1436,13 +1448,19 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
         std::vector<int64_t> cells;
         pa = std::max(pa, wz0 + 1);
         pb = std::min(pb, wz1 - 1);
-        for (int k = pa; k < pb; ++k)
-            for (size_t c = size_t(k - wz0) * plane; c < size_t(k - wz0 + 1) * plane; ++c) {
-                if (!W.active(c)) continue;
-                bool in = band[c] != 0;
-                for (int q = 0; q < 6 && !in; ++q) in = band[size_t(ptrdiff_t(c) + off[q])] != 0;
-                if (in) cells.push_back(int64_t(c));
+        if (pb <= pa) return cells;
+        const int64_t rows = int64_t(pb - pa) * gd.ny;  // x-rows of the planes, in cell order
+        parallelCollect<int64_t>(rows, 64, cells, [&](int64_t r0, int64_t r1, std::vector<int64_t> &part) {
+            for (int64_t r = r0; r < r1; ++r) {
+                const size_t c0 = (size_t(pa - wz0) * gd.ny + size_t(r)) * size_t(gd.nx);
+                for (size_t c = c0; c < c0 + size_t(gd.nx); ++c) {
+                    if (!W.active(c)) continue;
+                    bool in = band[c] != 0;
+                    for (int q = 0; q < 6 && !in; ++q) in = band[size_t(ptrdiff_t(c) + off[q])] != 0;
+                    if (in) part.push_back(int64_t(c));
+                }
             }
+        });
         return cells;
     };
     const bool lo = z0 > 0, hi = z1 < gd.nz;
@@ -1463,8 +1481,14 @@ void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int d
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[1].begin(), L.bandPlane[1].end());
     out.bandExt.insert(out.bandExt.end(), L.bandPlane[3].begin(), L.bandPlane[3].end());
     W.allocEntryOf();
-    for (size_t c = 0; c < wcells; ++c)
-        if (band[c]) W.entryOf[c] = BandWindow::kDeepBand;
+    {
+        int32_t *ep = W.entryOf.data();
+        const uint8_t *bp = band.data();
+        parallelFor(int64_t(wcells), [ep, bp](int64_t b, int64_t e) {
+            for (int64_t c = b; c < e; ++c)
+                if (bp[c]) ep[c] = BandWindow::kDeepBand;
+        }, 1 << 20);
+    }
     W.seedCellOwn.resize(out.bandExt.size());
     W.entryDiagOwn.assign(L.bandDiag.begin(), L.bandDiag.end());
     W.entryDiagOwn.resize(out.bandExt.size(), 0);

@@ -133,6 +133,7 @@ struct mgps_solver {
     hipStream_t commStream = nullptr;
     hipEvent_t evEdge = nullptr, evComm = nullptr;
     int64_t overlappedExchanges = 0;
+    int64_t exchanges = 0;         // ghost / stage exchanges issued so far (mgps_exchange_count: the bench line's exchanges_per_cycle)
     std::vector<int> splits;       // slab run: rank r owns the fine planes [splits[r], splits[r + 1])
     int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
     int totalLevels = 0;           // levels of the whole hierarchy
@@ -513,6 +514,7 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL,
     const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
     if (mode == GHOST_FULL) {
         const size_t bytes = plane * sizeof(float);
+        ++h->exchanges;
         MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, bytes, lo ? a - plane : nullptr, bytes,
                                       hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, bytes,
                                       hi ? a + size_t(L.d.nz) * plane : nullptr, bytes, on ? on : h->stream));
@@ -521,6 +523,7 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL,
     const int *n = L.nbandPlane;
     if (lo) MGPS_LAUNCH(h, launchPack(h->stream, L.packBuf[0], a, L.bandPlane[0], n[0]));
     if (hi) MGPS_LAUNCH(h, launchPack(h->stream, L.packBuf[2], a, L.bandPlane[2], n[2]));
+    ++h->exchanges;
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? L.packBuf[0] : nullptr, size_t(n[0]) * sizeof(float),
                                   lo ? L.packBuf[1] : nullptr, size_t(n[1]) * sizeof(float),
                                   hi ? L.packBuf[2] : nullptr, size_t(n[2]) * sizeof(float),
@@ -562,6 +565,7 @@ int bandStageDeep(mgps_solver *h, int l, float *x, const float *b, hipStream_t o
     // the fused stage on the solver's stream waits for it
     hipStream_t cs = on ? on : h->stream;
     MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane));
+    ++h->exchanges;
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
                                   hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], cs));
     MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane));
@@ -1415,6 +1419,7 @@ int exchangeGhosts64(mgps_solver *h, double *a)
     DevLevel &L = h->lv[0];
     const size_t plane = size_t(L.d.nx) * L.d.ny, bytes = plane * sizeof(double);
     const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
+    ++h->exchanges;
     MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? a : nullptr, bytes, lo ? a - plane : nullptr, bytes,
                                   hi ? a + (size_t(L.d.nz) - 1) * plane : nullptr, bytes, hi ? a + size_t(L.d.nz) * plane : nullptr, bytes,
                                   h->stream));
@@ -3113,10 +3118,16 @@ try {
 }
 MGPS_API_CATCH(nullptr)
 
-int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab,
-                            const float *wy_slab, const float *wz_slab, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
-                            const mgps_comm *comm, const int *splits)
-try {
+}  // extern "C"
+namespace {
+// weightsOnDevice: wx_slab / wy_slab / wz_slab are DEVICE arrays (the field passes of mgps_fields.h leave them there): nothing of
+// their 12 B per cell crosses PCIe -- at 1024^3 / 8 ranks the 1.6 GB of a slab's weights coming from pageable host memory were
+// 300 of the 470 ms a rank's set-up took -- and the operator rows of the slab's BOUNDARY cells are evaluated by
+// launchBoundaryRows like mgps_create_device_weights does for a whole grid
+int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab,
+                   const float *wy_slab, const float *wz_slab, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
+                   const mgps_comm *comm, const int *splits, bool weightsOnDevice)
+{
     if (!out) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: out is NULL");
     *out = nullptr;
     if (!labels_global_host || !wx_slab || !wy_slab || !wz_slab || !comm || !splits)
@@ -3139,6 +3150,7 @@ try {
     if (o.precision != 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: options.precision = 1 is for single-device solvers");
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
+    StageClock sclock(getenv("MGPS_SETUP_TIMING") != nullptr);
     mgps_hierarchy *hier = nullptr;
     {  // the rank's window of the hierarchy: labels of every level, band lists around its slab only
         static const bool windowedSetup = [] {  // MGPS_SLAB_WINDOW=0: band lists of the whole grid on every rank (rounds 1-2; A/B)
@@ -3148,6 +3160,7 @@ try {
         const int window[2] = {splits[rank], splits[rank + 1]};
         MGPS_TRY(hierarchyCreate(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o, false, true, (windowedSetup && P > 1) ? window : nullptr));
     }
+    sclock.lap("slab: host hierarchy");
     // distributed levels (distributedLevelsFor); the last level is always collapsed
     const int D = distributedLevelsFor(splits, P, nx, ny, hier->levels, use_gauss_seidel != 0, o);
     if (D < 1) {
@@ -3166,13 +3179,16 @@ try {
     std::memcpy(&h->comm, comm, size_t(comm->struct_size));  // (struct_size bytes are the caller's; the rest stays NULL)
     h->comm.struct_size = int(sizeof(mgps_comm));
     {
-        // MGPS_OVERLAP=1: exchanges beside the sweeps (see sweepSplit).  Off by default: on one GPU with a null transport the
-        // split launches and the two event hops cost the slowest rank 0.07 ms of a 1.75 ms cycle at 1024^3 / 8 ranks (rank 0:
-        // 0.23 ms, its two half-size launches no longer fill the chip; 0.15-0.27 ms at 2 and 4 ranks), and what the overlap
-        // returns -- an estimated 0.3-0.6 ms of plane transfers per cycle -- can only be measured on real links.
+        // Exchanges beside the sweeps (see sweepSplit) on levels whose planes are at least 1 MiB (sweepSplittable; the 1024^2 and
+        // 512^2 levels of a 1024^3 run).  Decided from the null-transport costs (round 4; off in rounds 2-3): on one GPU the split
+        // launches and the two event hops cost the slowest rank of 8 0.07 ms of a 1.75 ms cycle at 1024^3 (rank 0: 0.23 ms, its
+        // two half-size launches no longer fill the chip; 0.15-0.27 ms at 2 and 4 ranks) against the transfers they take off the
+        // critical path -- nine per cycle and level, 27 us each for a 4 MiB plane at 150 GB/s per xGMI link plus the collective's
+        // own 6-7 us: 0.3-0.6 ms.  A smaller plane crosses a link in less than the two hops cost, so those levels keep the
+        // solver's stream.  MGPS_OVERLAP=0 turns it off (A/B on real links).
         static const bool overlap = [] {
             const char *e = getenv("MGPS_OVERLAP");
-            return e && e[0] == '1';
+            return !(e && e[0] == '0');
         }();
         if (overlap && P > 1 &&
             (hipStreamCreateWithFlags(&h->commStream, hipStreamNonBlocking) != hipSuccess ||
@@ -3194,20 +3210,69 @@ try {
     const int z0 = splits[rank], nzl = splits[rank + 1] - z0;
     const size_t wn[3] = {size_t(nx + 1) * ny * nzl, size_t(nx) * (ny + 1) * nzl, size_t(nx) * ny * (nzl + 1)};
     const float *wh[3] = {wx_slab, wy_slab, wz_slab};
-    for (int a = 0; a < 3; ++a) {
-        int rc = devAlloc(h, &h->w[a], wn[a], false);
-        if (rc != MGPS_OK) return bail(rc);
-        if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-            return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
+    if (weightsOnDevice && o.borrow_device_weights) {
+        for (int a = 0; a < 3; ++a) h->w[a] = const_cast<float *>(wh[a]);
+        h->weightsBorrowed = true;
+    } else
+        for (int a = 0; a < 3; ++a) {
+            int rc = devAlloc(h, &h->w[a], wn[a], false);
+            if (rc != MGPS_OK) return bail(rc);
+            if (hipMemcpy(h->w[a], wh[a], wn[a] * sizeof(float), weightsOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
+                return bail(failH(h, MGPS_ERR_HIP, "weight upload failed"));
+        }
+    (void)hipDeviceSynchronize();
+    sclock.lap("slab: weights");
+    // device weights: the rows of the slab's BOUNDARY cells (band order) from a kernel over the slab's labels + ghost planes
+    std::vector<float> rows0;
+    if (weightsOnDevice) {
+        const HostLevel &G = hier->lv[0];
+        const size_t plane = size_t(nx) * ny;
+        const int gLo = z0 > 0 ? 1 : 0, gHi = z0 + nzl < nz_global ? 1 : 0;
+        std::vector<int32_t> cells;  // slab-local linear indices, in band order
+        const int64_t lo = int64_t(size_t(z0) * plane), hi = int64_t(size_t(z0 + nzl) * plane);
+        for (int32_t c : G.band)
+            if (c >= lo && c < hi && G.labels[size_t(c)] == MGPS_BOUNDARY_CELL) cells.push_back(int32_t(c - lo));
+        rows0.resize(8 * cells.size());
+        uint8_t *labDev = nullptr;
+        int32_t *cellsDev = nullptr;
+        float *rowsDev = nullptr;
+        int *violDev = nullptr;
+        int violations = 0;
+        hipError_t e = cacheMalloc(reinterpret_cast<void **>(&labDev), size_t(nzl + 2) * plane);
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&cellsDev), std::max<size_t>(1, cells.size()) * sizeof(int32_t));
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&rowsDev), std::max<size_t>(1, rows0.size()) * sizeof(float));
+        if (e == hipSuccess) e = cacheMalloc(reinterpret_cast<void **>(&violDev), sizeof(int));
+        if (e == hipSuccess) e = hipMemset(labDev, MGPS_EXTERIOR_CELL, size_t(nzl + 2) * plane);  // (the planes outside the grid)
+        if (e == hipSuccess)
+            e = hipMemcpy(labDev + size_t(1 - gLo) * plane, G.labels.data() + size_t(z0 - gLo) * plane, size_t(nzl + gLo + gHi) * plane, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !cells.empty()) e = hipMemcpy(cellsDev, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(violDev, 0, sizeof(int));
+        Dims sd;
+        sd.nx = nx, sd.ny = ny, sd.nz = nzl;
+        if (e == hipSuccess) e = hipError_t(launchBoundaryRows(nullptr, sd, labDev + plane, wx_slab, wy_slab, wz_slab, cellsDev, int(cells.size()), rowsDev, violDev));
+        if (e == hipSuccess && !rows0.empty()) e = hipMemcpy(rows0.data(), rowsDev, rows0.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&violations, violDev, sizeof(int), hipMemcpyDeviceToHost);
+        (void)cacheFree(labDev);
+        (void)cacheFree(cellsDev);
+        (void)cacheFree(rowsDev);
+        (void)cacheFree(violDev);
+        if (e != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string("mgps_create_slab (device weights): ") + hipGetErrorString(e)));
+        if (violations != 0)
+            return bail(failH(h, MGPS_ERR_HIERARCHY, "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
     }
+    sclock.lap("slab: fine rows");
     h->lv.resize(D + 1);
     for (int l = 0; l <= D; ++l) {
         HostLevel HL;
         const int gz = hier->lv[l].d.nz, lz0 = z0 >> l, lz1 = (z0 + nzl) >> l;
-        buildSlabLevel(hier->lv[l], lz0, lz1, l == 0 ? wx_slab : nullptr, l == 0 ? wy_slab : nullptr,
-                       l == 0 ? wz_slab : nullptr, HL);
+        const bool hostW = l == 0 && !weightsOnDevice;
+        buildSlabLevel(hier->lv[l], lz0, lz1, hostW ? wx_slab : nullptr, hostW ? wy_slab : nullptr, hostW ? wz_slab : nullptr, HL,
+                       (l == 0 && weightsOnDevice) ? (rows0.empty() ? &kNoRows : rows0.data()) : nullptr);
+        sclock.lap("slab: host lists", l);
         int rc = uploadLevel(h, h->lv[l], HL, lz0, lz1, gz, l == 0, l < D, l > 0);
         if (rc != MGPS_OK) return bail(rc);
+        (void)hipDeviceSynchronize();
+        sclock.lap("slab: upload level", l);
         if (l == D || P == 1 || !o.deep_band_halo || o.band_iterations < 1 || o.band_iterations > kBandMaxDepth) continue;
         // The neighbours' band cells near a cut are recomputed here, so their operator rows are needed: on the
         // unit-weight levels (and on an all-simple fine level) the labels give them; otherwise the ranks
@@ -3285,6 +3350,8 @@ try {
         if (rc == MGPS_OK) rc = devUpload(h, &H.groups.neighbours, SH.groups.neighbours);
         if (rc != MGPS_OK) return bail(rc);
         H.depth = SH.depth;
+        (void)hipDeviceSynchronize();
+        sclock.lap("slab: halo groups", l);
     }
     int rc = commonDeviceState(h, false);
     if (rc != MGPS_OK) return bail(rc);
@@ -3306,6 +3373,7 @@ try {
             return MGPS_OK;
         }();
     }
+    sclock.lap("slab: common state + tail");
     // every rank leaves with the same verdict: rank 0 failing alone would leave the others waiting in the first gather
     double failed = tailRc != MGPS_OK ? double(tailRc) : 0.0;
     if (h->comm.allreduce(h->comm.user, &failed, 1, 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
@@ -3315,6 +3383,21 @@ try {
     }
     *out = h;
     return MGPS_OK;
+}
+}  // namespace
+extern "C" {
+int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab,
+                            const float *wy_slab, const float *wz_slab, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
+                            const mgps_comm *comm, const int *splits)
+try {
+    return createSlabImpl(out, nx, ny, nz_global, labels_global_host, wx_slab, wy_slab, wz_slab, mg_levels, use_gauss_seidel, opt, comm, splits, false);
+}
+MGPS_API_CATCH(nullptr)
+int mgps_create_slab_device_weights(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host, const float *wx_slab_dev,
+                                    const float *wy_slab_dev, const float *wz_slab_dev, int mg_levels, int use_gauss_seidel, const mgps_options *opt,
+                                    const mgps_comm *comm, const int *splits)
+try {
+    return createSlabImpl(out, nx, ny, nz_global, labels_global_host, wx_slab_dev, wy_slab_dev, wz_slab_dev, mg_levels, use_gauss_seidel, opt, comm, splits, true);
 }
 MGPS_API_CATCH(nullptr)
 
@@ -3410,6 +3493,7 @@ try {
 MGPS_API_CATCH(h)
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
 int64_t mgps_overlapped_exchanges(const mgps_solver *h) { return h ? h->overlappedExchanges : 0; }
+int64_t mgps_exchange_count(const mgps_solver *h) { return h ? h->exchanges : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
 try {

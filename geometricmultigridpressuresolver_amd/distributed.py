@@ -247,16 +247,23 @@ class SlabSolver(GeometricMultigridPoissonSolver):
     writes into."""
 
     def __init__(self, labels, slab_weights, mg_levels, use_gauss_seidel, comm, device=None, options=None, splits=None):
-        """splits: the cuts (slab_partition); None = nz / size planes per rank"""
+        """splits: the cuts (slab_partition); None = nz / size planes per rank.
+        slab_weights: numpy arrays (mgps_create_slab_ranges) or float32 CUDA tensors (mgps_create_slab_device_weights: nothing of
+        the weights crosses PCIe)."""
         labels = _np_u8(labels)
-        w = [_np_f32(a) for a in slab_weights]
+        on_device = all(isinstance(a, torch.Tensor) and a.is_cuda for a in slab_weights)
+        if on_device:
+            assert all(a.dtype == torch.float32 and a.is_contiguous() for a in slab_weights)
+            w = list(slab_weights)
+        else:
+            w = [_np_f32(a) for a in slab_weights]
         nz, ny, nx = labels.shape
         if splits is None:
             assert nz % comm.size == 0, "nz must divide evenly over the ranks"
             splits = [nz // comm.size * r for r in range(comm.size + 1)]
         assert len(splits) == comm.size + 1
         nzl = splits[comm.rank + 1] - splits[comm.rank]
-        assert w[0].shape == (nzl, ny, nx + 1) and w[1].shape == (nzl, ny + 1, nx) and w[2].shape == (nzl + 1, ny, nx)
+        assert tuple(w[0].shape) == (nzl, ny, nx + 1) and tuple(w[1].shape) == (nzl, ny + 1, nx) and tuple(w[2].shape) == (nzl + 1, ny, nx)
         self.splits = [int(v) for v in splits]
         opt = options if options is not None else default_options()
         if device is not None:
@@ -264,12 +271,22 @@ class SlabSolver(GeometricMultigridPoissonSolver):
         self.comm = comm
         self.h = C.c_void_p()
         cuts = (C.c_int * (comm.size + 1))(*self.splits)
-        check(
-            lib().mgps_create_slab_ranges(
-                C.byref(self.h), nx, ny, nz, _p(labels), _p(w[0]), _p(w[1]), _p(w[2]), int(mg_levels),
-                int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct), cuts,
+        if on_device:
+            torch.cuda.synchronize()  # (the library reads the tensors on its own stream)
+            ptr = [C.c_void_p(a.data_ptr()) for a in w]
+            check(
+                lib().mgps_create_slab_device_weights(
+                    C.byref(self.h), nx, ny, nz, _p(labels), ptr[0], ptr[1], ptr[2], int(mg_levels),
+                    int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct), cuts,
+                )
             )
-        )
+        else:
+            check(
+                lib().mgps_create_slab_ranges(
+                    C.byref(self.h), nx, ny, nz, _p(labels), _p(w[0]), _p(w[1]), _p(w[2]), int(mg_levels),
+                    int(bool(use_gauss_seidel)), C.byref(opt), C.byref(comm.struct), cuts,
+                )
+            )
         self.shape = (nzl, ny, nx)
         self.global_shape = (nz, ny, nx)
         self.use_gauss_seidel = bool(use_gauss_seidel)
@@ -285,6 +302,11 @@ class SlabSolver(GeometricMultigridPoissonSolver):
     def overlapped_exchanges(self):
         lib().mgps_overlapped_exchanges.restype = C.c_int64
         return lib().mgps_overlapped_exchanges(self.h)
+
+    @property
+    def exchange_count(self):
+        lib().mgps_exchange_count.restype = C.c_int64
+        return lib().mgps_exchange_count(self.h)
 
     def slab_range(self, level=0):
         z0, z1 = C.c_int(), C.c_int()

@@ -416,13 +416,24 @@ int mgps_slab_partition(int nx, int ny, int nz, const uint8_t *labels_global_hos
 int mgps_create_slab_ranges(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
                             const float *wx_slab, const float *wy_slab, const float *wz_slab, int mg_levels,
                             int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm, const int *splits);
+/* The same with the slab's face weights already on the rank's DEVICE (what mgps_fields_build_* leave there): no weight
+ * crosses PCIe -- at 1024^3 on 8 ranks the 1.6 GB of a slab's weights arriving from pageable host memory were 300 of the
+ * 470 ms a rank's set-up took -- and the rows of the slab's BOUNDARY cells are evaluated on the device (Ops.h:208-256, as
+ * mgps_create_device_weights does for a whole grid).  The arrays are copied unless options.borrow_device_weights is set
+ * (then they must outlive the solver).  Same result as mgps_create_slab_ranges, bit for bit. */
+int mgps_create_slab_device_weights(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
+                                    const float *wx_slab_dev, const float *wy_slab_dev, const float *wz_slab_dev, int mg_levels,
+                                    int use_gauss_seidel, const mgps_options *opt, const mgps_comm *comm, const int *splits);
 /* owned plane range [z0, z1) of `level` on this rank (levels past the distributed ones: the range
  * of the collapse level) and the number of distributed levels */
 int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1);
 int mgps_distributed_levels(const mgps_solver *h);
 /* slab runs: how many ghost exchanges so far were queued on the transfer stream, beside the interior part of the sweep that
- * produced their planes (MGPS_OVERLAP=1; 0 otherwise and on single-device solvers) */
+ * produced their planes (the default on levels with planes >= 1 MiB since round 4, MGPS_OVERLAP=0 turns it off; 0 on
+ * single-device solvers) */
 int64_t mgps_overlapped_exchanges(const mgps_solver *h);
+/* slab runs: ghost / band-stage exchanges this rank issued so far (each one message pair per neighbour); 0 on single-device solvers */
+int64_t mgps_exchange_count(const mgps_solver *h);
 /* raw copies between host memory and device memory of the solver's device (used by transports
  * that stage through the host) */
 int mgps_copy_to_host(mgps_solver *h, void *dst_host, const void *src_dev, size_t bytes);

@@ -105,7 +105,7 @@ def gpu_mode():
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
             # exchanges queued on the transfer stream beside the interior part of the sweep that made their planes
-            if os.environ.get("MGPS_OVERLAP") != "1":
+            if os.environ.get("MGPS_OVERLAP") == "0":
                 assert slab.overlapped_exchanges == 0
             elif rank == 0:  # (a slab without liquid -- the top of the scene -- has nothing to launch edge first)
                 assert slab.overlapped_exchanges > 0, (kind, use_gs, deep)
@@ -123,6 +123,15 @@ def gpu_mode():
                 assert ss["rel_residual_recomputed"] < 1e-6 and rel_l2(slab64.gather_global(xs), xw.cpu().numpy()) < 1e-5
                 slab64.close()
                 whole64.close()
+                # the slab's face weights handed over on the device (mgps_create_slab_device_weights: rows evaluated by a kernel,
+                # nothing of the weights crosses PCIe): the same solver bit for bit
+                slabd = SlabSolver(lab, [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda() for a in slab_w], lev, use_gs,
+                                   TorchDistComm(), device=0, options=opt)
+                xa, xb = slab.new_grid(), slabd.new_grid()
+                slab.applyVCycle(xa, bs, False)
+                slabd.applyVCycle(xb, slabd.to_device(b_glob[z0:z1]), False)
+                assert torch.equal(xa, xb), (kind, use_gs, "device weights")
+                slabd.close()
             if rank == 0:
                 print(f"  {kind} gs={use_gs} deep={deep}: D={slab.distributed_levels} exchanges={comm.exchanges} "
                       f"({comm.bytes_sent / 1e6:.1f} MB sent) pcg it {ss['iterations']}", flush=True)

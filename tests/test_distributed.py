@@ -33,8 +33,8 @@ def run_workers(mode, nproc, timeout, extra_env=None):
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), mode,
     ]
-    # MGPS_OVERLAP=1: the exchanges that follow a sweep run on the transfer stream (off by default until it is measured on real
-    # links); MGPS_OVERLAP_MIN_PLANE_KB=0: on every cut level of these small grids, not only for planes >= 1 MiB
+    # MGPS_OVERLAP=1 (the default since round 4): the exchanges that follow a sweep run on the transfer stream;
+    # MGPS_OVERLAP_MIN_PLANE_KB=0: on every cut level of these small grids, not only for planes >= 1 MiB
     env = dict(os.environ, OMP_NUM_THREADS="2", MGPS_OVERLAP="1", MGPS_OVERLAP_MIN_PLANE_KB="0")
     env.update(extra_env or {})
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=env)
@@ -78,8 +78,8 @@ def test_slabs_balanced_by_active_cells(nproc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["gpu", "plane"])
 def test_slabs_without_overlap(mode):
-    """MGPS_OVERLAP=0, the default: every exchange on the solver's own stream (the other tests of this file run with
-    MGPS_OVERLAP=1: a cut level's sweeps launched edge first, the exchange that follows on a transfer stream beside the
+    """MGPS_OVERLAP=0: every exchange on the solver's own stream (the other tests of this file run with the default,
+    MGPS_OVERLAP=1, on every cut level: a cut level's sweeps launched edge first, the exchange that follows on a transfer stream beside the
     interior part) -- same results either way."""
     out = run_workers(mode, 2, 420, {"MGPS_OVERLAP": "0"})
     print(out[-800:])

@@ -1,4 +1,6 @@
-"""Set-up time of one rank of a P-rank slab run (null transport, one GPU): python tools/slab_setup_time.py N P RANK
+"""Set-up time of one rank of a P-rank slab run (null transport, one GPU): python tools/slab_setup_time.py N P RANK [host|device]
+host (default): the slab's face weights come from numpy arrays (mgps_create_slab_ranges); device: from CUDA tensors
+(mgps_create_slab_device_weights: where mgps_fields_* leave them).
 MGPS_SLAB_WINDOW=0 builds the band lists of the whole grid on the rank (rounds 1-2), the default only the rank's window."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,10 +25,13 @@ while (n >> (levels - 1)) > 16:
 cuts = [n // P * r for r in range(P + 1)]
 z0, z1 = cuts[rank], cuts[rank + 1]
 lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
+where = sys.argv[4] if len(sys.argv) > 4 else "host"
+if where == "device":
+    w = [torch.from_numpy(a).cuda() for a in w]
 for rep in range(3):
     torch.cuda.synchronize()
     t = time.time()
     s = SlabSolver(lab, w, levels, False, NullComm(rank, P), device=0, splits=cuts)
     torch.cuda.synchronize()
-    print("slab set-up N=%d P=%d rank=%d window=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), (time.time() - t) * 1e3), flush=True)
+    print("slab set-up N=%d P=%d rank=%d window=%s weights=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), where, (time.time() - t) * 1e3), flush=True)
     s.close()
