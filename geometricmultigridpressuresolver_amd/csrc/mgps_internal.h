@@ -187,9 +187,9 @@ constexpr int kBoxThreads = 1024;
 constexpr int kBoxSlots = kBoxMaxList / kBoxThreads;
 constexpr int kBoxMaxGeneral = 384;   // general band cells of a region (their rows sit in LDS: 13.5 KB)
 constexpr int kBoxInfoInts = 16;
-constexpr int kBoxUInfoInts = 8;      // per group, made on the device from the list (launchBandBoxUpdates): simple band cells with ring <= r (r = 0..4), closure-output cells
 enum BoxNode : uint8_t { kBoxSkip = 0, kBoxFrozen = 1, kBoxZero = 2, kBoxGeneral = 3, kBoxSimple = 4, kBoxFrozenOut = 11, kBoxFrozenFar = 12 };
-// info: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first entry in `list`, [3] unused,
+// info: [0] linear cell of the region's origin, [1] rx | ry << 8 | rz << 16, [2] first entry in `list`, [3] (device, after
+// compactBandBoxLists) the entries the plain mode walks,
 // [4] first entry in `general`, [5] general entries, [6] unused, [7] list entries, [8 + r] band cells with ring <= r
 // (r = 0..4; r > depth repeats), [13] closure-output cells, [14] origin of O inside the region (packed like [1]),
 // [15] extents of O (packed)
@@ -207,19 +207,17 @@ struct BandBoxesDev {
     uint32_t *list = nullptr;
     size_t listCount = 0, generalInts = 0;
     bool anyGeneral = false;
-    // the update list of every group (round 4): the entries of `list` that are ever updated, at the group's offset in `list` --
-    // simple band cells sorted by ring, then the closure-output cells -- and their counts (kBoxUInfoInts per group).  Made on
-    // the device from info + list (launchBandBoxUpdates) whoever built those
-    uint32_t *ulist = nullptr;
-    int32_t *uinfo = nullptr;
 };
-int launchBandBoxUpdates(void *stream, const BandBoxesDev &bx);
 // the box kernels address a region cell by a 32-bit byte offset from the region's origin (31 planes at most) formed with 24-bit
 // multiplies: a level whose x-y planes hold 2^24 cells or more (4096 x 4096) keeps the pass-by-pass band smoother
 inline bool boxPlaneFits(const Dims &d) { return size_t(d.nx) * size_t(d.ny) < (size_t(1) << 24); }
-// the groups in the Morton order of their tiles (launch order = L2 locality of the overlapping regions): info / uinfo permuted
-// into infoOut / uinfoOut; synchronises the stream
-int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, const int32_t *uinfo, int ngroups, int32_t *infoOut, int32_t *uinfoOut);
+// the region lists without the class-2 entries (the kernel clears its LDS block) and with the class-12 entries at the end of
+// every group's list (info[3] = what the plain mode walks, info[7] = all, info[2] = new offsets); listOut: listCount entries;
+// synchronises the stream
+int compactBandBoxLists(void *stream, int32_t *info, const uint32_t *list, int ngroups, uint32_t *listOut, size_t *newCount);
+// the groups in the Morton order of their tiles (launch order = L2 locality of the overlapping regions): info permuted into
+// infoOut; synchronises the stream
+int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, int ngroups, int32_t *infoOut);
 
 // The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
 // besides its ghost plane a rank receives the *band closure* (band cells and their active face neighbours)

@@ -319,8 +319,11 @@ __global__ __launch_bounds__(256) void stencilQuadKernel(GridP g, TX *__restrict
 // quad live in registers (each x value is loaded from memory once per tile instead of three times),
 // the current plane is staged in an LDS tile with a one-cell halo (double buffered, one barrier per
 // plane) for the x+-1 / y+-1 neighbours, and the next plane's loads are issued before the current
-// plane is computed.  Measured against the cache-only kernel above: HBM-side read traffic 9.2 vs
-// 14.8 B/cell (rocprofv3 FETCH_SIZE), 2.63 vs 2.87 ms at 1024^3.
+// plane is computed.  History of the comparison with the cache-only kernel above on 4 MiB planes (1024^3): round 1 2.63 vs
+// 2.87 ms (HBM-side reads 9.2 vs 14.8 B per cell, rocprofv3 FETCH_SIZE: the quad kernel walked its runs plane by plane and
+// the z neighbours missed the L2); rounds 2-3 the quad kernel walks 32-row strips through all planes (1.03 x the algorithmic
+// traffic) and skips the row-end padding: 1.82 ms against 1.85 ms here -- planes up to 4 MiB (kPlaneSweepMinPlaneBytes) take
+// the quad kernel since the end of round 3, larger planes this one.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the rows 16-byte aligned
 // lerp of Ops.h:841-871: (1 - f) a + f b, this exact form (HDK's SYSlerp breaks the R / P symmetry, Ops.h:837-839)
@@ -1109,40 +1112,32 @@ __global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGeneral && cls <= kBoxSimple + 6; }
 
-// Round 4: TWO lists per group.  The region list above (`list`: every region cell that matters, region order) stages the
-// values: consecutive lanes take consecutive cells of a row.  The passes walk `ulist`, the cells that are ever UPDATED -- the
-// simple band cells sorted by ring (stable: region order inside a ring), then the closure-output cells -- so that pass p is the
-// prefix ucount[H - p] of it with every lane busy: in the region list only one entry in four is a band cell (3.9 entries per
-// band cell on the cube, 4.9 on the pool), and a pass that walks it runs its 7 LDS reads per slot at a quarter of the lanes
-// (rocprofv3 SQ counters, round 3: 7 LDS instructions per vector-memory read, SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY 3.3 at 8 waves per
-// SIMD -- the LDS pipe, not the load chain: walking the groups by persistent workgroups with the next group's loads in flight
-// changed nothing, 1024^3 97.0 -> 97.0 cycles/s).  The rhs is loaded for the update list only, a thread keeps the value of its
-// cell in a register from pass to pass (6 LDS reads per update instead of 7) and writes its outputs from that register: no LDS
-// read and no barrier after the last pass.  Same expressions in the same order per cell.
-// uinfo (kBoxUInfoInts per group): [r] = simple band cells with ring <= r (r = 0..4), [5] = closure-output cells.
-// XZERO: src is zero everywhere (see stencilQuadKernel): no value of it is loaded
+// Round 4, what was tried on this kernel and what stayed (LABNOTES.md R4 has the numbers): persistent workgroups with the next
+// group's loads in flight (no change: not the load chain); a second, ring-sorted list of the cells that are ever updated so
+// that a pass is a dense prefix (LDS instructions halved, +10 % fabric traffic for the second list, 7 % SLOWER per launch at
+// 1024^3: dropped -- the stage follows its bytes, not its instructions); 24-bit address multiplies and the Morton launch
+// order of the groups (orderBandBoxes: overlapping regions of neighbouring groups meet in the chiplet's L2): kept, 0.300 ->
+// 0.277 ms per launch at 1024^3.
+// XZERO: src is zero everywhere (see stencilQuadKernel): no value of it is loaded -- closure mode, and the plain mode of a
+// Gauss-Seidel down-stroke, which then writes the iterate in place
 // (the body: bandBoxKernel runs group remapBlock(blockIdx.x), strokeFrontKernel its first workgroups)
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO>
 __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                             TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                            const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                             const int32_t *__restrict__ general, float omega, int depth, const MixScale &ms,
                                             double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned group, unsigned slot)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
-    __shared__ float val[2][kBoxMaxNodes];
+    __shared__ __attribute__((aligned(16))) float val[2][kBoxMaxNodes];
     __shared__ float grow[7][kGenRows];
     __shared__ float gbv[kGenRows];
     __shared__ uint16_t gnode[kGenRows], gring[kGenRows];  // region cell and ring
     // the group's description is wave-uniform: scalar registers (addresses below: scalar base + one 32-bit vector offset)
     const int32_t *gip = info + kBoxInfoInts * size_t(group);
-    const int32_t *uip = uinfo + kBoxUInfoInts * size_t(group);
-    int gi[8], cnt[6];
+    int gi[kBoxInfoInts];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) cnt[q] = __builtin_amdgcn_readfirstlane(uip[q]);
+    for (int q = 0; q < kBoxInfoInts; ++q) gi[q] = __builtin_amdgcn_readfirstlane(gip[q]);
     const int rx = gi[1] & 255, ry = (gi[1] >> 8) & 255, sxy = rx * ry;
     // a region cell's address = the region's origin + a 32-bit offset inside the region (it stays below 32 planes)
     const unsigned sy = unsigned(g.nx), sz = unsigned(g.nx) * unsigned(g.ny);
@@ -1152,15 +1147,15 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
     if (dst) dst += origin;
     if (CLOSURE && snap) snap += origin;
     if (DOT) dotOld += origin;
-    const uint32_t *U = list + gi[2], *UB = ulist + gi[2];
-    const int ngen = GEN ? gi[5] : 0, nList = gi[7];
-    const int nSimple = cnt[4], nUpd = cnt[4] + cnt[5];  // update list: [0, nSimple) band cells by ring, [nSimple, nUpd) closure-output cells
+    const uint32_t *U = list + gi[2];
+    // (lists as compactBandBoxLists leaves them: no entries for the inactive cells -- the whole block is cleared instead -- and
+    // the cells only the closure mode reads at the end, past the info[3] entries the plain mode walks)
+    const int ngen = GEN ? gi[5] : 0, nList = CLOSURE ? gi[7] : gi[3];
     const int H = depth + (CLOSURE ? 1 : 0);
     const float bm = kMixed ? mixRhsScale(ms) : 1.f;
     const int tid = threadIdx.x;
-    // (24-bit multiplies: v_mul_u32_u24 / v_mad_u32_u24 run at the full rate, the 32-bit v_mul_lo_u32 / v_mad_u64_u32 at a quarter
-    // of it -- two of them per address, twice per entry, were a third of the kernel's vector ALU time.  launchBandBox refuses
-    // levels whose planes do not fit 24 bits)
+    // (24-bit multiplies: v_mul_u32_u24 / v_mad_u32_u24 run at the full rate, the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler
+    // emits otherwise at a quarter of it; launchBandBox refuses levels whose planes do not fit 24 bits: boxPlaneFits)
     auto nodeOf = [&](uint32_t e) { return int(__umul24((e >> 10) & 31u, unsigned(sxy)) + __umul24((e >> 5) & 31u, unsigned(rx)) + (e & 31u)); };
     auto cellOf = [&](uint32_t e) { return (e & 31u) + __umul24((e >> 5) & 31u, sy) + __umul24((e >> 10) & 31u, sz); };
     // element c of a grid whose base is the region's origin: scalar base + 32-bit BYTE offset (the form the global_load /
@@ -1168,20 +1163,16 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
     auto rd = [&](const TX *base, unsigned c) { return Cell<TX>::load1(reinterpret_cast<const TX *>(reinterpret_cast<const char *>(base) + c * unsigned(sizeof(TX)))); };
     auto rdf = [&](const float *base, unsigned c) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + c * 4u); };
     auto wr = [&](TX *base, unsigned c, float v) { Cell<TX>::store1(reinterpret_cast<TX *>(reinterpret_cast<char *>(base) + c * unsigned(sizeof(TX))), v); };
-    uint32_t ub[kBoxSlots];  // this thread's update entries
-    unsigned cb[kBoxSlots];  // ... and their cells (offsets from the region's origin)
-    float bv[kBoxSlots], xcur[kBoxSlots];
-    uint32_t ge = 0;  // this thread's general cell: its list entry and its row, in the first batch like the rest
-    const int nRhs = CLOSURE ? nSimple : cnt[min(H - 1, 4)];  // the band cells that are updated at all: ring <= H - 1 (closure mode: every listed one)
+    uint32_t ue[kBoxSlots];
+    float bv[kBoxSlots];
     {
         // first batch of loads: every list entry of this thread (and its general entry); second batch: every value
-        uint32_t ue[kBoxSlots];
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
             const int k = tid + m * kBoxThreads;
             ue[m] = k < nList ? U[k] : (uint32_t(kBoxSkip) << 16);
-            ub[m] = k < nUpd ? UB[k] : 0u;
         }
+        uint32_t ge = 0;  // this thread's general cell: its list entry and its row, in the first batch like the rest
         int32_t grw = 0;
         if (GEN && tid < ngen) {
             ge = uint32_t(general[2 * size_t(gi[4] + tid)]);
@@ -1192,13 +1183,12 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
         float xv[kBoxSlots];
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const int k = tid + m * kBoxThreads;
             const unsigned cls = (ue[m] >> 16) & 15u;
             const bool need = cls != kBoxSkip && cls != kBoxZero && (CLOSURE || cls != kBoxFrozenFar);
-            const bool bneed = k < nRhs || (CLOSURE && k >= nSimple && k < nUpd);
-            xv[m] = XZERO ? 0.f : rd(src, need ? cellOf(ue[m]) : 0u);
-            cb[m] = cellOf(ub[m]);
-            bv[m] = rdf(b, bneed ? cb[m] : 0u);
+            const bool bneed = (cls > kBoxSimple && cls <= kBoxSimple + 6 && int(ue[m] >> 20) <= H - 1) || (CLOSURE && cls == kBoxFrozenOut);
+            const unsigned c = cellOf(ue[m]);
+            xv[m] = XZERO ? 0.f : rd(src, need ? c : 0u);
+            bv[m] = rdf(b, bneed ? c : 0u);
         }
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
@@ -1206,6 +1196,15 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
             if (cls == kBoxSkip || cls == kBoxZero) xv[m] = 0.f;  // (class 12 in the plain mode: whatever was loaded, nobody reads it)
             if (kMixed) bv[m] *= bm;
         }
+        {  // inactive neighbours read 0: the region's block is cleared while the loads above are in flight
+            const int rz = (gi[1] >> 16) & 255, ncell4 = (sxy * rz + 3) >> 2;
+            float4 *z0 = reinterpret_cast<float4 *>(val[0]), *z1 = reinterpret_cast<float4 *>(val[1]);
+            for (int q = tid; q < ncell4; q += kBoxThreads) {
+                z0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                z1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
         if (GEN && tid < ngen) {
             const uint32_t e = ge;
             gring[tid] = uint16_t(e >> 20);
@@ -1224,141 +1223,68 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
                 val[1][n] = xv[m];
             }
     }
-    int nd[kBoxSlots];
-#pragma unroll
-    for (int m = 0; m < kBoxSlots; ++m) {
-        nd[m] = nodeOf(ub[m]);
-        xcur[m] = 0.f;
-    }
-    float gcur = 0.f;
     __syncthreads();
     for (int p = 1; p <= H; ++p) {
         const float *from = val[(p - 1) & 1];
         float *to = val[p & 1];
-        const int lim = H - p;  // the band cells with ring <= H - p: a prefix of the update list
-        const int nAct = cnt[min(lim, 4)];
+        const int lim = H - p;  // the band cells with ring <= H - p
         const bool last = CLOSURE && p == H;
 #pragma unroll
         for (int m = 0; m < kBoxSlots; ++m) {
-            const int k = tid + m * kBoxThreads;
-            if (m * kBoxThreads >= (last ? nUpd : nAct)) break;  // (wave-uniform)
-            const bool out = last && k >= nSimple && k < nUpd;
-            if (k < nAct || out) {
-                const int n = nd[m];
-                const float xc = (p == 1 || out) ? from[n] : xcur[m];  // (a cell of the prefix was in every earlier pass: its value is what this thread wrote)
-                const float diag = out ? 6.f : float(int((ub[m] >> 16) & 15u) - int(kBoxSimple));
+            const unsigned cls = (ue[m] >> 16) & 15u;
+            const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
+            if ((simple && int(ue[m] >> 20) <= lim) || (last && cls == kBoxFrozenOut)) {
+                const int n = nodeOf(ue[m]);
+                const float xc = from[n];
+                const float diag = cls == kBoxFrozenOut ? 6.f : float(int(cls) - int(kBoxSimple));
                 const float lap = diag * xc - (from[n - 1] + from[n + 1] + from[n - rx] + from[n + rx] + from[n - sxy] + from[n + sxy]);
-                const float v = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
-                to[n] = v;
-                xcur[m] = v;
+                to[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));  // Ops.h:596-599 / 356-361
             }
         }
         if (GEN && tid < ngen && int(gring[tid]) <= lim) {
-            const int n = gnode[tid];
-            const float xc = from[n];
+            const int nd = gnode[tid];
+            const float xc = from[nd];
             float acc = 0.f;
-            acc -= grow[0][tid] * from[n - 1];
-            acc -= grow[1][tid] * from[n + 1];
-            acc -= grow[2][tid] * from[n - rx];
-            acc -= grow[3][tid] * from[n + rx];
-            acc -= grow[4][tid] * from[n - sxy];
-            acc -= grow[5][tid] * from[n + sxy];
+            acc -= grow[0][tid] * from[nd - 1];
+            acc -= grow[1][tid] * from[nd + 1];
+            acc -= grow[2][tid] * from[nd - rx];
+            acc -= grow[3][tid] * from[nd + rx];
+            acc -= grow[4][tid] * from[nd - sxy];
+            acc -= grow[5][tid] * from[nd + sxy];
             const float diag = grow[6][tid];
             const float lap = acc + diag * xc;
-            gcur = xc + omega * ((gbv[tid] - lap) / diag);
-            to[n] = gcur;
+            to[nd] = xc + omega * ((gbv[tid] - lap) / diag);
         }
-        if (p < H) __syncthreads();
+        __syncthreads();
     }
-    // the owned box's band cells (ring 0: in every pass, so the register holds the final value) and, in the closure mode, its
-    // closure-output cells (computed by the last pass); the plain mode with outClosure passes their staged value on -- what the
-    // closure launch left in the snapshot goes to dst, which then needs nothing from the closure launch itself
+    const float *fin = val[H & 1];
     double acc = 0.0;
-    auto emit = [&](unsigned c, float v) {
-        if (DOT) {
-            const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
-            acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
-        }
-        if (dst) wr(dst, c, v);
-        if (CLOSURE && snap) wr(snap, c, v);
-    };
 #pragma unroll
     for (int m = 0; m < kBoxSlots; ++m) {
-        const int k = tid + m * kBoxThreads;
-        if (k < cnt[0]) emit(cb[m], xcur[m]);
-        else if ((CLOSURE || outClosure) && k >= nSimple && k < nUpd) emit(cb[m], CLOSURE ? xcur[m] : val[0][nd[m]]);
+        const unsigned cls = (ue[m] >> 16) & 15u;
+        // plain mode with outClosure: the closure-output cells too -- their staged value (what the closure launch left in the
+        // snapshot) goes to dst, which then needs nothing from the closure launch itself
+        if ((ue[m] >> 20) == 0u && (boxBand(cls) || ((CLOSURE || outClosure) && cls == kBoxFrozenOut))) {
+            const unsigned c = cellOf(ue[m]);
+            const float v = fin[nodeOf(ue[m])];
+            if (DOT) {
+                const float stored = kMixed ? __half2float(toHalfSat(v)) : v;
+                acc += (double(stored) - double(rd(dotOld, c))) * double(rdf(b, c));
+            }
+            if (dst) wr(dst, c, v);
+            if (CLOSURE && snap) wr(snap, c, v);
+        }
     }
-    if (GEN && tid < ngen && (ge >> 20) == 0u) emit(cellOf(ge), gcur);
     if (DOT) blockDotStore(acc, dotPartials, slot);
 }
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
 __global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
                                                               TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                                              const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                                               const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
                                                               double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
 {
-    bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, ulist, uinfo, general, omega, depth, ms, dotPartials, dotOld, outClosure,
+    bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, general, omega, depth, ms, dotPartials, dotOld, outClosure,
                                               remapBlock(blockIdx.x, gridDim.x), blockIdx.x);
-}
-
-// The update list of every group (see bandBoxBody) from its region list: a stable counting sort by (ring of a simple band cell,
-// then closure-output cells); one workgroup per group, a thread = 16 consecutive entries.  Set-up only.
-__global__ __launch_bounds__(256) void boxUpdateListKernel(const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint32_t *__restrict__ ulist,
-                                                         int32_t *__restrict__ uinfo)
-{
-    constexpr int kKeys = 6, kPer = kBoxMaxList / 256;
-    __shared__ int counts[kKeys][256];
-    __shared__ int keyBase[kKeys + 1];
-    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
-    const uint32_t *U = list + gi[2];
-    uint32_t *UB = ulist + gi[2];
-    const int nList = gi[7], tid = threadIdx.x, k0 = tid * kPer;
-    auto keyOf = [](uint32_t e) {
-        const unsigned cls = (e >> 16) & 15u, ring = e >> 20;
-        if (cls > kBoxSimple && cls <= kBoxSimple + 6) return int(min(ring, 4u));
-        return (cls == kBoxFrozenOut && ring == 0u) ? 5 : -1;
-    };
-    int mine[kKeys] = {0, 0, 0, 0, 0, 0};
-    uint32_t e[kPer];
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        e[q] = k0 + q < nList ? U[k0 + q] : 0u;
-        const int key = k0 + q < nList ? keyOf(e[q]) : -1;
-#pragma unroll
-        for (int c = 0; c < kKeys; ++c) mine[c] += key == c ? 1 : 0;
-    }
-#pragma unroll
-    for (int c = 0; c < kKeys; ++c) counts[c][tid] = mine[c];
-    __syncthreads();
-    if (tid == 0) {  // (1536 additions once per group at set-up)
-        int run = 0;
-        for (int c = 0; c < kKeys; ++c) {
-            keyBase[c] = run;
-            for (int t = 0; t < 256; ++t) {
-                const int v = counts[c][t];
-                counts[c][t] = run;
-                run += v;
-            }
-        }
-        keyBase[kKeys] = run;
-        int32_t *ui = uinfo + kBoxUInfoInts * size_t(blockIdx.x);
-        for (int c = 0; c < 5; ++c) ui[c] = keyBase[c + 1];  // simple band cells with ring <= c
-        ui[5] = keyBase[6] - keyBase[5];
-        ui[6] = 0;
-        ui[7] = 0;
-    }
-    __syncthreads();
-    int at[kKeys];
-#pragma unroll
-    for (int c = 0; c < kKeys; ++c) at[c] = counts[c][tid];
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        const int key = k0 + q < nList ? keyOf(e[q]) : -1;
-#pragma unroll
-        for (int c = 0; c < kKeys; ++c)
-            if (key == c) UB[at[c]++] = e[q];
-    }
 }
 
 // The front of a smoothing stroke in ONE launch: the closure launch of the band boxes (workgroups [0, ngroups)) and the sweep
@@ -1370,12 +1296,11 @@ __global__ __launch_bounds__(256) void boxUpdateListKernel(const int32_t *__rest
 template <bool GEN, bool XZERO>
 __global__ __launch_bounds__(kBoxThreads, 8) void strokeFrontKernel(GridP g, float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ b,
                                                                   float *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                                                  const uint32_t *__restrict__ ulist, const int32_t *__restrict__ uinfo,
                                                                   const int32_t *__restrict__ general, float omega, int depth, unsigned ngroups,
                                                                   unsigned nshares, const int32_t *__restrict__ chunks, const uint32_t *__restrict__ keep)
 {
     if (blockIdx.x < ngroups) {
-        bandBoxBody<float, true, false, GEN, XZERO>(g, x, b, nullptr, snap, info, list, ulist, uinfo, general, omega, depth, MixScale{}, nullptr, nullptr, 0,
+        bandBoxBody<float, true, false, GEN, XZERO>(g, x, b, nullptr, snap, info, list, general, omega, depth, MixScale{}, nullptr, nullptr, 0,
                                                     remapBlock(blockIdx.x, ngroups), 0u);
         return;
     }
@@ -2734,7 +2659,7 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
     const unsigned ng = unsigned(bx.ngroups);
     const bool dot = dotPartials != nullptr;
 #define MGPS_BOX_LAUNCH3(C, D, G, Z) \
-    bandBoxKernel<TX, C, D, G, Z><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.ulist, bx.uinfo, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure)
+    bandBoxKernel<TX, C, D, G, Z><<<ng, kBoxThreads, 0, s>>>(g, src, b, dst, snap, bx.info, bx.list, bx.general, omega, bx.depth, ms, dotPartials, dotOld, outClosure)
 #define MGPS_BOX_LAUNCH(C, D, Z)                               \
     do {                                                       \
         if (bx.anyGeneral) MGPS_BOX_LAUNCH3(C, D, true, Z);    \
@@ -2756,18 +2681,11 @@ int launchBandBoxT(hipStream_t s, const GridP &g, const BandBoxesDev &bx, bool c
     return int(hipGetLastError());
 }
 }  // namespace
-int launchBandBoxUpdates(void *stream, const BandBoxesDev &bx)
-{
-    if (bx.ngroups <= 0) return 0;
-    if (!bx.ulist || !bx.uinfo) return int(hipErrorInvalidValue);
-    boxUpdateListKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(bx.info, bx.list, bx.ulist, bx.uinfo);
-    return int(hipGetLastError());
-}
 int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool closure, const void *src, const float *b, void *dst, void *snap, float omega,
                   bool half, const MixScale &ms, double *dotPartials, const void *dotOld, bool outClosure)
 {
     if (bx.ngroups <= 0) return 0;
-    if (!bx.ulist || !bx.uinfo || size_t(g.nx) * size_t(g.ny) >= (size_t(1) << 24)) return int(hipErrorInvalidValue);  // (24-bit plane stride: boxPlaneFits)
+    if (!boxPlaneFits(Dims{g.nx, g.ny, g.nz})) return int(hipErrorInvalidValue);  // (24-bit plane stride)
     if (!dst && !(closure && snap)) return int(hipErrorInvalidValue);  // (dst == nullptr: the closure launch fills the snapshot only)
     if ((src && src == dst) || (dotPartials && !dotOld)) return int(hipErrorInvalidValue);  // (a group reads what its neighbours own; src == nullptr: the iterate is zero everywhere, nothing is read and dst may be the iterate itself)
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2788,7 +2706,7 @@ int launchStrokeFront(void *stream, const GridP &g, const BandBoxesDev &bx, floa
     const unsigned nshares = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
     const unsigned ng = unsigned(bx.ngroups), nb = ng + (nshares + kBoxThreads / 256 - 1) / (kBoxThreads / 256);
     const int32_t *chunks = list ? g.chunks : nullptr;
-#define MGPS_FRONT(G, Z) strokeFrontKernel<G, Z><<<nb, kBoxThreads, 0, s>>>(g, out, x, b, snap, bx.info, bx.list, bx.ulist, bx.uinfo, bx.general, omega, bx.depth, ng, nshares, chunks, keep)
+#define MGPS_FRONT(G, Z) strokeFrontKernel<G, Z><<<nb, kBoxThreads, 0, s>>>(g, out, x, b, snap, bx.info, bx.list, bx.general, omega, bx.depth, ng, nshares, chunks, keep)
     if (bx.anyGeneral) {
         if (x) MGPS_FRONT(true, false);
         else MGPS_FRONT(true, true);

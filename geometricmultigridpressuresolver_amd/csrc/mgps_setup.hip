@@ -1187,8 +1187,8 @@ int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const u
 // fastest -- the z-neighbour of a group is a hundred groups away: its lines have left the chiplet's 4 MiB L2 by then, and the
 // overlap is paid in fabric traffic (rocprofv3 PMC, round 3: 1.08 GB per closure launch at 1024^3 against ~0.55 GB of distinct
 // lines).  The groups are therefore put in the Morton order of their tiles -- any run of 64 consecutive groups, what a chiplet
-// has in flight, is a compact patch -- by a stable counting sort over the tile keys; only info / uinfo move (16 + 8 ints per
-// group), the lists stay where their offsets point.
+// has in flight, is a compact patch -- by a stable counting sort over the tile keys; only info moves (16 ints per group), the
+// lists stay where their offsets point.
 __device__ __forceinline__ unsigned spreadBits3(unsigned v)  // 10 bits -> every third bit
 {
     v &= 0x3ffu;
@@ -1213,13 +1213,13 @@ __global__ __launch_bounds__(256) void boxOrderKeysKernel(Dims d, const int32_t 
     atomicAdd(count + k, 1);
     atomicMin(first + k, gidx);
 }
-__global__ __launch_bounds__(256) void boxOrderMoveKernel(const int32_t *__restrict__ info, const int32_t *__restrict__ uinfo, int n, const int32_t *__restrict__ key,
+__global__ __launch_bounds__(256) void boxOrderMoveKernel(const int32_t *__restrict__ info, int n, const int32_t *__restrict__ key,
                                                         const int32_t *__restrict__ start, const int32_t *__restrict__ first, int32_t *__restrict__ infoOut,
-                                                        int32_t *__restrict__ uinfoOut, int *__restrict__ broken)
+                                                        int *__restrict__ broken)
 {
-    // a thread per int: 24 per group
+    // a thread per int: 16 per group
     const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int gidx = int(t / (kBoxInfoInts + kBoxUInfoInts)), q = int(t % (kBoxInfoInts + kBoxUInfoInts));
+    const int gidx = int(t / kBoxInfoInts), q = int(t % kBoxInfoInts);
     if (gidx >= n) return;
     const int k = key[gidx], local = gidx - first[k];
     if (local < 0 || local >= start[k + 1] - start[k]) {  // (the groups of a tile are consecutive in both builders)
@@ -1227,16 +1227,15 @@ __global__ __launch_bounds__(256) void boxOrderMoveKernel(const int32_t *__restr
         return;
     }
     const size_t pos = size_t(start[k]) + size_t(local);
-    if (q < kBoxInfoInts) infoOut[pos * kBoxInfoInts + q] = info[size_t(gidx) * kBoxInfoInts + q];
-    else uinfoOut[pos * kBoxUInfoInts + (q - kBoxInfoInts)] = uinfo[size_t(gidx) * kBoxUInfoInts + (q - kBoxInfoInts)];
+    infoOut[pos * kBoxInfoInts + q] = info[size_t(gidx) * kBoxInfoInts + q];
 }
 __global__ __launch_bounds__(256) void fillIntKernel(int32_t *__restrict__ a, size_t n, int32_t v)
 {
     const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t < n) a[t] = v;
 }
-// infoOut / uinfoOut: arrays of the same sizes as info / uinfo; synchronises the stream (it owns temporaries)
-int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, const int32_t *uinfo, int ngroups, int32_t *infoOut, int32_t *uinfoOut)
+// infoOut: an array of the size of info; synchronises the stream (it owns temporaries)
+int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, int ngroups, int32_t *infoOut)
 {
     if (ngroups <= 0) return 0;
     const int tmax = std::max((d.nx + kTile - 1) / kTile, std::max((d.ny + kTile - 1) / kTile, (d.nz + kTile - 1) / kTile));
@@ -1263,13 +1262,111 @@ int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, const int32
     fillIntKernel<<<blocksFor(nbins, 256), 256, 0, s>>>(first, nbins, 0x7fffffff);
     boxOrderKeysKernel<<<blocksFor(size_t(ngroups), 256), 256, 0, s>>>(d, info, ngroups, bits, key, count, first);
     rc = launchExclusiveScan(stream, count, start, nbins, scratch);
-    boxOrderMoveKernel<<<blocksFor(size_t(ngroups) * (kBoxInfoInts + kBoxUInfoInts), 256), 256, 0, s>>>(info, uinfo, ngroups, key, start, first, infoOut, uinfoOut, broken);
+    boxOrderMoveKernel<<<blocksFor(size_t(ngroups) * kBoxInfoInts, 256), 256, 0, s>>>(info, ngroups, key, start, first, infoOut, broken);
     int bad = 0;
     if (!rc) rc = int(hipMemcpyAsync(&bad, broken, 4, hipMemcpyDeviceToHost, s));
     if (!rc) rc = int(hipStreamSynchronize(s));
     if (!rc) rc = int(hipGetLastError());
     release();
     if (!rc && bad) rc = int(hipErrorUnknown);
+    return rc;
+}
+
+// ---- the region lists as the kernels walk them (round 4) -----------------------------------------------------------------
+// The builders emit every region cell that matters, inactive neighbours (class 2: "the value is 0") and the cells only the
+// closure mode reads (class 12) included -- 17 % and 21 % of the entries on the BASELINE cube (tools/box_stats.py).  The band
+// stage follows its bytes (a second list made it 7 % slower), and the list is a quarter of them: here every group's list is
+// rewritten without the class-2 entries (the kernel clears its LDS block instead) and with the class-12 entries moved to the
+// end, stable otherwise -- info[3] = the entries the plain mode walks, info[7] = all of them, info[2] = the new offset.
+constexpr int kCompactPer = kBoxMaxList / 256;
+__device__ __forceinline__ int boxCompactKey(uint32_t e)
+{
+    const unsigned cls = (e >> 16) & 15u;
+    return (cls == kBoxZero || cls == kBoxSkip) ? -1 : (cls == kBoxFrozenFar ? 1 : 0);
+}
+__global__ __launch_bounds__(256) void boxCompactCountKernel(const int32_t *__restrict__ info, const uint32_t *__restrict__ list, int32_t *__restrict__ cnt)
+{
+    __shared__ int part[4];
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const uint32_t *U = list + gi[2];
+    int mine = 0;
+    for (int k = threadIdx.x; k < gi[7]; k += 256) mine += boxCompactKey(U[k]) >= 0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void boxCompactFillKernel(int32_t *__restrict__ info, const uint32_t *__restrict__ list, const int32_t *__restrict__ start,
+                                                          uint32_t *__restrict__ listOut)
+{
+    __shared__ int counts[2][256];
+    __shared__ int base[3];
+    int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const int oldStart = gi[2], nList = gi[7], tid = threadIdx.x, k0 = tid * kCompactPer;
+    const uint32_t *U = list + oldStart;
+    uint32_t *O = listOut + start[blockIdx.x];
+    uint32_t e[kCompactPer];
+    int mine[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < kCompactPer; ++q) {
+        e[q] = k0 + q < nList ? U[k0 + q] : (uint32_t(kBoxSkip) << 16);
+        const int key = boxCompactKey(e[q]);
+        mine[0] += key == 0 ? 1 : 0;
+        mine[1] += key == 1 ? 1 : 0;
+    }
+    counts[0][tid] = mine[0];
+    counts[1][tid] = mine[1];
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < 2; ++c) {
+            base[c] = run;
+            for (int t = 0; t < 256; ++t) {
+                const int v = counts[c][t];
+                counts[c][t] = run;
+                run += v;
+            }
+        }
+        base[2] = run;
+        gi[2] = start[blockIdx.x];
+        gi[3] = base[1];  // the plain mode's entries
+        gi[7] = run;
+    }
+    __syncthreads();
+    int at[2] = {counts[0][tid], counts[1][tid]};
+#pragma unroll
+    for (int q = 0; q < kCompactPer; ++q) {
+        const int key = boxCompactKey(e[q]);
+        if (key >= 0) O[at[key]++] = e[q];
+    }
+}
+// listOut: an array of listCount entries (an upper bound); *newCount = the entries it holds afterwards.  Rewrites info in place;
+// synchronises the stream
+int compactBandBoxLists(void *stream, int32_t *info, const uint32_t *list, int ngroups, uint32_t *listOut, size_t *newCount)
+{
+    *newCount = 0;
+    if (ngroups <= 0) return 0;
+    int32_t *cnt = nullptr, *start = nullptr, *scratch = nullptr;
+    auto release = [&]() {
+        for (void *p : {(void *)cnt, (void *)start, (void *)scratch})
+            if (p) (void)deviceFree(p);
+    };
+    int rc = 0;
+    if ((rc = deviceAlloc(reinterpret_cast<void **>(&cnt), size_t(ngroups) * 4)) || (rc = deviceAlloc(reinterpret_cast<void **>(&start), (size_t(ngroups) + 1) * 4)) ||
+        (rc = deviceAlloc(reinterpret_cast<void **>(&scratch), scanScratchInts(size_t(ngroups)) * 4))) {
+        release();
+        return rc;
+    }
+    hipStream_t s = S(stream);
+    boxCompactCountKernel<<<unsigned(ngroups), 256, 0, s>>>(info, list, cnt);
+    rc = launchExclusiveScan(stream, cnt, start, size_t(ngroups), scratch);
+    boxCompactFillKernel<<<unsigned(ngroups), 256, 0, s>>>(info, list, start, listOut);
+    int32_t total = 0;
+    if (!rc) rc = int(hipMemcpyAsync(&total, start + ngroups, 4, hipMemcpyDeviceToHost, s));
+    if (!rc) rc = int(hipStreamSynchronize(s));
+    if (!rc) rc = int(hipGetLastError());
+    release();
+    *newCount = size_t(std::max(total, 0));
     return rc;
 }
 

@@ -449,8 +449,6 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.neighbours);
         (void)cacheFree(L.bandBoxes.info);
         (void)cacheFree(L.bandBoxes.list);
-        (void)cacheFree(L.bandBoxes.ulist);
-        (void)cacheFree(L.bandBoxes.uinfo);
         (void)cacheFree(L.nearBand);
         (void)cacheFree(L.planeFlags);
         (void)cacheFree(L.keepBits);
@@ -1789,9 +1787,9 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 
 // The plane-marching sweep visits blocks of 256 x 16 x zc cells, the quad sweep runs of 1024 .. 32 cells: where the liquid
 // fills a small part of the grid (a 480^3 simulation inside the reference's 1024^3 power-of-two expansion: 57 M of 1074 M
-// cells) the blocks hold twice the cells of the runs, and the 9 % the plane kernel gains per visited cell (2.63 vs 2.87 ms
-// at 1024^3) are lost many times over: measured there, V-cycle 2.48 ms through the quad kernel, 3.07 ms through the plane
-// kernel.  The level goes to whichever costs less, cells visited x cost per cell (runCostFactor; plane 0.92).  0 = the quad
+// cells) the blocks hold twice the cells of the runs, and the few percent the plane kernel gains per visited cell on planes
+// beyond 4 MiB (round 1 measured 9 % at 1024^2, before the quad kernel caught up there) are lost many times over: measured on
+// that case, V-cycle 2.48 ms through the quad kernel, 3.07 ms through the plane kernel.  The level goes to whichever costs less, cells visited x cost per cell (runCostFactor; plane 0.92).  0 = the quad
 // sweep (options.stencil_path = 2 still forces the plane kernel).
 int planeZcFor(const mgps_options &o, int planeZc, size_t nplaneBlocks, size_t nchunks, int chunkCells)
 {
@@ -1822,32 +1820,38 @@ struct StageClock {
 };
 
 // codesPreloaded: the caller allocated L.codes, copies the labels into it itself and patches the simple cells afterwards
-// The boxes of a level once info / list / general are on the device, whoever built them: the update lists (launchBandBoxUpdates)
-// and the launch order of the groups (orderBandBoxes; MGPS_BOX_ORDER=0 keeps the builders' tile order: A/B)
+// The boxes of a level once info / list / general are on the device, whoever built them: the lists compacted
+// (compactBandBoxLists) and the launch order of the groups (orderBandBoxes; MGPS_BOX_ORDER=0 keeps the builders' tile order: A/B)
 int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
 {
     BandBoxesDev &bx = L.bandBoxes;
-    MGPS_TRY(devAlloc(h, &bx.ulist, bx.listCount, true));  // (zeroed: the slots past a group's update count are never written, and tests compare the array)
-    MGPS_TRY(devAlloc(h, &bx.uinfo, size_t(kBoxUInfoInts) * size_t(bx.ngroups), false));
-    MGPS_LAUNCH(h, launchBandBoxUpdates(s, bx));
+    {  // the lists as the kernels walk them: no class-2 entries, class-12 entries last (compactBandBoxLists)
+        uint32_t *list2 = nullptr;
+        MGPS_TRY(devAlloc(h, &list2, bx.listCount, false));
+        size_t count2 = 0;
+        const int e = compactBandBoxLists(s, bx.info, bx.list, bx.ngroups, list2, &count2);
+        if (e != 0) {
+            (void)cacheFree(list2);
+            return failH(h, MGPS_ERR_HIP, std::string("compactBandBoxLists: ") + hipGetErrorString(hipError_t(e)));
+        }
+        (void)cacheFree(bx.list);
+        bx.list = list2;
+        bx.listCount = count2;
+    }
     static const bool ordered = [] {
         const char *e = getenv("MGPS_BOX_ORDER");
         return !(e && e[0] == '0');
     }();
     if (!ordered || bx.ngroups < 64) return MGPS_OK;  // (fewer groups than a chiplet has in flight)
-    int32_t *info2 = nullptr, *uinfo2 = nullptr;
+    int32_t *info2 = nullptr;
     MGPS_TRY(devAlloc(h, &info2, size_t(kBoxInfoInts) * size_t(bx.ngroups), false));
-    MGPS_TRY(devAlloc(h, &uinfo2, size_t(kBoxUInfoInts) * size_t(bx.ngroups), false));
-    const int e = orderBandBoxes(s, L.d, bx.info, bx.uinfo, bx.ngroups, info2, uinfo2);
+    const int e = orderBandBoxes(s, L.d, bx.info, bx.ngroups, info2);
     if (e != 0) {
         (void)cacheFree(info2);
-        (void)cacheFree(uinfo2);
         return failH(h, MGPS_ERR_HIP, std::string("orderBandBoxes: ") + hipGetErrorString(hipError_t(e)));
     }
     (void)cacheFree(bx.info);
-    (void)cacheFree(bx.uinfo);
     bx.info = info2;
-    bx.uinfo = uinfo2;
     return MGPS_OK;
 }
 
@@ -3479,8 +3483,6 @@ try {
     case 11: src = L.bandBoxes.info, n = size_t(kBoxInfoInts) * size_t(L.bandBoxes.ngroups); break;
     case 12: src = L.bandBoxes.list, n = L.bandBoxes.listCount; break;
     case 13: src = L.bandBoxes.general, n = L.bandBoxes.generalInts; break;
-    case 14: src = L.bandBoxes.ulist, n = L.bandBoxes.listCount; break;
-    case 15: src = L.bandBoxes.uinfo, n = size_t(kBoxUInfoInts) * size_t(L.bandBoxes.ngroups); break;
     default: return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_level_array: unknown array");
     }
     *count = int64_t(n);

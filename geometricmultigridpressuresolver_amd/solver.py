@@ -245,7 +245,7 @@ class GeometricMultigridPoissonSolver:
     LEVEL_ARRAYS = {"codes": (0, np.uint8), "band": (1, np.int32), "band_diag": (2, np.uint8), "rows": (3, np.float32), "chunks": (4, np.int32),
                     "plane_blocks": (5, np.int32), "pure_even": (6, np.int32), "pure_odd": (7, np.int32), "mixed_even": (8, np.int32),
                     "mixed_odd": (9, np.int32), "tile_bnd_start": (10, np.int32), "box_info": (11, np.int32), "box_list": (12, np.uint32),
-                    "box_general": (13, np.int32), "box_ulist": (14, np.uint32), "box_uinfo": (15, np.int32)}
+                    "box_general": (13, np.int32)}
 
     def level_array(self, level, name):
         """mgps_level_array: one of the set-up arrays of a level as it sits on the device (tests / tools)."""

@@ -155,8 +155,7 @@ int mgps_device_count(int *count);
  * 0 cell codes (u8, nx*ny*nz), 1 band list in device order (i32), 2 band diagonals (u8), 3 operator rows of the general
  * BOUNDARY cells (f32, 7 x count SoA), 4 activity chunks (i32), 5 plane blocks (i32), 6 / 7 pure tiles even / odd (i32),
  * 8 / 9 mixed tiles even / odd (i32), 10 per-tile start of the general BOUNDARY cells (i32), 11..13 the boxes of the fused
- * band stage: info (i32, 16 per group), list entries (u32), general entries (i32, 2 per entry), 14 / 15 their update lists
- * (u32, at the groups' list offsets, zero-padded) and update counts (i32, 8 per group).
+ * band stage: info (i32, 16 per group, in launch order), list entries (u32), general entries (i32, 2 per entry).
  * *count = number of elements; out == NULL asks for the count only. */
 int mgps_level_array(mgps_solver *h, int level, int which, void *out, int64_t *count);
 

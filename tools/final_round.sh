@@ -21,7 +21,16 @@ python tools/prof_pcg.py 512 0 1 2>/dev/null | tail -n 1 > gpurun_out/${round}_p
 python tools/prof_pcg.py 512 1 1 2>/dev/null | tail -n 1 >> gpurun_out/${round}_pcg512_gs_fp32_vs_mixed.txt
 # multi-GPU compute ceiling (null transport on one GPU) and slab set-up time
 python tools/slab_compute_bound.py 1024 > gpurun_out/${round}_slab_compute_bound_1024.json 2> gpurun_out/slab_cb.err || echo "slab_compute_bound failed"
-python tools/slab_setup_time.py 1024 8 3 > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
+python tools/slab_setup_time.py 1024 8 3 host > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
+python tools/slab_setup_time.py 1024 8 3 device >> gpurun_out/${round}_slab_setup_time_1024.txt 2>> gpurun_out/slab_st.err || echo "slab_setup_time (device) failed"
+python tools/slab_setup_time.py 1024 8 0 device >> gpurun_out/${round}_slab_setup_time_1024.txt 2>> gpurun_out/slab_st.err || echo "slab_setup_time (rank 0) failed"
+MGPS_SETUP_TIMING=1 python tools/slab_setup_time.py 1024 8 3 device 2>&1 | grep "mgps set-up: slab" | tail -16 >> gpurun_out/${round}_slab_setup_time_1024.txt
+# the plugin's own configuration untraced (512^3 pool MG-PCG, every CG vector mode), and the Gauss-Seidel band stage A/B
+python bench.py --workload free_surface_pcg --size 512 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_free_surface_untraced.json
+for v in 1 0; do MGPS_GS_SNAPSHOT=$v python bench.py --size 512 --smoother gs --no-frac512 --no-cpu --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_gs_snapshot$v.json; done
+# SQ / TCP / TCC counters of the 1024^3 and 512^3 kernels (the kernel the bench line names included)
+bash tools/sq_pmc.sh ${round} 1024 > /dev/null 2>&1; bash tools/sq_pmc.sh ${round} 512 > /dev/null 2>&1
+tools/facebench 1024 > gpurun_out/${round}_facebench.txt 2>&1; tools/facebench 512 >> gpurun_out/${round}_facebench.txt 2>&1
 for sz in 256 512; do
   rocprofv3 --kernel-trace -d gpurun_out/tl_$sz --output-format csv -- python3 bench.py --size $sz --steps 6 --warmup 2 --no-cpu --no-frac512 > /dev/null 2>&1
   python3 tools/cycle_timeline.py gpurun_out/tl_$sz 7 > gpurun_out/${round}_cycle_timeline_$sz.txt  # (a cycle of the timed region: the last five carry the stage timers)
