@@ -74,7 +74,42 @@ struct RcclState {
     double *scratchDev = nullptr;  // all-reduce staging
     double *scratchHost = nullptr;
     hipStream_t own = nullptr;     // stream of the scalar all-reduces
+    // The solver uses the communicator from more than one stream (the scalar all-reduces above; since round 4 the exchanges that
+    // follow a sweep go on a transfer stream beside the sweep's interior part).  Every rank issues its calls in the same
+    // order, which is what the library asks for; so that two operations of one communicator never run side by side on the
+    // device -- a combination this code has never been run with on more than one GPU -- each operation waits for the event
+    // the previous one left when it was queued on another stream.  Compute beside a transfer is unaffected.
+    hipEvent_t lastDone = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool used = false;
 };
+int commBegin(RcclState *s, hipStream_t st)
+{
+    if (s->used && s->lastStream != st && s->lastDone && hipStreamWaitEvent(st, s->lastDone, 0) != hipSuccess) return 1;
+    return 0;
+}
+int commEnd(RcclState *s, hipStream_t st)
+{
+    if (!s->lastDone && hipEventCreateWithFlags(&s->lastDone, hipEventDisableTiming) != hipSuccess) return 1;
+    if (hipEventRecord(s->lastDone, st) != hipSuccess) return 1;
+    s->lastStream = st;
+    s->used = true;
+    return 0;
+}
+#define COMM_ORDER_BEGIN(s, st)                                                         \
+    do {                                                                                \
+        if (commBegin(s, st)) {                                                         \
+            setLastGlobalError("mgps rccl transport: hipStreamWaitEvent failed");       \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+#define COMM_ORDER_END(s, st)                                                           \
+    do {                                                                                \
+        if (commEnd(s, st)) {                                                           \
+            setLastGlobalError("mgps rccl transport: hipEventRecord failed");           \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
 
 #define NCCL_TRY(call)                                                                              \
     do {                                                                                            \
@@ -98,12 +133,14 @@ int rcclExchange(void *user, const void *sendLo, size_t sendLoBytes, void *recvL
 {
     auto *s = static_cast<RcclState *>(user);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    COMM_ORDER_BEGIN(s, st);
     NCCL_TRY(gApi.GroupStart());
     if (sendLo && sendLoBytes) NCCL_TRY(gApi.Send(sendLo, sendLoBytes, ncclChar, s->rank - 1, s->comm, st));
     if (recvLo && recvLoBytes) NCCL_TRY(gApi.Recv(recvLo, recvLoBytes, ncclChar, s->rank - 1, s->comm, st));
     if (sendHi && sendHiBytes) NCCL_TRY(gApi.Send(sendHi, sendHiBytes, ncclChar, s->rank + 1, s->comm, st));
     if (recvHi && recvHiBytes) NCCL_TRY(gApi.Recv(recvHi, recvHiBytes, ncclChar, s->rank + 1, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -113,7 +150,9 @@ int rcclAllreduce(void *user, double *values, int count, int op)
     if (count > 64) return 1;
     std::memcpy(s->scratchHost, values, size_t(count) * sizeof(double));
     HIP_TRY(hipMemcpyAsync(s->scratchDev, s->scratchHost, size_t(count) * sizeof(double), hipMemcpyHostToDevice, s->own));
+    COMM_ORDER_BEGIN(s, s->own);
     NCCL_TRY(gApi.AllReduce(s->scratchDev, s->scratchDev, size_t(count), ncclDouble, op == 0 ? ncclSum : ncclMax, s->comm, s->own));
+    COMM_ORDER_END(s, s->own);
     HIP_TRY(hipMemcpyAsync(s->scratchHost, s->scratchDev, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, s->own));
     HIP_TRY(hipStreamSynchronize(s->own));
     std::memcpy(values, s->scratchHost, size_t(count) * sizeof(double));
@@ -124,7 +163,10 @@ int rcclAllreduce(void *user, double *values, int count, int op)
 int rcclAllreduceDevice(void *user, double *valuesDev, int count, int op, void *stream)
 {
     auto *s = static_cast<RcclState *>(user);
-    NCCL_TRY(gApi.AllReduce(valuesDev, valuesDev, size_t(count), ncclDouble, op == 0 ? ncclSum : ncclMax, s->comm, static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    COMM_ORDER_BEGIN(s, st);
+    NCCL_TRY(gApi.AllReduce(valuesDev, valuesDev, size_t(count), ncclDouble, op == 0 ? ncclSum : ncclMax, s->comm, st));
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -133,6 +175,7 @@ int rcclGather(void *user, const void *send, void *recv, size_t bytes, int root,
     auto *s = static_cast<RcclState *>(user);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (s->rank == root) HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + size_t(root) * bytes, send, bytes, hipMemcpyDeviceToDevice, st));
+    COMM_ORDER_BEGIN(s, st);
     NCCL_TRY(gApi.GroupStart());
     if (s->rank == root) {
         for (int r = 0; r < s->size; ++r)
@@ -140,6 +183,7 @@ int rcclGather(void *user, const void *send, void *recv, size_t bytes, int root,
     } else
         NCCL_TRY(gApi.Send(send, bytes, ncclChar, root, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -149,6 +193,7 @@ int rcclGatherv(void *user, const void *send, size_t sendBytes, void *recv, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (s->rank == root && sendBytes)
         HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + displs[root], send, sendBytes, hipMemcpyDeviceToDevice, st));
+    COMM_ORDER_BEGIN(s, st);
     NCCL_TRY(gApi.GroupStart());
     if (s->rank == root) {
         for (int r = 0; r < s->size; ++r)
@@ -156,6 +201,7 @@ int rcclGatherv(void *user, const void *send, size_t sendBytes, void *recv, cons
     } else if (sendBytes)
         NCCL_TRY(gApi.Send(send, sendBytes, ncclChar, root, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -165,6 +211,7 @@ int rcclScatterv(void *user, const void *send, const size_t *counts, const size_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (s->rank == root && recvBytes)
         HIP_TRY(hipMemcpyAsync(recv, static_cast<const char *>(send) + displs[root], recvBytes, hipMemcpyDeviceToDevice, st));
+    COMM_ORDER_BEGIN(s, st);
     NCCL_TRY(gApi.GroupStart());
     if (s->rank == root) {
         for (int r = 0; r < s->size; ++r)
@@ -172,6 +219,7 @@ int rcclScatterv(void *user, const void *send, const size_t *counts, const size_
     } else if (recvBytes)
         NCCL_TRY(gApi.Recv(recv, recvBytes, ncclChar, root, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -180,6 +228,7 @@ int rcclScatter(void *user, const void *send, void *recv, size_t bytes, int root
     auto *s = static_cast<RcclState *>(user);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (s->rank == root) HIP_TRY(hipMemcpyAsync(recv, static_cast<const char *>(send) + size_t(root) * bytes, bytes, hipMemcpyDeviceToDevice, st));
+    COMM_ORDER_BEGIN(s, st);
     NCCL_TRY(gApi.GroupStart());
     if (s->rank == root) {
         for (int r = 0; r < s->size; ++r)
@@ -187,6 +236,7 @@ int rcclScatter(void *user, const void *send, void *recv, size_t bytes, int root
     } else
         NCCL_TRY(gApi.Recv(recv, bytes, ncclChar, root, s->comm, st));
     NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
     return 0;
 }
 
@@ -195,6 +245,7 @@ void rcclDestroy(void *user)
     auto *s = static_cast<RcclState *>(user);
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->lastDone) (void)hipEventDestroy(s->lastDone);
     if (s->comm) gApi.CommDestroy(s->comm);
     (void)hipFree(s->scratchDev);
     if (s->scratchHost) (void)hipHostFree(s->scratchHost);
