@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -1008,6 +1009,22 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
 
 int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid = false, bool wantDot = false);
 
+// MGPS_POISON_SPARES=1 (tests): the grids a zero-start stroke neither clears nor is supposed to read -- the never-cleared iterate
+// and its Jacobi partner -- get NaN in every active cell first.  The shortcut rests on "nobody reads them before writing them";
+// a stale read then poisons the result instead of hiding behind the previous cycle's plausible values
+int poisonSpares(mgps_solver *h, int l, float *a, float *b2)
+{
+    static const bool on = [] {
+        const char *e = getenv("MGPS_POISON_SPARES");
+        return e && e[0] == '1';
+    }();
+    if (!on) return MGPS_OK;
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    MGPS_LAUNCH(h, launchScale(h->stream, h->lv[l].g, a, nan));
+    MGPS_LAUNCH(h, launchScale(h->stream, h->lv[l].g, b2, nan));
+    return MGPS_OK;
+}
+
 // Up-stroke of level l as "Jacobi(x + 4 P e)" in one pass (launchProlongJacobi) + the two box launches: single-device levels that
 // take the plane-marching sweep and the box form of the band stage, the reference's one Jacobi sweep per stroke
 bool prolongFusable(const mgps_solver *h, int l, const float *cur, const float *other, const float *b)
@@ -1106,8 +1123,8 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
     bool fresh = false, zero0 = false;
     if (!useInitialGuess) {  // MG.cpp:439-440
         zero0 = ownGrid && strokeTakesZero(h, 0, cur[0], other[0], b, h->gatherDot && !hasBottom);
-        if (zero0) {
-        } else if (ownGrid) MGPS_TRY(zeroOwnGrid(h, 0, x, true));
+        if (zero0) MGPS_TRY(poisonSpares(h, 0, cur[0], other[0]));
+        else if (ownGrid) MGPS_TRY(zeroOwnGrid(h, 0, x, true));
         else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
@@ -1128,6 +1145,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 rhs = F.b;
                 const bool zl = strokeTakesZero(h, l, cur[l], other[l], rhs, false);
                 if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
+                else MGPS_TRY(poisonSpares(h, l, cur[l], other[l]));
                 haveResidual = zl && downStrokeFusesResidual(h, l);
                 if (haveResidual) MGPS_TRY(zeroStrokeWithResidual(h, l, cur[l], other[l], rhs));
                 else MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
@@ -1211,6 +1229,7 @@ int innerCycle(mgps_solver *h, int first, float **result)
         other[l] = F.tmp;
         const bool zl = strokeTakesZero(h, l, cur[l], other[l], F.b, false);
         if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
+        else MGPS_TRY(poisonSpares(h, l, cur[l], other[l]));
         MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, true, true, false, zl));
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], F.b, 0.f, true));
         MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));

@@ -190,7 +190,8 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_RESTRICT", "cube512"),
+                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"),
+                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -208,6 +209,8 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     MGPS_ZERO_START (default on) -- down-strokes that start from the zero iterate take it as zero instead of clearing and
     reading the grid: the never-cleared grids then hold the previous cycle's values (the second cycle and the PCG run on such
     stale grids), which must not reach the result -- the invariant behind the shortcut.
+    MGPS_POISON_SPARES (a test hook, off by default) -- NaN in every active cell of the grids a zero-start stroke neither clears
+    nor may read, before every such stroke: a stale read would poison the answer; it must stay bit-equal and finite.
     MGPS_RESTRICT (default: the LDS-tiled march, restrictTileKernel; "march": the register-only march it replaced) -- the same
     sums in the same order, compared to round-off (not bit for bit: two kernels, two FMA contractions); cube512: the 512^3 cube, whose 256^3 coarse level is large enough to take either.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
@@ -270,7 +273,7 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
-    assert np.abs(outs[0]["x"]).max() > 0
+    assert np.abs(outs[0]["x"]).max() > 0 and all(np.isfinite(outs[0][key]).all() for key in ("x", "y", "z"))
     for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
         if switch == "MGPS_RESTRICT":  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
             assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-6 * np.abs(outs[1][key]).max(), key
