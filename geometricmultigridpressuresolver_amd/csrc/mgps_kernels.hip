@@ -2897,8 +2897,18 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     }();
     // the march is a serial chain of kc coarse planes per thread: below ~2048 workgroups of columns the chip is not
     // filled and the thread-per-cell kernel wins (coarse 128^3: 19 us against 51 us)
-    const int kc = 16;
-    const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8, nbz = (coarse.nz + kc - 1) / kc;
+    // (kc: coarse planes a workgroup marches.  16 where that still leaves >= 8192 workgroups; fewer planes -- more workgroups, a
+    // little more plane overlap -- on smaller levels: a 256^3 coarse level has 2048 columns of tiles, two waves per SIMD at kc = 16)
+    static const int kcForced = [] {
+        const char *e = getenv("MGPS_RESTRICT_KC");
+        const int v = e ? atoi(e) : 0;
+        return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
+    }();
+    int kc = 16;
+    const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8;
+    while (!kcForced && kc > 4 && size_t(nbx) * nby * ((coarse.nz + kc - 1) / kc) < 8192) kc >>= 1;
+    if (kcForced) kc = kcForced;
+    const unsigned nbz = (coarse.nz + kc - 1) / kc;
     // (the march walks every coarse column; the per-cell kernel walks the coarse level's activity runs at 1.3 x the cost per
     // cell -- 1.13 vs 0.88 ms at 1024^3 -> 512^3, 0.14 vs 0.118 ms one level down: it takes over where those runs hold a
     // clearly smaller part of the level.  On the cube they hold 76 %: the march stays)
