@@ -144,6 +144,23 @@ int rcclExchange(void *user, const void *sendLo, size_t sendLoBytes, void *recvL
     return 0;
 }
 
+int rcclExchange2(void *user, const mgps_xfer2 *sendLo, const mgps_xfer2 *recvLo, const mgps_xfer2 *sendHi, const mgps_xfer2 *recvHi, void *stream)
+{
+    auto *s = static_cast<RcclState *>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    COMM_ORDER_BEGIN(s, st);
+    NCCL_TRY(gApi.GroupStart());
+    for (int q = 0; q < 2; ++q) {  // segment 0 of every message, then segment 1: the same order on both ends of a link
+        if (sendLo && sendLo->bytes[q]) NCCL_TRY(gApi.Send(sendLo->ptr[q], sendLo->bytes[q], ncclChar, s->rank - 1, s->comm, st));
+        if (recvLo && recvLo->bytes[q]) NCCL_TRY(gApi.Recv(recvLo->ptr[q], recvLo->bytes[q], ncclChar, s->rank - 1, s->comm, st));
+        if (sendHi && sendHi->bytes[q]) NCCL_TRY(gApi.Send(sendHi->ptr[q], sendHi->bytes[q], ncclChar, s->rank + 1, s->comm, st));
+        if (recvHi && recvHi->bytes[q]) NCCL_TRY(gApi.Recv(recvHi->ptr[q], recvHi->bytes[q], ncclChar, s->rank + 1, s->comm, st));
+    }
+    NCCL_TRY(gApi.GroupEnd());
+    COMM_ORDER_END(s, st);
+    return 0;
+}
+
 int rcclAllreduce(void *user, double *values, int count, int op)
 {
     auto *s = static_cast<RcclState *>(user);
@@ -325,6 +342,7 @@ try {
     out->gatherv = rcclGatherv;
     out->scatterv = rcclScatterv;
     out->allreduce_device = rcclAllreduceDevice;
+    out->exchange2 = rcclExchange2;
     return MGPS_OK;
 }
 MGPS_API_CATCH(nullptr)

@@ -417,8 +417,10 @@ struct HaloSide {
     int nb = 0;
     float *hx = nullptr, *hb = nullptr;
 };
-int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane);
-int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane);
+// withPlane = false: only the lists are packed / unpacked (at their usual place behind the plane's slot in buf); the plane
+// itself goes straight from / into the grid as segment 0 of the message (mgps_comm::exchange2)
+int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane, bool withPlane = true);
+int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane, bool withPlane = true);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 // snap / snapTile (optional): the tiles flagged in snapTile (launchMarkSnapTiles) leave a second copy of their result in `snap`
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,

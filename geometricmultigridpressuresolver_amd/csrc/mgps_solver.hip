@@ -563,11 +563,27 @@ int bandStageDeep(mgps_solver *h, int l, float *x, const float *b, hipStream_t o
     // the message (pack, transfer, unpack) on `on` -- the solver's stream, or the transfer stream of an overlapped sweep: then
     // the fused stage on the solver's stream waits for it
     hipStream_t cs = on ? on : h->stream;
-    MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane));
     ++h->exchanges;
-    MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
-                                  hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], cs));
-    MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane));
+    if (h->comm.exchange2) {  // the boundary plane straight from the grid into the neighbour's ghost plane, the packed lists behind it
+        MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane, false));
+        const size_t pb = plane * sizeof(float);
+        mgps_xfer2 seg[4];  // send lo, recv lo, send hi, recv hi
+        if (lo) {
+            seg[0] = mgps_xfer2{{x, H.sendBuf[0] + plane}, {pb, bytes[0] - pb}};
+            seg[1] = mgps_xfer2{{x - plane, H.recvBuf[0] + plane}, {pb, rbytes[0] - pb}};
+        }
+        if (hi) {
+            seg[2] = mgps_xfer2{{x + (size_t(L.d.nz) - 1) * plane, H.sendBuf[1] + plane}, {pb, bytes[1] - pb}};
+            seg[3] = mgps_xfer2{{x + size_t(L.d.nz) * plane, H.recvBuf[1] + plane}, {pb, rbytes[1] - pb}};
+        }
+        MGPS_COMM(h, h->comm.exchange2(h->comm.user, lo ? &seg[0] : nullptr, lo ? &seg[1] : nullptr, hi ? &seg[2] : nullptr, hi ? &seg[3] : nullptr, cs));
+        MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane, false));
+    } else {
+        MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane));
+        MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
+                                      hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], cs));
+        MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane));
+    }
     if (on) {
         MGPS_HIP(h, hipEventRecord(h->evComm, on));
         MGPS_HIP(h, hipStreamWaitEvent(h->stream, h->evComm, 0));

@@ -31,6 +31,15 @@ _SCATV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.P
 _ALLRD = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 
+class Xfer2(C.Structure):
+    """mgps_xfer2: one message of mgps_comm.exchange2 in two segments"""
+
+    _fields_ = [("ptr", C.c_void_p * 2), ("bytes", C.c_size_t * 2)]
+
+
+_EXCH2 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Xfer2), C.POINTER(Xfer2), C.POINTER(Xfer2), C.POINTER(Xfer2), C.c_void_p)
+
+
 class CommStruct(C.Structure):
     """mgps_comm (include/mgps.h)."""
 
@@ -47,6 +56,7 @@ class CommStruct(C.Structure):
         ("gatherv", _GATHV),
         ("scatterv", _SCATV),
         ("allreduce_device", _ALLRD),
+        ("exchange2", _EXCH2),
     ]
 
 
@@ -96,9 +106,10 @@ class TorchDistComm:
         self.exchanges = 0
         self.bytes_sent = 0
         self._cb = (_EXCH(self._exchange), _ALLR(self._allreduce), _GATH(self._gather), _GATH(self._scatter))
-        self._cbv = (_GATHV(self._gatherv), _SCATV(self._scatterv), _ALLRD(self._allreduce_device))
+        self._cbv = (_GATHV(self._gatherv), _SCATV(self._scatterv), _ALLRD(self._allreduce_device), _EXCH2(self._exchange2))
         self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST(), *self._cbv)
         self.device_allreduces = 0
+        self.segmented_exchanges = 0
 
     # -- staging helpers ---------------------------------------------------------------------------
     def _d2h(self, ptr, nbytes, stream):
@@ -135,6 +146,31 @@ class TorchDistComm:
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print("TorchDistComm.exchange failed:", e, flush=True)
+            return 1
+
+    def _exchange2(self, user, send_lo, recv_lo, send_hi, recv_hi, stream):
+        """exchange with two segments per message (segment 0 of every message first, then segment 1)"""
+        try:
+            self.exchanges += 1
+            self.segmented_exchanges += 1
+            ops, recvs = [], []
+            for q in range(2):
+                for send, recv, peer in ((send_lo, recv_lo, self.rank - 1), (send_hi, recv_hi, self.rank + 1)):
+                    if send and send.contents.bytes[q]:
+                        self.bytes_sent += send.contents.bytes[q]
+                        out = self._d2h(send.contents.ptr[q], send.contents.bytes[q], stream)
+                        ops.append(dist.P2POp(dist.isend, out, self._global(peer), self.group))
+                    if recv and recv.contents.bytes[q]:
+                        inc = torch.empty(recv.contents.bytes[q], dtype=torch.uint8)
+                        ops.append(dist.P2POp(dist.irecv, inc, self._global(peer), self.group))
+                        recvs.append((recv.contents.ptr[q], inc))
+            for w in dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            for ptr, inc in recvs:
+                self._h2d(ptr, inc)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("TorchDistComm.exchange2 failed:", e, flush=True)
             return 1
 
     def _allreduce(self, user, values, count, op):

@@ -345,6 +345,7 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
  * over anything else (the test-suite plugs torch.distributed/gloo in through it).
  * All pointers handed to exchange / gather / scatter are device pointers; `hip_stream` is the
  * solver's stream: an implementation either enqueues on it or synchronises it and blocks. */
+struct mgps_xfer2;
 typedef struct mgps_comm {
     int struct_size; /* sizeof(mgps_comm) as the caller was compiled: members appended later (allreduce_device) may be missing and read as NULL */
     int rank, size;
@@ -375,7 +376,18 @@ typedef struct mgps_comm {
      * the host and |r|^2 -- the convergence test -- is the one host round trip of an iteration.  NULL is allowed: the loop then
      * sums every scalar through `allreduce` (three round trips per iteration). */
     int (*allreduce_device)(void *user, double *values_dev, int count, int op, void *hip_stream);
+    /* `exchange` with two segments per message (round 4; NULL is allowed: the solver then packs everything into one buffer).
+     * The band-stage message of a cut level is the boundary plane of x -- 4 MiB of its ~4.5 MiB at 1024^3, contiguous in the
+     * grid -- and the packed closure lists: with this entry the plane travels straight from / into the grids and only the lists
+     * are packed.  Each argument describes one message: segment 0, then segment 1, sent / received back to back in that order
+     * (a segment of 0 bytes is skipped); NULL = no neighbour on that side.  All four in ONE group, like `exchange`. */
+    int (*exchange2)(void *user, const struct mgps_xfer2 *send_lo, const struct mgps_xfer2 *recv_lo, const struct mgps_xfer2 *send_hi,
+                     const struct mgps_xfer2 *recv_hi, void *hip_stream);
 } mgps_comm;
+typedef struct mgps_xfer2 {
+    void *ptr[2]; /* device pointers (read-only for a send) */
+    size_t bytes[2];
+} mgps_xfer2;
 
 /* RCCL transport.  Rank 0 calls mgps_rccl_unique_id and ships the 128 bytes to the other ranks by
  * any means (the bench uses torch.distributed.broadcast); then every rank calls

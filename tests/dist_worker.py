@@ -104,6 +104,8 @@ def gpu_mode():
             assert comm.device_allreduces >= 3 * ss["iterations"], (comm.device_allreduces, ss)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
+            # the one-exchange band stage sends the boundary plane straight from the grid (mgps_comm::exchange2), only the lists packed
+            assert (comm.segmented_exchanges > 0) == (deep == 1), (deep, comm.segmented_exchanges)
             # exchanges queued on the transfer stream beside the interior part of the sweep that made their planes
             if os.environ.get("MGPS_OVERLAP") == "0":
                 assert slab.overlapped_exchanges == 0
