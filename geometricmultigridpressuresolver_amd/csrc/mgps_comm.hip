@@ -381,6 +381,29 @@ try {
             setLastGlobalError("mgps_comm_rccl_selftest: received data differ from the data sent");
             rc = MGPS_ERR_COMM;
         }
+        // the call shape of exchange2: two segments per message, all four operations in one group, segment by segment
+        if (rc == MGPS_OK && e == hipSuccess && floats >= 2) {
+            e = hipMemset(dst, 0, floats * sizeof(float));
+            const size_t a = floats / 3 + 1, b = floats - a;  // uneven halves
+            if (e == hipSuccess) {
+                r = gApi.GroupStart();
+                if (r == ncclSuccess) r = gApi.Send(src, a * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+                if (r == ncclSuccess) r = gApi.Recv(dst, a * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+                if (r == ncclSuccess) r = gApi.Send(src + a, b * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+                if (r == ncclSuccess) r = gApi.Recv(dst + a, b * sizeof(float), ncclChar, s->rank, s->comm, s->own);
+                if (r == ncclSuccess) r = gApi.GroupEnd();
+                if (r != ncclSuccess) {
+                    setLastGlobalError(std::string("mgps_comm_rccl_selftest (two segments): ") + gApi.GetErrorString(r));
+                    rc = MGPS_ERR_COMM;
+                }
+                if (rc == MGPS_OK) e = hipStreamSynchronize(s->own);
+                if (rc == MGPS_OK && e == hipSuccess) e = hipMemcpy(back.data(), dst, floats * sizeof(float), hipMemcpyDeviceToHost);
+                if (rc == MGPS_OK && e == hipSuccess && back != host) {
+                    setLastGlobalError("mgps_comm_rccl_selftest: two-segment messages arrived out of order or incomplete");
+                    rc = MGPS_ERR_COMM;
+                }
+            }
+        }
     }
     (void)hipFree(src);
     (void)hipFree(dst);

@@ -448,6 +448,138 @@ GridP g, float *__restrict__ out,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The residual of a down-stroke, restricted along z as it is formed (round 4; Ops.h:716-732 into the z part of Ops.h:734-835).
+// Full weighting is separable: coarse(I, J, K) = sum_c w_c sum_b w_b sum_a w_a r(2I-1+a, 2J-1+b, 2K-1+c).  The plane-marching
+// form above walks the planes of a column in order, so a thread can fold the four planes of every coarse K itself and store
+// rz(i, j, K) = w0 r(2K-1) + w1 r(2K) + w2 r(2K+1) + w3 r(2K+2) -- half the planes of r, which is never written: 11 B per
+// cell instead of 13, and the x-y restriction that follows (restrictXYKernel) reads 2 B per fine cell with no overlap along
+// z instead of 4 B with the 4-plane footprint.  A block of planes [k0, k1) also forms r on planes k0 - 1 and k1 (two more
+// planes per zc).  Levels without general BOUNDARY cells, ghost planes or binary16 grids (launchResidualZ); `rz` is a grid
+// of nx x ny x nz/2 that nobody else writes: the blocks without active cells are never visited and stay zero.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, float *__restrict__ rz, const float *__restrict__ x,
+                                                                     const float *__restrict__ b, unsigned nbx, unsigned nby, int zc,
+                                                                     const int32_t *__restrict__ blocks)
+{
+    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
+    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    if (blocks) bid = unsigned(blocks[bid]);
+    bid = __builtin_amdgcn_readfirstlane(bid);  // (the plane bases below: scalar registers)
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
+    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
+    const bool live = ic >= g.xlo && ic < g.xhi;
+    const bool valid = i < g.nx && j < g.ny && live;
+    const size_t sz = size_t(g.nx) * g.ny;
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);  // both even
+    const int ks = max(k0 - 1, 0), ke = min(k1, g.nz - 1);   // planes outside the grid: r = 0, nothing to add
+    // addresses: the plane's base (wave-uniform: scalar registers) + one 32-bit offset inside the plane per thread
+    const unsigned off = unsigned(jc) * unsigned(g.nx) + unsigned(ic);
+    const unsigned offYm = jc > 0 ? off - unsigned(g.nx) : off, offYp = jc < g.ny - 1 ? off + unsigned(g.nx) : off;
+    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
+    const bool hasL = ic > 0, hasR = ic + 4 < g.nx;  // (the grid continues on that side)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    // (planes clamped into the grid: the first and the last plane of a whole-grid level are EXTERIOR shell, whose results are 0
+    // whatever their neighbours hold -- the assumption stencilPlaneKernel makes at the faces)
+    // (the plane index through readfirstlane: a scalar the loop optimiser cannot fold into a 64-bit vector induction variable per
+    // array -- two vector registers each, 20 bytes of scratch)
+    auto planeOf = [&](const float *p, int k) { return p + size_t(__builtin_amdgcn_readfirstlane(min(max(k, 0), g.nz - 1))) * sz; };
+    // (scalar base + 32-bit BYTE offset: the form a global_load takes with one vector register, see bandBoxBody)
+    auto q4 = [](const float *base, unsigned cell) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + cell * 4u); };
+    auto q1 = [](const float *base, unsigned cell) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + cell * 4u); };
+    float *const mine0 = plane[0] + (ty + 1) * kPlanePitch + 4 + lane * 4;
+    constexpr int kBufFloats = (kPlaneRows + 2) * kPlanePitch;
+    {  // plane ks - 1 of the thread's own quad: the z - 1 values of a step are read back from the LDS buffer of the step before
+        const float4 xm = live ? q4(planeOf(x, ks - 1), off) : zero4;
+        *reinterpret_cast<float4 *>(mine0 + kBufFloats) = xm;
+    }
+    const float *xk = planeOf(x, ks);
+    float4 xc = live ? q4(xk, off) : zero4;
+    float4 xp = live ? q4(planeOf(x, ks + 1), off) : zero4;
+    float4 hy = zero4;
+    if (live && rowTop) hy = q4(xk, offYm);
+    if (live && rowBot) hy = q4(xk, offYp);
+    // the x-halo cell of the first / last lane: one unconditional load per wave (the other lanes re-read their own cell and drop it)
+    // -- a branch per side made every wave wait for all its loads in flight before each of the two
+    const unsigned offHx = (colL && hasL) ? off - 1u : (colR && hasR) ? off + 4u : off;
+    const bool useHx = live && ((colL && hasL) || (colR && hasR));
+    float hx = live ? q1(xk, offHx) : 0.f;
+    if (!useHx) hx = 0.f;
+    constexpr float w0 = 0.125f, w1 = 0.375f, w2 = 0.375f, w3 = 0.125f;
+    // coarse plane (k - 1) / 2 with its first terms (accPrev) and the one after it (accCur), see the fold below
+    float accPrev[4] = {0.f, 0.f, 0.f, 0.f}, accCur[4] = {0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int k = ks; k <= ke; ++k) {
+        float *me = mine0 + buf * kBufFloats;
+        *reinterpret_cast<float4 *>(me) = xc;
+        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
+        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
+        if (colL) me[-1] = hx;
+        if (colR) me[4] = hx;
+        // this plane's rhs and codes (in flight across the barrier), the own quad two planes ahead, the next plane's halo
+        const float *bk = planeOf(b, k);
+        const uint8_t *lk = g.lab + size_t(__builtin_amdgcn_readfirstlane(k)) * sz;
+        const float *xn = planeOf(x, k + 1), *xq2 = planeOf(x, k + 2);
+        float4 xq = zero4, hyn = hy, bc = zero4;
+        uchar4 lc = ext4;
+        float hxn = hx;
+        if (live) {
+            bc = streamLoad4(reinterpret_cast<const float *>(reinterpret_cast<const char *>(bk) + off * 4u));
+            lc = streamLoad4(reinterpret_cast<const uint8_t *>(reinterpret_cast<const char *>(lk) + off));
+        }
+        if (k < ke && live) {
+            xq = q4(xq2, off);
+            if (rowTop) hyn = q4(xn, offYm);
+            if (rowBot) hyn = q4(xn, offYp);
+            hxn = q1(xn, offHx);
+            if (!useHx) hxn = 0.f;
+        }
+        __syncthreads();
+        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
+        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+        const float4 xm = *reinterpret_cast<const float4 *>(mine0 + (buf ^ 1) * kBufFloats);  // (this thread's own store of the last step)
+        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
+        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // the arithmetic of stencilPlaneKernel<OP_RESIDUAL>
+            const float diag = simpleDiag(ls[e]);
+            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), 0.f) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
+        }
+        // the fold along z, terms in the order of the planes: plane 2 m + 1 is the third term of coarse plane m and the first of
+        // m + 1, plane 2 m the second term of m and the last of m - 1
+        if (k & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accPrev[e] = accCur[e] + w2 * res[e];
+                accCur[e] = w0 * res[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accPrev[e] += w3 * res[e];
+                accCur[e] += w1 * res[e];
+            }
+            if (valid && k >= k0 + 2) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rz + size_t(__builtin_amdgcn_readfirstlane((k >> 1) - 1)) * sz) + off * 4u) = make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]);
+        }
+        xc = xp;
+        xp = xq;
+        hy = hyn;
+        hx = hxn;
+        buf ^= 1;
+    }
+    // the top block of the grid: plane nz does not exist, the last coarse plane is complete with three terms
+    if (valid && k1 == g.nz)
+        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rz + size_t((g.nz >> 1) - 1) * sz) + off * 4u) = make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The down-stroke's sweep and residual in ONE pass when the stroke starts from the zero iterate (MG.cpp:439-440 / 566, then
 // 445-547 / 571-660): the Jacobi sweep of x = 0 is pointwise, x1 = omega b / diag (Ops.h:356-361 with x = 0), so the residual
 // r = b - A x1 (Ops.h:716-732) needs no iterate from memory at all -- every x1 it reads is rebuilt from the rhs and the code of
@@ -1893,6 +2025,81 @@ __global__ __launch_bounds__(256) void restrictTileKernel(GridP cg, float *__res
     }
 }
 
+// The x-y half of the restriction for a residual that residualZKernel folded along z already: `rz` has the fine level's x-y
+// extents and the coarse level's planes; coarse(I, J, K) = sum_b w_b sum_a w_a rz(2I-1+a, 2J-1+b, K), x first, then y.  The
+// staging of restrictTileKernel (18 rows x 34 aligned quads per plane, two LDS buffers, one barrier per plane), one plane in,
+// one plane out: no overlap along z.
+__global__ __launch_bounds__(256) void restrictXYKernel(GridP cg, float *__restrict__ coarse, const float *__restrict__ rz, int kc, unsigned nbx, unsigned nby)
+{
+    __shared__ float tile[2][kRtRows * kRtStride];
+    __shared__ int anyActiveCol;
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int I0 = int(bx) * kRtI, J0 = int(by) * kRtJ;
+    const int li = int(threadIdx.x & 63), lp = int(threadIdx.x >> 6);
+    const int I = I0 + li, J = J0 + 2 * lp;
+    const int K0 = int(bz) * kc, K1 = min(K0 + kc, cg.nz);
+    const size_t cplane = size_t(cg.nx) * cg.ny, col = size_t(J) * cg.nx + I;
+    const bool inGrid = I < cg.nx && J < cg.ny && I >= cg.xlo && I < cg.xhi;
+    const bool second = J + 1 < cg.ny;
+    bool any = false;
+    if (inGrid)
+        for (int K = K0; K < K1; ++K) {
+            any = any || activeLabel(cg.lab[size_t(K) * cplane + col]);
+            if (second) any = any || activeLabel(cg.lab[size_t(K) * cplane + col + cg.nx]);
+        }
+    if (threadIdx.x == 0) anyActiveCol = 0;
+    __syncthreads();
+    if (any) anyActiveCol = 1;
+    __syncthreads();
+    if (!anyActiveCol) return;  // (the destination holds 0 there already)
+    const int fnx = 2 * cg.nx, fny = 2 * cg.ny;
+    const int fxlo = max(2 * cg.xlo - 4, 0), fxhi = min(2 * cg.xhi + 4, fnx);
+    ptrdiff_t off[kRtLoads];
+    bool ok[kRtLoads];
+#pragma unroll
+    for (int m = 0; m < kRtLoads; ++m) {
+        const int t = int(threadIdx.x) + m * 256;
+        const int r = t / kRtQuads, q = t % kRtQuads;
+        const int fx = 2 * I0 - 4 + 4 * q, fy = min(max(2 * J0 - 1 + r, 0), fny - 1);  // (rows clamped: results masked)
+        ok[m] = t < kRtRows * kRtQuads && fx >= fxlo && fx + 3 < fxhi;
+        off[m] = ptrdiff_t(fy) * fnx + fx;
+    }
+    auto loadPlane = [&](int K, float4 (&v)[kRtLoads]) {
+        const float *p = rz + ptrdiff_t(K) * fny * fnx;
+#pragma unroll
+        for (int m = 0; m < kRtLoads; ++m) v[m] = ok[m] ? *reinterpret_cast<const float4 *>(p + off[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const float w[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    float4 nextv[kRtLoads];
+    loadPlane(K0, nextv);
+    for (int K = K0; K < K1; ++K) {
+        float *buf = tile[K & 1];  // (the buffer of plane K - 2: everybody finished with it before the last barrier)
+#pragma unroll
+        for (int m = 0; m < kRtLoads; ++m) {
+            const int t = int(threadIdx.x) + m * 256;
+            if (t < kRtRows * kRtQuads) *reinterpret_cast<float4 *>(buf + (t / kRtQuads) * kRtStride + 4 * (t % kRtQuads)) = nextv[m];
+        }
+        if (K + 1 < K1) loadPlane(K + 1, nextv);
+        __syncthreads();
+        // this thread's two coarse columns: fine x 2 I - 1 .. 2 I + 2 = tile column 2 li + 3 .., fine rows 4 lp .. 4 lp + 5 of the tile
+        const float *p = buf + (4 * lp) * kRtStride + 2 * li + 3;
+        float rs[6];
+#pragma unroll
+        for (int yo = 0; yo < 6; ++yo) {
+            const float *r = p + yo * kRtStride;
+            const float2 mid = *reinterpret_cast<const float2 *>(r + 1);
+            rs[yo] = w[0] * r[0] + w[1] * mid.x + w[2] * mid.y + w[3] * r[3];
+        }
+        if (inGrid && any) {
+            const size_t c = size_t(K) * cplane + col;
+            const float va = w[0] * rs[0] + w[1] * rs[1] + w[2] * rs[2] + w[3] * rs[3], vb = w[0] * rs[2] + w[1] * rs[3] + w[2] * rs[4] + w[3] * rs[5];
+            coarse[c] = activeLabel(cg.lab[c]) ? va : 0.f;
+            if (second) coarse[c + cg.nx] = activeLabel(cg.lab[c + cg.nx]) ? vb : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Prolongation + add (Ops.h:873-972): fine c += 4 * trilerp(coarse) at sample point c/2 - 1/4:
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
@@ -2941,6 +3148,33 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
     }
     const unsigned nb = coarse.chunks ? unsigned(size_t(coarse.nchunks) * size_t(coarse.chunkCells) / 256) : blocksFor(n, 256);
     if (nb > 0) restrictKernel<<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine);
+    return int(hipGetLastError());
+}
+
+// The residual of level `fine` restricted to level `coarse` without writing the residual: residualZKernel into `rz` (a grid of
+// fine.nx x fine.ny x fine.nz / 2 floats, zero where no block with active cells ever writes), then restrictXYKernel.
+// residualRestrictFits: the shapes both kernels take
+bool residualRestrictFits(const GridP &fine, const GridP &coarse)
+{
+    return fine.planeZc >= 2 && (fine.planeZc & 1) == 0 && (fine.nz & 1) == 0 && fine.nbnd == 0 && !fine.ghostLo && !fine.ghostHi && coarse.nx >= 64 &&
+           (coarse.nx & 1) == 0 && 2 * coarse.nx == fine.nx && 2 * coarse.ny == fine.ny && 2 * coarse.nz == fine.nz && !coarse.ghostLo && !coarse.ghostHi;
+}
+int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b)
+{
+    const int zc = fine.planeZc;
+    const unsigned nbx = (fine.nx + 255) / 256, nby = (fine.ny + kPlaneRows - 1) / kPlaneRows, nbz = (fine.nz + zc - 1) / zc;
+    const bool list = fine.planeBlocks != nullptr;
+    const unsigned nb = list ? unsigned(fine.nplaneBlocks) : nbx * nby * nbz;
+    if (nb > 0) residualZKernel<<<nb, 64 * kPlaneRows, 0, static_cast<hipStream_t>(stream)>>>(fine, rz, x, b, nbx, nby, zc, list ? fine.planeBlocks : nullptr);
+    return int(hipGetLastError());
+}
+int launchRestrictXY(void *stream, const GridP &coarse, float *coarseOut, const float *rz)
+{
+    int kc = 16;  // (no overlap along z: any kc costs the same bytes; enough workgroups to fill the chip several times over)
+    const unsigned nbx = (coarse.nx + kRtI - 1) / kRtI, nby = (coarse.ny + kRtJ - 1) / kRtJ;
+    while (kc > 1 && size_t(nbx) * nby * ((coarse.nz + kc - 1) / kc) < 8192) kc >>= 1;
+    const unsigned nbz = (coarse.nz + kc - 1) / kc;
+    restrictXYKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, rz, kc, nbx, nby);
     return int(hipGetLastError());
 }
 

@@ -68,6 +68,7 @@ struct DevLevel {
     uint32_t *nearBand = nullptr;
     float *stage = nullptr;
     uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
+    float *rz = nullptr;            // the residual folded along z (residualRestrictFuses; nx x ny x nz / 2, made on first use, zero where nothing writes)
     uint8_t *snapTile = nullptr;    // Gauss-Seidel strokes: a byte per 16^3 tile, set where a box group reads (launchMarkSnapTiles; made on first use)
     uint32_t *keepBits = nullptr;   // launchStrokeFront: one bit per cell, the owned band / closure-output cells of the boxes (made on first use)
     // fused band stage of a cut level (SlabHalo): one exchange per stage
@@ -454,6 +455,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.planeFlags);
         (void)cacheFree(L.keepBits);
         (void)cacheFree(L.snapTile);
+        (void)cacheFree(L.rz);
         gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
@@ -839,6 +841,37 @@ int zeroStrokeWithResidual(mgps_solver *h, int l, float *&cur, float *&other, co
     return MGPS_OK;
 }
 
+// Residual + restriction of a down-stroke without the residual grid (launchResidualZ + launchRestrictXY): whole-grid fp32 levels
+// that have plane blocks and no general BOUNDARY cells (every coarse level, and the fine level of a domain whose weights are all
+// 0 / 1) and whose x-y planes are 4 MiB or more.  Measured on MI355X, separate passes against the pair, ms per cycle: 1024^3 fine level
+// residual 1.78 + restriction 0.80 against 1.80 + 0.44 (100.2 -> 103.6 cycles/s); 512^3 0.22 + 0.11 against 0.25 + 0.064 (a wash: 784
+// workgroups of 1024 threads are one and a half rounds of the chip, and the residual it never writes would have stayed in the
+// Infinity Cache); 256^3 0.027 + 0.019 against 0.048 + 0.014.  MGPS_FUSE_RR=0: never; =1: every level that fits (tests).  The
+// terms of a coarse cell are added along z first instead of last: the last bits of the coarse rhs differ from the separate passes'.
+bool residualRestrictFuses(const mgps_solver *h, int l)
+{
+    static const int mode = [] {  // -1: by size
+        const char *e = getenv("MGPS_FUSE_RR");
+        return !e ? -1 : (e[0] == '0' ? 0 : 1);
+    }();
+    if (mode == 0 || h->dist || l + 1 >= int(h->lv.size())) return false;
+    const GridP &F = h->lv[l].g;
+    if (mode < 0 && size_t(F.nx) * F.ny * sizeof(float) < kPlaneSweepMinPlaneBytes) return false;
+    return residualRestrictFits(F, h->lv[l + 1].g);
+}
+int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
+{
+    DevLevel &F = h->lv[l], &C = h->lv[l + 1];
+    if (!F.rz) MGPS_TRY(devAlloc(h, &F.rz, F.d.cells() / 2, true));
+    {
+        StageScope scope(h, ST_RESIDUAL, l);
+        MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs));
+    }
+    StageScope scope(h, ST_RESTRICT, l);
+    MGPS_LAUNCH(h, launchRestrictXY(h->stream, C.g, C.b, F.rz));
+    return MGPS_OK;
+}
+
 // The closure launch and the sweep of a stroke in one launch (launchStrokeFront): whole-grid levels that take the quad sweep, up to
 // MGPS_FRONT_MAX_CELLS cells (default 2^24 = a 256^3 level; 0 = off) -- where a launch is a latency chain, one chain instead of two
 bool strokeFrontMerges(const mgps_solver *h, int l)
@@ -1167,6 +1200,10 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 else MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
             }
             bool rExchanged = false;
+            if (!haveResidual && residualRestrictFuses(h, l)) {
+                MGPS_TRY(residualRestrict(h, l, cur[l], rhs));
+                continue;
+            }
             if (!haveResidual) {
                 StageScope scope(h, ST_RESIDUAL, l);
                 MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
@@ -1247,6 +1284,10 @@ int innerCycle(mgps_solver *h, int first, float **result)
         if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
         else MGPS_TRY(poisonSpares(h, l, cur[l], other[l]));
         MGPS_TRY(smoothStroke(h, l, cur[l], other[l], F.b, true, true, false, zl));
+        if (residualRestrictFuses(h, l)) {
+            MGPS_TRY(residualRestrict(h, l, cur[l], F.b));
+            continue;
+        }
         MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], F.b, 0.f, true));
         MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
     }

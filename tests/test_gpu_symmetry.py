@@ -191,7 +191,7 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
                                          ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"),
-                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"),
+                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -213,6 +213,9 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     nor may read, before every such stroke: a stale read would poison the answer; it must stay bit-equal and finite.
     MGPS_RESTRICT (default: the LDS-tiled march, restrictTileKernel; "march": the register-only march it replaced) -- the same
     sums in the same order, compared to round-off (not bit for bit: two kernels, two FMA contractions); cube512: the 512^3 cube, whose 256^3 coarse level is large enough to take either.
+    MGPS_FUSE_RR (default on) -- the residual of a down-stroke folded along z as it is formed and restricted in x-y from there
+    (launchResidualZ + launchRestrictXY; levels without general BOUNDARY cells that have plane blocks) against residual pass +
+    restriction: the same products, added along z first instead of last -- compared to round-off like MGPS_RESTRICT.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
@@ -269,13 +272,17 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
             path = os.path.join(tmp, f"x{fuse}.npz")
             value = {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else {"1": "tile", "0": "march"}[fuse] if switch == "MGPS_RESTRICT" else fuse
             env = dict(os.environ, **{switch: value})
+            if switch in ("MGPS_RESTRICT", "MGPS_FUSE_DOWN"):
+                # (the restriction kernels under test run where the residual + restriction pair does not take the level; a fused
+                # down-stroke leaves a residual grid, which the pair -- other order of the sums -- would not restrict)
+                env["MGPS_FUSE_RR"] = "0"
             if not case.startswith("pool128") and case != "cube512":
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0 and all(np.isfinite(outs[0][key]).all() for key in ("x", "y", "z"))
     for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
-        if switch == "MGPS_RESTRICT":  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
+        if switch in ("MGPS_RESTRICT", "MGPS_FUSE_RR"):  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
             assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-6 * np.abs(outs[1][key]).max(), key
         else:
             assert np.array_equal(outs[0][key], outs[1][key]), key
