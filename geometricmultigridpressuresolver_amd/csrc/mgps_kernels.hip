@@ -447,6 +447,42 @@ GridP g, float *__restrict__ out,
     }
 }
 
+// A wave-uniform pointer pinned to a scalar register pair, its derivation hidden from the optimiser (an empty asm): in the
+// plane-marching kernels below the loop optimiser otherwise folds "plane base + lane offset" into one 64-bit vector induction
+// variable per array -- two vector registers each, and the spills that follow.  With the base in scalar registers an access takes
+// the form global_load v, v_offset32, s[base:base+1].  The asm also hides that the pointer came from a kernel argument, and a
+// pointer of unknown origin is accessed with flat_load / flat_store: the accessors below go through the global address space
+// explicitly (base + a 32-bit offset in cells).
+template <class T>
+__device__ __forceinline__ T *scalarBase(T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define MGPS_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ float4 gLoad4(const float *base, unsigned cell)
+{
+    const v4f v = *(const MGPS_GLOBAL_AS v4f *)((const MGPS_GLOBAL_AS char *)base + cell * 4u);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gLoad4nt(const float *base, unsigned cell)
+{
+    const v4f v = __builtin_nontemporal_load((const MGPS_GLOBAL_AS v4f *)((const MGPS_GLOBAL_AS char *)base + cell * 4u));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float gLoad1(const float *base, unsigned cell) { return *(const MGPS_GLOBAL_AS float *)((const MGPS_GLOBAL_AS char *)base + cell * 4u); }
+__device__ __forceinline__ uchar4 gLoadCodes4nt(const uint8_t *base, unsigned cell)
+{
+    const v4b v = __builtin_nontemporal_load((const MGPS_GLOBAL_AS v4b *)((const MGPS_GLOBAL_AS char *)base + cell));
+    return make_uchar4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ unsigned gLoadCode1(const uint8_t *base, unsigned cell) { return *((const MGPS_GLOBAL_AS uint8_t *)base + cell); }
+__device__ __forceinline__ void gStore4(float *base, unsigned cell, float4 v) { *(MGPS_GLOBAL_AS v4f *)((MGPS_GLOBAL_AS char *)base + cell * 4u) = v4f{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gStore4nt(float *base, unsigned cell, float4 v)
+{
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (MGPS_GLOBAL_AS v4f *)((MGPS_GLOBAL_AS char *)base + cell * 4u));
+}
+
 // ---------------------------------------------------------------------------------------------
 // The residual of a down-stroke, restricted along z as it is formed (round 4; Ops.h:716-732 into the z part of Ops.h:734-835).
 // Full weighting is separable: coarse(I, J, K) = sum_c w_c sum_b w_b sum_a w_a r(2I-1+a, 2J-1+b, 2K-1+c).  The plane-marching
@@ -483,29 +519,24 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
     // (planes clamped into the grid: the first and the last plane of a whole-grid level are EXTERIOR shell, whose results are 0
     // whatever their neighbours hold -- the assumption stencilPlaneKernel makes at the faces)
-    // (the plane index through readfirstlane: a scalar the loop optimiser cannot fold into a 64-bit vector induction variable per
-    // array -- two vector registers each, 20 bytes of scratch)
-    auto planeOf = [&](const float *p, int k) { return p + size_t(__builtin_amdgcn_readfirstlane(min(max(k, 0), g.nz - 1))) * sz; };
-    // (scalar base + 32-bit BYTE offset: the form a global_load takes with one vector register, see bandBoxBody)
-    auto q4 = [](const float *base, unsigned cell) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + cell * 4u); };
-    auto q1 = [](const float *base, unsigned cell) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + cell * 4u); };
+    auto planeOf = [&](const float *p, int k) { return scalarBase(p + size_t(min(max(k, 0), g.nz - 1)) * sz); };
     float *const mine0 = plane[0] + (ty + 1) * kPlanePitch + 4 + lane * 4;
     constexpr int kBufFloats = (kPlaneRows + 2) * kPlanePitch;
     {  // plane ks - 1 of the thread's own quad: the z - 1 values of a step are read back from the LDS buffer of the step before
-        const float4 xm = live ? q4(planeOf(x, ks - 1), off) : zero4;
+        const float4 xm = live ? gLoad4(planeOf(x, ks - 1), off) : zero4;
         *reinterpret_cast<float4 *>(mine0 + kBufFloats) = xm;
     }
     const float *xk = planeOf(x, ks);
-    float4 xc = live ? q4(xk, off) : zero4;
-    float4 xp = live ? q4(planeOf(x, ks + 1), off) : zero4;
+    float4 xc = live ? gLoad4(xk, off) : zero4;
+    float4 xp = live ? gLoad4(planeOf(x, ks + 1), off) : zero4;
     float4 hy = zero4;
-    if (live && rowTop) hy = q4(xk, offYm);
-    if (live && rowBot) hy = q4(xk, offYp);
+    if (live && rowTop) hy = gLoad4(xk, offYm);
+    if (live && rowBot) hy = gLoad4(xk, offYp);
     // the x-halo cell of the first / last lane: one unconditional load per wave (the other lanes re-read their own cell and drop it)
     // -- a branch per side made every wave wait for all its loads in flight before each of the two
     const unsigned offHx = (colL && hasL) ? off - 1u : (colR && hasR) ? off + 4u : off;
     const bool useHx = live && ((colL && hasL) || (colR && hasR));
-    float hx = live ? q1(xk, offHx) : 0.f;
+    float hx = live ? gLoad1(xk, offHx) : 0.f;
     if (!useHx) hx = 0.f;
     constexpr float w0 = 0.125f, w1 = 0.375f, w2 = 0.375f, w3 = 0.125f;
     // coarse plane (k - 1) / 2 with its first terms (accPrev) and the one after it (accCur), see the fold below
@@ -520,20 +551,20 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
         if (colR) me[4] = hx;
         // this plane's rhs and codes (in flight across the barrier), the own quad two planes ahead, the next plane's halo
         const float *bk = planeOf(b, k);
-        const uint8_t *lk = g.lab + size_t(__builtin_amdgcn_readfirstlane(k)) * sz;
+        const uint8_t *lk = scalarBase(g.lab + size_t(k) * sz);
         const float *xn = planeOf(x, k + 1), *xq2 = planeOf(x, k + 2);
         float4 xq = zero4, hyn = hy, bc = zero4;
         uchar4 lc = ext4;
         float hxn = hx;
         if (live) {
-            bc = streamLoad4(reinterpret_cast<const float *>(reinterpret_cast<const char *>(bk) + off * 4u));
-            lc = streamLoad4(reinterpret_cast<const uint8_t *>(reinterpret_cast<const char *>(lk) + off));
+            bc = gLoad4nt(bk, off);
+            lc = gLoadCodes4nt(lk, off);
         }
         if (k < ke && live) {
-            xq = q4(xq2, off);
-            if (rowTop) hyn = q4(xn, offYm);
-            if (rowBot) hyn = q4(xn, offYp);
-            hxn = q1(xn, offHx);
+            xq = gLoad4(xq2, off);
+            if (rowTop) hyn = gLoad4(xn, offYm);
+            if (rowBot) hyn = gLoad4(xn, offYp);
+            hxn = gLoad1(xn, offHx);
             if (!useHx) hxn = 0.f;
         }
         __syncthreads();
@@ -566,7 +597,7 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
                 accPrev[e] += w3 * res[e];
                 accCur[e] += w1 * res[e];
             }
-            if (valid && k >= k0 + 2) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rz + size_t(__builtin_amdgcn_readfirstlane((k >> 1) - 1)) * sz) + off * 4u) = make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]);
+            if (valid && k >= k0 + 2) gStore4(scalarBase(rz + size_t((k >> 1) - 1) * sz), off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
         }
         xc = xp;
         xp = xq;
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     }
     // the top block of the grid: plane nz does not exist, the last coarse plane is complete with three terms
     if (valid && k1 == g.nz)
-        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rz + size_t((g.nz >> 1) - 1) * sz) + off * 4u) = make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]);
+        gStore4(rz + size_t((g.nz >> 1) - 1) * sz, off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -818,7 +849,7 @@ __global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKe
     // three coarse planes in rotation (plane q in slot q % 3): the pair a fine plane interpolates from and the next one
     // on its way; kCoarseRows rows of the 130 coarse values the tile's columns (+ the two x-halo cells) read
     __shared__ float cpl[3][kCoarseRows * kCoarsePitch];
-    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    const unsigned bid = __builtin_amdgcn_readfirstlane(remapBlock(blockIdx.x, gridDim.x));
     const unsigned bx = bid % nbx, by = (bid / nbx) % nbyF, bz = bid / (nbx * nbyF);
     const int j0 = int(by) * kFusedRows;  // first output row
     if (blockFlags) {  // the 256 x 16 x zc blocks of the sweep's activity list that this tile's output rows touch
@@ -828,13 +859,23 @@ __global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKe
     const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
     const int i = int(bx) * 256 + lane * 4, j = j0 - 1 + ty;
     const bool outRow = ty >= 1 && ty <= kFusedRows;
-    const bool valid = outRow && i < g.nx && j < g.ny;
     const int ic = min(i, g.nx - 4), jc = min(max(j, 0), g.ny - 1);
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    // quad columns outside the level's active x range (GridP::xlo): zero in every grid -- staged as zeros, nothing loaded or stored
+    const bool live = ic >= g.xlo && ic < g.xhi;
+    const bool valid = outRow && i < g.nx && j < g.ny && live;
+    const size_t sz = size_t(g.nx) * g.ny;
     const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
     const bool colL = lane == 0, colR = lane == kWave - 1;
     const int cnx = g.nx >> 1, cny = g.ny >> 1, cnz = g.nz >> 1;
     const int cb = (j0 - 2) >> 1;  // coarse row of local row 0: what fine row j0 - 1 reads first
+    // addresses: the plane's base (scalarBase) + one 32-bit offset inside the plane per thread
+    const unsigned off = unsigned(jc) * unsigned(g.nx) + unsigned(ic);
+    auto planeOf = [&](const float *p, int k) { return scalarBase(p + size_t(min(max(k, 0), g.nz - 1)) * sz); };
+    auto labOf = [&](int k) { return scalarBase(g.lab + size_t(min(max(k, 0), g.nz - 1)) * sz); };
+    // the x-halo cell of the first / last lane (value and label): one unconditional load per wave -- the other lanes re-read their
+    // own cell and drop it (a branch per side made every wave wait for its loads in flight before each of the two)
+    const bool useHx = live && ((colL && ic > 0) || (colR && ic + 4 < g.nx));
+    const unsigned offHx = !useHx ? off : (colL ? off - 1u : off + 4u);
     // slot q % 3 <- coarse plane q: rows cb .., values 128 bx - 1 .. (clamped: the clamps only bite on the EXTERIOR shell)
     auto fillCoarse = [&](int q) {
         const int qc = min(max(q, 0), cnz - 1);
@@ -881,78 +922,82 @@ __global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKe
         }
         return 4.f * lerpRef(vy[0], vy[1], wz);
     };
-    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
     const int p0 = (k0 - 1) >> 1;  // k0 is even: planes k0 - 1 and k0 share the pair p0, p0 + 1; plane k0 + 1 needs p0 + 2
     fillCoarse(p0);
     fillCoarse(p0 + 1);
     fillCoarse(p0 + 2);
-    float4 xc = *reinterpret_cast<const float4 *>(x + c);
-    uchar4 lc = streamLoad4(g.lab + c);
-    float hx = 0.f;
-    unsigned hl = MGPS_EXTERIOR_CELL;
-    if (colL && ic > 0) {
-        hx = x[c - 1];
-        hl = g.lab[c - 1];
+    const float *xk = planeOf(x, k0);
+    const uint8_t *lk = labOf(k0);
+    float4 xc = live ? gLoad4(xk, off) : zero4;
+    uchar4 lc = live ? gLoadCodes4nt(lk, off) : ext4;
+    float hx = live ? gLoad1(xk, offHx) : 0.f;
+    unsigned hl = live ? gLoadCode1(lk, offHx) : unsigned(MGPS_EXTERIOR_CELL);
+    if (!useHx) {
+        hx = 0.f;
+        hl = MGPS_EXTERIOR_CELL;
     }
-    if (colR && ic + 4 < g.nx) {
-        hx = x[c + 4];
-        hl = g.lab[c + 4];
+    // plane k0 - 1 of the own quad (prolonged): the z - 1 values of a step are read back from the LDS buffer of the step before
+    float4 xm = zero4;
+    uchar4 lm = ext4;
+    if (k0 > 0 && outRow && live) {
+        xm = gLoad4(planeOf(x, k0 - 1), off);
+        lm = gLoadCodes4nt(labOf(k0 - 1), off);
     }
-    float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
-    uchar4 lm = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-    if (k0 > 0 && outRow) {
-        xm = *reinterpret_cast<const float4 *>(x + c - sz);
-        lm = *reinterpret_cast<const uchar4 *>(g.lab + c - sz);
-    }
-    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (outRow) bc = streamLoad4(b + c);
+    float4 bc = zero4;
+    if (outRow && live) bc = gLoad4nt(planeOf(b, k0), off);
     __syncthreads();
+    float *const mine0 = plane[0] + ty * kPlanePitch + 4 + lane * 4;
+    constexpr int kBufFloats = kFusedThreadRows * kPlanePitch;
     if (k0 > 0 && outRow) xm = prolongQuad(k0 - 1, xm, lm);
+    *reinterpret_cast<float4 *>(mine0 + kBufFloats) = xm;
     xc = prolongQuad(k0, xc, lc);
-    if ((colL || colR) && activeLabel(hl)) hx += edgeAdd(k0, colR);
+    if (useHx && activeLabel(hl)) hx += edgeAdd(k0, colR);
     int buf = 0;
     for (int k = k0; k < k1; ++k) {
-        float *me = plane[buf] + ty * kPlanePitch + 4 + lane * 4;
+        float *me = mine0 + buf * kBufFloats;
         *reinterpret_cast<float4 *>(me) = xc;
         if (colL) me[-1] = hx;
         if (colR) me[4] = hx;
         if (nearBand && valid) {  // the band stage's groups read x' here
-            const size_t q = c >> 2;
-            if ((nearBand[q >> 5] >> (q & 31)) & 1u) *reinterpret_cast<float4 *>(stage + c) = xc;
+            const size_t q = (size_t(k) * sz + off) >> 2;
+            if ((nearBand[q >> 5] >> (q & 31)) & 1u)
+                gStore4(scalarBase(stage + size_t(k) * sz), off, xc);
         }
         // next plane: its loads before this plane is computed; its prolongation needs the pair (k >> 1, + 1): in LDS since the
         // barrier of the iteration before (filled below, two planes ahead)
         const int kn = k + 1;
-        const size_t cn = kn < g.nz ? c + sz : c;
+        const float *xn = planeOf(x, kn);
+        const uint8_t *ln8 = labOf(kn);
         float4 xp = xc, bn = bc;
         uchar4 ln = lc;
         float hxn = hx;
         unsigned hln = MGPS_EXTERIOR_CELL;
-        if (kn < g.nz) {
-            xp = *reinterpret_cast<const float4 *>(x + cn);
-            ln = streamLoad4(g.lab + cn);
-            if (outRow && kn < k1) bn = streamLoad4(b + cn);
-            if (colL && ic > 0) {
-                hxn = x[cn - 1];
-                hln = g.lab[cn - 1];
-            }
-            if (colR && ic + 4 < g.nx) {
-                hxn = x[cn + 4];
-                hln = g.lab[cn + 4];
-            }
+        if (kn < g.nz && live) {
+            xp = gLoad4(xn, off);
+            ln = gLoadCodes4nt(ln8, off);
+            if (outRow && kn < k1) bn = gLoad4nt(planeOf(b, kn), off);
+            hxn = gLoad1(xn, offHx);
+            hln = gLoadCode1(ln8, offHx);
+        }
+        if (!useHx) {
+            hxn = 0.f;
+            hln = MGPS_EXTERIOR_CELL;
         }
         if (k & 1) fillCoarse(((k + 1) >> 1) + 1);  // what fine plane k + 2 will add to its pair
         if (kn < g.nz) {
             xp = prolongQuad(kn, xp, ln);
-            if ((colL || colR) && activeLabel(hln)) hxn += edgeAdd(kn, colR);
+            if (useHx && activeLabel(hln)) hxn += edgeAdd(kn, colR);
         }
         __syncthreads();
         if (outRow) {
             const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
             const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+            const float4 zm = *reinterpret_cast<const float4 *>(mine0 + (buf ^ 1) * kBufFloats);  // (this thread's own store of the step before)
             const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
             const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
-            const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+            const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
             const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
             const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
             float res[4];
@@ -962,14 +1007,13 @@ __global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKe
                 const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
                 res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_JACOBI>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_JACOBI>(xs[e + 1]);
             }
-            if (valid) __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
+            if (valid)
+                gStore4nt(scalarBase(out + size_t(k) * sz), off, make_float4(res[0], res[1], res[2], res[3]));
         }
-        xm = xc;
         xc = xp;
         bc = bn;
         lc = ln;
         hx = hxn;
-        c = cn;
         buf ^= 1;
     }
 }
