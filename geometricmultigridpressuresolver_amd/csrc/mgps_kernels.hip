@@ -329,124 +329,6 @@ constexpr int kPlanePitch = 256 + 8;  // 4 floats of halo on each side keep the 
 // lerp of Ops.h:841-871: (1 - f) a + f b, this exact form (HDK's SYSlerp breaks the R / P symmetry, Ops.h:837-839)
 __device__ __forceinline__ float lerpRef(float a, float b, float f) { return (1.f - f) * a + f * b; }
 
-template <int OP, bool DOT = false, bool XZERO = false>  // XZERO: see stencilQuadKernel
-__global__ __launch_bounds__(64 * kPlaneRows, 8) void stencilPlaneKernel(  // (8 waves per SIMD = two workgroups per CU: at most 64 registers)
-GridP g, float *__restrict__ out,
-                                                                      const float *__restrict__ x,
-                                                                      const float *__restrict__ b, float omega,
-                                                                      unsigned nbx, unsigned nby, unsigned nbz, int zc,
-                                                                      const int32_t *__restrict__ blocks,
-                                                                      double *__restrict__ dotPartials = nullptr)
-{
-    double dotAcc = 0.0;
-    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
-    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
-    if (blocks) bid = unsigned(blocks[bid]);  // only blocks that hold active cells
-    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
-    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
-    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
-    // threads past the grid edge shadow the last quad / row: their loads stay in bounds, they take
-    // part in the barriers, they do not store
-    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
-    // quad columns outside the level's active x range (GridP::xlo): zero in every grid, staged as zeros, nothing loaded or stored
-    const bool live = ic >= g.xlo && ic < g.xhi;
-    const bool valid = i < g.nx && j < g.ny && live;
-    const bool ld = live && !XZERO;
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
-    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
-    const ptrdiff_t dym = jc > 0 ? -ptrdiff_t(sy) : 0, dyp = jc < g.ny - 1 ? ptrdiff_t(sy) : 0;
-    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
-
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-    // Two planes of a thread's own x quad are in flight at any time: plane k + 2 is requested while plane k is computed, so the
-    // plane k + 1 a step needs (its z + 1 neighbours) was requested a whole step earlier -- like the rhs, the codes and the halo,
-    // which are requested one plane ahead and used one step later (with one plane of look-ahead for x every step ended by
-    // waiting out a full memory round trip).
-    // (Tried on top and dropped: the four planes in a ring of named registers with the march unrolled four times -- the rolled loop's
-    // end-of-step copies xc = xp = xq are waits for those loads --, every load unconditional (dead lanes aim at the range's nearest
-    // quad, every thread loads a halo row / cell) and ordered by first use: the waits became partial (vmcnt(4-5) instead of 0), but
-    // the halo row then has to be parked in a register that is free only after a wait, and every thread pays a fifth load per plane:
-    // 1024^3 cycle 10.32 -> 12.22 ms.)
-    auto planeAt = [&](int k) { return (k < g.nz || g.ghostHi) ? (size_t(min(k, g.nz)) * g.ny + jc) * sy + ic : (size_t(g.nz - 1) * g.ny + jc) * sy + ic; };
-    float4 xm = ld ? *reinterpret_cast<const float4 *>(x + ((k0 > 0 || g.ghostLo) ? c - sz : c)) : zero4;
-    float4 xc = ld ? *reinterpret_cast<const float4 *>(x + c) : zero4;
-    const size_t c1 = planeAt(k0 + 1);
-    float4 xp = ld ? *reinterpret_cast<const float4 *>(x + c1) : zero4;
-    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (OP != OP_APPLY && live) bc = streamLoad4(b + c);
-    uchar4 lc = live ? streamLoad4(g.lab + c) : ext4;
-    float4 hy = make_float4(0.f, 0.f, 0.f, 0.f);  // y-halo row this thread stages (top / bottom rows only)
-    if (ld && rowTop) hy = *reinterpret_cast<const float4 *>(x + c + dym);
-    if (ld && rowBot) hy = *reinterpret_cast<const float4 *>(x + c + dyp);
-    float hx = 0.f;  // x-halo cell this thread stages (first / last lane only)
-    if (ld && colL) hx = ic > 0 ? x[c - 1] : 0.f;
-    if (ld && colR) hx = ic + 4 < g.nx ? x[c + 4] : 0.f;
-
-    int buf = 0;
-    for (int k = k0; k < k1; ++k) {
-        float *me = plane[buf] + (ty + 1) * kPlanePitch + 4 + lane * 4;
-        *reinterpret_cast<float4 *>(me) = xc;
-        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
-        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
-        if (colL) me[-1] = hx;
-        if (colR) me[4] = hx;
-        // the plane after the next one (own quad); the next plane's halo
-        const size_t cn = (k + 1 < g.nz || g.ghostHi) ? c + sz : c;
-        const size_t cq = planeAt(k + 2);
-        float4 xq = zero4, bn = bc, hyn = hy;
-        uchar4 ln = lc;
-        float hxn = hx;
-        if (k + 1 < k1 && ld) xq = *reinterpret_cast<const float4 *>(x + cq);  // (the last step's z + 1 plane is already here: xp)
-        if (k + 1 < k1 && live) {  // (rhs and codes of the next plane: used a step from now as they are)
-            if (OP != OP_APPLY) bn = streamLoad4(b + cn);
-            ln = streamLoad4(g.lab + cn);
-        }
-        if (k + 1 < k1 && ld) {
-            if (rowTop) hyn = *reinterpret_cast<const float4 *>(x + cn + dym);
-            if (rowBot) hyn = *reinterpret_cast<const float4 *>(x + cn + dyp);
-            if (colL) hxn = ic > 0 ? x[cn - 1] : 0.f;
-            if (colR) hxn = ic + 4 < g.nx ? x[cn + 4] : 0.f;
-        }
-        __syncthreads();
-        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
-        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
-        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
-        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
-        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
-        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
-        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
-        float res[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float diag = simpleDiag(ls[e]);
-            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
-        }
-        if (valid)  // streamed out: nothing re-reads the sweep's output before it has left the caches (+5 % at 1024^3)
-            __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(out + c));
-        if (DOT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (valid && simpleCell(ls[e])) dotAcc += dotTerm<OP>(xs[e + 1], bs[e], res[e]);
-        }
-        xm = xc;
-        xc = xp;
-        xp = xq;
-        bc = bn;
-        lc = ln;
-        hy = hyn;
-        hx = hxn;
-        c = cn;
-        buf ^= 1;
-    }
-    if (DOT) {
-        __syncthreads();  // (the LDS planes are done with)
-        blockDotStore(dotAcc, dotPartials, blockIdx.x);
-    }
-}
-
 // A wave-uniform pointer pinned to a scalar register pair, its derivation hidden from the optimiser (an empty asm): in the
 // plane-marching kernels below the loop optimiser otherwise folds "plane base + lane offset" into one 64-bit vector induction
 // variable per array -- two vector registers each, and the spills that follow.  With the base in scalar registers an access takes
@@ -481,6 +363,125 @@ __device__ __forceinline__ void gStore4(float *base, unsigned cell, float4 v) { 
 __device__ __forceinline__ void gStore4nt(float *base, unsigned cell, float4 v)
 {
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (MGPS_GLOBAL_AS v4f *)((MGPS_GLOBAL_AS char *)base + cell * 4u));
+}
+
+template <int OP, bool DOT = false, bool XZERO = false>  // XZERO: see stencilQuadKernel
+__global__ __launch_bounds__(64 * kPlaneRows, 8) void stencilPlaneKernel(  // (8 waves per SIMD = two workgroups per CU: at most 64 registers)
+GridP g, float *__restrict__ out,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ b, float omega,
+                                                                      unsigned nbx, unsigned nby, unsigned nbz, int zc,
+                                                                      const int32_t *__restrict__ blocks,
+                                                                      double *__restrict__ dotPartials = nullptr)
+{
+    double dotAcc = 0.0;
+    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
+    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    if (blocks) bid = unsigned(blocks[bid]);  // only blocks that hold active cells
+    bid = __builtin_amdgcn_readfirstlane(bid);
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
+    // threads past the grid edge shadow the last quad / row: their loads stay in bounds, they take
+    // part in the barriers, they do not store
+    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
+    // quad columns outside the level's active x range (GridP::xlo): zero in every grid, staged as zeros, nothing loaded or stored
+    const bool live = ic >= g.xlo && ic < g.xhi;
+    const bool valid = i < g.nx && j < g.ny && live;
+    const bool ld = live && !XZERO;
+    const ptrdiff_t sz = ptrdiff_t(g.nx) * g.ny;
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
+    // addresses: the plane's base (scalarBase) + one 32-bit offset inside the plane per thread.  Planes are clamped to what exists:
+    // the ghost planes of a slab, else the first / last plane (EXTERIOR shell there: results 0 whatever the neighbours hold)
+    const int kLo = g.ghostLo ? -1 : 0, kHi = g.ghostHi ? g.nz : g.nz - 1;
+    const unsigned off = unsigned(jc) * unsigned(g.nx) + unsigned(ic);
+    const unsigned offYm = jc > 0 ? off - unsigned(g.nx) : off, offYp = jc < g.ny - 1 ? off + unsigned(g.nx) : off;
+    auto planeOf = [&](const float *p, int k) { return scalarBase(p + ptrdiff_t(min(max(k, kLo), kHi)) * sz); };
+    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
+    // the x-halo cell of the first / last lane: one unconditional load per wave (the other lanes re-read their own cell and drop
+    // it) -- a branch per side made every wave wait for all its loads in flight before each of the two
+    const bool useHx = ld && ((colL && ic > 0) || (colR && ic + 4 < g.nx));
+    const unsigned offHx = !useHx ? off : (colL ? off - 1u : off + 4u);
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
+    // Two planes of a thread's own x quad are in flight at any time: plane k + 2 is requested while plane k is computed, so the
+    // plane k + 1 a step needs (its z + 1 neighbours) was requested a whole step earlier; the halo is requested one plane ahead,
+    // the rhs and the codes of a plane at the top of its own step (in flight across the barrier).  The z - 1 values of a step are
+    // the thread's own store of the step before, read back from the other LDS buffer.
+    // (Tried on top and dropped: the four planes in a ring of named registers with the march unrolled four times, every load
+    // unconditional and ordered by first use: 1024^3 cycle 10.32 -> 12.22 ms.  Round 4: plane bases in scalar registers, the
+    // z - 1 quad out of LDS, no rhs / code look-ahead, the branch-free x-halo load -- no spills left: see residualZKernel.)
+    float *const mine0 = plane[0] + (ty + 1) * kPlanePitch + 4 + lane * 4;
+    constexpr int kBufFloats = (kPlaneRows + 2) * kPlanePitch;
+    *reinterpret_cast<float4 *>(mine0 + kBufFloats) = ld ? gLoad4(planeOf(x, k0 - 1), off) : zero4;
+    const float *xk = XZERO ? x : planeOf(x, k0);
+    float4 xc = ld ? gLoad4(xk, off) : zero4;
+    float4 xp = ld ? gLoad4(planeOf(x, k0 + 1), off) : zero4;
+    float4 hy = zero4;  // y-halo row this thread stages (top / bottom rows only)
+    if (ld && rowTop) hy = gLoad4(xk, offYm);
+    if (ld && rowBot) hy = gLoad4(xk, offYp);
+    float hx = ld ? gLoad1(xk, offHx) : 0.f;  // x-halo cell this thread stages (first / last lane only)
+    if (!useHx) hx = 0.f;
+
+    int buf = 0;
+    for (int k = k0; k < k1; ++k) {
+        float *me = mine0 + buf * kBufFloats;
+        *reinterpret_cast<float4 *>(me) = xc;
+        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
+        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
+        if (colL) me[-1] = hx;
+        if (colR) me[4] = hx;
+        float4 bc = zero4;
+        uchar4 lc = ext4;
+        if (live) {
+            if (OP != OP_APPLY) bc = gLoad4nt(scalarBase(b + ptrdiff_t(k) * sz), off);
+            lc = gLoadCodes4nt(scalarBase(g.lab + ptrdiff_t(k) * sz), off);
+        }
+        // the plane after the next one (own quad); the next plane's halo
+        float4 xq = zero4, hyn = hy;
+        float hxn = hx;
+        if (k + 1 < k1 && ld) {  // (the last step's z + 1 plane is already here: xp)
+            const float *xn = planeOf(x, k + 1);
+            xq = gLoad4(planeOf(x, k + 2), off);
+            if (rowTop) hyn = gLoad4(xn, offYm);
+            if (rowBot) hyn = gLoad4(xn, offYp);
+            hxn = gLoad1(xn, offHx);
+            if (!useHx) hxn = 0.f;
+        }
+        __syncthreads();
+        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
+        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
+        const float4 xm = *reinterpret_cast<const float4 *>(mine0 + (buf ^ 1) * kBufFloats);
+        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
+        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
+        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float diag = simpleDiag(ls[e]);
+            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP>(xs[e + 1]);
+        }
+        if (valid)  // streamed out: nothing re-reads the sweep's output before it has left the caches (+5 % at 1024^3)
+            gStore4nt(scalarBase(out + ptrdiff_t(k) * sz), off, make_float4(res[0], res[1], res[2], res[3]));
+        if (DOT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (valid && simpleCell(ls[e])) dotAcc += dotTerm<OP>(xs[e + 1], bs[e], res[e]);
+        }
+        xc = xp;
+        xp = xq;
+        hy = hyn;
+        hx = hxn;
+        buf ^= 1;
+    }
+    if (DOT) {
+        __syncthreads();  // (the LDS planes are done with)
+        blockDotStore(dotAcc, dotPartials, blockIdx.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

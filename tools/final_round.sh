@@ -28,6 +28,9 @@ MGPS_SETUP_TIMING=1 python tools/slab_setup_time.py 1024 8 3 device 2>&1 | grep 
 # the plugin's own configuration untraced (512^3 pool MG-PCG, every CG vector mode), and the Gauss-Seidel band stage A/B
 python bench.py --workload free_surface_pcg --size 512 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_free_surface_untraced.json
 for v in 1 0; do MGPS_GS_SNAPSHOT=$v python bench.py --size 512 --smoother gs --no-frac512 --no-cpu --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_gs_snapshot$v.json; done
+# residual + restriction without the residual grid (1024^3 fine level by size): the pair against the two separate passes
+MGPS_FUSE_RR=0 python bench.py --no-cpu --no-frac512 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench1024_fuse_rr0.json
+python bench.py --no-cpu --no-frac512 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench1024_fuse_rr1.json
 # SQ / TCP / TCC counters of the 1024^3 and 512^3 kernels (the kernel the bench line names included)
 bash tools/sq_pmc.sh ${round} 1024 > /dev/null 2>&1; bash tools/sq_pmc.sh ${round} 512 > /dev/null 2>&1
 tools/facebench 1024 > gpurun_out/${round}_facebench.txt 2>&1; tools/facebench 512 >> gpurun_out/${round}_facebench.txt 2>&1
