@@ -147,7 +147,7 @@ def gpu_mode():
 
 def plane_mode():
     """The plane-marching sweep (stencilPlaneKernel, the 1024^3 kernel) on cut slabs: its ghostLo / ghostHi reads of the
-    plane below the first and above the last owned plane.  options.stencil_path = 2 forces it onto a 264 x 40/72 x nz
+    plane below the first and above the last owned plane.  options.stencil_path = 2 forces it onto a 264 x 40 x 32 (two ranks) or 272 x 72 x 64 (four ranks, four levels)
     free-surface + cut-cell grid; slab runs must reproduce the whole-grid run of the same kernel (A.x bit for bit)."""
     import geometricmultigridpressuresolver_amd as G
     from conftest import make_domain
@@ -156,16 +156,20 @@ def plane_mode():
 
     rank, size = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    g = 24 if size == 2 else 56
-    shape = (32, 40, 264) if size == 2 else (64, 72, 264)
-    lab, w, off, lev, dx = make_domain("widesolid", g, 3, shape)
+    # (four levels on the larger grid: with three its coarsest level has ~10 000 unknowns, and factorising that -- rank 0's tail on
+    # the host, the whole-grid solver on every rank -- took 70 of this test's 75 seconds)
+    g, levels = (24, 3) if size == 2 else (48, 4)
+    shape = (32, 40, 264) if size == 2 else (64, 72, 272)
+    lab, w, off, lev, dx = make_domain("widesolid", g, levels, shape)
     nz = lab.shape[0]
     nzl = nz // size
     z0, z1 = rank * nzl, (rank + 1) * nzl
     assert all(D.active_mask(lab[c - 1 : c + 1]).any() for c in range(nzl, nz, nzl))
     slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
     b_glob = D.random_rhs(lab, dx)
+    import time
     for use_gs, deep in ((False, 1), (False, 0)):
+        t0 = time.time()
         opt = G.default_options()
         opt.min_cells_per_rank, opt.deep_band_halo, opt.stencil_path = 0, deep, 2
         ow = G.default_options()
@@ -173,6 +177,7 @@ def plane_mode():
         slab = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=opt)
         whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0, options=ow)
         assert slab.stencil_kernel(0) == "plane" and whole.stencil_kernel(0) == "plane"
+        t1 = time.time()
         bw, bs = whole.to_device(b_glob), slab.to_device(b_glob[z0:z1])
         xw, xs = whole.to_device(b_glob * 3.0), slab.to_device(b_glob[z0:z1] * 3.0)
         yw, ys = whole.new_grid(), slab.new_grid()
@@ -191,13 +196,15 @@ def plane_mode():
             slab.applyVCycle(xs, bs, it > 0)
             err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
             assert err < 1e-6, (deep, it, err)
+        t2 = time.time()
         xw, xs = whole.new_grid(), slab.new_grid()
         sw = whole.solveGeometricConjugateGradient(xw, bw, 1e-5, 200, True)  # A.p + <p, A p> from the DOT variant on the whole grid
         ss = slab.solveGeometricConjugateGradient(xs, bs, 1e-5, 200, True)
         assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
         assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
         if rank == 0:
-            print(f"  plane sweep on {size} slabs, deep={deep}: D={slab.distributed_levels}, pcg it {ss['iterations']}", flush=True)
+            print(f"  plane sweep on {size} slabs, deep={deep}: D={slab.distributed_levels}, pcg it {ss['iterations']}; set-up {t1 - t0:.1f} s, "
+                  f"operators + cycles {t2 - t1:.1f} s, pcg {time.time() - t2:.1f} s, exchanges {slab.exchange_count}", flush=True)
         slab.close()
         whole.close()
         dist.barrier()
