@@ -1636,20 +1636,26 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
         return fail(MGPS_ERR_COARSE_TOO_LARGE,
                     "coarsest level has " + std::to_string(cn) + " unknowns (cap " + std::to_string(maxUnknowns) +
                         "): raise mg_levels or options.max_coarse_unknowns");
-    H.coarseOnDevice = cn > kHostCoarseMax;
-    if (H.coarseOnDevice) {  // (BASELINE configs 3 / 5 as SURVEY 8(d) states them: 512^3 with 5 levels, coarsest 32^3)
+    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
+    int bw = 0;
+    if (cn <= kHostCoarseMax)
+        for (int r = 0; r < cn; ++r)
+            for (int a = 0; a < 3; ++a)
+                for (int s = -1; s <= 1; s += 2) {
+                    const int q = H.coarseIndex[H.coarseCell[r] + s * stride[a]];
+                    if (q >= 0) bw = std::max(bw, std::abs(q - r));
+                }
+    // The banded factor below costs n x bw^2 on one thread, and the reference's tile numbering makes bw the better part of a tile
+    // (thousands) as soon as the level is larger than one 16^3 tile: a 66 x 18 x 16 level with 10 000 unknowns took 30 s here
+    // against well under a second for the dense factorisation on the device.  Past kHostCoarseMax unknowns or kHostFactorFlops
+    // the solver factorises and inverts on the device (BASELINE configs 3 / 5 as SURVEY 8(d) states them: 512^3 with 5 levels,
+    // coarsest 32^3).
+    H.coarseOnDevice = cn > kHostCoarseMax || double(cn) * double(bw) * double(bw) > kHostFactorFlops;
+    if (H.coarseOnDevice) {
         H.coarseBW = 0;
         H.coarseL.clear();
         return MGPS_OK;
     }
-    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
-    int bw = 0;
-    for (int r = 0; r < cn; ++r)
-        for (int a = 0; a < 3; ++a)
-            for (int s = -1; s <= 1; s += 2) {
-                const int q = H.coarseIndex[H.coarseCell[r] + s * stride[a]];
-                if (q >= 0) bw = std::max(bw, std::abs(q - r));
-            }
     H.coarseBW = bw;
     const int W = bw + 1;
     std::vector<double> &A = H.coarseL;
@@ -2565,7 +2571,7 @@ try {
     if (!hier || !x || !b) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_coarse_solve: bad arguments");
     if (hier->coarseOnDevice)
         return fail(MGPS_ERR_COARSE_TOO_LARGE, "mgps_hierarchy_coarse_solve: the host factor stops at " + std::to_string(kHostCoarseMax) +
-                                                   " unknowns (larger coarsest levels are factorised on the device: mgps_coarse_solve)");
+                                                   " unknowns or a banded factorisation of 4e9 operations (such coarsest levels are factorised on the device: mgps_coarse_solve)");
     std::vector<double> v(hier->coarseN);
     for (int r = 0; r < hier->coarseN; ++r) v[r] = b[hier->coarseCell[r]];
     hier->bandedSolve(v.data());

@@ -559,6 +559,7 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 
 namespace mgps {
 constexpr int kHostCoarseMax = 8192;
+constexpr double kHostFactorFlops = 4e9;  // n x bandwidth^2 of the host's banded Cholesky factor (buildCoarseSolver): beyond it the device factorises
 }
 
 // Host-only hierarchy (C-ABI opaque type).
@@ -575,8 +576,8 @@ struct mgps_hierarchy {
     std::vector<int32_t> coarseIndex;   // linear cell -> unknown id or -1
     std::vector<double> coarseL;        // banded Cholesky factor, coarseN x (coarseBW+1)
     std::vector<float> coarseInverse;   // dense coarseN x coarseN inverse (built on demand for the GPU)
-    // more unknowns than kHostCoarseMax: no factor on the host (the reference's tile numbering gives the banded factor a width
-    // of thousands there); the solver factorises and inverts the dense matrix on the device (hipSOLVER potrf / potri in fp64)
+    // more unknowns than kHostCoarseMax or a banded factor past kHostFactorFlops: no factor on the host (the reference's tile
+    // numbering gives the banded factor a width of thousands there); the solver factorises and inverts the dense matrix on the device (hipSOLVER potrf / potri in fp64)
     bool coarseOnDevice = false;
     void bandedSolve(double *v) const;
     void buildDenseInverse();

@@ -2103,7 +2103,7 @@ int buildDeviceInverse(mgps_solver *h)
     static HipSolver *solver = new HipSolver();  // (never unloaded: process tear-down order)
     if (!solver->ok)
         return failH(h, MGPS_ERR_COARSE_TOO_LARGE, "coarsest level has " + std::to_string(n) + " unknowns: above " + std::to_string(kHostCoarseMax) +
-                                                       " the direct solver needs libhipsolver.so, which could not be loaded (raise mg_levels)");
+                                                       " (or past 4e9 operations for the host's banded factor) the direct solver needs libhipsolver.so, which could not be loaded (raise mg_levels)");
     const int kLower = 122;  // HIPSOLVER_FILL_MODE_LOWER
     double *A = nullptr, *work = nullptr;
     int32_t *index = nullptr, *cells = nullptr;

@@ -70,8 +70,10 @@ typedef struct mgps_options {
     float jacobi_weight;    /* 2/3 */
     int device;             /* HIP device ordinal; -1 = current device */
     int print_stats;        /* doPrintStats of MG.h:24: per-stage timings on stdout */
-    int max_coarse_unknowns;/* direct-solve cap, default 32768 (a 32^3 coarsest level); above 8192 unknowns the solver
-                             * factorises the dense matrix on the device (hipSOLVER) instead of on host threads */
+    int max_coarse_unknowns;/* direct-solve cap, default 32768 (a 32^3 coarsest level); above 8192 unknowns -- or where the
+                             * host's banded factor would cost more than 4e9 operations: a coarsest level larger than one
+                             * 16^3 tile with a few thousand unknowns -- the solver factorises the dense matrix on the
+                             * device (hipSOLVER) instead of on a host thread */
     int fuse_band_passes;   /* 1 (default) = run the band_iterations band-Jacobi passes of a level that is not cut
                                into slabs as one launch (same arithmetic per cell); 0 = one launch pair per pass */
     int deep_band_halo;     /* slab runs, 1 (default): one ghost exchange per band stage -- the message carries the ghost
