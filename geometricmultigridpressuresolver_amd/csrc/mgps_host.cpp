@@ -1650,7 +1650,8 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
     // against well under a second for the dense factorisation on the device.  Past kHostCoarseMax unknowns or kHostFactorFlops
     // the solver factorises and inverts on the device (BASELINE configs 3 / 5 as SURVEY 8(d) states them: 512^3 with 5 levels,
     // coarsest 32^3).
-    H.coarseOnDevice = cn > kHostCoarseMax || double(cn) * double(bw) * double(bw) > kHostFactorFlops;
+    // (the dense inverse the device mat-vec needs is one banded solve per unknown on the host threads: 2 n^2 bw, priced at 5 x the budget)
+    H.coarseOnDevice = cn > kHostCoarseMax || double(cn) * double(bw) * double(bw) > kHostFactorFlops || 2.0 * double(cn) * double(cn) * double(bw) > 5.0 * kHostFactorFlops;
     if (H.coarseOnDevice) {
         H.coarseBW = 0;
         H.coarseL.clear();
