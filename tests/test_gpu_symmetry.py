@@ -191,7 +191,7 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
                                          ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"),
-                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"),
+                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"), ("MGPS_FUSE_RR", "rag264"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -218,7 +218,8 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     restriction: the same products, added along z first instead of last -- compared to round-off like MGPS_RESTRICT.
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
-    box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0)."""
+    box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0); rag264: a small box whose grid ends in ragged tiles in every
+    direction (the residual + restriction pair forced onto it)."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -235,7 +236,9 @@ elif case == "cube512":
     lab, w, dx = D.interior_cube(512, 6)
     lev = 6
 else:
-    shape = (64, 992, int(case[5:]))
+    # planeN: an N x 992 x 64 box in a 1024 x 1024 x 96 grid; rag264: a 248 x 44 x 20 box in a 264 x 52 x 28 grid (the last tile of
+    # every direction is ragged: 256 + 8 columns, 3 x 16 + 4 rows, planes in blocks of 4)
+    shape = (20, 44, 248) if case == "rag264" else (64, 992, int(case[5:]))
     bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
     bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
     bw = []
@@ -245,7 +248,10 @@ else:
         wa[D._inner_faces(wa, axis)] = np.where((back == D.INTERIOR) | (fwd == D.INTERIOR), 1.0, 0.0)
         bw.append(wa)
     dx = 1.0 / 992
-    lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
+    if case == "rag264":
+        lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(28, 52, 264))
+    else:
+        lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
 s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)
 if case not in ("pool128", "cube512"):
     assert s.stencil_kernel(0) == "plane"
@@ -288,5 +294,7 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
             assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
     assert int(outs[0]["it"]) == int(outs[1]["it"])
+    if switch == "MGPS_FUSE_RR":
+        assert not np.array_equal(outs[0]["x"], outs[1]["x"])  # (the switch was live: other order of the sums, other last bits)
     if switch == "MGPS_X_RANGE" and case != "pool128":
         assert int(outs[0]["swept"]) < int(outs[1]["swept"])  # (the switch was live: fewer cells visited with it on)
