@@ -433,11 +433,14 @@ int launchTiledGSMixed(void *stream, const GridP &g, void *xH, const float *b, c
 // codes[band[t]] = kCodeSimple + bandDiag[t] for the BOUNDARY cells among the entries t >= nbnd (the simple ones)
 int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, const uint8_t *bandDiag, int nbnd, int nband);
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine);
-// residual of `fine` (no general BOUNDARY cells, no ghost planes, plane blocks) restricted to `coarse` without writing the residual:
-// launchResidualZ folds r = b - A x along z into rz (fine.nx x fine.ny x fine.nz / 2 floats that nothing else writes: what no
-// active block covers stays zero), launchRestrictXY does the x-y half.  residualRestrictFits: the shapes the pair takes
+// residual of `fine` (no ghost planes, plane blocks) restricted to `coarse` without writing the residual: launchResidualZ folds
+// r = b - A x along z into rz (fine.nx x fine.ny x fine.nz / 2 floats that nothing else writes: zero wherever the launches do not
+// go), general BOUNDARY cells by a patch in four conflict-free launches; launchRestrictXY does the x-y half.  edges (device, may
+// be empty): the blocks off the activity list that lie below / above a listed one, as planeBlockEdges makes them from a host copy
+// of the block flags (launchPlaneBlockFlags) -- they owe rz one plane of terms each.  residualRestrictFits: the shapes the pair takes
 bool residualRestrictFits(const GridP &fine, const GridP &coarse);
-int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b);
+std::vector<int32_t> planeBlockEdges(const GridP &g, const std::vector<uint8_t> &flags);
+int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges);
 int launchRestrictXY(void *stream, const GridP &coarse, float *coarseOut, const float *rz);
 // ---- mixed precision (options.precision = 1): binary16 grids of the fine level, passed as void* -----------------------
 bool mixedPrecisionShapeOk(int nx, int ny, int nz);  // the fine level must take the quad sweep and the block prolongation

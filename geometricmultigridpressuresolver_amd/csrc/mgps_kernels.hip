@@ -492,7 +492,8 @@ GridP g, float *__restrict__ out,
 // cell instead of 13, and the x-y restriction that follows (restrictXYKernel) reads 2 B per fine cell with no overlap along
 // z instead of 4 B with the 4-plane footprint.  A block of planes [k0, k1) also forms r on planes k0 - 1 and k1 (two more
 // planes per zc).  Levels without general BOUNDARY cells, ghost planes or binary16 grids (launchResidualZ); `rz` is a grid
-// of nx x ny x nz/2 that nobody else writes: the blocks without active cells are never visited and stay zero.
+// of nx x ny x nz/2 that nobody else writes: blocks with no active cell in them, below them or above them are never written and stay
+// zero (residualZEdgeKernel serves the blocks next to active ones).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, float *__restrict__ rz, const float *__restrict__ x,
                                                                      const float *__restrict__ b, unsigned nbx, unsigned nby, int zc,
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
 {
     __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
     unsigned bid = remapBlock(blockIdx.x, gridDim.x);
-    if (blocks) bid = unsigned(blocks[bid]);
+    if (blocks) bid = unsigned(blocks[bid]);  // (blocks without active cells: residualZEdgeKernel writes what they owe rz)
     bid = __builtin_amdgcn_readfirstlane(bid);  // (the plane bases below: scalar registers)
     const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
     const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
@@ -609,6 +610,56 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     // the top block of the grid: plane nz does not exist, the last coarse plane is complete with three terms
     if (valid && k1 == g.nz)
         gStore4(rz + size_t((g.nz >> 1) - 1) * sz, off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
+}
+
+// A block without active cells still owes rz the terms of the planes next to it when the block below or above holds active cells:
+// w0 r on the last plane of the block below is the first (and only non-zero) term of its first coarse plane, w3 r on the first plane
+// of the block above the last term of its last one -- coarse cells of a NEIGHBOURING column of blocks read those entries.  One
+// workgroup per such block and side (a list made once, planeBlockEdges); every other entry of a block off the activity list is
+// 0, which is what rz holds there since it was made.
+// One plane, no march: the quad kernel's way of gathering the neighbours (x by lane shuffle, y and z from the caches).
+__global__ __launch_bounds__(64 * kPlaneRows) void residualZEdgeKernel(GridP g, float *__restrict__ rz, const float *__restrict__ x, const float *__restrict__ b,
+                                                                      unsigned nbx, unsigned nby, int zc, const int32_t *__restrict__ edges)
+{
+    // edges[w] = 2 * block + side: the blocks without active cells whose neighbour below (side 0) / above (side 1) has some
+    const unsigned bid = unsigned(edges[blockIdx.x]) >> 1, side = unsigned(edges[blockIdx.x]) & 1u;
+    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
+    const int k = side == 0 ? k0 - 1 : k1, K = side == 0 ? (k0 >> 1) : (k1 >> 1) - 1;
+    const float wz = 0.125f;  // w0 = w3
+    if (k < 0 || k >= g.nz) return;
+    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
+    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
+    if (i >= g.nx || j >= g.ny) return;  // (whole wavefront rows leave together only when j is past the grid; lanes past nx: no shuffle partner needs them)
+    const bool live = i >= g.xlo && i < g.xhi;
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
+    const size_t c = size_t(k) * sz + size_t(j) * sy + i;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (faces of the grid: EXTERIOR shell, results 0 whatever the clamped neighbours hold)
+    const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c, czm = k > 0 ? c - sz : c, czp = k < g.nz - 1 ? c + sz : c;
+    const float4 xc = live ? *reinterpret_cast<const float4 *>(x + c) : zero4;
+    const float4 ym = live ? *reinterpret_cast<const float4 *>(x + cym) : zero4, yp = live ? *reinterpret_cast<const float4 *>(x + cyp) : zero4;
+    const float4 zm = live ? *reinterpret_cast<const float4 *>(x + czm) : zero4, zp = live ? *reinterpret_cast<const float4 *>(x + czp) : zero4;
+    const float4 bc = live ? *reinterpret_cast<const float4 *>(b + c) : zero4;
+    const unsigned labw = live ? *reinterpret_cast<const unsigned *>(g.lab + c) : 0x01010101u * unsigned(MGPS_EXTERIOR_CELL);
+    float left = __shfl_up(xc.w, 1), right = __shfl_down(xc.x, 1);
+    if (lane == 0) left = (live && i > 0) ? x[c - 1] : 0.f;
+    if (lane == kWave - 1 || i + 4 >= g.nx) right = (live && i + 4 < g.nx) ? x[c + 4] : 0.f;
+    if (!live) return;
+    const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
+    const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
+    const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
+    const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
+    const unsigned ls[4] = {labw & 255u, (labw >> 8) & 255u, (labw >> 16) & 255u, labw >> 24};
+    float res[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // the arithmetic of stencil...Kernel<OP_RESIDUAL>, then the one z weight
+        const float diag = simpleDiag(ls[e]);
+        const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
+        const float r = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), 0.f) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
+        res[e] = wz * r;
+    }
+    *reinterpret_cast<float4 *>(rz + size_t(K) * sz + size_t(j) * sy + i) = make_float4(res[0], res[1], res[2], res[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2145,6 +2196,31 @@ __global__ __launch_bounds__(256) void restrictXYKernel(GridP cg, float *__restr
     }
 }
 
+// General BOUNDARY cells of a level that takes the pair above: residualZKernel leaves them out (their code is not a simple one: r = 0),
+// this kernel adds their part to rz -- r = b - (row . x) from the cell's operator row (boundaryOpKernel<OP_RESIDUAL>), times the z
+// weight, into the two coarse planes K with 2 K - 1 <= k <= 2 K + 2.  One launch per k mod 4 (`phase`): two general cells of one
+// column that add into the same rz entry are less than four planes apart, so within a launch no two threads write the same entry
+// and the adds need no atomics -- every entry gets its terms in the order of the launches, the same on every run.
+__global__ __launch_bounds__(256) void residualZGeneralKernel(GridP g, float *__restrict__ rz, const float *__restrict__ x, const float *__restrict__ b, int phase)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= g.nbnd) return;
+    const size_t c = size_t(g.bnd[t]);
+    const size_t sz = size_t(g.nx) * g.ny;
+    const int k = int(c / sz);
+    if ((k & 3) != phase) return;
+    float lap, diag;
+    boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
+    const float r = epilogue<OP_RESIDUAL>(x[c], b[c], lap, diag, 0.f);
+    const size_t col = c - size_t(k) * sz;
+    // plane 2 m is the second term of coarse plane m and the last of m - 1, plane 2 m + 1 the third of m and the first of m + 1
+    const int m = k >> 1, Ka = (k & 1) ? m : m - 1, Kb = (k & 1) ? m + 1 : m;
+    const float wa = (k & 1) ? 0.375f : 0.125f, wb = (k & 1) ? 0.125f : 0.375f;
+    const int cnz = g.nz >> 1;
+    if (Ka >= 0 && Ka < cnz) rz[size_t(Ka) * sz + col] += wa * r;
+    if (Kb >= 0 && Kb < cnz) rz[size_t(Kb) * sz + col] += wb * r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Prolongation + add (Ops.h:873-972): fine c += 4 * trilerp(coarse) at sample point c/2 - 1/4:
 // even c = 2m reads coarse m-1, m with f = 3/4; odd c = 2m+1 reads m, m+1 with f = 1/4.  lerp is
@@ -3201,16 +3277,34 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
 // residualRestrictFits: the shapes both kernels take
 bool residualRestrictFits(const GridP &fine, const GridP &coarse)
 {
-    return fine.planeZc >= 2 && (fine.planeZc & 1) == 0 && (fine.nz & 1) == 0 && fine.nbnd == 0 && !fine.ghostLo && !fine.ghostHi && coarse.nx >= 64 &&
+    return fine.planeZc >= 4 && (fine.planeZc & 1) == 0 && (fine.nz & 1) == 0 && !fine.ghostLo && !fine.ghostHi && coarse.nx >= 64 &&
            (coarse.nx & 1) == 0 && 2 * coarse.nx == fine.nx && 2 * coarse.ny == fine.ny && 2 * coarse.nz == fine.nz && !coarse.ghostLo && !coarse.ghostHi;
 }
-int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b)
+// the (block, side) pairs residualZEdgeKernel serves, from a host copy of the block flags (planeBlockCount bytes): 2 * block + side
+std::vector<int32_t> planeBlockEdges(const GridP &g, const std::vector<uint8_t> &flags)
+{
+    const int zc = g.planeZc > 0 ? g.planeZc : 1;
+    const size_t layer = size_t((g.nx + 255) / 256) * size_t((g.ny + kPlaneRows - 1) / kPlaneRows), nbz = size_t((g.nz + zc - 1) / zc);
+    std::vector<int32_t> edges;
+    for (size_t bid = 0; bid < flags.size() && bid < layer * nbz; ++bid) {
+        if (flags[bid]) continue;
+        const size_t bz = bid / layer;
+        if (bz > 0 && flags[bid - layer]) edges.push_back(int32_t(2 * bid));
+        if (bz + 1 < nbz && flags[bid + layer]) edges.push_back(int32_t(2 * bid + 1));
+    }
+    return edges;
+}
+int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges)
 {
     const int zc = fine.planeZc;
     const unsigned nbx = (fine.nx + 255) / 256, nby = (fine.ny + kPlaneRows - 1) / kPlaneRows, nbz = (fine.nz + zc - 1) / zc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const bool list = fine.planeBlocks != nullptr;
     const unsigned nb = list ? unsigned(fine.nplaneBlocks) : nbx * nby * nbz;
-    if (nb > 0) residualZKernel<<<nb, 64 * kPlaneRows, 0, static_cast<hipStream_t>(stream)>>>(fine, rz, x, b, nbx, nby, zc, list ? fine.planeBlocks : nullptr);
+    if (nb > 0) residualZKernel<<<nb, 64 * kPlaneRows, 0, s>>>(fine, rz, x, b, nbx, nby, zc, list ? fine.planeBlocks : nullptr);
+    if (list && nedges > 0) residualZEdgeKernel<<<unsigned(nedges), 64 * kPlaneRows, 0, s>>>(fine, rz, x, b, nbx, nby, zc, edges);
+    if (fine.nbnd > 0)  // the general BOUNDARY cells' part (their entries lie in blocks the launches above have just written)
+        for (int phase = 0; phase < 4; ++phase) residualZGeneralKernel<<<blocksFor(size_t(fine.nbnd), 256), 256, 0, s>>>(fine, rz, x, b, phase);
     return int(hipGetLastError());
 }
 int launchRestrictXY(void *stream, const GridP &coarse, float *coarseOut, const float *rz)

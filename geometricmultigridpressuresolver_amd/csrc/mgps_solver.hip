@@ -68,6 +68,8 @@ struct DevLevel {
     uint32_t *nearBand = nullptr;
     float *stage = nullptr;
     uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
+    int32_t *rzEdges = nullptr;     // launchResidualZ: the blocks without active cells below / above a block with some (planeBlockEdges), made with rz
+    int nrzEdges = 0;
     float *rz = nullptr;            // the residual folded along z (residualRestrictFuses; nx x ny x nz / 2, made on first use, zero where nothing writes)
     uint8_t *snapTile = nullptr;    // Gauss-Seidel strokes: a byte per 16^3 tile, set where a box group reads (launchMarkSnapTiles; made on first use)
     uint32_t *keepBits = nullptr;   // launchStrokeFront: one bit per cell, the owned band / closure-output cells of the boxes (made on first use)
@@ -456,6 +458,7 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.keepBits);
         (void)cacheFree(L.snapTile);
         (void)cacheFree(L.rz);
+        (void)cacheFree(L.rzEdges);
         gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
@@ -862,10 +865,24 @@ bool residualRestrictFuses(const mgps_solver *h, int l)
 int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
 {
     DevLevel &F = h->lv[l], &C = h->lv[l + 1];
-    if (!F.rz) MGPS_TRY(devAlloc(h, &F.rz, F.d.cells() / 2, true));
+    if (!F.rz) {
+        MGPS_TRY(devAlloc(h, &F.rz, F.d.cells() / 2, true));
+        if (F.g.planeBlocks) {  // once: which blocks off the activity list sit below / above a listed one
+            if (!F.planeFlags) {
+                MGPS_TRY(devAlloc(h, &F.planeFlags, planeBlockCount(F.g), true));
+                MGPS_LAUNCH(h, launchPlaneBlockFlags(h->stream, F.g, F.planeFlags));
+            }
+            std::vector<uint8_t> flags(planeBlockCount(F.g));
+            MGPS_HIP(h, hipMemcpyAsync(flags.data(), F.planeFlags, flags.size(), hipMemcpyDeviceToHost, h->stream));
+            MGPS_HIP(h, hipStreamSynchronize(h->stream));
+            const std::vector<int32_t> edges = planeBlockEdges(F.g, flags);
+            F.nrzEdges = int(edges.size());
+            if (F.nrzEdges) MGPS_TRY(devUpload(h, &F.rzEdges, edges));
+        }
+    }
     {
         StageScope scope(h, ST_RESIDUAL, l);
-        MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs));
+        MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs, F.rzEdges, F.nrzEdges));
     }
     StageScope scope(h, ST_RESTRICT, l);
     MGPS_LAUNCH(h, launchRestrictXY(h->stream, C.g, C.b, F.rz));
@@ -1094,7 +1111,7 @@ int ensureProlongFusion(mgps_solver *h, int l)
     MGPS_TRY(devAlloc(h, &L.nearBand, words, true));
     MGPS_TRY(gridAlloc(h, &L.stage, L.d));
     MGPS_LAUNCH(h, launchMarkNearBand(h->stream, L.g, L.bandBoxes, L.nearBand));
-    if (L.g.planeBlocks) {
+    if (L.g.planeBlocks && !L.planeFlags) {
         MGPS_TRY(devAlloc(h, &L.planeFlags, planeBlockCount(L.g), true));
         MGPS_LAUNCH(h, launchPlaneBlockFlags(h->stream, L.g, L.planeFlags));
     }

@@ -191,7 +191,7 @@ np.save(sys.argv[1], x.cpu().numpy())
 
 @pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
                                          ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"),
-                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"), ("MGPS_FUSE_RR", "rag264"),
+                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"), ("MGPS_FUSE_RR", "rag264"), ("MGPS_FUSE_RR", "wsolid"), ("MGPS_FUSE_RR", "stair"),
                                          ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
@@ -219,7 +219,9 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0); rag264: a small box whose grid ends in ragged tiles in every
-    direction (the residual + restriction pair forced onto it)."""
+    direction (the residual + restriction pair forced onto it); wsolid: a free surface with a solid on such a grid (general BOUNDARY
+    cells in the pair); stair: a step in the liquid on block boundaries (a block without active cells owes rz the terms of the block
+    below it)."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -235,12 +237,22 @@ if case == "pool128":
 elif case == "cube512":
     lab, w, dx = D.interior_cube(512, 6)
     lev = 6
+elif case == "wsolid":  # free surface + cut-cell solid in a 264 x 40 x 32 grid: general BOUNDARY rows, plane blocks of 4 planes that the surface cuts
+    bl, bw, dx = D.build_complex_domain((24, 32, 256), use_solid=True)
+    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(32, 40, 264))
 else:
     # planeN: an N x 992 x 64 box in a 1024 x 1024 x 96 grid; rag264: a 248 x 44 x 20 box in a 264 x 52 x 28 grid (the last tile of
     # every direction is ragged: 256 + 8 columns, 3 x 16 + 4 rows, planes in blocks of 4)
-    shape = (20, 44, 248) if case == "rag264" else (64, 992, int(case[5:]))
+    shape = (20, 44, 248) if case == "rag264" else (24, 32, 248) if case == "stair" else (64, 992, int(case[5:]))
     bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
-    bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
+    if case == "stair":
+        # a step in the liquid exactly on block boundaries of the 264 x 40 x 32 grid (offset 4): rows below solver row 16 are liquid
+        # up to solver plane 11, the rows from 16 on up to plane 19 -- the 256 x 16 x 4 block above the low part has no active cell,
+        # and the coarse cells of the high part next to it read the terms it owes rz (residualZEdgeKernel)
+        bl[1:8, 1:12, 1:-1] = D.INTERIOR
+        bl[1:16, 12:31, 1:-1] = D.INTERIOR
+    else:
+        bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
     bw = []
     for axis in range(3):
         wa = np.zeros(D.face_shape(*shape, axis), dtype=np.float32)
@@ -250,6 +262,8 @@ else:
     dx = 1.0 / 992
     if case == "rag264":
         lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(28, 52, 264))
+    elif case == "stair":
+        lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(32, 40, 264))
     else:
         lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
 s = G.GeometricMultigridPoissonSolver(lab, w, lev, gs)
@@ -289,7 +303,10 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
     assert np.abs(outs[0]["x"]).max() > 0 and all(np.isfinite(outs[0][key]).all() for key in ("x", "y", "z"))
     for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
         if switch in ("MGPS_RESTRICT", "MGPS_FUSE_RR"):  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
-            assert np.abs(outs[0][key] - outs[1][key]).max() <= 2e-6 * np.abs(outs[1][key]).max(), key
+            # (z: eight CG iterations preconditioned by cycles that differ in their last bits -- on the free surface with a solid the
+            # iterates drift apart like the fp32 recurrence itself does, 2e-4 of the solution)
+            tol = 1e-3 if (key == "z" and case == "wsolid") else 2e-6
+            assert np.abs(outs[0][key] - outs[1][key]).max() <= tol * np.abs(outs[1][key]).max(), key
         else:
             assert np.array_equal(outs[0][key], outs[1][key]), key
     assert np.array_equal(outs[0]["x"], outs[0]["y"])
