@@ -491,7 +491,8 @@ GridP g, float *__restrict__ out,
 // rz(i, j, K) = w0 r(2K-1) + w1 r(2K) + w2 r(2K+1) + w3 r(2K+2) -- half the planes of r, which is never written: 11 B per
 // cell instead of 13, and the x-y restriction that follows (restrictXYKernel) reads 2 B per fine cell with no overlap along
 // z instead of 4 B with the 4-plane footprint.  A block of planes [k0, k1) also forms r on planes k0 - 1 and k1 (two more
-// planes per zc).  Levels without general BOUNDARY cells, ghost planes or binary16 grids (launchResidualZ); `rz` is a grid
+// planes per zc).  Levels without ghost planes or binary16 grids; general BOUNDARY cells (not a simple code: r = 0 here) join through
+// residualZGeneralKernel (launchResidualZ); `rz` is a grid
 // of nx x ny x nz/2 that nobody else writes: blocks with no active cell in them, below them or above them are never written and stay
 // zero (residualZEdgeKernel serves the blocks next to active ones).
 // ---------------------------------------------------------------------------------------------

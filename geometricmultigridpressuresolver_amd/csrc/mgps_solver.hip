@@ -845,9 +845,9 @@ int zeroStrokeWithResidual(mgps_solver *h, int l, float *&cur, float *&other, co
 }
 
 // Residual + restriction of a down-stroke without the residual grid (launchResidualZ + launchRestrictXY): whole-grid fp32 levels
-// that have plane blocks and no general BOUNDARY cells (every coarse level, and the fine level of a domain whose weights are all
-// 0 / 1) and whose x-y planes are 4 MiB or more.  Measured on MI355X, separate passes against the pair, ms per cycle: 1024^3 fine level
-// residual 1.78 + restriction 0.80 against 1.80 + 0.44 (100.2 -> 103.6 cycles/s); 512^3 0.22 + 0.11 against 0.25 + 0.064 (a wash: 784
+// that kept their plane blocks (planeZcFor: the liquid fills most of the blocks it touches) and whose x-y planes are 4 MiB or more.
+// Measured on MI355X, separate passes against the pair, ms per cycle: 1024^3 fine level
+// residual 1.79 + restriction 0.80 against 1.75 + 0.44 (99.2 -> 104.0 cycles/s); 512^3 0.22 + 0.11 against 0.25 + 0.064 (a wash: 784
 // workgroups of 1024 threads are one and a half rounds of the chip, and the residual it never writes would have stayed in the
 // Infinity Cache); 256^3 0.027 + 0.019 against 0.048 + 0.014.  MGPS_FUSE_RR=0: never; =1: every level that fits (tests).  The
 // terms of a coarse cell are added along z first instead of last: the last bits of the coarse rhs differ from the separate passes'.
