@@ -421,8 +421,7 @@ GridP g, float *__restrict__ out,
     float4 hy = zero4;  // y-halo row this thread stages (top / bottom rows only)
     if (ld && rowTop) hy = gLoad4(xk, offYm);
     if (ld && rowBot) hy = gLoad4(xk, offYp);
-    float hx = ld ? gLoad1(xk, offHx) : 0.f;  // x-halo cell this thread stages (first / last lane only)
-    if (!useHx) hx = 0.f;
+    float hx = ld ? gLoad1(xk, offHx) : 0.f;  // x-halo cell this thread stages (first / last lane only; the others drop it where it is staged)
 
     int buf = 0;
     for (int k = k0; k < k1; ++k) {
@@ -430,8 +429,8 @@ GridP g, float *__restrict__ out,
         *reinterpret_cast<float4 *>(me) = xc;
         if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
         if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
-        if (colL) me[-1] = hx;
-        if (colR) me[4] = hx;
+        if (colL) me[-1] = useHx ? hx : 0.f;
+        if (colR) me[4] = useHx ? hx : 0.f;
         float4 bc = zero4;
         uchar4 lc = ext4;
         if (live) {
@@ -447,7 +446,6 @@ GridP g, float *__restrict__ out,
             if (rowTop) hyn = gLoad4(xn, offYm);
             if (rowBot) hyn = gLoad4(xn, offYp);
             hxn = gLoad1(xn, offHx);
-            if (!useHx) hxn = 0.f;
         }
         __syncthreads();
         const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
@@ -539,8 +537,8 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     // -- a branch per side made every wave wait for all its loads in flight before each of the two
     const unsigned offHx = (colL && hasL) ? off - 1u : (colR && hasR) ? off + 4u : off;
     const bool useHx = live && ((colL && hasL) || (colR && hasR));
-    float hx = live ? gLoad1(xk, offHx) : 0.f;
-    if (!useHx) hx = 0.f;
+    float hx = live ? gLoad1(xk, offHx) : 0.f;  // (lanes without such a cell: whatever arrives is dropped where hx is staged -- a select here
+                                                // would wait for the load, the last one requested, and with it for every load in flight)
     constexpr float w0 = 0.125f, w1 = 0.375f, w2 = 0.375f, w3 = 0.125f;
     // coarse plane (k - 1) / 2 with its first terms (accPrev) and the one after it (accCur), see the fold below
     float accPrev[4] = {0.f, 0.f, 0.f, 0.f}, accCur[4] = {0.f, 0.f, 0.f, 0.f};
@@ -550,8 +548,8 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
         *reinterpret_cast<float4 *>(me) = xc;
         if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
         if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
-        if (colL) me[-1] = hx;
-        if (colR) me[4] = hx;
+        if (colL) me[-1] = useHx ? hx : 0.f;
+        if (colR) me[4] = useHx ? hx : 0.f;
         // this plane's rhs and codes (in flight across the barrier), the own quad two planes ahead, the next plane's halo
         const float *bk = planeOf(b, k);
         const uint8_t *lk = scalarBase(g.lab + size_t(k) * sz);
@@ -568,7 +566,6 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
             if (rowTop) hyn = gLoad4(xn, offYm);
             if (rowBot) hyn = gLoad4(xn, offYp);
             hxn = gLoad1(xn, offHx);
-            if (!useHx) hxn = 0.f;
         }
         __syncthreads();
         const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
