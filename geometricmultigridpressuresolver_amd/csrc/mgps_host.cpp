@@ -110,13 +110,14 @@ static inline int ilog2ceil(int v)
 }
 
 // MGPS_SETUP_TIMING=1: stage times of the host-side set-up on stderr (tuning aid)
+bool setupTimingOn()
+{
+    static const bool v = getenv("MGPS_SETUP_TIMING") != nullptr;
+    return v;
+}
 struct HostLap {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    static bool on()
-    {
-        static const bool v = getenv("MGPS_SETUP_TIMING") != nullptr;
-        return v;
-    }
+    static bool on() { return setupTimingOn(); }
     void lap(const char *what)
     {
         if (!on()) return;
@@ -322,18 +323,12 @@ static void buildTileLists(HostLevel &L, int tileZOffset);
 
 // Run length of a level's activity list from the number of active runs of 1024, 256, 64 and 32 cells: the length whose runs
 // cost least, cells visited x cost per visited cell.  The costs are measured on the 512^3 cube's fine Jacobi sweep with the
-// length forced (MGPS_RUN_CELLS): 2.41 / 2.46 / 2.72 / 2.94 ps per visited cell -- shorter runs mean more list entries, more
+// length forced: 2.41 / 2.46 / 2.72 / 2.94 ps per visited cell -- shorter runs mean more list entries, more
 // run ends that fetch their x-neighbour from memory, and waves that gather from eight places.  A shorter length has to win by
 // 3 % to be taken.  (The cube keeps 1024-cell runs although 32-cell runs would skip its 33-cell padding: 540 against 528
 // V-cycles/s; the reference's free-surface test domain goes to 32: MG-PCG 79.8 / 69.7 / 65.2 ms with 256 / 64 / 32.)
 int chooseRunCells(const int64_t nAct[4])
 {
-    static const int forced = [] {  // MGPS_RUN_CELLS=1024|256|64|32: A/B switch for tuning runs
-        const char *e = getenv("MGPS_RUN_CELLS");
-        return e ? atoi(e) : 0;
-    }();
-    for (int z = 0; z < 4; ++z)
-        if (forced == kRunSizes[z]) return forced;
     int cells = kRunSizes[0];
     double best = double(nAct[0]) * kRunSizes[0] * runCostFactor(kRunSizes[0]);
     for (int z = 1; z < 4; ++z) {
@@ -1612,6 +1607,7 @@ using namespace mgps;
 // Coarsest system (MG.cpp:288-411): one row per active cell, -1 per active neighbour, diagonal =
 // #active + #DIRICHLET neighbours; unknowns numbered tile by tile, x fastest inside a tile.
 // Factorised as a banded Cholesky (an exact SPD direct solve like Eigen::SimplicialCholesky).
+static int factorCoarseOnHost(mgps_hierarchy &H);
 static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
 {
     const HostLevel &L = H.lv[H.levels - 1];
@@ -1651,13 +1647,22 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
     // the solver factorises and inverts on the device (BASELINE configs 3 / 5 as SURVEY 8(d) states them: 512^3 with 5 levels,
     // coarsest 32^3).
     // (the dense inverse the device mat-vec needs is one banded solve per unknown on the host threads: 2 n^2 bw, priced at 5 x the budget)
+    H.coarseBW = bw;
     H.coarseOnDevice = cn > kHostCoarseMax || double(cn) * double(bw) * double(bw) > kHostFactorFlops || 2.0 * double(cn) * double(cn) * double(bw) > 5.0 * kHostFactorFlops;
     if (H.coarseOnDevice) {
-        H.coarseBW = 0;
         H.coarseL.clear();
         return MGPS_OK;
     }
-    H.coarseBW = bw;
+    return factorCoarseOnHost(H);
+}
+
+// the banded Cholesky factor of the coarsest matrix (numbering and coarseBW from buildCoarseSolver)
+static int factorCoarseOnHost(mgps_hierarchy &H)
+{
+    const HostLevel &L = H.lv[H.levels - 1];
+    const Dims d = L.d;
+    const ptrdiff_t stride[3] = {1, d.nx, ptrdiff_t(d.nx) * d.ny};
+    const int cn = H.coarseN, bw = H.coarseBW;
     const int W = bw + 1;
     std::vector<double> &A = H.coarseL;
     A.assign(size_t(cn) * W, 0.0);
@@ -1690,6 +1695,24 @@ static int buildCoarseSolver(mgps_hierarchy &H, int maxUnknowns)
     }
     return MGPS_OK;
 }
+
+// A coarsest level that the cost rule sent to the device (coarseOnDevice) but that the host can still factorise -- at most
+// kHostCoarseMax unknowns: slowly (the reference's tile numbering gives the band a width of thousands), for callers without
+// libhipsolver and for the host-only mgps_hierarchy_coarse_solve
+namespace mgps {
+int hostCoarseFallback(mgps_hierarchy *H)
+{
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    if (!H->coarseOnDevice) return MGPS_OK;
+    if (H->coarseN > kHostCoarseMax)
+        return fail(MGPS_ERR_COARSE_TOO_LARGE, "coarsest level has " + std::to_string(H->coarseN) + " unknowns: above " + std::to_string(kHostCoarseMax) +
+                                                   " the direct solver needs libhipsolver.so (raise mg_levels)");
+    const int rc = factorCoarseOnHost(*H);
+    if (rc == MGPS_OK) H->coarseOnDevice = false;
+    return rc;
+}
+}  // namespace mgps
 
 void mgps_hierarchy::bandedSolve(double *v) const
 {
@@ -2570,9 +2593,10 @@ int mgps_hierarchy_coarse_unknowns(const mgps_hierarchy *hier) { return hier ? h
 int mgps_hierarchy_coarse_solve(const mgps_hierarchy *hier, float *x, const float *b)
 try {
     if (!hier || !x || !b) return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_coarse_solve: bad arguments");
-    if (hier->coarseOnDevice)
-        return fail(MGPS_ERR_COARSE_TOO_LARGE, "mgps_hierarchy_coarse_solve: the host factor stops at " + std::to_string(kHostCoarseMax) +
-                                                   " unknowns or a banded factorisation of 4e9 operations (such coarsest levels are factorised on the device: mgps_coarse_solve)");
+    if (hier->coarseOnDevice) {  // (the cost rule sent this level to the device: the host factorises it now, slowly, up to kHostCoarseMax unknowns)
+        const int rc = hostCoarseFallback(const_cast<mgps_hierarchy *>(hier));
+        if (rc != MGPS_OK) return rc;
+    }
     std::vector<double> v(hier->coarseN);
     for (int r = 0; r < hier->coarseN; ++r) v[r] = b[hier->coarseCell[r]];
     hier->bandedSolve(v.data());

@@ -335,12 +335,7 @@ inline int planeSweepZc(int nx, int ny, int nz)
 {
     if ((nx & 3) != 0 || nx < 256 || ny < kPlaneRows) return 0;
     const size_t nbx = (nx + 255) / 256, nby = (ny + kPlaneRows - 1) / kPlaneRows;
-    static const int zcTop = [] {  // MGPS_PLANE_ZC=N: planes per block on large levels (tuning runs)
-        const char *e = getenv("MGPS_PLANE_ZC");
-        const int v = e ? atoi(e) : 0;
-        return v >= 4 && v <= 256 ? v : 32;
-    }();
-    int zc = zcTop;  // fewer planes per workgroup on small grids so that the launch still fills 256 CUs
+    int zc = 32;  // fewer planes per workgroup on small grids so that the launch still fills 256 CUs
     while (zc > 4 && nbx * nby * size_t((nz + zc - 1) / zc) < 1024) zc >>= 1;
     return zc;
 }
@@ -353,6 +348,8 @@ enum StencilOp { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_APPLY = 2 };
 size_t stencilSweptCells(const GridP &g);
 // which kernel launchStencil takes on this level: 1 = stencilQuadKernel, 2 = stencilPlaneKernel, 3 = stencilScalarKernel
 int stencilKernelOf(const GridP &g);
+int forcedStencilPath();  // MGPS_STENCIL=quad|plane (A/B switch of launchStencil): 0 none, 1 quad, 2 plane
+bool setupTimingOn();     // MGPS_SETUP_TIMING=1: stage times of the set-up on stdout / stderr (mgps_host.cpp)
 int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                   bool skipInactive);
 // out = A x and *resultDev = <x, A x> over the active cells of level g in one pass (the CG loop's A.p and its dot);
@@ -393,11 +390,6 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
                   bool outClosure = false);
 // dst = src on the band cells of every owned box (the legacy form of the plain stage: out of place into a scratch grid,
 // then this copy -- used where no snapshot of the input exists)
-// Down-stroke from the zero iterate, sweep and residual in one pass: xout = omega b / diag (the Jacobi sweep of x = 0), rout = b - A xout.
-// Right away from the band; after the plain box launch has put the band closure into xout, launchBoxResidual recomputes r on the
-// closure and on the cells next to it.  Levels that take the quad or the plane sweep (stencilKernelOf != 3)
-int launchZeroSweepResidual(void *stream, const GridP &g, float *xout, float *rout, const float *b, float omega);
-int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, const float *x, const float *b, float *r);
 // The closure launch and the sweep of a stroke as one launch (levels that take the quad sweep; x == nullptr: the zero iterate): the
 // sweep leaves the cells whose bit is set in `keep` alone (launchMarkClosure: the owned band / closure-output cells of the boxes, one
 // bit per cell, cells / 32 words zeroed by the caller), which the plain launch writes afterwards
@@ -455,17 +447,8 @@ int launchFromHalf(void *stream, float *dst, const void *srcH, const float *sigm
 int launchMixSigma(void *stream, const double *maxAbsDev, float *sigmaDev);
 int launchZeroActiveHalf(void *stream, const GridP &g, void *aH);
 int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const float *coarse, float *snap = nullptr, const uint8_t *snapTile = nullptr);
-// the up-stroke's prolongation folded into the sweep that follows it: out = Jacobi(x + 4 P coarse), x itself is not updated;
-// quads flagged in nearBand (launchMarkNearBand: every quad a box group stages; (cells / 4 + 31) / 32 words, zeroed first)
-// also leave x + 4 P coarse in `stage`
-bool prolongJacobiApplies(const GridP &fine);
-// blockFlags (optional): a byte per block of the plane-marching sweep (planeBlockCount; launchPlaneBlockFlags sets the listed ones):
-// tiles whose rows touch no active block return at once
-int launchProlongJacobi(void *stream, const GridP &fine, float *out, const float *x, const float *b, const float *coarse, float omega, const uint32_t *nearBand,
-                        float *stage, const uint8_t *blockFlags);
 size_t planeBlockCount(const GridP &g);
 int launchPlaneBlockFlags(void *stream, const GridP &g, uint8_t *flags);
-int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits);
 // dense coarsest matrix (n x n doubles, zeroed by the caller) from the level's labels; fp32 inverse from the triangle potri left
 int launchCoarseAssemble(void *stream, int n, int nx, int ny, const int32_t *cells, const int32_t *index, const uint8_t *lab, double *A);
 int launchCoarseNarrow(void *stream, int n, const double *A, float *inv);
@@ -563,6 +546,11 @@ int launchUnpack(void *stream, float *a, const float *buf, const int32_t *idx, i
 namespace mgps {
 constexpr int kHostCoarseMax = 8192;
 constexpr double kHostFactorFlops = 4e9;  // n x bandwidth^2 of the host's banded Cholesky factor (buildCoarseSolver): beyond it the device factorises
+}
+
+struct mgps_hierarchy;
+namespace mgps {
+int hostCoarseFallback(mgps_hierarchy *H);  // coarseOnDevice -> a host factor after all (<= kHostCoarseMax unknowns; mgps_host.cpp)
 }
 
 // Host-only hierarchy (C-ABI opaque type).

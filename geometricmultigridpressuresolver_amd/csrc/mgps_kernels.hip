@@ -660,414 +660,6 @@ __global__ __launch_bounds__(64 * kPlaneRows) void residualZEdgeKernel(GridP g, 
     *reinterpret_cast<float4 *>(rz + size_t(K) * sz + size_t(j) * sy + i) = make_float4(res[0], res[1], res[2], res[3]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The down-stroke's sweep and residual in ONE pass when the stroke starts from the zero iterate (MG.cpp:439-440 / 566, then
-// 445-547 / 571-660): the Jacobi sweep of x = 0 is pointwise, x1 = omega b / diag (Ops.h:356-361 with x = 0), so the residual
-// r = b - A x1 (Ops.h:716-732) needs no iterate from memory at all -- every x1 it reads is rebuilt from the rhs and the code of
-// that cell.  13 B per cell (rhs 4, code 1, x1 4, r 4) instead of 9 (the zero-start sweep) + 13 (the residual).  The same
-// expressions in the same order as stencil...Kernel<OP_JACOBI, ..., XZERO> followed by <OP_RESIDUAL>: the same bits.
-// Right away from the band: the band stages change x on the band closure, so x1 there and r on the closure dilated by one
-// cell are overwritten after this launch (launchBandBox, plain mode; launchBoxResidual).  General BOUNDARY cells (all band
-// cells) are left to those launches entirely.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float zeroSweepCell(float b, unsigned l, float omega)
-{
-    // stencil...Kernel<OP_JACOBI, XZERO>: lap = diag * 0 - 0, res = 0 + omega * ((b - lap) * rcp(diag))
-    const float diag = simpleDiag(l);
-    const float lap = diag * 0.f - (0.f + 0.f + 0.f + 0.f + 0.f + 0.f);
-    return simpleCell(l) ? epilogueRcp<OP_JACOBI>(0.f, b, lap, simpleRcp(diag), omega) : inactiveValue<OP_JACOBI>(0.f);
-}
-__device__ __forceinline__ float4 zeroSweepQuad(float4 b, uchar4 l, float omega)
-{
-    return make_float4(zeroSweepCell(b.x, l.x, omega), zeroSweepCell(b.y, l.y, omega), zeroSweepCell(b.z, l.z, omega), zeroSweepCell(b.w, l.w, omega));
-}
-
-__global__ __launch_bounds__(256) void zeroSweepResidualQuadKernel(GridP g, float *__restrict__ xout, float *__restrict__ rout, const float *__restrict__ b,
-                                                                    float omega, unsigned nblocks, const int32_t *__restrict__ chunks)
-{
-    const unsigned nq = unsigned(g.nx) >> 2;
-    const size_t rows = size_t(g.ny) * g.nz;
-    const size_t totalQuads = size_t(nq) * rows;
-    const unsigned block = remapBlock(blockIdx.x, nblocks);
-    size_t t = size_t(block) * blockDim.x + threadIdx.x;
-    bool valid = true;
-    if (chunks) valid = listQuad(chunks, g.chunkCells, block, t);
-    valid = valid && t < totalQuads;
-    const size_t tt = valid ? t : totalQuads - 1;
-    const unsigned q = unsigned(tt % nq);
-    const size_t row = tt / nq;
-    const int j = int(row % g.ny), k = int(row / g.ny);
-    const int i = int(q) << 2;
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const size_t c = row * sy + i;
-    const size_t cym = j > 0 ? c - sy : c, cyp = j < g.ny - 1 ? c + sy : c;
-    const size_t czm = k > 0 ? c - sz : c, czp = k < g.nz - 1 ? c + sz : c;
-    auto quadAt = [&](size_t p) { return zeroSweepQuad(*reinterpret_cast<const float4 *>(b + p), *reinterpret_cast<const uchar4 *>(g.lab + p), omega); };
-    const uchar4 lab = *reinterpret_cast<const uchar4 *>(g.lab + c);
-    const float4 bc = *reinterpret_cast<const float4 *>(b + c);
-    const float4 xc = zeroSweepQuad(bc, lab, omega);
-    const float4 ym = quadAt(cym), yp = quadAt(cyp), zm = quadAt(czm), zp = quadAt(czp);
-    const int runMask = listRunMask(chunks, g.chunkCells), lane = threadIdx.x & runMask;
-    float left = __shfl_up(xc.w, 1);
-    float right = __shfl_down(xc.x, 1);
-    if (lane == 0 || q == 0) left = (i > 0) ? zeroSweepCell(b[c - 1], g.lab[c - 1], omega) : 0.f;
-    if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? zeroSweepCell(b[c + 4], g.lab[c + 4], omega) : 0.f;
-    const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
-    const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
-    const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {zp.x, zp.y, zp.z, zp.w};
-    const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
-    const unsigned ls[4] = {lab.x, lab.y, lab.z, lab.w};
-    float res[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float diag = simpleDiag(ls[e]);
-        const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-        res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
-    }
-    if (valid) {
-        *reinterpret_cast<float4 *>(xout + c) = xc;
-        *reinterpret_cast<float4 *>(rout + c) = make_float4(res[0], res[1], res[2], res[3]);
-    }
-}
-
-// the plane-marching form (stencilPlaneKernel): x1 of planes z - 1 / z / z + 1 in registers, built from the rhs and code
-// planes as they arrive; the halo row / cell a thread stages likewise
-__global__ __launch_bounds__(64 * kPlaneRows) void zeroSweepResidualPlaneKernel(GridP g, float *__restrict__ xout, float *__restrict__ rout,
-                                                                                const float *__restrict__ b, float omega, unsigned nbx, unsigned nby,
-                                                                                unsigned nbz, int zc, const int32_t *__restrict__ blocks)
-{
-    __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
-    unsigned bid = remapBlock(blockIdx.x, gridDim.x);
-    if (blocks) bid = unsigned(blocks[bid]);
-    const unsigned bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
-    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
-    const int i = int(bx) * 256 + lane * 4, j = int(by) * kPlaneRows + ty;
-    const bool valid = i < g.nx && j < g.ny;
-    const int ic = min(i, g.nx - 4), jc = min(j, g.ny - 1);
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
-    size_t c = (size_t(k0) * g.ny + jc) * sy + ic;
-    const ptrdiff_t dym = jc > 0 ? -ptrdiff_t(sy) : 0, dyp = jc < g.ny - 1 ? ptrdiff_t(sy) : 0;
-    const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
-    const ptrdiff_t dh = rowTop ? dym : dyp;                 // the y-halo row of the first / last thread row
-    const bool edgeRow = rowTop || rowBot, edgeCol = colL || colR;
-    const ptrdiff_t dx = colL ? (ic > 0 ? -1 : 0) : (ic + 4 < g.nx ? 4 : 3);  // the x-halo cell of the first / last lane (clamped: a cell of the quad, result unused)
-    const bool xHaloReal = colL ? ic > 0 : ic + 4 < g.nx;
-
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t cm = k0 > 0 ? c - sz : c;
-    float4 xm = zeroSweepQuad(*reinterpret_cast<const float4 *>(b + cm), *reinterpret_cast<const uchar4 *>(g.lab + cm), omega);
-    float4 bc = streamLoad4(b + c);
-    uchar4 lc = streamLoad4(g.lab + c);
-    float4 xc = zeroSweepQuad(bc, lc, omega);
-    float4 hy = zero4;
-    if (edgeRow) hy = zeroSweepQuad(*reinterpret_cast<const float4 *>(b + c + dh), *reinterpret_cast<const uchar4 *>(g.lab + c + dh), omega);
-    float hx = 0.f;
-    if (edgeCol && xHaloReal) hx = zeroSweepCell(b[c + dx], g.lab[c + dx], omega);
-
-    int buf = 0;
-    for (int k = k0; k < k1; ++k) {
-        float *me = plane[buf] + (ty + 1) * kPlanePitch + 4 + lane * 4;
-        *reinterpret_cast<float4 *>(me) = xc;
-        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
-        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
-        if (colL) me[-1] = hx;
-        if (colR) me[4] = hx;
-        // next plane: rhs and codes (the plane after the block's last one: its x1 only, plain loads)
-        const size_t cn = k + 1 < g.nz ? c + sz : c;
-        float4 bn;
-        uchar4 ln;
-        if (k + 1 < k1) {
-            bn = streamLoad4(b + cn);
-            ln = streamLoad4(g.lab + cn);
-        } else {
-            bn = *reinterpret_cast<const float4 *>(b + cn);
-            ln = *reinterpret_cast<const uchar4 *>(g.lab + cn);
-        }
-        float4 hbn = zero4;
-        uchar4 hln = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-        float hxb = 0.f;
-        unsigned hxl = MGPS_EXTERIOR_CELL;
-        if (k + 1 < k1) {
-            if (edgeRow) {
-                hbn = *reinterpret_cast<const float4 *>(b + cn + dh);
-                hln = *reinterpret_cast<const uchar4 *>(g.lab + cn + dh);
-            }
-            if (edgeCol && xHaloReal) {
-                hxb = b[cn + dx];
-                hxl = g.lab[cn + dx];
-            }
-        }
-        __syncthreads();
-        const float4 xp = zeroSweepQuad(bn, ln, omega);
-        const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
-        const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
-        const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
-        const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
-        const float zms[4] = {xm.x, xm.y, xm.z, xm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
-        const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
-        const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
-        float res[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float diag = simpleDiag(ls[e]);
-            const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-            res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_RESIDUAL>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_RESIDUAL>(xs[e + 1]);
-        }
-        if (valid) {
-            __builtin_nontemporal_store(v4f{xc.x, xc.y, xc.z, xc.w}, reinterpret_cast<v4f *>(xout + c));
-            __builtin_nontemporal_store(v4f{res[0], res[1], res[2], res[3]}, reinterpret_cast<v4f *>(rout + c));
-        }
-        xm = xc;
-        xc = xp;
-        bc = bn;
-        lc = ln;
-        hy = zeroSweepQuad(hbn, hln, omega);
-        hx = zeroSweepCell(hxb, hxl, omega);
-        c = cn;
-        buf ^= 1;
-    }
-}
-
-// r = b - A x on the cells whose residual the one-pass kernel above could not know: the band closure (its x came from the box
-// launches) and the cells next to it (class "far": a neighbour's x did).  One thread per list entry, x from
-// the grid (every value final: this runs after the plain launch); the arithmetic of stencil...Kernel<OP_RESIDUAL> /
-// boundaryOpKernel<OP_RESIDUAL>, so the residual grid ends with the bits the separate residual pass leaves.
-__global__ __launch_bounds__(kBoxThreads) void boxResidualKernel(GridP g, const float *__restrict__ x, const float *__restrict__ b, float *__restrict__ r,
-                                                                 const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
-                                                                 const int32_t *__restrict__ general)
-{
-    const int32_t *gi = info + kBoxInfoInts * size_t(remapBlock(blockIdx.x, gridDim.x));
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, origin = size_t(gi[0]);
-    const uint32_t *U = list + gi[2];
-    const int nList = gi[7], ngen = gi[5];
-    for (int k = threadIdx.x; k < nList; k += kBoxThreads) {
-        const uint32_t e = U[k];
-        const unsigned cls = (e >> 16) & 15u;
-        const bool simple = cls > kBoxSimple && cls <= kBoxSimple + 6;
-        // owned closure cells; "far" cells up to one cell outside the owned box -- an active cell next to a closure-output cell
-        // lies there and may be inside no group's owned box (two groups may write it: the same bits, r = b - A x of the final x)
-        if (!(((simple || cls == kBoxFrozenOut) && (e >> 20) == 0u) || (cls == kBoxFrozenFar && (e >> 20) <= 1u))) continue;  // (general cells: below)
-        const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
-        const float diag = simple ? float(int(cls) - int(kBoxSimple)) : 6.f;
-        const float xc = x[c];
-        const float lap = diag * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
-        r[c] = epilogueRcp<OP_RESIDUAL>(xc, b[c], lap, 0.f, 0.f);
-    }
-    for (int k = threadIdx.x; k < ngen; k += kBoxThreads) {
-        const uint32_t e = uint32_t(general[2 * size_t(gi[4] + k)]);
-        if ((e >> 20) != 0u) continue;
-        const int t = general[2 * size_t(gi[4] + k) + 1];
-        const size_t c = origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz;
-        float lap, diag;
-        boundaryRow(g, [&](size_t p) { return x[p]; }, t, c, lap, diag);
-        r[c] = epilogue<OP_RESIDUAL>(x[c], b[c], lap, diag, 0.f);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Prolongation folded into the sweep that follows it (up-stroke, MG.cpp:695-757 / 787-850): out = Jacobi(x + 4 P e)
-// in ONE pass over the fine grid -- 13.5 B per cell (x 4, coarse 0.5, rhs 4, code 1, out 4) instead of 9.5 + 13 for
-// prolongAddBlockKernel followed by stencilPlaneKernel<OP_JACOBI>.  The plane-marching sweep with every value of x
-// replaced, the moment it is loaded, by x' = x + 4 trilerp(e) on active cells (Ops.h:873-972; the same lerp order as
-// prolongAddBlockKernel, so x' has the bits the separate pass would have stored).  A thread keeps the 2 x 2 coarse rows
-// its quad interpolates from in registers (four values each); the pair of coarse planes advances every other fine plane,
-// the y-halo row of a tile's first / last thread row interpolates from the same coarse rows as its neighbour inside the
-// tile (tiles start at even j), the x-halo cells from the first / last coarse value of the thread's rows.
-// The iterate itself is never written back: the sweep's output replaces it (the grids swap).  What still needs x' after
-// this launch are the box groups of the band stage (launchBandBox, closure mode, reads the un-smoothed iterate on its
-// regions): quads flagged in `nearBand` (one bit per quad, set for every quad a group stages) also leave x' in `stage`.
-// ---------------------------------------------------------------------------------------------
-// Tiles: kFusedRows = 10 output rows per workgroup; its 12 thread rows stage rows j0 - 1 .. j0 + 10 (the first and the last
-// thread row only prolong and stage their row: the y-halo).  A thread row per halo row instead of a second quad per edge
-// thread, and 768 threads instead of 1024: the kernel needs 88 registers, which leaves two workgroups per CU only at
-// twelve waves each (with 16-row tiles and the halo rows staged by the edge rows it needed 108, one workgroup per CU, and
-// ran at 3.0 TB/s: 3.66 ms at 1024^3 against 1.27 + 1.92 ms for the two separate passes).  Measured in this form: 3.11 ms,
-// 3.9 TB/s of the 14.8 B per cell it really moves (y-halo rows 12 / 10, coarse rows re-read per tile) -- break-even with the two
-// passes, so the solver takes it only when asked to (MGPS_FUSE_PROLONG=1).  Keeping the x- / y-lerps of a coarse pair for the two
-// fine planes that share it: 3.28 ms (nine more registers spilled).
-constexpr int kFusedThreadRows = 12, kFusedRows = kFusedThreadRows - 2;
-constexpr int kCoarseRows = kFusedThreadRows / 2 + 2, kCoarsePitch = 132;  // coarse rows / values a tile (+ halo) interpolates from
-
-__global__ __launch_bounds__(64 * kFusedThreadRows, 6) void prolongJacobiPlaneKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
-                                                                              const float *__restrict__ b, const float *__restrict__ coarse,
-                                                                              float omega, unsigned nbx, unsigned nbyF, unsigned nby16, int zc,
-                                                                              const uint8_t *__restrict__ blockFlags, const uint32_t *__restrict__ nearBand,
-                                                                              float *__restrict__ stage)
-{
-    __shared__ float plane[2][kFusedThreadRows * kPlanePitch];
-    // three coarse planes in rotation (plane q in slot q % 3): the pair a fine plane interpolates from and the next one
-    // on its way; kCoarseRows rows of the 130 coarse values the tile's columns (+ the two x-halo cells) read
-    __shared__ float cpl[3][kCoarseRows * kCoarsePitch];
-    const unsigned bid = __builtin_amdgcn_readfirstlane(remapBlock(blockIdx.x, gridDim.x));
-    const unsigned bx = bid % nbx, by = (bid / nbx) % nbyF, bz = bid / (nbx * nbyF);
-    const int j0 = int(by) * kFusedRows;  // first output row
-    if (blockFlags) {  // the 256 x 16 x zc blocks of the sweep's activity list that this tile's output rows touch
-        const unsigned ya = unsigned(j0) / kPlaneRows, yb = min(unsigned(j0 + kFusedRows - 1) / kPlaneRows, nby16 - 1);
-        if (!blockFlags[(size_t(bz) * nby16 + ya) * nbx + bx] && !blockFlags[(size_t(bz) * nby16 + yb) * nbx + bx]) return;
-    }
-    const int lane = threadIdx.x & (kWave - 1), ty = threadIdx.x / kWave;
-    const int i = int(bx) * 256 + lane * 4, j = j0 - 1 + ty;
-    const bool outRow = ty >= 1 && ty <= kFusedRows;
-    const int ic = min(i, g.nx - 4), jc = min(max(j, 0), g.ny - 1);
-    // quad columns outside the level's active x range (GridP::xlo): zero in every grid -- staged as zeros, nothing loaded or stored
-    const bool live = ic >= g.xlo && ic < g.xhi;
-    const bool valid = outRow && i < g.nx && j < g.ny && live;
-    const size_t sz = size_t(g.nx) * g.ny;
-    const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);
-    const bool colL = lane == 0, colR = lane == kWave - 1;
-    const int cnx = g.nx >> 1, cny = g.ny >> 1, cnz = g.nz >> 1;
-    const int cb = (j0 - 2) >> 1;  // coarse row of local row 0: what fine row j0 - 1 reads first
-    // addresses: the plane's base (scalarBase) + one 32-bit offset inside the plane per thread
-    const unsigned off = unsigned(jc) * unsigned(g.nx) + unsigned(ic);
-    auto planeOf = [&](const float *p, int k) { return scalarBase(p + size_t(min(max(k, 0), g.nz - 1)) * sz); };
-    auto labOf = [&](int k) { return scalarBase(g.lab + size_t(min(max(k, 0), g.nz - 1)) * sz); };
-    // the x-halo cell of the first / last lane (value and label): one unconditional load per wave -- the other lanes re-read their
-    // own cell and drop it (a branch per side made every wave wait for its loads in flight before each of the two)
-    const bool useHx = live && ((colL && ic > 0) || (colR && ic + 4 < g.nx));
-    const unsigned offHx = !useHx ? off : (colL ? off - 1u : off + 4u);
-    // slot q % 3 <- coarse plane q: rows cb .., values 128 bx - 1 .. (clamped: the clamps only bite on the EXTERIOR shell)
-    auto fillCoarse = [&](int q) {
-        const int qc = min(max(q, 0), cnz - 1);
-        float *dst = cpl[(q + 3) % 3];
-        for (int t = threadIdx.x; t < kCoarseRows * kCoarsePitch; t += 64 * kFusedThreadRows) {
-            const int lr = t / kCoarsePitch, lx = t - lr * kCoarsePitch;
-            const int gy = min(max(cb + lr, 0), cny - 1), gx = min(max(128 * int(bx) - 1 + lx, 0), cnx - 1);
-            dst[t] = coarse[(size_t(qc) * cny + gy) * cnx + gx];
-        }
-    };
-    const int lr = ((jc - 1) >> 1) - cb;  // this thread's first coarse row (0 .. kCoarseRows - 2)
-    const float fy = (jc & 1) ? 0.25f : 0.75f;
-    // x' = x + 4 trilerp on the active cells of this thread's quad in fine plane k (Ops.h:841-871, 931-966; lerp order x, y, z as
-    // in prolongAddBlockKernel; the plane's coarse pair (k - 1) >> 1, + 1 must be in LDS)
-    auto prolongQuad = [&](int k, float4 v, uchar4 l) {
-        const int p = (k - 1) >> 1;
-        const float wz = (k & 1) ? 0.25f : 0.75f;
-        float vy[2][4];
-#pragma unroll
-        for (int zz = 0; zz < 2; ++zz) {
-            const float *base = cpl[(p + zz + 3) % 3] + lr * kCoarsePitch + 2 * lane;
-            const float2 a01 = *reinterpret_cast<const float2 *>(base), a23 = *reinterpret_cast<const float2 *>(base + 2);
-            const float2 c01 = *reinterpret_cast<const float2 *>(base + kCoarsePitch), c23 = *reinterpret_cast<const float2 *>(base + kCoarsePitch + 2);
-            vy[zz][0] = lerpRef(lerpRef(a01.x, a01.y, 0.75f), lerpRef(c01.x, c01.y, 0.75f), fy);
-            vy[zz][1] = lerpRef(lerpRef(a01.y, a23.x, 0.25f), lerpRef(c01.y, c23.x, 0.25f), fy);
-            vy[zz][2] = lerpRef(lerpRef(a01.y, a23.x, 0.75f), lerpRef(c01.y, c23.x, 0.75f), fy);
-            vy[zz][3] = lerpRef(lerpRef(a23.x, a23.y, 0.25f), lerpRef(c23.x, c23.y, 0.25f), fy);
-        }
-        if (activeLabel(l.x)) v.x += 4.f * lerpRef(vy[0][0], vy[1][0], wz);
-        if (activeLabel(l.y)) v.y += 4.f * lerpRef(vy[0][1], vy[1][1], wz);
-        if (activeLabel(l.z)) v.z += 4.f * lerpRef(vy[0][2], vy[1][2], wz);
-        if (activeLabel(l.w)) v.w += 4.f * lerpRef(vy[0][3], vy[1][3], wz);
-        return v;
-    };
-    // the x-halo cells: fine i - 1 (odd: coarse 2m-1, 2m at 1/4) and i + 4 (even: coarse 2m+1, 2m+2 at 3/4), this thread's row
-    auto edgeAdd = [&](int k, bool right) {
-        const int p = (k - 1) >> 1;
-        const float wz = (k & 1) ? 0.25f : 0.75f, wx = right ? 0.75f : 0.25f;
-        float vy[2];
-#pragma unroll
-        for (int zz = 0; zz < 2; ++zz) {
-            const float *base = cpl[(p + zz + 3) % 3] + lr * kCoarsePitch + 2 * lane + (right ? 2 : 0);
-            vy[zz] = lerpRef(lerpRef(base[0], base[1], wx), lerpRef(base[kCoarsePitch], base[kCoarsePitch + 1], wx), fy);
-        }
-        return 4.f * lerpRef(vy[0], vy[1], wz);
-    };
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-    const int p0 = (k0 - 1) >> 1;  // k0 is even: planes k0 - 1 and k0 share the pair p0, p0 + 1; plane k0 + 1 needs p0 + 2
-    fillCoarse(p0);
-    fillCoarse(p0 + 1);
-    fillCoarse(p0 + 2);
-    const float *xk = planeOf(x, k0);
-    const uint8_t *lk = labOf(k0);
-    float4 xc = live ? gLoad4(xk, off) : zero4;
-    uchar4 lc = live ? gLoadCodes4nt(lk, off) : ext4;
-    float hx = live ? gLoad1(xk, offHx) : 0.f;
-    unsigned hl = live ? gLoadCode1(lk, offHx) : unsigned(MGPS_EXTERIOR_CELL);
-    if (!useHx) {
-        hx = 0.f;
-        hl = MGPS_EXTERIOR_CELL;
-    }
-    // plane k0 - 1 of the own quad (prolonged): the z - 1 values of a step are read back from the LDS buffer of the step before
-    float4 xm = zero4;
-    uchar4 lm = ext4;
-    if (k0 > 0 && outRow && live) {
-        xm = gLoad4(planeOf(x, k0 - 1), off);
-        lm = gLoadCodes4nt(labOf(k0 - 1), off);
-    }
-    float4 bc = zero4;
-    if (outRow && live) bc = gLoad4nt(planeOf(b, k0), off);
-    __syncthreads();
-    float *const mine0 = plane[0] + ty * kPlanePitch + 4 + lane * 4;
-    constexpr int kBufFloats = kFusedThreadRows * kPlanePitch;
-    if (k0 > 0 && outRow) xm = prolongQuad(k0 - 1, xm, lm);
-    *reinterpret_cast<float4 *>(mine0 + kBufFloats) = xm;
-    xc = prolongQuad(k0, xc, lc);
-    if (useHx && activeLabel(hl)) hx += edgeAdd(k0, colR);
-    int buf = 0;
-    for (int k = k0; k < k1; ++k) {
-        float *me = mine0 + buf * kBufFloats;
-        *reinterpret_cast<float4 *>(me) = xc;
-        if (colL) me[-1] = hx;
-        if (colR) me[4] = hx;
-        if (nearBand && valid) {  // the band stage's groups read x' here
-            const size_t q = (size_t(k) * sz + off) >> 2;
-            if ((nearBand[q >> 5] >> (q & 31)) & 1u)
-                gStore4(scalarBase(stage + size_t(k) * sz), off, xc);
-        }
-        // next plane: its loads before this plane is computed; its prolongation needs the pair (k >> 1, + 1): in LDS since the
-        // barrier of the iteration before (filled below, two planes ahead)
-        const int kn = k + 1;
-        const float *xn = planeOf(x, kn);
-        const uint8_t *ln8 = labOf(kn);
-        float4 xp = xc, bn = bc;
-        uchar4 ln = lc;
-        float hxn = hx;
-        unsigned hln = MGPS_EXTERIOR_CELL;
-        if (kn < g.nz && live) {
-            xp = gLoad4(xn, off);
-            ln = gLoadCodes4nt(ln8, off);
-            if (outRow && kn < k1) bn = gLoad4nt(planeOf(b, kn), off);
-            hxn = gLoad1(xn, offHx);
-            hln = gLoadCode1(ln8, offHx);
-        }
-        if (!useHx) {
-            hxn = 0.f;
-            hln = MGPS_EXTERIOR_CELL;
-        }
-        if (k & 1) fillCoarse(((k + 1) >> 1) + 1);  // what fine plane k + 2 will add to its pair
-        if (kn < g.nz) {
-            xp = prolongQuad(kn, xp, ln);
-            if (useHx && activeLabel(hln)) hxn += edgeAdd(kn, colR);
-        }
-        __syncthreads();
-        if (outRow) {
-            const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
-            const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
-            const float4 zm = *reinterpret_cast<const float4 *>(mine0 + (buf ^ 1) * kBufFloats);  // (this thread's own store of the step before)
-            const float xs[6] = {me[-1], xc.x, xc.y, xc.z, xc.w, me[4]};
-            const float yms[4] = {ym.x, ym.y, ym.z, ym.w}, yps[4] = {yp.x, yp.y, yp.z, yp.w};
-            const float zms[4] = {zm.x, zm.y, zm.z, zm.w}, zps[4] = {xp.x, xp.y, xp.z, xp.w};
-            const float bs[4] = {bc.x, bc.y, bc.z, bc.w};
-            const unsigned ls[4] = {lc.x, lc.y, lc.z, lc.w};
-            float res[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float diag = simpleDiag(ls[e]);
-                const float lap = diag * xs[e + 1] - (xs[e] + xs[e + 2] + yms[e] + yps[e] + zms[e] + zps[e]);
-                res[e] = simpleCell(ls[e]) ? epilogueRcp<OP_JACOBI>(xs[e + 1], bs[e], lap, simpleRcp(diag), omega) : inactiveValue<OP_JACOBI>(xs[e + 1]);
-            }
-            if (valid)
-                gStore4nt(scalarBase(out + size_t(k) * sz), off, make_float4(res[0], res[1], res[2], res[3]));
-        }
-        xc = xp;
-        bc = bn;
-        lc = ln;
-        hx = hxn;
-        buf ^= 1;
-    }
-}
-
 // Scalar fallback for levels whose nx is not a multiple of 4 (only the tiniest coarse levels).
 template <int OP, bool DOT = false>
 __global__ void stencilScalarKernel(GridP g, float *__restrict__ out, const float *__restrict__ x,
@@ -1348,10 +940,12 @@ __device__ __forceinline__ bool boxBand(unsigned cls) { return cls >= kBoxGenera
 // Gauss-Seidel down-stroke, which then writes the iterate in place
 // (the body: bandBoxKernel runs group remapBlock(blockIdx.x), strokeFrontKernel its first workgroups)
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO>
-__device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+// (dst and dotOld carry no __restrict__: the gathered dot of a Jacobi stroke reads the sweep's value of a cell through dotOld == dst
+// right before the store that replaces it)
+__device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict__ src, const float *__restrict__ b, TX *dst,
                                             TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
                                             const int32_t *__restrict__ general, float omega, int depth, const MixScale &ms,
-                                            double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure, unsigned group, unsigned slot)
+                                            double *__restrict__ dotPartials, const TX *dotOld, int outClosure, unsigned group, unsigned slot)
 {
     constexpr bool kMixed = !std::is_same<TX, float>::value;
     constexpr int kGenRows = GEN ? kBoxMaxGeneral : 1;
@@ -1504,10 +1098,10 @@ __device__ __forceinline__ void bandBoxBody(const GridP &g, const TX *__restrict
     if (DOT) blockDotStore(acc, dotPartials, slot);
 }
 template <class TX, bool CLOSURE, bool DOT, bool GEN, bool XZERO = false>
-__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *__restrict__ dst,
+__global__ __launch_bounds__(kBoxThreads, 8) void bandBoxKernel(GridP g, const TX *__restrict__ src, const float *__restrict__ b, TX *dst,
                                                               TX *__restrict__ snap, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
                                                               const int32_t *__restrict__ general, float omega, int depth, MixScale ms,
-                                                              double *__restrict__ dotPartials, const TX *__restrict__ dotOld, int outClosure)
+                                                              double *__restrict__ dotPartials, const TX *dotOld, int outClosure)
 {
     bandBoxBody<TX, CLOSURE, DOT, GEN, XZERO>(g, src, b, dst, snap, info, list, general, omega, depth, ms, dotPartials, dotOld, outClosure,
                                               remapBlock(blockIdx.x, gridDim.x), blockIdx.x);
@@ -2595,14 +2189,15 @@ inline unsigned blocksFor(size_t work, unsigned per) { return unsigned((work + p
 
 // ---- launchers -------------------------------------------------------------------------------
 
-static int forcedStencil(const GridP &g)
+int forcedStencilPath()
 {
     static const int forced = [] {  // MGPS_STENCIL=quad|plane: A/B switch for tuning runs
         const char *e = getenv("MGPS_STENCIL");
         return !e ? 0 : (e[0] == 'q' ? 1 : 2);
     }();
-    return g.sweepPath ? g.sweepPath : forced;  // options.stencil_path wins over the environment
+    return forced;
 }
+static int forcedStencil(const GridP &g) { return g.sweepPath ? g.sweepPath : forcedStencilPath(); }  // options.stencil_path wins over the environment
 
 // Cells one activity-skipping full-domain sweep visits (the denominator of the measured bytes per cell): the cells of the listed
 // runs / blocks that lie inside the level's active x range (GridP::xlo) -- counted on the device from the list the sweep walks
@@ -2728,35 +2323,6 @@ int launchStencil(void *stream, StencilOp op, const GridP &g, float *out, const 
             default: boundaryOpKernel<OP_APPLY><<<nb, 256, 0, s>>>(g, out, x, b, omega, nb); break;
         }
     }
-    return int(hipGetLastError());
-}
-
-// xout = the Jacobi sweep of the zero iterate, rout = b - A xout, one pass (zeroSweepResidual...Kernel; quad or plane form as
-// launchStencil chooses; the scalar form has no such kernel: invalid value)
-int launchZeroSweepResidual(void *stream, const GridP &g, float *xout, float *rout, const float *b, float omega)
-{
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int kind = stencilKernelOf(g);
-    if (kind == 3 || !xout || !rout || xout == rout) return int(hipErrorInvalidValue);
-    if (kind == 2) {
-        const int zc = g.planeZc;
-        const unsigned nbx = (g.nx + 255) / 256, nby = (g.ny + kPlaneRows - 1) / kPlaneRows, nbz = (g.nz + zc - 1) / zc;
-        const bool list = g.planeBlocks != nullptr;
-        const unsigned nb = list ? unsigned(g.nplaneBlocks) : nbx * nby * nbz;
-        if (nb > 0) zeroSweepResidualPlaneKernel<<<nb, 64 * kPlaneRows, 0, s>>>(g, xout, rout, b, omega, nbx, nby, nbz, zc, list ? g.planeBlocks : nullptr);
-    } else {
-        const size_t n = size_t(g.nx) * g.ny * g.nz;
-        const bool list = g.chunks != nullptr;
-        const unsigned nb = list ? unsigned(g.nchunks) / unsigned(kChunkCells / g.chunkCells) : blocksFor(n >> 2, 256);
-        if (nb > 0) zeroSweepResidualQuadKernel<<<nb, 256, 0, s>>>(g, xout, rout, b, omega, nb, list ? g.chunks : nullptr);
-    }
-    return int(hipGetLastError());
-}
-
-int launchBoxResidual(void *stream, const GridP &g, const BandBoxesDev &bx, const float *x, const float *b, float *r)
-{
-    if (bx.ngroups <= 0) return 0;
-    boxResidualKernel<<<unsigned(bx.ngroups), kBoxThreads, 0, static_cast<hipStream_t>(stream)>>>(g, x, b, r, bx.info, bx.list, bx.general);
     return int(hipGetLastError());
 }
 
@@ -3234,34 +2800,21 @@ int launchPatchSimpleCodes(void *stream, uint8_t *codes, const int32_t *band, co
 int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const float *fine)
 {
     const size_t n = size_t(coarse.nx) * coarse.ny * coarse.nz;
-    static const bool perCell = [] {  // MGPS_RESTRICT=cell: A/B switch for tuning runs
-        const char *e = getenv("MGPS_RESTRICT");
-        return e && e[0] == 'c';
-    }();
     // the march is a serial chain of kc coarse planes per thread: below ~2048 workgroups of columns the chip is not
     // filled and the thread-per-cell kernel wins (coarse 128^3: 19 us against 51 us)
     // (kc: coarse planes a workgroup marches.  16 where that still leaves >= 8192 workgroups; fewer planes -- more workgroups, a
     // little more plane overlap -- on smaller levels: a 256^3 coarse level has 2048 columns of tiles, two waves per SIMD at kc = 16)
-    static const int kcForced = [] {
-        const char *e = getenv("MGPS_RESTRICT_KC");
-        const int v = e ? atoi(e) : 0;
-        return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
-    }();
     int kc = 16;
     const unsigned nbx = (coarse.nx + 63) / 64, nby = (coarse.ny + 7) / 8;
-    while (!kcForced && kc > 4 && size_t(nbx) * nby * ((coarse.nz + kc - 1) / kc) < 8192) kc >>= 1;
-    if (kcForced) kc = kcForced;
+    while (kc > 4 && size_t(nbx) * nby * ((coarse.nz + kc - 1) / kc) < 8192) kc >>= 1;
     const unsigned nbz = (coarse.nz + kc - 1) / kc;
     // (the march walks every coarse column; the per-cell kernel walks the coarse level's activity runs at 1.3 x the cost per
     // cell -- 1.13 vs 0.88 ms at 1024^3 -> 512^3, 0.14 vs 0.118 ms one level down: it takes over where those runs hold a
     // clearly smaller part of the level.  On the cube they hold 76 %: the march stays)
     const bool runsWin = coarse.chunks && double(coarse.nchunks) * coarse.chunkCells * 1.3 * runCostFactor(coarse.chunkCells) < 0.8 * double(n);
-    static const bool tiled = [] {  // MGPS_RESTRICT=march: the register-only march (A/B)
-        const char *e = getenv("MGPS_RESTRICT");
-        return !(e && e[0] == 'm');
-    }();
-    if (!perCell && !runsWin && coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
-        if (tiled && (coarse.nx & 1) == 0) restrictTileKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
+    if (!runsWin && coarse.nx >= 64 && coarse.nz >= kc && nbx * nby * nbz >= 2048u) {
+        // (odd coarse nx: the register-only march, which the LDS-tiled one replaced elsewhere -- LABNOTES R4)
+        if ((coarse.nx & 1) == 0) restrictTileKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         else restrictMarchKernel<<<nbx * nby * nbz, 256, 0, static_cast<hipStream_t>(stream)>>>(coarse, coarseOut, fine, kc, nbx, nby);
         return int(hipGetLastError());
     }
@@ -3350,15 +2903,11 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
 {
     if (snap && !snapTile) return int(hipErrorInvalidValue);
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
-    static const bool perCell = [] {  // MGPS_PROLONG=quad: A/B switch for tuning runs
-        const char *e = getenv("MGPS_PROLONG");
-        return e && e[0] == 'q';
-    }();
     // The block kernel (one thread = 16 fine cells that share their coarse rows) walks the whole grid; the quad kernel walks the
     // level's activity runs at 1.7 x the cost per cell (0.272 vs 0.162 ms on the full 512^3 cube).  Where the liquid fills a small
     // part of the grid -- a 480^3 simulation in the 1024^3 power-of-two expansion: 62 M of 1074 M cells in runs -- the runs win.
     const bool runsWin = fine.chunks && double(fine.nchunks) * fine.chunkCells * 1.7 * runCostFactor(fine.chunkCells) < 0.8 * double(n);  // (a clear win only)
-    if (!perCell && !runsWin && (fine.nx & 3) == 0 && fine.nx >= 8 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.ny >= 4 && fine.nz >= 2) {
+    if (!runsWin && (fine.nx & 3) == 0 && fine.nx >= 8 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.ny >= 4 && fine.nz >= 2) {
         const int npj = fine.ny / 2 - 1;  // row pairs (1,2) .. (ny-3, ny-2)
         const int kp0 = fine.ghostLo ? -1 : 0, kp1 = fine.ghostHi ? fine.nz / 2 - 1 : fine.nz / 2 - 2;
         const size_t total = size_t(fine.nx >> 2) * npj * size_t(std::max(kp1 - kp0 + 1, 0));
@@ -3373,20 +2922,6 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
     return int(hipGetLastError());
 }
 
-// out = Jacobi(x + 4 P coarse) in one pass (prolongJacobiPlaneKernel): levels that take the plane-marching sweep, fine and
-// coarse extents in the 2 : 1 ratio, whole grids (no slab ghosts), no general BOUNDARY patch (the caller's closure launch
-// computes those cells).  nearBand / stage: see the kernel.  false: the shape does not qualify
-bool prolongJacobiApplies(const GridP &fine) { return stencilKernelOf(fine) == 2 && !fine.ghostLo && !fine.ghostHi && (fine.nx & 3) == 0 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.nz >= 4; }
-int launchProlongJacobi(void *stream, const GridP &g, float *out, const float *x, const float *b, const float *coarse, float omega, const uint32_t *nearBand,
-                        float *stage, const uint8_t *blockFlags)
-{
-    const int zc = g.planeZc;
-    if (!prolongJacobiApplies(g) || zc <= 0 || (zc & 1)) return int(hipErrorInvalidValue);
-    const unsigned nbx = (g.nx + 255) / 256, nby16 = (g.ny + kPlaneRows - 1) / kPlaneRows, nbyF = (g.ny + kFusedRows - 1) / kFusedRows, nbz = (g.nz + zc - 1) / zc;
-    prolongJacobiPlaneKernel<<<nbx * nbyF * nbz, 64 * kFusedThreadRows, 0, static_cast<hipStream_t>(stream)>>>(g, out, x, b, coarse, omega, nbx, nbyF, nby16, zc, blockFlags,
-                                                                                                         nearBand, stage);
-    return int(hipGetLastError());
-}
 // flags[block] = 1 for the blocks of the plane-marching sweep's activity list (a byte per 256 x 16 x zc block, zeroed by the caller)
 __global__ __launch_bounds__(256) void planeBlockFlagsKernel(const int32_t *__restrict__ blocks, int n, uint8_t *__restrict__ flags)
 {
@@ -3402,25 +2937,6 @@ int launchPlaneBlockFlags(void *stream, const GridP &g, uint8_t *flags)
 {
     if (!g.planeBlocks || g.nplaneBlocks <= 0) return 0;
     planeBlockFlagsKernel<<<blocksFor(size_t(g.nplaneBlocks), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(g.planeBlocks, g.nplaneBlocks, flags);
-    return int(hipGetLastError());
-}
-// nearBand bits (one per quad of the level's grid, zeroed by the caller) for every quad that holds a cell some group stages
-__global__ __launch_bounds__(256) void markNearBandKernel(GridP g, const int32_t *__restrict__ info, const uint32_t *__restrict__ list, uint32_t *__restrict__ bits)
-{
-    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, origin = size_t(gi[0]);
-    const uint32_t *U = list + gi[2];
-    for (int k = threadIdx.x; k < gi[7]; k += 256) {
-        const uint32_t e = U[k], cls = (e >> 16) & 15u;
-        if (cls == kBoxSkip || cls == kBoxZero) continue;
-        const size_t q = (origin + (e & 31u) + ((e >> 5) & 31u) * sy + ((e >> 10) & 31u) * sz) >> 2;
-        atomicOr(bits + (q >> 5), 1u << (q & 31));
-    }
-}
-int launchMarkNearBand(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits)
-{
-    if (bx.ngroups <= 0) return 0;
-    markNearBandKernel<<<unsigned(bx.ngroups), 256, 0, static_cast<hipStream_t>(stream)>>>(g, bx.info, bx.list, bits);
     return int(hipGetLastError());
 }
 

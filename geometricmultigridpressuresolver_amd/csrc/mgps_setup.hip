@@ -1189,17 +1189,21 @@ int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const u
 // lines).  The groups are therefore put in the Morton order of their tiles -- any run of 64 consecutive groups, what a chiplet
 // has in flight, is a compact patch -- by a stable counting sort over the tile keys; only info moves (16 ints per group), the
 // lists stay where their offsets point.
-__device__ __forceinline__ unsigned spreadBits3(unsigned v)  // 10 bits -> every third bit
+// Morton key of a tile with bx / by / bz bits per axis (a long or flat level interleaves only the bits every axis still has:
+// the key space stays within 8 x the number of tiles)
+__device__ __forceinline__ unsigned boxOrderKey(unsigned tx, unsigned ty, unsigned tz, int bx, int by, int bz)
 {
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+    unsigned key = 0;
+    int pos = 0;
+    for (int p = 0; p < 10; ++p) {
+        if (p < bx) key |= ((tx >> p) & 1u) << pos++;
+        if (p < by) key |= ((ty >> p) & 1u) << pos++;
+        if (p < bz) key |= ((tz >> p) & 1u) << pos++;
+    }
+    return key;
 }
-__global__ __launch_bounds__(256) void boxOrderKeysKernel(Dims d, const int32_t *__restrict__ info, int n, int bits, int32_t *__restrict__ key, int32_t *__restrict__ count,
-                                                        int32_t *__restrict__ first)
+__global__ __launch_bounds__(256) void boxOrderKeysKernel(Dims d, const int32_t *__restrict__ info, int n, int bx, int by, int bz, int32_t *__restrict__ key,
+                                                        int32_t *__restrict__ count, int32_t *__restrict__ first)
 {
     const int gidx = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (gidx >= n) return;
@@ -1207,8 +1211,7 @@ __global__ __launch_bounds__(256) void boxOrderKeysKernel(Dims d, const int32_t 
     const size_t c = size_t(gi[0]);
     const int ox = int(c % size_t(d.nx)) + (gi[14] & 255), oy = int((c / size_t(d.nx)) % size_t(d.ny)) + ((gi[14] >> 8) & 255),
               oz = int(c / (size_t(d.nx) * d.ny)) + ((gi[14] >> 16) & 255);
-    const unsigned m = spreadBits3(unsigned(ox / kTile)) | (spreadBits3(unsigned(oy / kTile)) << 1) | (spreadBits3(unsigned(oz / kTile)) << 2);
-    const int k = int(m & ((1u << (3 * bits)) - 1u));
+    const int k = int(boxOrderKey(unsigned(ox / kTile), unsigned(oy / kTile), unsigned(oz / kTile), bx, by, bz));
     key[gidx] = k;
     atomicAdd(count + k, 1);
     atomicMin(first + k, gidx);
@@ -1238,11 +1241,14 @@ __global__ __launch_bounds__(256) void fillIntKernel(int32_t *__restrict__ a, si
 int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, int ngroups, int32_t *infoOut)
 {
     if (ngroups <= 0) return 0;
-    const int tmax = std::max((d.nx + kTile - 1) / kTile, std::max((d.ny + kTile - 1) / kTile, (d.nz + kTile - 1) / kTile));
-    int bits = 1;
-    while ((1 << bits) < tmax) ++bits;
-    if (bits > 10) return int(hipErrorInvalidValue);
-    const size_t nbins = size_t(1) << (3 * bits);
+    auto bitsFor = [](int tiles) {
+        int b = 0;
+        while ((1 << b) < tiles) ++b;
+        return b;
+    };
+    const int bx = bitsFor((d.nx + kTile - 1) / kTile), by = bitsFor((d.ny + kTile - 1) / kTile), bz = bitsFor((d.nz + kTile - 1) / kTile);
+    if (bx > 10 || by > 10 || bz > 10 || bx + by + bz > 28) return int(hipErrorInvalidValue);
+    const size_t nbins = size_t(1) << (bx + by + bz);  // (at most 8 x the tiles of the level)
     int32_t *key = nullptr, *count = nullptr, *first = nullptr, *start = nullptr, *scratch = nullptr;
     int *broken = nullptr;
     auto release = [&]() {
@@ -1254,13 +1260,14 @@ int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, int ngroups
         (rc = deviceAlloc(reinterpret_cast<void **>(&first), nbins * 4)) || (rc = deviceAlloc(reinterpret_cast<void **>(&start), (nbins + 1) * 4)) ||
         (rc = deviceAlloc(reinterpret_cast<void **>(&scratch), scanScratchInts(nbins) * 4)) || (rc = deviceAlloc(reinterpret_cast<void **>(&broken), 4))) {
         release();
-        return rc;
+        (void)hipGetLastError();
+        return int(hipErrorOutOfMemory);  // (the caller keeps the builders' order: the ordering is an optimisation)
     }
     hipStream_t s = S(stream);
     (void)hipMemsetAsync(count, 0, nbins * 4, s);
     (void)hipMemsetAsync(broken, 0, 4, s);
     fillIntKernel<<<blocksFor(nbins, 256), 256, 0, s>>>(first, nbins, 0x7fffffff);
-    boxOrderKeysKernel<<<blocksFor(size_t(ngroups), 256), 256, 0, s>>>(d, info, ngroups, bits, key, count, first);
+    boxOrderKeysKernel<<<blocksFor(size_t(ngroups), 256), 256, 0, s>>>(d, info, ngroups, bx, by, bz, key, count, first);
     rc = launchExclusiveScan(stream, count, start, nbins, scratch);
     boxOrderMoveKernel<<<blocksFor(size_t(ngroups) * kBoxInfoInts, 256), 256, 0, s>>>(info, ngroups, key, start, first, infoOut, broken);
     int bad = 0;

@@ -63,10 +63,6 @@ struct DevLevel {
     int32_t *chunks = nullptr, *planeBlocks = nullptr;  // activity lists
     int edgeChunks = 0, edgePlaneBlocks = 0;            // cut slab levels: the leading entries that touch the planes next to a cut
     BandBoxesDev bandBoxes;  // fused band stage, box form (levels that are not cut into slabs)
-    // up-stroke with the prolongation folded into the sweep (launchProlongJacobi; made on first use): one bit per quad that a
-    // box group stages, and the grid in which those quads receive x + 4 P e
-    uint32_t *nearBand = nullptr;
-    float *stage = nullptr;
     uint8_t *planeFlags = nullptr;  // a byte per block of the plane-marching sweep: on its activity list or not
     int32_t *rzEdges = nullptr;     // launchResidualZ: the blocks without active cells below / above a block with some (planeBlockEdges), made with rz
     int nrzEdges = 0;
@@ -453,13 +449,11 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.halo.groups.neighbours);
         (void)cacheFree(L.bandBoxes.info);
         (void)cacheFree(L.bandBoxes.list);
-        (void)cacheFree(L.nearBand);
         (void)cacheFree(L.planeFlags);
         (void)cacheFree(L.keepBits);
         (void)cacheFree(L.snapTile);
         (void)cacheFree(L.rz);
         (void)cacheFree(L.rzEdges);
-        gridFree(L.stage, L.d);
         (void)cacheFree(L.bandBoxes.general);
     }
     for (int a = 0; a < 3 && !h->weightsBorrowed; ++a) (void)cacheFree(h->w[a]);
@@ -804,46 +798,6 @@ bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float 
            !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
 }
 
-// A zero-start down-stroke that is followed by the residual (every level above the coarsest one) can leave sweep and residual in one
-// pass over the level (launchZeroSweepResidual): 13 instead of 9 + 13 bytes per cell, bit-equal.  OPT-IN (MGPS_FUSE_DOWN=1, levels of
-// at least MGPS_FUSE_DOWN_MIN_CELLS cells): measured, it does not pay -- 512^3 pool MG-PCG 60.0 -> 61.5 ms, 1024^3 pool level 0:
-// 1.36 ms + 0.35 ms for the residual patch against 0.66 + 1.07 ms for the two passes
-bool downStrokeFusesResidual(const mgps_solver *h, int l)
-{
-    static const bool allowed = [] {
-        const char *e = getenv("MGPS_FUSE_DOWN");
-        return e && e[0] == '1';
-    }();
-    static const size_t minCells = [] {
-        const char *e = getenv("MGPS_FUSE_DOWN_MIN_CELLS");
-        return e ? size_t(std::max(0ll, atoll(e))) : size_t(0);
-    }();
-    return allowed && h->lv[l].d.cells() >= minCells;
-}
-// `cur` is the never-cleared iterate grid (see strokeTakesZero): free during the stroke, it takes the closure launch's snapshot
-// -- the level's residual grid, where smoothStroke keeps it, is being written by the one-pass kernel.  On return `cur` holds the
-// smoothed iterate and L.r the residual (MG.cpp:445-547 / 571-660)
-int zeroStrokeWithResidual(mgps_solver *h, int l, float *&cur, float *&other, const float *b)
-{
-    DevLevel &L = h->lv[l];
-    {
-        StageScope scope(h, ST_BAND, l);
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, nullptr, b, nullptr, cur, h->opt.jacobi_weight));
-    }
-    {
-        StageScope scope(h, ST_SMOOTH, l);
-        MGPS_LAUNCH(h, launchZeroSweepResidual(h->stream, L.g, other, L.r, b, h->opt.jacobi_weight));
-    }
-    std::swap(cur, other);
-    {
-        StageScope scope(h, ST_BAND, l);
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, other, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, nullptr, nullptr, true));
-    }
-    StageScope scope(h, ST_RESIDUAL, l);
-    MGPS_LAUNCH(h, launchBoxResidual(h->stream, L.g, L.bandBoxes, cur, b, L.r));
-    return MGPS_OK;
-}
-
 // Residual + restriction of a down-stroke without the residual grid (launchResidualZ + launchRestrictXY): whole-grid fp32 levels
 // that kept their plane blocks (planeZcFor: the liquid fills most of the blocks it touches) and whose x-y planes are 4 MiB or more.
 // Measured on MI355X, separate passes against the pair, ms per cycle: 1024^3 fine level
@@ -890,13 +844,10 @@ int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
 }
 
 // The closure launch and the sweep of a stroke in one launch (launchStrokeFront): whole-grid levels that take the quad sweep, up to
-// MGPS_FRONT_MAX_CELLS cells (default 2^24 = a 256^3 level; 0 = off) -- where a launch is a latency chain, one chain instead of two
+// 2^24 cells (a 256^3 level) -- where a launch is a latency chain, one chain instead of two
 bool strokeFrontMerges(const mgps_solver *h, int l)
 {
-    static const size_t maxCells = [] {
-        const char *e = getenv("MGPS_FRONT_MAX_CELLS");
-        return e ? size_t(std::max(0ll, atoll(e))) : (size_t(1) << 24);
-    }();
+    constexpr size_t maxCells = size_t(1) << 24;
     const DevLevel &L = h->lv[l];
     return !h->dist && L.d.cells() <= maxCells && stencilKernelOf(L.g) == 1 && (L.d.cells() & 31) == 0;  // (512^3 level: 618-629 -> 565-593 cycles/s merged)
 }
@@ -956,7 +907,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             h->dotUsed += unsigned(L.bandBoxes.ngroups);
         }
         if (reps > 0)
-            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sink, cur));
+            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sink, L.r));  // (old values: the snapshot holds every band cell of a flagged tile)
         else
             MGPS_TRY(bandPasses(h, l, cur, b, GHOST_NONE, dot));
         return MGPS_OK;
@@ -1091,33 +1042,6 @@ int poisonSpares(mgps_solver *h, int l, float *a, float *b2)
     return MGPS_OK;
 }
 
-// Up-stroke of level l as "Jacobi(x + 4 P e)" in one pass (launchProlongJacobi) + the two box launches: single-device levels that
-// take the plane-marching sweep and the box form of the band stage, the reference's one Jacobi sweep per stroke
-bool prolongFusable(const mgps_solver *h, int l, const float *cur, const float *other, const float *b)
-{
-    static const bool allowed = [] {  // MGPS_FUSE_PROLONG=1: on (off by default: measured break-even at 1024^3, see prolongJacobiPlaneKernel)
-        const char *e = getenv("MGPS_FUSE_PROLONG");
-        return e && e[0] == '1';
-    }();
-    const DevLevel &L = h->lv[l];
-    return allowed && !h->dist && !h->useGS && h->opt.post_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && prolongJacobiApplies(L.g) &&
-           cur != L.r && other != L.r && b != L.r;
-}
-int ensureProlongFusion(mgps_solver *h, int l)
-{
-    DevLevel &L = h->lv[l];
-    if (L.nearBand) return MGPS_OK;
-    const size_t words = (L.d.cells() / 4 + 31) / 32;
-    MGPS_TRY(devAlloc(h, &L.nearBand, words, true));
-    MGPS_TRY(gridAlloc(h, &L.stage, L.d));
-    MGPS_LAUNCH(h, launchMarkNearBand(h->stream, L.g, L.bandBoxes, L.nearBand));
-    if (L.g.planeBlocks && !L.planeFlags) {
-        MGPS_TRY(devAlloc(h, &L.planeFlags, planeBlockCount(L.g), true));
-        MGPS_LAUNCH(h, launchPlaneBlockFlags(h->stream, L.g, L.planeFlags));
-    }
-    return MGPS_OK;
-}
-
 // levels distLevels .. totalLevels-1 of a slab run: gather the rhs of the collapse level to rank 0,
 // run the rest of the cycle there on the whole grid, scatter the correction back
 int collapsedTail(mgps_solver *h)
@@ -1167,11 +1091,7 @@ int zeroOwnGrid(mgps_solver *h, int l, float *a, bool withGhosts)
 // <x, b> of the result is left in h->resultDev as a by-product of the last stroke (mgps_solver::gatherDot)
 int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool ownGrid, bool wantDot)
 {
-    static const bool gatherAllowed = [] {  // MGPS_GATHER_DOT=0: separate <z, r> reduction (A/B timing)
-        const char *e = getenv("MGPS_GATHER_DOT");
-        return !(e && e[0] == '0');
-    }();
-    h->gatherDot = wantDot && gatherAllowed && !h->dist && h->dotPartials != nullptr;
+    h->gatherDot = wantDot && !h->dist && h->dotPartials != nullptr;
     h->dotUsed = 0;
     const int nlv = int(h->lv.size());
     if (h->tailOfSlabRun && nlv == 1) {  // the tail of a slab run can be the direct solve alone
@@ -1194,9 +1114,7 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
         else MGPS_TRY(zeroGrid(h, x, h->lv[0].d, h->dist));
         fresh = true;
     }
-    bool haveResidual = zero0 && hasBottom && downStrokeFusesResidual(h, 0);  // (level 0's residual came with the stroke)
-    if (haveResidual) MGPS_TRY(zeroStrokeWithResidual(h, 0, cur[0], other[0], b));
-    else MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom, zero0));
+    MGPS_TRY(smoothStroke(h, 0, cur[0], other[0], b, true, fresh, h->gatherDot && !hasBottom, zero0));
     if (hasBottom) {
         const float *rhs = b;
         // options.interrupt is also polled once per level and stroke of a single-device cycle (the reference polls inside
@@ -1212,16 +1130,14 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 const bool zl = strokeTakesZero(h, l, cur[l], other[l], rhs, false);
                 if (!zl) MGPS_TRY(zeroOwnGrid(h, l, F.x, true));  // MG.cpp:566
                 else MGPS_TRY(poisonSpares(h, l, cur[l], other[l]));
-                haveResidual = zl && downStrokeFusesResidual(h, l);
-                if (haveResidual) MGPS_TRY(zeroStrokeWithResidual(h, l, cur[l], other[l], rhs));
-                else MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
+                MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
             }
             bool rExchanged = false;
-            if (!haveResidual && residualRestrictFuses(h, l)) {
+            if (residualRestrictFuses(h, l)) {
                 MGPS_TRY(residualRestrict(h, l, cur[l], rhs));
                 continue;
             }
-            if (!haveResidual) {
+            {
                 StageScope scope(h, ST_RESIDUAL, l);
                 MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
                                                       : h->opt.band_iterations > 0 ? GHOST_BAND
@@ -1251,22 +1167,6 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
             if (stopRequested()) return failH(h, MGPS_ERR_INTERRUPTED, "mgps_apply_vcycle: interrupted");
             const float *rhsUp = l == 0 ? b : F.b;
             bool upSnap = false;
-            if (!(h->gatherDot && l == 0) && prolongFusable(h, l, cur[l], other[l], rhsUp)) {
-                // prolongation + sweep in one pass over the level, then the two band stages as in smoothStroke: the closure launch
-                // reads x + 4 P e where the fused sweep left it for the quads near the band (F.stage)
-                MGPS_TRY(ensureProlongFusion(h, l));
-                {
-                    StageScope scope(h, ST_SMOOTH, l);
-                    GridP gs = F.g;
-                    gs.nbnd = 0;
-                    MGPS_LAUNCH(h, launchProlongJacobi(h->stream, gs, other[l], cur[l], rhsUp, cur[l + 1], h->opt.jacobi_weight, F.nearBand, F.stage, F.planeFlags));
-                }
-                StageScope scope(h, ST_BAND, l);
-                MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, true, F.stage, rhsUp, other[l], F.r, h->opt.jacobi_weight));
-                std::swap(cur[l], other[l]);
-                MGPS_LAUNCH(h, launchBandBox(h->stream, F.g, F.bandBoxes, false, F.r, rhsUp, cur[l], nullptr, h->opt.jacobi_weight));
-                continue;
-            }
             {
                 StageScope scope(h, ST_PROLONG, l);
                 MGPS_TRY(exchangeGhosts(h, l + 1, cur[l + 1]));
@@ -1749,14 +1649,10 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     // Single-device runs keep alpha and beta on the device (launchCgScalars): the reductions leave <p, A p> and
     // <z, r> there, the update and xpay kernels read them, and only |r|^2 -- the convergence test of CG.h:161 -- is
     // fetched: one host round trip per iteration instead of three.  Slab runs sum over ranks through the host.
-    static const bool deviceScalarsAllowed = [] {
-        const char *e = getenv("MGPS_CG_DEVICE_SCALARS");  // 0: the host computes alpha and beta (A/B timing)
-        return !(e && e[0] == '0');
-    }();
     // Slab runs do the same when the transport can all-reduce device doubles on the solver's stream (mgps_comm::
     // allreduce_device: ncclAllReduce for the RCCL transport): every rank's reduction leaves its share on the device, the
     // collective sums it there, the scalar kernel divides.
-    const bool devScal = (!h->dist || h->comm.allreduce_device != nullptr) && deviceScalarsAllowed && !checkGathered;
+    const bool devScal = (!h->dist || h->comm.allreduce_device != nullptr) && !checkGathered;
     double *scal = h->cgScal;
     float *betaDev = reinterpret_cast<float *>(h->cgScal + 4);
     auto sumOverRanks = [&](double *dev) -> int {  // (slab runs: the value a reduction just left on the device, summed in place)
@@ -1780,11 +1676,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
     bool converged = false, rFresh = false;
-    static const int wideReplaceEvery = [] {  // MGPS_WIDE_REPLACE=N (tuning runs): iterations between two residual replacements
-        const char *e = getenv("MGPS_WIDE_REPLACE");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 8;
-    }();
+    constexpr int wideReplaceEvery = 8;  // iterations between two residual replacements (every 4: +2 % time; every 16: one more iteration -- LABNOTES R4)
     for (; it < maxIt; ++it) {
         bool stop = false;
         MGPS_TRY(interruptRequested(h, &stop));
@@ -1832,13 +1724,8 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         }
         if (mixed) {  // z = M r stays in binary16: <z, r> and p = z + beta p read it there (CG.h:168-191)
             const float zScale = std::ldexp(1.f, h->mixExp);
-            if (devScal) {  // <z, r> gathered by the cycle's last stroke (MGPS_GATHER_DOT=0: a separate pass over x~ and r)
-                static const bool gatherMixed = [] {
-                    const char *e = getenv("MGPS_GATHER_DOT");
-                    return !(e && e[0] == '0');
-                }();
-                MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax, gatherMixed ? scal + 3 : nullptr));
-                if (!gatherMixed) MGPS_LAUNCH(h, launchHalfDot(h->stream, F.g, h->mixResult, r, h->mixSigma, zScale, h->partials, scal + 3));
+            if (devScal) {  // <z, r> gathered by the cycle's last stroke
+                MGPS_TRY(vcycleMixed(h, nullptr, r, false, h->mixMax, scal + 3));
                 MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 0));
                 MGPS_LAUNCH(h, launchXpayHalf(h->stream, F.g, p, h->mixResult, h->mixSigma, zScale, betaDev, 0.f));
             } else {
@@ -1886,11 +1773,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
 // sweep (options.stencil_path = 2 still forces the plane kernel).
 int planeZcFor(const mgps_options &o, int planeZc, size_t nplaneBlocks, size_t nchunks, int chunkCells)
 {
-    static const bool envPlane = [] {  // MGPS_STENCIL=plane: the A/B switch of launchStencil
-        const char *e = getenv("MGPS_STENCIL");
-        return e && e[0] == 'p';
-    }();
-    if (!planeZc || o.stencil_path == 2 || envPlane) return planeZc;
+    if (!planeZc || o.stencil_path == 2 || forcedStencilPath() == 2) return planeZc;  // (MGPS_STENCIL=plane: the A/B switch of launchStencil)
     const double planeCost = double(nplaneBlocks) * 256.0 * kPlaneRows * planeZc * 0.92, runCost = double(nchunks) * chunkCells * runCostFactor(chunkCells);
     return planeCost > runCost ? 0 : planeZc;
 }
@@ -1914,7 +1797,7 @@ struct StageClock {
 
 // codesPreloaded: the caller allocated L.codes, copies the labels into it itself and patches the simple cells afterwards
 // The boxes of a level once info / list / general are on the device, whoever built them: the lists compacted
-// (compactBandBoxLists) and the launch order of the groups (orderBandBoxes; MGPS_BOX_ORDER=0 keeps the builders' tile order: A/B)
+// (compactBandBoxLists) and the launch order of the groups (orderBandBoxes)
 int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
 {
     BandBoxesDev &bx = L.bandBoxes;
@@ -1931,14 +1814,14 @@ int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
         bx.list = list2;
         bx.listCount = count2;
     }
-    static const bool ordered = [] {
-        const char *e = getenv("MGPS_BOX_ORDER");
-        return !(e && e[0] == '0');
-    }();
-    if (!ordered || bx.ngroups < 64) return MGPS_OK;  // (fewer groups than a chiplet has in flight)
+    if (bx.ngroups < 64) return MGPS_OK;  // (fewer groups than a chiplet has in flight)
     int32_t *info2 = nullptr;
     MGPS_TRY(devAlloc(h, &info2, size_t(kBoxInfoInts) * size_t(bx.ngroups), false));
     const int e = orderBandBoxes(s, L.d, bx.info, bx.ngroups, info2);
+    if (e == int(hipErrorOutOfMemory) || e == int(hipErrorInvalidValue)) {  // no room for the sort (or a level past its key space): the builders' order stays
+        (void)cacheFree(info2);
+        return MGPS_OK;
+    }
     if (e != 0) {
         (void)cacheFree(info2);
         return failH(h, MGPS_ERR_HIP, std::string("orderBandBoxes: ") + hipGetErrorString(hipError_t(e)));
@@ -2118,9 +2001,12 @@ int buildDeviceInverse(mgps_solver *h)
         }
     }
     static HipSolver *solver = new HipSolver();  // (never unloaded: process tear-down order)
-    if (!solver->ok)
-        return failH(h, MGPS_ERR_COARSE_TOO_LARGE, "coarsest level has " + std::to_string(n) + " unknowns: above " + std::to_string(kHostCoarseMax) +
-                                                       " (or past 4e9 operations for the host's banded factor) the direct solver needs libhipsolver.so, which could not be loaded (raise mg_levels)");
+    if (!solver->ok) {  // no libhipsolver: the host's banded factor after all, slowly, while the level is small enough for it
+        const int rc = hostCoarseFallback(hier);
+        if (rc != MGPS_OK) return failH(h, rc, lastGlobalError());
+        hier->buildDenseInverse();
+        return devUpload(h, &h->cinv, hier->coarseInverse);
+    }
     const int kLower = 122;  // HIPSOLVER_FILL_MODE_LOWER
     double *A = nullptr, *work = nullptr;
     int32_t *index = nullptr, *cells = nullptr;
@@ -2318,10 +2204,7 @@ void pinnedTrim()
 int pickDevice(const mgps_options &o, int *device)
 {
     static std::once_flag once;
-    std::call_once(once, [] {
-        const char *e = getenv("MGPS_PINNED_SETUP");  // 0: pageable set-up arrays (A/B timing)
-        if (!e || e[0] != '0') setHostBigAllocator(pinnedAlloc, pinnedFree);
-    });
+    std::call_once(once, [] { setHostBigAllocator(pinnedAlloc, pinnedFree); });
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return failH(nullptr, MGPS_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
@@ -3247,7 +3130,7 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
     if (o.precision != 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: options.precision = 1 is for single-device solvers");
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
-    StageClock sclock(getenv("MGPS_SETUP_TIMING") != nullptr);
+    StageClock sclock(setupTimingOn());
     mgps_hierarchy *hier = nullptr;
     {  // the rank's window of the hierarchy: labels of every level, band lists around its slab only
         static const bool windowedSetup = [] {  // MGPS_SLAB_WINDOW=0: band lists of the whole grid on every rank (rounds 1-2; A/B)

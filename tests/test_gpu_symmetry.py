@@ -147,62 +147,14 @@ def test_convergence_trace_50_cycles(kind, g, domain_factory, torch_cuda):
     gpu.close()
 
 
-def test_prolongation_folded_into_the_sweep_matches_the_two_passes(torch_cuda):
-    """MGPS_FUSE_PROLONG=1 (opt-in: launchProlongJacobi, the up-stroke's prolongation inside the plane-marching sweep, with
-    the band boxes reading the staged x + 4 P e) against the default path on a grid that takes the plane-marching sweep
-    (1024 x 1024 x 96): three V-cycles, same result to fp32 round-off (the lerp order and the Jacobi formula are the same;
-    the only difference is which kernel evaluates them)."""
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, %r)
-import geometricmultigridpressuresolver_amd as G
-from geometricmultigridpressuresolver_amd import domains as D
-shape = (64, 992, 992)  # build_simple_domain (Test.cpp:466-625) on a box that is not a cube
-bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)
-bl[1:-1, 1:-1, 1:-1] = D.INTERIOR
-bw = []
-for axis in range(3):
-    wa = np.zeros(D.face_shape(*shape, axis), dtype=np.float32)
-    back, fwd = D._shift_pair(bl, axis)
-    wa[D._inner_faces(wa, axis)] = np.where((back == D.INTERIOR) | (fwd == D.INTERIOR), 1.0, 0.0)
-    bw.append(wa)
-dx = 1.0 / 992
-lab, w, off, lev = D.expand_domain(bl, bw, levels=5, solver_shape=(96, 1024, 1024))
-s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
-assert s.stencil_kernel(0) == "plane"
-b = s.to_device(D.random_rhs(lab, dx))
-x = s.new_grid()
-for it in range(3):
-    s.applyVCycle(x, b, it > 0)
-np.save(sys.argv[1], x.cpu().numpy())
-""" % ROOT
-    import tempfile
-
-    outs = []
-    with tempfile.TemporaryDirectory() as tmp:
-        for fuse in ("1", "0"):
-            path = os.path.join(tmp, f"x{fuse}.npy")
-            env = dict(os.environ, MGPS_FUSE_PROLONG=fuse, MGPS_STENCIL="plane")  # (a 4 MiB plane goes to the quad kernel by size since round 3)
-            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
-            outs.append(np.load(path))
-    ref = np.abs(outs[1]).max()
-    assert ref > 0 and np.abs(outs[0] - outs[1]).max() < 2e-6 * ref
-
-
-@pytest.mark.parametrize("switch,case", [("MGPS_FUSE_DOWN", "pool128"), ("MGPS_FUSE_DOWN", "plane992"), ("MGPS_X_RANGE", "pool128"),
-                                         ("MGPS_X_RANGE", "plane880"), ("MGPS_FRONT_MAX_CELLS", "pool128"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"), ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"),
-                                         ("MGPS_POISON_SPARES", "plane992"), ("MGPS_RESTRICT", "cube512"), ("MGPS_FUSE_RR", "cube512"), ("MGPS_FUSE_RR", "plane992"), ("MGPS_FUSE_RR", "rag264"), ("MGPS_FUSE_RR", "wsolid"), ("MGPS_FUSE_RR", "stair"),
-                                         ("MGPS_GS_SNAPSHOT", "plane992gs")])
+@pytest.mark.parametrize("switch,case", [("MGPS_X_RANGE", "pool128"), ("MGPS_X_RANGE", "plane880"), ("MGPS_GS_SNAPSHOT", "pool128gs"), ("MGPS_ZERO_START", "pool128"),
+                                         ("MGPS_ZERO_START", "plane992"), ("MGPS_POISON_SPARES", "pool128"), ("MGPS_POISON_SPARES", "plane992"), ("MGPS_FUSE_RR", "cube512"),
+                                         ("MGPS_FUSE_RR", "plane992"), ("MGPS_FUSE_RR", "rag264"), ("MGPS_FUSE_RR", "wsolid"), ("MGPS_FUSE_RR", "stair"), ("MGPS_GS_SNAPSHOT", "plane992gs")])
 def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, case, switch):
     """Switches that must not change a single bit of the answer, each on against off:
-    MGPS_FUSE_DOWN (opt-in) -- the down-stroke from the zero iterate with the residual in the same pass
-    (launchZeroSweepResidual + launchBoxResidual) against zero-start sweep, band boxes, separate residual pass: the same
-    expressions in the same order;
     MGPS_X_RANGE (default on) -- sweeps leave the quads outside the level's active x range alone (GridP::xlo: the EXTERIOR
     padding of the power-of-two expansion) against visiting whole runs / blocks;
     (plane880: 880 active cells of a 1024-cell row; the sweep must visit fewer cells with the range on.)
-    MGPS_FRONT_MAX_CELLS (default 2^24) -- the closure launch of the band boxes and the sweep of a stroke as ONE launch
-    (launchStrokeFront: the sweep's stores masked on the band closure) on every level against three launches per stroke.
     MGPS_GS_SNAPSHOT (default on; cases ending in "gs" run the tiled Gauss-Seidel smoother) -- the band stages of a Gauss-Seidel
     stroke read a snapshot that the tile kernels / the prolongation left and write the iterate in place (or start from the
     cleared iterate and read nothing) against "out of place, then copy".
@@ -211,11 +163,9 @@ def test_switches_that_only_change_which_bytes_move_are_bit_equal(torch_cuda, ca
     stale grids), which must not reach the result -- the invariant behind the shortcut.
     MGPS_POISON_SPARES (a test hook, off by default) -- NaN in every active cell of the grids a zero-start stroke neither clears
     nor may read, before every such stroke: a stale read would poison the answer; it must stay bit-equal and finite.
-    MGPS_RESTRICT (default: the LDS-tiled march, restrictTileKernel; "march": the register-only march it replaced) -- the same
-    sums in the same order, compared to round-off (not bit for bit: two kernels, two FMA contractions); cube512: the 512^3 cube, whose 256^3 coarse level is large enough to take either.
     MGPS_FUSE_RR (default on) -- the residual of a down-stroke folded along z as it is formed and restricted in x-y from there
     (launchResidualZ + launchRestrictXY; levels without general BOUNDARY cells that have plane blocks) against residual pass +
-    restriction: the same products, added along z first instead of last -- compared to round-off like MGPS_RESTRICT.
+    restriction: the same products, added along z first instead of last -- compared to round-off (cube512: the 512^3 cube).
     Two V-cycles from the zero guess -- every level's down-stroke starts from zero -- and an MG-PCG solve.  pool128: free
     surface with a solid (general BOUNDARY rows, ragged activity lists, quad kernels); plane992 / plane880: a 992 (880) x 992 x 64
     box in a 1024 x 1024 x 96 grid (plane-marching kernels on level 0); rag264: a small box whose grid ends in ragged tiles in every
@@ -290,19 +240,14 @@ np.savez(sys.argv[1], x=x.cpu().numpy(), y=y.cpu().numpy(), z=z.cpu().numpy(), i
     with tempfile.TemporaryDirectory() as tmp:
         for fuse in ("1", "0"):
             path = os.path.join(tmp, f"x{fuse}.npz")
-            value = {"1": "1000000000", "0": "0"}[fuse] if switch == "MGPS_FRONT_MAX_CELLS" else {"1": "tile", "0": "march"}[fuse] if switch == "MGPS_RESTRICT" else fuse
-            env = dict(os.environ, **{switch: value})
-            if switch in ("MGPS_RESTRICT", "MGPS_FUSE_DOWN"):
-                # (the restriction kernels under test run where the residual + restriction pair does not take the level; a fused
-                # down-stroke leaves a residual grid, which the pair -- other order of the sums -- would not restrict)
-                env["MGPS_FUSE_RR"] = "0"
+            env = dict(os.environ, **{switch: fuse})
             if not case.startswith("pool128") and case != "cube512":
                 env["MGPS_STENCIL"] = "plane"  # (by size a 4 MiB plane takes the quad kernel since round 3)
             subprocess.run([sys.executable, "-c", code, path, case], check=True, env=env, timeout=600)
             outs.append(np.load(path))
     assert np.abs(outs[0]["x"]).max() > 0 and all(np.isfinite(outs[0][key]).all() for key in ("x", "y", "z"))
     for key in ("x", "y", "z") + (("u",) if case.endswith("gs") else ()):
-        if switch in ("MGPS_RESTRICT", "MGPS_FUSE_RR"):  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
+        if switch == "MGPS_FUSE_RR":  # (two kernels: the compiler contracts the same sums into different FMAs -- equal to round-off)
             # (z: eight CG iterations preconditioned by cycles that differ in their last bits -- on the free surface with a solid the
             # iterates drift apart like the fp32 recurrence itself does, 2e-4 of the solution)
             tol = 1e-3 if (key == "z" and case == "wsolid") else 2e-6
