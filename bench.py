@@ -350,7 +350,7 @@ def main():
         # the barrier), what the set-up cost and how many exchanges a cycle issues (middle ranks: two neighbours each)
         slab_diag = {"rank_cycle_ms_max": float(t[2]) / args.steps * 1e3, "rank_cycle_ms_min": float(tmin[2]) / args.steps * 1e3,
                      "setup_ms_max": float(t[3]), "setup_ms_min": float(tmin[3]), "exchanges_per_cycle_max": float(t[4]),
-                     "exchanges_per_cycle_min": float(tmin[4]), "overlapped_exchanges_rank0": int(solver.overlapped_exchanges),
+                     "exchanges_per_cycle_min": float(tmin[4]),
                      "distributed_levels": solver.distributed_levels}
 
     cells = float(n) ** 3  # whole job; a rank holds cells / world of them

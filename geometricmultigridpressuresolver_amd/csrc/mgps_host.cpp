@@ -2178,9 +2178,11 @@ int mgps::hierarchyLight(mgps_hierarchy **out, int nx, int ny, int nz, int level
     H->lv.resize(size_t(levels));
     for (int l = 0; l < levels; ++l) H->lv[size_t(l)].d = Dims{nx >> l, ny >> l, nz >> l};
     HostLevel &C = H->lv[size_t(levels - 1)];
-    C.labels.resize(C.d.cells());
-    std::memcpy(C.labels.data(), coarsestLabels, C.d.cells());
-    if (needCoarseSolver) {
+    if (coarsestLabels) {  // (nullptr: a slab rank keeps the extents only)
+        C.labels.resize(C.d.cells());
+        std::memcpy(C.labels.data(), coarsestLabels, C.d.cells());
+    }
+    if (needCoarseSolver && coarsestLabels) {
         // A time-stepping caller builds a solver per sub-step and the coarsest labels rarely change between two of them:
         // the last few factorisations and dense inverses (10 ms of host threads at 14^3 unknowns) are kept by label pattern.
         struct Kept {

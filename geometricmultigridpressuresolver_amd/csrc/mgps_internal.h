@@ -413,6 +413,16 @@ struct HaloSide {
 // itself goes straight from / into the grid as segment 0 of the message (mgps_comm::exchange2)
 int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane, bool withPlane = true);
 int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane, bool withPlane = true);
+// one side of the list part of a cut level's band-stage message (box form): n cells at base + idx[t] (offsets from owned cell 0);
+// buf: 2 n floats.  buf == nullptr: no neighbour on that side
+struct HaloList {
+    float *buf = nullptr;
+    const int32_t *idx = nullptr;
+    int n = 0;
+    ptrdiff_t base = 0;
+};
+int launchHaloListPack(void *stream, const HaloList &lo, const HaloList &hi, const float *a0, const float *a1);      // a1 may be nullptr (one array)
+int launchHaloListUnpack(void *stream, const HaloList &lo, const HaloList &hi, float *a0, float *a1);
 // pure = tiles whose 4096 cells are all INTERIOR; mixed = every other tile with active cells
 // snap / snapTile (optional): the tiles flagged in snapTile (launchMarkSnapTiles) leave a second copy of their result in `snap`
 int launchTiledGS(void *stream, const GridP &g, float *x, const float *b, const int32_t *pureTiles, int npure,
@@ -493,6 +503,18 @@ int deviceAlloc(void **p, size_t bytes);
 int deviceFree(void *p);
 void deviceTrim();
 // ---- device-side set-up (mgps_setup.hip): see the kernels there ------------------------------------------------------
+// Slab runs (round 5): a rank builds a distributed level on a BUFFER of labels -- its owned planes [own0, own1) of the buffer and
+// label ghost planes on both sides -- with the whole-grid kernels; `need` = the planes beyond the owned range in which band masks
+// are still wanted (the tiles farther out are skipped).  nullptr = a whole grid.
+struct SlabWindow {
+    int own0 = 0, own1 = 0, need = 0;
+};
+// the face weights of a level: whole-grid arrays, or (gw > 0) a slab's arrays -- plane k0 of the label buffer is their plane 0 -- with
+// gw planes of the neighbours' weights below (lo) and above (hi); farther out the weights read as 1
+struct WeightView {
+    const float *w[3] = {nullptr, nullptr, nullptr}, *lo[3] = {nullptr, nullptr, nullptr}, *hi[3] = {nullptr, nullptr, nullptr};
+    int nz = 0, gw = 0, k0 = 0;
+};
 int launchCoarsenLabels(void *stream, const Dims &fine, const uint8_t *fineLab, uint8_t *coarseLab, int *activeFlag);
 int launchAnyActive(void *stream, const Dims &d, const uint8_t *lab, int *activeFlag);
 int launchShellCheck(void *stream, const Dims &d, const uint8_t *lab, int *badFlag);
@@ -500,14 +522,29 @@ int launchMarkBoundary(void *stream, const Dims &d, uint8_t *lab);
 size_t scanScratchInts(size_t n);
 int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n, int32_t *scratch);  // out: n + 1 entries
 int launchBandCandidates(void *stream, const Dims &d, const uint8_t *lab, int32_t *tileKind, uint8_t *tileBits, int32_t *flags, int32_t *rank,
-                         int32_t *list, int32_t *scanScratch);  // the tiles that can hold band cells (or need the INTERIOR check)
+                         int32_t *list, int32_t *scanScratch, const SlabWindow *win = nullptr);  // the tiles that can hold band cells (or need the INTERIOR check)
 int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
-                    int *interiorBad, const int32_t *tiles, int ntiles);  // interiorBad (optional): set when an INTERIOR cell has an inactive neighbour
+                    int *interiorBad, const int32_t *tiles, int ntiles, const SlabWindow *win = nullptr);  // interiorBad (optional): set when an INTERIOR cell (of the owned planes) has an inactive neighbour
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band);
 int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                        uint8_t *diagS, int32_t *general, int *violations);
 int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                     const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows);
+// the same two over a slab's label buffer (violations: counted on the owned planes only)
+int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const WeightView &wv, const int32_t *band, int n, uint8_t *diagS, int32_t *general,
+                       int *violations, const SlabWindow *win);
+int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const WeightView &wv, const int32_t *band, int n, const uint8_t *diagS, const int32_t *genRank,
+                    int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows);
+// slab windows: see the end of mgps_setup.hip
+int launchShellCheckSlab(void *stream, const Dims &d, const uint8_t *lab, bool zFaceLo, bool zFaceHi, int *badFlag);
+int launchOwnedFlags(void *stream, const int32_t *band, const int32_t *general, int n, int32_t c0, int32_t c1, int32_t *own, int32_t *ownGen);
+int launchBandSplitOwned(void *stream, const int32_t *band, int n, int32_t c0, const uint8_t *diagS, const int32_t *ownRank, const int32_t *ownGenRank,
+                         const int32_t *genRank, const float *rowsAll, int32_t *bandOut, uint8_t *diagOut, float *rowsOut);
+int launchHaloMark(void *stream, int nx, int ny, int nzOwn, int ghost, const int32_t *info, const uint32_t *list, int ngroups, uint8_t *lo, uint8_t *hi, int *broken);
+int launchAddInt(void *stream, int32_t *out, const int32_t *in, int n, int32_t delta);
+int launchRebaseBoxes(void *stream, int32_t *info, int ngroups, int32_t delta);  // info[0] -= delta for every group
+int launchCheckIndex(void *stream, const int32_t *idx, int n, int32_t limit, int *bad);
+int launchGhostPlaneBlockFlags(void *stream, const Dims &d, const uint8_t *lab, int k, int zc, uint8_t *flags);
 int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out);
 int launchActivityFlags(void *stream, const Dims &d, const uint8_t *lab, uint8_t *chunkFlags, uint8_t *planeFlags, int zc);
 // counts[z] += the runs of kRunSizes[z] cells that hold an active cell (counts zeroed by the caller); then the flags folded
@@ -521,17 +558,18 @@ int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *
 // one Gauss-Seidel tile list (colour parity `odd`, pure or mixed tiles) from the per-tile kinds; the active plane blocks
 // from their flags: list entries ascending, rank[n] = the count
 int launchTileClassList(void *stream, const Dims &d, const int32_t *kind, int odd, int mixed, int32_t *flags, int32_t *rank, int32_t *list,
-                        int32_t *scanScratch);
+                        int32_t *scanScratch, int tkOffset = 0);  // tkOffset (slab windows): global tile plane of the grid's first one (tile colours)
 int launchByteList(void *stream, const uint8_t *bytes, int n, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
 // the boxes of the fused band stage (BandBoxes), built over the list of tiles that can hold a band-closure cell; counts
 // and offsets are indexed by list position
 int launchBoxTileList(void *stream, const Dims &d, const int32_t *tileStart, int32_t *flags, int32_t *rank, int32_t *list, int32_t *scanScratch);
 // counts / at: three arrays each (groups, list entries, general entries)
 int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken);
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken,
+                         const SlabWindow *win = nullptr);
 int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *const at[3],
-                        int32_t *info, uint32_t *list, int32_t *general, int *broken);
+                        int32_t *info, uint32_t *list, int32_t *general, int *broken, const SlabWindow *win = nullptr);
 int launchZero(void *stream, float *a, size_t count);
 int launchZeroInactive(void *stream, const GridP &g, float *a);  // a = 0 on the cells of level g that are not active
 // the same for a grid of level g whose chunks without active cells already hold 0 (solver-owned grids)

@@ -2545,6 +2545,39 @@ int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float
     return int(hipGetLastError());
 }
 
+// The list part of a cut level's band-stage messages (round 5, box form): buf = [a0 at base + idx | a1 at base + idx] for the cells the
+// neighbour's boxes read (pack), and the same back into the deep ghost planes of the grids (unpack).  Both sides in one launch.
+__global__ __launch_bounds__(256) void haloListPackKernel(HaloList lo, HaloList hi, unsigned blocksLo, const float *__restrict__ a0, const float *__restrict__ a1)
+{
+    const bool upper = blockIdx.x >= blocksLo;
+    const HaloList &s = upper ? hi : lo;
+    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x, n = size_t(s.n);
+    if (t < n) s.buf[t] = a0[s.base + s.idx[t]];
+    else if (a1 && t < 2 * n) s.buf[t] = a1[s.base + s.idx[t - n]];
+}
+__global__ __launch_bounds__(256) void haloListUnpackKernel(HaloList lo, HaloList hi, unsigned blocksLo, float *__restrict__ a0, float *__restrict__ a1)
+{
+    const bool upper = blockIdx.x >= blocksLo;
+    const HaloList &s = upper ? hi : lo;
+    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x, n = size_t(s.n);
+    if (t < n) a0[s.base + s.idx[t]] = s.buf[t];
+    else if (a1 && t < 2 * n) a1[s.base + s.idx[t - n]] = s.buf[t];
+}
+int launchHaloListPack(void *stream, const HaloList &lo, const HaloList &hi, const float *a0, const float *a1)
+{
+    const unsigned per = a1 ? 2u : 1u, bl = lo.buf ? blocksFor(size_t(lo.n) * per, 256) : 0, bh = hi.buf ? blocksFor(size_t(hi.n) * per, 256) : 0;
+    if (bl + bh == 0) return 0;
+    haloListPackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, a0, a1);
+    return int(hipGetLastError());
+}
+int launchHaloListUnpack(void *stream, const HaloList &lo, const HaloList &hi, float *a0, float *a1)
+{
+    const unsigned per = a1 ? 2u : 1u, bl = lo.buf ? blocksFor(size_t(lo.n) * per, 256) : 0, bh = hi.buf ? blocksFor(size_t(hi.n) * per, 256) : 0;
+    if (bl + bh == 0) return 0;
+    haloListUnpackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, a0, a1);
+    return int(hipGetLastError());
+}
+
 int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
                     float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb, const float *frows,
                     int foreignBase, int nForeign, double *dotPartials)

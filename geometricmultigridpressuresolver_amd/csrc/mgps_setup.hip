@@ -239,11 +239,17 @@ __global__ __launch_bounds__(64) void tileStatsKernel(Dims d, const uint8_t *__r
 // flags[t] = 1: the tile goes through bandMaskKernel -- a BOUNDARY cell in it or in one of its 26 neighbours can seed band
 // cells in it (band_width - 1 <= 7 cells of reach), or it holds an INTERIOR cell that may touch an inactive one (its own or a
 // face neighbour's: the INTERIOR rule of unitTestBoundaryCells is checked there).  Every other tile has no band cells.
-__global__ __launch_bounds__(256) void tileCandidateKernel(int tx, int ty, int tz, const uint8_t *__restrict__ bits, int32_t *__restrict__ flags)
+// kLo / kHi (slab windows): only tiles that hold a plane of [kLo, kHi) are candidates -- the rest of the label buffer is there for
+// the coarsening only
+__global__ __launch_bounds__(256) void tileCandidateKernel(int tx, int ty, int tz, const uint8_t *__restrict__ bits, int32_t *__restrict__ flags, int kLo, int kHi)
 {
     const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= tx * ty * tz) return;
     const int ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    if (tk * kTile >= kHi || (tk + 1) * kTile <= kLo) {
+        flags[t] = 0;
+        return;
+    }
     bool seed = false, inactive = false;
     for (int dz = -1; dz <= 1; ++dz)
         for (int dy = -1; dy <= 1; ++dy)
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void tileCandidateKernel(int tx, int ty, int t
 // six active neighbours, Ops.h:1771-1870).
 __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__restrict__ lab, int width, int tx, int ty, uint32_t *__restrict__ mask,
                                                       uint16_t *__restrict__ prefix, int32_t *__restrict__ tileCount, int32_t *__restrict__ tileKind,
-                                                      int *__restrict__ interiorBad, const int32_t *__restrict__ tiles)
+                                                      int *__restrict__ interiorBad, const int32_t *__restrict__ tiles, int chk0, int chk1)
 {
     extern __shared__ uint8_t sm[];
     const int halo = max(width - 1, 1), E = kTile + 2 * halo, E2 = E * E, E3 = E2 * E;
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
         unsigned bits = 0;
         int act = 0, inter = 0;
         bool bad = false;
+        const bool chk = interiorBad && tk * kTile + lk >= chk0 && tk * kTile + lk < chk1;  // (slab windows: the rank's own planes only)
 #pragma unroll
         for (int li = 0; li < kTile; ++li) {
             const int c = c0 + li;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256) void bandMaskKernel(Dims d, const uint8_t *__r
             const unsigned v = sl[c];
             act += activeCode(v);
             inter += v == MGPS_INTERIOR_CELL;
-            if (interiorBad && v == MGPS_INTERIOR_CELL)  // (cells past the grid read EXTERIOR: not active)
+            if (chk && v == MGPS_INTERIOR_CELL)  // (cells past the grid read EXTERIOR: not active)
                 bad = bad || !activeCode(sl[c - 1]) || !activeCode(sl[c + 1]) || !activeCode(sl[c - E]) || !activeCode(sl[c + E]) ||
                       !activeCode(sl[c - E2]) || !activeCode(sl[c + E2]);
         }
@@ -409,21 +416,33 @@ struct RowEval {
     float w[6], diag;
     bool simple, ruleOk;
 };
-// the host's rowOf (mgps_host.cpp) / boundaryRowsKernel term by term (Ops.h:208-256); wx == nullptr: unit weights
-__device__ __forceinline__ RowEval evalRow(const Dims &d, const uint8_t *__restrict__ lab, const float *__restrict__ wx, const float *__restrict__ wy,
-                                           const float *__restrict__ wz, size_t c)
+// the host's rowOf (mgps_host.cpp) / boundaryRowsKernel term by term (Ops.h:208-256); wv.w[0] == nullptr: unit weights
+// Slab windows (WeightView::gw > 0): the grid is the rank's label buffer, its plane k is plane k - wv.k0 of the weight arrays,
+// which hold the owned planes; the gw planes below / above them come from the neighbours (wv.lo / wv.hi); farther out the weights
+// read as 1 -- rows there are never used
+__device__ __forceinline__ float faceWeight(const WeightView &wv, int a, int k, size_t inPlane, size_t planeSize, int nplanes)
+{
+    // nplanes: planes the owned array of axis a holds (nz, or nz + 1 for the z faces)
+    if (k >= 0 && k < nplanes) return wv.w[a][size_t(k) * planeSize + inPlane];
+    if (k < 0 && k >= -wv.gw && wv.lo[a]) return wv.lo[a][size_t(k + wv.gw) * planeSize + inPlane];
+    if (k >= nplanes && k < nplanes + wv.gw && wv.hi[a]) return wv.hi[a][size_t(k - nplanes) * planeSize + inPlane];
+    return 1.f;
+}
+__device__ __forceinline__ RowEval evalRow(const Dims &d, const uint8_t *__restrict__ lab, const WeightView &wv, size_t c)
 {
     const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
     const size_t plane = size_t(d.nx) * d.ny;
     float w[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (wx) {
-        const size_t fx = (size_t(k) * d.ny + j) * (d.nx + 1) + i, fy = (size_t(k) * (d.ny + 1) + j) * d.nx + i;
-        w[0] = wx[fx];
-        w[1] = wx[fx + 1];
-        w[2] = wy[fy];
-        w[3] = wy[fy + d.nx];
-        w[4] = wz[c];
-        w[5] = wz[c + plane];
+    if (wv.w[0]) {
+        const int ko = k - wv.k0;
+        const size_t px = size_t(d.nx + 1) * d.ny, py = size_t(d.nx) * (d.ny + 1);
+        const size_t fx = size_t(j) * (d.nx + 1) + i, fy = size_t(j) * d.nx + i, fz = size_t(j) * d.nx + i;
+        w[0] = faceWeight(wv, 0, ko, fx, px, wv.nz);
+        w[1] = faceWeight(wv, 0, ko, fx + 1, px, wv.nz);
+        w[2] = faceWeight(wv, 1, ko, fy, py, wv.nz);
+        w[3] = faceWeight(wv, 1, ko, fy + d.nx, py, wv.nz);
+        w[4] = faceWeight(wv, 2, ko, fz, plane, wv.nz + 1);
+        w[5] = faceWeight(wv, 2, ko + 1, fz, plane, wv.nz + 1);
     }
     const ptrdiff_t off[6] = {-1, 1, -ptrdiff_t(d.nx), ptrdiff_t(d.nx), -ptrdiff_t(plane), ptrdiff_t(plane)};
     RowEval r;
@@ -457,9 +476,9 @@ __device__ __forceinline__ RowEval evalRow(const Dims &d, const uint8_t *__restr
 
 // per entry s of the sorted band list: diagS = 0 for a general BOUNDARY cell, else the diagonal (6 for INTERIOR cells);
 // general[s] = 1 / 0; *violations counts BOUNDARY cells that break the weight half of unitTestBoundaryCells
-__global__ __launch_bounds__(256) void bandClassifyKernel(Dims d, const uint8_t *__restrict__ lab, const float *__restrict__ wx,
-                                                          const float *__restrict__ wy, const float *__restrict__ wz, const int32_t *__restrict__ band,
-                                                          int n, uint8_t *__restrict__ diagS, int32_t *__restrict__ general, int *__restrict__ violations)
+__global__ __launch_bounds__(256) void bandClassifyKernel(Dims d, const uint8_t *__restrict__ lab, WeightView wv, const int32_t *__restrict__ band,
+                                                          int n, uint8_t *__restrict__ diagS, int32_t *__restrict__ general, int *__restrict__ violations,
+                                                          size_t own0, size_t own1)
 {
     const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (s >= n) return;
@@ -467,21 +486,20 @@ __global__ __launch_bounds__(256) void bandClassifyKernel(Dims d, const uint8_t 
     uint8_t dg = 6;
     int gen = 0;
     if (lab[c] >= MGPS_BOUNDARY_CELL) {
-        const RowEval r = evalRow(d, lab, wx, wy, wz, c);
+        const RowEval r = evalRow(d, lab, wv, c);
         if (r.simple) dg = uint8_t(int(r.diag));
         else {
             dg = 0;
             gen = 1;
         }
-        if (!r.ruleOk && violations) atomicAdd(violations, 1);
+        if (!r.ruleOk && violations && c >= own0 && c < own1) atomicAdd(violations, 1);  // (slab windows: every rank answers for its own cells)
     }
     diagS[s] = dg;
     general[s] = gen;
 }
 
 // the device order: entry = rank among the general cells, or nGeneral + rank among the rest
-__global__ __launch_bounds__(256) void bandSplitKernel(Dims d, const uint8_t *__restrict__ lab, const float *__restrict__ wx, const float *__restrict__ wy,
-                                                       const float *__restrict__ wz, const int32_t *__restrict__ band, int n,
+__global__ __launch_bounds__(256) void bandSplitKernel(Dims d, const uint8_t *__restrict__ lab, WeightView wv, const int32_t *__restrict__ band, int n,
                                                        const uint8_t *__restrict__ diagS, const int32_t *__restrict__ genRank, int32_t *__restrict__ bandDev,
                                                        uint8_t *__restrict__ bandDiag, int32_t *__restrict__ bandEntry, float *__restrict__ rows)
 {
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(256) void bandSplitKernel(Dims d, const uint8_t *__
     bandDiag[entry] = diagS[s];
     bandEntry[s] = entry;
     if (gen) {
-        const RowEval r = evalRow(d, lab, wx, wy, wz, size_t(c));
+        const RowEval r = evalRow(d, lab, wv, size_t(c));
 #pragma unroll
         for (int q = 0; q < 6; ++q) rows[size_t(q) * nGen + g] = r.w[q];
         rows[size_t(6) * nGen + g] = r.diag;
@@ -523,12 +541,13 @@ __global__ __launch_bounds__(256) void tileListKernel(const int32_t *__restrict_
 
 // flags[t] = 1 for the tiles of one Gauss-Seidel list: active, of colour parity `odd` ((ti + tj + tk) & 1), pure (all 4096
 // cells INTERIOR, kind bit 0) or mixed; which = 0 pure, 1 mixed (buildTileLists / tileListsFromKinds in mgps_host.cpp)
+// tkOffset (slab windows): the global tile plane of the grid's first tile plane -- the colour of a tile is that of the whole grid
 __global__ __launch_bounds__(256) void tileClassFlagKernel(const int32_t *__restrict__ kind, int n, int tx, int ty, int odd, int mixed,
-                                                           int32_t *__restrict__ flags)
+                                                           int32_t *__restrict__ flags, int tkOffset)
 {
     const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= n) return;
-    const int kd = kind[t], ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty);
+    const int kd = kind[t], ti = t % tx, tj = (t / tx) % ty, tk = t / (tx * ty) + tkOffset;
     flags[t] = ((kd >> 1) != 0 && ((ti + tj + tk) & 1) == odd && ((kd & 1) == 0) == (mixed != 0)) ? 1 : 0;
 }
 // flags of bytes (plane blocks) as ints for the scan
@@ -662,7 +681,8 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
                                                                    int32_t *__restrict__ nList, int32_t *__restrict__ nGeneral,
                                                                    const int32_t *__restrict__ groupAt, const int32_t *__restrict__ listAt,
                                                                    const int32_t *__restrict__ generalAt, int32_t *__restrict__ info,
-                                                                   uint32_t *__restrict__ list, int32_t *__restrict__ general, int *__restrict__ broken)
+                                                                   uint32_t *__restrict__ list, int32_t *__restrict__ general, int *__restrict__ broken,
+                                                                   int own0, int own1)
 {
     extern __shared__ uint8_t sm[];
     const int D = depth, P = depth + 2, E = kTile + 2 * P, E2 = E * E, E3 = E2 * E;
@@ -684,12 +704,15 @@ __global__ __launch_bounds__(kBoxBuildThreads) void boxBuildKernel(Dims d, const
     };
     // the window's labels: EXTERIOR everywhere, then the part inside the grid row by row as aligned 4-byte words
     for (int q = tid; q < (E3 + 3) / 4; q += kBoxBuildThreads) reinterpret_cast<uint32_t *>(fl)[q] = 0x01010101u * MGPS_EXTERIOR_CELL;
-    if (tid == 0) {
-        sp = 1;
+    if (tid == 0) {  // (slab windows: the owned boxes lie in the rank's own planes [own0, own1) of the label buffer)
+        const int zl = max(0, own0 - tk * kTile), zh = min(kTile - 1, own1 - 1 - tk * kTile);
+        sp = zl <= zh ? 1 : 0;
         for (int a = 0; a < 3; ++a) {
             stack[0].lo[a] = 0;
             stack[0].hi[a] = kTile - 1;
         }
+        stack[0].lo[2] = int8_t(max(zl, 0));
+        stack[0].hi[2] = int8_t(min(zh, kTile - 1));
     }
     __syncthreads();
     {
@@ -1026,11 +1049,11 @@ int launchExclusiveScan(void *stream, const int32_t *in, int32_t *out, size_t n,
 
 // tileKind and tileBits of every tile, then flags / rank / list: the tiles that go through the band kernel (rank[nt] = count)
 int launchBandCandidates(void *stream, const Dims &d, const uint8_t *lab, int32_t *tileKind, uint8_t *tileBits, int32_t *flags, int32_t *rank,
-                         int32_t *list, int32_t *scanScratch)
+                         int32_t *list, int32_t *scanScratch, const SlabWindow *win)
 {
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile, nt = tx * ty * tz;
     tileStatsKernel<<<unsigned(ty * tz), 64, 0, S(stream)>>>(d, lab, tx, ty, tileKind, tileBits);
-    tileCandidateKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(tx, ty, tz, tileBits, flags);
+    tileCandidateKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(tx, ty, tz, tileBits, flags, win ? win->own0 - win->need : 0, win ? win->own1 + win->need : d.nz);
     const int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
     if (e != 0) return e;
     tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
@@ -1039,14 +1062,15 @@ int launchBandCandidates(void *stream, const Dims &d, const uint8_t *lab, int32_
 // tiles == nullptr: every tile (and the kernel fills tileKind); else the ntiles listed ones -- mask / prefix / tileCount of
 // the others must have been zeroed, their tileKind set by launchBandCandidates
 int launchBandMasks(void *stream, const Dims &d, const uint8_t *lab, int width, uint32_t *mask, uint16_t *prefix, int32_t *tileCount, int32_t *tileKind,
-                    int *interiorBad, const int32_t *tiles, int ntiles)
+                    int *interiorBad, const int32_t *tiles, int ntiles, const SlabWindow *win)
 {
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
     if (width < 1 || width > 8) return int(hipErrorInvalidValue);
     const int E = kTile + 2 * std::max(width - 1, 1);
     const size_t lds = 2 * size_t(E) * E * E;
     const unsigned nb = tiles ? unsigned(ntiles) : unsigned(tx * ty * tz);
-    if (nb > 0) bandMaskKernel<<<nb, 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind, interiorBad, tiles);
+    if (nb > 0)
+        bandMaskKernel<<<nb, 256, lds, S(stream)>>>(d, lab, width, tx, ty, mask, prefix, tileCount, tileKind, interiorBad, tiles, win ? win->own0 : 0, win ? win->own1 : d.nz);
     return int(hipGetLastError());
 }
 int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart, int32_t *band)
@@ -1055,16 +1079,36 @@ int launchBandFill(void *stream, const Dims &d, const uint32_t *mask, const uint
     bandFillKernel<<<unsigned(tx * ty * tz), 256, 0, S(stream)>>>(d, tx, ty, mask, prefix, tileStart, band);
     return int(hipGetLastError());
 }
+static WeightView wholeGridWeights(const Dims &d, const float *wx, const float *wy, const float *wz)
+{
+    WeightView wv;
+    wv.w[0] = wx, wv.w[1] = wy, wv.w[2] = wz;
+    wv.nz = d.nz;
+    return wv;
+}
 int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                        uint8_t *diagS, int32_t *general, int *violations)
 {
-    if (n > 0) bandClassifyKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wx, wy, wz, band, n, diagS, general, violations);
+    return launchBandClassify(stream, d, lab, wholeGridWeights(d, wx, wy, wz), band, n, diagS, general, violations, nullptr);
+}
+int launchBandClassify(void *stream, const Dims &d, const uint8_t *lab, const WeightView &wv, const int32_t *band, int n, uint8_t *diagS, int32_t *general,
+                       int *violations, const SlabWindow *win)
+{
+    const size_t plane = size_t(d.nx) * d.ny;
+    if (n > 0)
+        bandClassifyKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wv, band, n, diagS, general, violations, win ? size_t(win->own0) * plane : 0,
+                                                                           win ? size_t(win->own1) * plane : d.cells());
     return int(hipGetLastError());
 }
 int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const float *wx, const float *wy, const float *wz, const int32_t *band, int n,
                     const uint8_t *diagS, const int32_t *genRank, int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows)
 {
-    if (n > 0) bandSplitKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wx, wy, wz, band, n, diagS, genRank, bandDev, bandDiag, bandEntry, rows);
+    return launchBandSplit(stream, d, lab, wholeGridWeights(d, wx, wy, wz), band, n, diagS, genRank, bandDev, bandDiag, bandEntry, rows);
+}
+int launchBandSplit(void *stream, const Dims &d, const uint8_t *lab, const WeightView &wv, const int32_t *band, int n, const uint8_t *diagS, const int32_t *genRank,
+                    int32_t *bandDev, uint8_t *bandDiag, int32_t *bandEntry, float *rows)
+{
+    if (n > 0) bandSplitKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(d, lab, wv, band, n, diagS, genRank, bandDev, bandDiag, bandEntry, rows);
     return int(hipGetLastError());
 }
 int launchGather(void *stream, const int32_t *rank, const int32_t *start, int n, int32_t *out)
@@ -1126,10 +1170,10 @@ int launchBandTileList(void *stream, const int32_t *tileStart, int nt, int32_t *
 }
 // list = the tiles t with (kind[t] >> 1) != 0 of one colour and class, ascending; rank[nt] = their number afterwards
 int launchTileClassList(void *stream, const Dims &d, const int32_t *kind, int odd, int mixed, int32_t *flags, int32_t *rank, int32_t *list,
-                        int32_t *scanScratch)
+                        int32_t *scanScratch, int tkOffset)
 {
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile, nt = tx * ty * tz;
-    tileClassFlagKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(kind, nt, tx, ty, odd, mixed, flags);
+    tileClassFlagKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(kind, nt, tx, ty, odd, mixed, flags, tkOffset);
     const int e = launchExclusiveScan(stream, flags, rank, size_t(nt), scanScratch);
     if (e != 0) return e;
     tileListKernel<<<blocksFor(size_t(nt), 256), 256, 0, S(stream)>>>(rank, nt, list);
@@ -1161,23 +1205,25 @@ static size_t boxBuildLds(int depth)
     return 2 * E * E * E + 8;
 }
 int launchBandBoxesCount(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
-                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken)
+                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, int32_t *const counts[3], int *broken,
+                         const SlabWindow *win)
 {
     if (ntiles <= 0) return 0;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
     boxBuildKernel<false><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
                                                                                                 counts[0], counts[1], counts[2], nullptr, nullptr, nullptr, nullptr,
-                                                                                                nullptr, nullptr, broken);
+                                                                                                nullptr, nullptr, broken, win ? win->own0 : 0, win ? win->own1 : d.nz);
     return int(hipGetLastError());
 }
 int launchBandBoxesFill(void *stream, const Dims &d, const uint8_t *lab, const uint32_t *mask, const uint16_t *prefix, const int32_t *tileStart,
                         const int32_t *bandEntry, const uint8_t *bandDiag, int depth, const int32_t *tiles, int ntiles, const int32_t *const at[3],
-                        int32_t *info, uint32_t *list, int32_t *general, int *broken)
+                        int32_t *info, uint32_t *list, int32_t *general, int *broken, const SlabWindow *win)
 {
     if (ntiles <= 0) return 0;
     const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile;
     boxBuildKernel<true><<<unsigned(ntiles), kBoxBuildThreads, boxBuildLds(depth), S(stream)>>>(d, lab, tx, ty, mask, prefix, tileStart, bandEntry, bandDiag, depth, tiles,
-                                                                                               nullptr, nullptr, nullptr, at[0], at[1], at[2], info, list, general, broken);
+                                                                                               nullptr, nullptr, nullptr, at[0], at[1], at[2], info, list, general, broken,
+                                                                                               win ? win->own0 : 0, win ? win->own1 : d.nz);
     return int(hipGetLastError());
 }
 
@@ -1375,6 +1421,176 @@ int compactBandBoxLists(void *stream, int32_t *info, const uint32_t *list, int n
     release();
     *newCount = size_t(std::max(total, 0));
     return rc;
+}
+
+
+// ---- slab windows (round 5): a rank of a Z-slab run builds its levels on the device -----------------------------------------
+// The rank holds a BUFFER of labels per distributed level: its owned planes [own0, own1) and label ghost planes on both sides
+// (real labels as far as the band masks and the band boxes of the owned planes reach, EXTERIOR beyond).  The kernels above build
+// band masks, band list, rows and boxes on that buffer as if it were a whole grid; what follows cuts the rank's own lists out of
+// them and finds the cells of the neighbours' planes its boxes read.
+namespace {
+
+// the x / y faces of the rank's planes and, where the rank holds the first / last plane of the grid, that plane: flags[0] = 1 when
+// a cell there is not EXTERIOR (shellCheckKernel for a slab: the ranks' verdicts are OR-ed by the caller)
+__global__ __launch_bounds__(256) void shellCheckSlabKernel(Dims d, const uint8_t *__restrict__ lab, int zFaceLo, int zFaceHi, int *__restrict__ flags)
+{
+    const size_t fz = size_t(d.nx) * d.ny, fy = size_t(d.nx) * d.nz, fx = size_t(d.ny) * d.nz;
+    size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    int i, j, k;
+    if (t < 2 * fz) {
+        const bool low = t < fz;
+        if ((low && !zFaceLo) || (!low && !zFaceHi)) return;
+        k = low ? 0 : d.nz - 1;
+        t %= fz;
+        i = int(t % d.nx);
+        j = int(t / d.nx);
+    } else if (t < 2 * fz + 2 * fy) {
+        t -= 2 * fz;
+        j = t < fy ? 0 : d.ny - 1;
+        t %= fy;
+        i = int(t % d.nx);
+        k = int(t / d.nx);
+    } else if (t < 2 * fz + 2 * fy + 2 * fx) {
+        t -= 2 * fz + 2 * fy;
+        i = t < fx ? 0 : d.nx - 1;
+        t %= fx;
+        j = int(t % d.ny);
+        k = int(t / d.ny);
+    } else
+        return;
+    if (lab[cellIdx(d, i, j, k)] != MGPS_EXTERIOR_CELL) flags[0] = 1;
+}
+
+// per entry s of the sorted band list of the buffer: own[s] = the cell lies in the rank's planes, ownGen[s] = ... and is a general cell
+__global__ __launch_bounds__(256) void ownedFlagsKernel(const int32_t *__restrict__ band, const int32_t *__restrict__ general, int n, int32_t c0, int32_t c1,
+                                                        int32_t *__restrict__ own, int32_t *__restrict__ ownGen)
+{
+    const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= n) return;
+    const int32_t c = band[s];
+    const int in = (c >= c0 && c < c1) ? 1 : 0;
+    own[s] = in;
+    ownGen[s] = in && general[s] ? 1 : 0;
+}
+// the rank's own band list in the device order (general cells first, each class in the buffer's order), cells as offsets from owned
+// cell 0; the rows of its general cells copied from the buffer's (SoA, 7 x nGenOwn)
+__global__ __launch_bounds__(256) void bandSplitOwnedKernel(const int32_t *__restrict__ band, int n, int32_t c0, const uint8_t *__restrict__ diagS,
+                                                            const int32_t *__restrict__ ownRank, const int32_t *__restrict__ ownGenRank,
+                                                            const int32_t *__restrict__ genRank, const float *__restrict__ rowsAll,
+                                                            int32_t *__restrict__ bandOut, uint8_t *__restrict__ diagOut, float *__restrict__ rowsOut)
+{
+    const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= n || ownRank[s + 1] == ownRank[s]) return;
+    const int nGenOwn = ownGenRank[n], nGenAll = genRank[n], g = ownGenRank[s];
+    const bool gen = ownGenRank[s + 1] != g;
+    const int entry = gen ? g : nGenOwn + (ownRank[s] - g);
+    bandOut[entry] = band[s] - c0;
+    diagOut[entry] = diagS[s];
+    if (gen) {
+        const int ga = genRank[s];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) rowsOut[size_t(q) * nGenOwn + g] = rowsAll[size_t(q) * nGenAll + ga];
+    }
+}
+
+// The cells of the neighbours' planes the rank's boxes read (closure mode: every list entry): a byte per cell of the `ghost`
+// planes below (lo) and above (hi) the owned planes.  info[0] is the region's origin as an offset from owned cell 0 (rebased).
+// broken: an entry beyond the ghost planes (cannot happen: a region reaches depth + 1 planes past its owned box)
+__global__ __launch_bounds__(256) void haloMarkKernel(int nx, int ny, int nzOwn, int ghost, const int32_t *__restrict__ info, const uint32_t *__restrict__ list,
+                                                      uint8_t *__restrict__ lo, uint8_t *__restrict__ hi, int *__restrict__ broken)
+{
+    const int32_t *gi = info + kBoxInfoInts * size_t(blockIdx.x);
+    const ptrdiff_t sy = nx, sz = ptrdiff_t(nx) * ny, origin = gi[0], top = ptrdiff_t(nzOwn) * sz;
+    const uint32_t *U = list + gi[2];
+    for (int k = threadIdx.x; k < gi[7]; k += 256) {
+        const uint32_t e = U[k];
+        const ptrdiff_t c = origin + ptrdiff_t(e & 31u) + ptrdiff_t((e >> 5) & 31u) * sy + ptrdiff_t((e >> 10) & 31u) * sz;
+        if (c < 0) {
+            if (c < -ptrdiff_t(ghost) * sz) *broken = 1;
+            else lo[c + ptrdiff_t(ghost) * sz] = 1;
+        } else if (c >= top) {
+            if (c >= top + ptrdiff_t(ghost) * sz) *broken = 1;
+            else hi[c - top] = 1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void addIntKernel(int32_t *__restrict__ out, const int32_t *__restrict__ in, int n, int32_t delta)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) out[t] = in[t] + delta;
+}
+__global__ __launch_bounds__(256) void rebaseBoxesKernel(int32_t *__restrict__ info, int n, int32_t delta)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n) info[kBoxInfoInts * size_t(t)] -= delta;
+}
+// *bad = 1 when an index lies outside [0, limit)
+__global__ __launch_bounds__(256) void checkIndexKernel(const int32_t *__restrict__ idx, int n, int32_t limit, int *__restrict__ bad)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t < n && (idx[t] < 0 || idx[t] >= limit)) *bad = 1;
+}
+// a byte per block of the plane-marching sweep (256 x kPlaneRows x zc): set where plane k of the grid (a ghost plane: -1 or nz, clamped
+// into the first / last layer of blocks) holds an active cell -- the residual + restriction pair of a cut level visits such blocks too
+__global__ __launch_bounds__(256) void ghostPlaneBlockFlagsKernel(Dims d, const uint8_t *__restrict__ lab, int k, int zc, int nbx, int nby, uint8_t *__restrict__ flags)
+{
+    const size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x, nq = size_t(d.nx) * d.ny / 4;
+    if (q >= nq) return;
+    const ptrdiff_t sz = ptrdiff_t(d.nx) * d.ny;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(lab + ptrdiff_t(k) * sz + ptrdiff_t(q) * 4);
+    if (!(activeCode(v & 0xffu) || activeCode((v >> 8) & 0xffu) || activeCode((v >> 16) & 0xffu) || activeCode(v >> 24))) return;
+    const size_t c = q * 4;
+    const int i = int(c % d.nx), j = int(c / d.nx), kb = min(max(k, 0), d.nz - 1) / zc;
+    flags[(size_t(kb) * nby + j / kPlaneRows) * nbx + i / 256] = 1;
+}
+
+}  // namespace
+
+int launchShellCheckSlab(void *stream, const Dims &d, const uint8_t *lab, bool zFaceLo, bool zFaceHi, int *badFlag)
+{
+    const size_t n = 2 * (size_t(d.nx) * d.ny + size_t(d.nx) * d.nz + size_t(d.ny) * d.nz);
+    shellCheckSlabKernel<<<blocksFor(n, 256), 256, 0, S(stream)>>>(d, lab, zFaceLo ? 1 : 0, zFaceHi ? 1 : 0, badFlag);
+    return int(hipGetLastError());
+}
+int launchOwnedFlags(void *stream, const int32_t *band, const int32_t *general, int n, int32_t c0, int32_t c1, int32_t *own, int32_t *ownGen)
+{
+    if (n > 0) ownedFlagsKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(band, general, n, c0, c1, own, ownGen);
+    return int(hipGetLastError());
+}
+int launchBandSplitOwned(void *stream, const int32_t *band, int n, int32_t c0, const uint8_t *diagS, const int32_t *ownRank, const int32_t *ownGenRank,
+                         const int32_t *genRank, const float *rowsAll, int32_t *bandOut, uint8_t *diagOut, float *rowsOut)
+{
+    if (n > 0)
+        bandSplitOwnedKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(band, n, c0, diagS, ownRank, ownGenRank, genRank, rowsAll, bandOut, diagOut, rowsOut);
+    return int(hipGetLastError());
+}
+int launchHaloMark(void *stream, int nx, int ny, int nzOwn, int ghost, const int32_t *info, const uint32_t *list, int ngroups, uint8_t *lo, uint8_t *hi, int *broken)
+{
+    if (ngroups > 0) haloMarkKernel<<<unsigned(ngroups), 256, 0, S(stream)>>>(nx, ny, nzOwn, ghost, info, list, lo, hi, broken);
+    return int(hipGetLastError());
+}
+int launchAddInt(void *stream, int32_t *out, const int32_t *in, int n, int32_t delta)
+{
+    if (n > 0) addIntKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(out, in, n, delta);
+    return int(hipGetLastError());
+}
+int launchRebaseBoxes(void *stream, int32_t *info, int ngroups, int32_t delta)
+{
+    if (ngroups > 0) rebaseBoxesKernel<<<blocksFor(size_t(ngroups), 256), 256, 0, S(stream)>>>(info, ngroups, delta);
+    return int(hipGetLastError());
+}
+int launchCheckIndex(void *stream, const int32_t *idx, int n, int32_t limit, int *bad)
+{
+    if (n > 0) checkIndexKernel<<<blocksFor(size_t(n), 256), 256, 0, S(stream)>>>(idx, n, limit, bad);
+    return int(hipGetLastError());
+}
+int launchGhostPlaneBlockFlags(void *stream, const Dims &d, const uint8_t *lab, int k, int zc, uint8_t *flags)
+{
+    if ((d.nx & 3) != 0 || zc <= 0) return 0;
+    const int nbx = (d.nx + 255) / 256, nby = (d.ny + kPlaneRows - 1) / kPlaneRows;
+    ghostPlaneBlockFlagsKernel<<<blocksFor(size_t(d.nx) * d.ny / 4, 256), 256, 0, S(stream)>>>(d, lab, k, zc, nbx, nby, flags);
+    return int(hipGetLastError());
 }
 
 }  // namespace mgps

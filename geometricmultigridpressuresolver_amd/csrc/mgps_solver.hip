@@ -69,20 +69,21 @@ struct DevLevel {
     float *rz = nullptr;            // the residual folded along z (residualRestrictFuses; nx x ny x nz / 2, made on first use, zero where nothing writes)
     uint8_t *snapTile = nullptr;    // Gauss-Seidel strokes: a byte per 16^3 tile, set where a box group reads (launchMarkSnapTiles; made on first use)
     uint32_t *keepBits = nullptr;   // launchStrokeFront: one bit per cell, the owned band / closure-output cells of the boxes (made on first use)
-    // fused band stage of a cut level (SlabHalo): one exchange per stage
-    struct Halo {
-        int depth = 0;
-        int32_t *sendIdx[2] = {nullptr, nullptr};
+    // A cut level of a slab run built on the device (round 5): the box form of the band stage with the neighbours' cells its
+    // regions read kept in the deep ghost planes of the grids (mgps_solver::ghost planes on either side of every grid).  recvIdx:
+    // those cells, offsets into the ghost planes below [0] / above [1] the owned planes (ascending); sendIdx: the cells of this
+    // rank's planes the lower [0] / upper [1] neighbour asked for at set-up (offsets from owned cell 0).  A stage message is the
+    // boundary plane straight from the grid plus the packed lists (x and rhs: closure launch; snapshot: plain launch).
+    struct BoxHalo {
+        int32_t *sendIdx[2] = {nullptr, nullptr}, *recvIdx[2] = {nullptr, nullptr};
         int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
         float *sendBuf[2] = {nullptr, nullptr}, *recvBuf[2] = {nullptr, nullptr};
-        float *hx = nullptr, *hb = nullptr;
-        int32_t *bandExt = nullptr;
-        int nbandExt = 0;
-        float *tmpExt = nullptr;
-        float *frows = nullptr;  // rows of the neighbours' band cells near the cuts (levels with general cells)
-        int nForeign = 0;
-        BandGroupsDev groups;
     } halo;
+    bool boxForm = false;      // cut level: every rank runs the box protocol on this level (agreed at set-up)
+    bool hasBandPlanes = false;  // host-built slab levels: packed band cells of the planes at the cuts (GHOST_BAND exchanges)
+    GridP gBox{};              // the level as the box launches of a cut level see it: rows of the general cells of the whole label buffer
+    float *extRows = nullptr;
+    int elo = 0;               // label ghost planes below owned plane 0 in the level's label buffer (codes allocation: spare plane | buffer | spare plane)
 };
 
 }  // namespace
@@ -124,15 +125,13 @@ struct mgps_solver {
     int mixExp = 0;
     double *mixMax = nullptr;   // max |r| left by the CG update pass: the next preconditioning cycle's normalisation
     void *mixResult = nullptr;  // the binary16 grid that holds the last cycle's result (scale 2^mixExp / *mixSigma)
-    std::vector<void *> userGrids;  // allocation bases handed out by mgps_grid_alloc (ghost plane first)
+    std::vector<void *> userGrids;  // allocation bases handed out by mgps_grid_alloc (ghost planes first)
+    // planes every grid of this solver carries below and above its owned planes: 1 (the ghost plane of a slab run; spare otherwise),
+    // kSlabGhostPlanes on slab ranks set up on the device (the neighbours' cells their band boxes read live there)
+    int ghost = 1;
     // slab run
     bool dist = false;
     mgps_comm comm{};
-    // slab runs, MGPS_OVERLAP=1: the exchanges that follow a full-domain sweep run on their own stream while the sweep's interior
-    // part is still under way (edgeFirst in mgps_host.cpp); otherwise everything stays on the solver's stream
-    hipStream_t commStream = nullptr;
-    hipEvent_t evEdge = nullptr, evComm = nullptr;
-    int64_t overlappedExchanges = 0;
     int64_t exchanges = 0;         // ghost / stage exchanges issued so far (mgps_exchange_count: the bench line's exchanges_per_cycle)
     std::vector<int> splits;       // slab run: rank r owns the fine planes [splits[r], splits[r + 1])
     int distLevels = 0;            // levels 0 .. distLevels-1 are distributed, lv[distLevels] is the collapse level
@@ -391,18 +390,18 @@ int devUpload(mgps_solver *h, T **p, const std::vector<T, A> &v)
     return MGPS_OK;
 }
 
-// a grid of d.nz owned planes with a zeroed ghost plane on each side; *p addresses owned plane 0
+// a grid of d.nz owned planes with h->ghost zeroed ghost planes on each side; *p addresses owned plane 0
 int gridAlloc(mgps_solver *h, float **p, const Dims &d)
 {
     const size_t plane = size_t(d.nx) * d.ny;
     float *base = nullptr;
-    MGPS_TRY(devAlloc(h, &base, (size_t(d.nz) + 2) * plane, true));
-    *p = base + plane;
+    MGPS_TRY(devAlloc(h, &base, (size_t(d.nz) + 2 * size_t(h->ghost)) * plane, true));
+    *p = base + size_t(h->ghost) * plane;
     return MGPS_OK;
 }
-void gridFree(float *p, const Dims &d)
+void gridFree(const mgps_solver *h, float *p, const Dims &d)
 {
-    if (p) (void)cacheFree(p - size_t(d.nx) * d.ny);
+    if (p) (void)cacheFree(p - size_t(h->ghost) * size_t(d.nx) * d.ny);
 }
 
 void freeAll(mgps_solver *h)
@@ -413,10 +412,10 @@ void freeAll(mgps_solver *h)
     if (h->tail) freeAll(h->tail);
     for (auto &L : h->lv) {
         (void)cacheFree(L.codes);
-        gridFree(L.x, L.d);
-        gridFree(L.b, L.d);
-        gridFree(L.r, L.d);
-        gridFree(L.tmp, L.d);
+        gridFree(h, L.x, L.d);
+        gridFree(h, L.b, L.d);
+        gridFree(h, L.r, L.d);
+        gridFree(h, L.tmp, L.d);
         (void)cacheFree(L.band);
         (void)cacheFree(L.bandTmp);
         (void)cacheFree(L.rows);
@@ -434,19 +433,11 @@ void freeAll(mgps_solver *h)
         (void)cacheFree(L.planeBlocks);
         for (int q = 0; q < 2; ++q) {
             (void)cacheFree(L.halo.sendIdx[q]);
+            (void)cacheFree(L.halo.recvIdx[q]);
             (void)cacheFree(L.halo.sendBuf[q]);
             (void)cacheFree(L.halo.recvBuf[q]);
         }
-        (void)cacheFree(L.halo.hx);
-        (void)cacheFree(L.halo.hb);
-        (void)cacheFree(L.halo.bandExt);
-        (void)cacheFree(L.halo.tmpExt);
-        (void)cacheFree(L.halo.frows);
-        (void)cacheFree(L.halo.groups.info);
-        (void)cacheFree(L.halo.groups.updateEntry);
-        (void)cacheFree(L.halo.groups.updateCell);
-        (void)cacheFree(L.halo.groups.readCell);
-        (void)cacheFree(L.halo.groups.neighbours);
+        (void)cacheFree(L.extRows);
         (void)cacheFree(L.bandBoxes.info);
         (void)cacheFree(L.bandBoxes.list);
         (void)cacheFree(L.planeFlags);
@@ -473,13 +464,10 @@ void freeAll(mgps_solver *h)
         if (g64) (void)cacheFree(g64 - size_t(h->lv[0].d.nx) * h->lv[0].d.ny);
     if (h->resultHost) (void)hipHostFree(h->resultHost);
     if (!h->lv.empty()) {
-        for (int q = 0; q < 4; ++q) gridFree(h->pcg[q], h->lv[0].d);
-        gridFree(h->dinv, h->lv[0].d);
+        for (int q = 0; q < 4; ++q) gridFree(h, h->pcg[q], h->lv[0].d);
+        gridFree(h, h->dinv, h->lv[0].d);
     }
     for (void *p : h->userGrids) (void)cacheFree(p);
-    if (h->evEdge) (void)hipEventDestroy(h->evEdge);
-    if (h->evComm) (void)hipEventDestroy(h->evComm);
-    if (h->commStream) (void)hipStreamDestroy(h->commStream);
     for (hipEvent_t e : h->profEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->stageEvents) (void)hipEventDestroy(e);
     mgps_hierarchy_destroy(h->hier);
@@ -510,6 +498,7 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL,
     DevLevel &L = h->lv[l];
     const size_t plane = size_t(L.d.nx) * L.d.ny;
     const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
+    if (mode == GHOST_BAND && !L.hasBandPlanes) mode = GHOST_FULL;  // (levels built on the device keep no packed lists of the cut planes' band cells)
     if (mode == GHOST_FULL) {
         const size_t bytes = plane * sizeof(float);
         ++h->exchanges;
@@ -533,81 +522,71 @@ int exchangeGhosts(mgps_solver *h, int l, float *a, GhostMode mode = GHOST_FULL,
 
 // ---- level operators -----------------------------------------------------------------------------
 
-// The band stage of a cut level in one exchange (SlabHalo): ghost plane + band closure of the next planes,
-// x and rhs, in one message per neighbour; then every rank runs the fused stage over its band and the band
-// cells of its ghost planes.  Leaves the ghost planes of x complete.
-int bandStageDeep(mgps_solver *h, int l, float *x, const float *b, hipStream_t on = nullptr)
+// The list part of a cut level's band-stage messages (DevLevel::BoxHalo): a0 (and a1) at the cells the neighbours' boxes read,
+// packed, exchanged, and put into the deep ghost planes of the same grids on the other side.  withPlane: the boundary plane of a0
+// travels with it, straight from the grid into the neighbour's ghost plane (mgps_comm::exchange2; without that entry: a plane
+// exchange of its own first).  One message per neighbour.
+int haloListExchange(mgps_solver *h, int l, float *a0, float *a1, bool withPlane)
 {
     DevLevel &L = h->lv[l];
-    DevLevel::Halo &H = L.halo;
-    const size_t plane = size_t(L.d.nx) * L.d.ny;
+    DevLevel::BoxHalo &H = L.halo;
+    const size_t plane = size_t(L.d.nx) * L.d.ny, G = size_t(h->ghost);
     const bool lo = h->comm.rank > 0, hi = h->comm.rank < h->comm.size - 1;
-    // bandPlane: [0] my plane 0, [1] ghost plane below, [2] my top plane, [3] ghost plane above (band cells, same order both sides)
-    const int *nbp = L.nbandPlane;
-    const size_t bytes[2] = {(plane + 2 * size_t(H.nsend[0]) + size_t(nbp[0])) * sizeof(float),
-                             (plane + 2 * size_t(H.nsend[1]) + size_t(nbp[2])) * sizeof(float)};
-    const size_t rbytes[2] = {(plane + 2 * size_t(H.nrecv[0]) + size_t(nbp[1])) * sizeof(float),
-                              (plane + 2 * size_t(H.nrecv[1]) + size_t(nbp[3])) * sizeof(float)};
-    float *bw = const_cast<float *>(b);  // only the ghost planes are written: solver scratch by contract (mgps_grid_alloc)
-    HaloSide sLo, sHi, rLo, rHi;  // send / receive descriptions of the two sides
+    if (!lo && !hi) return MGPS_OK;
+    const size_t per = a1 ? 2 : 1;
+    HaloList sLo, sHi, rLo, rHi;
     if (lo) {
-        sLo = HaloSide{H.sendBuf[0], 0, H.sendIdx[0], H.nsend[0], L.bandPlane[0], nbp[0], nullptr, nullptr};
-        rLo = HaloSide{H.recvBuf[0], -ptrdiff_t(plane), nullptr, H.nrecv[0], L.bandPlane[1], nbp[1], H.hx, H.hb};
+        sLo = HaloList{H.sendBuf[0], H.sendIdx[0], H.nsend[0], 0};
+        rLo = HaloList{H.recvBuf[0], H.recvIdx[0], H.nrecv[0], -ptrdiff_t(G * plane)};
     }
     if (hi) {
-        sHi = HaloSide{H.sendBuf[1], ptrdiff_t((size_t(L.d.nz) - 1) * plane), H.sendIdx[1], H.nsend[1], L.bandPlane[2], nbp[2], nullptr, nullptr};
-        rHi = HaloSide{H.recvBuf[1], ptrdiff_t(size_t(L.d.nz) * plane), nullptr, H.nrecv[1], L.bandPlane[3], nbp[3], H.hx + H.nrecv[0],
-                       H.hb + H.nrecv[0]};
+        sHi = HaloList{H.sendBuf[1], H.sendIdx[1], H.nsend[1], 0};
+        rHi = HaloList{H.recvBuf[1], H.recvIdx[1], H.nrecv[1], ptrdiff_t(size_t(L.d.nz) * plane)};
     }
-    // the message (pack, transfer, unpack) on `on` -- the solver's stream, or the transfer stream of an overlapped sweep: then
-    // the fused stage on the solver's stream waits for it
-    hipStream_t cs = on ? on : h->stream;
+    MGPS_LAUNCH(h, launchHaloListPack(h->stream, sLo, sHi, a0, a1));
+    const size_t pb = plane * sizeof(float);
+    const size_t sb[2] = {size_t(H.nsend[0]) * per * sizeof(float), size_t(H.nsend[1]) * per * sizeof(float)};
+    const size_t rb[2] = {size_t(H.nrecv[0]) * per * sizeof(float), size_t(H.nrecv[1]) * per * sizeof(float)};
     ++h->exchanges;
-    if (h->comm.exchange2) {  // the boundary plane straight from the grid into the neighbour's ghost plane, the packed lists behind it
-        MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane, false));
-        const size_t pb = plane * sizeof(float);
-        mgps_xfer2 seg[4];  // send lo, recv lo, send hi, recv hi
+    if (withPlane && h->comm.exchange2) {
+        mgps_xfer2 seg[4];  // send lo, recv lo, send hi, recv hi: [plane | lists]
         if (lo) {
-            seg[0] = mgps_xfer2{{x, H.sendBuf[0] + plane}, {pb, bytes[0] - pb}};
-            seg[1] = mgps_xfer2{{x - plane, H.recvBuf[0] + plane}, {pb, rbytes[0] - pb}};
+            seg[0] = mgps_xfer2{{a0, H.sendBuf[0]}, {pb, sb[0]}};
+            seg[1] = mgps_xfer2{{a0 - plane, H.recvBuf[0]}, {pb, rb[0]}};
         }
         if (hi) {
-            seg[2] = mgps_xfer2{{x + (size_t(L.d.nz) - 1) * plane, H.sendBuf[1] + plane}, {pb, bytes[1] - pb}};
-            seg[3] = mgps_xfer2{{x + size_t(L.d.nz) * plane, H.recvBuf[1] + plane}, {pb, rbytes[1] - pb}};
+            seg[2] = mgps_xfer2{{a0 + (size_t(L.d.nz) - 1) * plane, H.sendBuf[1]}, {pb, sb[1]}};
+            seg[3] = mgps_xfer2{{a0 + size_t(L.d.nz) * plane, H.recvBuf[1]}, {pb, rb[1]}};
         }
-        MGPS_COMM(h, h->comm.exchange2(h->comm.user, lo ? &seg[0] : nullptr, lo ? &seg[1] : nullptr, hi ? &seg[2] : nullptr, hi ? &seg[3] : nullptr, cs));
-        MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane, false));
+        MGPS_COMM(h, h->comm.exchange2(h->comm.user, lo ? &seg[0] : nullptr, lo ? &seg[1] : nullptr, hi ? &seg[2] : nullptr, hi ? &seg[3] : nullptr, h->stream));
     } else {
-        MGPS_LAUNCH(h, launchHaloPack(cs, sLo, sHi, x, b, plane));
-        MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, bytes[0], lo ? H.recvBuf[0] : nullptr, rbytes[0],
-                                      hi ? H.sendBuf[1] : nullptr, bytes[1], hi ? H.recvBuf[1] : nullptr, rbytes[1], cs));
-        MGPS_LAUNCH(h, launchHaloUnpack(cs, rLo, rHi, x, bw, plane));
+        if (withPlane) MGPS_TRY(exchangeGhosts(h, l, a0, GHOST_FULL));
+        MGPS_COMM(h, h->comm.exchange(h->comm.user, lo ? H.sendBuf[0] : nullptr, sb[0], lo ? H.recvBuf[0] : nullptr, rb[0], hi ? H.sendBuf[1] : nullptr, sb[1],
+                                      hi ? H.recvBuf[1] : nullptr, rb[1], h->stream));
     }
-    if (on) {
-        MGPS_HIP(h, hipEventRecord(h->evComm, on));
-        MGPS_HIP(h, hipStreamWaitEvent(h->stream, h->evComm, 0));
-    }
-    MGPS_LAUNCH(h, launchBandFused(h->stream, L.g, x, b, H.bandExt, H.nbandExt, H.tmpExt, h->opt.jacobi_weight, H.groups, H.hx, H.hb,
-                                   H.frows, L.nband, H.nForeign));
+    MGPS_LAUNCH(h, launchHaloListUnpack(h->stream, rLo, rHi, a0, a1));
     return MGPS_OK;
 }
 
-// true: bandPasses leaves the ghost planes of x complete (nothing to exchange before the next operator)
-bool bandStageCompletesGhosts(const mgps_solver *h, int l)
-{
-    return h->dist && h->lv[l].halo.depth > 0 && h->lv[l].halo.depth == h->opt.band_iterations;
-}
+// true: the band stage of level l leaves the ghost planes of x complete (never since round 5: the box form of a cut level exchanges
+// the planes the next operator reads when it needs them)
+bool bandStageCompletesGhosts(const mgps_solver *, int) { return false; }
 
 // the level runs the box form of the fused band stage (BandBoxes: whole-grid levels, options.fuse_band_passes)
-bool levelHasBoxes(const mgps_solver *h, int l) { return h->lv[l].bandBoxes.ngroups > 0 && h->lv[l].bandBoxes.depth == h->opt.band_iterations; }
+// (a cut level of a slab run: every rank runs the box protocol, also a rank whose planes hold no band cell)
+bool levelHasBoxes(const mgps_solver *h, int l)
+{
+    if (h->lv[l].boxForm) return true;
+    return h->lv[l].bandBoxes.ngroups > 0 && h->lv[l].bandBoxes.depth == h->opt.band_iterations;
+}
+// the level as the band boxes see it (a cut level: operator rows of the whole label buffer)
+const GridP &boxGrid(const mgps_solver *h, int l) { return h->lv[l].boxForm ? h->lv[l].gBox : h->lv[l].g; }
 
 // `first`: what the ghosts of x need before the first pass; the later passes follow a band pass
 // dot (single-device runs only): the scatters append their corrections to h->dotPartials (see mgps_solver::gatherDot)
-// afterSplitSweep: the sweep before was launched edge first (sweepSplit): the stage's message goes on the transfer stream
-int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first, bool dot = false, bool afterSplitSweep = false)
+int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first, bool dot = false)
 {
     DevLevel &L = h->lv[l];
-    if (bandStageCompletesGhosts(h, l)) return bandStageDeep(h, l, x, b, afterSplitSweep ? h->commStream : nullptr);
     auto sink = [&]() -> double * {
         if (!dot || L.nband <= 0) return nullptr;
         double *p = h->dotPartials + h->dotUsed;
@@ -622,7 +601,9 @@ int bandPasses(mgps_solver *h, int l, float *x, const float *b, GhostMode first,
             h->dotUsed += unsigned(L.bandBoxes.ngroups);
         }
         if (x == L.r || b == L.r) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "band stage: the level's residual grid is its scratch");
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, x, b, L.r, nullptr, h->opt.jacobi_weight, false, MixScale{}, s, x));
+        // (a cut level: the boundary plane and the neighbours' cells the boxes read arrive first, x and rhs in one message)
+        if (L.boxForm) MGPS_TRY(haloListExchange(h, l, x, const_cast<float *>(b), true));
+        MGPS_LAUNCH(h, launchBandBox(h->stream, boxGrid(h, l), L.bandBoxes, false, x, b, L.r, nullptr, h->opt.jacobi_weight, false, MixScale{}, s, x));
         MGPS_LAUNCH(h, launchBandBoxCopy(h->stream, L.g, L.bandBoxes, L.r, x));
         return MGPS_OK;
     }
@@ -695,48 +676,6 @@ int profMark(mgps_solver *h, bool begin)
     }
     MGPS_HIP(h, hipEventRecord(h->profEvents[h->profUsed + (begin ? 0 : 1)], h->stream));
     if (!begin) h->profUsed += 2;
-    return MGPS_OK;
-}
-
-// Overlap of a cut level's exchanges with its sweeps (slab runs): can the sweep of level l be launched edge first?
-bool sweepSplittable(const mgps_solver *h, int l)
-{
-    if (!h->dist || !h->commStream) return false;
-    const DevLevel &L = h->lv[l];
-    if (!L.g.ghostLo && !L.g.ghostHi) return false;
-    // the two event hops of an overlapped exchange cost about 15 us each (measured with a null transport: +0.15 ms per cycle
-    // over nine of them at 1024^3 / 8 ranks); a plane below 1 MiB crosses a link in less
-    static const size_t minPlaneBytes = [] {
-        const char *e = getenv("MGPS_OVERLAP_MIN_PLANE_KB");  // (tests use 0: every cut level)
-        return size_t(e ? std::max(0, atoi(e)) : 1024) << 10;
-    }();
-    if (size_t(L.d.nx) * L.d.ny * sizeof(float) < minPlaneBytes) return false;
-    const int kernel = stencilKernelOf(L.g);
-    if (kernel == 2) return L.g.planeBlocks && L.edgePlaneBlocks > 0 && L.edgePlaneBlocks <= L.g.nplaneBlocks;
-    return kernel == 1 && L.g.chunks && L.edgeChunks > 0 && L.edgeChunks <= L.g.nchunks;
-}
-// The sweep in two launches: the runs / blocks that touch the planes next to a cut, then the rest.  The transfer stream
-// is made to wait for the first part only -- whoever queues the exchange there next gets it started while the second part
-// still runs.  (The general BOUNDARY cells are patched after each part: the patch reads the sweep's input, so repeating it
-// is harmless, and the main kernel of the second part would otherwise overwrite the first patch.)
-int sweepSplit(mgps_solver *h, int l, StencilOp op, float *out, const float *x, const float *b, float omega)
-{
-    DevLevel &L = h->lv[l];
-    GridP ge = L.g, gi = L.g;
-    if (stencilKernelOf(L.g) == 2) {
-        ge.nplaneBlocks = L.edgePlaneBlocks;
-        gi.planeBlocks = L.g.planeBlocks + L.edgePlaneBlocks;
-        gi.nplaneBlocks = L.g.nplaneBlocks - L.edgePlaneBlocks;
-    } else {
-        ge.nchunks = L.edgeChunks;
-        gi.chunks = L.g.chunks + L.edgeChunks;
-        gi.nchunks = L.g.nchunks - L.edgeChunks;
-    }
-    MGPS_LAUNCH(h, launchStencil(h->stream, op, ge, out, x, b, omega, true));
-    MGPS_HIP(h, hipEventRecord(h->evEdge, h->stream));
-    MGPS_HIP(h, hipStreamWaitEvent(h->commStream, h->evEdge, 0));
-    MGPS_LAUNCH(h, launchStencil(h->stream, op, gi, out, x, b, omega, true));
-    ++h->overlappedExchanges;  // (every caller queues exactly one exchange on the transfer stream next)
     return MGPS_OK;
 }
 
@@ -931,9 +870,15 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
             MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, nullptr, nullptr, true));
             return MGPS_OK;
         }
+        // A cut level of a slab run (DevLevel::boxForm) runs the same three launches on its own planes with two messages: before
+        // the closure launch the boundary plane of the iterate (the sweep's ghost plane) and, packed, iterate and rhs at the
+        // neighbours' cells its regions read (up to depth + 1 planes deep: they live in the deep ghost planes of the grids); before
+        // the plain launch the snapshot at the same cells.  The stroke leaves the ghost planes of its result stale: whoever reads
+        // across the cut next exchanges them (the residual, the finer level's prolongation).
         {
             StageScope scope(h, ST_BAND, l);
-            MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, true, src, b, nullptr, L.r, h->opt.jacobi_weight));
+            if (L.boxForm) MGPS_TRY(haloListExchange(h, l, cur, const_cast<float *>(b), true));
+            MGPS_LAUNCH(h, launchBandBox(h->stream, boxGrid(h, l), L.bandBoxes, true, src, b, nullptr, L.r, h->opt.jacobi_weight));
         }
         {
             StageScope scope(h, ST_SMOOTH, l);
@@ -956,8 +901,9 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         }
         StageScope scope(h, ST_BAND, l);
         std::swap(cur, other);
+        if (L.boxForm) MGPS_TRY(haloListExchange(h, l, L.r, nullptr, false));
         // (the gathered dot: the sweep left sum x' b with its own values everywhere; this launch adds (new - sweep's) b on every cell it writes)
-        MGPS_LAUNCH(h, launchBandBox(h->stream, L.g, L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, cur, true));
+        MGPS_LAUNCH(h, launchBandBox(h->stream, boxGrid(h, l), L.bandBoxes, false, L.r, b, cur, nullptr, h->opt.jacobi_weight, false, MixScale{}, sinkB, cur, true));
         return MGPS_OK;
     }
     const int reps = down ? h->opt.pre_sweeps : h->opt.post_sweeps;
@@ -965,7 +911,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
     // first band stage and the first sweep as above -- sweep over the un-smoothed grid, then the closure launch writes what the
     // sweep should hold on the band closure straight into its output (no snapshot: the next sweep reads the grid) -- two launches
     // instead of three (band stage out of place, copy, sweep); the remaining sweeps and the last band stage as below
-    const bool firstFused = bands && !h->useGS && reps > 1 && levelHasBoxes(h, l) && cur != L.r && other != L.r && b != L.r;
+    const bool firstFused = bands && !h->useGS && reps > 1 && levelHasBoxes(h, l) && !L.boxForm && cur != L.r && other != L.r && b != L.r;
     if (firstFused) {
         {
             StageScope scope(h, ST_SMOOTH, l);
@@ -987,9 +933,8 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         MGPS_TRY(bandPasses(h, l, cur, b, ghostsFresh ? GHOST_NONE : GHOST_FULL));
     }
     // after the band passes only band cells are stale across the cut -- unless there were none
-    const GhostMode afterBands = bandStageCompletesGhosts(h, l) ? GHOST_NONE : bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
+    const GhostMode afterBands = bands ? GHOST_BAND : (ghostsFresh ? GHOST_NONE : GHOST_FULL);
     const bool timed = h->profiling && l == 0;
-    bool split = false;  // the last sweep went edge first: the band stage after it overlaps its message with the sweep's interior
     for (int rep = firstFused ? 1 : 0; rep < reps; ++rep) {
         StageScope scope(h, ST_SMOOTH, l);
         const GhostMode before = rep == 0 ? afterBands : GHOST_FULL;  // a sweep rewrote everything
@@ -1005,10 +950,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         } else {
             MGPS_TRY(exchangeGhosts(h, l, cur, before));
             if (timed) MGPS_TRY(profMark(h, true));
-            if (!d && rep == reps - 1 && bands && bandStageCompletesGhosts(h, l) && sweepSplittable(h, l)) {
-                MGPS_TRY(sweepSplit(h, l, OP_JACOBI, other, cur, b, h->opt.jacobi_weight));
-                split = true;
-            } else if (d) {
+            if (d) {
                 unsigned used = 0;
                 MGPS_LAUNCH(h, launchStencilDot(h->stream, OP_JACOBI, L.g, other, cur, b, h->opt.jacobi_weight, h->dotPartials + h->dotUsed, &used));
                 h->dotUsed += used;
@@ -1020,7 +962,7 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         if (timed) ++h->profSweeps;
     }
     StageScope scope(h, ST_BAND, l);
-    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot, split));  // the full-domain smoother rewrote everything
+    MGPS_TRY(bandPasses(h, l, cur, b, GHOST_FULL, dot));  // the full-domain smoother rewrote everything
     return MGPS_OK;
 }
 
@@ -1132,27 +1074,19 @@ int vcycle(mgps_solver *h, float *x, const float *b, bool useInitialGuess, bool 
                 else MGPS_TRY(poisonSpares(h, l, cur[l], other[l]));
                 MGPS_TRY(smoothStroke(h, l, cur[l], other[l], rhs, true, true, false, zl));
             }
-            bool rExchanged = false;
             if (residualRestrictFuses(h, l)) {
                 MGPS_TRY(residualRestrict(h, l, cur[l], rhs));
                 continue;
             }
             {
                 StageScope scope(h, ST_RESIDUAL, l);
-                MGPS_TRY(exchangeGhosts(h, l, cur[l], bandStageCompletesGhosts(h, l) ? GHOST_NONE
-                                                      : h->opt.band_iterations > 0 ? GHOST_BAND
-                                                                                   : GHOST_FULL));
-                if (sweepSplittable(h, l)) {  // the residual's edge planes travel while its interior is computed
-                    MGPS_TRY(sweepSplit(h, l, OP_RESIDUAL, F.r, cur[l], rhs, 0.f));
-                    MGPS_TRY(exchangeGhosts(h, l, F.r, GHOST_FULL, h->commStream));
-                    MGPS_HIP(h, hipEventRecord(h->evComm, h->commStream));
-                    MGPS_HIP(h, hipStreamWaitEvent(h->stream, h->evComm, 0));
-                    rExchanged = true;
-                } else
-                    MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
+                // (a cut level in box form: the stroke's last launch rewrote band and closure cells of a grid whose ghost planes are
+                // the sweep's input -- whole planes; per-pass band smoothing: only band cells changed since the last whole plane)
+                MGPS_TRY(exchangeGhosts(h, l, cur[l], F.boxForm ? GHOST_FULL : h->opt.band_iterations > 0 ? GHOST_BAND : GHOST_FULL));
+                MGPS_LAUNCH(h, launchStencil(h->stream, OP_RESIDUAL, F.g, F.r, cur[l], rhs, 0.f, true));
             }
             StageScope scope(h, ST_RESTRICT, l);
-            if (!rExchanged) MGPS_TRY(exchangeGhosts(h, l, F.r));
+            MGPS_TRY(exchangeGhosts(h, l, F.r));
             MGPS_LAUNCH(h, launchRestrict(h->stream, C.g, C.b, F.r));
         }
         DevLevel &B = h->lv[nsmooth];
@@ -1798,7 +1732,8 @@ struct StageClock {
 // codesPreloaded: the caller allocated L.codes, copies the labels into it itself and patches the simple cells afterwards
 // The boxes of a level once info / list / general are on the device, whoever built them: the lists compacted
 // (compactBandBoxLists) and the launch order of the groups (orderBandBoxes)
-int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
+// dims: the grid info[0] counts cells of (a cut slab level: its label buffer)
+int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s, const Dims *dims = nullptr)
 {
     BandBoxesDev &bx = L.bandBoxes;
     {  // the lists as the kernels walk them: no class-2 entries, class-12 entries last (compactBandBoxLists)
@@ -1817,7 +1752,7 @@ int finishBandBoxes(mgps_solver *h, DevLevel &L, hipStream_t s)
     if (bx.ngroups < 64) return MGPS_OK;  // (fewer groups than a chiplet has in flight)
     int32_t *info2 = nullptr;
     MGPS_TRY(devAlloc(h, &info2, size_t(kBoxInfoInts) * size_t(bx.ngroups), false));
-    const int e = orderBandBoxes(s, L.d, bx.info, bx.ngroups, info2);
+    const int e = orderBandBoxes(s, dims ? *dims : L.d, bx.info, bx.ngroups, info2);
     if (e == int(hipErrorOutOfMemory) || e == int(hipErrorInvalidValue)) {  // no room for the sort (or a level past its key space): the builders' order stays
         (void)cacheFree(info2);
         return MGPS_OK;
@@ -1863,12 +1798,14 @@ int uploadLevel(mgps_solver *h, DevLevel &L, const HostLevel &HL, int z0, int z1
     L.nmixed[0] = int(HL.mixedEven.size());
     L.nmixed[1] = int(HL.mixedOdd.size());
     MGPS_TRY(devUpload(h, &L.tileBndStart, HL.tileBndStart));
-    if (h->dist)
+    if (h->dist) {
         for (int q = 0; q < 4; ++q) {
             MGPS_TRY(devUpload(h, &L.bandPlane[q], HL.bandPlane[q]));
             L.nbandPlane[q] = int(HL.bandPlane[q].size());
             MGPS_TRY(devAlloc(h, &L.packBuf[q], HL.bandPlane[q].size(), true));
         }
+        L.hasBandPlanes = true;
+    }
     MGPS_TRY(devUpload(h, &L.chunks, HL.chunks));
     MGPS_TRY(devUpload(h, &L.planeBlocks, HL.planeBlocks));
     // band passes fuse only where no ghost exchange has to happen between them
@@ -2424,8 +2361,10 @@ void fillGridP(mgps_solver *h, DevLevel &L, bool withWeights, int nchunks, int c
     if (!L.g.planeZc) L.g.planeBlocks = nullptr;
 }
 
+// tail: the collapsed tail of a slab run on rank 0 -- unit weights (wx == nullptr), the coarsest solver even for a single level, no
+// shell test of its finest level (the level cap of the whole hierarchy has been applied by the ranks together)
 int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t *labels, const float *wx, const float *wy, const float *wz,
-                        hipMemcpyKind kind, int mgLevels, bool useGS, const mgps_options &o, int device)
+                        hipMemcpyKind kind, int mgLevels, bool useGS, const mgps_options &o, int device, bool tail = false)
 {
     // the argument rules of mgps_hierarchy_create (MG.cpp:159-161)
     if (mgLevels < 1 || nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1))
@@ -2441,6 +2380,8 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     h->useGS = useGS;
     h->device = device;
     h->requestedLevels = mgLevels;
+    h->tailOfSlabRun = tail;
+    if (tail) h->opt.precision = 0;
     std::thread inverseJob;  // the coarsest level's direct solver, on host threads beside the device work
     struct Joiner {          // (an exception on the way out -- std::bad_alloc -- must not meet a joinable thread)
         std::thread &t;
@@ -2510,7 +2451,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     }
     std::vector<int> hflags(nflags);
     ODS_HIP(hipMemcpy(hflags.data(), flags, nflags * sizeof(int), hipMemcpyDeviceToHost));
-    if (hflags[0]) return bail(failH(h, MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)"));
+    if (hflags[0] && !tail) return bail(failH(h, MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)"));
     if (!hflags[1]) return bail(failH(h, MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain"));
     int levels = mgLevels;
     for (int l = 1; l < mgLevels; ++l) {  // MG.cpp:238-253
@@ -2534,7 +2475,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
     clock.lap("labels of all levels (device)");
 
     // ---- the coarsest level's direct solver on host threads, beside everything below
-    const bool needCoarse = levels > 1;
+    const bool needCoarse = levels > 1 || tail;
     int rcInverse = MGPS_OK;
     {
         const Dims cd = h->lv[size_t(levels - 1)].d;
@@ -2550,7 +2491,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         const size_t wn[3] = {size_t(d0.nx + 1) * d0.ny * d0.nz, size_t(d0.nx) * (d0.ny + 1) * d0.nz, size_t(d0.nx) * d0.ny * (d0.nz + 1)};
         const float *src[3] = {wx, wy, wz};
         h->weightsBorrowed = kind == hipMemcpyDeviceToDevice && o.borrow_device_weights != 0;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && wx; ++a) {
             if (h->weightsBorrowed) {
                 h->w[a] = const_cast<float *>(src[a]);
                 continue;
@@ -2767,7 +2708,7 @@ int createWholeOnDevice(mgps_solver **out, int nx, int ny, int nz, const uint8_t
         L.npure[1] = counts[1];
         L.nmixed[0] = counts[2];
         L.nmixed[1] = counts[3];
-        fillGridP(h, L, l == 0, t.listLen, t.runCells, counts[4], t.planeZc);
+        fillGridP(h, L, l == 0 && wx, t.listLen, t.runCells, counts[4], t.planeZc);
     }
     clock.lap("device order, codes, activity + tile lists");
     // ---- boxes: totals to the host, arrays filled
@@ -3100,6 +3041,801 @@ MGPS_API_CATCH(nullptr)
 
 }  // extern "C"
 namespace {
+// ---- a slab rank set up on the device (round 5) ---------------------------------------------------------------------------
+// What createSlabImpl below does through the host builder -- 217-280 ms for a 1024^3 / 8 rank, of which 90 ms went into coarsening
+// the GLOBAL labels on every rank's host and 80 ms into the halo groups of the graph-form band stage -- with the kernels of
+// createWholeOnDevice on a window of the labels:
+//   * per level a label BUFFER: the owned planes and, on both sides, ghost planes of labels (kLabelGhost0 x 2^(Dmax-1-l) planes: the
+//     buffers of two levels nest, the coarsening kernel runs on them unchanged).  Real labels as far as the coarser levels' windows
+//     need them (the rank's window of the global labels goes up once, 1 B per cell), EXTERIOR beyond;
+//   * band masks, band list, operator rows and band boxes are built on the buffer as if it were a whole grid; the boxes are
+//     clipped to the owned planes, their regions reach into the ghost zone -- the neighbours' cells they read are found from the
+//     box lists themselves and ASKED FOR at set-up (the ranks trade index lists once; nobody has to derive a neighbour's
+//     structure), and live in the deep ghost planes of the grids from then on (DevLevel::BoxHalo);
+//   * the rank's own lists (band list with rows, activity runs, plane blocks, Gauss-Seidel tiles) are cut out of the buffer's;
+//   * the face weights of the kSlabGhostPlanes planes next to a cut come from the neighbour (operator rows of the ghost zone's
+//     general cells);
+//   * level cap and shell tests are agreed by an all-reduce of the ranks' flags; rank 0 receives the collapse level's labels and
+//     builds the tail with createWholeOnDevice.
+// Every failure is folded into an all-reduce that all ranks take part in before the next collective: no rank leaves alone.
+constexpr int kSlabGhostPlanes = kBandMaxDepth + 1;  // planes of every grid beyond its owned ones: a box region reaches depth + 1 past its owned box
+constexpr int kLabelGhost0 = 16;                     // label ghost planes of the coarsest distributed level's buffer (>= the reach below, tile-aligned)
+
+// host -> device from pageable memory: slices copied into a page-locked block by several threads, each slice sent as soon as
+// it is there (a pageable array uploads at ~3 GB/s on this platform, a page-locked one at ~55)
+int uploadPageable(mgps_solver *h, void *dst, const void *src, size_t bytes, int device)
+{
+    if (bytes == 0) return MGPS_OK;
+    void *stage = bytes >= (size_t(4) << 20) ? pinnedAlloc(bytes) : nullptr;
+    if (!stage) {
+        MGPS_HIP(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return MGPS_OK;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = int(std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, std::min<size_t>(16, bytes >> 22))));
+    std::atomic<int> failed{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] {
+            if (hipSetDevice(device) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+            const size_t per = ((bytes + size_t(nt) - 1) / size_t(nt) + 4095) & ~size_t(4095);
+            for (size_t off = size_t(t) * per, end = std::min(bytes, off + per); off < end;) {
+                const size_t n = std::min<size_t>(end - off, size_t(8) << 20);
+                std::memcpy(static_cast<char *>(stage) + off, static_cast<const char *>(src) + off, n);
+                if (hipMemcpyAsync(static_cast<char *>(dst) + off, static_cast<char *>(stage) + off, n, hipMemcpyHostToDevice, nullptr) != hipSuccess) failed = 1;
+                off += n;
+            }
+        });
+    for (auto &th : pool) th.join();
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    pinnedFree(stage);
+    if (failed || e != hipSuccess) return failH(h, MGPS_ERR_HIP, "label upload failed");
+    return MGPS_OK;
+}
+
+int createSlabOnDevice(mgps_solver **out, int nx, int ny, int nzg, const uint8_t *labels_global_host, const float *wx_slab, const float *wy_slab,
+                       const float *wz_slab, bool weightsOnDevice, int mgLevels, bool useGS, const mgps_options &o, const mgps_comm *comm, const int *splits, int device)
+{
+    if (mgLevels < 2 || nx < 2 || ny < 2 || nzg < 2 || (nx & 1) || (ny & 1) || (nzg & 1))
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: extents must be even and >= 2, mg_levels >= 2");
+    if (size_t(nx) * ny * nzg > size_t(0x7fffffff)) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: more than 2^31-1 cells per grid");
+    for (int l = 1; l < mgLevels; ++l)
+        if (((nx >> (l - 1)) & 1) || ((ny >> (l - 1)) & 1) || ((nzg >> (l - 1)) & 1) || (nx >> l) < 1 || (ny >> l) < 1 || (nzg >> l) < 1)
+            return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: extents are not divisible by 2^(levels-1)");
+    if (o.band_width < 1 || o.band_width > 8 || o.band_iterations < 0)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: band_width 1 .. 8, band_iterations >= 0");
+    const int P = comm->size, rank = comm->rank;
+    const bool lo = rank > 0, hi = rank < P - 1;
+    // the deepest the distributed part can be (the level cap can only shorten the hierarchy): label windows are sized for it
+    const int Dmax = distributedLevelsFor(splits, P, nx, ny, mgLevels, useGS, o);
+    if (Dmax < 1)
+        return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT,
+                     "mgps_create_slab: every rank needs at least 16 planes cut on even planes (multiples of 16 with Gauss-Seidel) and the "
+                     "hierarchy at least 2 levels");
+    auto *h = new mgps_solver();
+    h->opt = o;
+    h->useGS = useGS;
+    h->device = device;
+    h->dist = true;
+    h->ghost = kSlabGhostPlanes;
+    h->requestedLevels = mgLevels;
+    h->comm = mgps_comm{};
+    std::memcpy(&h->comm, comm, size_t(comm->struct_size));  // (struct_size bytes are the caller's; the rest stays NULL)
+    h->comm.struct_size = int(sizeof(mgps_comm));
+    h->splits.assign(splits, splits + P + 1);
+    auto bail = [&](int code) {
+        setLastGlobalError(h->lastError);
+        freeAll(h);
+        return code;
+    };
+    StageClock sclock(setupTimingOn());
+    DevScratch tmp;
+    // a verdict all ranks share: the largest status (0 = fine).  Every rank calls it at the same places.
+    auto agree = [&](int mine, int *all) -> int {
+        double v = double(mine);
+        if (h->comm.allreduce(h->comm.user, &v, 1, 1) != 0) return failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up");
+        *all = int(v);
+        return MGPS_OK;
+    };
+    const int z0 = splits[rank], z1 = splits[rank + 1];
+    const bool wantBoxes = o.fuse_band_passes && o.deep_band_halo && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth;
+    const int depth = o.band_iterations;
+    // planes beyond the owned ones in which band masks must be right: a box region reaches depth + 1 planes out, classifying its
+    // cells looks one plane farther, band membership there depends on BOUNDARY cells band_width - 1 planes farther; + 1 spare
+    const int reach = (o.band_width - 1) + (wantBoxes ? depth + 2 : 1) + 1;
+    if (reach > kLabelGhost0) return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: band_width + band_iterations reach past 16 planes"));
+
+    // ---- label buffers of levels 0 .. Dmax: spare plane | elo ghost planes | owned planes | elo ghost planes | spare plane
+    struct Buf {
+        Dims d;          // the buffer as a grid
+        Dims own;        // the owned planes as a grid
+        int elo = 0;     // ghost planes on either side
+        int real = 0;    // of which this many next to the owned planes hold real labels (inside the global grid)
+        uint8_t *base = nullptr;
+        uint8_t *lab() const { return base + size_t(d.nx) * d.ny; }                      // buffer plane 0
+        uint8_t *owned() const { return base + size_t(1 + elo) * size_t(d.nx) * d.ny; }  // owned plane 0
+    };
+    std::vector<Buf> B;
+    B.resize(size_t(Dmax) + 1);
+    for (int l = 0; l <= Dmax; ++l) {
+        Buf &b = B[size_t(l)];
+        b.elo = l < Dmax ? kLabelGhost0 << (Dmax - 1 - l) : kLabelGhost0 / 2;
+        b.own = Dims{nx >> l, ny >> l, (z1 - z0) >> l};
+        b.d = Dims{nx >> l, ny >> l, b.own.nz + 2 * b.elo};
+    }
+    B[size_t(Dmax)].real = 3;  // (the collapse level is marked on its owned planes: one plane of neighbours, and one for theirs)
+    if (Dmax >= 1) B[size_t(Dmax) - 1].real = std::max(reach, 2 * B[size_t(Dmax)].real + 2);
+    for (int l = Dmax - 2; l >= 0; --l) B[size_t(l)].real = 2 * B[size_t(l) + 1].real + 2;
+    for (int l = 0; l <= Dmax; ++l) {
+        Buf &b = B[size_t(l)];
+        if (b.real > b.elo) return bail(failH(h, MGPS_ERR_INTERNAL, "slab set-up: label window past its buffer"));
+        const size_t plane = size_t(b.d.nx) * b.d.ny;
+        int rc = tmp.get(h, &b.base, (size_t(b.d.nz) + 2) * plane);
+        if (rc != MGPS_OK) return bail(rc);
+        if (hipMemsetAsync(b.base, MGPS_EXTERIOR_CELL, (size_t(b.d.nz) + 2) * plane, nullptr) != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, "memset failed"));
+    }
+    int status = MGPS_OK;
+    {  // the rank's window of the fine labels
+        const Buf &b = B[0];
+        const int a = std::max(0, z0 - b.real), e = std::min(nzg, z1 + b.real);
+        const size_t plane = size_t(nx) * ny;
+        status = uploadPageable(h, b.owned() + ptrdiff_t(a - z0) * ptrdiff_t(plane), labels_global_host + size_t(a) * plane, size_t(e - a) * plane, device);
+    }
+    sclock.lap("slab: label window upload");
+    // flags: per level l [2 l] shell broken, [2 l + 1] holds an active cell; then interior rule, weight rule, boxes broken per level
+    const size_t nflags = size_t(2 * (mgLevels + 1) + 2 + mgLevels);
+    int *flags = nullptr;
+    if (status == MGPS_OK) status = tmp.get(h, &flags, nflags);
+    const int fInterior = 2 * (mgLevels + 1), fWeights = fInterior + 1, fBoxes = fInterior + 2;
+    std::vector<int> hflags(nflags, 0);
+    // (levels beyond Dmax are the tail's: rank 0 applies cap and shell tests to them when it builds the tail, and tells the others)
+    if (status == MGPS_OK) status = [&]() -> int {
+        MGPS_HIP(h, hipMemsetAsync(flags, 0, nflags * sizeof(int), nullptr));
+        MGPS_LAUNCH(h, launchShellCheckSlab(nullptr, B[0].own, B[0].owned(), !lo, !hi, flags));
+        MGPS_LAUNCH(h, launchAnyActive(nullptr, B[0].own, B[0].owned(), flags + 1));
+        for (int l = 1; l <= Dmax; ++l) {
+            int scratchFlag = 0;
+            (void)scratchFlag;
+            MGPS_LAUNCH(h, launchCoarsenLabels(nullptr, B[size_t(l) - 1].d, B[size_t(l) - 1].lab(), B[size_t(l)].lab(), flags + 2 * l + 1));
+            MGPS_LAUNCH(h, launchShellCheckSlab(nullptr, B[size_t(l)].own, B[size_t(l)].owned(), !lo, !hi, flags + 2 * l));
+        }
+        // (the buffers' "active" flags cover ghost planes too: an OR over ranks either way)
+        for (int l = 1; l <= Dmax; ++l) MGPS_LAUNCH(h, launchMarkBoundary(nullptr, B[size_t(l)].d, B[size_t(l)].lab()));
+        MGPS_HIP(h, hipMemcpy(hflags.data(), flags, nflags * sizeof(int), hipMemcpyDeviceToHost));
+        return MGPS_OK;
+    }();
+    sclock.lap("slab: labels of all levels");
+    // ---- the ranks' flags together: level cap (MG.cpp:238-253), shell tests
+    int levels = mgLevels;
+    {
+        std::vector<double> v(size_t(2 * mgLevels) + 1, 0.0);
+        for (int q = 0; q < 2 * mgLevels; ++q) v[size_t(q)] = hflags[size_t(q)] ? 1.0 : 0.0;
+        v[size_t(2 * mgLevels)] = double(status);
+        if (h->comm.allreduce(h->comm.user, v.data(), int(v.size()), 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+        if (int(v[size_t(2 * mgLevels)]) != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, int(v[size_t(2 * mgLevels)]), "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : int(v[size_t(2 * mgLevels)]));
+        }
+        if (v[0] != 0.0) return bail(failH(h, MGPS_ERR_HIERARCHY, "labels need an EXTERIOR shell on all six sides (unitTestExteriorCells)"));
+        if (v[1] == 0.0) return bail(failH(h, MGPS_ERR_HIERARCHY, "no INTERIOR or BOUNDARY cell in the domain"));
+        for (int l = 1; l <= Dmax && l < mgLevels; ++l) {
+            if (v[size_t(2 * l)] != 0.0)
+                return bail(failH(h, MGPS_ERR_HIERARCHY,
+                                  "level " + std::to_string(l) + " has no EXTERIOR shell (unitTestExteriorCells, MG.cpp:252): " + std::to_string(mgLevels) +
+                                      " levels need 2^(levels-1) = " + std::to_string(1 << (mgLevels - 1)) + " EXTERIOR cells on every side of the solver grid"));
+            if (v[size_t(2 * l + 1)] == 0.0) {
+                levels = l - 1;  // the reference drops the last solvable level too (MG.cpp:245)
+                break;
+            }
+        }
+        if (levels < 1) return bail(failH(h, MGPS_ERR_HIERARCHY, "level cap left no multigrid level (first coarse level has no solvable cell)"));
+    }
+    const int D = distributedLevelsFor(splits, P, nx, ny, levels, useGS, o);
+    if (D < 1)
+        return bail(failH(h, MGPS_ERR_INVALID_ARGUMENT,
+                          "mgps_create_slab: every rank needs at least 16 planes cut on even planes (multiples of 16 with Gauss-Seidel) and the "
+                          "hierarchy at least 2 levels"));
+    h->distLevels = D;
+    h->totalLevels = levels;  // (the tail may still shorten it: the level cap below the collapse level)
+    h->lv.resize(size_t(D) + 1);
+
+    // ---- face weights: the slab's own, and kSlabGhostPlanes planes of each neighbour's next to the cuts
+    const int nzl = z1 - z0, gw = kSlabGhostPlanes;
+    const size_t wplane[3] = {size_t(nx + 1) * ny, size_t(nx) * (ny + 1), size_t(nx) * ny};
+    const size_t wn[3] = {wplane[0] * size_t(nzl), wplane[1] * size_t(nzl), wplane[2] * size_t(nzl + 1)};
+    float *wlo[3] = {nullptr, nullptr, nullptr}, *whi[3] = {nullptr, nullptr, nullptr};
+    status = [&]() -> int {
+        const float *wh[3] = {wx_slab, wy_slab, wz_slab};
+        if (weightsOnDevice && o.borrow_device_weights) {
+            for (int a = 0; a < 3; ++a) h->w[a] = const_cast<float *>(wh[a]);
+            h->weightsBorrowed = true;
+        } else
+            for (int a = 0; a < 3; ++a) {
+                MGPS_TRY(devAlloc(h, &h->w[a], wn[a], false));
+                MGPS_HIP(h, hipMemcpyAsync(h->w[a], wh[a], wn[a] * sizeof(float), weightsOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, nullptr));
+            }
+        for (int a = 0; a < 3; ++a) {
+            MGPS_TRY(tmp.get(h, &wlo[a], wplane[a] * size_t(gw)));
+            MGPS_TRY(tmp.get(h, &whi[a], wplane[a] * size_t(gw)));
+        }
+        MGPS_HIP(h, hipStreamSynchronize(nullptr));
+        return MGPS_OK;
+    }();
+    {
+        int all = MGPS_OK;
+        const int rc = agree(status, &all);
+        if (rc != MGPS_OK) return bail(rc);
+        if (all != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, all, "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : all);
+        }
+    }
+    // what travels: wx / wy planes [0, gw) down and [nzl - gw, nzl) up; of wz the faces [1, gw] down and [nzl - gw, nzl - 1] up
+    // (before the exchange the ghost planes hold a mirror image of the rank's own: a transport that moves nothing -- the
+    // compute-bound tools -- leaves plausible weights there)
+    for (int a = 0; a < 3 && nzl >= gw; ++a) {
+        const size_t bytes = wplane[a] * size_t(gw) * sizeof(float);
+        const float *down = h->w[a] + (a == 2 ? wplane[a] : 0), *up = h->w[a] + wplane[a] * size_t(nzl - gw);
+        if (hipMemcpyAsync(wlo[a], up, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess || hipMemcpyAsync(whi[a], down, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess)
+            return bail(failH(h, MGPS_ERR_HIP, "weight ghost planes: copy failed"));
+        if (P > 1 && h->comm.exchange(h->comm.user, lo ? down : nullptr, bytes, lo ? wlo[a] : nullptr, bytes, hi ? up : nullptr, bytes, hi ? whi[a] : nullptr, bytes, nullptr) != 0)
+            return bail(failH(h, MGPS_ERR_COMM, "weight ghost planes: exchange failed"));
+    }
+    (void)hipStreamSynchronize(nullptr);
+    sclock.lap("slab: weights + their ghost planes");
+
+    // ---- the distributed levels on their buffers
+    struct LevelTmp {
+        int nt = 0, tx = 0, ty = 0, tz = 0;
+        uint32_t *mask = nullptr;
+        uint16_t *prefix = nullptr;
+        int32_t *tileCount = nullptr, *tileKind = nullptr, *tileStart = nullptr, *scan = nullptr;
+        int32_t *sorted = nullptr, *general = nullptr, *genRank = nullptr, *bandEntry = nullptr, *extBand = nullptr;
+        int32_t *own = nullptr, *ownGen = nullptr, *ownRank = nullptr, *ownGenRank = nullptr;
+        uint8_t *diagS = nullptr, *extDiag = nullptr, *chunkFlags = nullptr, *planeFlags = nullptr;
+        int32_t *gcount[3] = {nullptr, nullptr, nullptr}, *gat[3] = {nullptr, nullptr, nullptr};
+        int32_t *tileFlags = nullptr, *tileRank = nullptr, *bandTiles = nullptr, *boxTiles = nullptr;
+        uint8_t *tileBits = nullptr;
+        int *runCounts = nullptr;
+        int32_t *listCounts = nullptr;
+        int runCells = 0, listLen = 0, nbandExt = 0, nGenExt = 0, planeZc = 0, nBoxTiles = 0, nplaneBlocks = 0;
+        size_t nfine = 0, nplane = 0;
+        SlabWindow win;
+    };
+    std::vector<LevelTmp> T;
+    T.resize(size_t(D));
+    std::vector<int> boxesOk(size_t(D), 0);
+    status = [&]() -> int {
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            L.d = b.own;
+            L.z0 = z0 >> l;
+            L.z1 = z1 >> l;
+            L.elo = b.elo;
+            t.win = SlabWindow{b.elo, b.elo + b.own.nz, reach};
+            t.tx = (b.d.nx + kTile - 1) / kTile;
+            t.ty = (b.d.ny + kTile - 1) / kTile;
+            t.tz = (b.d.nz + kTile - 1) / kTile;
+            t.nt = t.tx * t.ty * t.tz;
+            MGPS_TRY(tmp.get(h, &t.mask, size_t(t.nt) * 128));
+            MGPS_TRY(tmp.get(h, &t.prefix, size_t(t.nt) * 128));
+            MGPS_TRY(tmp.get(h, &t.tileCount, size_t(t.nt)));
+            MGPS_TRY(tmp.get(h, &t.tileKind, size_t(t.nt)));
+            MGPS_TRY(tmp.get(h, &t.tileStart, size_t(t.nt) + 1));
+            MGPS_TRY(tmp.get(h, &t.scan, scanScratchInts(b.d.cells())));
+            MGPS_TRY(tmp.get(h, &t.tileFlags, size_t(t.nt)));
+            MGPS_TRY(tmp.get(h, &t.tileRank, size_t(t.nt) + 1));
+            MGPS_TRY(tmp.get(h, &t.bandTiles, size_t(t.nt)));
+            MGPS_TRY(tmp.get(h, &t.tileBits, size_t(t.nt)));
+            MGPS_HIP(h, hipMemsetAsync(t.mask, 0, size_t(t.nt) * 128 * sizeof(uint32_t), nullptr));
+            MGPS_HIP(h, hipMemsetAsync(t.prefix, 0, size_t(t.nt) * 128 * sizeof(uint16_t), nullptr));
+            MGPS_HIP(h, hipMemsetAsync(t.tileCount, 0, size_t(t.nt) * sizeof(int32_t), nullptr));
+            MGPS_LAUNCH(h, launchBandCandidates(nullptr, b.d, b.lab(), t.tileKind, t.tileBits, t.tileFlags, t.tileRank, t.bandTiles, t.scan, &t.win));
+        }
+        for (int l = 0; l < D; ++l) {
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            int ncand = 0;
+            MGPS_HIP(h, hipMemcpy(&ncand, t.tileRank + t.nt, sizeof(int), hipMemcpyDeviceToHost));
+            MGPS_LAUNCH(h, launchBandMasks(nullptr, b.d, b.lab(), o.band_width, t.mask, t.prefix, t.tileCount, t.tileKind, l == 0 ? flags + fInterior : nullptr, t.bandTiles,
+                                           ncand, &t.win));
+            MGPS_LAUNCH(h, launchExclusiveScan(nullptr, t.tileCount, t.tileStart, size_t(t.nt), t.scan));
+        }
+        for (int l = 0; l < D; ++l) MGPS_HIP(h, hipMemcpy(&T[size_t(l)].nbandExt, T[size_t(l)].tileStart + T[size_t(l)].nt, sizeof(int), hipMemcpyDeviceToHost));
+        // band lists of the buffers in reference order, classification (level 0: with the weights and their ghost planes), rows
+        WeightView wv;
+        for (int a = 0; a < 3; ++a) {
+            wv.w[a] = h->w[a];
+            wv.lo[a] = wlo[a];
+            wv.hi[a] = whi[a];
+        }
+        wv.nz = nzl;
+        wv.gw = nzl >= gw ? gw : 0;
+        wv.k0 = B[0].elo;
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            const size_t nb = size_t(t.nbandExt);
+            MGPS_TRY(tmp.get(h, &t.sorted, nb));
+            MGPS_TRY(tmp.get(h, &t.general, nb));
+            MGPS_TRY(tmp.get(h, &t.genRank, nb + 1));
+            MGPS_TRY(tmp.get(h, &t.bandEntry, nb));
+            MGPS_TRY(tmp.get(h, &t.diagS, nb));
+            MGPS_TRY(tmp.get(h, &t.extBand, nb));
+            MGPS_TRY(tmp.get(h, &t.extDiag, nb));
+            MGPS_TRY(tmp.get(h, &t.own, nb));
+            MGPS_TRY(tmp.get(h, &t.ownGen, nb));
+            MGPS_TRY(tmp.get(h, &t.ownRank, nb + 1));
+            MGPS_TRY(tmp.get(h, &t.ownGenRank, nb + 1));
+            if (t.nbandExt > 0) {
+                MGPS_LAUNCH(h, launchBandFill(nullptr, b.d, t.mask, t.prefix, t.tileStart, t.sorted));
+                MGPS_LAUNCH(h, launchBandClassify(nullptr, b.d, b.lab(), l == 0 ? wv : WeightView{}, t.sorted, t.nbandExt, t.diagS, t.general, l == 0 ? flags + fWeights : nullptr,
+                                                  &t.win));
+            }
+            MGPS_LAUNCH(h, launchExclusiveScan(nullptr, t.general, t.genRank, nb, t.scan));
+            const size_t plane = size_t(b.d.nx) * b.d.ny;
+            MGPS_LAUNCH(h, launchOwnedFlags(nullptr, t.sorted, t.general, t.nbandExt, int32_t(size_t(t.win.own0) * plane), int32_t(size_t(t.win.own1) * plane), t.own, t.ownGen));
+            MGPS_LAUNCH(h, launchExclusiveScan(nullptr, t.own, t.ownRank, nb, t.scan));
+            MGPS_LAUNCH(h, launchExclusiveScan(nullptr, t.ownGen, t.ownGenRank, nb, t.scan));
+            (void)L;
+        }
+        for (int l = 0; l < D; ++l) {
+            LevelTmp &t = T[size_t(l)];
+            DevLevel &L = h->lv[size_t(l)];
+            MGPS_HIP(h, hipMemcpy(&t.nGenExt, t.genRank + t.nbandExt, sizeof(int), hipMemcpyDeviceToHost));
+            MGPS_HIP(h, hipMemcpy(&L.nband, t.ownRank + t.nbandExt, sizeof(int), hipMemcpyDeviceToHost));
+            MGPS_HIP(h, hipMemcpy(&L.nbndGeneral, t.ownGenRank + t.nbandExt, sizeof(int), hipMemcpyDeviceToHost));
+        }
+        MGPS_HIP(h, hipMemcpy(hflags.data() + fInterior, flags + fInterior, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        if (hflags[size_t(fInterior)] || hflags[size_t(fWeights)])
+            return failH(h, MGPS_ERR_HIERARCHY, "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels");
+        sclock.lap("slab: band lists + classification");
+        // the buffer's device order and rows, the codes, the rank's own lists, activity
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            const size_t plane = size_t(b.d.nx) * b.d.ny;
+            MGPS_TRY(devAlloc(h, &L.extRows, size_t(7) * size_t(t.nGenExt), false));
+            MGPS_LAUNCH(h, launchBandSplit(nullptr, b.d, b.lab(), l == 0 ? wv : WeightView{}, t.sorted, t.nbandExt, t.diagS, t.genRank, t.extBand, t.extDiag, t.bandEntry,
+                                           L.extRows));
+            MGPS_LAUNCH(h, launchPatchSimpleCodes(nullptr, b.lab(), t.extBand, t.extDiag, t.nGenExt, t.nbandExt));
+            MGPS_TRY(devAlloc(h, &L.band, size_t(L.nband), false));
+            MGPS_TRY(devAlloc(h, &L.bandDiag, size_t(L.nband), false));
+            MGPS_TRY(devAlloc(h, &L.bandTmp, size_t(L.nband), false));
+            MGPS_TRY(devAlloc(h, &L.rows, size_t(7) * size_t(L.nbndGeneral), false));
+            MGPS_LAUNCH(h, launchBandSplitOwned(nullptr, t.sorted, t.nbandExt, int32_t(size_t(t.win.own0) * plane), t.diagS, t.ownRank, t.ownGenRank, t.genRank, L.extRows, L.band,
+                                                L.bandDiag, L.rows));
+            // per owned tile (+ 1) the first of its general cells in the rank's list (the mixed Gauss-Seidel tiles look their rows up there)
+            const int ntOwn = t.tx * t.ty * ((b.own.nz + kTile - 1) / kTile), tileOff = (b.elo / kTile) * t.tx * t.ty;
+            MGPS_TRY(devAlloc(h, &L.tileBndStart, size_t(ntOwn) + 1, false));
+            MGPS_LAUNCH(h, launchGather(nullptr, t.ownGenRank, t.tileStart + tileOff, ntOwn + 1, L.tileBndStart));
+            // activity of the owned planes
+            t.nfine = (b.own.cells() + kSegCells - 1) / kSegCells;
+            t.planeZc = planeSweepZc(b.own.nx, b.own.ny, b.own.nz);
+            MGPS_TRY(tmp.get(h, &t.chunkFlags, t.nfine));
+            if (t.planeZc) {
+                t.nplane = size_t((b.own.nx + 255) / 256) * size_t((b.own.ny + kPlaneRows - 1) / kPlaneRows) * size_t((b.own.nz + t.planeZc - 1) / t.planeZc);
+                MGPS_TRY(tmp.get(h, &t.planeFlags, t.nplane));
+                MGPS_HIP(h, hipMemsetAsync(t.planeFlags, 0, t.nplane, nullptr));
+            }
+            MGPS_LAUNCH(h, launchActivityFlags(nullptr, b.own, b.owned(), t.chunkFlags, t.planeFlags, t.planeZc));
+            if (t.planeZc) {  // (a block next to a cut with active cells only across it still takes part in the residual + restriction pair)
+                if (lo) MGPS_LAUNCH(h, launchGhostPlaneBlockFlags(nullptr, b.own, b.owned(), -1, t.planeZc, t.planeFlags));
+                if (hi) MGPS_LAUNCH(h, launchGhostPlaneBlockFlags(nullptr, b.own, b.owned(), b.own.nz, t.planeZc, t.planeFlags));
+            }
+            MGPS_TRY(tmp.get(h, &t.runCounts, 4));
+            MGPS_HIP(h, hipMemsetAsync(t.runCounts, 0, 4 * sizeof(int), nullptr));
+            MGPS_LAUNCH(h, launchCountRuns(nullptr, t.chunkFlags, t.nfine, t.runCounts));
+        }
+        // boxes of the fused band stage, clipped to the owned planes: counts
+        for (int l = 0; l < D && wantBoxes; ++l) {
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            if (!boxPlaneFits(b.d)) continue;
+            boxesOk[size_t(l)] = 1;
+            if (t.nbandExt == 0) continue;
+            MGPS_TRY(tmp.get(h, &t.boxTiles, size_t(t.nt)));
+            MGPS_LAUNCH(h, launchBoxTileList(nullptr, b.d, t.tileStart, t.tileFlags, t.tileRank, t.boxTiles, t.scan));
+            MGPS_HIP(h, hipMemcpy(&t.nBoxTiles, t.tileRank + t.nt, sizeof(int), hipMemcpyDeviceToHost));
+            for (int q = 0; q < 3; ++q) {
+                MGPS_TRY(tmp.get(h, &t.gcount[q], size_t(t.nBoxTiles)));
+                MGPS_TRY(tmp.get(h, &t.gat[q], size_t(t.nBoxTiles) + 1));
+            }
+            MGPS_LAUNCH(h, launchBandBoxesCount(nullptr, b.d, b.lab(), t.mask, t.prefix, t.tileStart, t.bandEntry, t.extDiag, depth, t.boxTiles, t.nBoxTiles, t.gcount,
+                                                flags + fBoxes + l, &t.win));
+            for (int q = 0; q < 3; ++q) MGPS_LAUNCH(h, launchExclusiveScan(nullptr, t.gcount[q], t.gat[q], size_t(t.nBoxTiles), t.scan));
+        }
+        // lists of the owned planes
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            int rc4[4] = {0, 0, 0, 0};
+            MGPS_HIP(h, hipMemcpy(rc4, t.runCounts, sizeof(rc4), hipMemcpyDeviceToHost));
+            const int64_t rc64[4] = {rc4[0], rc4[1], rc4[2], rc4[3]};
+            const int runCells = chooseRunCells(rc64);
+            const size_t nruns = (t.nfine + size_t(runCells / kSegCells) - 1) / size_t(runCells / kSegCells);
+            uint8_t *runFlags = t.chunkFlags;
+            if (runCells != kSegCells) {
+                MGPS_TRY(tmp.get(h, &runFlags, nruns));
+                MGPS_LAUNCH(h, launchFoldRunFlags(nullptr, t.chunkFlags, t.nfine, runCells, runFlags));
+            }
+            int activeRuns = 0;
+            for (int z = 0; z < 4; ++z)
+                if (kRunSizes[z] == runCells) activeRuns = rc4[z];
+            const int perGroup = kChunkCells / runCells, listLen = (activeRuns + perGroup - 1) / perGroup * perGroup;
+            {
+                int32_t *tmpFlags = nullptr, *rnk = nullptr, *base = nullptr;
+                MGPS_TRY(tmp.get(h, &tmpFlags, nruns));
+                MGPS_TRY(tmp.get(h, &rnk, nruns + 1));
+                MGPS_TRY(tmp.get(h, &base, 1));
+                MGPS_TRY(devAlloc(h, &L.chunks, size_t(listLen), false));
+                MGPS_LAUNCH(h, launchRunList(nullptr, b.own, runFlags, nruns, runCells, tmpFlags, rnk, t.scan, base, L.chunks, listLen));
+            }
+            MGPS_TRY(tmp.get(h, &t.listCounts, 5));
+            MGPS_HIP(h, hipMemsetAsync(t.listCounts, 0, 5 * sizeof(int32_t), nullptr));
+            {
+                const int tileOff = (b.elo / kTile) * t.tx * t.ty, ntOwn = t.tx * t.ty * ((b.own.nz + kTile - 1) / kTile);
+                const int tkOffset = ((z0 >> l) / kTile) & 1;  // (tile colours are the whole grid's; with Gauss-Seidel the cuts are multiples of 16 planes)
+                int32_t **cls[4] = {&L.pure[0], &L.pure[1], &L.mixed[0], &L.mixed[1]};
+                for (int q = 0; q < 4; ++q) {
+                    MGPS_TRY(devAlloc(h, cls[q], size_t(ntOwn) / 2 + 1, false));
+                    MGPS_LAUNCH(h, launchTileClassList(nullptr, b.own, t.tileKind + tileOff, q & 1, q >> 1, t.tileFlags, t.tileRank, *cls[q], t.scan, tkOffset));
+                    MGPS_HIP(h, hipMemcpyAsync(t.listCounts + q, t.tileRank + ntOwn, sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+                }
+                if (t.nplane) {
+                    int32_t *pf = nullptr, *pr = nullptr;
+                    MGPS_TRY(tmp.get(h, &pf, t.nplane));
+                    MGPS_TRY(tmp.get(h, &pr, t.nplane + 1));
+                    MGPS_TRY(devAlloc(h, &L.planeBlocks, t.nplane, false));
+                    MGPS_LAUNCH(h, launchByteList(nullptr, t.planeFlags, int(t.nplane), pf, pr, L.planeBlocks, t.scan));
+                    MGPS_HIP(h, hipMemcpyAsync(t.listCounts + 4, pr + t.nplane, sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+                }
+            }
+            t.runCells = runCells;
+            t.listLen = listLen;
+            if (l > 0) {
+                MGPS_TRY(gridAlloc(h, &L.x, L.d));
+                MGPS_TRY(gridAlloc(h, &L.b, L.d));
+            }
+            MGPS_TRY(gridAlloc(h, &L.r, L.d));
+            MGPS_TRY(gridAlloc(h, &L.tmp, L.d));
+        }
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            int32_t counts[5] = {0, 0, 0, 0, 0};
+            MGPS_HIP(h, hipMemcpy(counts, t.listCounts, sizeof(counts), hipMemcpyDeviceToHost));
+            L.npure[0] = counts[0];
+            L.npure[1] = counts[1];
+            L.nmixed[0] = counts[2];
+            L.nmixed[1] = counts[3];
+            t.nplaneBlocks = counts[4];
+        }
+        sclock.lap("slab: own lists");
+        // boxes: arrays
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            if (!boxesOk[size_t(l)] || t.nbandExt == 0) continue;
+            int tot[3] = {0, 0, 0}, brokenL = 0;
+            for (int q = 0; q < 3; ++q) MGPS_HIP(h, hipMemcpy(&tot[q], t.gat[q] + t.nBoxTiles, sizeof(int), hipMemcpyDeviceToHost));
+            MGPS_HIP(h, hipMemcpy(&brokenL, flags + fBoxes + l, sizeof(int), hipMemcpyDeviceToHost));
+            if (brokenL) {
+                boxesOk[size_t(l)] = 0;
+                continue;
+            }
+            L.bandBoxes.depth = depth;
+            L.bandBoxes.ngroups = tot[0];
+            L.bandBoxes.listCount = size_t(tot[1]);
+            L.bandBoxes.generalInts = 2 * size_t(tot[2]);
+            L.bandBoxes.anyGeneral = tot[2] > 0;
+            if (tot[0] == 0) continue;  // (no band-closure cell in the rank's planes)
+            MGPS_TRY(devAlloc(h, &L.bandBoxes.info, size_t(kBoxInfoInts) * size_t(tot[0]), false));
+            MGPS_TRY(devAlloc(h, &L.bandBoxes.list, size_t(tot[1]), false));
+            MGPS_TRY(devAlloc(h, &L.bandBoxes.general, 2 * size_t(tot[2]), false));
+            MGPS_LAUNCH(h, launchBandBoxesFill(nullptr, b.d, b.lab(), t.mask, t.prefix, t.tileStart, t.bandEntry, t.extDiag, depth, t.boxTiles, t.nBoxTiles, t.gat, L.bandBoxes.info,
+                                               L.bandBoxes.list, L.bandBoxes.general, flags + fBoxes + l, &t.win));
+            MGPS_TRY(finishBandBoxes(h, L, nullptr, &b.d));
+            // cells as offsets from owned cell 0 (a region below the owned planes starts at a negative one)
+            MGPS_LAUNCH(h, launchRebaseBoxes(nullptr, L.bandBoxes.info, L.bandBoxes.ngroups, int32_t(size_t(b.elo) * size_t(b.d.nx) * b.d.ny)));
+            MGPS_HIP(h, hipMemcpy(&brokenL, flags + fBoxes + l, sizeof(int), hipMemcpyDeviceToHost));
+            if (brokenL) boxesOk[size_t(l)] = 0;
+        }
+        MGPS_HIP(h, hipDeviceSynchronize());
+        sclock.lap("slab: band boxes");
+        return MGPS_OK;
+    }();
+    // ---- every rank takes the same form of the band stage on a level; every rank knows whether all are still fine
+    {
+        std::vector<double> v(size_t(D) + 1, 0.0);
+        for (int l = 0; l < D; ++l) v[size_t(l)] = boxesOk[size_t(l)] ? 0.0 : 1.0;
+        v[size_t(D)] = double(status);
+        if (h->comm.allreduce(h->comm.user, v.data(), int(v.size()), 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+        if (int(v[size_t(D)]) != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, int(v[size_t(D)]), "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : int(v[size_t(D)]));
+        }
+        for (int l = 0; l < D; ++l) h->lv[size_t(l)].boxForm = v[size_t(l)] == 0.0;
+    }
+    // ---- level descriptions; the cells the neighbours' planes must deliver; the index lists traded
+    const int G = h->ghost;
+    auto keepBuffer = [&](int l) {  // the label buffer of level l leaves the scratch set: the level's codes (allocation base: the spare plane in front)
+        h->lv[size_t(l)].codes = B[size_t(l)].base;
+        for (auto it = tmp.ptrs.begin(); it != tmp.ptrs.end(); ++it)
+            if (*it == B[size_t(l)].base) {
+                tmp.ptrs.erase(it);
+                break;
+            }
+    };
+    std::vector<int32_t *> wantDev(size_t(2 * D), nullptr);  // per level and side: the rank's request in the neighbour's own cell offsets
+    int32_t *countsDev = nullptr;                             // per level: [my lo request, my hi request, lo neighbour's request, hi neighbour's request]
+    status = [&]() -> int {
+        MGPS_TRY(tmp.get(h, &countsDev, size_t(4 * D)));
+        std::vector<int32_t> hc(size_t(4 * D), 0);
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            LevelTmp &t = T[size_t(l)];
+            const Buf &b = B[size_t(l)];
+            const size_t plane = size_t(b.d.nx) * b.d.ny;
+            keepBuffer(l);  // (the label buffer is the level's codes from here on)
+            fillGridP(h, L, l == 0, t.listLen, t.runCells, t.nplaneBlocks, t.planeZc);
+            L.g.lab = b.owned();
+            L.g.ghostLo = lo ? 1 : 0;
+            L.g.ghostHi = hi ? 1 : 0;
+            L.gBox = L.g;
+            L.gBox.rows = L.extRows;
+            L.gBox.nbnd = t.nGenExt;
+            if (!L.boxForm) {  // (per-pass band smoothing on this level: no boxes kept)
+                (void)cacheFree(L.bandBoxes.info);
+                (void)cacheFree(L.bandBoxes.list);
+                (void)cacheFree(L.bandBoxes.general);
+                L.bandBoxes = BandBoxesDev{};
+                continue;
+            }
+            L.bandBoxes.depth = depth;
+            uint8_t *mk[2] = {nullptr, nullptr};
+            int32_t *fl = nullptr, *rk = nullptr;
+            const size_t zone = size_t(G) * plane;
+            int *brokenDev = flags + fBoxes + l;
+            for (int q = 0; q < 2; ++q) {
+                MGPS_TRY(tmp.get(h, &mk[q], zone));
+                MGPS_HIP(h, hipMemsetAsync(mk[q], 0, zone, nullptr));
+            }
+            MGPS_LAUNCH(h, launchHaloMark(nullptr, b.d.nx, b.d.ny, b.own.nz, G, L.bandBoxes.info, L.bandBoxes.list, L.bandBoxes.ngroups, mk[0], mk[1], brokenDev));
+            MGPS_TRY(tmp.get(h, &fl, zone));
+            MGPS_TRY(tmp.get(h, &rk, zone + 1));
+            for (int q = 0; q < 2; ++q) {
+                const bool nb = q == 0 ? lo : hi;
+                if (!nb) continue;  // (no neighbour: beyond the grid, EXTERIOR -- nothing is read there)
+                int32_t *list = nullptr;
+                MGPS_TRY(tmp.get(h, &list, zone));
+                MGPS_LAUNCH(h, launchByteList(nullptr, mk[q], int(zone), fl, rk, list, t.scan));
+                int n = 0;
+                MGPS_HIP(h, hipMemcpy(&n, rk + zone, sizeof(int), hipMemcpyDeviceToHost));
+                L.halo.nrecv[q] = n;
+                MGPS_TRY(devAlloc(h, &L.halo.recvIdx[q], size_t(n), false));
+                MGPS_HIP(h, hipMemcpyAsync(L.halo.recvIdx[q], list, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+                // the same cells as the neighbour counts them: below, its top planes (nzNb - G .. nzNb - 1); above, its planes 0 .. G - 1
+                const int nzNb = q == 0 ? (splits[rank] - splits[rank - 1]) >> l : 0;
+                MGPS_TRY(tmp.get(h, &wantDev[size_t(2 * l + q)], size_t(n)));
+                MGPS_LAUNCH(h, launchAddInt(nullptr, wantDev[size_t(2 * l + q)], list, n, q == 0 ? int32_t(size_t(nzNb - G) * plane) : 0));
+                hc[size_t(4 * l + q)] = n;
+            }
+            int brokenL = 0;
+            MGPS_HIP(h, hipMemcpy(&brokenL, brokenDev, sizeof(int), hipMemcpyDeviceToHost));
+            if (brokenL) return failH(h, MGPS_ERR_INTERNAL, "slab set-up: a box region reaches past the ghost planes on level " + std::to_string(l));
+        }
+        // what the neighbours ask of this rank: until a transport says otherwise, the mirror image of the rank's own request (the
+        // compute-bound tools run with a transport that moves nothing)
+        for (int l = 0; l < D; ++l) {
+            hc[size_t(4 * l + 2)] = hc[size_t(4 * l + 1)];
+            hc[size_t(4 * l + 3)] = hc[size_t(4 * l + 0)];
+        }
+        MGPS_HIP(h, hipMemcpy(countsDev, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        return MGPS_OK;
+    }();
+    {
+        int all = MGPS_OK;
+        const int rc = agree(status, &all);
+        if (rc != MGPS_OK) return bail(rc);
+        if (all != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, all, "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : all);
+        }
+    }
+    // counts first (one int per level and side), then the lists
+    std::vector<int32_t> hc(size_t(4 * D), 0);
+    for (int l = 0; l < D && P > 1; ++l) {
+        int32_t *c = countsDev + 4 * l;
+        if (h->comm.exchange(h->comm.user, lo ? c : nullptr, sizeof(int32_t), lo ? c + 2 : nullptr, sizeof(int32_t), hi ? c + 1 : nullptr, sizeof(int32_t), hi ? c + 3 : nullptr,
+                             sizeof(int32_t), nullptr) != 0)
+            return bail(failH(h, MGPS_ERR_COMM, "halo list counts: exchange failed"));
+    }
+    status = [&]() -> int {
+        MGPS_HIP(h, hipMemcpy(hc.data(), countsDev, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            if (!L.boxForm) continue;
+            const size_t plane = size_t(L.d.nx) * L.d.ny;
+            for (int q = 0; q < 2; ++q) {
+                const bool nb = q == 0 ? lo : hi;
+                if (!nb) continue;
+                const int n = hc[size_t(4 * l + 2 + q)];
+                if (n < 0 || size_t(n) > size_t(G) * plane) return failH(h, MGPS_ERR_COMM, "halo list counts: a neighbour asked for more cells than the ghost planes hold");
+                L.halo.nsend[q] = n;
+                MGPS_TRY(devAlloc(h, &L.halo.sendIdx[q], size_t(n), false));
+                // (the default: the mirror image of the other side's request)
+                const int other = 1 - q, no = hc[size_t(4 * l + other)];
+                if (no == n && wantDev[size_t(2 * l + other)])
+                    MGPS_LAUNCH(h, launchAddInt(nullptr, L.halo.sendIdx[q], L.halo.recvIdx[other], n, q == 0 ? 0 : int32_t(size_t(L.d.nz - G) * plane)));
+                else if (n > 0)
+                    MGPS_HIP(h, hipMemsetAsync(L.halo.sendIdx[q], 0, size_t(n) * sizeof(int32_t), nullptr));
+                MGPS_TRY(devAlloc(h, &L.halo.sendBuf[q], 2 * size_t(n), true));
+                MGPS_TRY(devAlloc(h, &L.halo.recvBuf[q], 2 * size_t(L.halo.nrecv[q]), true));
+            }
+        }
+        MGPS_HIP(h, hipDeviceSynchronize());
+        return MGPS_OK;
+    }();
+    {
+        int all = MGPS_OK;
+        const int rc = agree(status, &all);
+        if (rc != MGPS_OK) return bail(rc);
+        if (all != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, all, "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : all);
+        }
+    }
+    for (int l = 0; l < D && P > 1; ++l) {
+        DevLevel &L = h->lv[size_t(l)];
+        if (!L.boxForm) continue;
+        const DevLevel::BoxHalo &H = L.halo;
+        if (h->comm.exchange(h->comm.user, lo ? wantDev[size_t(2 * l)] : nullptr, size_t(H.nrecv[0]) * sizeof(int32_t), lo ? H.sendIdx[0] : nullptr,
+                             size_t(H.nsend[0]) * sizeof(int32_t), hi ? wantDev[size_t(2 * l + 1)] : nullptr, size_t(H.nrecv[1]) * sizeof(int32_t),
+                             hi ? H.sendIdx[1] : nullptr, size_t(H.nsend[1]) * sizeof(int32_t), nullptr) != 0)
+            return bail(failH(h, MGPS_ERR_COMM, "halo lists: exchange failed"));
+    }
+    status = [&]() -> int {
+        // what a neighbour asked for must lie in this rank's planes
+        int *bad = flags;
+        MGPS_HIP(h, hipMemsetAsync(bad, 0, sizeof(int), nullptr));
+        for (int l = 0; l < D; ++l) {
+            DevLevel &L = h->lv[size_t(l)];
+            for (int q = 0; q < 2; ++q) MGPS_LAUNCH(h, launchCheckIndex(nullptr, L.halo.sendIdx[q], L.halo.nsend[q], int32_t(L.d.cells()), bad));
+        }
+        int hbad = 0;
+        MGPS_HIP(h, hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost));
+        if (hbad) return failH(h, MGPS_ERR_COMM, "halo lists: a neighbour asked for cells outside this rank's planes");
+        // the collapse level on this rank: its owned planes (labels, activity runs) and the two grids the collapse moves
+        DevLevel &C = h->lv[size_t(D)];
+        const Buf &b = B[size_t(D)];
+        C.d = b.own;
+        C.z0 = z0 >> D;
+        C.z1 = z1 >> D;
+        C.elo = b.elo;
+        if (D == Dmax) MGPS_LAUNCH(h, launchMarkBoundary(nullptr, b.d, b.lab()));  // (levels below Dmax were marked with the others)
+        {
+            const size_t nfine = (b.own.cells() + kSegCells - 1) / kSegCells;
+            uint8_t *cf = nullptr;
+            int *rcnt = nullptr;
+            MGPS_TRY(tmp.get(h, &cf, nfine));
+            MGPS_TRY(tmp.get(h, &rcnt, 4));
+            MGPS_HIP(h, hipMemsetAsync(rcnt, 0, 4 * sizeof(int), nullptr));
+            MGPS_LAUNCH(h, launchActivityFlags(nullptr, b.own, b.owned(), cf, nullptr, 0));
+            MGPS_LAUNCH(h, launchCountRuns(nullptr, cf, nfine, rcnt));
+            int rc4[4] = {0, 0, 0, 0};
+            MGPS_HIP(h, hipMemcpy(rc4, rcnt, sizeof(rc4), hipMemcpyDeviceToHost));
+            const int64_t rc64[4] = {rc4[0], rc4[1], rc4[2], rc4[3]};
+            const int runCells = chooseRunCells(rc64);
+            const size_t nruns = (nfine + size_t(runCells / kSegCells) - 1) / size_t(runCells / kSegCells);
+            uint8_t *runFlags = cf;
+            if (runCells != kSegCells) {
+                MGPS_TRY(tmp.get(h, &runFlags, nruns));
+                MGPS_LAUNCH(h, launchFoldRunFlags(nullptr, cf, nfine, runCells, runFlags));
+            }
+            int activeRuns = 0;
+            for (int z = 0; z < 4; ++z)
+                if (kRunSizes[z] == runCells) activeRuns = rc4[z];
+            const int perGroup = kChunkCells / runCells, listLen = (activeRuns + perGroup - 1) / perGroup * perGroup;
+            int32_t *tmpFlags = nullptr, *rnk = nullptr, *base = nullptr, *scan = nullptr;
+            MGPS_TRY(tmp.get(h, &tmpFlags, nruns));
+            MGPS_TRY(tmp.get(h, &rnk, nruns + 1));
+            MGPS_TRY(tmp.get(h, &base, 1));
+            MGPS_TRY(tmp.get(h, &scan, scanScratchInts(b.d.cells())));
+            MGPS_TRY(devAlloc(h, &C.chunks, size_t(listLen), false));
+            MGPS_LAUNCH(h, launchRunList(nullptr, b.own, runFlags, nruns, runCells, tmpFlags, rnk, scan, base, C.chunks, listLen));
+            MGPS_TRY(gridAlloc(h, &C.x, C.d));
+            MGPS_TRY(gridAlloc(h, &C.b, C.d));
+            keepBuffer(D);
+            fillGridP(h, C, false, listLen, runCells, 0, 0);
+            C.g.lab = b.owned();
+            C.g.ghostLo = lo ? 1 : 0;
+            C.g.ghostHi = hi ? 1 : 0;
+        }
+        MGPS_HIP(h, hipDeviceSynchronize());
+        return MGPS_OK;
+    }();
+    sclock.lap("slab: halo lists + collapse level");
+    if (status == MGPS_OK) status = commonDeviceState(h, false);
+    {
+        int all = MGPS_OK;
+        const int rc = agree(status, &all);
+        if (rc != MGPS_OK) return bail(rc);
+        if (all != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, all, "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : all);
+        }
+    }
+    // ---- the collapsed tail on rank 0: the collapse level's labels of all ranks, then the whole-grid builder
+    int tailRc = MGPS_OK;
+    {
+        const DevLevel &C = h->lv[size_t(D)];
+        const Dims cg{nx >> D, ny >> D, nzg >> D};
+        const size_t planeC = size_t(cg.nx) * cg.ny, mine = C.d.cells();
+        uint8_t *all = nullptr;
+        if (rank == 0 && devAlloc(h, &all, cg.cells(), false) != MGPS_OK) tailRc = MGPS_ERR_ALLOC;
+        bool uniform = true;
+        for (int r = 1; r < P; ++r) uniform = uniform && (splits[r + 1] - splits[r]) == (splits[1] - splits[0]);
+        int crc = 0;
+        if (uniform) crc = h->comm.gather(h->comm.user, C.g.lab, rank == 0 ? all : nullptr, mine, 0, nullptr);
+        else {
+            std::vector<size_t> counts, displs;
+            for (int r = 0; r < P; ++r) {
+                displs.push_back(size_t(splits[r] >> D) * planeC);
+                counts.push_back(size_t((splits[r + 1] - splits[r]) >> D) * planeC);
+            }
+            crc = h->comm.gatherv(h->comm.user, C.g.lab, mine, rank == 0 ? all : nullptr, counts.data(), displs.data(), 0, nullptr);
+        }
+        if (crc != 0) {
+            (void)cacheFree(all);
+            return bail(failH(h, MGPS_ERR_COMM, "collapse level labels: gather failed"));
+        }
+        if (rank == 0 && tailRc == MGPS_OK) {
+            (void)hipStreamSynchronize(nullptr);
+            tailRc = [&]() -> int {
+                int trc = createWholeOnDevice(&h->tail, cg.nx, cg.ny, cg.nz, all, nullptr, nullptr, nullptr, hipMemcpyDeviceToDevice, levels - D, useGS, o, device, true);
+                if (trc != MGPS_OK) return failH(h, trc, std::string("collapsed tail: ") + lastGlobalError());
+                trc = gridAlloc(h->tail, &h->tailX, cg);
+                if (trc == MGPS_OK) trc = gridAlloc(h->tail, &h->tailB, cg);
+                if (trc != MGPS_OK) return trc;
+                h->tail->userGrids.push_back(h->tailX - planeC);
+                h->tail->userGrids.push_back(h->tailB - planeC);
+                if (hipDeviceSynchronize() != hipSuccess) return failH(h, MGPS_ERR_HIP, "device synchronize failed");
+                return MGPS_OK;
+            }();
+        }
+        (void)hipDeviceSynchronize();
+        (void)cacheFree(all);
+    }
+    sclock.lap("slab: tail");
+    {  // every rank leaves with the same verdict, and with the number of levels the tail ended with (the level cap below the collapse level)
+        double v[2] = {double(tailRc), rank == 0 && h->tail ? double(h->tail->totalLevels) : 0.0};
+        if (h->comm.allreduce(h->comm.user, v, 2, 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+        if (int(v[0]) != MGPS_OK) {
+            if (tailRc == MGPS_OK) failH(h, int(v[0]), "the collapsed tail could not be built on rank 0 (status " + std::to_string(int(v[0])) + ")");
+            return bail(tailRc != MGPS_OK ? tailRc : int(v[0]));
+        }
+        if (int(v[1]) >= 1) levels = D + int(v[1]);  // (a transport that moves nothing leaves the other ranks with what they asked for)
+    }
+    h->totalLevels = levels;
+    {
+        const int rcLight = hierarchyLight(&h->hier, nx, ny, nzg, levels, nullptr, o, false);
+        if (rcLight != MGPS_OK) return bail(failH(h, rcLight, lastGlobalError()));
+    }
+    *out = h;
+    return MGPS_OK;
+}
+
 // weightsOnDevice: wx_slab / wy_slab / wz_slab are DEVICE arrays (the field passes of mgps_fields.h leave them there): nothing of
 // their 12 B per cell crosses PCIe -- at 1024^3 / 8 ranks the 1.6 GB of a slab's weights coming from pageable host memory were
 // 300 of the 470 ms a rank's set-up took -- and the operator rows of the slab's BOUNDARY cells are evaluated by
@@ -3130,15 +3866,15 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
     if (o.precision != 0) return failH(nullptr, MGPS_ERR_INVALID_ARGUMENT, "mgps_create_slab: options.precision = 1 is for single-device solvers");
     int device = 0;
     MGPS_TRY(pickDevice(o, &device));
+    // the default since round 5: everything on the device, from the rank's window of the labels (createSlabOnDevice).  What follows is
+    // the host builder (options.host_setup = 1): the checker of the device arrays, with the band stage pass by pass on cut levels
+    if (!hostSetup(o))
+        return createSlabOnDevice(out, nx, ny, nz_global, labels_global_host, wx_slab, wy_slab, wz_slab, weightsOnDevice, mg_levels, use_gauss_seidel != 0, o, comm, splits, device);
     StageClock sclock(setupTimingOn());
     mgps_hierarchy *hier = nullptr;
     {  // the rank's window of the hierarchy: labels of every level, band lists around its slab only
-        static const bool windowedSetup = [] {  // MGPS_SLAB_WINDOW=0: band lists of the whole grid on every rank (rounds 1-2; A/B)
-            const char *e = getenv("MGPS_SLAB_WINDOW");
-            return !(e && e[0] == '0');
-        }();
         const int window[2] = {splits[rank], splits[rank + 1]};
-        MGPS_TRY(hierarchyCreate(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o, false, true, (windowedSetup && P > 1) ? window : nullptr));
+        MGPS_TRY(hierarchyCreate(&hier, nx, ny, nz_global, labels_global_host, mg_levels, &o, false, true, P > 1 ? window : nullptr));
     }
     sclock.lap("slab: host hierarchy");
     // distributed levels (distributedLevelsFor); the last level is always collapsed
@@ -3158,27 +3894,6 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
     h->comm = mgps_comm{};
     std::memcpy(&h->comm, comm, size_t(comm->struct_size));  // (struct_size bytes are the caller's; the rest stays NULL)
     h->comm.struct_size = int(sizeof(mgps_comm));
-    {
-        // Exchanges beside the sweeps (see sweepSplit) on levels whose planes are at least 1 MiB (sweepSplittable; the 1024^2 and
-        // 512^2 levels of a 1024^3 run).  Decided from the null-transport costs (round 4; off in rounds 2-3): on one GPU the split
-        // launches and the two event hops cost the slowest rank of 8 0.07 ms of a 1.75 ms cycle at 1024^3 (rank 0: 0.23 ms, its
-        // two half-size launches no longer fill the chip; 0.15-0.27 ms at 2 and 4 ranks) against the transfers they take off the
-        // critical path -- nine per cycle and level, 27 us each for a 4 MiB plane at 150 GB/s per xGMI link plus the collective's
-        // own 6-7 us: 0.3-0.6 ms.  A smaller plane crosses a link in less than the two hops cost, so those levels keep the
-        // solver's stream.  MGPS_OVERLAP=0 turns it off (A/B on real links).
-        static const bool overlap = [] {
-            const char *e = getenv("MGPS_OVERLAP");
-            return !(e && e[0] == '0');
-        }();
-        if (overlap && P > 1 &&
-            (hipStreamCreateWithFlags(&h->commStream, hipStreamNonBlocking) != hipSuccess ||
-             hipEventCreateWithFlags(&h->evEdge, hipEventDisableTiming) != hipSuccess ||
-             hipEventCreateWithFlags(&h->evComm, hipEventDisableTiming) != hipSuccess)) {
-            (void)hipGetLastError();
-            if (h->commStream) (void)hipStreamDestroy(h->commStream);
-            h->commStream = nullptr;  // (no overlap then)
-        }
-    }
     h->splits.assign(splits, splits + P + 1);
     h->distLevels = D;
     h->totalLevels = hier->levels;
@@ -3204,6 +3919,7 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
     sclock.lap("slab: weights");
     // device weights: the rows of the slab's BOUNDARY cells (band order) from a kernel over the slab's labels + ghost planes
     std::vector<float> rows0;
+    int rowsRc = MGPS_OK;
     if (weightsOnDevice) {
         const HostLevel &G = hier->lv[0];
         const size_t plane = size_t(nx) * ny;
@@ -3236,9 +3952,17 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
         (void)cacheFree(cellsDev);
         (void)cacheFree(rowsDev);
         (void)cacheFree(violDev);
-        if (e != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string("mgps_create_slab (device weights): ") + hipGetErrorString(e)));
-        if (violations != 0)
-            return bail(failH(h, MGPS_ERR_HIERARCHY, "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels"));
+        if (e != hipSuccess) rowsRc = failH(h, MGPS_ERR_HIP, std::string("mgps_create_slab (device weights): ") + hipGetErrorString(e));
+        else if (violations != 0)
+            rowsRc = failH(h, MGPS_ERR_HIERARCHY, "labels/weights violate the BOUNDARY-cell rules (unitTestBoundaryCells): run mgps_fields_set_boundary_labels");
+    }
+    {  // every rank leaves together: one with bad labels or weights must not leave the others waiting in the collectives below
+        double v = double(rowsRc);
+        if (h->comm.allreduce(h->comm.user, &v, 1, 1) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
+        if (int(v) != MGPS_OK) {
+            if (rowsRc == MGPS_OK) failH(h, int(v), "slab set-up failed on another rank");
+            return bail(rowsRc != MGPS_OK ? rowsRc : int(v));
+        }
     }
     sclock.lap("slab: fine rows");
     h->lv.resize(D + 1);
@@ -3253,85 +3977,6 @@ int createSlabImpl(mgps_solver **out, int nx, int ny, int nz_global, const uint8
         if (rc != MGPS_OK) return bail(rc);
         (void)hipDeviceSynchronize();
         sclock.lap("slab: upload level", l);
-        if (l == D || P == 1 || !o.deep_band_halo || o.band_iterations < 1 || o.band_iterations > kBandMaxDepth) continue;
-        // The neighbours' band cells near a cut are recomputed here, so their operator rows are needed: on the
-        // unit-weight levels (and on an all-simple fine level) the labels give them; otherwise the ranks
-        // trade the rows of their `band_iterations` planes next to each cut once, now (collective).
-        std::vector<float> foreignRows;
-        bool haveForeign = false;
-        if (l == 0) {
-            double general = double(HL.numBoundary);
-            if (h->comm.allreduce(h->comm.user, &general, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
-            if (general != 0.0) {
-                const int depth = o.band_iterations;
-                const bool lo = rank > 0, hi = rank < P - 1;
-                std::vector<float> send[2], recv[2];
-                if (lo) slabBandRows(hier->lv[0], HL, lz0, lz0, 1, depth, send[0]);
-                if (hi) slabBandRows(hier->lv[0], HL, lz0, lz1 - 1, -1, depth, send[1]);
-                size_t nrecv[2] = {0, 0}, nghost[2] = {0, 0};
-                for (int q = 1; lo && q <= depth; ++q) nrecv[0] += bandCellsInPlane(hier->lv[0], lz0 - q);
-                for (int q = 0; hi && q < depth; ++q) nrecv[1] += bandCellsInPlane(hier->lv[0], lz1 + q);
-                if (lo) nghost[0] = bandCellsInPlane(hier->lv[0], lz0 - 1);
-                if (hi) nghost[1] = bandCellsInPlane(hier->lv[0], lz1);
-                float *sd[2] = {nullptr, nullptr}, *rd[2] = {nullptr, nullptr};
-                for (int q = 0; q < 2; ++q) {
-                    recv[q].resize(nrecv[q] * 8);
-                    rc = devUpload(h, &sd[q], send[q]);
-                    if (rc == MGPS_OK) rc = devAlloc(h, &rd[q], recv[q].size(), true);
-                    if (rc != MGPS_OK) return bail(rc);
-                }
-                (void)hipStreamSynchronize(h->stream);
-                const int crc = h->comm.exchange(h->comm.user, lo ? sd[0] : nullptr, send[0].size() * sizeof(float), lo ? rd[0] : nullptr,
-                                                 recv[0].size() * sizeof(float), hi ? sd[1] : nullptr, send[1].size() * sizeof(float),
-                                                 hi ? rd[1] : nullptr, recv[1].size() * sizeof(float), h->stream);
-                hipError_t e = hipStreamSynchronize(h->stream);
-                for (int q = 0; q < 2 && e == hipSuccess; ++q)
-                    if (!recv[q].empty()) e = hipMemcpy(recv[q].data(), rd[q], recv[q].size() * sizeof(float), hipMemcpyDeviceToHost);
-                for (int q = 0; q < 2; ++q) {
-                    (void)cacheFree(sd[q]);
-                    (void)cacheFree(rd[q]);
-                }
-                if (crc != 0) return bail(failH(h, MGPS_ERR_COMM, "row exchange failed during set-up"));
-                if (e != hipSuccess) return bail(failH(h, MGPS_ERR_HIP, std::string("row exchange: ") + hipGetErrorString(e)));
-                // storage order of buildSlabHalo: ghost below, ghost above, deeper below, deeper above
-                for (int q = 0; q < 2; ++q) foreignRows.insert(foreignRows.end(), recv[q].begin(), recv[q].begin() + ptrdiff_t(nghost[q] * 8));
-                for (int q = 0; q < 2; ++q) foreignRows.insert(foreignRows.end(), recv[q].begin() + ptrdiff_t(nghost[q] * 8), recv[q].end());
-                haveForeign = true;
-            }
-        }
-        SlabHalo SH;
-        buildSlabHalo(hier->lv[l], HL, lz0, lz1, o.band_iterations, SH, haveForeign ? &foreignRows : nullptr);
-        double failed = SH.depth == 0 ? 1.0 : 0.0;  // every rank must take the same form of the stage
-        if (h->comm.allreduce(h->comm.user, &failed, 1, 0) != 0) return bail(failH(h, MGPS_ERR_COMM, "all-reduce failed during set-up"));
-        if (failed != 0.0) continue;
-        DevLevel::Halo &H = h->lv[l].halo;
-        const size_t plane = size_t(nx) * ny >> (2 * l);
-        for (int q = 0; q < 2; ++q) {
-            H.nsend[q] = int(SH.sendIdx[q].size());
-            H.nrecv[q] = SH.nrecv[q];
-            rc = devUpload(h, &H.sendIdx[q], SH.sendIdx[q]);
-            if (rc == MGPS_OK) rc = devAlloc(h, &H.sendBuf[q], plane + 2 * SH.sendIdx[q].size() + HL.bandPlane[2 * q].size(), true);
-            if (rc == MGPS_OK) rc = devAlloc(h, &H.recvBuf[q], plane + 2 * size_t(SH.nrecv[q]) + HL.bandPlane[2 * q + 1].size(), true);
-            if (rc != MGPS_OK) return bail(rc);
-        }
-        rc = devAlloc(h, &H.hx, size_t(SH.nrecv[0]) + SH.nrecv[1], true);
-        if (rc == MGPS_OK) rc = devAlloc(h, &H.hb, size_t(SH.nrecv[0]) + SH.nrecv[1], true);
-        if (rc == MGPS_OK) rc = devUpload(h, &H.bandExt, SH.bandExt);
-        if (rc == MGPS_OK) rc = devAlloc(h, &H.tmpExt, SH.bandExt.size(), true);
-        if (rc == MGPS_OK && SH.nForeign > 0) rc = devUpload(h, &H.frows, SH.foreignRows);
-        H.nForeign = SH.nForeign;
-        H.nbandExt = int(SH.bandExt.size());
-        H.groups.depth = SH.groups.depth;
-        H.groups.ngroups = int(SH.groups.groups());
-        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.info, SH.groups.info);
-        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.updateEntry, SH.groups.updateEntry);
-        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.updateCell, SH.groups.updateCell);
-        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.readCell, SH.groups.readCell);
-        if (rc == MGPS_OK) rc = devUpload(h, &H.groups.neighbours, SH.groups.neighbours);
-        if (rc != MGPS_OK) return bail(rc);
-        H.depth = SH.depth;
-        (void)hipDeviceSynchronize();
-        sclock.lap("slab: halo groups", l);
     }
     int rc = commonDeviceState(h, false);
     if (rc != MGPS_OK) return bail(rc);
@@ -3470,7 +4115,15 @@ try {
 }
 MGPS_API_CATCH(h)
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
-int64_t mgps_overlapped_exchanges(const mgps_solver *h) { return h ? h->overlappedExchanges : 0; }
+int mgps_ghost_planes(const mgps_solver *h) { return h ? h->ghost : 1; }
+int mgps_band_stage_form(const mgps_solver *h, int level, int *form)
+try {
+    if (!h || !form || level < 0 || level >= int(h->lv.size())) return MGPS_ERR_INVALID_ARGUMENT;
+    *form = levelHasBoxes(h, level) ? 1 : 0;
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
+int64_t mgps_overlapped_exchanges(const mgps_solver *) { return 0; }  // (round 5: every exchange runs on the solver's stream until a first run on real links)
 int64_t mgps_exchange_count(const mgps_solver *h) { return h ? h->exchanges : 0; }
 
 int mgps_level_dims(const mgps_solver *h, int level, int out_dims[3])
@@ -3517,7 +4170,7 @@ try {
     MGPS_TRY(checkLevel(h, level, "mgps_grid_alloc"));
     if (!out_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_grid_alloc: out is NULL");
     MGPS_TRY(gridAlloc(h, out_dev, h->lv[level].d));
-    h->userGrids.push_back(*out_dev - size_t(h->lv[level].d.nx) * h->lv[level].d.ny);
+    h->userGrids.push_back(*out_dev - size_t(h->ghost) * size_t(h->lv[level].d.nx) * h->lv[level].d.ny);
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)
@@ -3527,7 +4180,7 @@ try {
     MGPS_TRY(checkLevel(h, 0, "mgps_grid_free"));
     for (auto it = h->userGrids.begin(); it != h->userGrids.end(); ++it)
         for (const DevLevel &L : h->lv)
-            if (static_cast<float *>(*it) + size_t(L.d.nx) * L.d.ny == dev) {
+            if (static_cast<float *>(*it) + size_t(h->ghost) * size_t(L.d.nx) * L.d.ny == dev) {
                 void *base = *it;
                 h->userGrids.erase(it);
                 MGPS_HIP(h, hipStreamSynchronize(h->stream));

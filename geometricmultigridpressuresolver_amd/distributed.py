@@ -334,10 +334,12 @@ class SlabSolver(GeometricMultigridPoissonSolver):
     def distributed_levels(self):
         return lib().mgps_distributed_levels(self.h)
 
-    @property
-    def overlapped_exchanges(self):
-        lib().mgps_overlapped_exchanges.restype = C.c_int64
-        return lib().mgps_overlapped_exchanges(self.h)
+    def band_stage_form(self, level):
+        """how the band stage of a distributed level runs: "boxes" (one launch per stage; on a cut level two list messages per
+        stroke) or "passes" (a launch pair and an exchange per band pass)"""
+        form = C.c_int()
+        check(lib().mgps_band_stage_form(self.h, int(level), C.byref(form)), self.h)
+        return {0: "passes", 1: "boxes"}[form.value]
 
     @property
     def exchange_count(self):
@@ -349,10 +351,16 @@ class SlabSolver(GeometricMultigridPoissonSolver):
         check(lib().mgps_slab_range(self.h, level, C.byref(z0), C.byref(z1)), self.h)
         return z0.value, z1.value
 
+    @property
+    def ghost_planes(self):
+        """planes every grid of this solver carries below and above its owned ones (mgps_ghost_planes)"""
+        return int(lib().mgps_ghost_planes(self.h))
+
     def new_grid(self, level=0):
         nz, ny, nx = self.level_shape(level)
-        padded = torch.zeros((nz + 2, ny, nx), dtype=torch.float32, device=self.device)
-        return padded[1:-1]  # contiguous view; the storage keeps the ghost planes alive
+        g = self.ghost_planes
+        padded = torch.zeros((nz + 2 * g, ny, nx), dtype=torch.float32, device=self.device)
+        return padded[g:-g]  # contiguous view; the storage keeps the ghost planes alive
 
     def to_device(self, a, level=0):
         g = self.new_grid(level)

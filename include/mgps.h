@@ -441,6 +441,15 @@ int mgps_create_slab_device_weights(mgps_solver **out, int nx, int ny, int nz_gl
  * of the collapse level) and the number of distributed levels */
 int mgps_slab_range(const mgps_solver *h, int level, int *z0, int *z1);
 int mgps_distributed_levels(const mgps_solver *h);
+/* Planes every grid handed to this solver must carry below and above its owned planes (mgps_grid_alloc provides them): 1 for a
+ * single-device solver (unused) and for a slab rank built on the host (the ghost plane); 5 for a slab rank set up on the device
+ * (the default since round 5): besides the ghost plane the neighbours' cells that the band boxes next to a cut read live there,
+ * up to band_iterations + 1 planes deep.  A caller that allocates slab grids itself (the Python front end does) pads by this. */
+int mgps_ghost_planes(const mgps_solver *h);
+/* how the band stage (the `band_iterations` boundary-Jacobi passes of Ops.h:524-619 around a full-domain sweep) of level `level`
+ * runs: *form = 1: the box form (one launch per stage; on a cut level of a slab run with two list messages per stroke), 0: pass by
+ * pass (a launch pair per pass, on cut levels an exchange per pass).  The same arithmetic per cell either way. */
+int mgps_band_stage_form(const mgps_solver *h, int level, int *form);
 /* slab runs: how many ghost exchanges so far were queued on the transfer stream, beside the interior part of the sweep that
  * produced their planes (the default on levels with planes >= 1 MiB since round 4, MGPS_OVERLAP=0 turns it off; 0 on
  * single-device solvers) */

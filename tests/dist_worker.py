@@ -39,6 +39,44 @@ def scene_domain(gz, levels, eshape):
     return lab.astype(np.uint8), [a.astype(np.float32) for a in w], offset, lev, sc["dx"]
 
 
+def compare_with_host_builder(slab, lab, slab_w, lev, use_gs, opt, what):
+    """The rank's own lists as the device built them (createSlabOnDevice: cut out of the lists of its label buffer) against the
+    host builder's (options.host_setup = 1: buildSlabLevel over the global hierarchy): codes, band list with diagonals and rows,
+    activity runs, plane blocks, Gauss-Seidel tiles -- array_equal where the rank's planes start on a tile of the whole grid
+    (the band list is in tile order), equal as sets otherwise."""
+    import copy
+
+    from geometricmultigridpressuresolver_amd.distributed import SlabSolver, TorchDistComm
+
+    oh = copy.copy(opt)
+    oh.host_setup = 1
+    host = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=oh, splits=slab.splits)
+    try:
+        assert host.ghost_planes == 1 and host.distributed_levels == slab.distributed_levels
+        for l in range(slab.distributed_levels):
+            z0, _ = slab.slab_range(l)
+            aligned = z0 % 16 == 0
+            for name in ("codes", "chunks", "plane_blocks"):
+                assert np.array_equal(slab.level_array(l, name), host.level_array(l, name)), (what, l, name)
+            bd, bh = slab.level_array(l, "band"), host.level_array(l, "band")
+            dd, dh = slab.level_array(l, "band_diag"), host.level_array(l, "band_diag")
+            rd, rh = slab.level_array(l, "rows").reshape(7, -1), host.level_array(l, "rows").reshape(7, -1)
+            assert bd.size == bh.size and rd.shape == rh.shape, (what, l, bd.size, bh.size, rd.shape, rh.shape)
+            ngen = rd.shape[1]
+            if aligned:
+                assert np.array_equal(bd, bh) and np.array_equal(dd, dh) and np.array_equal(rd, rh), (what, l)
+                for name in ("pure_even", "pure_odd", "mixed_even", "mixed_odd", "tile_bnd_start"):
+                    assert np.array_equal(slab.level_array(l, name), host.level_array(l, name)), (what, l, name)
+            else:  # the same cells with the same rows, general cells first
+                for a, b2 in ((0, ngen), (ngen, bd.size)):
+                    od, oh2 = np.argsort(bd[a:b2], kind="stable"), np.argsort(bh[a:b2], kind="stable")
+                    assert np.array_equal(bd[a:b2][od], bh[a:b2][oh2]) and np.array_equal(dd[a:b2][od], dh[a:b2][oh2]), (what, l)
+                    if a == 0:
+                        assert np.array_equal(rd[:, od], rh[:, oh2]), (what, l)
+    finally:
+        host.close()
+
+
 def gpu_mode():
     import geometricmultigridpressuresolver_amd as G
     from conftest import make_domain
@@ -104,13 +142,11 @@ def gpu_mode():
             assert comm.device_allreduces >= 3 * ss["iterations"], (comm.device_allreduces, ss)
             assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
-            # the one-exchange band stage sends the boundary plane straight from the grid (mgps_comm::exchange2), only the lists packed
+            # the box form of a cut level's band stage (deep = 1) sends the boundary plane straight from the grid (mgps_comm::exchange2), only the lists packed
             assert (comm.segmented_exchanges > 0) == (deep == 1), (deep, comm.segmented_exchanges)
-            # exchanges queued on the transfer stream beside the interior part of the sweep that made their planes
-            if os.environ.get("MGPS_OVERLAP") == "0":
-                assert slab.overlapped_exchanges == 0
-            elif rank == 0:  # (a slab without liquid -- the top of the scene -- has nothing to launch edge first)
-                assert slab.overlapped_exchanges > 0, (kind, use_gs, deep)
+            assert slab.ghost_planes == 5 and all(slab.band_stage_form(l) == ("boxes" if deep == 1 else "passes") for l in range(slab.distributed_levels))
+            if deep == 1 and not use_gs:
+                compare_with_host_builder(slab, lab, slab_w, lev, use_gs, opt, (kind, size))
             if deep == 1:  # the CG vectors in fp64 (options.pcg_fp64_vectors): their ghost planes travel as doubles
                 o64 = G.default_options()
                 o64.min_cells_per_rank, o64.pcg_fp64_vectors = 0, 1

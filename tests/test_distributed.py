@@ -4,11 +4,12 @@
   operators (tests/slab_emulation.py) reproduces the whole-grid oracle to round-off, and stops doing so
   when exchanges are dropped.
 
-* gpu: two (and four) ranks share the one GPU of the test box; the slab orchestration of libmgps.so (one
-  ghost exchange per band stage -- or per band pass with deep_band_halo = 0 -- and per whole-grid operator
-  that reads across a cut, collapse of the coarse tail to rank 0) runs over TorchDistComm/gloo and must
-  reproduce the single-GPU solver on three domains (box, cut-cell solid, free-surface scene).  Only the transport differs
-  from production (RCCL refuses two ranks on one device).
+* gpu: two (and four) ranks share the one GPU of the test box; the slab ranks are set up on the device from their window of
+  the labels (round 5; every list against the host builder's), the slab orchestration of libmgps.so (the box form of the
+  band stage on cut levels with two list messages per stroke -- or an exchange per band pass with deep_band_halo = 0 -- a
+  ghost plane per whole-grid operator that reads across a cut, collapse of the coarse tail to rank 0) runs over
+  TorchDistComm/gloo and must reproduce the single-GPU solver on four domains (box, cut-cell solid, free-surface scene,
+  random labels).  Only the transport differs from production (RCCL refuses two ranks on one device).
 """
 import os
 import socket
@@ -33,9 +34,7 @@ def run_workers(mode, nproc, timeout, extra_env=None):
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), mode,
     ]
-    # MGPS_OVERLAP=1 (the default since round 4): the exchanges that follow a sweep run on the transfer stream;
-    # MGPS_OVERLAP_MIN_PLANE_KB=0: on every cut level of these small grids, not only for planes >= 1 MiB
-    env = dict(os.environ, OMP_NUM_THREADS="2", MGPS_OVERLAP="1", MGPS_OVERLAP_MIN_PLANE_KB="0")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
     env.update(extra_env or {})
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=env)
     ok = [f"WORKER_OK {r}" in res.stdout for r in range(nproc)]
@@ -72,16 +71,6 @@ def test_slabs_balanced_by_active_cells(nproc):
     """mgps_slab_partition + mgps_create_slab_ranges: slabs of different sizes (equal active cells instead of equal planes),
     the collapse through gatherv / scatterv; Jacobi with the library's cuts, Gauss-Seidel with the caller's own."""
     out = run_workers("balanced", nproc, 420)
-    print(out[-800:])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["gpu", "plane"])
-def test_slabs_without_overlap(mode):
-    """MGPS_OVERLAP=0: every exchange on the solver's own stream (the other tests of this file run with the default,
-    MGPS_OVERLAP=1, on every cut level: a cut level's sweeps launched edge first, the exchange that follows on a transfer stream beside the
-    interior part) -- same results either way."""
-    out = run_workers(mode, 2, 420, {"MGPS_OVERLAP": "0"})
     print(out[-800:])
 
 
