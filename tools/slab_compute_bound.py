@@ -4,33 +4,18 @@ nothing (exchanges, gather and scatter return at once; the values in the ghost p
 kernels and launches are exactly those of the real run).  What it gives: the per-rank device time of one cycle
 without any communication -- the ceiling of the strong-scaling curve -- for rank 0 (which also runs the collapsed
 tail) and a middle rank.   python tools/slab_compute_bound.py [N]"""
-import ctypes as C
 import json
 import sys
 import time
 
 import torch
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geometricmultigridpressuresolver_amd import domains as D
-from geometricmultigridpressuresolver_amd.distributed import _ALLR, _ALLRD, _DEST, _EXCH, _EXCH2, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver, slab_partition
-
-
-class NullComm:
-    def __init__(self, rank, size):
-        self.rank, self.size = rank, size
-        self.calls = 0
-
-        def exch(*a):
-            self.calls += 1
-            return 0
-
-        def exch2(*a):
-            self.calls += 1
-            return 0
-
-        self._cb = (_EXCH(exch), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
-        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0), _EXCH2(exch2))
-        self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
+from geometricmultigridpressuresolver_amd.distributed import SlabSolver, slab_partition
+from nullcomm import NullComm
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
@@ -45,7 +30,7 @@ for P in (1, 2, 4, 8):
     for rank in sorted({0, P // 2}):
         z0, z1 = cuts[rank], cuts[rank + 1]
         lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
-        comm = NullComm(rank, P)
+        comm = NullComm(rank, P, lab, levels)
         s = SlabSolver(lab, w, levels, False, comm, device=0, splits=cuts)
         b = s.to_device(D.random_rhs(lab, h, z0=z0, z1=z1))
         x = s.new_grid()

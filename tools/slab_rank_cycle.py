@@ -1,19 +1,11 @@
 """A few V-cycles of ONE rank of a P-rank slab run with a transport that moves nothing (for rocprofv3 --kernel-trace):
 python tools/slab_rank_cycle.py N P RANK [cycles]"""
-import ctypes as C, os, sys, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geometricmultigridpressuresolver_amd import domains as D
-from geometricmultigridpressuresolver_amd.distributed import _ALLR, _ALLRD, _DEST, _EXCH, _EXCH2, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver, slab_partition
-
-
-class NullComm:
-    def __init__(self, rank, size):
-        self.rank, self.size = rank, size
-        exch2 = lambda *a: 0
-        self._cb = (_EXCH(lambda *a: 0), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
-        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0), _EXCH2(exch2))
-        self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
+from geometricmultigridpressuresolver_amd.distributed import SlabSolver, slab_partition
+from nullcomm import NullComm
 
 
 n, P, rank = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -24,7 +16,7 @@ while (n >> (levels - 1)) > 16:
 cuts = slab_partition(D.interior_cube_slab(n, levels, 0, 1)[0], levels, P, False)
 z0, z1 = cuts[rank], cuts[rank + 1]
 lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
-s = SlabSolver(lab, w, levels, False, NullComm(rank, P), device=0, splits=cuts)
+s = SlabSolver(lab, w, levels, False, NullComm(rank, P, lab, levels), device=0, splits=cuts)
 b = s.to_device(D.random_rhs(lab, h, z0=z0, z1=z1))
 x = s.new_grid()
 for _ in range(2):

@@ -4,19 +4,10 @@ host (default): the slab's face weights come from numpy arrays (mgps_create_slab
 MGPS_SLAB_WINDOW=0 builds the band lists of the whole grid on the rank (rounds 1-2), the default only the rank's window."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import ctypes as C
 import torch
 from geometricmultigridpressuresolver_amd import domains as D
-from geometricmultigridpressuresolver_amd.distributed import _ALLR, _ALLRD, _DEST, _EXCH, _EXCH2, _GATH, _GATHV, _SCATV, CommStruct, SlabSolver
-
-
-class NullComm:  # a transport that moves nothing (set-up has collectives: they see their own values)
-    def __init__(self, rank, size):
-        self.rank, self.size = rank, size
-        exch2 = lambda *a: 0
-        self._cb = (_EXCH(lambda *a: 0), _ALLR(lambda *a: 0), _GATH(lambda *a: 0), _GATH(lambda *a: 0))
-        self._cbv = (_GATHV(lambda *a: 0), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0), _EXCH2(exch2))
-        self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
+from geometricmultigridpressuresolver_amd.distributed import SlabSolver
+from nullcomm import NullComm
 
 
 n, P, rank = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -32,7 +23,7 @@ if where == "device":
 for rep in range(3):
     torch.cuda.synchronize()
     t = time.time()
-    s = SlabSolver(lab, w, levels, False, NullComm(rank, P), device=0, splits=cuts)
+    s = SlabSolver(lab, w, levels, False, NullComm(rank, P, lab, levels), device=0, splits=cuts)
     torch.cuda.synchronize()
     print("slab set-up N=%d P=%d rank=%d window=%s weights=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), where, (time.time() - t) * 1e3), flush=True)
     s.close()
