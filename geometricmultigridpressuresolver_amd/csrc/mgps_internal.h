@@ -442,7 +442,9 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
 // of the block flags (launchPlaneBlockFlags) -- they owe rz one plane of terms each.  residualRestrictFits: the shapes the pair takes
 bool residualRestrictFits(const GridP &fine, const GridP &coarse);
 std::vector<int32_t> planeBlockEdges(const GridP &g, const std::vector<uint8_t> &flags);
-int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges);
+// rEdge (cut levels): the level's residual grid, whose ghost planes hold the neighbours' r on the planes next to the slab
+int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges, const float *rEdge = nullptr);
+int launchResidualEdgePlanes(void *stream, const GridP &g, float *r, const float *x, const float *b);
 int launchRestrictXY(void *stream, const GridP &coarse, float *coarseOut, const float *rz);
 // ---- mixed precision (options.precision = 1): binary16 grids of the fine level, passed as void* -----------------------
 bool mixedPrecisionShapeOk(int nx, int ny, int nz);  // the fine level must take the quad sweep and the block prolongation

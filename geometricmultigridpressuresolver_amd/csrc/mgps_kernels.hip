@@ -494,9 +494,13 @@ GridP g, float *__restrict__ out,
 // of nx x ny x nz/2 that nobody else writes: blocks with no active cell in them, below them or above them are never written and stay
 // zero (residualZEdgeKernel serves the blocks next to active ones).
 // ---------------------------------------------------------------------------------------------
+// A cut level of a slab run (g.ghostLo / g.ghostHi, round 5): the planes just outside the slab are the neighbours' -- x there is the
+// ghost plane, and r there comes complete from the neighbour in the ghost planes of `rEdge` (the level's residual grid: the ranks
+// exchange r on their boundary planes, as the separate restriction does): w0 r(-1) opens coarse plane 0, w3 r(nz) closes the last
+// one, in the order of the planes like everywhere else.
 __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, float *__restrict__ rz, const float *__restrict__ x,
                                                                      const float *__restrict__ b, unsigned nbx, unsigned nby, int zc,
-                                                                     const int32_t *__restrict__ blocks)
+                                                                     const int32_t *__restrict__ blocks, const float *__restrict__ rEdge)
 {
     __shared__ float plane[2][(kPlaneRows + 2) * kPlanePitch];
     unsigned bid = remapBlock(blockIdx.x, gridDim.x);
@@ -518,9 +522,10 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     const bool hasL = ic > 0, hasR = ic + 4 < g.nx;  // (the grid continues on that side)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
-    // (planes clamped into the grid: the first and the last plane of a whole-grid level are EXTERIOR shell, whose results are 0
-    // whatever their neighbours hold -- the assumption stencilPlaneKernel makes at the faces)
-    auto planeOf = [&](const float *p, int k) { return scalarBase(p + size_t(min(max(k, 0), g.nz - 1)) * sz); };
+    // (planes clamped to what exists -- the ghost planes of a slab, else the grid: the first and the last plane of a whole-grid level
+    // are EXTERIOR shell, whose results are 0 whatever their neighbours hold -- the assumption stencilPlaneKernel makes at the faces)
+    const int kLo = g.ghostLo ? -1 : 0, kHi = g.ghostHi ? g.nz : g.nz - 1;
+    auto planeOf = [&](const float *p, int k) { return scalarBase(p + ptrdiff_t(min(max(k, kLo), kHi)) * ptrdiff_t(sz)); };
     float *const mine0 = plane[0] + (ty + 1) * kPlanePitch + 4 + lane * 4;
     constexpr int kBufFloats = (kPlaneRows + 2) * kPlanePitch;
     {  // plane ks - 1 of the thread's own quad: the z - 1 values of a step are read back from the LDS buffer of the step before
@@ -542,6 +547,13 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     constexpr float w0 = 0.125f, w1 = 0.375f, w2 = 0.375f, w3 = 0.125f;
     // coarse plane (k - 1) / 2 with its first terms (accPrev) and the one after it (accCur), see the fold below
     float accPrev[4] = {0.f, 0.f, 0.f, 0.f}, accCur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rEdge && k0 == 0 && g.ghostLo && live) {  // the neighbour's r on the plane below the slab: the first term of coarse plane 0
+        const float4 e = gLoad4(scalarBase(rEdge - ptrdiff_t(sz)), off);
+        accCur[0] = w0 * e.x;
+        accCur[1] = w0 * e.y;
+        accCur[2] = w0 * e.z;
+        accCur[3] = w0 * e.w;
+    }
     int buf = 0;
     for (int k = ks; k <= ke; ++k) {
         float *me = mine0 + buf * kBufFloats;
@@ -605,9 +617,18 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
         hx = hxn;
         buf ^= 1;
     }
-    // the top block of the grid: plane nz does not exist, the last coarse plane is complete with three terms
-    if (valid && k1 == g.nz)
+    // the top block of the grid: plane nz does not exist, the last coarse plane is complete with three terms -- or, on a cut, its
+    // fourth term is the neighbour's r on the plane above the slab
+    if (valid && k1 == g.nz) {
+        if (rEdge && g.ghostHi) {
+            const float4 e = gLoad4(scalarBase(rEdge + ptrdiff_t(g.nz) * ptrdiff_t(sz)), off);
+            accPrev[0] += w3 * e.x;
+            accPrev[1] += w3 * e.y;
+            accPrev[2] += w3 * e.z;
+            accPrev[3] += w3 * e.w;
+        }
         gStore4(rz + size_t((g.nz >> 1) - 1) * sz, off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
+    }
 }
 
 // A block without active cells still owes rz the terms of the planes next to it when the block below or above holds active cells:
@@ -2861,8 +2882,8 @@ int launchRestrict(void *stream, const GridP &coarse, float *coarseOut, const fl
 // residualRestrictFits: the shapes both kernels take
 bool residualRestrictFits(const GridP &fine, const GridP &coarse)
 {
-    return fine.planeZc >= 4 && (fine.planeZc & 1) == 0 && (fine.nz & 1) == 0 && !fine.ghostLo && !fine.ghostHi && coarse.nx >= 64 &&
-           (coarse.nx & 1) == 0 && 2 * coarse.nx == fine.nx && 2 * coarse.ny == fine.ny && 2 * coarse.nz == fine.nz && !coarse.ghostLo && !coarse.ghostHi;
+    return fine.planeZc >= 4 && (fine.planeZc & 1) == 0 && (fine.nz & 1) == 0 && coarse.nx >= 64 && (coarse.nx & 1) == 0 && 2 * coarse.nx == fine.nx &&
+           2 * coarse.ny == fine.ny && 2 * coarse.nz == fine.nz;
 }
 // the (block, side) pairs residualZEdgeKernel serves, from a host copy of the block flags (planeBlockCount bytes): 2 * block + side
 std::vector<int32_t> planeBlockEdges(const GridP &g, const std::vector<uint8_t> &flags)
@@ -2878,14 +2899,44 @@ std::vector<int32_t> planeBlockEdges(const GridP &g, const std::vector<uint8_t> 
     }
     return edges;
 }
-int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges)
+// The residual on the boundary planes of a cut level alone (plane 0 where the slab has a lower neighbour, plane nz - 1 where it has
+// an upper one), general BOUNDARY cells included, into `r`: what the neighbours' marches fold in as their edge terms.
+int launchResidualEdgePlanes(void *stream, const GridP &g, float *r, const float *x, const float *b)
+{
+    const size_t sz = size_t(g.nx) * g.ny;
+    for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? g.ghostLo : g.ghostHi)) continue;
+        const int k = side == 0 ? 0 : g.nz - 1;
+        GridP p = g;  // the plane as a grid of its own: its neighbours below and above are its "ghost planes"
+        p.nz = 1;
+        p.lab = g.lab + size_t(k) * sz;
+        p.ghostLo = (k > 0 || g.ghostLo) ? 1 : 0;
+        p.ghostHi = (k < g.nz - 1 || g.ghostHi) ? 1 : 0;
+        p.chunks = nullptr;
+        p.nchunks = 0;
+        p.planeBlocks = nullptr;
+        p.nplaneBlocks = 0;
+        p.planeZc = 0;
+        p.sweepPath = 1;
+        p.nbnd = 0;
+        p.streaming = 0;
+        const int e = launchStencil(stream, OP_RESIDUAL, p, r + size_t(k) * sz, x + size_t(k) * sz, b + size_t(k) * sz, 0.f, true);
+        if (e) return e;
+    }
+    if (g.nbnd > 0) {  // (every general cell of the slab: the ones on the two planes are among them, the rest lands in scratch)
+        const unsigned nb = blocksFor(size_t(g.nbnd), 256);
+        boundaryOpKernel<OP_RESIDUAL><<<nb, 256, 0, static_cast<hipStream_t>(stream)>>>(g, r, x, b, 0.f, nb);
+    }
+    return int(hipGetLastError());
+}
+int launchResidualZ(void *stream, const GridP &fine, float *rz, const float *x, const float *b, const int32_t *edges, int nedges, const float *rEdge)
 {
     const int zc = fine.planeZc;
     const unsigned nbx = (fine.nx + 255) / 256, nby = (fine.ny + kPlaneRows - 1) / kPlaneRows, nbz = (fine.nz + zc - 1) / zc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool list = fine.planeBlocks != nullptr;
     const unsigned nb = list ? unsigned(fine.nplaneBlocks) : nbx * nby * nbz;
-    if (nb > 0) residualZKernel<<<nb, 64 * kPlaneRows, 0, s>>>(fine, rz, x, b, nbx, nby, zc, list ? fine.planeBlocks : nullptr);
+    if (nb > 0) residualZKernel<<<nb, 64 * kPlaneRows, 0, s>>>(fine, rz, x, b, nbx, nby, zc, list ? fine.planeBlocks : nullptr, rEdge);
     if (list && nedges > 0) residualZEdgeKernel<<<unsigned(nedges), 64 * kPlaneRows, 0, s>>>(fine, rz, x, b, nbx, nby, zc, edges);
     if (fine.nbnd > 0)  // the general BOUNDARY cells' part (their entries lie in blocks the launches above have just written)
         for (int phase = 0; phase < 4; ++phase) residualZGeneralKernel<<<blocksFor(size_t(fine.nbnd), 256), 256, 0, s>>>(fine, rz, x, b, phase);

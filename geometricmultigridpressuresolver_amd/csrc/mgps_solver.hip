@@ -733,7 +733,8 @@ bool strokeTakesZero(const mgps_solver *h, int l, const float *cur, const float 
         return !(e && e[0] == '0');
     }();
     const DevLevel &L = h->lv[l];
-    return allowed && !dot && !h->dist && !h->useGS && h->opt.pre_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && stencilKernelOf(L.g) != 3 &&
+    // (a slab run: cut levels in box form -- the stroke's first message then carries the rhs at the neighbours' cells and nothing of the iterate)
+    return allowed && !dot && (!h->dist || L.boxForm) && !h->useGS && h->opt.pre_sweeps == 1 && h->opt.band_iterations > 0 && levelHasBoxes(h, l) && stencilKernelOf(L.g) != 3 &&
            !(h->profiling && l == 0) && cur != L.r && other != L.r && b != L.r;
 }
 
@@ -750,7 +751,7 @@ bool residualRestrictFuses(const mgps_solver *h, int l)
         const char *e = getenv("MGPS_FUSE_RR");
         return !e ? -1 : (e[0] == '0' ? 0 : 1);
     }();
-    if (mode == 0 || h->dist || l + 1 >= int(h->lv.size())) return false;
+    if (mode == 0 || l + 1 >= int(h->lv.size())) return false;
     const GridP &F = h->lv[l].g;
     if (mode < 0 && size_t(F.nx) * F.ny * sizeof(float) < kPlaneSweepMinPlaneBytes) return false;
     return residualRestrictFits(F, h->lv[l + 1].g);
@@ -775,7 +776,13 @@ int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
     }
     {
         StageScope scope(h, ST_RESIDUAL, l);
-        MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs, F.rzEdges, F.nrzEdges));
+        const bool cut = h->dist && (F.g.ghostLo || F.g.ghostHi);
+        if (cut) {  // r on the planes at the cuts first: the neighbours' marches fold it in as their edge terms (one message, like the restriction's)
+            MGPS_TRY(exchangeGhosts(h, l, const_cast<float *>(x), F.boxForm ? GHOST_FULL : h->opt.band_iterations > 0 ? GHOST_BAND : GHOST_FULL));  // (see vcycle)
+            MGPS_LAUNCH(h, launchResidualEdgePlanes(h->stream, F.g, F.r, x, rhs));
+            MGPS_TRY(exchangeGhosts(h, l, F.r, GHOST_FULL));
+        }
+        MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs, F.rzEdges, F.nrzEdges, cut ? F.r : nullptr));
     }
     StageScope scope(h, ST_RESTRICT, l);
     MGPS_LAUNCH(h, launchRestrictXY(h->stream, C.g, C.b, F.rz));
@@ -877,7 +884,8 @@ int smoothStroke(mgps_solver *h, int l, float *&cur, float *&other, const float 
         // across the cut next exchanges them (the residual, the finer level's prolongation).
         {
             StageScope scope(h, ST_BAND, l);
-            if (L.boxForm) MGPS_TRY(haloListExchange(h, l, cur, const_cast<float *>(b), true));
+            if (L.boxForm && xZero) MGPS_TRY(haloListExchange(h, l, const_cast<float *>(b), nullptr, false));  // (the iterate is zero on every rank: the rhs alone)
+            else if (L.boxForm) MGPS_TRY(haloListExchange(h, l, cur, const_cast<float *>(b), true));
             MGPS_LAUNCH(h, launchBandBox(h->stream, boxGrid(h, l), L.bandBoxes, true, src, b, nullptr, L.r, h->opt.jacobi_weight));
         }
         {
@@ -2971,16 +2979,19 @@ try {
     // depth of the distributed part as the even cut gives it; the balanced cuts keep it
     const int D = distributedLevelsFor(out_splits, size, nx, ny, mg_levels, use_gauss_seidel != 0, o);
     if (D < 1 || use_gauss_seidel) return MGPS_OK;  // Gauss-Seidel: cuts on multiples of 16 planes of EVERY distributed level -- the even cut
-    const int unit = std::max(kTile, 1 << D);        // Jacobi: whole planes of the collapse level, at least 16 fine planes
+    const int unit = 1 << D;                         // Jacobi: whole planes of the collapse level (round 5: the device-side set-up takes cuts that are not
+                                                     // multiples of 16 planes; at 1024^3 / 8 ranks the unit of 8 planes is what lets the middle ranks shed load)
     if (nz % unit != 0) return MGPS_OK;
-    const int units = nz / unit, minUnits = std::max(1, (kTile << (D - 1)) / unit);
+    const int units = nz / unit, minUnits = std::max(1, ((kTile << (D - 1)) + unit - 1) / unit);  // (every rank: 16 planes of the coarsest distributed level)
     if (units < size * minUnits) return MGPS_OK;
-    // Load of a unit of planes: active cells + 30 x BOUNDARY cells.  The weights are measured (tools/slab_compute_bound.py, 1024^3,
-    // one rank at a time with a null transport): a rank's cycle costs 0.0103 ms per million active cells and 0.101 ms per
-    // million band cells (four fused band stages of three passes each, gather-bound) -- and the band is three cells deep,
-    // i.e. about 3 x the BOUNDARY cells (all this function sees are labels); rank 0 also runs the collapsed tail, about
-    // 0.2 ms of launch-bound small levels there = 2.3 % of the whole load, which everybody waits for
-    constexpr double kBoundaryWeight = 30.0, kTailShare = 0.023;
+    // Load of a unit of planes: active cells + w x BOUNDARY cells.  The weights are measured (tools/slab_compute_bound.py, 1024^3,
+    // one rank at a time with a null transport, round 5: P = 1, 2, 4, 8 fitted by cycle = c x active planes + F x faces + T on
+    // rank 0 + a constant): c = 10.8 us per 1024^2 plane of liquid, F = 60 us for a z face of 894^2 BOUNDARY cells (the box form
+    // of the band stage: 5.6 planes' worth, w = 6 -- the graph form of rounds 2-4 cost five times that, w = 30, which is what the
+    // pass-by-pass stage still gets), T = 0.23 ms for the collapsed tail on rank 0 = 2.3 % of the whole load, which everybody
+    // waits for
+    const double kBoundaryWeight = (o.fuse_band_passes && o.deep_band_halo && o.band_iterations >= 1 && o.band_iterations <= kBandMaxDepth) ? 6.0 : 30.0;
+    constexpr double kTailShare = 0.032;  // (2.3 % by the fit; rank 0 also pays for the EXTERIOR planes in front of the liquid: measured, 3.2 % levels rank 0 with the middle ranks at 1024^3 / 8)
     std::vector<double> load(size_t(units), 0.0);
     const size_t plane = size_t(nx) * ny;
     {
@@ -4116,6 +4127,13 @@ try {
 MGPS_API_CATCH(h)
 int mgps_distributed_levels(const mgps_solver *h) { return h ? h->distLevels : 0; }
 int mgps_ghost_planes(const mgps_solver *h) { return h ? h->ghost : 1; }
+int mgps_residual_restrict_fused(const mgps_solver *h, int level, int *fused)
+try {
+    if (!h || !fused || level < 0 || level >= int(h->lv.size())) return MGPS_ERR_INVALID_ARGUMENT;
+    *fused = (h->opt.precision == 0 || level > 0) && residualRestrictFuses(h, level) ? 1 : 0;
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
 int mgps_band_stage_form(const mgps_solver *h, int level, int *form)
 try {
     if (!h || !form || level < 0 || level >= int(h->lv.size())) return MGPS_ERR_INVALID_ARGUMENT;

@@ -402,6 +402,12 @@ class GeometricMultigridPoissonSolver:
         check(lib().mgps_swept_cells(self.h, int(level), C.byref(a), C.byref(b)), self.h)
         return a.value, b.value
 
+    def residual_restrict_fused(self, level=0):
+        """mgps_residual_restrict_fused: does a down-stroke of this level run residual + restriction as the z-folded pair?"""
+        f = C.c_int()
+        check(lib().mgps_residual_restrict_fused(self.h, int(level), C.byref(f)), self.h)
+        return bool(f.value)
+
     def stencil_kernel(self, level=0):
         """'quad' | 'plane' | 'scalar': the kernel the Jacobi / residual / A.x sweeps of `level` launch"""
         k = C.c_int()

@@ -450,6 +450,11 @@ int mgps_ghost_planes(const mgps_solver *h);
  * runs: *form = 1: the box form (one launch per stage; on a cut level of a slab run with two list messages per stroke), 0: pass by
  * pass (a launch pair per pass, on cut levels an exchange per pass).  The same arithmetic per cell either way. */
 int mgps_band_stage_form(const mgps_solver *h, int level, int *form);
+/* *fused = 1 when a down-stroke of level `level` takes residual and restriction as the pair "residual folded along z as it is
+ * formed + x-y restriction" (no residual grid written; Ops.h:716-732 into Ops.h:734-835), 0 when they run as two passes over
+ * the residual grid.  By size (x-y planes >= 4 MiB) on levels whose shape the pair takes; MGPS_FUSE_RR=0 / 1 forces it off /
+ * onto every level that fits (tests).  The same products either way, added along z first instead of last. */
+int mgps_residual_restrict_fused(const mgps_solver *h, int level, int *fused);
 /* slab runs: how many ghost exchanges so far were queued on the transfer stream, beside the interior part of the sweep that
  * produced their planes (the default on levels with planes >= 1 MiB since round 4, MGPS_OVERLAP=0 turns it off; 0 on
  * single-device solvers) */

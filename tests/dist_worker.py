@@ -219,6 +219,8 @@ def plane_mode():
         slab = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=opt)
         whole = G.GeometricMultigridPoissonSolver(lab, w, lev, use_gs, device=0, options=ow)
         assert slab.stencil_kernel(0) == "plane" and whole.stencil_kernel(0) == "plane"
+        if os.environ.get("MGPS_EXPECT_FUSED_RR") == "1":  # (the residual + restriction pair on the cut fine level)
+            assert slab.residual_restrict_fused(0) and whole.residual_restrict_fused(0)
         t1 = time.time()
         bw, bs = whole.to_device(b_glob), slab.to_device(b_glob[z0:z1])
         xw, xs = whole.to_device(b_glob * 3.0), slab.to_device(b_glob[z0:z1] * 3.0)
@@ -237,7 +239,8 @@ def plane_mode():
             whole.applyVCycle(xw, bw, it > 0)
             slab.applyVCycle(xs, bs, it > 0)
             err = rel_l2(slab.gather_global(xs), xw.cpu().numpy())
-            assert err < 1e-6, (deep, it, err)
+            # (the residual + restriction pair adds a coarse cell's terms along z first: with it the last bits differ where general cells meet a cut)
+            assert err < (2e-6 if os.environ.get("MGPS_EXPECT_FUSED_RR") == "1" else 1e-6), (deep, it, err)
         t2 = time.time()
         xw, xs = whole.new_grid(), slab.new_grid()
         sw = whole.solveGeometricConjugateGradient(xw, bw, 1e-5, 200, True)  # A.p + <p, A p> from the DOT variant on the whole grid
@@ -282,7 +285,7 @@ def balanced_mode():
     for use_gs, cuts in cases:
         planes = [cuts[r + 1] - cuts[r] for r in range(size)]
         assert len(set(planes)) > 1, cuts  # really uneven
-        load = lambda a, c: int(D.active_mask(lab[a:c]).sum()) + 30 * int((lab[a:c] == 3).sum())  # noqa: E731  (the partition's load model)
+        load = lambda a, c: int(D.active_mask(lab[a:c]).sum()) + 6 * int((lab[a:c] == 3).sum())  # noqa: E731  (the partition's load model, box form of the band stage)
         active = [load(cuts[r], cuts[r + 1]) for r in range(size)]
         even = [load(nz // size * r, nz // size * (r + 1)) for r in range(size)]
         assert max(active) < max(even) or use_gs, (active, even)

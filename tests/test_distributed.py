@@ -75,6 +75,17 @@ def test_slabs_balanced_by_active_cells(nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,nproc", [("gpu", 2), ("plane", 2), ("plane", 4)])
+def test_slabs_residual_restriction_pair_on_cut_levels(mode, nproc):
+    """MGPS_FUSE_RR=1: residual + restriction of a down-stroke as the z-folded pair (residualZKernel + restrictXYKernel) on every
+    level that fits -- by size only 4 MiB planes take it -- including CUT levels (round 5): the ranks exchange r on their boundary
+    planes and the marches fold the neighbours' planes in as their edge terms.  Must reproduce the whole-grid solver, which takes
+    the pair too; the worker asserts that the cut fine level really took it."""
+    out = run_workers(mode, nproc, 420, {"MGPS_FUSE_RR": "1", "MGPS_EXPECT_FUSED_RR": "1"})
+    print(out[-800:])
+
+
+@pytest.mark.gpu
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One V-cycle's launches in time order from a rocprofv3 --kernel-trace CSV: start, duration, gap to the previous kernel's end.
-usage: cycle_timeline.py TRACE_DIR [which]   (the cycle = the span between two consecutive coarsest-level solves; which: its index from the end, default 2)"""
+usage: cycle_timeline.py TRACE_DIR [which [marker]]   (the cycle = the span between two consecutive coarsest-level solves -- or launches of the
+kernel whose name starts with `marker`: a slab rank other than 0 has no coarsest level; which: its index from the end, default 2)"""
 import csv
 import glob
 import sys
@@ -8,11 +9,11 @@ import sys
 from profsum import short
 
 
-def main(d, which=2):
+def main(d, which=2, marker=None):
     f = glob.glob(f"{d}/*/*_kernel_trace.csv")[0]
     rows = sorted(({"n": short(r["Kernel_Name"]), "g": int(r["Grid_Size_X"]), "s": int(r["Start_Timestamp"]), "e": int(r["End_Timestamp"])} for r in csv.DictReader(open(f))),
                   key=lambda r: r["s"])
-    marks = [i for i, r in enumerate(rows) if r["n"].startswith("coarseSolve") or r["n"].startswith("coarseMatVec")]
+    marks = [i for i, r in enumerate(rows) if (r["n"].startswith(marker) if marker else r["n"].startswith("coarseSolve") or r["n"].startswith("coarseMatVec"))]
     if len(marks) < which + 1:
         print("no cycle found")
         return
@@ -30,4 +31,4 @@ def main(d, which=2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2, sys.argv[3] if len(sys.argv) > 3 else None)

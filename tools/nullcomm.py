@@ -17,7 +17,7 @@ class NullComm:
     def __init__(self, rank, size, labels=None, levels=None):
         self.rank, self.size = rank, size
         self.calls = 0
-        self._labels, self._levels, self._served = labels, levels, False
+        self._labels, self._levels, self._coarse = labels, levels, None
         self._hip = C.CDLL("libamdhip64.so")
         self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
@@ -35,17 +35,21 @@ class NullComm:
         self._cbv = (_GATHV(gatherv), _SCATV(lambda *a: 0), _ALLRD(lambda *a: 0), _EXCH2(exch))
         self.struct = CommStruct(C.sizeof(CommStruct), rank, size, None, *self._cb, _DEST(), *self._cbv)
 
+    def prepare(self):
+        """the coarse labels a set-up may ask for, made ahead of any timed region (rank 0 only)"""
+        if self._labels is None or self.rank != 0 or self._coarse is not None:
+            return
+        hier = Hierarchy(self._labels, self._levels)
+        self._coarse = {lev: np.ascontiguousarray(hier.level_labels(lev)) for lev in range(1, hier.levels)}
+        hier.close()
+
     def _serve(self, recv, total):
-        """the first gather that reaches the root is the set-up's: the collapse level's labels of the whole grid"""
-        if self._served or not recv or self._labels is None:
+        """the set-up's gather (a byte per cell of the collapse level; the cycle's gathers move floats): the collapse level's labels"""
+        if not recv or self._labels is None:
             return 0
-        self._served = True
-        nz, ny, nx = self._labels.shape
-        for lev in range(1, self._levels):
-            if (nz >> lev) * (ny >> lev) * (nx >> lev) == total:
-                hier = Hierarchy(self._labels, self._levels)
-                lab = np.ascontiguousarray(hier.level_labels(lev))
-                hier.close()
+        self.prepare()
+        for lab in self._coarse.values():
+            if lab.nbytes == total:
                 assert self._hip.hipMemcpy(recv, lab.ctypes.data, lab.nbytes, 1) == 0
-                return 0
+                break
         return 0

@@ -20,10 +20,12 @@ lab, w, h = D.interior_cube_slab(n, levels, z0, z1)
 where = sys.argv[4] if len(sys.argv) > 4 else "host"
 if where == "device":
     w = [torch.from_numpy(a).cuda() for a in w]
+comm = NullComm(rank, P, lab, levels)
+comm.prepare()
 for rep in range(3):
     torch.cuda.synchronize()
     t = time.time()
-    s = SlabSolver(lab, w, levels, False, NullComm(rank, P, lab, levels), device=0, splits=cuts)
+    s = SlabSolver(lab, w, levels, False, comm, device=0, splits=cuts)
     torch.cuda.synchronize()
     print("slab set-up N=%d P=%d rank=%d window=%s weights=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), where, (time.time() - t) * 1e3), flush=True)
     s.close()
