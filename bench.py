@@ -59,6 +59,11 @@ def parse():
     ap.add_argument("--zero-guess", action="store_true",
                     help="time applyVCycle(useInitialGuess=false): the cycle as the CG preconditioner runs it (CG.h:86, 180). The mixed-precision "
                          "cycle is built for this form; from an initial guess it adds an fp32 residual and a correction pass")
+    ap.add_argument("--write-check", action="store_true",
+                    help="--gpus 1 only: store this configuration's check value (relative residual after three V-cycles) in bench_check.json, "
+                         "the table every run -- a first N > 1 run above all -- compares its own value with")
+    ap.add_argument("--test-drop-exchange", type=int, default=0,
+                    help="test hook (--rehearse-gloo): the host-staged transport drops every N-th exchange during the check cycles; the check must fail")
     ap.add_argument("--workload", choices=["vcycle", "free_surface_pcg"], default="vcycle",
                     help="free_surface_pcg = BASELINE config 3 (single GPU): MG-PCG to 1e-5 on the free-surface pool")
     return ap.parse_args()
@@ -300,6 +305,10 @@ def main():
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
         comm = TorchDistComm() if args.rehearse_gloo else RcclComm(device=local_rank)
+        # before anything is timed: rank-stamped data through every entry of the transport, verified on arrival (mgps_comm_preflight)
+        from geometricmultigridpressuresolver_amd.distributed import comm_preflight
+
+        ranks_seen = comm_preflight(comm, 1 << 16)
         torch.cuda.synchronize()
         t_setup = time.perf_counter()
         solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt, splits=cuts)
@@ -338,6 +347,29 @@ def main():
         solver.applyVCycle(x, b, guess)
     stages = solver.stage_times()
     solver.profile_enable(False)
+    # ---- does the run compute the right thing?  Relative residual |b - A x| / |b| after three V-cycles from zero (outside the timed
+    # region), against the value the single-GPU solver stored for this configuration in bench_check.json (--write-check)
+    check_key = f"{n}^3 L{levels} {args.smoother} sweeps{args.sweeps} {args.precision}"
+    if args.test_drop_exchange and slab_run and args.rehearse_gloo:
+        comm.drop_every = args.test_drop_exchange
+    xc, rc = solver.new_grid(), solver.new_grid()
+    for it in range(3):
+        solver.applyVCycle(xc, b, it > 0)
+    solver.computePoissonResidual(rc, xc, b)
+    check_value = solver.l2Norm(rc) / solver.l2Norm(b)
+    del xc, rc
+    table_path = os.path.join(ROOT, "bench_check.json")
+    try:
+        table = json.load(open(table_path))
+    except Exception:
+        table = {}
+    if args.write_check and not slab_run and rank == 0:
+        table[check_key] = check_value
+        json.dump(table, open(table_path, "w"), indent=1, sort_keys=True)
+    ref = table.get(check_key)
+    check = {"what": "|b - A x| / |b| after three V-cycles from zero", "value": check_value, "reference": ref, "reference_from": "bench_check.json (--gpus 1 --write-check)",
+             "tolerance_rel": 1e-4,
+             "status": "no reference for this configuration" if ref is None else ("ok" if abs(check_value - ref) <= 1e-4 * abs(ref) else "FAILED")}
     slab_diag = None
     if slab_run:  # the job is as slow as its slowest rank
         dev = "cpu" if args.rehearse_gloo else "cuda"
@@ -351,7 +383,9 @@ def main():
         slab_diag = {"rank_cycle_ms_max": float(t[2]) / args.steps * 1e3, "rank_cycle_ms_min": float(tmin[2]) / args.steps * 1e3,
                      "setup_ms_max": float(t[3]), "setup_ms_min": float(tmin[3]), "exchanges_per_cycle_max": float(t[4]),
                      "exchanges_per_cycle_min": float(tmin[4]),
-                     "distributed_levels": solver.distributed_levels}
+                     "distributed_levels": solver.distributed_levels, "ghost_planes": solver.ghost_planes,
+                     "band_stage": [solver.band_stage_form(l) for l in range(solver.distributed_levels)],
+                     "preflight": "ok", "rccl_ranks_seen": ranks_seen, "check": check}
 
     cells = float(n) ** 3  # whole job; a rank holds cells / world of them
     active_cells = float(((lab[z0:z1] == 0) | (lab[z0:z1] == 3)).sum())  # this rank's INTERIOR + BOUNDARY cells
@@ -391,6 +425,7 @@ def main():
             "distributed_levels": solver.distributed_levels if slab_run else 0,
         },
         **({"slab": slab_diag} if slab_diag else {}),
+        "check": check,
         "vcycle_algorithmic_GBps": VCYCLE_BYTES_PER_FINE_CELL * cells * vps / 1e9,
         # the whole cycle against the HBM peak: SURVEY 8(d)'s 60.7 B per fine cell (band passes excluded) x the cells a sweep
         # visits (active runs), per GPU
@@ -497,6 +532,9 @@ def main():
         print(json.dumps(out), flush=True)
     if slab_run:
         dist.destroy_process_group()
+    if check["status"] == "FAILED":
+        print(f"bench.py: the check FAILED: {check}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

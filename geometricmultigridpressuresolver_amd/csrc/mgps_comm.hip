@@ -415,6 +415,122 @@ try {
 }
 MGPS_API_CATCH(nullptr)
 
+// A check of ANY transport (the vtable alone: RCCL, or the test-suite's torch.distributed one) before a run trusts it: every rank
+// pushes rank-stamped data through exchange, exchange2, allreduce_device, allreduce and gather / scatter and verifies what arrives
+// from its neighbours.  Every rank walks through all steps whatever it finds, and the verdicts are joined at the end (a rank that
+// left early would leave the others waiting).  *ranks_seen = the sum over ranks of 1, as the device all-reduce delivered it.
+int mgps_comm_preflight(const mgps_comm *comm, size_t floats, int *ranks_seen)
+try {
+    if (!comm || !comm->exchange || !comm->allreduce || !comm->gather || !comm->scatter || floats < 4) {
+        setLastGlobalError("mgps_comm_preflight: incomplete mgps_comm");
+        return MGPS_ERR_INVALID_ARGUMENT;
+    }
+    const int rank = comm->rank, size = comm->size;
+    const bool lo = rank > 0, hi = rank < size - 1;
+    std::string what;
+    auto note = [&](const std::string &m) {
+        if (what.empty()) what = m;
+    };
+    auto stamp = [](int r, int side, size_t i) { return float(r) + 0.25f * float(side) + 1e-3f * float(i % 101); };
+    float *dev = nullptr;  // send lo | send hi | recv lo | recv hi
+    double *dd = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&dev), 4 * floats * sizeof(float)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&dd), 2 * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dev) (void)hipFree(dev);
+        setLastGlobalError("mgps_comm_preflight: allocation failed");
+        return MGPS_ERR_ALLOC;
+    }
+    std::vector<float> host(4 * floats, -1.f), back(2 * floats);
+    for (size_t i = 0; i < floats; ++i) {
+        host[i] = stamp(rank, 1, i);           // what goes down
+        host[floats + i] = stamp(rank, 2, i);  // what goes up
+    }
+    auto upload = [&] { return hipMemcpy(dev, host.data(), 4 * floats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess; };
+    auto verify = [&](const char *step) {
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(back.data(), dev + 2 * floats, 2 * floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            note(std::string(step) + ": reading the received data failed");
+            return;
+        }
+        for (size_t i = 0; i < floats; ++i) {
+            if (lo && back[i] != stamp(rank - 1, 2, i)) {
+                note(std::string(step) + ": data from the lower neighbour differ from what it sent");
+                return;
+            }
+            if (hi && back[floats + i] != stamp(rank + 1, 1, i)) {
+                note(std::string(step) + ": data from the upper neighbour differ from what it sent");
+                return;
+            }
+        }
+    };
+    const size_t bytes = floats * sizeof(float);
+    if (!upload()) note("upload failed");
+    if (comm->exchange(comm->user, lo ? dev : nullptr, bytes, lo ? dev + 2 * floats : nullptr, bytes, hi ? dev + floats : nullptr, bytes, hi ? dev + 3 * floats : nullptr, bytes, nullptr) != 0)
+        note("exchange returned an error");
+    verify("exchange");
+    if (comm->exchange2) {
+        if (!upload()) note("upload failed");
+        const size_t a = floats / 3 + 1, b = floats - a;  // two uneven segments per message
+        mgps_xfer2 seg[4] = {{{dev, dev + a}, {a * sizeof(float), b * sizeof(float)}},
+                             {{dev + 2 * floats, dev + 2 * floats + a}, {a * sizeof(float), b * sizeof(float)}},
+                             {{dev + floats, dev + floats + a}, {a * sizeof(float), b * sizeof(float)}},
+                             {{dev + 3 * floats, dev + 3 * floats + a}, {a * sizeof(float), b * sizeof(float)}}};
+        if (comm->exchange2(comm->user, lo ? &seg[0] : nullptr, lo ? &seg[1] : nullptr, hi ? &seg[2] : nullptr, hi ? &seg[3] : nullptr, nullptr) != 0)
+            note("exchange2 returned an error");
+        verify("exchange2");
+    }
+    double seen = 0.0;
+    if (comm->allreduce_device) {
+        const double ones[2] = {1.0, double(rank)};
+        if (hipMemcpy(dd, ones, sizeof(ones), hipMemcpyHostToDevice) != hipSuccess) note("upload failed");
+        if (comm->allreduce_device(comm->user, dd, 1, 0, nullptr) != 0 || comm->allreduce_device(comm->user, dd + 1, 1, 1, nullptr) != 0) note("allreduce_device returned an error");
+        double got[2] = {0, 0};
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(got, dd, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) note("allreduce_device: reading the result failed");
+        if (got[0] != double(size) || got[1] != double(size - 1)) note("allreduce_device: sum / max over the ranks is wrong");
+        seen = got[0];
+    }
+    {
+        double v[2] = {1.0, double(rank)};
+        if (comm->allreduce(comm->user, v, 1, 0) != 0 || comm->allreduce(comm->user, v + 1, 1, 1) != 0) note("allreduce returned an error");
+        if (v[0] != double(size) || v[1] != double(size - 1)) note("allreduce: sum / max over the ranks is wrong");
+        if (!comm->allreduce_device) seen = v[0];
+    }
+    {  // gather to rank 0 and scatter back (the collapse's collectives): a stamp per rank
+        const size_t n = std::min<size_t>(floats, 64), gb = n * sizeof(float);
+        float *all = nullptr;
+        if (rank == 0 && hipMalloc(reinterpret_cast<void **>(&all), gb * size_t(size)) != hipSuccess) note("allocation failed");
+        if (comm->gather(comm->user, dev, rank == 0 ? all : nullptr, gb, 0, nullptr) != 0) note("gather returned an error");
+        if (rank == 0 && all) {
+            std::vector<float> g(n * size_t(size));
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(g.data(), all, gb * size_t(size), hipMemcpyDeviceToHost) != hipSuccess) note("gather: reading the result failed");
+            for (int r = 0; r < size; ++r)
+                for (size_t i = 0; i < n; ++i)
+                    if (g[size_t(r) * n + i] != stamp(r, 1, i)) note("gather: rank " + std::to_string(r) + "'s share is wrong");
+        }
+        if (comm->scatter(comm->user, rank == 0 ? all : nullptr, dev + 2 * floats, gb, 0, nullptr) != 0) note("scatter returned an error");
+        std::vector<float> mine(n);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(mine.data(), dev + 2 * floats, gb, hipMemcpyDeviceToHost) != hipSuccess) note("scatter: reading the result failed");
+        for (size_t i = 0; i < n; ++i)
+            if (mine[i] != stamp(rank, 1, i)) note("scatter: this rank's share is wrong");
+        if (all) (void)hipFree(all);
+    }
+    (void)hipFree(dev);
+    (void)hipFree(dd);
+    double failed = what.empty() ? 0.0 : 1.0;
+    (void)comm->allreduce(comm->user, &failed, 1, 1);
+    if (ranks_seen) *ranks_seen = int(seen);
+    if (!what.empty()) {
+        setLastGlobalError("mgps_comm_preflight (rank " + std::to_string(rank) + "): " + what);
+        return MGPS_ERR_COMM;
+    }
+    if (failed != 0.0) {
+        setLastGlobalError("mgps_comm_preflight: another rank found the transport broken");
+        return MGPS_ERR_COMM;
+    }
+    return MGPS_OK;
+}
+MGPS_API_CATCH(nullptr)
+
+
 int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *us_per_exchange)
 try {
     // device time of `reps` back-to-back send-to-self + receive-from-self groups of `floats` floats: what one

@@ -482,8 +482,9 @@ int launchReduce(void *stream, int kind, const GridP &g, const float *a, const f
 // alphaDev (optional): alpha = float(alphaDev[0] / alphaDev[1]) read on the device instead of the host's value
 // maxAbsDev (optional; `partials` then holds 2 x kReducePartials doubles): *maxAbsDev = max |r| of the new residual
 // xWide (optional): the iterate in fp64 (options.pcg_fp64_vectors = 2) -- updated instead of x, with alpha in double
+// xFirst (fp32 x): x = alpha p instead of x += alpha p -- x is the sum of the updates since the last flush of the fp64-iterate loop
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev = nullptr, double *maxAbsDev = nullptr, double *xWide = nullptr);
+                   double *resultDev, const double *alphaDev = nullptr, double *maxAbsDev = nullptr, double *xWide = nullptr, bool xFirst = false);
 // CG steps that read the mixed-precision V-cycle's binary16 result in place, z = (mul / *sigma) x~ (level g = the fine level;
 // the grid's dimensions need n % 4 == 0): *resultDev = <z, r>; p = z + beta p
 int launchHalfDot(void *stream, const GridP &g, const void *xH, const float *r, const float *sigmaDev, float mul, double *partials, double *resultDev);
@@ -492,8 +493,11 @@ int launchCgScalars(void *stream, double *scal, float *beta, int init);
 // fp64 CG vectors (options.pcg_fp64_vectors), level g = the fine level of a single-device solver:
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
 // (`partials` holds `capacity` doubles: the per-workgroup sums and launchFoldDot's scratch)
+// mode 2 (dx != nullptr, out != x): the iterate is x + dx (fp32 sum of the updates since the last flush): out32 = float(b - A (x + dx)),
+// *resultDev its squared norm, out = x + dx on the active cells (x elsewhere)
 int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
-                    double *partials, size_t capacity, double *resultDev);
+                    double *partials, size_t capacity, double *resultDev, const float *dx = nullptr);
+int launchNarrowSum(void *stream, const GridP &g, float *x32, const double *x64, bool addDx);  // x32 = float(x64 (+ x32 on active cells))
 int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
                      double *partials, size_t capacity, double *resultDev);
 int launchXpay64(void *stream, const GridP &g, double *p, const float *z, double beta, int first);

@@ -3237,10 +3237,14 @@ __global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, c
 // iteration next to the V-cycle.
 // ---------------------------------------------------------------------------------------------
 // MODE 0: out = A x (and <x, A x> shares in partials), MODE 1: out = b - A x (and |out|^2 shares), out32 = float(out)
+// MODE 2 (round 5, the fp64-iterate CG loop): the iterate is x + dx -- the fp64 grid as of the last residual replacement and the
+// fp32 sum of the updates alpha p since then (van der Vorst & Ye's group-wise update) -- read as such at all seven points;
+// out32 = float(b - A (x + dx)) like MODE 1, and `out` receives the FLUSHED iterate x + dx (active cells; the others keep x):
+// the loop swaps the two fp64 grids and starts the next group
 template <int MODE>
 __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restrict__ out, const double *__restrict__ x,
                                                         const float *__restrict__ b, float *__restrict__ out32,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials, const float *__restrict__ dx = nullptr)
 {
     const size_t n = size_t(g.nx) * g.ny * g.nz, nq = n >> 2;
     const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny;
@@ -3253,6 +3257,7 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
         const size_t c0 = q << 2;
         const bool any = simpleCell(ls[0]) || simpleCell(ls[1]) || simpleCell(ls[2]) || simpleCell(ls[3]);
         double res[4] = {0.0, 0.0, 0.0, 0.0};  // general BOUNDARY cells: boundary64Kernel right after
+        double flushed[4] = {0.0, 0.0, 0.0, 0.0};  // MODE 2: x + dx on the quad's cells
         if (any && (g.nx & 3) == 0) {
             // the quad lies in one x-row with an active cell in it: the row is not on a grid face, so the four
             // neighbour rows and the cells left and right of the quad exist (EXTERIOR shell); 16-byte loads
@@ -3263,17 +3268,30 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
                 v[1] = a.y;
                 v[2] = bb.x;
                 v[3] = bb.y;
+                if (MODE == 2) {  // (dx is zero -- never written -- on inactive cells of solver-owned grids; the caller's x there is the centre's business below)
+                    const float4 d = *reinterpret_cast<const float4 *>(dx + at);
+                    v[0] += double(d.x);
+                    v[1] += double(d.y);
+                    v[2] += double(d.z);
+                    v[3] += double(d.w);
+                }
             };
             double xs[6], ym[4], yp[4], zm[4], zp[4];
             row(ptrdiff_t(c0), xs + 1);
             xs[0] = x[c0 - 1];
             xs[5] = x[c0 + 4];
+            if (MODE == 2) {
+                xs[0] += double(dx[c0 - 1]);
+                xs[5] += double(dx[c0 + 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) flushed[e] = xs[e + 1];
+            }
             row(ptrdiff_t(c0) - sy, ym);
             row(ptrdiff_t(c0) + sy, yp);
             row(ptrdiff_t(c0) - sz, zm);
             row(ptrdiff_t(c0) + sz, zp);
             float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == 1) bq = reinterpret_cast<const float4 *>(b)[q];
+            if (MODE != 0) bq = reinterpret_cast<const float4 *>(b)[q];
             const float bs[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -3282,24 +3300,33 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
                     res[e] = MODE == 0 ? lap : double(bs[e]) - lap;
                     acc += MODE == 0 ? xs[e + 1] * res[e] : res[e] * res[e];
                 }
-        } else if (any) {
+        } else {
+            auto at = [&](size_t c) { return MODE == 2 ? x[c] + double(dx[c]) : x[c]; };
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const size_t c = c0 + e;
-                if (simpleCell(ls[e])) {  // INTERIOR / simple BOUNDARY: all six neighbours exist (EXTERIOR shell)
-                    const double xc = x[c];
-                    const double lap = double(simpleDiag(ls[e])) * xc - (x[c - 1] + x[c + 1] + x[c - sy] + x[c + sy] + x[c - sz] + x[c + sz]);
+                if (MODE == 2) flushed[e] = at(c);
+                if (any && simpleCell(ls[e])) {  // INTERIOR / simple BOUNDARY: all six neighbours exist (EXTERIOR shell)
+                    const double xc = at(c);
+                    const double lap = double(simpleDiag(ls[e])) * xc - (at(c - 1) + at(c + 1) + at(c - sy) + at(c + sy) + at(c - sz) + at(c + sz));
                     res[e] = MODE == 0 ? lap : double(b[c]) - lap;
                     acc += MODE == 0 ? xc * res[e] : res[e] * res[e];
                 }
             }
         }
-        if (out) {  // (out == nullptr: only float(out) is wanted -- the residual replacement of the fp64-iterate CG loop)
+        if (MODE == 2) {  // the flushed iterate: x + dx on the active cells (general BOUNDARY cells included), x elsewhere
+            typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!activeLabel(ls[e])) flushed[e] = x[c0 + e];
+            reinterpret_cast<d2 *>(out + c0)[0] = d2{flushed[0], flushed[1]};
+            reinterpret_cast<d2 *>(out + c0)[1] = d2{flushed[2], flushed[3]};
+        } else if (out) {  // (out == nullptr: only float(out) is wanted)
             typedef double d2 __attribute__((ext_vector_type(2)));
             reinterpret_cast<d2 *>(out + c0)[0] = d2{res[0], res[1]};
             reinterpret_cast<d2 *>(out + c0)[1] = d2{res[2], res[3]};
         }
-        if (MODE == 1) reinterpret_cast<float4 *>(out32)[q] = make_float4(float(res[0]), float(res[1]), float(res[2]), float(res[3]));
+        if (MODE != 0) reinterpret_cast<float4 *>(out32)[q] = make_float4(float(res[0]), float(res[1]), float(res[2]), float(res[3]));
     }
     const double total = blockReduce<0>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -3307,24 +3334,26 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
 template <int MODE>
 __global__ __launch_bounds__(256) void boundary64Kernel(GridP g, double *__restrict__ out, const double *__restrict__ x,
                                                          const float *__restrict__ b, float *__restrict__ out32,
-                                                         double *__restrict__ partials)
+                                                         double *__restrict__ partials, const float *__restrict__ dx = nullptr)
 {
     double acc = 0.0;
     for (int t = int(blockIdx.x * blockDim.x + threadIdx.x); t < g.nbnd; t += int(gridDim.x * blockDim.x)) {
         const size_t c = size_t(g.bnd[t]), nb = size_t(g.nbnd);
         const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny;
         const float *r = g.rows + t;
-        double lap = double(r[6 * nb]) * x[c];
-        lap -= double(r[0]) * x[c - 1];
-        lap -= double(r[nb]) * x[c + 1];
-        lap -= double(r[2 * nb]) * x[c - sy];
-        lap -= double(r[3 * nb]) * x[c + sy];
-        lap -= double(r[4 * nb]) * x[c - sz];
-        lap -= double(r[5 * nb]) * x[c + sz];
+        auto at = [&](ptrdiff_t p) { return MODE == 2 ? x[p] + double(dx[p]) : x[p]; };  // (MODE 2: the iterate is x + dx; the stencil pass has stored the flushed cell itself)
+        const ptrdiff_t cc = ptrdiff_t(c);
+        double lap = double(r[6 * nb]) * at(cc);
+        lap -= double(r[0]) * at(cc - 1);
+        lap -= double(r[nb]) * at(cc + 1);
+        lap -= double(r[2 * nb]) * at(cc - sy);
+        lap -= double(r[3 * nb]) * at(cc + sy);
+        lap -= double(r[4 * nb]) * at(cc - sz);
+        lap -= double(r[5 * nb]) * at(cc + sz);
         const double res = MODE == 0 ? lap : double(b[c]) - lap;
-        if (out) out[c] = res;
-        if (MODE == 1) out32[c] = float(res);
-        acc += MODE == 0 ? x[c] * res : res * res;
+        if (MODE != 2 && out) out[c] = res;
+        if (MODE != 0) out32[c] = float(res);
+        acc += MODE == 0 ? at(cc) * res : res * res;
     }
     const double total = blockReduce<0>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -3425,20 +3454,36 @@ static unsigned cg64Blocks(const GridP &g, size_t capacity)
 }
 // mode 0: out = A x, *resultDev = <x, A x>; mode 1: out = b - A x, out32 = float(out), *resultDev = |out|^2
 int launchStencil64(void *stream, int mode, const GridP &g, double *out, const double *x, const float *b, float *out32,
-                    double *partials, size_t capacity, double *resultDev)
+                    double *partials, size_t capacity, double *resultDev, const float *dx)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned nb = cg64Blocks(g, capacity);
+    if (mode == 2 && (!dx || !out || out == x)) return int(hipErrorInvalidValue);
     if (mode == 0) stencil64Kernel<0><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
-    else stencil64Kernel<1><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
+    else if (mode == 1) stencil64Kernel<1><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials);
+    else stencil64Kernel<2><<<nb, 256, 0, s>>>(g, out, x, b, out32, partials, dx);
     unsigned nparts = nb;
     if (g.nbnd > 0) {
         const unsigned nbb = std::min(blocksFor(size_t(g.nbnd), 256), 1024u);  // grid-stride beyond that
         if (mode == 0) boundary64Kernel<0><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
-        else boundary64Kernel<1><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
+        else if (mode == 1) boundary64Kernel<1><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb);
+        else boundary64Kernel<2><<<nbb, 256, 0, s>>>(g, out, x, b, out32, partials + nb, dx);
         nparts += nbb;
     }
     return launchFoldDot(stream, partials, nparts, resultDev);
+}
+// x32 = float(x64 (+ x32)) on the active cells of level g (the others keep what the caller put there): the fp64-iterate CG loop hands its result back
+__global__ __launch_bounds__(256) void narrowSumKernel(size_t n, const uint8_t *__restrict__ lab, float *__restrict__ x32, const double *__restrict__ x64, int addDx)
+{
+    const size_t c = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (activeLabel(lab[c])) x32[c] = addDx ? float(x64[c] + double(x32[c])) : float(x64[c]);  // (inactive cells: the caller's values, never touched)
+}
+int launchNarrowSum(void *stream, const GridP &g, float *x32, const double *x64, bool addDx)
+{
+    const size_t n = size_t(g.nx) * g.ny * g.nz;
+    narrowSumKernel<<<blocksFor(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, g.lab, x32, x64, addDx ? 1 : 0);
+    return int(hipGetLastError());
 }
 int launchCgUpdate64(void *stream, const GridP &g, double *x, const double *p, double *r, const double *t, double alpha, float *r32,
                      double *partials, size_t capacity, double *resultDev)
@@ -3520,8 +3565,10 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
                                                       const float *__restrict__ p, float *__restrict__ r,
                                                       const float *__restrict__ t, float alpha, double *__restrict__ partials,
                                                       const int32_t *__restrict__ chunks, int nchunks, int chunkCells,
-                                                      const double *__restrict__ alphaDev, double *__restrict__ maxPartials)
+                                                      const double *__restrict__ alphaDev, double *__restrict__ maxPartials, int xFirst = 0)
 {
+    // xFirst (fp32 x, the fp64-iterate loop of round 5): x is the sum of the updates since the last flush and this is the first
+    // of a group -- x = alpha p on the active cells, nothing of the old x read
     constexpr bool kWide = std::is_same<XT, double>::value;
     double alphaD = double(alpha);
     if (alphaDev) {  // <z, r> / <p, A p> left on the device by the reductions (CG.h:121)
@@ -3547,11 +3594,13 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
             xq[0] = xa;
             xq[1] = xb;
         } else {
-            float4 xv = reinterpret_cast<const float4 *>(x)[q];
-            if (activeLabel(l.x)) xv.x = xv.x + alpha * pv.x;
-            if (activeLabel(l.y)) xv.y = xv.y + alpha * pv.y;
-            if (activeLabel(l.z)) xv.z = xv.z + alpha * pv.z;
-            if (activeLabel(l.w)) xv.w = xv.w + alpha * pv.w;
+            const bool all = activeLabel(l.x) && activeLabel(l.y) && activeLabel(l.z) && activeLabel(l.w);
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!xFirst || !all) xv = reinterpret_cast<const float4 *>(x)[q];  // (a quad with an inactive cell keeps that cell's value)
+            if (activeLabel(l.x)) xv.x = (xFirst ? 0.f : xv.x) + alpha * pv.x;
+            if (activeLabel(l.y)) xv.y = (xFirst ? 0.f : xv.y) + alpha * pv.y;
+            if (activeLabel(l.z)) xv.z = (xFirst ? 0.f : xv.z) + alpha * pv.z;
+            if (activeLabel(l.w)) xv.w = (xFirst ? 0.f : xv.w) + alpha * pv.w;
             reinterpret_cast<float4 *>(x)[q] = xv;
         }
         if (activeLabel(l.x)) { rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); big = fmaxf(big, fabsf(rv.x)); }
@@ -3563,7 +3612,7 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t c = (nq << 2) + threadIdx.x;
         if (activeLabel(lab[c])) {
-            x[c] = kWide ? XT(double(x[c]) + alphaD * double(p[c])) : XT(float(x[c]) + alpha * p[c]);
+            x[c] = kWide ? XT(double(x[c]) + alphaD * double(p[c])) : XT((xFirst ? 0.f : float(x[c])) + alpha * p[c]);
             r[c] = r[c] + (-alpha) * t[c];
             acc += double(r[c]) * double(r[c]);
             big = fmaxf(big, fabsf(r[c]));
@@ -3579,14 +3628,14 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
 }
 
 int launchCgUpdate(void *stream, const GridP &g, float *x, const float *p, float *r, const float *t, float alpha, double *partials,
-                   double *resultDev, const double *alphaDev, double *maxAbsDev, double *xWide)
+                   double *resultDev, const double *alphaDev, double *maxAbsDev, double *xWide, bool xFirst)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = size_t(g.nx) * g.ny * g.nz;
     const unsigned nb = std::min<unsigned>(vecBlocks(g, n), unsigned(kReducePartials));
     double *maxPartials = maxAbsDev ? partials + kReducePartials : nullptr;  // (`partials` holds 2 x kReducePartials doubles)
     if (xWide) cgUpdateKernel<double><<<nb, 256, 0, s>>>(n, g.lab, xWide, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
-    else cgUpdateKernel<float><<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials);
+    else cgUpdateKernel<float><<<nb, 256, 0, s>>>(n, g.lab, x, p, r, t, alpha, partials, g.chunks, g.nchunks, g.chunkCells, alphaDev, maxPartials, xFirst ? 1 : 0);
     reduceFinalKernel<1><<<1, 256, 0, s>>>(int(nb), partials, resultDev);
     if (maxAbsDev) reduceFinalKernel<3><<<1, 256, 0, s>>>(int(nb), maxPartials, maxAbsDev);
     return int(hipGetLastError());

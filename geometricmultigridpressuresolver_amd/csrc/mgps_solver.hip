@@ -1517,29 +1517,46 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     // loop at eps * cond (2.8e-3 at 512^3, 2e-2 at 1024^3 on the free-surface pool, while the pressure is 4e-7 from the oracle's)
     // is the fp32 STORAGE of x: the loop then carries x in fp64 (x += alpha p, 8 B more per cell and iteration), takes the
     // residuals of CG.h:50-51 and 203-205 in fp64 from it and hands back the rounded x; r, p, A p and the V-cycle stay fp32
+    // Round 5: the fp64 iterate is touched only where a true residual is taken.  Between two such points the updates alpha p are
+    // summed in fp32 IN THE CALLER'S x (free during the solve: the iterate is x64 + x) -- the group-wise update of van der Vorst &
+    // Ye: the rounding of that sum is relative to the sum, eight updates small against the iterate -- so an iteration moves the
+    // bytes of the fp32 loop; the replacement pass reads x64 + x at its seven points, leaves float(b - A (x64 + x)) and the flushed
+    // iterate in the second fp64 grid (the two swap), and the next group starts with x = alpha p.  Per iteration 3 B per cell
+    // more than the fp32 loop instead of 10.
     const bool wideX = h->opt.pcg_fp64_vectors == 2 && !(useMG && h->opt.precision == 1);
-    double *x64 = nullptr;
+    double *x64 = nullptr, *x64Spare = nullptr;
+    int grouped = 0;  // updates summed in x since the last flush
     if (wideX) {
         const size_t plane = size_t(F.d.nx) * F.d.ny;
-        if (!h->cg64[0]) {
-            double *base = nullptr;
-            MGPS_TRY(devAlloc(h, &base, F.d.cells() + 2 * plane, true));
-            h->cg64[0] = base + plane;
-        }
+        for (int q = 0; q < 2; ++q)
+            if (!h->cg64[q]) {
+                double *base = nullptr;
+                MGPS_TRY(devAlloc(h, &base, F.d.cells() + 2 * plane, true));
+                h->cg64[q] = base + plane;
+            }
         x64 = h->cg64[0];
+        x64Spare = h->cg64[1];
     }
     SolveClock clock(h);  // (destroys its events and resets h->dotTarget on every way out)
     if (!clock.ok) return failH(h, MGPS_ERR_HIP, "hipEventCreate failed");
+    bool widened = false;  // (x64 holds the caller's iterate: from then on x is the sum of the pending updates)
     auto finish = [&](int outcome) {
-        if (wideX && outcome != MGPS_PCG_RHS_ZERO) (void)launchNarrow(h->stream, x, x64, F.d.cells());  // (what the iterations reached, rounded once)
+        if (wideX && widened) (void)launchNarrowSum(h->stream, F.g, x, x64, grouped > 0);  // (what the iterations reached, rounded once)
         st->outcome = outcome;
         st->solve_ms = clock.stop();
         return MGPS_OK;
     };
-    // r = b - A x from the wide iterate: the fp64 stencil pass of the fp64-vector loop (it leaves float(r) in r32 and |r|^2 on the device)
+    // r = float(b - A x) from the wide iterate x64 (+ the pending updates in x, which are flushed on the way): it leaves float(r) in r
+    // and |r|^2 on the device
     auto wideResidual = [&](double *res2) -> int {
         MGPS_TRY(exchangeGhosts64(h, x64));
-        MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, nullptr, x64, b, r, h->dotPartials, h->dotCapacity, h->resultDev));
+        if (grouped > 0) {
+            MGPS_TRY(exchangeGhosts(h, 0, x));
+            MGPS_LAUNCH(h, launchStencil64(h->stream, 2, F.g, x64Spare, x64, b, r, h->dotPartials, h->dotCapacity, h->resultDev, x));
+            std::swap(x64, x64Spare);
+            grouped = 0;
+        } else
+            MGPS_LAUNCH(h, launchStencil64(h->stream, 1, F.g, nullptr, x64, b, r, h->dotPartials, h->dotCapacity, h->resultDev));
         return fetchReduction(h, 1, res2);
     };
     // dst = M src; gathered: <dst, src> is already in h->resultDev (a by-product of the V-cycle's last stroke)
@@ -1578,6 +1595,8 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     double res2 = 0;
     if (wideX) {
         MGPS_LAUNCH(h, launchWiden(h->stream, x64, x, F.d.cells()));
+        // (the second fp64 grid: zero since its allocation wherever no pass writes -- inactive cells, which read as 0 in every grid)
+        widened = true;
         MGPS_TRY(wideResidual(&res2));  // CG.h:50-57 (r = float of the fp64 residual)
     } else {
         MGPS_TRY(applyOp(h, OP_RESIDUAL, 0, r, x, b, true));  // CG.h:50-51
@@ -1640,7 +1659,8 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         // x += alpha p (CG.h:132), r -= alpha t (143) and |r|^2 (153) in one pass over the grids
         const bool mixed = useMG && h->opt.precision == 1;  // the pass also leaves max |r| for the cycle's normalisation
         MGPS_LAUNCH(h, launchCgUpdate(h->stream, F.g, x, p, r, t, float(alpha), h->partials, h->resultDev, devScal ? scal : nullptr,
-                                      mixed ? h->mixMax : nullptr, x64));
+                                      mixed ? h->mixMax : nullptr, nullptr, wideX && grouped == 0));
+        if (wideX) ++grouped;
         if (devScal && h->dist) {  // |r|^2 summed on the device too: the fetch below is then the iteration's only host round trip
             MGPS_TRY(sumOverRanks(h->resultDev));
             MGPS_HIP(h, hipMemcpyAsync(h->resultHost, h->resultDev, sizeof(double), hipMemcpyDeviceToHost, h->stream));

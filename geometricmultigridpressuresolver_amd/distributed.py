@@ -110,6 +110,7 @@ class TorchDistComm:
         self.struct = CommStruct(C.sizeof(CommStruct), self.rank, self.size, None, *self._cb, _DEST(), *self._cbv)
         self.device_allreduces = 0
         self.segmented_exchanges = 0
+        self.drop_every = 0  # test hook: > 0 = what every N-th exchange receives is thrown away
 
     # -- staging helpers ---------------------------------------------------------------------------
     def _d2h(self, ptr, nbytes, stream):
@@ -141,6 +142,8 @@ class TorchDistComm:
                     recvs.append((recv, inc))
             for w in dist.batch_isend_irecv(ops) if ops else []:
                 w.wait()
+            if self.drop_every and self.exchanges % self.drop_every == 0:
+                return 0  # (test hook: the ghost data never arrive)
             for recv, inc in recvs:
                 self._h2d(recv, inc)
             return 0
@@ -166,6 +169,8 @@ class TorchDistComm:
                         recvs.append((recv.contents.ptr[q], inc))
             for w in dist.batch_isend_irecv(ops) if ops else []:
                 w.wait()
+            if self.drop_every and self.exchanges % self.drop_every == 0:
+                return 0  # (test hook)
             for ptr, inc in recvs:
                 self._h2d(ptr, inc)
             return 0
@@ -261,6 +266,15 @@ class TorchDistComm:
 
     def close(self):
         pass
+
+
+def comm_preflight(comm, floats=1 << 16):
+    """mgps_comm_preflight: rank-stamped data through every entry of the transport, verified on arrival.  Collective.  Returns the
+    number of ranks the (device) all-reduce counted; raises when something arrives wrong."""
+    seen = C.c_int()
+    lib().mgps_comm_preflight.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    check(lib().mgps_comm_preflight(C.byref(comm.struct), int(floats), C.byref(seen)))
+    return seen.value
 
 
 def slab_partition(labels, mg_levels, size, use_gauss_seidel, options=None):

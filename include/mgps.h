@@ -403,6 +403,11 @@ int mgps_comm_rccl_selftest(mgps_comm *comm, size_t floats);
 /* diagnostic: device time (microseconds per group, HIP events) of `reps` back-to-back self send + receive
  * groups of `floats` floats -- the floor of one ghost exchange on this box */
 int mgps_comm_rccl_selfbench(mgps_comm *comm, size_t floats, int reps, double *us_per_exchange);
+/* A check of any transport before a run trusts it (bench.py --gpus N calls it before its timed region): every rank pushes
+ * rank-stamped data through exchange, exchange2, allreduce_device, allreduce, gather and scatter and verifies what arrives from
+ * its neighbours; the ranks leave with one verdict (MGPS_OK, or MGPS_ERR_COMM with the first finding in mgps_last_error(NULL)).
+ * *ranks_seen: the number of ranks as the (device) all-reduce counted them.  Collective: every rank calls it. */
+int mgps_comm_preflight(const mgps_comm *comm, size_t floats, int *ranks_seen);
 void mgps_comm_destroy(mgps_comm *comm);
 
 /* The slab form of the constructor.  labels_global_host: the WHOLE solver grid's labels

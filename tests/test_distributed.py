@@ -91,6 +91,42 @@ def test_rccl_transport_single_rank():
     run_workers("rccl1", 1, 300)
 
 
+def run_bench(extra, timeout=600):
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--size", "256", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-frac512"] + extra
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="2"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--gpus", "1", "--force-slab"], ["--gpus", "2", "--rehearse-gloo"], ["--gpus", "4", "--rehearse-gloo"]])
+def test_bench_slab_line_checks_itself(extra):
+    """bench.py --gpus N (round 5): before the timed region every rank pushes rank-stamped data through every entry of the
+    transport (slab.preflight, slab.rccl_ranks_seen); after it the relative residual of three V-cycles is compared with the
+    value the single-GPU solver stored in bench_check.json (slab.check).  --force-slab: the RCCL transport with one rank;
+    --rehearse-gloo: 2 and 4 ranks sharing the GPU over the host-staged transport."""
+    import json
+
+    res = run_bench(extra)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    n = int(extra[1])
+    assert line["n_gpus"] == n and line["slab"]["preflight"] == "ok" and line["slab"]["rccl_ranks_seen"] == n
+    assert line["slab"]["check"]["status"] == "ok" and line["check"]["reference"] is not None, line["slab"]["check"]
+    assert line["slab"]["ghost_planes"] == 5 and all(f == "boxes" for f in line["slab"]["band_stage"])
+
+
+@pytest.mark.gpu
+def test_bench_check_catches_a_dropped_exchange():
+    """the same line with the transport's test hook dropping every third exchange during the check cycles: the check must
+    fail and the process must exit non-zero"""
+    import json
+
+    res = run_bench(["--gpus", "2", "--rehearse-gloo", "--test-drop-exchange", "3"])
+    assert res.returncode != 0, res.stdout[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["slab"]["check"]["status"] == "FAILED", line["slab"]["check"]
+
+
 @pytest.mark.parametrize("nproc", [2, 4])
 def test_slab_schedule_emulation_cpu(nproc):
     out = run_workers("cpu", nproc, 600)

@@ -998,16 +998,18 @@ def test_large_coarsest_level_is_factorised_on_the_device(oracle, torch_cuda):
     gpu.close()
 
 
-@pytest.mark.parametrize("levels", [6, 5])
-def test_config3_512_free_surface_pcg(levels, oracle, torch_cuda):
+@pytest.mark.parametrize("levels,use_gs", [(6, True), (5, True), (6, False)])
+def test_config3_512_free_surface_pcg(levels, use_gs, oracle, torch_cuda):
     """BASELINE config 3: 512^3 free-surface pool (sine liquid surface, ghost-fluid weights up to 1/0.01, cut-cell solid
-    box), MG-preconditioned CG with the plugin's smoother (tiled Gauss-Seidel, Plug.cpp:466) to 1e-5 on the delta +
-    random rhs.  Stated criteria, against the fp64 oracle solving the same system (about 15 s on 16 host cores):
+    box), MG-preconditioned CG with the plugin's smoother (tiled Gauss-Seidel, Plug.cpp:466) -- and with damped Jacobi, what
+    MGPS_DOP_SMOOTHER=jacobi selects in the shipped DOP node -- to 1e-5 on the delta +
+    random rhs.  Stated criteria, against the fp64 oracle solving the same system with the same smoother (about 15 s on 16 host cores):
       * iteration count within +-2 of the oracle's;
       * pressure field relative L2 difference < 1e-5 (the "same pressure field" criterion of the north star);
       * fp32 CG vectors: the recurrence residual CG tests is < 1e-5; the residual *recomputed* in fp32 from the fp32
         iterate floors at eps * cond (ghost-fluid weights of 100 amplify the rounding of x) and is only required < 1e-2;
-      * options.pcg_fp64_vectors: the recomputed residual is a true fp64 residual and must itself be < 1e-5."""
+      * options.pcg_fp64_vectors = 1 (all CG vectors fp64) and = 2 (the default: the iterate in fp64 with group-wise fp32 updates
+        and residual replacement): the recomputed residual is a true fp64 residual and must itself be < 1e-5."""
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
 
@@ -1018,18 +1020,18 @@ def test_config3_512_free_surface_pcg(levels, oracle, torch_cuda):
     pad = 2 ** (levels - 1)
     b = (D.delta_rhs(lab, n - 2 * pad, pad, h) + D.random_rhs(lab, h)).astype(np.float32)
     results = {}
-    variants = (0, 1) if levels == 6 else (0,)
+    variants = ((0, 1, 2) if use_gs else (2,)) if levels == 6 else (2,)
     for fp64 in variants:
         opt = G.default_options()
         opt.pcg_fp64_vectors = fp64
-        gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, True, options=opt)
+        gpu = G.GeometricMultigridPoissonSolver(lab, w, levels, use_gs, options=opt)
         xd = gpu.new_grid()
         st = gpu.solveGeometricConjugateGradient(xd, gpu.to_device(b), 1e-5, 2500, True)
         results[fp64] = (st, xd.cpu().numpy().astype(np.float64))
         gpu.close()
         del gpu, xd
         torch_cuda.cuda.empty_cache()
-    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, True)
+    orc = oracle.solver(lab.astype(np.int32), [a.astype(np.float64) for a in w], levels, use_gs)
     x_ref = np.zeros(lab.shape)
     ref = orc.solve_pcg(x_ref, b.astype(np.float64), 1e-5, 2500, True)
     assert ref["rel_residual_recomputed"] < 1e-5
