@@ -756,7 +756,8 @@ bool residualRestrictFuses(const mgps_solver *h, int l)
     if (mode < 0 && size_t(F.nx) * F.ny * sizeof(float) < kPlaneSweepMinPlaneBytes) return false;
     return residualRestrictFits(F, h->lv[l + 1].g);
 }
-int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
+// out (optional): where the coarse rhs goes instead of the coarse level's own rhs grid (mgps_residual_downsample)
+int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs, float *out = nullptr)
 {
     DevLevel &F = h->lv[l], &C = h->lv[l + 1];
     if (!F.rz) {
@@ -785,7 +786,7 @@ int residualRestrict(mgps_solver *h, int l, const float *x, const float *rhs)
         MGPS_LAUNCH(h, launchResidualZ(h->stream, F.g, F.rz, x, rhs, F.rzEdges, F.nrzEdges, cut ? F.r : nullptr));
     }
     StageScope scope(h, ST_RESTRICT, l);
-    MGPS_LAUNCH(h, launchRestrictXY(h->stream, C.g, C.b, F.rz));
+    MGPS_LAUNCH(h, launchRestrictXY(h->stream, C.g, out ? out : C.b, F.rz));
     return MGPS_OK;
 }
 
@@ -4341,6 +4342,22 @@ try {
     // "destination cleared first" (Ops.h:756): the kernel itself only visits chunks with active cells
     MGPS_LAUNCH(h, launchZero(h->stream, coarse_dev, h->lv[fine_level + 1].d.cells()));
     MGPS_LAUNCH(h, launchRestrict(h->stream, h->lv[fine_level + 1].g, coarse_dev, fine_dev));
+    return MGPS_OK;
+}
+MGPS_API_CATCH(h)
+
+int mgps_residual_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *x_dev, const float *b_dev)
+try {
+    MGPS_TRY(checkLevel(h, fine_level + 1, "mgps_residual_downsample"));
+    if (fine_level < 0 || !coarse_dev || !x_dev || !b_dev) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_residual_downsample: bad arguments");
+    if (h->opt.precision == 1 && fine_level == 0) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_residual_downsample: fp32 levels only");
+    DevLevel &F = h->lv[fine_level];
+    MGPS_LAUNCH(h, launchZero(h->stream, coarse_dev, h->lv[fine_level + 1].d.cells()));  // "destination cleared first" (Ops.h:756)
+    if (residualRestrictFuses(h, fine_level)) return residualRestrict(h, fine_level, x_dev, b_dev, coarse_dev);
+    if (!F.r) return failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_residual_downsample: level has no work grids");
+    MGPS_TRY(applyOp(h, OP_RESIDUAL, fine_level, F.r, const_cast<float *>(x_dev), b_dev, true));
+    MGPS_TRY(exchangeGhosts(h, fine_level, F.r));
+    MGPS_LAUNCH(h, launchRestrict(h->stream, h->lv[fine_level + 1].g, coarse_dev, F.r));
     return MGPS_OK;
 }
 MGPS_API_CATCH(h)

@@ -310,6 +310,10 @@ class GeometricMultigridPoissonSolver:
     def downsample(self, destination, source, fine_level=0):
         check(lib().mgps_downsample(self.h, fine_level, self._g(destination, fine_level + 1), self._g(source, fine_level)), self.h)
 
+    def residualDownsample(self, destination, solution, rhs, fine_level=0):
+        """mgps_residual_downsample: destination (level fine_level + 1) = downsample(rhs - A solution) as a down-stroke forms it"""
+        check(lib().mgps_residual_downsample(self.h, fine_level, self._g(destination, fine_level + 1), self._g(solution, fine_level), self._g(rhs, fine_level)), self.h)
+
     def upsampleAndAdd(self, destination, source, fine_level=0):
         check(lib().mgps_upsample_add(self.h, fine_level, self._g(destination, fine_level), self._g(source, fine_level + 1)), self.h)
 

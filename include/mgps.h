@@ -295,6 +295,12 @@ int mgps_apply_poisson(mgps_solver *h, int level, float *y_dev, const float *x_d
 int mgps_residual(mgps_solver *h, int level, float *r_dev, const float *x_dev, const float *b_dev);
 /* downsample (Ops.h:734-835): coarse (level+1) = Restrict(fine (level)) */
 int mgps_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *fine_dev);
+/* coarse = downsample(b - A x) of level fine_level the way a down-stroke of the V-cycle forms it (MG.cpp:519-553: computePoissonResidual,
+ * Ops.h:716-732, then downsample, Ops.h:734-835): as two passes over the level's residual grid, or -- where
+ * mgps_residual_restrict_fused says so -- as the pair that folds the residual along z while it is formed and restricts in x-y
+ * from there, without writing the residual.  coarse_dev: a grid of level fine_level + 1 (cleared first, Ops.h:756). */
+int mgps_residual_downsample(mgps_solver *h, int fine_level, float *coarse_dev, const float *x_dev, const float *b_dev);
+
 /* upsampleAndAdd (Ops.h:873-972): fine (level) += 4 * Trilerp(coarse (level+1)) */
 int mgps_upsample_add(mgps_solver *h, int fine_level, float *fine_dev, const float *coarse_dev);
 /* coarsest-level direct solve (MG.cpp:669-692) on device grids of the coarsest level */

@@ -811,6 +811,9 @@ def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
     assert int((lab == 3).sum()) > 100000
     gpu = G.GeometricMultigridPoissonSolver(lab, w, lev, False)
     assert gpu.stencil_kernel(0) == "quad" and gpu.stencil_kernel(1) == "quad"
+    # by size (4 MiB planes) the fine level's down-stroke takes residual + restriction as the z-folded pair (residualZKernel with its
+    # edge and general-cell launches + restrictXYKernel, round 4) -- the V-cycles below run through it; level 1 (1 MiB planes) does not
+    assert gpu.residual_restrict_fused(0) and not gpu.residual_restrict_fused(1)
     lab32 = lab.astype(np.int32)
     w64 = [a.astype(np.float64) for a in w]
     x0 = _rand_active(lab, 1)
@@ -821,6 +824,15 @@ def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
     rd = gpu.new_grid()
     gpu.computePoissonResidual(rd, xd, bd)
     assert rel_err(rd.cpu().numpy(), ref) < OP_TOL
+    # the pair as an operator against the oracle's downsample(residual): free surface (blocks the liquid leaves: edge launches) and
+    # a cut-cell solid (general BOUNDARY cells: the four patch launches)
+    lab1 = gpu.hierarchy().level_labels(1).astype(np.int32)
+    coarse_ref = np.zeros(lab1.shape)
+    oracle.downsample(coarse_ref, ref, lab1)
+    cd = gpu.new_grid(1)
+    gpu.residualDownsample(cd, xd, bd, 0)
+    assert rel_err(cd.cpu().numpy(), coarse_ref) < OP_TOL
+    del coarse_ref, cd
     xj = x0.copy()
     oracle.jacobi(xj, b0, lab32, w64)
     gpu.jacobiPoissonSmoother(xd, bd)
@@ -835,6 +847,74 @@ def test_plane_sweep_natural_dispatch_matches_oracle(oracle, torch_cuda):
         gpu.applyVCycle(xs, bd, it > 0)
         assert rel_l2(xs.cpu().numpy(), x_ref) < VCYCLE_TOL * (it + 1), it
     gpu.close()
+
+
+@pytest.mark.parametrize("case", ["stair", "wsolid", "rag264"])
+def test_residual_restriction_pair_matches_oracle(case, torch_cuda):
+    """residualZKernel / residualZEdgeKernel / residualZGeneralKernel + restrictXYKernel (round 4) against the ORACLE's
+    downsample(residual(x)) as one operator (mgps_residual_downsample), forced onto small grids with MGPS_FUSE_RR=1 (by size only
+    4 MiB planes take the pair): stair -- a step in the liquid on block boundaries, so that blocks without active cells owe rz a
+    plane of terms (the edge launch); wsolid -- free surface + cut-cell solid: general BOUNDARY cells (the four patch launches);
+    rag264 -- ragged tiles at the end of every axis.  Also against the two separate passes of the same solver (MGPS_FUSE_RR=0)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import geometricmultigridpressuresolver_amd as G\n"
+        "from geometricmultigridpressuresolver_amd import domains as D\n"
+        "from oracle.mg_oracle import Oracle\n"
+        "case, fused = sys.argv[1], sys.argv[2] == '1'\n"
+        "if case == 'wsolid':\n"
+        "    bl, bw, dx = D.build_complex_domain((24, 32, 256), use_solid=True)\n"
+        "    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(32, 40, 264))\n"
+        "else:\n"
+        "    shape = (20, 44, 248) if case == 'rag264' else (24, 32, 248)\n"
+        "    bl = np.full(shape, D.DIRICHLET, dtype=np.uint8)\n"
+        "    if case == 'stair':\n"
+        "        bl[1:8, 1:12, 1:-1] = D.INTERIOR\n"
+        "        bl[1:16, 12:31, 1:-1] = D.INTERIOR\n"
+        "    else:\n"
+        "        bl[1:-1, 1:-1, 1:-1] = D.INTERIOR\n"
+        "    bw = []\n"
+        "    for axis in range(3):\n"
+        "        wa = np.zeros(D.face_shape(*shape, axis), dtype=np.float32)\n"
+        "        back, fwd = D._shift_pair(bl, axis)\n"
+        "        wa[D._inner_faces(wa, axis)] = np.where((back == D.INTERIOR) | (fwd == D.INTERIOR), 1.0, 0.0)\n"
+        "        bw.append(wa)\n"
+        "    dx = 1.0 / 248\n"
+        "    lab, w, off, lev = D.expand_domain(bl, bw, levels=3, solver_shape=(28, 52, 264) if case == 'rag264' else (32, 40, 264))\n"
+        "s = G.GeometricMultigridPoissonSolver(lab, w, lev, False)\n"
+        "assert s.stencil_kernel(0) == 'plane' and s.residual_restrict_fused(0) == fused, (s.stencil_kernel(0), s.residual_restrict_fused(0))\n"
+        "rng = np.random.default_rng(5)\n"
+        "act = D.active_mask(lab)\n"
+        "x0 = np.where(act, rng.standard_normal(lab.shape), 0.0).astype(np.float32)\n"
+        "b0 = np.where(act, rng.standard_normal(lab.shape) * dx * dx, 0.0).astype(np.float32)\n"
+        "cd = s.new_grid(1)\n"
+        "s.residualDownsample(cd, s.to_device(x0), s.to_device(b0), 0)\n"
+        "orc = Oracle()\n"
+        "r = np.zeros(lab.shape); orc.residual(r, x0.astype(np.float64), b0.astype(np.float64), lab.astype(np.int32), [a.astype(np.float64) for a in w])\n"
+        "lab1 = s.hierarchy().level_labels(1).astype(np.int32)\n"
+        "ref = np.zeros(lab1.shape); orc.downsample(ref, r, lab1)\n"
+        "err = np.abs(cd.cpu().numpy() - ref).max() / np.abs(ref).max()\n"
+        "assert np.abs(ref).max() > 0 and err < 5e-6, err\n"
+        "np.save(sys.argv[3], cd.cpu().numpy())\n"
+        "print('PAIR_OK', err)\n"
+    ) % (ROOT, ROOT)
+    import tempfile
+
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for fused in ("1", "0"):
+            path = __import__("os").path.join(tmp, f"c{fused}.npy")
+            env = dict(**__import__("os").environ, MGPS_FUSE_RR=fused, MGPS_STENCIL="plane")
+            res = subprocess.run([sys.executable, "-c", code, case, fused, path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+            assert res.returncode == 0 and "PAIR_OK" in res.stdout, res.stdout[-3000:]
+            outs.append(np.load(path))
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * np.abs(outs[1]).max()
 
 
 def test_plane_sweep_by_size_matches_oracle(oracle, torch_cuda):
