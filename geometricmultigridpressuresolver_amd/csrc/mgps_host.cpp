@@ -749,350 +749,6 @@ void buildSlabLevel(const HostLevel &G, int z0, int z1, const float *wx, const f
     }
 }
 
-// ---- fused band passes: group builder (see BandGroups) ----------------------------------------------
-namespace {
-
-struct GroupBuild {
-    std::vector<int32_t> updateEntry, updateCell, readCell;
-    std::vector<uint16_t> neighbours;
-    int cnt[kBandMaxDepth] = {0, 0, 0, 0};
-};
-
-// What the builder walks over: a window of whole x-y planes (the whole grid, or a slab plus the planes of
-// its neighbours that the passes reach), indexed like a grid of extents wd.
-struct BandWindow {
-    Dims wd;
-    const uint8_t *labels = nullptr;     // reference labels or device codes of the window (active: 0 or >= 3)
-    // window cell -> output entry (>= 0), kDeepBand, or kNoBand.  A big block of the library (hostBigAlloc: page-locked and kept
-    // for the next solver -- in a process that holds GPU mappings 0.6 GB of FRESH pages cost ~100 ms, a third of a slab
-    // rank's set-up at 1024^3 / 8)
-    RawVec<int32_t> entryOf;
-    void allocEntryOf()                  // filled with kNoBand by all host threads (0.5 GB at 512^3)
-    {
-        const size_t n = wd.cells();
-        entryOf.resize(n);
-        int32_t *p = entryOf.data();
-        parallelFor(int64_t(n), [p](int64_t b, int64_t e) { std::fill(p + b, p + e, kNoBand); }, 1 << 20);
-    }
-    // whole-grid windows skip the dense map: the reference band order is (tile, k, j, i), so a cell is found by a
-    // binary search among the band cells of its 16^3 tile
-    const int32_t *sortedBand = nullptr;  // band cells in reference order
-    const int32_t *tileStart = nullptr;      // per tile (+1): first index of its cells in sortedBand
-    size_t ntiles = 0;
-    const int32_t *entryOfSorted = nullptr;  // per index of sortedBand: the output entry
-    int tilesX = 0, tilesY = 0;
-    int32_t entryAt(size_t wc) const
-    {
-        if (!entryOf.empty()) return entryOf[wc];
-        const int i = int(wc % wd.nx), j = int((wc / wd.nx) % wd.ny), k = int(wc / (size_t(wd.nx) * wd.ny));
-        const size_t tile = (size_t(k / kTile) * tilesY + j / kTile) * tilesX + i / kTile;
-        const int32_t *lo = sortedBand + tileStart[tile], *hi = sortedBand + tileStart[tile + 1];
-        const int32_t *it = std::lower_bound(lo, hi, int32_t(wc));  // same tile: reference order == cell order
-        return (it != hi && *it == int32_t(wc)) ? entryOfSorted[size_t(it - sortedBand)] : kNoBand;
-    }
-    const int32_t *seedCell = nullptr;   // per output entry: its window cell
-    size_t nSeeds = 0;
-    const uint8_t *entryDiag = nullptr;  // per output entry: diagonal 1..6, 0 = general BOUNDARY cell (row list)
-    std::vector<int32_t> seedCellOwn;    // (storage of the two when the window is not a level's own band)
-    std::vector<uint8_t> entryDiagOwn;
-    // device address of a window cell: grid offset from owned cell 0 for the planes that live in the grid
-    // allocation, otherwise a slot of the halo buffers (encoded below gridLoCode)
-    int gridPlaneLo = 0, gridPlaneHi = 0;
-    ptrdiff_t cellShift = 0;
-    const std::unordered_map<int64_t, int32_t> *haloSlot = nullptr;
-    int32_t gridLoCode = 0;
-    // band cells of neighbouring slabs that are nobody's output here: their rows (8 floats each, see buildSlabHalo)
-    const std::unordered_map<int64_t, int32_t> *foreignRowOf = nullptr;  // window cell -> row index
-    const float *foreignRows8 = nullptr;
-    int32_t foreignBase = 0;  // band entry that addresses foreign row 0 in the kernel
-    static constexpr int32_t kNoBand = -1, kDeepBand = -2;  // kDeepBand: a band cell that is nobody's output here
-
-    size_t cellLimit = SIZE_MAX;         // whole-grid windows: cells past the array (a level without EXTERIOR shell) are inactive
-    bool active(size_t wc) const { return wc < cellLimit && (labels[wc] == MGPS_INTERIOR_CELL || labels[wc] >= kCodeGeneral); }
-    int diagFromLabels(size_t wc) const  // simple cell: number of non-EXTERIOR face neighbours
-    {
-        const ptrdiff_t sy = wd.nx, sz = ptrdiff_t(wd.nx) * wd.ny, off[6] = {-1, 1, -sy, sy, -sz, sz};
-        int dgn = 0;
-        for (int q = 0; q < 6; ++q) dgn += labels[ptrdiff_t(wc) + off[q]] != MGPS_EXTERIOR_CELL;
-        return dgn;
-    }
-    bool deviceCell(size_t wc, int32_t &code) const
-    {
-        const int k = int(wc / (size_t(wd.nx) * wd.ny));
-        if (k >= gridPlaneLo && k < gridPlaneHi) {
-            code = int32_t(ptrdiff_t(wc) - cellShift);
-            return true;
-        }
-        if (!haloSlot) return false;
-        auto it = haloSlot->find(int64_t(wc));
-        if (it == haloSlot->end()) return false;
-        code = gridLoCode - 1 - it->second;
-        return true;
-    }
-};
-
-// breadth-first over band-to-band stencil edges from the owned entries; 0 = fits one workgroup, 1 = too
-// large (split the owned set), 2 = a cell the passes reach has no device address (builder bug)
-int buildOneGroup(const BandWindow &W, const std::vector<int32_t> &owned, int depth, GroupBuild &g)
-{
-    const ptrdiff_t sy = W.wd.nx, sz = ptrdiff_t(W.wd.nx) * W.wd.ny;
-    const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    g = GroupBuild();
-    // node ids of the cells the passes can reach: a dense array over the bounding box of the owned cells grown
-    // by `depth` (the walk never leaves it); kUnset = not seen, read-only nodes as -(r + 2)
-    constexpr int32_t kUnset = INT32_MIN;
-    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
-    for (int32_t t : owned) {
-        const size_t c = size_t(W.seedCell[size_t(t)]);
-        const int ijk[3] = {int(c % W.wd.nx), int((c / W.wd.nx) % W.wd.ny), int(c / (size_t(W.wd.nx) * W.wd.ny))};
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], ijk[a]);
-            hi[a] = std::max(hi[a], ijk[a]);
-        }
-    }
-    const int ext[3] = {hi[0] - lo[0] + 1 + 2 * depth, hi[1] - lo[1] + 1 + 2 * depth, hi[2] - lo[2] + 1 + 2 * depth};
-    static thread_local std::vector<int32_t> id;
-    id.assign(size_t(ext[0]) * ext[1] * ext[2], kUnset);
-    auto localOf = [&](ptrdiff_t wc) {  // index into `id` (three divisions: only the owned cells pay them)
-        const int i = int(wc % W.wd.nx) - lo[0] + depth, j = int((wc / W.wd.nx) % W.wd.ny) - lo[1] + depth;
-        const int k = int(wc / (ptrdiff_t(W.wd.nx) * W.wd.ny)) - lo[2] + depth;
-        return int32_t((size_t(k) * ext[1] + j) * ext[0] + i);
-    };
-    const int32_t loff[6] = {-1, 1, -ext[0], ext[0], -ext[0] * ext[1], ext[0] * ext[1]};
-    std::vector<int32_t> nbrTmp;  // ids as stored in `id`, fixed up at the end
-    std::vector<int64_t> updateW, readW;  // window cells of the nodes
-    std::vector<int32_t> updateL, readL;  // and the nodes' indices into `id`
-    for (int32_t t : owned) {
-        const int32_t li = localOf(W.seedCell[size_t(t)]);
-        id[size_t(li)] = int32_t(updateW.size());
-        updateW.push_back(W.seedCell[size_t(t)]);
-        updateL.push_back(li);
-        g.updateEntry.push_back(t | (int32_t(W.entryDiag[size_t(t)]) << kBandDiagShift));
-    }
-    size_t begin = 0;
-    constexpr int32_t kZero = -1;
-    for (int dist = 0; dist < depth; ++dist) {
-        const size_t end = updateW.size();
-        g.cnt[dist] = int(end);
-        for (size_t n = begin; n < end; ++n) {
-            const ptrdiff_t c = ptrdiff_t(updateW[n]);
-            const int32_t cl = updateL[n];
-            for (int q = 0; q < 6; ++q) {
-                const ptrdiff_t cq = c + off[q];
-                if (!W.active(size_t(cq))) {  // inactive: holds exactly 0
-                    nbrTmp.push_back(kZero);
-                    continue;
-                }
-                int32_t &v = id[size_t(cl + loff[q])];
-                if (v == kUnset) {
-                    const int32_t e = W.entryAt(size_t(cq));
-                    if (e != BandWindow::kNoBand && dist + 1 < depth) {
-                        v = int32_t(updateW.size());
-                        updateW.push_back(cq);
-                        updateL.push_back(cl + loff[q]);
-                        if (e >= 0) g.updateEntry.push_back(e | (int32_t(W.entryDiag[size_t(e)]) << kBandDiagShift));
-                        else if (!W.foreignRowOf) g.updateEntry.push_back(int32_t(W.diagFromLabels(size_t(cq))) << kBandDiagShift);  // no output, simple
-                        else {  // no output; its entry field addresses its row when it is a general cell
-                            const auto fr = W.foreignRowOf->find(int64_t(cq));
-                            if (fr == W.foreignRowOf->end()) return 2;
-                            const float *row = W.foreignRows8 + 8 * size_t(fr->second);
-                            g.updateEntry.push_back(row[7] != 0.f ? int32_t(row[6]) << kBandDiagShift : W.foreignBase + fr->second);
-                        }
-                    } else {
-                        v = -int32_t(readW.size()) - 2;
-                        readW.push_back(cq);
-                        readL.push_back(cl + loff[q]);
-                    }
-                }
-                nbrTmp.push_back(v);
-            }
-            if (updateW.size() > size_t(kBandMaxUpdate) || updateW.size() + readW.size() + 1 > size_t(kBandMaxNodes)) return 1;
-        }
-        begin = end;
-    }
-    for (int dist = depth; dist < kBandMaxDepth; ++dist) g.cnt[dist] = g.cnt[depth - 1];
-    const int32_t nUpd = int32_t(updateW.size()), nRead = int32_t(readW.size());
-    // Canonical node order (the walk's discovery order is an accident of the queue; the device-side builder, which has no
-    // queue, produces this one): the owned nodes as given, the nodes of every further distance and the read-only nodes by
-    // their position in the dilated bounding box (k, j, i).  The kernel computes every node on its own: order is free.
-    const size_t nU = size_t(nUpd), nR = size_t(nRead);
-    std::vector<int32_t> updOrder(nU), readOrder(nR), updNew(nU), readNew(nR);
-    for (int32_t n = 0; n < nUpd; ++n) updOrder[size_t(n)] = n;
-    for (int32_t n = 0; n < nRead; ++n) readOrder[size_t(n)] = n;
-    for (int dist = 1; dist < depth; ++dist)
-        std::sort(updOrder.begin() + g.cnt[dist - 1], updOrder.begin() + (dist + 1 < depth ? g.cnt[dist] : nUpd),
-                  [&](int32_t a, int32_t b) { return updateL[size_t(a)] < updateL[size_t(b)]; });
-    std::sort(readOrder.begin(), readOrder.end(), [&](int32_t a, int32_t b) { return readL[size_t(a)] < readL[size_t(b)]; });
-    for (int32_t n = 0; n < nUpd; ++n) updNew[size_t(updOrder[size_t(n)])] = n;
-    for (int32_t n = 0; n < nRead; ++n) readNew[size_t(readOrder[size_t(n)])] = n;
-    g.neighbours.resize(nbrTmp.size());
-    {
-        std::vector<int32_t> entryOld;
-        entryOld.swap(g.updateEntry);
-        g.updateEntry.resize(size_t(nUpd));
-        for (int32_t n = 0; n < nUpd; ++n) {
-            const int32_t o = updOrder[size_t(n)];
-            g.updateEntry[size_t(n)] = entryOld[size_t(o)];
-            for (int q = 0; q < 6; ++q) {
-                const int32_t v = nbrTmp[6 * size_t(o) + q];
-                g.neighbours[6 * size_t(n) + q] = uint16_t(v >= 0 ? updNew[size_t(v)] : (v == kZero ? nUpd + nRead : nUpd + readNew[size_t(-v - 2)]));
-            }
-        }
-    }
-    g.updateCell.resize(updateW.size());
-    g.readCell.resize(readW.size());
-    for (int32_t n = 0; n < nUpd; ++n)
-        if (!W.deviceCell(size_t(updateW[size_t(updOrder[size_t(n)])]), g.updateCell[size_t(n)])) return 2;
-    for (int32_t n = 0; n < nRead; ++n)
-        if (!W.deviceCell(size_t(readW[size_t(readOrder[size_t(n)])]), g.readCell[size_t(n)])) return 2;
-    return 0;
-}
-
-// groups over all output entries of the window; false = a reached cell had no device address
-bool buildGroupsOverWindow(const BandWindow &W, int depth, BandGroups &out)
-{
-    out = BandGroups();
-    out.depth = depth;
-    const size_t nent = W.nSeeds;
-    if (depth < 1 || depth > kBandMaxDepth || nent == 0 || nent > size_t(kBandEntryMask)) return true;
-    const Dims d = W.wd;
-    HostLap lap;
-    // initial partition: the output entries of each 16^3 tile of the window
-    const int tx = (d.nx + kTile - 1) / kTile, ty = (d.ny + kTile - 1) / kTile, tz = (d.nz + kTile - 1) / kTile;
-    std::vector<std::vector<int32_t>> work;
-    if (W.sortedBand) {  // the reference order already groups the cells by tile
-        for (size_t t = 0; t < W.ntiles; ++t)
-            if (W.tileStart[t + 1] > W.tileStart[t])
-                work.emplace_back(W.entryOfSorted + W.tileStart[t], W.entryOfSorted + W.tileStart[t + 1]);
-    } else {
-        std::vector<std::vector<int32_t>> buckets(size_t(tx) * ty * tz);
-        for (size_t t = 0; t < nent; ++t) {
-            const size_t c = size_t(W.seedCell[t]);
-            const int i = int(c % d.nx), j = int((c / d.nx) % d.ny), k = int(c / (size_t(d.nx) * d.ny));
-            buckets[(size_t(k / kTile) * ty + j / kTile) * tx + i / kTile].push_back(int32_t(t));
-        }
-        for (auto &b : buckets)
-            if (!b.empty()) work.push_back(std::move(b));
-    }
-    lap.lap("band groups: buckets");
-    std::vector<std::vector<GroupBuild>> built(work.size());
-    std::atomic<int64_t> next{0};
-    std::atomic<bool> broken{false};
-    auto worker = [&] {
-        for (;;) {
-            const int64_t w = next.fetch_add(1);
-            if (w >= int64_t(work.size())) break;
-            std::vector<std::vector<int32_t>> stack;
-            stack.push_back(std::move(work[size_t(w)]));
-            while (!stack.empty()) {
-                std::vector<int32_t> owned = std::move(stack.back());
-                stack.pop_back();
-                GroupBuild g;
-                const int rc = buildOneGroup(W, owned, depth, g);
-                if (rc == 0) {
-                    built[size_t(w)].push_back(std::move(g));
-                    continue;
-                }
-                if (rc == 2 || owned.size() < 2) {
-                    broken = true;
-                    return;
-                }
-                // too many nodes for one workgroup: halve the owned set along the longest axis of its bounding box
-                int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
-                auto coord = [&](int32_t t, int a) {
-                    const size_t c = size_t(W.seedCell[size_t(t)]);
-                    return a == 0 ? int(c % d.nx) : a == 1 ? int((c / d.nx) % d.ny) : int(c / (size_t(d.nx) * d.ny));
-                };
-                for (int32_t t : owned)
-                    for (int a = 0; a < 3; ++a) {
-                        lo[a] = std::min(lo[a], coord(t, a));
-                        hi[a] = std::max(hi[a], coord(t, a));
-                    }
-                int axis = 0;
-                for (int a = 1; a < 3; ++a)
-                    if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
-                std::vector<int32_t> left, right;
-                if (hi[axis] > lo[axis]) {
-                    const int mid = (lo[axis] + hi[axis] + 1) / 2;
-                    for (int32_t t : owned) (coord(t, axis) < mid ? left : right).push_back(t);
-                } else {  // a single cell column cannot happen with 16^3 buckets; split by count for safety
-                    left.assign(owned.begin(), owned.begin() + owned.size() / 2);
-                    right.assign(owned.begin() + owned.size() / 2, owned.end());
-                }
-                stack.push_back(std::move(right));
-                stack.push_back(std::move(left));
-            }
-        }
-    };
-    {
-        const int nt = int(std::min<size_t>(size_t(hostThreads()), std::max<size_t>(1, work.size() / 64)));
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto &th : pool) th.join();
-    }
-    lap.lap("band groups: per-bucket walks");
-    if (broken) {
-        out = BandGroups();
-        return false;
-    }
-    // concatenate: offsets first, then every group copies itself into place (all host threads)
-    std::vector<const GroupBuild *> flat;
-    for (auto &list : built)
-        for (auto &g : list) flat.push_back(&g);
-    std::vector<size_t> updAt(flat.size() + 1, 0), readAt(flat.size() + 1, 0);
-    for (size_t q = 0; q < flat.size(); ++q) {
-        updAt[q + 1] = updAt[q] + flat[q]->updateEntry.size();
-        readAt[q + 1] = readAt[q] + flat[q]->readCell.size();
-    }
-    out.info.resize(8 * flat.size());
-    out.updateEntry.resize(updAt.back());
-    out.updateCell.resize(updAt.back());
-    out.neighbours.resize(6 * updAt.back());
-    out.readCell.resize(readAt.back());
-    parallelFor(int64_t(flat.size()), [&](int64_t b, int64_t e) {
-        for (int64_t q = b; q < e; ++q) {
-            const GroupBuild &g = *flat[size_t(q)];
-            const int32_t inf[8] = {int32_t(updAt[size_t(q)]), int32_t(readAt[size_t(q)]), int32_t(g.readCell.size()), g.cnt[0], g.cnt[1], g.cnt[2], g.cnt[3], 0};
-            std::copy(inf, inf + 8, out.info.begin() + 8 * q);
-            std::copy(g.updateEntry.begin(), g.updateEntry.end(), out.updateEntry.begin() + ptrdiff_t(updAt[size_t(q)]));
-            std::copy(g.updateCell.begin(), g.updateCell.end(), out.updateCell.begin() + ptrdiff_t(updAt[size_t(q)]));
-            std::copy(g.neighbours.begin(), g.neighbours.end(), out.neighbours.begin() + ptrdiff_t(6 * updAt[size_t(q)]));
-            std::copy(g.readCell.begin(), g.readCell.end(), out.readCell.begin() + ptrdiff_t(readAt[size_t(q)]));
-        }
-    }, 16);
-    lap.lap("band groups: concatenate");
-    return true;
-}
-
-}  // namespace
-
-void buildBandGroups(const HostLevel &L, int depth, BandGroups &out)
-{
-    out = BandGroups();
-    out.depth = depth;
-    const size_t nband = L.bandDev.size();
-    if (nband == 0) return;
-    HostLap lap0;
-    BandWindow W;
-    W.wd = L.d;
-    W.labels = L.ownedLabels;  // a whole-grid level
-    W.cellLimit = L.d.cells();
-    W.seedCell = L.bandDev.data();
-    W.nSeeds = nband;
-    W.entryDiag = L.bandDiag.data();
-    W.tilesX = (L.d.nx + kTile - 1) / kTile;
-    W.tilesY = (L.d.ny + kTile - 1) / kTile;
-    W.ntiles = size_t(W.tilesX) * W.tilesY * size_t((L.d.nz + kTile - 1) / kTile);
-    W.sortedBand = L.band.data();
-    W.entryOfSorted = L.bandEntry.data();
-    W.tileStart = L.bandTileStart.data();
-    W.gridPlaneLo = 0;
-    W.gridPlaneHi = L.d.nz;
-    lap0.lap("band groups: entry map");
-    buildGroupsOverWindow(W, depth, out);
-}
-
 #define MGPS_TRY_RC(call)            \
     do {                              \
         const int rc_ = (call);       \
@@ -1371,173 +1027,6 @@ void buildBandBoxes(const HostLevel &L, int depth, BandBoxes &out)
             }
         }
     }, 64);
-}
-
-size_t bandCellsInPlane(const HostLevel &G, int p)
-{
-    if (p < 0 || p >= G.d.nz) return 0;
-    const size_t plane = size_t(G.d.nx) * G.d.ny, lo = size_t(p) * plane, hi = lo + plane;
-    size_t n = 0;
-    for (int32_t c : G.band) n += size_t(c) >= lo && size_t(c) < hi;
-    return n;
-}
-
-void slabBandRows(const HostLevel &G, const HostLevel &L, int z0, int p0, int step, int count, std::vector<float> &rows)
-{
-    rows.clear();
-    const size_t plane = size_t(G.d.nx) * G.d.ny;
-    std::unordered_map<int32_t, int32_t> entryOfCell;  // slab-local cell -> bandDev entry, for the planes asked for
-    for (int q = 0; q < count; ++q) {
-        const int p = p0 + q * step - z0;
-        for (size_t t = 0; t < L.bandDev.size(); ++t)
-            if (size_t(L.bandDev[t]) / plane == size_t(p)) entryOfCell.emplace(L.bandDev[t], int32_t(t));
-    }
-    const size_t nb = size_t(L.numBoundary);
-    for (int q = 0; q < count; ++q) {
-        const int p = p0 + q * step;
-        const size_t lo = size_t(p) * plane, hi = lo + plane;
-        for (int32_t gc : G.band) {
-            if (size_t(gc) < lo || size_t(gc) >= hi) continue;
-            const size_t t = size_t(entryOfCell.at(int32_t(size_t(gc) - size_t(z0) * plane)));
-            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, float(L.bandDiag[t]), 1.f};
-            if (t < nb) {
-                for (int a = 0; a < 7; ++a) r[a] = L.rows[size_t(a) * nb + t];
-                r[7] = 0.f;
-            }
-            rows.insert(rows.end(), r, r + 8);
-        }
-    }
-}
-
-void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out,
-                   const std::vector<float> *foreignRows)
-{
-    out = SlabHalo();
-    const Dims gd = G.d;
-    const size_t plane = size_t(gd.nx) * gd.ny;
-    if (depth < 1 || depth > kBandMaxDepth || z1 - z0 < 2 * (depth + 2)) return;
-    // window: the slab, its ghost planes, `depth` closure planes and one more plane for the closure test
-    const int wz0 = std::max(0, z0 - 2 - depth), wz1 = std::min(gd.nz, z1 + 2 + depth);
-    BandWindow W;
-    W.wd = Dims{gd.nx, gd.ny, wz1 - wz0};
-    W.labels = G.labels.data() + size_t(wz0) * plane;
-    const size_t wcells = W.wd.cells(), wlo = size_t(wz0) * plane, whi = size_t(wz1) * plane;
-    // (round 4: every pass over the window -- 145 M cells for a 128-plane slab of 1024^3 -- runs on all host threads; done one
-    // thread at a time, the flag array, the dense entry map and the closure scans were 240 of the 470 ms a rank's set-up took)
-    RawVec<uint8_t> band(wcells);
-    {
-        uint8_t *bp = band.data();
-        parallelFor(int64_t(wcells), [bp](int64_t b, int64_t e) { std::memset(bp + b, 0, size_t(e - b)); }, 1 << 22);
-        const int32_t *gb = G.band.data();
-        parallelFor(int64_t(G.band.size()), [bp, gb, wlo, whi](int64_t b, int64_t e) {
-            for (int64_t q = b; q < e; ++q) {
-                const size_t gc = size_t(gb[q]);
-                if (gc >= wlo && gc < whi) bp[gc - wlo] = 1;
-            }
-        }, 1 << 16);
-    }
-    const ptrdiff_t sy = gd.nx, sz = ptrdiff_t(plane);
-    const ptrdiff_t off[6] = {-1, 1, -sy, sy, -sz, sz};
-    // band closure of the global planes [pa, pb), as window cells in increasing order
-    auto closure = [&](int pa, int pb) {
-        std::vector<int64_t> cells;
-        pa = std::max(pa, wz0 + 1);
-        pb = std::min(pb, wz1 - 1);
-        if (pb <= pa) return cells;
-        const int64_t rows = int64_t(pb - pa) * gd.ny;  // x-rows of the planes, in cell order
-        parallelCollect<int64_t>(rows, 64, cells, [&](int64_t r0, int64_t r1, std::vector<int64_t> &part) {
-            for (int64_t r = r0; r < r1; ++r) {
-                const size_t c0 = (size_t(pa - wz0) * gd.ny + size_t(r)) * size_t(gd.nx);
-                for (size_t c = c0; c < c0 + size_t(gd.nx); ++c) {
-                    if (!W.active(c)) continue;
-                    bool in = band[c] != 0;
-                    for (int q = 0; q < 6 && !in; ++q) in = band[size_t(ptrdiff_t(c) + off[q])] != 0;
-                    if (in) part.push_back(int64_t(c));
-                }
-            }
-        });
-        return cells;
-    };
-    const bool lo = z0 > 0, hi = z1 < gd.nz;
-    const ptrdiff_t ownedShift = ptrdiff_t(z0 - wz0) * ptrdiff_t(plane);  // window cell of owned cell 0
-    std::unordered_map<int64_t, int32_t> slot;
-    if (lo) {
-        for (int64_t c : closure(z0 - 1 - depth, z0 - 1)) slot.emplace(c, int32_t(slot.size()));
-        out.nrecv[0] = int(slot.size());
-        for (int64_t c : closure(z0 + 1, z0 + 1 + depth)) out.sendIdx[0].push_back(int32_t(c - ownedShift));
-    }
-    if (hi) {
-        for (int64_t c : closure(z1 + 1, z1 + 1 + depth)) slot.emplace(c, int32_t(slot.size()));
-        out.nrecv[1] = int(slot.size()) - out.nrecv[0];
-        for (int64_t c : closure(z1 - 1 - depth, z1 - 1)) out.sendIdx[1].push_back(int32_t(c - ownedShift));
-    }
-    // output entries: the owned band cells, then the band cells of the two ghost planes
-    out.bandExt.assign(L.bandDev.begin(), L.bandDev.end());
-    out.bandExt.insert(out.bandExt.end(), L.bandPlane[1].begin(), L.bandPlane[1].end());
-    out.bandExt.insert(out.bandExt.end(), L.bandPlane[3].begin(), L.bandPlane[3].end());
-    W.allocEntryOf();
-    {
-        int32_t *ep = W.entryOf.data();
-        const uint8_t *bp = band.data();
-        parallelFor(int64_t(wcells), [ep, bp](int64_t b, int64_t e) {
-            for (int64_t c = b; c < e; ++c)
-                if (bp[c]) ep[c] = BandWindow::kDeepBand;
-        }, 1 << 20);
-    }
-    W.seedCellOwn.resize(out.bandExt.size());
-    W.entryDiagOwn.assign(L.bandDiag.begin(), L.bandDiag.end());
-    W.entryDiagOwn.resize(out.bandExt.size(), 0);
-    W.nSeeds = out.bandExt.size();
-    // rows of the neighbours' cells, when given: [ghost below][ghost above][z0-2 .. ][z1+1 ..], each plane in band order
-    std::unordered_map<int64_t, int32_t> foreignRowOf;
-    if (foreignRows) {
-        std::vector<int> planes;
-        if (lo) planes.push_back(z0 - 1);
-        if (hi) planes.push_back(z1);
-        for (int q = 2; lo && q <= depth; ++q) planes.push_back(z0 - q);
-        for (int q = 1; hi && q < depth; ++q) planes.push_back(z1 + q);
-        int32_t next = 0;
-        for (int p : planes) {
-            const size_t plo = size_t(p) * plane, phi = plo + plane;
-            for (int32_t gc : G.band)
-                if (size_t(gc) >= plo && size_t(gc) < phi) foreignRowOf.emplace(int64_t(size_t(gc) - wlo), next++);
-        }
-        if (size_t(next) * 8 != foreignRows->size()) return;  // the neighbours sent something else: leave depth 0
-        out.nForeign = int(next);
-        out.foreignRows.resize(size_t(next) * 7);
-        for (int32_t r = 0; r < next; ++r)
-            for (int a = 0; a < 7; ++a) out.foreignRows[size_t(a) * size_t(next) + size_t(r)] = (*foreignRows)[size_t(r) * 8 + size_t(a)];
-        W.foreignRowOf = &foreignRowOf;
-        W.foreignRows8 = foreignRows->data();
-        W.foreignBase = int32_t(L.bandDev.size());
-    }
-    for (size_t t = 0; t < out.bandExt.size(); ++t) {
-        const size_t wc = size_t(ptrdiff_t(out.bandExt[t]) + ownedShift);
-        W.seedCellOwn[t] = int32_t(wc);
-        W.entryOf[wc] = int32_t(t);
-        if (t < L.bandDev.size()) continue;
-        if (!foreignRows) {
-            W.entryDiagOwn[t] = uint8_t(W.diagFromLabels(wc));  // all-simple level (the caller checked)
-            continue;
-        }
-        // a ghost-plane cell: its row index is t - bandDev.size() by construction of the order above
-        const auto fr = foreignRowOf.find(int64_t(wc));
-        if (fr == foreignRowOf.end() || size_t(fr->second) != t - L.bandDev.size()) return;
-        const float *row = foreignRows->data() + 8 * size_t(fr->second);
-        W.entryDiagOwn[t] = row[7] != 0.f ? uint8_t(int(row[6])) : uint8_t(0);
-    }
-    W.seedCell = W.seedCellOwn.data();
-    W.entryDiag = W.entryDiagOwn.data();
-    W.gridPlaneLo = z0 - 1 - wz0;  // (a ghost plane outside the domain is never referenced: its cells are not active)
-    W.gridPlaneHi = z1 + 1 - wz0;
-    W.cellShift = ownedShift;
-    W.haloSlot = &slot;
-    W.gridLoCode = -int32_t(plane);
-    if (!buildGroupsOverWindow(W, depth, out.groups)) {  // (a slab without band cells still serves its neighbours' halos)
-        out = SlabHalo();
-        return;
-    }
-    out.depth = depth;
 }
 
 // tileZOffset: number of 16-plane tile layers below this slab (the colour uses the global tile index)
@@ -2281,96 +1770,6 @@ try {
         out_ijk[q++] = (c / d.nx) % d.ny;
         out_ijk[q++] = c / (d.nx * d.ny);
     }
-    return MGPS_OK;
-}
-MGPS_API_CATCH(nullptr)
-
-// Host check of the fused band stage: builds the level's groups, verifies their structure and replays
-// `depth` passes both ways (pass by pass over the whole band / group by group in local storage) on a
-// seeded grid with the unit-weight operator; the two must agree bit for bit.
-int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
-                                     int64_t *out_nodes)
-try {
-    if (!hier || level < 0 || level >= hier->levels || depth < 1 || depth > kBandMaxDepth)
-        return fail(MGPS_ERR_INVALID_ARGUMENT, "mgps_hierarchy_check_band_groups: bad arguments");
-    HostLevel L;
-    buildSlabLevel(hier->lv[level], 0, hier->lv[level].d.nz, nullptr, nullptr, nullptr, L);
-    BandGroups bg;
-    buildBandGroups(L, depth, bg);
-    const Dims d = L.d;
-    const size_t nband = L.bandDev.size();
-    if (out_groups) *out_groups = int64_t(bg.groups());
-    if (out_nodes) *out_nodes = int64_t(bg.updateEntry.size() + bg.readCell.size());
-    std::vector<uint8_t> ownedOnce(nband, 0);
-    for (size_t gI = 0; gI < bg.groups(); ++gI) {
-        const int32_t *gi = bg.info.data() + 8 * gI;
-        const int nUpd = gi[3 + depth - 1], nRead = gi[2];
-        if (gi[3] < 1 || nUpd > kBandMaxUpdate || nUpd + nRead + 1 > kBandMaxNodes)
-            return fail(MGPS_ERR_HIERARCHY, "band group exceeds the workgroup budget");
-        for (int q = 1; q < depth; ++q)
-            if (gi[3 + q] < gi[3 + q - 1]) return fail(MGPS_ERR_HIERARCHY, "band group: distance counts not monotone");
-        for (int n = 0; n < gi[3]; ++n) {
-            const int32_t t = bg.updateEntry[size_t(gi[0] + n)] & kBandEntryMask;
-            if (t < 0 || size_t(t) >= nband || ownedOnce[size_t(t)]++) return fail(MGPS_ERR_HIERARCHY, "band entry owned by two groups");
-        }
-        for (size_t q = 0; q < size_t(nUpd) * 6; ++q)
-            if (bg.neighbours[size_t(gi[0]) * 6 + q] > nUpd + nRead) return fail(MGPS_ERR_HIERARCHY, "band group: neighbour id out of range");
-    }
-    for (size_t t = 0; t < nband; ++t)
-        if (!ownedOnce[t]) return fail(MGPS_ERR_HIERARCHY, "band entry owned by no group");
-    // replay
-    const size_t n = d.cells();
-    const ptrdiff_t sy = d.nx, sz = ptrdiff_t(d.nx) * d.ny;
-    std::vector<float> x(n, 0.f), b(n, 0.f);
-    uint32_t state = 12345u + uint32_t(level);
-    auto rnd = [&] {
-        state = state * 1664525u + 1013904223u;
-        return float(state >> 8) * (1.f / 16777216.f);
-    };
-    for (size_t c = 0; c < n; ++c)
-        if (isActive(L.ownedLabels[c])) {
-            x[c] = rnd();
-            b[c] = rnd();
-        }
-    const float omega = 2.f / 3.f;
-    auto update = [&](float diag, float xc, float bc, float xm, float xp, float ym, float yp, float zm, float zp) {
-        const float lap = diag * xc - (xm + xp + ym + yp + zm + zp);
-        return xc + omega * ((bc - lap) / diag);
-    };
-    auto diagOf = [&](int32_t t) { return float(L.bandDiag[size_t(t)]); };  // unit weights: every cell is simple
-    if (L.numBoundary != 0) return fail(MGPS_ERR_HIERARCHY, "unit-weight level has general BOUNDARY cells");
-    std::vector<float> ref = x, tmp(nband);
-    for (int p = 0; p < depth; ++p) {
-        for (size_t t = 0; t < nband; ++t) {
-            const ptrdiff_t c = L.bandDev[t];
-            tmp[t] = update(diagOf(int32_t(t)), ref[c], b[c], ref[c - 1], ref[c + 1], ref[c - sy], ref[c + sy], ref[c - sz], ref[c + sz]);
-        }
-        for (size_t t = 0; t < nband; ++t) ref[size_t(L.bandDev[t])] = tmp[t];
-    }
-    std::vector<float> fusedOut(nband), v0, v1;
-    for (size_t gI = 0; gI < bg.groups(); ++gI) {
-        const int32_t *gi = bg.info.data() + 8 * gI;
-        const int nUpd = gi[3 + depth - 1], nRead = gi[2];
-        v0.assign(size_t(nUpd + nRead + 1), 0.f);
-        for (int q = 0; q < nUpd; ++q) v0[size_t(q)] = x[size_t(bg.updateCell[size_t(gi[0] + q)])];
-        for (int r = 0; r < nRead; ++r) v0[size_t(nUpd + r)] = x[size_t(bg.readCell[size_t(gi[1] + r)])];
-        v1 = v0;
-        for (int p = 1; p <= depth; ++p) {
-            const std::vector<float> &src = (p & 1) ? v0 : v1;
-            std::vector<float> &dst = (p & 1) ? v1 : v0;
-            for (int q = 0; q < gi[3 + depth - p]; ++q) {
-                const uint16_t *nb = bg.neighbours.data() + 6 * size_t(gi[0] + q);
-                const int32_t e = bg.updateEntry[size_t(gi[0] + q)], t = e & kBandEntryMask;
-                if ((e >> kBandDiagShift) != int32_t(L.bandDiag[size_t(t)])) return fail(MGPS_ERR_HIERARCHY, "band group: packed diagonal mismatch");
-                dst[size_t(q)] = update(diagOf(t), src[size_t(q)], b[size_t(bg.updateCell[size_t(gi[0] + q)])], src[nb[0]], src[nb[1]], src[nb[2]],
-                                        src[nb[3]], src[nb[4]], src[nb[5]]);
-            }
-        }
-        const std::vector<float> &fin = (depth & 1) ? v1 : v0;
-        for (int q = 0; q < gi[3]; ++q) fusedOut[size_t(bg.updateEntry[size_t(gi[0] + q)] & kBandEntryMask)] = fin[size_t(q)];
-    }
-    for (size_t t = 0; t < nband; ++t)
-        if (fusedOut[t] != ref[size_t(L.bandDev[t])]) return fail(MGPS_ERR_HIERARCHY, "fused band replay differs from pass-by-pass replay");
     return MGPS_OK;
 }
 MGPS_API_CATCH(nullptr)

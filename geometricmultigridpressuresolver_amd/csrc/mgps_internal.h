@@ -127,34 +127,9 @@ struct HostLevel {
     int64_t activeCells = 0;
 };
 
-// Fused band passes (whole-grid levels only).  The band is cut into groups of "owned" cells; a group
-// carries the sub-graph its P consecutive Jacobi passes touch: the band cells within P-1 steps of an
-// owned cell along band-to-band stencil edges ("update nodes", ordered by that distance, owned first)
-// and the cells those read but never write (band cells at distance P, non-band active cells, all
-// frozen during band passes).  One workgroup stages a group's values in LDS, runs the P passes there
-// (pass p recomputes the nodes of distance <= P-p: redundant work instead of P round trips through
-// HBM), and emits the owned cells' final values.  Pure restructuring: every cell sees exactly the
-// arithmetic of P separate compute/scatter passes (Ops.h:524-619).
-constexpr int kBandMaxDepth = 4;
-constexpr int kBandMaxNodes = 4096;   // update + read-only + the shared zero node; two LDS copies
-constexpr int kBandMaxUpdate = 2560;  // a workgroup of 512 threads keeps 5 of them per thread in registers
-constexpr int kBandDiagShift = 28;    // updateEntry = band entry | diagonal << 28 (0: general cell, row list)
-constexpr int kBandEntryMask = (1 << kBandDiagShift) - 1;
-struct BandGroups {
-    int depth = 0;
-    // per group 8 ints: first update node, first read-only node, read-only count,
-    // count of update nodes with distance <= 0 (owned), <= 1, <= 2, <= 3, unused
-    RawVec<int32_t> info;
-    RawVec<int32_t> updateEntry;   // per update node: its index t in bandDev | diagonal << kBandDiagShift
-    RawVec<int32_t> updateCell;    // per update node: linear cell index
-    RawVec<uint16_t> neighbours;   // per update node: 6 group-local node ids (-x,+x,-y,+y,-z,+z)
-    RawVec<int32_t> readCell;      // per read-only node: linear cell index
-    size_t groups() const { return info.size() / 8; }
-};
-void buildBandGroups(const HostLevel &L, int depth, BandGroups &out);
-
-// Fused band stage, box form (whole-grid levels; round 3).  The graph form above spends 20 B of metadata per update node
-// and gathers every value by index (PMC: 131 B per band cell at 1024^3 against 16 algorithmic).  Here a group is a BOX of the
+constexpr int kBandMaxDepth = 4;  // band passes the fused stage takes (options.band_iterations beyond: pass by pass)
+// Fused band stage, box form (round 3; on cut slab levels since round 5).  The graph form of rounds 1-2 (removed in round 5) spent 20 B of
+// metadata per update node and gathered every value by index (PMC: 131 B per band cell at 1024^3 against 16 algorithmic).  Here a group is a BOX of the
 // grid: the owned box O (a piece of a 16^3 tile: the bounding box of the tile's band-closure cells, halved until it fits)
 // and the region R around it that its passes touch (inside O dilated by depth + 1, every extent < 32).  The values of R
 // live in a dense LDS block -- the neighbours of region cell n are n +- 1, n +- rx, n +- rx*ry, no ids -- and the
@@ -218,32 +193,6 @@ int compactBandBoxLists(void *stream, int32_t *info, const uint32_t *list, int n
 // the groups in the Morton order of their tiles (launch order = L2 locality of the overlapping regions): info permuted into
 // infoOut; synchronises the stream
 int orderBandBoxes(void *stream, const Dims &d, const int32_t *info, int ngroups, int32_t *infoOut);
-
-// The fused band stage on a level that IS cut into slabs.  One exchange per stage replaces one per pass:
-// besides its ghost plane a rank receives the *band closure* (band cells and their active face neighbours)
-// of the next `depth` planes of each neighbour, x and rhs, and recomputes the neighbour's band cells it
-// needs itself -- including the band cells of its own ghost planes, whose final values it then holds
-// without a further exchange.  Both neighbours derive the closure lists from the same global labels and
-// band list, so the sender's pack order is the receiver's slot order.
-struct SlabHalo {
-    int depth = 0;                    // 0: not built (level not eligible)
-    std::vector<int32_t> sendIdx[2];  // my cells the lower [0] / upper [1] neighbour needs: offsets from owned cell 0
-    int nrecv[2] = {0, 0};            // closure cells received from the lower / upper neighbour; halo slots: lower first
-    std::vector<int32_t> bandExt;     // bandDev, then the band cells of the lower and of the upper ghost plane
-    std::vector<float> foreignRows;   // SoA 7 x nForeign (device layout) of the rows handed to buildSlabHalo; may be empty
-    int nForeign = 0;
-    BandGroups groups;                // over bandExt; cells outside the grid allocation are encoded as halo slots
-};
-// foreignRows (optional): operator rows of the neighbours' band cells near the cuts, 8 floats each (six weights,
-// diagonal, 1 / 0 simple / general), ordered [ghost plane below][ghost plane above][planes z0-2 .. z0-depth]
-// [planes z1+1 .. z1+depth-1], each plane in band order (slabBandRows builds the sender's half).  Without them
-// every foreign band cell must be a simple cell (diagonal from the labels).
-void buildSlabHalo(const HostLevel &G, const HostLevel &L, int z0, int z1, int depth, SlabHalo &out,
-                   const std::vector<float> *foreignRows = nullptr);
-// rows (8 floats, as above) of this slab's band cells in the planes [p0, p0 + count * step) walked p0, p0 + step, ...
-void slabBandRows(const HostLevel &G, const HostLevel &L, int z0, int p0, int step, int count, std::vector<float> &rows);
-// number of band cells of level G in plane p
-size_t bandCellsInPlane(const HostLevel &G, int p);
 
 // rowsIn (optional, instead of wx / wy / wz): the operator rows of the BOUNDARY band cells of the planes
 // [z0, z1) evaluated elsewhere (on the device, mgps_create_device_weights), 8 floats per cell in band order:
@@ -365,18 +314,6 @@ unsigned bandScatterBlocks(int nband);
 int launchStencilDot(void *stream, StencilOp op, const GridP &g, float *out, const float *x, const float *b, float omega,
                      double *partials, unsigned *nparts);
 int launchFoldDot(void *stream, double *partials, unsigned nparts, double *resultDev);
-// bg.depth fused band passes (device copy of BandGroups)
-struct BandGroupsDev {
-    int depth = 0, ngroups = 0;
-    int32_t *info = nullptr, *updateEntry = nullptr, *updateCell = nullptr, *readCell = nullptr;
-    uint16_t *neighbours = nullptr;
-};
-// hx / hb: halo values of x and of the rhs for node cells encoded below gridLo = -(nx*ny) (cut slabs), else nullptr
-// frows (cut slabs with general BOUNDARY cells near the cut): SoA rows 7 x nForeign of the neighbours' cells,
-// addressed by band entry - foreignBase
-int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx = nullptr, const float *hb = nullptr,
-                    const float *frows = nullptr, int foreignBase = 0, int nForeign = 0, double *dotPartials = nullptr);
 // Box form of the fused band stage (BandBoxes).  src: where the region's values are read; dst: where the results go (the
 // band cells of every owned box; closure mode: every closure cell of it), snap (closure mode, optional): a second copy.
 // Grids are float, or binary16 when `half` is set (mixed precision: ms as in launchBandFusedMixed).
@@ -396,23 +333,6 @@ int launchBandBox(void *stream, const GridP &g, const BandBoxesDev &bx, bool clo
 int launchStrokeFront(void *stream, const GridP &g, const BandBoxesDev &bx, float *out, const float *x, const float *b, float *snap, float omega, const uint32_t *keep);
 int launchMarkClosure(void *stream, const GridP &g, const BandBoxesDev &bx, uint32_t *bits);
 int launchBandBoxCopy(void *stream, const GridP &g, const BandBoxesDev &bx, const void *src, void *dst, bool half = false);
-// one message to / from a Z-neighbour: [boundary plane of x | x at idx | b at idx | b at the band cells of
-// that plane].  Pack reads the plane at planeStart; unpack writes it there (the ghost plane of x), puts the
-// two lists into the halo arrays and the last part into the band cells of the ghost plane of b (the grids'
-// ghost planes are the solver's scratch).  buf == nullptr: no neighbour on that side.
-struct HaloSide {
-    float *buf = nullptr;
-    ptrdiff_t planeStart = 0;
-    const int32_t *idx = nullptr;
-    int n = 0;
-    const int32_t *bandIdx = nullptr;
-    int nb = 0;
-    float *hx = nullptr, *hb = nullptr;
-};
-// withPlane = false: only the lists are packed / unpacked (at their usual place behind the plane's slot in buf); the plane
-// itself goes straight from / into the grid as segment 0 of the message (mgps_comm::exchange2)
-int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane, bool withPlane = true);
-int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane, bool withPlane = true);
 // one side of the list part of a cut level's band-stage message (box form): n cells at base + idx[t] (offsets from owned cell 0);
 // buf: 2 n floats.  buf == nullptr: no neighbour on that side
 struct HaloList {
@@ -450,8 +370,6 @@ int launchRestrictXY(void *stream, const GridP &coarse, float *coarseOut, const 
 bool mixedPrecisionShapeOk(int nx, int ny, int nz);  // the fine level must take the quad sweep and the block prolongation
 int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, const void *xH, const float *b, float omega, const MixScale &ms,
                        double *dotPartials = nullptr, unsigned *nparts = nullptr);
-int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
-                         const BandGroupsDev &bg, const MixScale &ms, double *dotPartials = nullptr);
 int launchScaleResult(void *stream, double *resultDev, const float *sigmaDev, float mul);  // *result *= mul / *sigma
 int launchRestrictMixed(void *stream, const GridP &coarse, float *coarseOut, const void *fineH, float fm);
 int launchProlongAddMixed(void *stream, const GridP &fine, void *fineH, const float *coarse, float pm);

@@ -779,151 +779,6 @@ __global__ void bandScatterKernel(TX *__restrict__ x, const int32_t *__restrict_
     if (DOT) blockDotStore(acc, dotPartials, blockIdx.x);
 }
 
-// `depth` consecutive band passes in one launch (BandGroups in mgps_internal.h): a workgroup stages the
-// values of its group's nodes in LDS (two copies: Jacobi reads the previous pass), recomputes the
-// shrinking set of update nodes pass by pass and emits the owned cells' final values into the band
-// list `tmp`; bandScatterKernel then writes them to the grid (other groups still read the old values of
-// these cells while this one runs, so the grid itself must not change in this launch).
-// Every thread keeps the description of its <= kBandSlots update nodes (neighbour ids, rhs, diagonal)
-// in registers, loaded once with all loads in flight together; the passes themselves touch only LDS.
-// general BOUNDARY cell of a band pass (rare: kept out of line so that the common path stays lean)
-// t < g.nbnd: a row of this rank's list; otherwise row t - foreignBase of the rows received from the neighbours
-__device__ __noinline__ float bandGeneralUpdate(const GridP &g, int t, float xc, float bc, float xm, float xp, float ym,
-                                                float yp, float zm, float zp, float omega, const float *frows, int foreignBase,
-                                                int nForeign)
-{
-    const bool own = t < g.nbnd;
-    const size_t nb = own ? size_t(g.nbnd) : size_t(nForeign);
-    const float *r = own ? g.rows + t : frows + (t - foreignBase);
-    float acc = 0.f;
-    acc -= r[0] * xm;
-    acc -= r[nb] * xp;
-    acc -= r[2 * nb] * ym;
-    acc -= r[3 * nb] * yp;
-    acc -= r[4 * nb] * zm;
-    acc -= r[5 * nb] * zp;
-    const float diag = r[6 * nb];
-    const float lap = acc + diag * xc;
-    return xc + omega * ((bc - lap) / diag);
-}
-
-constexpr int kBandThreads = 512;
-constexpr int kBandSlots = kBandMaxUpdate / kBandThreads;
-static_assert(kBandSlots * kBandThreads == kBandMaxUpdate, "update-node budget must be a whole number of slots");
-
-template <class TX = float>
-__global__ __launch_bounds__(kBandThreads, 6) void bandFusedKernel(GridP g, const TX *__restrict__ x,
-                                                                const float *__restrict__ b,
-                                                                const int32_t *__restrict__ info,
-                                                                const int32_t *__restrict__ updateEntry,
-                                                                const int32_t *__restrict__ updateCell,
-                                                                const uint16_t *__restrict__ neighbours,
-                                                                const int32_t *__restrict__ readCell,
-                                                                float *__restrict__ tmp, float omega, int depth,
-                                                                const float *__restrict__ hx, const float *__restrict__ hb,
-                                                                const float *__restrict__ frows, int foreignBase, int nForeign,
-                                                                MixScale ms = MixScale{})
-{
-    constexpr bool kMixed = !std::is_same<TX, float>::value;
-    __shared__ float val[2][kBandMaxNodes];
-    // node cells below gridLo are slots of the halo arrays (cells of a neighbouring slab, see SlabHalo)
-    const int gridLo = -(g.nx * g.ny);
-    const float bm = kMixed ? mixRhsScale(ms) : 1.f;
-    auto xAt = [&](int c) { return c >= gridLo ? Cell<TX>::load1(x + c) : hx[gridLo - 1 - c]; };
-    auto bAt = [&](int c) { return kMixed ? bm * b[c] : (c >= gridLo ? b[c] : hb[gridLo - 1 - c]); };
-    const int32_t *gi = info + 8 * size_t(blockIdx.x);
-    const int updStart = gi[0], readStart = gi[1], nRead = gi[2];
-    const int cnt[kBandMaxDepth] = {gi[3], gi[4], gi[5], gi[6]};
-    const int nUpd = cnt[depth - 1];
-    const int tid = threadIdx.x;
-
-    int entry[kBandSlots];
-    uint32_t q01[kBandSlots], q23[kBandSlots], q45[kBandSlots];
-    float bv[kBandSlots];
-    {
-        int cell[kBandSlots];
-#pragma unroll
-        for (int m = 0; m < kBandSlots; ++m) {
-            const int n = tid + m * kBandThreads;
-            const size_t at = size_t(updStart) + (n < nUpd ? n : 0);
-            entry[m] = updateEntry[at];
-            cell[m] = updateCell[at];
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(neighbours + 6 * at);
-            q01[m] = q[0];
-            q23[m] = q[1];
-            q45[m] = q[2];
-        }
-        float xv[kBandSlots];
-#pragma unroll
-        for (int m = 0; m < kBandSlots; ++m) {
-            xv[m] = xAt(cell[m]);
-            bv[m] = bAt(cell[m]);
-        }
-        // read-only nodes, four loads in flight per thread
-        for (int r0 = tid; r0 < nRead; r0 += 4 * kBandThreads) {
-            int rc[4];
-            float rv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * kBandThreads;
-                rc[u] = readCell[readStart + (r < nRead ? r : 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rv[u] = xAt(rc[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * kBandThreads;
-                if (r < nRead) {
-                    val[0][nUpd + r] = rv[u];
-                    val[1][nUpd + r] = rv[u];
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < kBandSlots; ++m) {
-            const int n = tid + m * kBandThreads;
-            if (n < nUpd) {
-                val[0][n] = xv[m];
-                val[1][n] = xv[m];
-            }
-        }
-    }
-    if (tid == 0) {  // every inactive neighbour: grids hold exactly 0 there
-        val[0][nUpd + nRead] = 0.f;
-        val[1][nUpd + nRead] = 0.f;
-    }
-    __syncthreads();
-    for (int p = 1; p <= depth; ++p) {
-        const float *src = val[(p - 1) & 1];
-        float *dst = val[p & 1];
-        const int np = cnt[depth - p];
-#pragma unroll
-        for (int m = 0; m < kBandSlots; ++m) {
-            const int n = tid + m * kBandThreads;
-            if (n < np) {
-                const float xm = src[q01[m] & 0xffffu], xp = src[q01[m] >> 16], ym = src[q23[m] & 0xffffu], yp = src[q23[m] >> 16];
-                const float zm = src[q45[m] & 0xffffu], zp = src[q45[m] >> 16];
-                const float xc = src[n];
-                const int d = entry[m] >> kBandDiagShift;
-                if (d != 0) {  // INTERIOR or simple BOUNDARY cell: the arithmetic of bandComputeKernel
-                    const float diag = float(d);
-                    const float lap = diag * xc - (xm + xp + ym + yp + zm + zp);
-                    dst[n] = xc + omega * ((bv[m] - lap) * simpleRcp(diag));
-                } else
-                    dst[n] = bandGeneralUpdate(g, entry[m] & kBandEntryMask, xc, bv[m], xm, xp, ym, yp, zm, zp, omega, frows, foreignBase,
-                                               nForeign);
-            }
-        }
-        __syncthreads();
-    }
-    const float *fin = val[depth & 1];
-#pragma unroll
-    for (int m = 0; m < kBandSlots; ++m) {
-        const int n = tid + m * kBandThreads;
-        if (n < cnt[0]) tmp[entry[m] & kBandEntryMask] = fin[n];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // The fused band stage, box form (BandBoxes in mgps_internal.h; whole-grid levels).  A workgroup takes one group: the
 // values of its region R (a box of the grid, <= kBoxMaxNodes cells) sit in a dense LDS block -- the six neighbours of
@@ -2507,65 +2362,6 @@ int launchBandJacobi(void *stream, const GridP &g, float *x, const float *b, con
     return int(hipGetLastError());
 }
 
-// Both neighbours' messages in one launch: blocks [0, blocksLo) serve the lower side, the rest the upper.  The plane -- 4 MiB of the
-// ~4.5 MiB of a level-0 message at 1024^3 -- moves as 16-byte quads (round 4: one float per thread took 21 us to pack and 20 us to
-// unpack, 9 % of a middle rank's cycle at 8 ranks), the lists one element per thread behind it
-__global__ __launch_bounds__(256) void haloPackKernel(HaloSide lo, HaloSide hi, unsigned blocksLo, const float *__restrict__ x, const float *__restrict__ b,
-                                                      size_t plane, size_t planeThreads, int quads)
-{
-    const bool upper = blockIdx.x >= blocksLo;
-    const HaloSide &s = upper ? hi : lo;
-    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x;
-    const size_t n = size_t(s.n);
-    if (t < planeThreads) {
-        if (quads) reinterpret_cast<float4 *>(s.buf)[t] = reinterpret_cast<const float4 *>(x + s.planeStart)[t];
-        else s.buf[t] = x[s.planeStart + ptrdiff_t(t)];
-        return;
-    }
-    const size_t e = t - planeThreads;
-    if (e < n) s.buf[plane + e] = x[s.idx[e]];
-    else if (e < 2 * n) s.buf[plane + e] = b[s.idx[e - n]];
-    else if (e < 2 * n + size_t(s.nb)) s.buf[plane + e] = b[s.bandIdx[e - 2 * n]];
-}
-__global__ __launch_bounds__(256) void haloUnpackKernel(HaloSide lo, HaloSide hi, unsigned blocksLo, float *__restrict__ x, float *__restrict__ b, size_t plane,
-                                                        size_t planeThreads, int quads)
-{
-    const bool upper = blockIdx.x >= blocksLo;
-    const HaloSide &s = upper ? hi : lo;
-    const size_t t = size_t(blockIdx.x - (upper ? blocksLo : 0)) * blockDim.x + threadIdx.x;
-    const size_t n = size_t(s.n);
-    if (t < planeThreads) {
-        if (quads) reinterpret_cast<float4 *>(x + s.planeStart)[t] = reinterpret_cast<const float4 *>(s.buf)[t];
-        else x[s.planeStart + ptrdiff_t(t)] = s.buf[t];
-        return;
-    }
-    const size_t e = t - planeThreads;
-    if (e < n) s.hx[e] = s.buf[plane + e];
-    else if (e < 2 * n) s.hb[e - n] = s.buf[plane + e];
-    else if (e < 2 * n + size_t(s.nb)) b[s.bandIdx[e - 2 * n]] = s.buf[plane + e];
-}
-
-static unsigned haloBlocks(const HaloSide &s, size_t planeThreads) { return s.buf ? blocksFor(planeThreads + 2 * size_t(s.n) + size_t(s.nb), 256) : 0; }
-
-int launchHaloPack(void *stream, const HaloSide &lo, const HaloSide &hi, const float *x, const float *b, size_t plane, bool withPlane)
-{
-    const int quads = (plane & 3) == 0 ? 1 : 0;  // (planes are whole rows of a grid with nx % 4 == 0 wherever the deep halo is built)
-    const size_t planeThreads = !withPlane ? 0 : quads ? plane >> 2 : plane;  // (without: the plane travels straight from the grid, mgps_comm::exchange2)
-    const unsigned bl = haloBlocks(lo, planeThreads), bh = haloBlocks(hi, planeThreads);
-    if (bl + bh == 0) return 0;
-    haloPackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, x, b, plane, planeThreads, quads);
-    return int(hipGetLastError());
-}
-int launchHaloUnpack(void *stream, const HaloSide &lo, const HaloSide &hi, float *x, float *b, size_t plane, bool withPlane)
-{
-    const int quads = (plane & 3) == 0 ? 1 : 0;
-    const size_t planeThreads = !withPlane ? 0 : quads ? plane >> 2 : plane;
-    const unsigned bl = haloBlocks(lo, planeThreads), bh = haloBlocks(hi, planeThreads);
-    if (bl + bh == 0) return 0;
-    haloUnpackKernel<<<bl + bh, 256, 0, static_cast<hipStream_t>(stream)>>>(lo, hi, bl, x, b, plane, planeThreads, quads);
-    return int(hipGetLastError());
-}
-
 // The list part of a cut level's band-stage messages (round 5, box form): buf = [a0 at base + idx | a1 at base + idx] for the cells the
 // neighbour's boxes read (pack), and the same back into the deep ghost planes of the grids (unpack).  Both sides in one launch.
 __global__ __launch_bounds__(256) void haloListPackKernel(HaloList lo, HaloList hi, unsigned blocksLo, const float *__restrict__ a0, const float *__restrict__ a1)
@@ -2599,20 +2395,6 @@ int launchHaloListUnpack(void *stream, const HaloList &lo, const HaloList &hi, f
     return int(hipGetLastError());
 }
 
-int launchBandFused(void *stream, const GridP &g, float *x, const float *b, const int32_t *band, int nband,
-                    float *bandTmp, float omega, const BandGroupsDev &bg, const float *hx, const float *hb, const float *frows,
-                    int foreignBase, int nForeign, double *dotPartials)
-{
-    if (nband <= 0 || bg.ngroups <= 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    bandFusedKernel<<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours,
-                                                                  bg.readCell, bandTmp, omega, bg.depth, hx, hb, frows, foreignBase,
-                                                                  nForeign);
-    const unsigned nb = blocksFor(size_t(nband), 256);
-    if (dotPartials) bandScatterKernel<true><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb, b, dotPartials);
-    else bandScatterKernel<<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
-    return int(hipGetLastError());
-}
 unsigned bandScatterBlocks(int nband) { return nband > 0 ? blocksFor(size_t(nband), 256) : 0; }
 namespace {
 template <class TX>
@@ -2736,19 +2518,6 @@ int launchStencilMixed(void *stream, StencilOp op, const GridP &g, void *outH, c
     return int(hipGetLastError());
 }
 
-int launchBandFusedMixed(void *stream, const GridP &g, void *xH, const float *b, const int32_t *band, int nband, float *bandTmp, float omega,
-                         const BandGroupsDev &bg, const MixScale &ms, double *dotPartials)
-{
-    if (nband <= 0 || bg.ngroups <= 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    __half *x = static_cast<__half *>(xH);
-    bandFusedKernel<__half><<<unsigned(bg.ngroups), kBandThreads, 0, s>>>(g, x, b, bg.info, bg.updateEntry, bg.updateCell, bg.neighbours, bg.readCell,
-                                                                          bandTmp, omega, bg.depth, nullptr, nullptr, nullptr, 0, 0, ms);
-    const unsigned nb = blocksFor(size_t(nband), 256);
-    if (dotPartials) bandScatterKernel<true, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb, b, dotPartials);  // sum (new - old) b shares
-    else bandScatterKernel<false, __half><<<nb, 256, 0, s>>>(x, band, nband, bandTmp, nb);
-    return int(hipGetLastError());
-}
 // *result *= mul / *sigma: turns the gathered sum x~ b of the mixed cycle into <z, b>
 __global__ void scaleResultKernel(double *__restrict__ result, const float *__restrict__ sigma, float mul) { *result *= double(mul) / double(*sigma); }
 int launchScaleResult(void *stream, double *resultDev, const float *sigmaDev, float mul)

@@ -154,12 +154,6 @@ class Hierarchy:
             check(lib().mgps_hierarchy_band_cells(self.h, level, _p(out)))
         return out
 
-    def check_band_groups(self, level, depth=3):
-        """host self-check of the fused band stage; returns (groups, nodes)"""
-        g, n = C.c_int64(), C.c_int64()
-        check(lib().mgps_hierarchy_check_band_groups(self.h, int(level), int(depth), C.byref(g), C.byref(n)))
-        return g.value, n.value
-
     def check_band_boxes(self, level, depth=3, weights=None):
         """host self-check of the box form of the fused band stage (level 0 with `weights` = [wx, wy, wz]: general BOUNDARY
         cells take part); returns (groups, region cells, general entries)"""

@@ -198,11 +198,6 @@ int mgps_hierarchy_level_labels(const mgps_hierarchy *hier, int level, uint8_t *
 int64_t mgps_hierarchy_band_count(const mgps_hierarchy *hier, int level);
 /* band cells as (i,j,k) int32 triples, in the reference's order (tile id, k, j, i) */
 int mgps_hierarchy_band_cells(const mgps_hierarchy *hier, int level, int32_t *out_ijk);
-/* host self-check of the fused band stage (options.fuse_band_passes): builds the level's workgroup
- * groups for `depth` passes (1..4), verifies their structure and replays the passes group by group and
- * pass by pass on a seeded grid -- the two must agree bit for bit.  Returns the group and node counts. */
-int mgps_hierarchy_check_band_groups(const mgps_hierarchy *hier, int level, int depth, int64_t *out_groups,
-                                     int64_t *out_nodes);
 /* host self-check of the box form of the fused band stage (round 3; what single-device solvers run): builds the level's
  * boxes for `depth` passes, verifies their structure and replays the three uses of launchBandBox group by group against
  * pass-by-pass band smoothing and a full Jacobi sweep on a seeded grid, bit for bit: the plain stage, the closure stage

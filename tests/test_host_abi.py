@@ -101,19 +101,6 @@ def test_hierarchy_matches_oracle(kind, g, oracle):
         assert (H.band_cells(l) == s.band(l)).all()  # same cells in the reference's (tile,k,j,i) order
 
 
-@pytest.mark.parametrize("kind,g", KINDS + [("solid", 40), ("solid", 72)])
-@pytest.mark.parametrize("depth", [1, 3, 4])
-def test_fused_band_groups_replay(kind, g, depth):
-    """Host side of the fused band stage: every band entry owned by exactly one workgroup group, groups
-    within the LDS budget, and the group-by-group replay of `depth` passes bit-identical to pass-by-pass."""
-    lab, w, off, lev, dx = make_domain(kind, g)
-    H = G.Hierarchy(lab, lev)
-    for l in range(H.levels):
-        groups, nodes = H.check_band_groups(l, depth)
-        nband = len(H.band_cells(l))
-        assert (groups > 0) == (nband > 0) and nodes >= nband
-
-
 @pytest.mark.parametrize("kind,g", KINDS + [("solid", 40), ("solid", 72), ("simple", 100)])
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_band_boxes_replay(kind, g, depth):
