@@ -35,23 +35,19 @@ int main()
         int rc = mgps_hierarchy_create(&H, n, n, n, lab.data(), levels, &o);
         if (rc != 0) { std::printf("trial %d: create rc %d (%s)\n", trial, rc, lastGlobalError()); continue; }
         for (int l = 0; l < mgps_hierarchy_levels(H); ++l)
-            for (int depth = 1; depth <= 4; ++depth) {
-                int64_t g = 0, nodes = 0;
-                rc = mgps_hierarchy_check_band_groups(H, l, depth, &g, &nodes);
+            for (int depth = 1; depth <= 4; ++depth) {  // the box form of the fused band stage: builder + bit-exact replay
+                int64_t g = 0, cells = 0, general = 0;
+                rc = mgps_hierarchy_check_band_boxes(H, l, depth, l == 0 ? wx.data() : nullptr, l == 0 ? wy.data() : nullptr, l == 0 ? wz.data() : nullptr, &g, &cells,
+                                                     &general);
                 if (rc != 0) { std::printf("trial %d level %d depth %d: rc %d (%s)\n", trial, l, depth, rc, lastGlobalError()); return 1; }
             }
-        // slab levels + deep halos for 2 and 4 ranks
+        // slab levels of the host builder (the checker of the device-side slab set-up) for 2 and 4 ranks
         for (int P : {2, 4}) {
             const int nzl = n / P;
             if (nzl % 16) continue;
             for (int r = 0; r < P; ++r) {
                 HostLevel L;
                 buildSlabLevel(H->lv[0], r * nzl, (r + 1) * nzl, nullptr, nullptr, nullptr, L);
-                SlabHalo halo;
-                buildSlabHalo(H->lv[0], L, r * nzl, (r + 1) * nzl, 3, halo);
-                std::vector<float> rows;
-                slabBandRows(H->lv[0], L, r * nzl, r * nzl, 1, 1, rows);
-                (void)bandCellsInPlane(H->lv[0], r * nzl);
             }
         }
         std::printf("trial %d ok: levels %d band0 %lld nn %zu\n", trial, mgps_hierarchy_levels(H), (long long)mgps_hierarchy_band_count(H, 0), nn);
