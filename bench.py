@@ -276,10 +276,11 @@ def main():
     if slab_run:
         import torch.distributed as dist
 
-        if args.rehearse_gloo:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # torch.distributed carries the rendezvous, the barriers and the max over ranks of the timings -- host-side, over gloo.  The
+        # data path is the library's own RCCL communicator (RcclComm: ncclSend / ncclRecv over xGMI on the solver's stream), the
+        # ONLY RCCL communicator of the process (rounds 2-4 opened torch's "nccl" group beside it: two communicators on one device,
+        # a combination that had never run on more than one GPU)
+        dist.init_process_group("gloo")
 
     import geometricmultigridpressuresolver_amd as G
     from geometricmultigridpressuresolver_amd import domains as D
@@ -372,8 +373,7 @@ def main():
              "status": "no reference for this configuration" if ref is None else ("ok" if abs(check_value - ref) <= 1e-4 * abs(ref) else "FAILED")}
     slab_diag = None
     if slab_run:  # the job is as slow as its slowest rank
-        dev = "cpu" if args.rehearse_gloo else "cuda"
-        t = torch.tensor([elapsed, smooth_ms, own_elapsed, setup_ms, float(exchanges_per_cycle)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, smooth_ms, own_elapsed, setup_ms, float(exchanges_per_cycle)], dtype=torch.float64)
         tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)

@@ -4092,6 +4092,10 @@ try {
         return full;
     }
     if (!h || !h->hier || !h->hier->light) return h ? h->hier : nullptr;
+    if (h->dist) {  // (a slab rank set up on the device holds its window of the labels only)
+        failH(h, MGPS_ERR_INVALID_ARGUMENT, "mgps_get_hierarchy: a slab rank set up on the device has no host hierarchy (options.host_setup = 1 builds one)");
+        return nullptr;
+    }
     (void)hipSetDevice(h->device);
     const Dims d = h->lv[0].d;
     RawVec<uint8_t> labels(d.cells());
