@@ -365,6 +365,10 @@ __device__ __forceinline__ void gStore4nt(float *base, unsigned cell, float4 v)
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (MGPS_GLOBAL_AS v4f *)((MGPS_GLOBAL_AS char *)base + cell * 4u));
 }
 
+// v where `keep`, else 0 -- component by component with the literal (a float4 of zeros as the other operand of the selects was a
+// register quad the compiler spilled)
+__device__ __forceinline__ float4 keepIf(float4 v, bool keep) { return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f); }
+
 template <int OP, bool DOT = false, bool XZERO = false>  // XZERO: see stencilQuadKernel
 __global__ __launch_bounds__(64 * kPlaneRows, 8) void stencilPlaneKernel(  // (8 waves per SIMD = two workgroups per CU: at most 64 registers)
 GridP g, float *__restrict__ out,
@@ -516,39 +520,42 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     const int k0 = int(bz) * zc, k1 = min(k0 + zc, g.nz);  // both even
     const int ks = max(k0 - 1, 0), ke = min(k1, g.nz - 1);   // planes outside the grid: r = 0, nothing to add
     // addresses: the plane's base (wave-uniform: scalar registers) + one 32-bit offset inside the plane per thread
-    const unsigned off = unsigned(jc) * unsigned(g.nx) + unsigned(ic);
-    const unsigned offYm = jc > 0 ? off - unsigned(g.nx) : off, offYp = jc < g.ny - 1 ? off + unsigned(g.nx) : off;
+    // Round 5: every load of the march is UNCONDITIONAL.  A lane outside the active x range (`live`) aims at the nearest quad of
+    // the range in its row -- a line the wave fetches anyway -- and what arrives is dropped where it is used; the wave of a middle
+    // row re-reads its own quad as its "y halo".  With no branch around a load the compiler can count them: the wait behind the
+    // barrier becomes vmcnt(3) -- this plane's rhs and codes -- and the three loads for the next planes stay in flight across the
+    // arithmetic (round 4: a branch per load left it no choice but vmcnt(0) there, a memory round trip per plane).
+    // (a live lane's own quad IS that quad: offL serves its stores as well)
+    const unsigned offL = unsigned(jc) * unsigned(g.nx) + unsigned(min(max(ic, g.xlo), max(g.xhi - 4, g.xlo)));
     const bool rowTop = ty == 0, rowBot = ty == kPlaneRows - 1, colL = lane == 0, colR = lane == kWave - 1;
     const bool hasL = ic > 0, hasR = ic + 4 < g.nx;  // (the grid continues on that side)
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uchar4 ext4 = make_uchar4(MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL, MGPS_EXTERIOR_CELL);
     // (planes clamped to what exists -- the ghost planes of a slab, else the grid: the first and the last plane of a whole-grid level
     // are EXTERIOR shell, whose results are 0 whatever their neighbours hold -- the assumption stencilPlaneKernel makes at the faces)
     const int kLo = g.ghostLo ? -1 : 0, kHi = g.ghostHi ? g.nz : g.nz - 1;
     auto planeOf = [&](const float *p, int k) { return scalarBase(p + ptrdiff_t(min(max(k, kLo), kHi)) * ptrdiff_t(sz)); };
     float *const mine0 = plane[0] + (ty + 1) * kPlanePitch + 4 + lane * 4;
     constexpr int kBufFloats = (kPlaneRows + 2) * kPlanePitch;
+    // the y-halo row a wave stages: the row above the tile (its first wave), below it (its last), else its own quad again
+    const unsigned offHy = (rowTop && jc > 0) ? offL - unsigned(g.nx) : (rowBot && jc < g.ny - 1) ? offL + unsigned(g.nx) : offL;
     {  // plane ks - 1 of the thread's own quad: the z - 1 values of a step are read back from the LDS buffer of the step before
-        const float4 xm = live ? gLoad4(planeOf(x, ks - 1), off) : zero4;
-        *reinterpret_cast<float4 *>(mine0 + kBufFloats) = xm;
+        const float4 xm = gLoad4(planeOf(x, ks - 1), offL);
+        *reinterpret_cast<float4 *>(mine0 + kBufFloats) = keepIf(xm, live);
     }
     const float *xk = planeOf(x, ks);
-    float4 xc = live ? gLoad4(xk, off) : zero4;
-    float4 xp = live ? gLoad4(planeOf(x, ks + 1), off) : zero4;
-    float4 hy = zero4;
-    if (live && rowTop) hy = gLoad4(xk, offYm);
-    if (live && rowBot) hy = gLoad4(xk, offYp);
+    float4 xc = gLoad4(xk, offL);
+    float4 xp = gLoad4(planeOf(x, ks + 1), offL);
+    float4 hy = gLoad4(xk, offHy);
     // the x-halo cell of the first / last lane: one unconditional load per wave (the other lanes re-read their own cell and drop it)
     // -- a branch per side made every wave wait for all its loads in flight before each of the two
-    const unsigned offHx = (colL && hasL) ? off - 1u : (colR && hasR) ? off + 4u : off;
     const bool useHx = live && ((colL && hasL) || (colR && hasR));
-    float hx = live ? gLoad1(xk, offHx) : 0.f;  // (lanes without such a cell: whatever arrives is dropped where hx is staged -- a select here
+    const unsigned offHx = !useHx ? offL : colL ? offL - 1u : offL + 4u;
+    float hx = gLoad1(xk, offHx);  // (lanes without such a cell: whatever arrives is dropped where hx is staged -- a select here
                                                 // would wait for the load, the last one requested, and with it for every load in flight)
     constexpr float w0 = 0.125f, w1 = 0.375f, w2 = 0.375f, w3 = 0.125f;
     // coarse plane (k - 1) / 2 with its first terms (accPrev) and the one after it (accCur), see the fold below
     float accPrev[4] = {0.f, 0.f, 0.f, 0.f}, accCur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (rEdge && k0 == 0 && g.ghostLo && live) {  // the neighbour's r on the plane below the slab: the first term of coarse plane 0
-        const float4 e = gLoad4(scalarBase(rEdge - ptrdiff_t(sz)), off);
+    if (rEdge && k0 == 0 && g.ghostLo) {  // the neighbour's r on the plane below the slab: the first term of coarse plane 0 (wave-uniform branch)
+        const float4 e = gLoad4(scalarBase(rEdge - ptrdiff_t(sz)), offL);
         accCur[0] = w0 * e.x;
         accCur[1] = w0 * e.y;
         accCur[2] = w0 * e.z;
@@ -557,28 +564,25 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     int buf = 0;
     for (int k = ks; k <= ke; ++k) {
         float *me = mine0 + buf * kBufFloats;
+        xc = keepIf(xc, live);  // (what the neighbours read of a quad outside the range is 0; its own results are never stored)
         *reinterpret_cast<float4 *>(me) = xc;
-        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = hy;
-        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = hy;
+        if (rowTop) *reinterpret_cast<float4 *>(me - kPlanePitch) = keepIf(hy, live);
+        if (rowBot) *reinterpret_cast<float4 *>(me + kPlanePitch) = keepIf(hy, live);
         if (colL) me[-1] = useHx ? hx : 0.f;
         if (colR) me[4] = useHx ? hx : 0.f;
         // this plane's rhs and codes (in flight across the barrier), the own quad two planes ahead, the next plane's halo
         const float *bk = planeOf(b, k);
         const uint8_t *lk = scalarBase(g.lab + size_t(k) * sz);
         const float *xn = planeOf(x, k + 1), *xq2 = planeOf(x, k + 2);
-        float4 xq = zero4, hyn = hy, bc = zero4;
-        uchar4 lc = ext4;
-        float hxn = hx;
-        if (live) {
-            bc = gLoad4nt(bk, off);
-            lc = gLoadCodes4nt(lk, off);
-        }
-        if (k < ke && live) {
-            xq = gLoad4(xq2, off);
-            if (rowTop) hyn = gLoad4(xn, offYm);
-            if (rowBot) hyn = gLoad4(xn, offYp);
-            hxn = gLoad1(xn, offHx);
-        }
+        // (unconditional, this plane's first: see offL; past the last plane the bases are clamped, what arrives is never used)
+        const float4 bc = gLoad4nt(bk, offL);
+        const uchar4 lc = gLoadCodes4nt(lk, offL);
+        // (in the order of their use: the halo of the next plane is staged at the top of the next step, the quad two planes ahead is
+        // needed behind the next barrier -- requested last, it is the one left in flight across the top of the loop)
+        const float hxn = gLoad1(xn, offHx);
+        float4 hyn = hy;
+        if (rowTop || rowBot) hyn = gLoad4(xn, offHy);  // (wave-uniform: the tile's first and last wave only)
+        const float4 xq = gLoad4(xq2, offL);
         __syncthreads();
         const float4 ym = *reinterpret_cast<const float4 *>(me - kPlanePitch);
         const float4 yp = *reinterpret_cast<const float4 *>(me + kPlanePitch);
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
                 accPrev[e] += w3 * res[e];
                 accCur[e] += w1 * res[e];
             }
-            if (valid && k >= k0 + 2) gStore4(scalarBase(rz + size_t((k >> 1) - 1) * sz), off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
+            if (valid && k >= k0 + 2) gStore4(scalarBase(rz + size_t((k >> 1) - 1) * sz), offL, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
         }
         xc = xp;
         xp = xq;
@@ -621,13 +625,13 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
     // fourth term is the neighbour's r on the plane above the slab
     if (valid && k1 == g.nz) {
         if (rEdge && g.ghostHi) {
-            const float4 e = gLoad4(scalarBase(rEdge + ptrdiff_t(g.nz) * ptrdiff_t(sz)), off);
+            const float4 e = gLoad4(scalarBase(rEdge + ptrdiff_t(g.nz) * ptrdiff_t(sz)), offL);
             accPrev[0] += w3 * e.x;
             accPrev[1] += w3 * e.y;
             accPrev[2] += w3 * e.z;
             accPrev[3] += w3 * e.w;
         }
-        gStore4(rz + size_t((g.nz >> 1) - 1) * sz, off, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
+        gStore4(rz + size_t((g.nz >> 1) - 1) * sz, offL, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
     }
 }
 

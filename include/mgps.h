@@ -76,11 +76,13 @@ typedef struct mgps_options {
                              * device (hipSOLVER) instead of on a host thread */
     int fuse_band_passes;   /* 1 (default) = run the band_iterations band-Jacobi passes of a level that is not cut
                                into slabs as one launch (same arithmetic per cell); 0 = one launch pair per pass */
-    int deep_band_halo;     /* slab runs, 1 (default): one ghost exchange per band stage -- the message carries the ghost
-                               plane plus the band closure of the next band_iterations planes, and each rank recomputes
-                               its neighbours' band cells near the cut -- instead of one exchange per band pass.  On a
-                               fine level with general BOUNDARY cells the ranks trade the operator rows of the cells in
-                               the band_iterations planes next to each cut once, at set-up */
+    int deep_band_halo;     /* slab runs, 1 (default): the band stage of a cut level runs in the box form of the single-device
+                               solver (one launch per stage) -- the cells of the neighbours' planes that the boxes next to
+                               a cut read, up to band_iterations + 1 planes deep, travel packed (two list messages per
+                               stroke, the first with the ghost plane) and live in the deep ghost planes of the grids
+                               (mgps_ghost_planes) -- instead of a launch pair and an exchange per band pass (0).  The
+                               ranks trade the index lists and the face weights of the planes next to each cut once, at
+                               set-up */
     int min_cells_per_rank; /* slab runs: a level below the finest stays distributed only while every rank owns at least
                                this many cells of it (default 2097152 = 128^3); smaller levels are gathered to rank 0,
                                where one GPU finishes the cycle faster than 17 ghost exchanges per level cost */
@@ -335,13 +337,14 @@ int mgps_solve_pcg(mgps_solver *h, float *x_dev, const float *b_dev, double tole
  * multiple of 16 (keeps the 16^3 Gauss-Seidel tile colouring identical to the single-GPU run and
  * restriction/prolongation rank-local up to one ghost plane) and every rank owns at least
  * options.min_cells_per_rank cells of it; the first level that fails either test, and everything
- * coarser, is gathered to rank 0 and solved there ("collapse").  One ghost plane per side.  A band
- * stage costs one exchange (options.deep_band_halo: ghost plane + the band closure of the next
- * band_iterations planes, the neighbours' band cells near the cut are recomputed locally and the
- * stage leaves the ghost planes complete); the whole-grid operators that follow something that rewrote
- * the grid (a Gauss-Seidel colour pass, the restriction's residual, the prolongation's coarse
- * correction) refresh the whole ghost plane first.  With deep_band_halo = 0 every band pass is preceded
- * by an exchange of the packed band cells of the plane (a few percent of it).
+ * coarser, is gathered to rank 0 and solved there ("collapse").  A rank is set up on the device from
+ * its window of the labels (round 5; options.host_setup = 1: the host builder).  A Jacobi stroke of a
+ * cut level (options.deep_band_halo) costs two messages per neighbour: the ghost plane of the iterate
+ * with, packed, iterate and rhs at the neighbour's cells the band boxes read, and the snapshot at
+ * the same cells between the sweep and the second band stage; the whole-grid operators that read
+ * across a cut (the residual, the restriction's residual planes, the prolongation's coarse
+ * correction, a Gauss-Seidel colour pass) refresh the ghost plane first.  With deep_band_halo = 0
+ * every band pass is preceded by an exchange.
  *
  * The transport is a small vtable so that the same orchestration runs over RCCL (production,
  * mgps_comm_create_rccl: ncclSend/ncclRecv pairs in one group on the solver's stream over xGMI) or
@@ -415,7 +418,7 @@ void mgps_comm_destroy(mgps_comm *comm);
  * (nx*ny*nz_global bytes, they are small); the face weights only for this rank's slab: wx / wy hold
  * the owned planes, wz the owned planes plus the closing face plane (nz_slab + 1 planes).
  * Grids passed to the operators of a slab solver hold the owned planes and must come from
- * mgps_grid_alloc (which surrounds them with the two ghost planes).  The vtable is copied; the
+ * mgps_grid_alloc (which surrounds them with mgps_ghost_planes(h) ghost planes on either side).  The vtable is copied; the
  * transport state behind `comm->user` stays owned by the caller, who destroys it (mgps_comm_destroy)
  * after the solver. */
 int mgps_create_slab(mgps_solver **out, int nx, int ny, int nz_global, const uint8_t *labels_global_host,
