@@ -322,6 +322,53 @@ def balanced_mode():
             dist.barrier()
 
 
+def violation_mode():
+    """Labels that break the BOUNDARY-cell rule (unitTestBoundaryCells) on ONE rank's planes: a BOUNDARY label on a cell deep in the
+    liquid, all of whose neighbours are active across faces of weight 1.  Every rank checks its own cells only, so one rank alone
+    finds it -- and every rank must come back with an error instead of waiting in a collective for the one that left.
+    Device-side set-up (the default) and the host builder with device weights."""
+    import geometricmultigridpressuresolver_amd as G
+    from conftest import make_domain
+    from geometricmultigridpressuresolver_amd import domains as D
+    from geometricmultigridpressuresolver_amd.distributed import SlabSolver, TorchDistComm
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    lab, w, off, lev, dx = make_domain("simple", 40 if size == 2 else 48, 4, (64, 64, 64))
+    nz = lab.shape[0]
+    nzl = nz // size
+    bad_rank = size - 1
+    # an INTERIOR cell of the bad rank's planes whose six neighbours are INTERIOR too, two planes away from the cut at least
+    z0b, z1b = bad_rank * nzl, (bad_rank + 1) * nzl
+    inner = lab == 0
+    core = inner.copy()
+    core[1:-1, 1:-1, 1:-1] &= inner[:-2, 1:-1, 1:-1] & inner[2:, 1:-1, 1:-1] & inner[1:-1, :-2, 1:-1] & inner[1:-1, 2:, 1:-1] & inner[1:-1, 1:-1, :-2] & inner[1:-1, 1:-1, 2:]
+    cand = np.argwhere(core[z0b + 2 : z1b - 2])
+    assert len(cand) > 0, "the test domain has no INTERIOR cell deep in the last rank's planes"
+    k, j, i = (int(v) for v in cand[len(cand) // 2])
+    k += z0b + 2
+    assert all(lab[k + dk, j + dj, i + di] in (0, 3) for dk, dj, di in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)))
+    lab = lab.copy()
+    lab[k, j, i] = 3
+    z0, z1 = rank * nzl, (rank + 1) * nzl
+    for host_setup, on_device in ((0, False), (0, True), (1, True)):
+        slab_w = [w[0][z0:z1], w[1][z0:z1], w[2][z0 : z1 + 1]]
+        if on_device:
+            slab_w = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda() for a in slab_w]
+        opt = G.default_options()
+        opt.min_cells_per_rank, opt.host_setup = 0, host_setup
+        try:
+            SlabSolver(lab, slab_w, lev, False, TorchDistComm(), device=0, options=opt)
+        except Exception as e:
+            msg = str(e)
+        else:
+            raise AssertionError(f"rank {rank}: the constructor accepted labels that break the BOUNDARY-cell rule on rank {bad_rank}")
+        assert ("BOUNDARY-cell rules" in msg) == (rank == bad_rank) or "another rank" in msg or "BOUNDARY-cell rules" in msg, msg
+        dist.barrier()  # (nobody is stuck in a set-up collective)
+        if rank == 0:
+            print(f"  violation on rank {bad_rank}, host_setup={host_setup}, device weights={on_device}: rank 0 got '{msg[:90]}'", flush=True)
+
+
 def cpu_mode():
     """Slab emulation on the CPU (no GPU involved): tests/slab_emulation.py over gloo vs the
     whole-grid oracle."""
@@ -420,6 +467,8 @@ if __name__ == "__main__":
         balanced_mode()
     elif mode == "rccl1":
         rccl_single_rank_mode()
+    elif mode == "violation":
+        violation_mode()
     elif mode == "cpu":
         cpu_mode()
     else:

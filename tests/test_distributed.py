@@ -86,6 +86,15 @@ def test_slabs_residual_restriction_pair_on_cut_levels(mode, nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_slab_setup_failure_on_one_rank_reaches_every_rank(nproc):
+    """labels that break the BOUNDARY-cell rule on the last rank's planes only: every rank's constructor must return an error --
+    the set-up folds each rank's status into an all-reduce before the next collective -- and nobody hangs"""
+    out = run_workers("violation", nproc, 300)
+    print(out[-600:])
+
+
+@pytest.mark.gpu
 def test_rccl_transport_single_rank():
     """The production transport (librccl through dlopen) with a world of one."""
     run_workers("rccl1", 1, 300)

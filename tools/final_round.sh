@@ -1,10 +1,13 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/final_round.sh r02 -> gpurun_out/<round>_*: everything kept under profiles/ for a round
-round=${1:-r02}
+round=${1:-r05}
 export TMPDIR=/tmp PYTHONPATH=$PWD
 mkdir -p gpurun_out
-bash tools/refresh_profiles.sh $round > gpurun_out/refresh.log 2>&1 || { tail -5 gpurun_out/refresh.log; exit 1; }
-echo "profiles refreshed"
+# (SKIP_REFRESH=1: the kernel traces / PMC passes were collected by a call of their own -- the two halves together pass gpurun's 20 minutes)
+if [ -z "$SKIP_REFRESH" ]; then
+  bash tools/refresh_profiles.sh $round > gpurun_out/refresh.log 2>&1 || { tail -5 gpurun_out/refresh.log; exit 1; }
+  echo "profiles refreshed"
+fi
 python bench.py > gpurun_out/${round}_bench1024_jacobi_1gpu.json 2> gpurun_out/bench1024.err || exit 1
 python bench.py --size 512 > gpurun_out/${round}_bench512_jacobi.json 2>/dev/null || exit 1
 python bench.py --size 256 > gpurun_out/${round}_bench256_jacobi.json 2>/dev/null || exit 1
@@ -19,12 +22,26 @@ done
 # config 5 with the plugin's smoother: 512^3 pool MG-PCG, tiled Gauss-Seidel, fp32 against mixed precision
 python tools/prof_pcg.py 512 0 1 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_gs_fp32_vs_mixed.txt
 python tools/prof_pcg.py 512 1 1 2>/dev/null | tail -n 1 >> gpurun_out/${round}_pcg512_gs_fp32_vs_mixed.txt
-# multi-GPU compute ceiling (null transport on one GPU) and slab set-up time
+# multi-GPU compute ceiling (null transport on one GPU), slab set-up time, one cycle's launches of a middle rank and of rank 0
 python tools/slab_compute_bound.py 1024 > gpurun_out/${round}_slab_compute_bound_1024.json 2> gpurun_out/slab_cb.err || echo "slab_compute_bound failed"
 python tools/slab_setup_time.py 1024 8 3 host > gpurun_out/${round}_slab_setup_time_1024.txt 2> gpurun_out/slab_st.err || echo "slab_setup_time failed"
 python tools/slab_setup_time.py 1024 8 3 device >> gpurun_out/${round}_slab_setup_time_1024.txt 2>> gpurun_out/slab_st.err || echo "slab_setup_time (device) failed"
 python tools/slab_setup_time.py 1024 8 0 device >> gpurun_out/${round}_slab_setup_time_1024.txt 2>> gpurun_out/slab_st.err || echo "slab_setup_time (rank 0) failed"
-MGPS_SETUP_TIMING=1 python tools/slab_setup_time.py 1024 8 3 device 2>&1 | grep "mgps set-up: slab" | tail -16 >> gpurun_out/${round}_slab_setup_time_1024.txt
+MGPS_SETUP_TIMING=1 python tools/slab_setup_time.py 1024 8 3 device 2>&1 | grep "mgps set-up: slab" | tail -8 >> gpurun_out/${round}_slab_setup_time_1024.txt
+MGPS_SETUP_TIMING=1 python tools/slab_setup_time.py 1024 8 0 device 2>&1 | grep "mgps set-up: slab" | tail -8 >> gpurun_out/${round}_slab_setup_time_1024.txt
+for r in 4 0; do
+  rocprofv3 --kernel-trace -d gpurun_out/slab_rank$r --output-format csv -- python3 tools/slab_rank_cycle.py 1024 8 $r 8 > /dev/null 2>&1
+  python3 tools/profsum.py gpurun_out/slab_rank$r > gpurun_out/${round}_slab_rank${r}_of_8_kernel_summary.txt
+  python3 tools/cycle_timeline.py gpurun_out/slab_rank$r 3 residualZKernel > gpurun_out/${round}_slab_rank${r}_of_8_cycle_timeline.txt
+  rm -rf gpurun_out/slab_rank$r
+done
+# the --gpus N line with its self-checks: the RCCL transport with one rank, and rehearsals of 2 and 4 ranks over the host-staged transport
+python bench.py --gpus 1 --force-slab --no-cpu --no-frac512 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench1024_force_slab.json
+python bench.py --gpus 2 --rehearse-gloo --size 512 --no-cpu --no-frac512 --steps 5 --warmup 2 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_rehearse_gloo2.json
+python bench.py --gpus 4 --rehearse-gloo --size 512 --no-cpu --no-frac512 --steps 5 --warmup 2 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_rehearse_gloo4.json
+# BASELINE config 3 where the band stage hurts: kernel summaries, one iteration's launches, PMC traffic of the band-stage launches
+bash tools/r5_pool_profile.sh $round > /dev/null 2>&1
+tools/kbench 1024 64 2>&1 | head -4 > gpurun_out/${round}_stream_ceilings_1024.txt
 # the plugin's own configuration untraced (512^3 pool MG-PCG, every CG vector mode), and the Gauss-Seidel band stage A/B
 python bench.py --workload free_surface_pcg --size 512 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_free_surface_untraced.json
 for v in 1 0; do MGPS_GS_SNAPSHOT=$v python bench.py --size 512 --smoother gs --no-frac512 --no-cpu --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_gs_snapshot$v.json; done
