@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-frac512", action="store_true", help="skip the extra 512^3 smoother measurement (roofline.frac_512)")
     ap.add_argument("--force-slab", action="store_true", help="use the multi-GPU code path (RCCL transport, slab solver) even with one rank")
     ap.add_argument("--even-slabs", action="store_true", help="multi-GPU: nz / N planes per rank instead of cuts balanced by active cells")
+    ap.add_argument("--test-fail-rccl", action="store_true", help="test hook: the RCCL transport counts as failed on rank 0; every rank must fall back to the host-staged one")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N-rank path on a box with fewer GPUs: ranks share the GPUs there are, gloo process group, "
                     "host-staged transport (RCCL refuses two ranks on one device).  The line it prints is marked and is not a measurement")
@@ -305,11 +306,37 @@ def main():
     if slab_run:
         from geometricmultigridpressuresolver_amd.distributed import RcclComm, SlabSolver, TorchDistComm
 
-        comm = TorchDistComm() if args.rehearse_gloo else RcclComm(device=local_rank)
         # before anything is timed: rank-stamped data through every entry of the transport, verified on arrival (mgps_comm_preflight)
         from geometricmultigridpressuresolver_amd.distributed import comm_preflight
 
-        ranks_seen = comm_preflight(comm, 1 << 16)
+        transport, transport_error = ("gloo, host staged (rehearsal)" if args.rehearse_gloo else "rccl"), None
+        if args.rehearse_gloo:
+            comm = TorchDistComm()
+            ranks_seen = comm_preflight(comm, 1 << 16)
+        else:
+            # RCCL has never carried more than one rank of this code (the pool's boxes have one GPU).  If the communicator does not
+            # come up or the preflight sees wrong data on ANY rank, all ranks fall back together to the host-staged transport: the
+            # line then still checks the slab code's answer, says so in slab.transport and carries the error -- it is not a
+            # measurement of the xGMI path.  (A hang inside librccl cannot be caught this way.)
+            comm = None
+            try:
+                comm = RcclComm(device=local_rank)
+                ranks_seen = comm_preflight(comm, 1 << 16)
+                if args.test_fail_rccl and rank == 0:
+                    raise RuntimeError("--test-fail-rccl")
+                if ranks_seen != world:
+                    raise RuntimeError(f"preflight all-reduce counted {ranks_seen} ranks of {world}")
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong, every rank must hear of it
+                transport_error = f"rank {rank}: {e!r}"
+            errors = [None] * world
+            dist.all_gather_object(errors, transport_error)
+            errors = [e for e in errors if e]
+            if errors:
+                transport_error = "; ".join(errors)[:600]
+                print(f"[bench] RCCL transport failed its preflight, falling back to the host-staged transport: {transport_error}", file=sys.stderr)
+                transport = "gloo, host staged -- FALLBACK, not a measurement of the RCCL path"
+                comm = TorchDistComm()
+                ranks_seen = comm_preflight(comm, 1 << 16)
         torch.cuda.synchronize()
         t_setup = time.perf_counter()
         solver = SlabSolver(lab, w, levels, use_gs, comm, device=local_rank, options=opt, splits=cuts)
@@ -385,7 +412,7 @@ def main():
                      "exchanges_per_cycle_min": float(tmin[4]),
                      "distributed_levels": solver.distributed_levels, "ghost_planes": solver.ghost_planes,
                      "band_stage": [solver.band_stage_form(l) for l in range(solver.distributed_levels)],
-                     "preflight": "ok", "rccl_ranks_seen": ranks_seen, "check": check}
+                     "preflight": "ok", "rccl_ranks_seen": ranks_seen, "transport": transport, "transport_error": transport_error, "check": check}
 
     cells = float(n) ** 3  # whole job; a rank holds cells / world of them
     active_cells = float(((lab[z0:z1] == 0) | (lab[z0:z1] == 3)).sum())  # this rank's INTERIOR + BOUNDARY cells
@@ -412,7 +439,8 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 arithmetic, f16 storage of the fine-level iterate and residual",
-        "data": "synthetic" if not args.rehearse_gloo else "synthetic; REHEARSAL over gloo with ranks sharing a GPU -- not a measurement",
+        "data": ("synthetic; REHEARSAL over gloo with ranks sharing a GPU -- not a measurement" if args.rehearse_gloo else
+                 "synthetic; RCCL FAILED ITS PREFLIGHT, host-staged fallback -- not a measurement of the multi-GPU path" if (slab_run and transport_error) else "synthetic"),
         "config": {
             "workload": f"{n}^3 interior-liquid cube, {levels}-level V-cycle, reference schedule "
             f"(3 band Jacobi + {args.sweeps} x {'2 tiled-GS half sweeps' if use_gs else 'damped-Jacobi sweep'} + 3 band Jacobi per stroke), "

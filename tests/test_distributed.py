@@ -136,6 +136,19 @@ def test_bench_check_catches_a_dropped_exchange():
     assert line["slab"]["check"]["status"] == "FAILED", line["slab"]["check"]
 
 
+@pytest.mark.gpu
+def test_bench_falls_back_when_rccl_fails_its_preflight():
+    """RCCL has never carried two ranks of this code.  When its communicator or the preflight fails on any rank, every rank
+    switches to the host-staged transport together: the line still checks the slab code's answer and says what happened."""
+    import json
+
+    res = run_bench(["--gpus", "1", "--force-slab", "--test-fail-rccl"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "FALLBACK" in line["slab"]["transport"] and "--test-fail-rccl" in line["slab"]["transport_error"], line["slab"]
+    assert "not a measurement" in line["data"] and line["slab"]["check"]["status"] == "ok"
+
+
 @pytest.mark.parametrize("nproc", [2, 4])
 def test_slab_schedule_emulation_cpu(nproc):
     out = run_workers("cpu", nproc, 600)
