@@ -1230,7 +1230,11 @@ __global__ __launch_bounds__(256) void tiledGSPureKernel(GridP g, TX *__restrict
 {
     __shared__ float sx[kHalo3];
     __shared__ float sb[kTile3];
-    gsPureTile<DOT, TX>(g, x, b, tiles[blockIdx.x], forward, dotPartials, blockIdx.x, sx, sb, std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms), snap, snapTile);
+    // (XCD-aware: a chiplet takes a contiguous run of the colour's tile list, so the lines a tile shares with the next tile of its
+    // colour -- its x-halo cell sits in that tile's own 128-byte line, its y / z halo rows in lines the tiles around it read too --
+    // meet in one L2 instead of being fetched by two)
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    gsPureTile<DOT, TX>(g, x, b, tiles[bid], forward, dotPartials, bid, sx, sb, std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms), snap, snapTile);
 }
 
 // one mixed tile by one workgroup (rowMask: bit i set = cell (i, j, k) of x-row (j, k) is BOUNDARY; rowStart: BOUNDARY cells of
@@ -1350,7 +1354,8 @@ __global__ __launch_bounds__(256) void tiledGSMixedKernel(GridP g, TX *__restric
     __shared__ unsigned short rowMask[kTile * kTile];
     __shared__ unsigned short rowStart[kTile * kTile];
     __shared__ int scanTmp[4];
-    gsMixedTile<DOT, TX>(g, x, b, tiles[blockIdx.x], tileBndStart, forward, dotPartials, blockIdx.x, sx, sb, sl, srow, rowMask, rowStart, scanTmp,
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);  // (see tiledGSPureKernel)
+    gsMixedTile<DOT, TX>(g, x, b, tiles[bid], tileBndStart, forward, dotPartials, bid, sx, sb, sl, srow, rowMask, rowStart, scanTmp,
                          std::is_same<TX, float>::value ? 1.f : mixRhsScale(ms), snap, snapTile);
 }
 // Both lists of a colour in one launch: workgroups [0, nmixed) take the mixed tiles, the rest the pure ones.  For the small
@@ -1897,22 +1902,27 @@ __device__ __forceinline__ float vecOp(float d, float a, float s, float scale)
 
 // quad index of this thread's `it`-th piece of work: plain grid stride, or (chunk list) the thread's quad
 // inside the it-th active chunk of this workgroup; returns false when the thread is done
-__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, int chunkCells, size_t nq, size_t it, size_t &q)
+// (bid: the workgroup's place in the launch -- blockIdx.x, or its XCD-aware remap for kernels that read neighbour rows)
+__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, int chunkCells, size_t nq, size_t it, size_t &q, unsigned bid)
 {
     if (chunks && chunkCells == kChunkCells) {  // one list entry per workgroup
-        const size_t ci = size_t(blockIdx.x) + it * gridDim.x;
+        const size_t ci = size_t(bid) + it * gridDim.x;
         if (ci >= size_t(nchunks)) return false;
         q = size_t(chunks[ci]) * (kChunkCells / 4) + threadIdx.x;
         return true;  // (a ragged last chunk is guarded by q < nq at the use)
     }
     if (chunks) {  // one entry per wavefront / per 16 lanes: nchunks is a multiple of 4 / 16
-        const size_t share = size_t(blockIdx.x) + it * gridDim.x;
+        const size_t share = size_t(bid) + it * gridDim.x;
         if (share * size_t(kChunkCells / chunkCells) >= size_t(nchunks)) return false;
         if (!listQuad(chunks, chunkCells, share, q)) q = nq;
         return true;  // (list padding and a ragged last chunk are guarded by q < nq at the use)
     }
-    q = size_t(blockIdx.x) * blockDim.x + threadIdx.x + it * size_t(gridDim.x) * blockDim.x;
+    q = size_t(bid) * blockDim.x + threadIdx.x + it * size_t(gridDim.x) * blockDim.x;
     return q < nq;
+}
+__device__ __forceinline__ bool nextQuad(const int32_t *chunks, int nchunks, int chunkCells, size_t nq, size_t it, size_t &q)
+{
+    return nextQuad(chunks, nchunks, chunkCells, nq, it, q, blockIdx.x);
 }
 
 template <int VOP>
@@ -3023,7 +3033,10 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
     const ptrdiff_t sy = g.nx, sz = ptrdiff_t(g.nx) * g.ny;
     double acc = 0.0;
     size_t q;
-    for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q); ++it) {
+    // (an XCD takes a contiguous run of the launch's shares: the y / z neighbour rows -- 8 B per cell here -- then meet in its own L2;
+    // with the hardware's round-robin the pass moved 2.7 GB for 1.4 GB algorithmic on the 512^3 pool)
+    const unsigned bid = remapBlock(blockIdx.x, gridDim.x);
+    for (size_t it = 0; nextQuad(g.chunks, g.nchunks, g.chunkCells, nq, it, q, bid); ++it) {
         if (q >= nq) continue;
         const uchar4 l4 = reinterpret_cast<const uchar4 *>(g.lab)[q];
         const unsigned ls[4] = {l4.x, l4.y, l4.z, l4.w};
