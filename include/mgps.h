@@ -464,9 +464,9 @@ int mgps_band_stage_form(const mgps_solver *h, int level, int *form);
  * the residual grid.  By size (x-y planes >= 4 MiB) on levels whose shape the pair takes; MGPS_FUSE_RR=0 / 1 forces it off /
  * onto every level that fits (tests).  The same products either way, added along z first instead of last. */
 int mgps_residual_restrict_fused(const mgps_solver *h, int level, int *fused);
-/* slab runs: how many ghost exchanges so far were queued on the transfer stream, beside the interior part of the sweep that
- * produced their planes (the default on levels with planes >= 1 MiB since round 4, MGPS_OVERLAP=0 turns it off; 0 on
- * single-device solvers) */
+/* kept for callers of round 4's ABI: always 0.  Round 4 queued the ghost exchanges that follow a sweep on a second stream beside
+ * the sweep's interior part; round 5 runs every exchange on the solver's stream until a first run on real links has shown
+ * where the time goes. */
 int64_t mgps_overlapped_exchanges(const mgps_solver *h);
 /* slab runs: ghost / band-stage exchanges this rank issued so far (each one message pair per neighbour); 0 on single-device solvers */
 int64_t mgps_exchange_count(const mgps_solver *h);

@@ -1,7 +1,7 @@
 """Set-up time of one rank of a P-rank slab run (null transport, one GPU): python tools/slab_setup_time.py N P RANK [host|device]
 host (default): the slab's face weights come from numpy arrays (mgps_create_slab_ranges); device: from CUDA tensors
-(mgps_create_slab_device_weights: where mgps_fields_* leave them).
-MGPS_SLAB_WINDOW=0 builds the band lists of the whole grid on the rank (rounds 1-2), the default only the rank's window."""
+(mgps_create_slab_device_weights: where mgps_fields_* leave them).  Since round 5 the rank is built on the device from its window
+of the labels (MGPS_HOST_SETUP=1: the host builder); MGPS_SETUP_TIMING=1 prints the stages."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,5 +27,5 @@ for rep in range(3):
     t = time.time()
     s = SlabSolver(lab, w, levels, False, comm, device=0, splits=cuts)
     torch.cuda.synchronize()
-    print("slab set-up N=%d P=%d rank=%d window=%s weights=%s: %.1f ms" % (n, P, rank, os.environ.get("MGPS_SLAB_WINDOW", "1"), where, (time.time() - t) * 1e3), flush=True)
+    print("slab set-up N=%d P=%d rank=%d builder=%s weights=%s: %.1f ms" % (n, P, rank, "host" if os.environ.get("MGPS_HOST_SETUP") == "1" else "device", where, (time.time() - t) * 1e3), flush=True)
     s.close()
