@@ -3494,11 +3494,13 @@ int launchXpayHalf(void *stream, const GridP &g, float *p, const void *xH, const
 
 // The scalars of the CG loop kept on the device so that only the convergence test meets the host:
 // scal[0] = <z, r> of the current direction, scal[1] = <p, A p>, scal[3] = the <z, r> just reduced.
-// init: scal[0] = scal[3]; else *beta = float(scal[3] / scal[0]) (CG.h:180-191), then scal[0] = scal[3]
+// init 1: scal[0] = scal[3]; init 2 (restart of the direction: p = z): the same and *beta = 0; else *beta = float(scal[3] / scal[0])
+// (CG.h:180-191), then scal[0] = scal[3]
 __global__ void cgScalarsKernel(double *__restrict__ scal, float *__restrict__ beta, int init)
 {
     const double fresh = scal[3];
     if (!init) *beta = float(fresh / scal[0]);
+    if (init == 2) *beta = 0.f;
     scal[0] = fresh;
 }
 int launchCgScalars(void *stream, double *scal, float *beta, int init)

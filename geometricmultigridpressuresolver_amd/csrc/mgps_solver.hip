@@ -1638,6 +1638,7 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
     MGPS_LAUNCH(h, launchZero(h->stream, t, F.d.cells()));
     int it = 0;
     bool converged = false, rFresh = false;
+    double groupStart2 = res2;  // |r|^2 (true) where the current group of fp32 updates began
     constexpr int wideReplaceEvery = 8;  // iterations between two residual replacements (every 4: +2 % time; every 16: one more iteration -- LABNOTES R4)
     for (; it < maxIt; ++it) {
         bool stop = false;
@@ -1675,9 +1676,23 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         // & Ye 2000): the drift a solve ends with is what the last few -- by then tiny -- updates added, and "converged" is
         // only ever said of a true residual.  One fp64 stencil pass per replacement.
         rFresh = false;
-        if (wideX && (res2 < threshold || (it + 1) % wideReplaceEvery == 0)) {
+        bool restartDir = false;
+        // (a group ends after wideReplaceEvery updates, when the recurrence claims convergence, or when the residual has dropped a
+        // hundredfold since the group began: the rounding of a group's fp32 sum is relative to its FIRST update, so a group
+        // that spans many decades of the residual leaves the true residual at eps * cond times where it began -- fast solves,
+        // the cube from the zero guess at 0.15 per iteration, flush every other iteration; the pool's 0.66 never triggers it)
+        if (wideX && (res2 < threshold || grouped >= wideReplaceEvery || res2 < 1e-4 * groupStart2)) {
+            const double recur2 = res2;
             MGPS_TRY(wideResidual(&res2));
+            groupStart2 = res2;
             rFresh = true;
+            // The true residual far above the recurrence's (more than twice its norm): the direction p was built for a residual
+            // that no longer exists, and beta = <z, r>_new / <z, r>_old would blow it up -- restart with p = z.  It happens when
+            // a group of fp32 updates was large against what fp32 resolves of it: the first group of a solve from the zero
+            // guess IS the solution, so the true residual after it sits at eps * cond * |b| whatever the recurrence says
+            // (64^3 box, tolerance 1e-6: 4.5e-5 against 9e-7 at the first claim; without the restart the loop then crawls
+            // for hundreds of iterations).  The groups after it start from that residual and are that much smaller.
+            restartDir = res2 > 4.0 * recur2 && res2 >= threshold;
         }
         if (h->opt.print_stats && (!h->dist || h->comm.rank == 0))
             std::printf("  Iteration: %d  Relative error: %.10g\n", it, std::sqrt(res2 / rhs2));
@@ -1703,12 +1718,12 @@ int pcg(mgps_solver *h, float *x, const float *b, double tol, int maxIt, bool us
         MGPS_TRY(precondition(z, r));  // CG.h:168
         if (devScal) {
             MGPS_TRY(dotToDevice(z));                                                // CG.h:180
-            MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, 0));
+            MGPS_LAUNCH(h, launchCgScalars(h->stream, scal, betaDev, restartDir ? 2 : 0));
             MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, betaDev, 0.f));       // CG.h:191
         } else {
             const double absOld = absNew;
             MGPS_TRY(dotWithResidual(z, &absNew));  // CG.h:180
-            const double beta = absNew / absOld;
+            const double beta = restartDir ? 0.0 : absNew / absOld;
             MGPS_LAUNCH(h, launchXpay(h->stream, F.g, p, z, p, nullptr, float(beta)));  // CG.h:191
         }
     }
