@@ -100,8 +100,13 @@ typedef struct mgps_options {
                                fp32 recurrence (5e-4 on the 512^3 pool), which the loop removes by REPLACING r with
                                float(b - A x) every 8 iterations and whenever the recurrence claims convergence
                                (residual replacement).  DEFAULT since round 4: same iteration counts (+-1), "Recomputed
-                               relative L2 Error" (CG.h:203-206) equal to the recurrence's, +3..5 % solve time at 512^3,
-                               +8..9 % at 1024^3, 8 B per fine cell of memory.  Not with precision = 1 (falls back to 0) */
+                               relative L2 Error" (CG.h:203-206) equal to the recurrence's.  Round 5: between two replacements
+                               the updates alpha p are summed in fp32 in the caller's x (group-wise update) and the fp64
+                               grids are touched by the replacement passes only; a group ends after 8 updates, at a
+                               convergence claim, or when the residual has dropped a hundredfold since it began, and a
+                               replacement that finds the true residual more than twice the recurrence's restarts the
+                               direction (p = z).  +1.5..3 % solve time at 512^3, 16 B per fine cell of memory.  Not with
+                               precision = 1 (falls back to 0) */
     int (*interrupt)(void *user); /* non-zero stops the call with MGPS_ERR_INTERRUPTED (UT_Interrupt::opInterrupt, which the
                                      reference polls in every operator loop, e.g. Ops.h:319).  Polled before every PCG
                                      iteration and, on single-device solvers, before every level of both strokes of a
