@@ -253,6 +253,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    # multi-process GPU work on this pool's driver needs dmabuf IPC (RCCL fails with "hipIpcGetMemHandle: invalid argument" otherwise);
+    # the image exports it already -- kept here for a shell that does not (read when the HIP runtime initialises, children inherit it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.workload == "free_surface_pcg":
         return free_surface_pcg(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
