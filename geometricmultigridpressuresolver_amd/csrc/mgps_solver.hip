@@ -3323,14 +3323,28 @@ int createSlabOnDevice(mgps_solver **out, int nx, int ny, int nzg, const uint8_t
     // what travels: wx / wy planes [0, gw) down and [nzl - gw, nzl) up; of wz the faces [1, gw] down and [nzl - gw, nzl - 1] up
     // (before the exchange the ghost planes hold a mirror image of the rank's own: a transport that moves nothing -- the
     // compute-bound tools -- leaves plausible weights there)
+    status = MGPS_OK;
     for (int a = 0; a < 3 && nzl >= gw; ++a) {
         const size_t bytes = wplane[a] * size_t(gw) * sizeof(float);
         const float *down = h->w[a] + (a == 2 ? wplane[a] : 0), *up = h->w[a] + wplane[a] * size_t(nzl - gw);
-        if (hipMemcpyAsync(wlo[a], up, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess || hipMemcpyAsync(whi[a], down, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
-            hipStreamSynchronize(nullptr) != hipSuccess)
-            return bail(failH(h, MGPS_ERR_HIP, "weight ghost planes: copy failed"));
+        if (hipMemcpyAsync(wlo[a], up, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess || hipMemcpyAsync(whi[a], down, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
+            status = failH(h, MGPS_ERR_HIP, "weight ghost planes: copy failed");
+    }
+    if (hipStreamSynchronize(nullptr) != hipSuccess && status == MGPS_OK) status = failH(h, MGPS_ERR_HIP, "weight ghost planes: copy failed");
+    {  // (a rank whose copies failed must not leave its neighbours waiting in the exchange below)
+        int all = MGPS_OK;
+        const int rc = agree(status, &all);
+        if (rc != MGPS_OK) return bail(rc);
+        if (all != MGPS_OK) {
+            if (status == MGPS_OK) failH(h, all, "slab set-up failed on another rank");
+            return bail(status != MGPS_OK ? status : all);
+        }
+    }
+    for (int a = 0; a < 3 && nzl >= gw; ++a) {
+        const size_t bytes = wplane[a] * size_t(gw) * sizeof(float);
+        const float *down = h->w[a] + (a == 2 ? wplane[a] : 0), *up = h->w[a] + wplane[a] * size_t(nzl - gw);
         if (P > 1 && h->comm.exchange(h->comm.user, lo ? down : nullptr, bytes, lo ? wlo[a] : nullptr, bytes, hi ? up : nullptr, bytes, hi ? whi[a] : nullptr, bytes, nullptr) != 0)
-            return bail(failH(h, MGPS_ERR_COMM, "weight ghost planes: exchange failed"));
+            return bail(failH(h, MGPS_ERR_COMM, "weight ghost planes: exchange failed"));  // (a transport failure: nobody is left waiting for this rank's data only)
     }
     (void)hipStreamSynchronize(nullptr);
     sclock.lap("slab: weights + their ghost planes");
