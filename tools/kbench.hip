@@ -38,6 +38,23 @@ __global__ __launch_bounds__(256) void copyK(float4 *__restrict__ o, const float
     size_t t = size_t(blockIdx.x) * 256 + threadIdx.x;
     if (t < nq) o[t] = a[t];
 }
+// in place: a[t] += c (read and write the same lines: what the prolongation does to the fine iterate)
+__global__ __launch_bounds__(256) void inplaceK(float4 *a, size_t nq)
+{
+    size_t t = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= nq) return;
+    float4 v = a[t];
+    a[t] = make_float4(v.x + 1.f, v.y + 1.f, v.z + 1.f, v.w + 1.f);
+}
+__global__ __launch_bounds__(256) void inplaceNtK(float4 *a, size_t nq)
+{
+    size_t t = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= nq) return;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(a) + t);
+    v += 1.f;
+    __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(a) + t);
+}
 __global__ __launch_bounds__(256) void stream3K(float4 *__restrict__ o, const float4 *__restrict__ x,
                                                 const float4 *__restrict__ b, const uchar4 *__restrict__ l, size_t nq)
 {
@@ -361,6 +378,8 @@ int main(int argc, char **argv)
     const size_t nq = cells / 4;
     const unsigned nbq = unsigned((nq + 255) / 256);
     run("copy float4 (8 B/cell)", 8, false, [&] { copyK<<<nbq, 256>>>((float4 *)o, (const float4 *)x, nq); });
+    run("in place a += c (8 B/cell)", 8, false, [&] { inplaceK<<<nbq, 256>>>((float4 *)o, nq); });
+    run("in place, nontemporal (8 B/cell)", 8, false, [&] { inplaceNtK<<<nbq, 256>>>((float4 *)o, nq); });
     run("stream3 x,b,lab->out (13 B/cell)", 13, false,
         [&] { stream3K<<<nbq, 256>>>((float4 *)o, (const float4 *)x, (const float4 *)b, (const uchar4 *)lab, nq); });
     run("jacA remap", 13, true, [&] { jacA<true><<<nbq, 256>>>(g, o, x, b, 0.6666667f, nbq); });
