@@ -99,7 +99,7 @@ def gpu_mode():
         elif kind == "random":  # blobs of every label, fractional weights everywhere (tests/test_device_setup.py): general cells in every group across the cuts
             from test_device_setup import random_domain
 
-            lab, w = random_domain(shape, levels, 4, closed_faces=False)
+            lab, w = random_domain(shape, levels, int(os.environ.get("MGPS_DIST_SEED", "4")), closed_faces=False)  # (MGPS_DIST_SEED: a one-off sweep over other seeds)
             off, lev, dx = 0, levels, 1.0 / shape[2]
         else:
             lab, w, off, lev, dx = make_domain(kind, g, levels, shape)
@@ -143,17 +143,23 @@ def gpu_mode():
             xw, xs = whole.new_grid(), slab.new_grid()
             sw = whole.solveGeometricConjugateGradient(xw, whole.to_device(bd), 1e-5, 200, True)
             ss = slab.solveGeometricConjugateGradient(xs, slab.to_device(bd[z0:z1]), 1e-5, 200, True)
-            assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+            # (other seeds of the random-label domain, MGPS_DIST_SEED: blobs of labels and weights do not promise a definite operator --
+            # the fp64 oracle's MG-PCG grows without bound on seeds 10 and 12 as well; there both solvers must fail alike)
+            definite = not (kind == "random" and sw["outcome"] != "converged")
+            if not definite:
+                assert ss["outcome"] == sw["outcome"], (ss, sw)
+            else:
+                assert ss["outcome"] == "converged" and abs(ss["iterations"] - sw["iterations"]) <= 1, (ss, sw)
+                assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             # alpha and beta stayed on the device: the CG scalars were summed through the transport's device all-reduce
             assert comm.device_allreduces >= 3 * ss["iterations"], (comm.device_allreduces, ss)
-            assert rel_l2(slab.gather_global(xs), xw.cpu().numpy()) < 1e-4
             counts[(use_gs, deep)] = comm.exchanges
             # the box form of a cut level's band stage (deep = 1) sends the boundary plane straight from the grid (mgps_comm::exchange2), only the lists packed
             assert (comm.segmented_exchanges > 0) == (deep == 1), (deep, comm.segmented_exchanges)
             assert slab.ghost_planes == 5 and all(slab.band_stage_form(l) == ("boxes" if deep == 1 else "passes") for l in range(slab.distributed_levels))
             if deep == 1 and not use_gs:
                 compare_with_host_builder(slab, lab, slab_w, lev, use_gs, opt, (kind, size))
-            if deep == 1:  # the CG vectors in fp64 (options.pcg_fp64_vectors): their ghost planes travel as doubles
+            if deep == 1 and definite:  # the CG vectors in fp64 (options.pcg_fp64_vectors): their ghost planes travel as doubles
                 o64 = G.default_options()
                 o64.min_cells_per_rank, o64.pcg_fp64_vectors = 0, 1
                 slab64 = SlabSolver(lab, slab_w, lev, use_gs, TorchDistComm(), device=0, options=o64)
