@@ -230,12 +230,17 @@ __device__ __forceinline__ void stencilQuadBody(const GridP &g, TX *__restrict__
     if (chunks) valid = listQuad(chunks, g.chunkCells, block, t, tid);  // only the runs that hold active cells
     valid = valid && t < totalQuads;
     const size_t tt = valid ? t : totalQuads - 1;
-    const unsigned q = unsigned(tt % nq);
-    const size_t row = tt / nq;
-    const int j = int(row % g.ny), k = int(row / g.ny);
-    const int i = int(q) << 2;
-    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny;
-    const size_t c = row * sy + i;
+    // Round 5: no division in the index arithmetic.  The quad's first cell is 4 tt (a row holds nq quads of 4 cells); its x index --
+    // needed for the active x range alone -- is a mask where nq is a power of two, else one 32-bit modulo; the row and the plane are
+    // not needed at all: a neighbour row / plane that would leave the array (the first and last x-row and plane of the grid) is
+    // replaced by the quad's own, as before, by comparing the flat index -- elsewhere at a grid face the neighbour "row" is the
+    // last row of the plane before: EXTERIOR shell cells either way, whose results are never formed from their neighbours.
+    // (the three divisions by nq and ny and the 64-bit products behind them were 100 of the kernel's 207 vector instructions per
+    // wave -- 59 % of the launch's SIMD cycles at 1024^3, r05_sq_1024.txt)
+    const size_t c = tt << 2;
+    const size_t sy = size_t(g.nx), sz = size_t(g.nx) * g.ny, ncells = totalQuads << 2;
+    const bool nqPow2 = (nq & (nq - 1u)) == 0u;
+    const int i = int((nqPow2 ? (unsigned(tt) & (nq - 1u)) : (totalQuads <= 0xffffffffull ? unsigned(tt) % nq : unsigned(tt % nq))) << 2);
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // quads outside the level's active x range (GridP::xlo): EXTERIOR padding, zero in every grid -- nothing of theirs is loaded or
@@ -245,10 +250,9 @@ __device__ __forceinline__ void stencilQuadBody(const GridP &g, TX *__restrict__
     const bool live = i >= g.xlo && i < g.xhi;
     valid = valid && live;
     const size_t cl = live ? c : c - size_t(i) + size_t(min(max(i, g.xlo), max(g.xhi - 4, 0)));
-    // clamp the neighbour rows at the domain faces: those cells are EXTERIOR padding, their
-    // results are discarded, the loads only have to stay in bounds
-    const size_t cym = j > 0 ? cl - sy : cl, cyp = j < g.ny - 1 ? cl + sy : cl;
-    const size_t czm = (k > 0 || g.ghostLo) ? cl - sz : cl, czp = (k < g.nz - 1 || g.ghostHi) ? cl + sz : cl;
+    // neighbour rows and planes: the loads only have to stay inside the array (or its ghost planes)
+    const size_t cym = cl >= sy ? cl - sy : cl, cyp = cl + sy < ncells ? cl + sy : cl;
+    const size_t czm = (cl >= sz || g.ghostLo) ? cl - sz : cl, czp = (cl + sz < ncells || g.ghostHi) ? cl + sz : cl;
     float4 xc = XZERO ? zero4 : Cell<TX>::load4(x + cl);
     const float4 ym = XZERO ? zero4 : Cell<TX>::load4(x + cym);
     const float4 yp = XZERO ? zero4 : Cell<TX>::load4(x + cyp);
@@ -265,9 +269,9 @@ __device__ __forceinline__ void stencilQuadBody(const GridP &g, TX *__restrict__
     const int runMask = listRunMask(chunks, g.chunkCells), lane = tid & runMask;
     float left = __shfl_up(xc.w, 1);
     float right = __shfl_down(xc.x, 1);
-    if (ld) {
-        if (lane == 0 || q == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
-        if (lane == runMask || q == nq - 1 || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
+    if (ld) {  // (a run that starts / ends at a row end reads the EXTERIOR cell of the row before / after, or nothing at the array's ends)
+        if (lane == 0 || i == 0) left = (i > 0) ? Cell<TX>::load1(x + c - 1) : 0.f;
+        if (lane == runMask || i + 4 >= g.nx || t + 1 >= totalQuads) right = (i + 4 < g.nx) ? Cell<TX>::load1(x + c + 4) : 0.f;
     }
 
     const float xs[6] = {left, xc.x, xc.y, xc.z, xc.w, right};
