@@ -1940,10 +1940,10 @@ __global__ __launch_bounds__(256) void vecKernel(size_t n, const uint8_t *__rest
     for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
-        float4 d = reinterpret_cast<const float4 *>(dst)[q];
+        float4 d = streamLoad4(dst + (q << 2));
         float4 av = d, sv = d;
-        if (VOP != V_SCALE) av = reinterpret_cast<const float4 *>(a)[q];
-        if (VOP == V_XPAY || VOP == V_MUL) sv = reinterpret_cast<const float4 *>(s)[q];
+        if (VOP != V_SCALE) av = streamLoad4(a + (q << 2));
+        if (VOP == V_XPAY || VOP == V_MUL) sv = streamLoad4(s + (q << 2));
         if (activeLabel(l.x)) d.x = vecOp<VOP>(d.x, av.x, sv.x, scale);
         if (activeLabel(l.y)) d.y = vecOp<VOP>(d.y, av.y, sv.y, scale);
         if (activeLabel(l.z)) d.z = vecOp<VOP>(d.z, av.z, sv.z, scale);
@@ -2023,9 +2023,9 @@ __global__ __launch_bounds__(256) void reduceKernel(size_t n, const uint8_t *__r
     for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
-        const float4 av = reinterpret_cast<const float4 *>(a)[q];
+        const float4 av = streamLoad4(a + (q << 2));  // (read once: nontemporal, like every pure stream of the CG loop -- see cgUpdateKernel)
         float4 bv = av;
-        if (KIND == 0) bv = reinterpret_cast<const float4 *>(b)[q];
+        if (KIND == 0) bv = streamLoad4(b + (q << 2));
         if (activeLabel(l.x)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.x, bv.x));
         if (activeLabel(l.y)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.y, bv.y));
         if (activeLabel(l.z)) acc = redCombine<KIND>(acc, redTerm<KIND>(av.z, bv.z));
@@ -3014,7 +3014,7 @@ __global__ __launch_bounds__(256) void zeroChunksKernel(float *__restrict__ a, c
     }
     size_t q;
     if (!listQuad(chunks, chunkCells, blockIdx.x, q)) return;
-    if (q < nq) reinterpret_cast<float4 *>(a)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nq) Cell<float>::store4nt(a + (q << 2), make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3372,8 +3372,11 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
     for (size_t it = 0; nextQuad(chunks, nchunks, chunkCells, nq, it, q); ++it) {
         if (q >= nq) continue;
         const uchar4 l = reinterpret_cast<const uchar4 *>(lab)[q];
-        float4 rv = reinterpret_cast<const float4 *>(r)[q];
-        const float4 pv = reinterpret_cast<const float4 *>(p)[q], tv = reinterpret_cast<const float4 *>(t)[q];
+        // (nontemporal loads and stores: these vectors are streams -- 512 MB each at 512^3, nothing of them is in a cache when it is
+        // wanted again -- and as streams they leave the L2 and the Infinity Cache to what does get re-read; 512^3 pool MG-PCG 60.4 ->
+        // 58.4 ms (Jacobi), 75.4 -> 73.9 (GS) in a same-box A/B.  r alone is stored normally: the V-cycle reads it next as its rhs)
+        float4 rv = streamLoad4(r + (q << 2));
+        const float4 pv = streamLoad4(p + (q << 2)), tv = streamLoad4(t + (q << 2));
         if (kWide) {
             double2 *xq = reinterpret_cast<double2 *>(x) + 2 * q;
             double2 xa = xq[0], xb = xq[1];
@@ -3386,12 +3389,12 @@ __global__ __launch_bounds__(256) void cgUpdateKernel(size_t n, const uint8_t *_
         } else {
             const bool all = activeLabel(l.x) && activeLabel(l.y) && activeLabel(l.z) && activeLabel(l.w);
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!xFirst || !all) xv = reinterpret_cast<const float4 *>(x)[q];  // (a quad with an inactive cell keeps that cell's value)
+            if (!xFirst || !all) xv = streamLoad4(reinterpret_cast<const float *>(x) + (q << 2));  // (a quad with an inactive cell keeps that cell's value)
             if (activeLabel(l.x)) xv.x = (xFirst ? 0.f : xv.x) + alpha * pv.x;
             if (activeLabel(l.y)) xv.y = (xFirst ? 0.f : xv.y) + alpha * pv.y;
             if (activeLabel(l.z)) xv.z = (xFirst ? 0.f : xv.z) + alpha * pv.z;
             if (activeLabel(l.w)) xv.w = (xFirst ? 0.f : xv.w) + alpha * pv.w;
-            reinterpret_cast<float4 *>(x)[q] = xv;
+            Cell<float>::store4nt(reinterpret_cast<float *>(x) + (q << 2), xv);
         }
         if (activeLabel(l.x)) { rv.x = rv.x + (-alpha) * tv.x; acc += double(rv.x) * double(rv.x); big = fmaxf(big, fabsf(rv.x)); }
         if (activeLabel(l.y)) { rv.y = rv.y + (-alpha) * tv.y; acc += double(rv.y) * double(rv.y); big = fmaxf(big, fabsf(rv.y)); }
