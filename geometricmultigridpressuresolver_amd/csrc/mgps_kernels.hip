@@ -1130,7 +1130,8 @@ __device__ __forceinline__ void gsLoadTile(const GridP &g, const TX *__restrict_
         for (int m = 0; m < 4; ++m) {
             const int r = tid + m * 256;
             const int q = r & 3, lj = (r >> 2) % kTile, lk = (r >> 2) / kTile;
-            bv[m] = *reinterpret_cast<const float4 *>(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q);
+            bv[m] = g.streaming ? streamLoad4(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q)
+                                : *reinterpret_cast<const float4 *>(b + (size_t(k0 + lk) * g.ny + j0 + lj) * g.nx + i0 + 4 * q);
         }
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
