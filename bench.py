@@ -504,10 +504,10 @@ def main():
                 "unit": "GB/s",
                 "frac": 16.0 * nband / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if band_ms > 0 else None,
                 "note": "O(N^2) cells at a line-granular cost: an x-face band row is three cells of one 128-B line per array "
-                        "(traffic: profiles/r04_pmc_hbm_traffic.json, bandBoxKernel entries of the fine level, fetched + written per band cell)",
+                        "(traffic: profiles/r05_pmc_hbm_traffic.json, bandBoxKernel entries of the fine level, fetched + written per band cell)",
             }
             try:  # measured bytes per band cell of the closure / plain launch at this size, from the committed PMC passes
-                kern = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")))["kernels"]
+                kern = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")))["kernels"]
                 fine = {k: v for k, v in kern.items() if k.startswith("bandBoxKernel<float, ") and f"@{n}^3" in k}
                 top = max(int(k.split("grid=")[1]) for k in fine) if fine else 0
                 for k, v in fine.items():
@@ -520,7 +520,7 @@ def main():
             out["band_stage"] = {"error": str(e)}
     # HBM traffic of the same kernel at the same size from the committed rocprofv3 PMC passes
     # (profiles/r01_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)
-    for pmc_file in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for pmc_file in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["fine_jacobi_sweep"]
             if str(n) in pmc and not use_gs and world == 1 and args.precision == "fp32":
