@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * kPlaneRows, 8) void residualZKernel(GridP g, f
                 accPrev[e] += w3 * res[e];
                 accCur[e] += w1 * res[e];
             }
-            if (valid && k >= k0 + 2) gStore4(scalarBase(rz + size_t((k >> 1) - 1) * sz), offL, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
+            if (valid && k >= k0 + 2) gStore4nt(scalarBase(rz + size_t((k >> 1) - 1) * sz), offL, make_float4(accPrev[0], accPrev[1], accPrev[2], accPrev[3]));
         }
         xc = xp;
         xp = xq;
