@@ -44,6 +44,7 @@ bash tools/r5_pool_profile.sh $round > /dev/null 2>&1
 tools/kbench 1024 64 2>&1 | head -4 > gpurun_out/${round}_stream_ceilings_1024.txt
 # the plugin's own configuration untraced (512^3 pool MG-PCG, every CG vector mode), and the Gauss-Seidel band stage A/B
 python bench.py --workload free_surface_pcg --size 512 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg512_free_surface_untraced.json
+python bench.py --workload free_surface_pcg --size 1024 2>/dev/null | tail -n 1 > gpurun_out/${round}_pcg1024_free_surface_untraced.json
 for v in 1 0; do MGPS_GS_SNAPSHOT=$v python bench.py --size 512 --smoother gs --no-frac512 --no-cpu --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench512_gs_snapshot$v.json; done
 # residual + restriction without the residual grid (1024^3 fine level by size): the pair against the two separate passes
 MGPS_FUSE_RR=0 python bench.py --no-cpu --no-frac512 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > gpurun_out/${round}_bench1024_fuse_rr0.json
