@@ -3082,7 +3082,7 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
             row(ptrdiff_t(c0) - sz, zm);
             row(ptrdiff_t(c0) + sz, zp);
             float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE != 0) bq = reinterpret_cast<const float4 *>(b)[q];
+            if (MODE != 0) bq = streamLoad4(b + (q << 2));  // (the rhs and the outputs are streams: nontemporal, like the CG loop's vectors)
             const float bs[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -3110,8 +3110,8 @@ __global__ __launch_bounds__(256) void stencil64Kernel(GridP g, double *__restri
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (!activeLabel(ls[e])) flushed[e] = x[c0 + e];
-            reinterpret_cast<d2 *>(out + c0)[0] = d2{flushed[0], flushed[1]};
-            reinterpret_cast<d2 *>(out + c0)[1] = d2{flushed[2], flushed[3]};
+            __builtin_nontemporal_store(d2{flushed[0], flushed[1]}, reinterpret_cast<d2 *>(out + c0));
+            __builtin_nontemporal_store(d2{flushed[2], flushed[3]}, reinterpret_cast<d2 *>(out + c0) + 1);
         } else if (out) {  // (out == nullptr: only float(out) is wanted)
             typedef double d2 __attribute__((ext_vector_type(2)));
             reinterpret_cast<d2 *>(out + c0)[0] = d2{res[0], res[1]};
