@@ -2776,9 +2776,11 @@ int launchProlongAdd(void *stream, const GridP &fine, float *fineInOut, const fl
     if (snap && !snapTile) return int(hipErrorInvalidValue);
     const size_t n = size_t(fine.nx) * fine.ny * fine.nz;
     // The block kernel (one thread = 16 fine cells that share their coarse rows) walks the whole grid; the quad kernel walks the
-    // level's activity runs at 1.7 x the cost per cell (0.272 vs 0.162 ms on the full 512^3 cube).  Where the liquid fills a small
-    // part of the grid -- a 480^3 simulation in the 1024^3 power-of-two expansion: 62 M of 1074 M cells in runs -- the runs win.
-    const bool runsWin = fine.chunks && double(fine.nchunks) * fine.chunkCells * 1.7 * runCostFactor(fine.chunkCells) < 0.8 * double(n);  // (a clear win only)
+    // level's activity runs at 1.7 x the cost per cell (0.272 vs 0.162 ms on the full 512^3 cube) -- and at more than that where the
+    // runs are short: on the 512^3 free-surface pool (47 M of 134 M cells in 32-cell runs) the block kernel is the faster one
+    // (MG-PCG 58.2 -> 57.4 ms, round 5: the factor below was 1.7).  Where the liquid fills a small part of the grid -- a 480^3
+    // simulation in the 1024^3 power-of-two expansion: 62 M of 1074 M cells in runs -- the runs win.
+    const bool runsWin = fine.chunks && double(fine.nchunks) * fine.chunkCells * 3.4 * runCostFactor(fine.chunkCells) < 0.8 * double(n);  // (a clear win only)
     if (!runsWin && (fine.nx & 3) == 0 && fine.nx >= 8 && (fine.ny & 1) == 0 && (fine.nz & 1) == 0 && fine.ny >= 4 && fine.nz >= 2) {
         const int npj = fine.ny / 2 - 1;  // row pairs (1,2) .. (ny-3, ny-2)
         const int kp0 = fine.ghostLo ? -1 : 0, kp1 = fine.ghostHi ? fine.nz / 2 - 1 : fine.nz / 2 - 2;
