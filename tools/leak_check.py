@@ -15,7 +15,7 @@ lab, w, h = D.free_surface_pool(n, levels)
 b = D.random_rhs(lab, h)
 base = None
 for it in range(cycles):
-    for fp64, prec in ((0, 0), (1, 0), (0, 1)):
+    for fp64, prec in ((0, 0), (1, 0), (2, 0), (0, 1)):
         opt = G.default_options()
         opt.pcg_fp64_vectors, opt.precision = fp64, prec
         s = G.GeometricMultigridPoissonSolver(lab, w, levels, bool(it & 1) and not prec, options=opt)
